@@ -1,0 +1,254 @@
+// Strided batched GEMM with fused epilogue on the gfx950 matrix cores.
+//   C = act(alpha * A.B + beta * C + bias)
+// 128x128x32 block tile, 4 waves (2x2), each wave a 64x64 sub-tile = 4x4 MFMA
+// tiles of 16x16.  MODE 0: fp32 operands, v_mfma_f32_16x16x4_f32 (exact fp32).
+// MODE 1: operands rounded to bf16 while being staged into LDS,
+// v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Global operands are always fp32.
+//
+// Operand staging handles three global layouts per operand (chosen on the host):
+//   1 = reduction dim contiguous (float4 along k),
+//   2 = row dim contiguous (4x4 register transpose, float4 along the row dim),
+//   0 = generic strides (scalar loads).
+// LDS image is always [row][k] with k innermost so the MFMA read side is uniform.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDF = 36;   // fp32 LDS row stride in floats  (144 B, 16 B aligned)
+constexpr int LDH = 40;   // bf16 LDS row stride in halves  (80 B, 16 B aligned)
+
+struct GemmP {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K;
+    long sAm, sAk, sBk, sBn, ldc, bsA, bsB, bsC;
+    float alpha, beta;
+    int act, amode, bmode;
+};
+
+// Load one 128 x 32 operand tile (rows r0.., reduction k0..) into 16 registers/thread.
+template <int LMODE>
+__device__ __forceinline__ void load_tile(const float* __restrict__ X, long sr, long sk, int R, int K,
+                                          int r0, int k0, int tid, float (&reg)[16]) {
+    if constexpr (LMODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int idx = tid + 256 * j;
+            int r = r0 + (idx >> 3), k = k0 + (idx & 7) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < R) {
+                const float* p = X + (long)r * sr + k;
+                if (k + 3 < K) v = *reinterpret_cast<const float4*>(p);
+                else {
+                    if (k < K) v.x = p[0];
+                    if (k + 1 < K) v.y = p[1];
+                    if (k + 2 < K) v.z = p[2];
+                }
+            }
+            reg[j * 4 + 0] = v.x; reg[j * 4 + 1] = v.y; reg[j * 4 + 2] = v.z; reg[j * 4 + 3] = v.w;
+        }
+    } else if constexpr (LMODE == 2) {
+        int rq = tid & 31, kq = tid >> 5;
+        int r = r0 + rq * 4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            int k = k0 + kq * 4 + kk;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < K) {
+                const float* p = X + (long)k * sk + r;
+                if (r + 3 < R) v = *reinterpret_cast<const float4*>(p);
+                else {
+                    if (r < R) v.x = p[0];
+                    if (r + 1 < R) v.y = p[1];
+                    if (r + 2 < R) v.z = p[2];
+                }
+            }
+            // reg[j*4+kk] = element (row rq*4+j, k kq*4+kk)
+            reg[0 * 4 + kk] = v.x; reg[1 * 4 + kk] = v.y; reg[2 * 4 + kk] = v.z; reg[3 * 4 + kk] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int idx = tid + 256 * j;
+            int r = r0 + (idx >> 5), k = k0 + (idx & 31);
+            reg[j] = (r < R && k < K) ? X[(long)r * sr + (long)k * sk] : 0.f;
+        }
+    }
+}
+
+template <int MODE, int LMODE>
+__device__ __forceinline__ void store_tile(void* lds, int tid, const float (&reg)[16]) {
+    if constexpr (LMODE == 1 || LMODE == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int row, kc;
+            if constexpr (LMODE == 1) { int idx = tid + 256 * j; row = idx >> 3; kc = (idx & 7) * 4; }
+            else { row = (tid & 31) * 4 + j; kc = (tid >> 5) * 4; }
+            if constexpr (MODE == 0) {
+                float* p = reinterpret_cast<float*>(lds) + row * LDF + kc;
+                *reinterpret_cast<float4*>(p) = make_float4(reg[j * 4], reg[j * 4 + 1], reg[j * 4 + 2], reg[j * 4 + 3]);
+            } else {
+                unsigned short* p = reinterpret_cast<unsigned short*>(lds) + row * LDH + kc;
+                uint2 w;
+                w.x = (unsigned)f2bf(reg[j * 4]) | ((unsigned)f2bf(reg[j * 4 + 1]) << 16);
+                w.y = (unsigned)f2bf(reg[j * 4 + 2]) | ((unsigned)f2bf(reg[j * 4 + 3]) << 16);
+                *reinterpret_cast<uint2*>(p) = w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int idx = tid + 256 * j;
+            int row = idx >> 5, kc = idx & 31;
+            if constexpr (MODE == 0) reinterpret_cast<float*>(lds)[row * LDF + kc] = reg[j];
+            else reinterpret_cast<unsigned short*>(lds)[row * LDH + kc] = f2bf(reg[j]);
+        }
+    }
+}
+
+template <int MODE, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+    constexpr int TILE_BYTES = (MODE == 0) ? BM * LDF * 4 : BM * LDH * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    void* As = smem;
+    void* Bs = smem + TILE_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, kg = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const long bz = blockIdx.z;
+    const float* A = p.A + bz * p.bsA;
+    const float* B = p.B + bz * p.bsB;
+    float* C = p.C + bz * p.bsC;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float ra[16], rb[16];
+    load_tile<AMODE>(A, p.sAm, p.sAk, p.M, p.K, m0, 0, tid, ra);
+    load_tile<BMODE>(B, p.sBn, p.sBk, p.N, p.K, n0, 0, tid, rb);
+
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+        __syncthreads();                         // previous tile fully consumed
+        store_tile<MODE, AMODE>(As, tid, ra);
+        store_tile<MODE, BMODE>(Bs, tid, rb);
+        __syncthreads();
+        if (k0 + BK < p.K) {                     // prefetch next tile while computing
+            load_tile<AMODE>(A, p.sAm, p.sAk, p.M, p.K, m0, k0 + BK, tid, ra);
+            load_tile<BMODE>(B, p.sBn, p.sBk, p.N, p.K, n0, k0 + BK, tid, rb);
+        }
+        if constexpr (MODE == 0) {
+            const float* Af = reinterpret_cast<const float*>(As) + (wm * 64 + li) * LDF + kg * 4;
+            const float* Bf = reinterpret_cast<const float*>(Bs) + (wn * 64 + li) * LDF + kg * 4;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 16) {
+                float4 a[4], b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float4*>(Af + i * 16 * LDF + kk);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const float4*>(Bf + j * 16 * LDF + kk);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
+            const unsigned short* Ah = reinterpret_cast<const unsigned short*>(As) + (wm * 64 + li) * LDH + kg * 8;
+            const unsigned short* Bh = reinterpret_cast<const unsigned short*>(Bs) + (wn * 64 + li) * LDH + kg * 8;
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Ah + i * 16 * LDH);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Bh + j * 16 * LDH);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: D tile (16x16): col = lane&15, row = (lane>>4)*4 + r
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = m0 + wm * 64 + i * 16 + kg * 4 + r;
+            if (row >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int col = n0 + wn * 64 + j * 16 + li;
+                if (col >= p.N) continue;
+                float* cp = C + (long)row * p.ldc + col;
+                float v = p.alpha * acc[i][j][r];
+                if (p.beta != 0.f) v += p.beta * (*cp);
+                if (p.bias) v += p.bias[col];
+                if (p.act == FT_ACT_TANH) v = tanhf_(v);
+                else if (p.act == FT_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == FT_ACT_SIGMOID) v = sigmoidf_(v);
+                *cp = v;
+            }
+        }
+    }
+}
+
+template <int MODE, int AMODE>
+void launch_b(const GemmP& p, dim3 grid, hipStream_t st) {
+    switch (p.bmode) {
+        case 1: hipLaunchKernelGGL((gemm_kernel<MODE, AMODE, 1>), grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<MODE, AMODE, 2>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_kernel<MODE, AMODE, 0>), grid, dim3(256), 0, st, p); break;
+    }
+}
+template <int MODE>
+void launch_a(const GemmP& p, dim3 grid, hipStream_t st) {
+    switch (p.amode) {
+        case 1: launch_b<MODE, 1>(p, grid, st); break;
+        case 2: launch_b<MODE, 2>(p, grid, st); break;
+        default: launch_b<MODE, 0>(p, grid, st); break;
+    }
+}
+
+// decide the staging path of one operand: rows stride sr, reduction stride sk
+int pick_mode(const float* base, long sr, long sk, long bs, int batch) {
+    bool al = (reinterpret_cast<uintptr_t>(base) % 16 == 0) && (batch <= 1 || bs % 4 == 0);
+    if (sk == 1 && al && sr % 4 == 0) return 1;
+    if (sr == 1 && al && sk % 4 == 0) return 2;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int ft_gemm(const ft_gemm_args* a, void* stream) {
+    FT_CHECK_ARG(a != nullptr);
+    FT_CHECK_ARG(a->A && a->B && a->C);
+    FT_CHECK_ARG(a->M >= 0 && a->N >= 0 && a->K >= 0 && a->batch >= 1);
+    FT_CHECK_ARG(a->mode == FT_F32 || a->mode == FT_BF16);
+    if (a->M == 0 || a->N == 0) return FT_OK;
+    FT_CHECK_ARG(a->K > 0);
+    GemmP p;
+    p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.sAm = a->sAm; p.sAk = a->sAk; p.sBk = a->sBk; p.sBn = a->sBn; p.ldc = a->ldc;
+    p.bsA = a->bsA; p.bsB = a->bsB; p.bsC = a->bsC;
+    p.alpha = a->alpha; p.beta = a->beta; p.act = a->act;
+    p.amode = pick_mode(a->A, a->sAm, a->sAk, a->bsA, a->batch);
+    p.bmode = pick_mode(a->B, a->sBn, a->sBk, a->bsB, a->batch);
+    dim3 grid(cdiv(a->N, BN), cdiv(a->M, BM), a->batch);
+    FT_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (a->mode == FT_F32) launch_a<0>(p, grid, st);
+    else launch_a<1>(p, grid, st);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}

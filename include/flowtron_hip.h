@@ -1,0 +1,184 @@
+/*
+ * flowtron_hip.h -- C ABI of libflowtron_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (NVIDIA/flowtron) has no FFI: its only boundary is the Python
+ * module API (flowtron.py Flowtron.forward/infer, audio_processing.py
+ * TacotronSTFT, distributed.py).  This header is the boundary a maintainer
+ * binds instead of the PyTorch/cuDNN/cuBLAS op call sites listed below; the
+ * ctypes stub that does it is flowtron_amd/_lib.py.
+ *
+ * Conventions
+ *   - every entry point returns 0 on success, a negative FT_E* code on error;
+ *     ft_last_error() returns a thread-local message for the last failure.
+ *   - all buffers are caller-owned DEVICE pointers (fp32 unless stated);
+ *     the library never allocates, frees or retains them.  Lengths are device
+ *     int32 arrays.  No entry point synchronises: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*), in order, and is hipGraph-capturable.
+ *   - `mode` selects the MFMA operand type of matmul-shaped work:
+ *     FT_F32 = fp32 operands (v_mfma_f32_16x16x4_f32, exact fp32, parity mode),
+ *     FT_BF16 = operands rounded to bf16 on the way into the matrix core
+ *     (v_mfma_f32_16x16x32_bf16), fp32 accumulate.  Storage stays fp32.
+ *   - time-major activations: [T,B,C] row-major, like the reference's
+ *     internal layout after flowtron.py:884.
+ */
+#ifndef FLOWTRON_HIP_H
+#define FLOWTRON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FT_ABI_VERSION 1
+
+enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
+enum { FT_F32 = 0, FT_BF16 = 1 };
+enum { FT_ACT_NONE = 0, FT_ACT_TANH = 1, FT_ACT_RELU = 2, FT_ACT_SIGMOID = 3 };
+
+int ft_abi_version(void);
+const char* ft_last_error(void);
+
+/* ---- GEMM ---------------------------------------------------------------
+ * C[b][m][n] = act( alpha * sum_k A[b](m,k) * B[b](k,n) + beta * C[b][m][n] + bias[n] )
+ * A(m,k) = A[b*bsA + m*sAm + k*sAk],  B(k,n) = B[b*bsB + k*sBk + n*sBn],
+ * C row-major with leading dimension ldc.  Replaces every nn.Linear / Conv1d /
+ * torch.bmm call site of the hot path: flowtron.py:568-571 (Q/K/V), :590 (context),
+ * :758 (gate), :767-768 (dense, 1x1 conv), the LSTM input projections inside
+ * nn.LSTM (:654-655, :488), the encoder Conv1d (:479-483, as im2col GEMM) and
+ * their autograd-derived transposes. */
+typedef struct {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K, batch;
+    int64_t sAm, sAk, sBk, sBn, ldc;
+    int64_t bsA, bsB, bsC;
+    float alpha, beta;
+    int act, mode;
+} ft_gemm_args;
+int ft_gemm(const ft_gemm_args* a, void* stream);
+
+/* ---- embedding gather (flowtron.py:873-874) ------------------------------
+ * out[r][0:dim] = W[ids[r]] for r < n (out row stride ld_out).  bwd: dW[ids[r]] += dout[r]. */
+int ft_embedding_fwd(const int64_t* ids, const float* W, float* out, int n, int dim, int64_t ld_out, void* stream);
+int ft_embedding_bwd(const int64_t* ids, const float* dout, float* dW, int n, int dim, int64_t ld_dout, void* stream);
+
+/* ---- encoder conv as im2col (flowtron.py:499-502) --------------------------
+ * x [L,B,C] time-major (must already be zero at l >= lens[b]);
+ * col[l][b][c*KW + k] = x[l + k - KW/2][b][c] (0 outside [0,lens[b])).
+ * col2im is the adjoint (gather form, deterministic). */
+int ft_im2col(const float* x, float* col, const int32_t* lens, int L, int B, int C, int KW, void* stream);
+int ft_col2im(const float* dcol, float* dx, const int32_t* lens, int L, int B, int C, int KW, void* stream);
+
+/* ---- masked instance norm + ReLU (+dropout keep-mask) (flowtron.py:53-92, :502)
+ * x,y [L,B,C]; statistics over l < lens[b] (biased variance, eps); y = relu(xhat*gamma+beta)*keep,
+ * y = 0 at l >= lens[b].  keep may be NULL.  Saves mean/rstd [B,C] for backward.
+ * bwd: dx (0 at pads), dgamma/dbeta [C] (overwritten). */
+int ft_instnorm_relu_fwd(const float* x, const float* gamma, const float* beta, const float* keep,
+                         const int32_t* lens, float* y, float* mean, float* rstd,
+                         int L, int B, int C, float eps, void* stream);
+int ft_instnorm_relu_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* keep,
+                         const int32_t* lens, const float* mean, const float* rstd,
+                         float* dx, float* dgamma, float* dbeta, int L, int B, int C, void* stream);
+
+/* ---- length-masked LSTM over a whole sequence (nn.LSTM on a packed sequence:
+ * flowtron.py:689-694 attention_lstm/lstm, :505-512 encoder BiLSTM) -----------------
+ * gx [T,B,4H] = x W_ih^T + b_ih + b_hh (from ft_gemm); w_hh [4H,H], gate rows i|f|g|o.
+ * Step s of sample b touches time t = s (forward) or lens[b]-1-s (reverse) while s < lens[b].
+ * y [T,B,ldy] gets h_t at valid t and 0 at t >= lens[b].  gates [T,B,4H] (post-activation
+ * i,f,g,o) and cell [T,B,H] are saved for backward.  work: ft_lstm_workspace_bytes() bytes.
+ * bwd: dy [T,B,ldy] -> dgx [T,B,4H] (0 at pads); dW_hh/dW_ih/dx/db follow as ft_gemm /
+ * ft_colsum calls over all T*B rows. */
+size_t ft_lstm_workspace_bytes(int B, int H);
+int ft_lstm_seq_fwd(const float* gx, const float* w_hh, const int32_t* lens,
+                    float* y, int64_t ldy, float* gates, float* cell, void* work,
+                    int T, int B, int H, int reverse, int mode, void* stream);
+int ft_lstm_seq_bwd(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens,
+                    const float* gates, const float* cell, float* dgx, void* work,
+                    int T, int B, int H, int reverse, int mode, void* stream);
+
+/* ---- additive attention scores + softmax + prior posterior (flowtron.py:544-583)
+ * Q [T,B,A] (time-major), K [L,B,A], v [A], in_lens [B], prior [B,T,L] or NULL.
+ * e[b,t,l] = sum_a v[a] tanh(Q[t,b,a]+K[l,b,a]) / temperature, -inf at l >= in_lens[b];
+ * p = softmax_l(e); with prior: logprob = log(p+1e-20)+log(prior+1e-20), attn = softmax_l(masked logprob);
+ * without: attn = p, logprob = log(p+1e-8).  The B*T*L*A tanh tensor is never materialised.
+ * Outputs attn, logprob [B,T,L]; p [B,T,L] is saved for backward when prior != NULL (may alias attn otherwise).
+ * bwd: dattn, dlogprob (may be NULL) -> dQ [T,B,A], dK [L,B,A] (atomically accumulated: zero it first),
+ * dv [A] (accumulated: zero it first). tanh is recomputed. */
+int ft_attention_fwd(const float* Q, const float* K, const float* v, const int32_t* in_lens, const float* prior,
+                     float* attn, float* logprob, float* p_save,
+                     int T, int B, int L, int A, float temperature, void* stream);
+int ft_attention_bwd(const float* Q, const float* K, const float* v, const int32_t* in_lens, const float* prior,
+                     const float* attn, const float* p_save, const float* dattn, const float* dlogprob,
+                     float* de_work, float* dQ, float* dK, float* dv,
+                     int T, int B, int L, int A, float temperature, void* stream);
+
+/* ---- affine coupling (flowtron.py:770-772) --------------------------------
+ * out [T,B,2M] = [log_s | b];  z = exp(log_s)*x + b.
+ * bwd: dout = [dz*x*exp(log_s) + dlog_s_ext | dz], dx = dz*exp(log_s)  (dlog_s_ext may be NULL). */
+int ft_affine_fwd(const float* out, const float* x, float* z, int64_t n_rows, int M, void* stream);
+int ft_affine_bwd(const float* out, const float* x, const float* dz, const float* dlog_s_ext,
+                  float* dout, float* dx, int64_t n_rows, int M, void* stream);
+/* inverse used by inference (flowtron.py:821): x = (z - b) / exp(log_s) */
+int ft_affine_inv(const float* out, const float* z, float* x, int64_t n_rows, int M, void* stream);
+
+/* ---- masked NLL partial sums (flowtron.py:206-235) -------------------------
+ * acc[0] += sum_{t<len_b} z^2 ; acc[1] += sum_{t<len_b} log_s  (acc zeroed by caller).
+ * x [T,B,M] with row stride ld (log_s is a strided view of the coupling output). */
+int ft_masked_sum(const float* x, int64_t ld, const int32_t* lens, float* acc, int square,
+                  int T, int B, int M, void* stream);
+/* dx = scale_dev[0] * coef * (square ? x : 1) at valid positions, 0 at pads */
+int ft_masked_sum_bwd(const float* x, int64_t ld, const int32_t* lens, const float* scale_dev, float coef, int square,
+                      float* dx, int64_t ld_dx, int T, int B, int M, void* stream);
+
+/* ---- gate BCE-with-logits (flowtron.py:237-243) ----------------------------
+ * gate [T,B], target [B,T]; acc[0] += sum_valid BCE(gate, target).  bwd: dgate = scale*(sigmoid(g)-y) valid, 0 pads */
+int ft_gate_bce_fwd(const float* gate, const float* target, const int32_t* lens, float* acc, int T, int B, void* stream);
+int ft_gate_bce_bwd(const float* gate, const float* target, const int32_t* lens, const float* scale_dev, float coef,
+                    float* dgate, int T, int B, void* stream);
+
+/* ---- reverse-by-length (flowtron.py:606-622, the flip+roll involution) --------
+ * time_major=1: x,y [T,B,C]; time_major=0: x,y [B,T,C].
+ * y[t] = x[len-1-t] (t < len), x[T-1+len-t] (t >= len). */
+int ft_reverse_by_length(const float* x, float* y, const int32_t* lens, int T, int B, int C, int time_major, void* stream);
+
+/* ---- column sums (bias gradients): out[n] = sum_r x[r*ld + n] -------------- */
+int ft_colsum(const float* x, float* out, int64_t rows, int N, int64_t ld, void* stream);
+
+/* ---- autoregressive decode, batch 1 (flowtron.py:775-828) ------------------
+ * One flow, N frames, fully enqueued without host synchronisation.  See ft_decode_args.
+ * n_done_dev[0] receives the number of frames produced (gate stop, flowtron.py:823-826). */
+typedef struct {
+    /* attention_lstm */  const float *att_w_ih, *att_w_hh, *att_b_ih, *att_b_hh;
+    /* attention     */   const float *w_query, *v, *K, *V;   /* K,V [L,A] precomputed once per utterance */
+    /* lstm l0, l1   */   const float *l0_w_ih, *l0_w_hh, *l0_b_ih, *l0_b_hh, *l1_w_ih, *l1_w_hh, *l1_b_ih, *l1_b_hh;
+    /* dense, conv   */   const float *d0_w, *d0_b, *d1_w, *d1_b, *conv_w, *conv_b;
+    /* gate (or NULL)*/   const float *gate_w, *gate_b;
+    const float* residual;   /* [N,M] */
+    float* mel_out;          /* [N,M] */
+    float* attn_out;         /* [N,L] */
+    int32_t* n_done_dev;     /* [1] */
+    void* work; size_t work_bytes;
+    int N, L, H, A, M;
+    float temperature, gate_threshold;
+    int use_graph;
+} ft_decode_args;
+size_t ft_decode_workspace_bytes(int L, int H, int A, int M);
+int ft_decode_flow(const ft_decode_args* a, void* stream);
+
+/* ---- STFT magnitude + mel + log (audio_processing.py:117-134, 207-235) -------
+ * y [B,N] in [-1,1] -> mel [B,n_mel,N/hop+1]; window [n_fft] (periodic hann),
+ * fb [n_mel, n_fft/2+1].  Radix-2 real FFT per frame in LDS (n_fft = 1024). */
+int ft_stft_mel(const float* y, const float* window, const float* fb, float* mel,
+                int B, int N, int n_fft, int hop, int n_mel, void* stream);
+
+/* ---- fused RAdam over a flat arena (radam.py:44-122) + grad-norm clip ---------- */
+int ft_sumsq(const float* x, float* acc, int64_t n, void* stream);
+int ft_radam_step(float* p, const float* g, float* m, float* v, int64_t n,
+                  const float* gnorm_sq_dev, float clip, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, float step_size, int rectified, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

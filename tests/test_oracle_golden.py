@@ -1,0 +1,118 @@
+"""Pins the CPU oracle (oracle/flowtron_oracle.py) against golden vectors that
+tests/golden/make_golden.py produced by executing the REAL reference
+(/root/reference/flowtron.py, audio_processing.py, scipy betabinom)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flowtron_oracle as O
+from oracle import synth
+
+TOL = 2e-5
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+def _maxdiff(a, b):
+    return (a - b).abs().max().item()
+
+
+@pytest.mark.parametrize("name", ["small_f2.pt", "small_f3.pt"])
+def test_forward_loss_grads_small(golden_dir, name):
+    g = _load(golden_dir, name)
+    cfg = g["cfg"]
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth.make_state_dict(cfg, seed=g["seed"]).items()}
+    b = synth.make_batch(cfg, g["out_lens"], g["in_lens"], seed=g["seed"], with_prior=g["with_prior"])
+    out = O.forward(sd, cfg, b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+    assert _maxdiff(out[0], g["z"]) < TOL
+    assert _maxdiff(out[2], g["gate"]) < TOL
+    for i in range(cfg["n_flows"]):
+        assert _maxdiff(out[1][i], g["log_s"][i]) < TOL
+        assert _maxdiff(out[3][i], g["attn"][i]) < TOL
+        assert _maxdiff(out[4][i], g["logprob"][i]) < 2e-4      # log of small probabilities
+    nll, gl, ctc = O.loss(out, b["gate_target"], b["in_lens"], b["out_lens"], 1.0, True, True, -8)
+    assert abs(nll.item() - g["nll"].item()) < 1e-5 * abs(g["nll"].item())
+    assert abs(gl.item() - g["gate_loss"].item()) < 1e-5
+    assert abs(ctc.item() - g["ctc"].item()) < 1e-4
+    (nll + gl + 0.01 * ctc).sum().backward()
+    for k, ref in g["grads"].items():
+        mine = sd[k].grad
+        assert mine is not None, k
+        denom = ref.norm().item() + 1e-12
+        assert (mine - ref).norm().item() / denom < 2e-4, (k, (mine - ref).norm().item() / denom)
+
+
+@pytest.mark.parametrize("name", ["small_f2.pt", "small_f3.pt"])
+def test_infer_small(golden_dir, name):
+    g = _load(golden_dir, name)
+    cfg = g["cfg"]
+    sd = synth.make_state_dict(cfg, seed=g["seed"])
+    b = synth.make_batch(cfg, g["out_lens"], g["in_lens"], seed=g["seed"], with_prior=g["with_prior"])
+    n = g["infer_mel"].shape[2]
+    rs = np.random.RandomState(g["seed"] + 11)
+    residual = torch.from_numpy(rs.standard_normal((1, cfg["n_mel_channels"], n)).astype(np.float32)) * 0.5
+    txt, spk = b["text"][:1, : g["in_lens"][0]], b["speaker_ids"][:1]
+    mel, attns = O.infer(sd, cfg, residual, spk, txt, gate_threshold=1.0)
+    assert _maxdiff(mel, g["infer_mel"]) < TOL
+    for a, ra in zip(attns, g["infer_attn"]):
+        assert _maxdiff(a, ra) < TOL
+    mel_g, _ = O.infer(sd, cfg, residual, spk, txt, gate_threshold=0.5)
+    assert mel_g.shape[2] == g["infer_gated_frames"]
+
+
+def test_cfg1_full_size(golden_dir):
+    """BASELINE config 1: 1-flow, n_text=148, B=2, T=800/650, fp32 (forward + losses + infer)."""
+    g = _load(golden_dir, "cfg1_full.pt")
+    cfg = g["cfg"]
+    sd = synth.make_state_dict(cfg, seed=g["seed"])
+    b = synth.make_batch(cfg, g["out_lens"], g["in_lens"], seed=g["seed"], with_prior=True)
+    O.LSTM_IMPL["fn"] = O.lstm_seq_fast
+    try:
+        with torch.no_grad():
+            out = O.forward(sd, cfg, b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+            nll, gl, ctc = O.loss(out, b["gate_target"], b["in_lens"], b["out_lens"], 1.0, True, True, -8)
+    finally:
+        O.LSTM_IMPL["fn"] = O.lstm_cell_seq
+    st = g["stride"]
+    assert _maxdiff(out[0][::st], g["z"]) < 1e-4
+    assert _maxdiff(out[1][0][::st], g["log_s"][0]) < 1e-4
+    assert _maxdiff(out[3][0][:, ::st], g["attn"][0]) < 1e-5
+    assert abs(nll.item() - g["nll"].item()) < 1e-5 * abs(g["nll"].item())
+    assert abs(gl.item() - g["gate_loss"].item()) < 1e-5
+    assert abs(ctc.item() - g["ctc"].item()) < 1e-4 * max(1.0, abs(g["ctc"].item()))
+    n = g["infer_mel"].shape[2]
+    rs = np.random.RandomState(g["seed"] + 11)
+    residual = torch.from_numpy(rs.standard_normal((1, 80, n)).astype(np.float32)) * 0.5
+    with torch.no_grad():
+        mel, _ = O.infer(sd, cfg, residual, b["speaker_ids"][:1], b["text"][:1, : g["in_lens"][0]], gate_threshold=1.0)
+    assert _maxdiff(mel, g["infer_mel"]) < 1e-4
+
+
+def test_stft_mel(golden_dir):
+    g = _load(golden_dir, "stft_mel.pt")
+    y = torch.stack([synth.make_audio(g["n_samples"], seed=s) for s in g["seeds"]])
+    mel = O.stft_mel(y)
+    assert mel.shape == g["mel"].shape
+    assert _maxdiff(mel, g["mel"]) < 2e-4
+
+
+def test_beta_binomial_prior(golden_dir):
+    g = _load(golden_dir, "prior.pt")
+    assert _maxdiff(O.beta_binomial_prior(13, 40), g["p13_m40"]) < 1e-12
+    assert _maxdiff(O.beta_binomial_prior(148, 800)[::50], g["p148_m800_s50"]) < 1e-12
+
+
+def test_reverse_by_length_is_flip_roll():
+    torch.manual_seed(0)
+    x = torch.randn(9, 3, 4)
+    lens = torch.tensor([9, 4, 1])
+    y = O.reverse_by_length(x, lens, 0, 1)
+    ref = torch.flip(x, (0,)).clone()
+    for k in range(3):
+        ref[:, k] = ref[:, k].roll(int(lens[k]), dims=0)          # flowtron.py:606-613
+    assert torch.equal(y, ref)
+    assert torch.equal(O.reverse_by_length(y, lens, 0, 1), x)     # involution
