@@ -1,0 +1,127 @@
+"""ctypes binding of libflowtron_hip.so (include/flowtron_hip.h).
+
+This is the stub a maintainer of the reference would add to bind the C ABI
+(see INTEGRATION.md).  There is NO fallback: if the shared object is missing
+or an entry point fails, a RuntimeError is raised -- the product path never
+routes around the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflowtron_hip.so")
+
+FT_F32, FT_BF16 = 0, 1
+ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+
+_p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", _p), ("B", _p), ("C", _p), ("bias", _p),
+                ("M", _i), ("N", _i), ("K", _i), ("batch", _i),
+                ("sAm", _l), ("sAk", _l), ("sBk", _l), ("sBn", _l), ("ldc", _l),
+                ("bsA", _l), ("bsB", _l), ("bsC", _l),
+                ("alpha", _f), ("beta", _f), ("act", _i), ("mode", _i)]
+
+
+class DecodeArgs(C.Structure):
+    _fields_ = [(n, _p) for n in (
+        "att_w_ih", "att_w_hh", "att_b_ih", "att_b_hh", "w_query", "v", "K", "V",
+        "l0_w_ih", "l0_w_hh", "l0_b_ih", "l0_b_hh", "l1_w_ih", "l1_w_hh", "l1_b_ih", "l1_b_hh",
+        "d0_w", "d0_b", "d1_w", "d1_b", "conv_w", "conv_b", "gate_w", "gate_b",
+        "residual", "mel_out", "attn_out", "n_done_dev", "work")] + [
+        ("work_bytes", _sz), ("N", _i), ("L", _i), ("H", _i), ("A", _i), ("M", _i),
+        ("temperature", _f), ("gate_threshold", _f), ("use_graph", _i)]
+
+
+# name -> argtypes (every symbol include/flowtron_hip.h declares; checked by tests/test_abi.py)
+SIGNATURES = {
+    "ft_abi_version": ([], _i),
+    "ft_last_error": ([], C.c_char_p),
+    "ft_gemm": ([C.POINTER(GemmArgs), _p], _i),
+    "ft_embedding_fwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
+    "ft_embedding_bwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
+    "ft_im2col": ([_p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "ft_col2im": ([_p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "ft_instnorm_relu_fwd": ([_p] * 8 + [_i, _i, _i, _f, _p], _i),
+    "ft_instnorm_relu_bwd": ([_p] * 11 + [_i, _i, _i, _p], _i),
+    "ft_lstm_workspace_bytes": ([_i, _i], _sz),
+    "ft_lstm_seq_fwd": ([_p, _p, _p, _p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "ft_lstm_seq_bwd": ([_p, _l, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "ft_attention_fwd": ([_p] * 8 + [_i, _i, _i, _i, _f, _p], _i),
+    "ft_attention_bwd": ([_p] * 13 + [_i, _i, _i, _i, _f, _p], _i),
+    "ft_affine_fwd": ([_p, _p, _p, _l, _i, _p], _i),
+    "ft_affine_bwd": ([_p, _p, _p, _p, _p, _p, _l, _i, _p], _i),
+    "ft_affine_inv": ([_p, _p, _p, _l, _i, _p], _i),
+    "ft_masked_sum": ([_p, _l, _p, _p, _i, _i, _i, _i, _p], _i),
+    "ft_masked_sum_bwd": ([_p, _l, _p, _p, _f, _i, _p, _l, _i, _i, _i, _p], _i),
+    "ft_gate_bce_fwd": ([_p, _p, _p, _p, _i, _i, _p], _i),
+    "ft_gate_bce_bwd": ([_p, _p, _p, _p, _f, _p, _i, _i, _p], _i),
+    "ft_reverse_by_length": ([_p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "ft_act_bwd": ([_p, _p, _p, _l, _i, _p], _i),
+    "ft_colsum": ([_p, _p, _l, _i, _l, _p], _i),
+    "ft_decode_workspace_bytes": ([_i, _i, _i, _i], _sz),
+    "ft_decode_flow": ([C.POINTER(DecodeArgs), _p], _i),
+    "ft_stft_mel": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "ft_sumsq": ([_p, _p, _l, _p], _i),
+    "ft_radam_step": ([_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _f, _f, _f, _i, _p], _i),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads the shared object once; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libflowtron_hip.so is missing (%s). Build it with `python -m flowtron_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (argt, rest) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = argt
+            fn.restype = rest
+        if l.ft_abi_version() != 1:
+            raise RuntimeError("libflowtron_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().ft_last_error().decode()))
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "flowtron_amd ops run on MI355X only: got a %s tensor. There is no CPU fallback "
+                "(the CPU oracle lives in oracle/ and is test infrastructure)." % t.device)
+
+
+def mfma_mode() -> int:
+    """Operand type fed to the matrix cores (env FLOWTRON_MFMA = f32 | bf16). Storage is fp32."""
+    m = os.environ.get("FLOWTRON_MFMA", "f32").lower()
+    if m in ("f32", "fp32"):
+        return FT_F32
+    if m in ("bf16",):
+        return FT_BF16
+    raise ValueError("FLOWTRON_MFMA must be f32 or bf16, got %r" % m)

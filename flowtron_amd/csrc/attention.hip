@@ -1,0 +1,392 @@
+// Additive (Bahdanau) attention of the Flowtron AR step, reference flowtron.py:544-583.
+//
+//   e[b,t,l] = (1/temp) * sum_a v[a] * tanh(Q[t,b,a] + K[l,b,a])      l < in_lens[b]
+//   p = softmax_l(e);  prior: u = log(p+1e-20)+log(prior+1e-20), attn = softmax_l(u)
+//
+// The reference materialises the B*T*L*A tanh tensor (4.85 GB in fp16 at B=32,T=800,
+// L=148) and keeps it for backward.  Here it never leaves the register file:
+//   forward  : one workgroup per (b, 32 query rows); Q and K a-chunks are staged in LDS,
+//              every thread owns a 4x4 (t,l) micro-tile so each LDS float4 feeds 16 tanh;
+//              scores land in an LDS [32][L] tile where the softmax / prior posterior is
+//              finished by one wave per 8 rows.  Transcendental-ALU bound.
+//   backward : softmax/posterior row kernel -> de, then dQ (workgroup per (b, 32 t)) and
+//              dK (workgroup per (b, 16 l)) kernels that recompute tanh with lane <-> a, so
+//              every gradient element is owned by exactly one thread (no atomics on dQ/dK).
+#include "common.h"
+
+namespace {
+
+constexpr int TT = 32;       // query rows per workgroup
+constexpr int LT = 128;      // key columns per pass
+constexpr int AC = 64;       // a-chunk staged per iteration
+constexpr int LDA = AC + 4;  // LDS row stride (floats): 16-lane groups of ds_read_b128 hit 64 distinct banks
+
+// 1 - 2/(exp(2x)+1) with the hardware exp/rcp: |abs err| ~ 2e-7, exact limits at +-inf
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+template <bool HAS_PRIOR>
+__global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ Q, const float* __restrict__ K,
+                                                  const float* __restrict__ v, const int* __restrict__ in_lens,
+                                                  const float* __restrict__ prior, float* __restrict__ attn,
+                                                  float* __restrict__ logprob, float* __restrict__ p_save,
+                                                  int T, int B, int L, int A, int LP, float inv_temp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* qs = smem;                 // [TT][LDA]
+    float* ks = qs + TT * LDA;        // [LT][LDA]
+    float* vs = ks + LT * LDA;        // [AC]
+    float* es = vs + AC;              // [TT][LP]
+
+    const int tid = threadIdx.x;
+    const int tl = tid & 31, tg = tid >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * TT;
+    const int len = min(in_lens[b], L);
+    const int nlt = (len + LT - 1) / LT;
+
+    for (int lt = 0; lt < nlt; ++lt) {
+        float acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        bool jact[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) jact[j] = (lt * LT + j * 32) < len;
+
+        for (int a0 = 0; a0 < A; a0 += AC) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < (TT * AC) / 256; ++r) {
+                const int idx = tid + 256 * r;
+                const int row = idx >> 6, col = idx & 63;
+                const int t = t0 + row, a = a0 + col;
+                qs[row * LDA + col] = (t < T && a < A) ? Q[((long)t * B + b) * A + a] : 0.f;
+            }
+#pragma unroll 4
+            for (int r = 0; r < (LT * AC) / 256; ++r) {
+                const int idx = tid + 256 * r;
+                const int row = idx >> 6, col = idx & 63;
+                const int l = lt * LT + row, a = a0 + col;
+                ks[row * LDA + col] = (l < len && a < A) ? K[((long)l * B + b) * A + a] : 0.f;
+            }
+            if (tid < AC) vs[tid] = (a0 + tid < A) ? v[a0 + tid] : 0.f;
+            __syncthreads();
+#pragma unroll 2
+            for (int a4 = 0; a4 < AC / 4; ++a4) {
+                const float4 vv = *reinterpret_cast<const float4*>(vs + a4 * 4);
+                float4 q[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const float4*>(qs + (tg * 4 + i) * LDA + a4 * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (jact[j]) {
+                        const float4 kk = *reinterpret_cast<const float4*>(ks + (j * 32 + tl) * LDA + a4 * 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            acc[i][j] += vv.x * tanh_fast(q[i].x + kk.x) + vv.y * tanh_fast(q[i].y + kk.y) +
+                                         vv.z * tanh_fast(q[i].z + kk.z) + vv.w * tanh_fast(q[i].w + kk.w);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (jact[j]) es[(tg * 4 + i) * LP + lt * LT + j * 32 + tl] = acc[i][j] * inv_temp;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int r = 0; r < TT / 4; ++r) {
+        const int row = wave * (TT / 4) + r;
+        const int t = t0 + row;
+        if (t >= T) break;
+        float* e = es + row * LP;
+        float m = -INFINITY;
+        for (int l = lane; l < len; l += 64) m = fmaxf(m, e[l]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int l = lane; l < len; l += 64) { const float p = expf(e[l] - m); e[l] = p; s += p; }
+        s = wave_sum(s);
+        const long base = ((long)b * T + t) * L;
+        if constexpr (!HAS_PRIOR) {
+            for (int l = lane; l < L; l += 64) {
+                const float p = (l < len) ? e[l] / s : 0.f;
+                attn[base + l] = p;
+                logprob[base + l] = logf(p + 1e-8f);
+            }
+        } else {
+            float m2 = -INFINITY;
+            for (int l = lane; l < L; l += 64) {
+                const float p = (l < len) ? e[l] / s : 0.f;
+                const float u = logf(p + 1e-20f) + logf(prior[base + l] + 1e-20f);
+                logprob[base + l] = u;
+                p_save[base + l] = p;
+                if (l < len) { e[l] = u; m2 = fmaxf(m2, u); }
+            }
+            m2 = wave_max(m2);
+            float s2 = 0.f;
+            for (int l = lane; l < len; l += 64) { const float p = expf(e[l] - m2); e[l] = p; s2 += p; }
+            s2 = wave_sum(s2);
+            for (int l = lane; l < L; l += 64) attn[base + l] = (l < len) ? e[l] / s2 : 0.f;
+        }
+    }
+}
+
+// one wave per (b,t) row: de = d(loss)/d(e) * (1/temp), 0 at l >= in_lens[b]
+template <bool HAS_PRIOR>
+__global__ __launch_bounds__(256) void attn_softmax_bwd_k(const float* __restrict__ attn, const float* __restrict__ p_save,
+                                                          const float* __restrict__ dattn, const float* __restrict__ dlogprob,
+                                                          const int* __restrict__ in_lens, float* __restrict__ de,
+                                                          int T, int B, int L, float inv_temp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= (long)B * T) return;
+    const int b = (int)(row / T);
+    const int len = min(in_lens[b], L);
+    const long base = row * L;
+    float s2 = 0.f;
+    if constexpr (HAS_PRIOR) {
+        float s1 = 0.f;
+        for (int l = lane; l < len; l += 64) s1 += attn[base + l] * dattn[base + l];
+        s1 = wave_sum(s1);
+        for (int l = lane; l < len; l += 64) {
+            const float p = p_save[base + l];
+            float du = attn[base + l] * (dattn[base + l] - s1);
+            if (dlogprob) du += dlogprob[base + l];
+            s2 += p * (du / (p + 1e-20f));
+        }
+        s2 = wave_sum(s2);
+        for (int l = lane; l < L; l += 64) {
+            float o = 0.f;
+            if (l < len) {
+                const float p = p_save[base + l];
+                float du = attn[base + l] * (dattn[base + l] - s1);
+                if (dlogprob) du += dlogprob[base + l];
+                o = p * (du / (p + 1e-20f) - s2) * inv_temp;
+            }
+            de[base + l] = o;
+        }
+    } else {
+        for (int l = lane; l < len; l += 64) {
+            const float p = attn[base + l];
+            float dp = dattn[base + l];
+            if (dlogprob) dp += dlogprob[base + l] / (p + 1e-8f);
+            s2 += p * dp;
+        }
+        s2 = wave_sum(s2);
+        for (int l = lane; l < L; l += 64) {
+            float o = 0.f;
+            if (l < len) {
+                const float p = attn[base + l];
+                float dp = dattn[base + l];
+                if (dlogprob) dp += dlogprob[base + l] / (p + 1e-8f);
+                o = p * (dp - s2) * inv_temp;
+            }
+            de[base + l] = o;
+        }
+    }
+}
+
+// dQ[t,b,a] = v[a] * sum_l de[b,t,l] * (1 - tanh^2(Q+K));  dv[a] += sum_{t,l} de * tanh(Q+K)
+__global__ __launch_bounds__(256) void attn_dq_k(const float* __restrict__ Q, const float* __restrict__ K,
+                                                 const float* __restrict__ v, const int* __restrict__ in_lens,
+                                                 const float* __restrict__ de, float* __restrict__ dQ, float* __restrict__ dv,
+                                                 int T, int B, int L, int A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* de_s = smem;                 // [len][32]
+    float* red = smem + (size_t)L * 32; // [4][64]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.y, t0 = blockIdx.x * 32;
+    const int len = min(in_lens[b], L);
+    for (int idx = tid; idx < len * 32; idx += 256) {
+        const int r = idx & 31, l = idx >> 5;
+        de_s[idx] = (t0 + r < T) ? de[((long)b * T + t0 + r) * L + l] : 0.f;
+    }
+    __syncthreads();
+    for (int a0 = 0; a0 < A; a0 += 64) {
+        const int a = a0 + lane;
+        const bool av = a < A;
+        float q[8], dq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = t0 + w * 8 + i;
+            q[i] = (av && t < T) ? Q[((long)t * B + b) * A + a] : 0.f;
+            dq[i] = 0.f;
+        }
+        float dva = 0.f;
+        const float* kp = K + (long)b * A + a;
+        const long ks = (long)B * A;
+        int l = 0;
+        for (; l + 4 <= len; l += 4) {
+            float kv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kv[u] = av ? kp[(l + u) * ks] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 d0 = *reinterpret_cast<const float4*>(de_s + (l + u) * 32 + w * 8);
+                const float4 d1 = *reinterpret_cast<const float4*>(de_s + (l + u) * 32 + w * 8 + 4);
+                const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float s = tanh_fast(q[i] + kv[u]);
+                    dq[i] += d[i] * (1.f - s * s);
+                    dva += d[i] * s;
+                }
+            }
+        }
+        for (; l < len; ++l) {
+            const float kv = av ? kp[l * ks] : 0.f;
+            const float4 d0 = *reinterpret_cast<const float4*>(de_s + l * 32 + w * 8);
+            const float4 d1 = *reinterpret_cast<const float4*>(de_s + l * 32 + w * 8 + 4);
+            const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float s = tanh_fast(q[i] + kv);
+                dq[i] += d[i] * (1.f - s * s);
+                dva += d[i] * s;
+            }
+        }
+        const float va = av ? v[a] : 0.f;
+        if (av) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t = t0 + w * 8 + i;
+                if (t < T) dQ[((long)t * B + b) * A + a] = dq[i] * va;
+            }
+        }
+        __syncthreads();
+        red[w * 64 + lane] = dva;
+        __syncthreads();
+        if (w == 0 && av) atomicAdd(dv + a, red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]);
+    }
+}
+
+// dK[l,b,a] = v[a] * sum_t de[b,t,l] * (1 - tanh^2(Q+K))
+__global__ __launch_bounds__(256) void attn_dk_k(const float* __restrict__ Q, const float* __restrict__ K,
+                                                 const float* __restrict__ v, const int* __restrict__ in_lens,
+                                                 const float* __restrict__ de, float* __restrict__ dK,
+                                                 int T, int B, int L, int A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* de_s = smem;   // [T][16]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.y, l0 = blockIdx.x * 16;
+    const int len = min(in_lens[b], L);
+    if (l0 >= len) {      // whole tile is padding: zero gradient
+        for (int idx = tid; idx < 16 * A; idx += 256) {
+            const int j = idx / A, a = idx - j * A;
+            if (l0 + j < L) dK[((long)(l0 + j) * B + b) * A + a] = 0.f;
+        }
+        return;
+    }
+    for (int idx = tid; idx < T * 16; idx += 256) {
+        const int j = idx & 15, t = idx >> 4;
+        de_s[idx] = (l0 + j < len) ? de[((long)b * T + t) * L + l0 + j] : 0.f;
+    }
+    __syncthreads();
+    const long qs = (long)B * A;
+    for (int a0 = 0; a0 < A; a0 += 64) {
+        const int a = a0 + lane;
+        const bool av = a < A;
+        float k[4], dk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int l = l0 + w * 4 + j;
+            k[j] = (av && l < L) ? K[((long)l * B + b) * A + a] : 0.f;
+            dk[j] = 0.f;
+        }
+        const float* qp = Q + (long)b * A + a;
+        int t = 0;
+        for (; t + 4 <= T; t += 4) {
+            float qv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) qv[u] = av ? qp[(t + u) * qs] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 d4 = *reinterpret_cast<const float4*>(de_s + (t + u) * 16 + w * 4);
+                const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float s = tanh_fast(qv[u] + k[j]);
+                    dk[j] += d[j] * (1.f - s * s);
+                }
+            }
+        }
+        for (; t < T; ++t) {
+            const float qv = av ? qp[t * qs] : 0.f;
+            const float4 d4 = *reinterpret_cast<const float4*>(de_s + t * 16 + w * 4);
+            const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float s = tanh_fast(qv + k[j]);
+                dk[j] += d[j] * (1.f - s * s);
+            }
+        }
+        if (av) {
+            const float va = v[a];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int l = l0 + w * 4 + j;
+                if (l < L) dK[((long)l * B + b) * A + a] = dk[j] * va;
+            }
+        }
+    }
+}
+
+constexpr int MAX_LDS = 160 * 1024;
+
+}  // namespace
+
+extern "C" int ft_attention_fwd(const float* Q, const float* K, const float* v, const int32_t* in_lens, const float* prior,
+                                float* attn, float* logprob, float* p_save,
+                                int T, int B, int L, int A, float temperature, void* stream) {
+    FT_CHECK_ARG(Q && K && v && in_lens && attn && logprob);
+    FT_CHECK_ARG(T >= 1 && B >= 1 && L >= 1 && A >= 1 && temperature > 0.f);
+    FT_CHECK_ARG(prior == nullptr || p_save != nullptr);
+    FT_CHECK_ARG(B <= 65535);
+    const int LP = cdiv(L, LT) * LT;
+    const size_t lds = sizeof(float) * ((size_t)TT * LDA + (size_t)LT * LDA + AC + (size_t)TT * LP);
+    if (lds > (size_t)MAX_LDS) return ft_fail(FT_EUNSUPPORTED, "ft_attention_fwd: L=%d needs %zu B of LDS (max %d)", L, lds, MAX_LDS);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(cdiv(T, TT), B);
+    if (prior) {
+        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+        hipLaunchKernelGGL(attn_fwd_k<true>, grid, dim3(256), lds, st, Q, K, v, in_lens, prior, attn, logprob, p_save, T, B, L, A, LP, 1.0f / temperature);
+    } else {
+        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+        hipLaunchKernelGGL(attn_fwd_k<false>, grid, dim3(256), lds, st, Q, K, v, in_lens, prior, attn, logprob, p_save, T, B, L, A, LP, 1.0f / temperature);
+    }
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+
+extern "C" int ft_attention_bwd(const float* Q, const float* K, const float* v, const int32_t* in_lens, const float* prior,
+                                const float* attn, const float* p_save, const float* dattn, const float* dlogprob,
+                                float* de_work, float* dQ, float* dK, float* dv,
+                                int T, int B, int L, int A, float temperature, void* stream) {
+    FT_CHECK_ARG(Q && K && v && in_lens && attn && dattn && de_work && dQ && dK && dv);
+    FT_CHECK_ARG(T >= 1 && B >= 1 && L >= 1 && A >= 1 && temperature > 0.f);
+    FT_CHECK_ARG(prior == nullptr || p_save != nullptr);
+    FT_CHECK_ARG(B <= 65535);
+    const size_t lds_q = sizeof(float) * ((size_t)L * 32 + 256);
+    const size_t lds_k = sizeof(float) * ((size_t)T * 16);
+    if (lds_q > (size_t)MAX_LDS || lds_k > (size_t)MAX_LDS)
+        return ft_fail(FT_EUNSUPPORTED, "ft_attention_bwd: T=%d L=%d exceed the LDS tiles (%zu / %zu B)", T, L, lds_k, lds_q);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const float inv_temp = 1.0f / temperature;
+    const int rows_grid = cdiv((int64_t)B * T, 4);
+    if (prior)
+        hipLaunchKernelGGL(attn_softmax_bwd_k<true>, dim3(rows_grid), dim3(256), 0, st, attn, p_save, dattn, dlogprob, in_lens, de_work, T, B, L, inv_temp);
+    else
+        hipLaunchKernelGGL(attn_softmax_bwd_k<false>, dim3(rows_grid), dim3(256), 0, st, attn, p_save, dattn, dlogprob, in_lens, de_work, T, B, L, inv_temp);
+    FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dq_k), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+    FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dk_k), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+    hipLaunchKernelGGL(attn_dq_k, dim3(cdiv(T, 32), B), dim3(256), lds_q, st, Q, K, v, in_lens, de_work, dQ, dv, T, B, L, A);
+    hipLaunchKernelGGL(attn_dk_k, dim3(cdiv(L, 16), B), dim3(256), lds_k, st, Q, K, v, in_lens, de_work, dK, T, B, L, A);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}

@@ -1,0 +1,332 @@
+// Autoregressive decode of one flow at batch 1 (reference AR_Step.infer, flowtron.py:775-828).
+//
+// Batch-1 decode is a chain of dependent GEMVs over 26.8 M weights per frame (107 MB fp32):
+// it is bound by streaming those weights (they stay resident in the 256 MiB Infinity Cache
+// across frames) and by the eight dependent stages per frame.  Each stage is one launch that
+// fills the chip with one wave per output row (or per hidden unit: the four i/f/g/o gate rows
+// of a unit are reduced by the same wave so the cell update fuses into the GEMV):
+//
+//   S1 attention_lstm step      S2 query projection      S3 scores+softmax+context (1 WG)
+//   S4 lstm layer 0 step        S5 lstm layer 1 step     S6/S7 dense tanh x2
+//   S8 1x1 conv -> (log_s,b), inverse coupling, gate sigmoid/threshold, frame counter
+//
+// Nothing returns to the host inside the loop: the frame index and the stop flag live in
+// device memory (the reference's python `if sigmoid(gate) > thr: break`, flowtron.py:823-826,
+// becomes a device flag every later stage tests first).  All kernels take one pointer to a
+// device-resident parameter block, so a chunk of frames can be captured ONCE into a hipGraph
+// and replayed for every chunk of every utterance that reuses the same workspace.
+#include <mutex>
+#include <unordered_map>
+
+#include "common.h"
+
+namespace {
+
+struct DecodeDev {
+    const float *att_w_ih, *att_w_hh, *att_b_ih, *att_b_hh;
+    const float *w_query, *v, *K, *V;
+    const float *l0_w_ih, *l0_w_hh, *l0_b_ih, *l0_b_hh, *l1_w_ih, *l1_w_hh, *l1_b_ih, *l1_b_hh;
+    const float *d0_w, *d0_b, *d1_w, *d1_b, *conv_w, *conv_b, *gate_w, *gate_b;
+    const float* residual; float* mel_out; float* attn_out; int* n_done_dev;
+    float *h_att, *c_att, *h0, *c0, *h1, *c1;   // h_*: [2][H] ping-pong by frame parity
+    float *q, *ctx, *u1, *u2, *prev;
+    int* ctl;                                    // [0] frame index, [1] done flag
+    int N, L, H, A, M;
+    float inv_temp, gate_threshold;
+};
+
+__device__ __forceinline__ float dot_seg(const float* __restrict__ w, const float* __restrict__ x, int K, int lane) {
+    float s = 0.f;
+    if (((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
+        const float4* w4 = reinterpret_cast<const float4*>(w);
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const int K4 = K >> 2;
+        for (int k = lane; k < K4; k += 64) {
+            const float4 a = w4[k], b = x4[k];
+            s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) s += w[k] * x[k];
+    }
+    return s;
+}
+
+__device__ __forceinline__ bool frame_live(const DecodeDev* P, int& i) {
+    i = P->ctl[0];
+    return (P->ctl[1] == 0) && (i < P->N);
+}
+
+// One wave per hidden unit u: gates_g = W_ih[g*H+u,:].x (+ second input segment) + W_hh[g*H+u,:].h + b
+template <int WHICH>   // 0 attention_lstm, 1 lstm l0, 2 lstm l1
+__global__ __launch_bounds__(256) void dec_lstm_k(const DecodeDev* __restrict__ P) {
+    int i;
+    if (!frame_live(P, i)) return;
+    const int lane = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int H = P->H;
+    if (u >= H) return;
+    const int par = i & 1;
+    const float *w_ih, *w_hh, *b_ih, *b_hh, *x0, *x1 = nullptr;
+    float *hbuf, *cbuf;
+    int K0, K1 = 0;
+    if (WHICH == 0) {
+        w_ih = P->att_w_ih; w_hh = P->att_w_hh; b_ih = P->att_b_ih; b_hh = P->att_b_hh;
+        x0 = P->prev; K0 = P->M; hbuf = P->h_att; cbuf = P->c_att;
+    } else if (WHICH == 1) {
+        w_ih = P->l0_w_ih; w_hh = P->l0_w_hh; b_ih = P->l0_b_ih; b_hh = P->l0_b_hh;
+        x0 = P->h_att + (par ^ 1) * H; K0 = H; x1 = P->ctx; K1 = P->A; hbuf = P->h0; cbuf = P->c0;
+    } else {
+        w_ih = P->l1_w_ih; w_hh = P->l1_w_hh; b_ih = P->l1_b_ih; b_hh = P->l1_b_hh;
+        x0 = P->h0 + (par ^ 1) * H; K0 = H; hbuf = P->h1; cbuf = P->c1;
+    }
+    const float* hold = hbuf + par * H;
+    const int Kin = K0 + K1;
+    float pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const size_t row = (size_t)g * H + u;
+        float s = dot_seg(w_ih + row * Kin, x0, K0, lane);
+        if (K1) s += dot_seg(w_ih + row * Kin + K0, x1, K1, lane);
+        s += dot_seg(w_hh + row * H, hold, H, lane);
+        pre[g] = wave_sum(s) + b_ih[row] + b_hh[row];
+    }
+    if (lane == 0) {
+        const float ig = 1.f / (1.f + expf(-pre[0]));
+        const float fg = 1.f / (1.f + expf(-pre[1]));
+        const float gg = tanhf(pre[2]);
+        const float og = 1.f / (1.f + expf(-pre[3]));
+        const float c = fg * cbuf[u] + ig * gg;
+        cbuf[u] = c;
+        hbuf[(par ^ 1) * H + u] = og * tanhf(c);
+    }
+}
+
+// y[n] = act(W[n,:].x + b[n]), one wave per row.  WHICH: 0 query (x = new h_att), 1 dense0 (x = new h1), 2 dense1 (x = u1)
+template <int WHICH>
+__global__ __launch_bounds__(256) void dec_gemv_k(const DecodeDev* __restrict__ P) {
+    int i;
+    if (!frame_live(P, i)) return;
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int H = P->H;
+    const int par = i & 1;
+    const float *W, *b = nullptr, *x;
+    float* y;
+    int N, K;
+    if (WHICH == 0) { W = P->w_query; x = P->h_att + (par ^ 1) * H; y = P->q; N = P->A; K = H; }
+    else if (WHICH == 1) { W = P->d0_w; b = P->d0_b; x = P->h1 + (par ^ 1) * H; y = P->u1; N = H; K = H; }
+    else { W = P->d1_w; b = P->d1_b; x = P->u1; y = P->u2; N = H; K = H; }
+    if (n >= N) return;
+    float s = wave_sum(dot_seg(W + (size_t)n * K, x, K, lane));
+    if (lane == 0) {
+        if (WHICH != 0) s = tanhf(s + b[n]);
+        y[n] = s;
+    }
+}
+
+// scores + softmax + context, one workgroup of 1024 threads (16 waves)
+__global__ __launch_bounds__(1024) void dec_attn_k(const DecodeDev* __restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [L] scores, [16] reduction, [A] q
+    int i;
+    if (!frame_live(P, i)) return;
+    const int L = P->L, A = P->A;
+    float* e = sm;
+    float* red = sm + L;
+    float* qs = red + 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int a = tid; a < A; a += 1024) qs[a] = P->q[a];
+    __syncthreads();
+    for (int l = wave; l < L; l += 16) {
+        const float* kr = P->K + (size_t)l * A;
+        float s = 0.f;
+        for (int a = lane; a < A; a += 64) s += P->v[a] * tanhf(qs[a] + kr[a]);
+        s = wave_sum(s);
+        if (lane == 0) e[l] = s * P->inv_temp;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int l = tid; l < L; l += 1024) m = fmaxf(m, e[l]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    __syncthreads();
+    float s = 0.f;
+    for (int l = tid; l < L; l += 1024) { const float p = expf(e[l] - m); e[l] = p; s += p; }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w];
+    float* arow = P->attn_out + (size_t)i * L;
+    for (int l = tid; l < L; l += 1024) arow[l] = e[l] / s;
+    const float inv = 1.f / s;
+    for (int a = tid; a < A; a += 1024) {
+        float c = 0.f;
+        for (int l = 0; l < L; ++l) c += (e[l] / s) * P->V[(size_t)l * A + a];
+        P->ctx[a] = c;
+    }
+    (void)inv;
+}
+
+// 1x1 conv (2M rows) + inverse affine + gate + frame bookkeeping, one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void dec_out_k(const DecodeDev* __restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [2M] conv outputs, [16] reduction
+    int i;
+    if (!frame_live(P, i)) return;
+    const int M = P->M, H = P->H, A = P->A;
+    float* o = sm;
+    float* red = sm + 2 * M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int par = i & 1;
+    for (int n = wave; n < 2 * M; n += 16) {
+        const float s = wave_sum(dot_seg(P->conv_w + (size_t)n * H, P->u2, H, lane));
+        if (lane == 0) o[n] = s + P->conv_b[n];
+    }
+    float g = 0.f;
+    if (P->gate_w) {
+        const float* hn = P->h_att + (par ^ 1) * H;
+        for (int k = tid; k < H; k += 1024) g += P->gate_w[k] * hn[k];
+        for (int k = tid; k < A; k += 1024) g += P->gate_w[H + k] * P->ctx[k];
+        g = wave_sum(g);
+        if (lane == 0) red[wave] = g;
+    }
+    __syncthreads();
+    for (int c = tid; c < M; c += 1024) {
+        const float x = (P->residual[(size_t)i * M + c] - o[M + c]) / expf(o[c]);
+        P->mel_out[(size_t)i * M + c] = x;
+        P->prev[c] = x;
+    }
+    if (tid == 0) {
+        int done = 0;
+        if (P->gate_w) {
+            float gs = P->gate_b[0];
+#pragma unroll
+            for (int w = 0; w < 16; ++w) gs += red[w];
+            const float sg = 1.f / (1.f + expf(-gs));
+            if (sg > P->gate_threshold) done = 1;
+        }
+        P->ctl[0] = i + 1;
+        P->n_done_dev[0] = i + 1;
+        if (done) P->ctl[1] = 1;
+    }
+}
+
+struct Layout {
+    size_t off_dev, off_state, n_state, off_ctl, total;
+    size_t h_att, c_att, h0, c0, h1, c1, q, ctx, u1, u2, prev;
+};
+
+Layout make_layout(int H, int A, int M) {
+    Layout l{};
+    auto up = [](size_t v) { return (v + 63) & ~size_t(63); };
+    l.off_dev = 0;
+    l.off_state = up(sizeof(DecodeDev));
+    size_t f = 0;
+    auto take = [&](size_t n) { size_t o = f; f += (n + 15) & ~size_t(15); return o; };
+    l.h_att = take(2 * H); l.c_att = take(H); l.h0 = take(2 * H); l.c0 = take(H); l.h1 = take(2 * H); l.c1 = take(H);
+    l.q = take(A); l.ctx = take(A); l.u1 = take(H); l.u2 = take(H); l.prev = take(M);
+    l.n_state = f;
+    l.off_ctl = l.off_state + f * sizeof(float);
+    l.total = l.off_ctl + 64;
+    return l;
+}
+
+constexpr int GRAPH_FRAMES = 8;
+std::mutex g_graph_mu;
+std::unordered_map<uint64_t, hipGraphExec_t> g_graph_cache;
+
+int enqueue_frame(const DecodeDev* dP, int H, int A, int L, int M, hipStream_t st) {
+    const dim3 b256(256), b1024(1024);
+    hipLaunchKernelGGL(dec_lstm_k<0>, dim3(cdiv(H, 4)), b256, 0, st, dP);
+    hipLaunchKernelGGL(dec_gemv_k<0>, dim3(cdiv(A, 4)), b256, 0, st, dP);
+    hipLaunchKernelGGL(dec_attn_k, dim3(1), b1024, sizeof(float) * (L + 32 + A), st, dP);
+    hipLaunchKernelGGL(dec_lstm_k<1>, dim3(cdiv(H, 4)), b256, 0, st, dP);
+    hipLaunchKernelGGL(dec_lstm_k<2>, dim3(cdiv(H, 4)), b256, 0, st, dP);
+    hipLaunchKernelGGL(dec_gemv_k<1>, dim3(cdiv(H, 4)), b256, 0, st, dP);
+    hipLaunchKernelGGL(dec_gemv_k<2>, dim3(cdiv(H, 4)), b256, 0, st, dP);
+    hipLaunchKernelGGL(dec_out_k, dim3(1), b1024, sizeof(float) * (2 * M + 32), st, dP);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t ft_decode_workspace_bytes(int L, int H, int A, int M) {
+    (void)L;
+    return make_layout(H, A, M).total;
+}
+
+extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
+    FT_CHECK_ARG(a != nullptr);
+    FT_CHECK_ARG(a->att_w_ih && a->att_w_hh && a->att_b_ih && a->att_b_hh && a->w_query && a->v && a->K && a->V);
+    FT_CHECK_ARG(a->l0_w_ih && a->l0_w_hh && a->l0_b_ih && a->l0_b_hh && a->l1_w_ih && a->l1_w_hh && a->l1_b_ih && a->l1_b_hh);
+    FT_CHECK_ARG(a->d0_w && a->d0_b && a->d1_w && a->d1_b && a->conv_w && a->conv_b);
+    FT_CHECK_ARG((a->gate_w == nullptr) == (a->gate_b == nullptr));
+    FT_CHECK_ARG(a->residual && a->mel_out && a->attn_out && a->n_done_dev && a->work);
+    FT_CHECK_ARG(a->N >= 0 && a->L >= 1 && a->H >= 1 && a->A >= 1 && a->M >= 1 && a->temperature > 0.f);
+    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(a->work) % 64 == 0);
+    const Layout lay = make_layout(a->H, a->A, a->M);
+    FT_CHECK_ARG(a->work_bytes >= lay.total);
+    if (sizeof(float) * ((size_t)a->L + 32 + a->A) > 160 * 1024)
+        return ft_fail(FT_EUNSUPPORTED, "ft_decode_flow: L=%d A=%d exceed the LDS score tile", a->L, a->A);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* base = reinterpret_cast<char*>(a->work);
+    float* fs = reinterpret_cast<float*>(base + lay.off_state);
+
+    DecodeDev h{};
+    h.att_w_ih = a->att_w_ih; h.att_w_hh = a->att_w_hh; h.att_b_ih = a->att_b_ih; h.att_b_hh = a->att_b_hh;
+    h.w_query = a->w_query; h.v = a->v; h.K = a->K; h.V = a->V;
+    h.l0_w_ih = a->l0_w_ih; h.l0_w_hh = a->l0_w_hh; h.l0_b_ih = a->l0_b_ih; h.l0_b_hh = a->l0_b_hh;
+    h.l1_w_ih = a->l1_w_ih; h.l1_w_hh = a->l1_w_hh; h.l1_b_ih = a->l1_b_ih; h.l1_b_hh = a->l1_b_hh;
+    h.d0_w = a->d0_w; h.d0_b = a->d0_b; h.d1_w = a->d1_w; h.d1_b = a->d1_b; h.conv_w = a->conv_w; h.conv_b = a->conv_b;
+    h.gate_w = a->gate_w; h.gate_b = a->gate_b;
+    h.residual = a->residual; h.mel_out = a->mel_out; h.attn_out = a->attn_out; h.n_done_dev = a->n_done_dev;
+    h.h_att = fs + lay.h_att; h.c_att = fs + lay.c_att; h.h0 = fs + lay.h0; h.c0 = fs + lay.c0; h.h1 = fs + lay.h1; h.c1 = fs + lay.c1;
+    h.q = fs + lay.q; h.ctx = fs + lay.ctx; h.u1 = fs + lay.u1; h.u2 = fs + lay.u2; h.prev = fs + lay.prev;
+    h.ctl = reinterpret_cast<int*>(base + lay.off_ctl);
+    h.N = a->N; h.L = a->L; h.H = a->H; h.A = a->A; h.M = a->M;
+    h.inv_temp = 1.0f / a->temperature; h.gate_threshold = a->gate_threshold;
+
+    // state (h, c, prev, frame counter, stop flag) = 0; parameter block = h.  hipMemcpyAsync from
+    // pageable host memory stages the bytes before returning, so `h` may live on this stack frame.
+    FT_CHECK_HIP(hipMemsetAsync(base + lay.off_state, 0, lay.total - lay.off_state, st));
+    FT_CHECK_HIP(hipMemsetAsync(a->n_done_dev, 0, sizeof(int), st));
+    FT_CHECK_HIP(hipMemcpyAsync(base + lay.off_dev, &h, sizeof(DecodeDev), hipMemcpyHostToDevice, st));
+    const DecodeDev* dP = reinterpret_cast<const DecodeDev*>(base + lay.off_dev);
+    FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+
+    if (!a->use_graph) {
+        for (int i = 0; i < a->N; ++i) enqueue_frame(dP, a->H, a->A, a->L, a->M, st);
+        FT_CHECK_LAUNCH();
+        return FT_OK;
+    }
+    // hipGraph path: GRAPH_FRAMES frames per graph; kernels past frame N or past the stop flag are no-ops.
+    const uint64_t key = (reinterpret_cast<uint64_t>(dP) * 1000003ull) ^ ((uint64_t)a->H << 40) ^ ((uint64_t)a->A << 28) ^
+                         ((uint64_t)a->L << 12) ^ (uint64_t)a->M;
+    hipGraphExec_t exec = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_graph_mu);
+        auto it = g_graph_cache.find(key);
+        if (it != g_graph_cache.end()) exec = it->second;
+        if (!exec) {
+            hipStream_t cs;
+            FT_CHECK_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                for (int f = 0; f < GRAPH_FRAMES; ++f) enqueue_frame(dP, a->H, a->A, a->L, a->M, cs);
+                e = hipStreamEndCapture(cs, &graph);
+            }
+            if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            if (graph) hipGraphDestroy(graph);
+            hipStreamDestroy(cs);
+            if (e != hipSuccess) return ft_fail(FT_EHIP, "ft_decode_flow: graph capture failed: %s", hipGetErrorString(e));
+            g_graph_cache[key] = exec;
+        }
+    }
+    for (int i = 0; i < a->N; i += GRAPH_FRAMES) FT_CHECK_HIP(hipGraphLaunch(exec, st));
+    return FT_OK;
+}

@@ -1,0 +1,410 @@
+// HBM-bound elementwise / gather / reduction kernels of the Flowtron hot path (gfx950).
+// Every kernel is a grid-stride or one-row-per-wave streaming pass: coalesced along the
+// channel dimension, fp32, no LDS beyond block reductions.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+
+inline int grid_for(int64_t n, int per_block = NT, int cap = 256 * 16) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// ---------------- embedding ----------------
+__global__ void embedding_fwd_k(const int64_t* __restrict__ ids, const float* __restrict__ W, float* __restrict__ out,
+                                int n, int dim, long ld) {
+    const long total = (long)n * dim;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / dim;
+        const int c = (int)(i - r * dim);
+        out[r * ld + c] = W[ids[r] * (long)dim + c];
+    }
+}
+__global__ void embedding_bwd_k(const int64_t* __restrict__ ids, const float* __restrict__ dout, float* __restrict__ dW,
+                                int n, int dim, long ld) {
+    const long total = (long)n * dim;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / dim;
+        const int c = (int)(i - r * dim);
+        atomicAdd(dW + ids[r] * (long)dim + c, dout[r * ld + c]);
+    }
+}
+
+// ---------------- im2col / col2im (encoder conv, time-major) ----------------
+// col[(l*B+b)][c*KW+k] = x[l+k-KW/2][b][c] if 0 <= l+k-KW/2 < lens[b] else 0
+__global__ void im2col_k(const float* __restrict__ x, float* __restrict__ col, const int* __restrict__ lens,
+                         int L, int B, int C, int KW) {
+    const long CK = (long)C * KW;
+    const long total = (long)L * B * CK;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / CK;
+        const int j = (int)(i - row * CK);
+        const int c = j / KW, k = j - c * KW;
+        const int l = (int)(row / B), b = (int)(row - (long)l * B);
+        const int ls = l + k - KW / 2;
+        float v = 0.f;
+        if (ls >= 0 && ls < lens[b]) v = x[((long)ls * B + b) * C + c];
+        col[i] = v;
+    }
+}
+// dx[l][b][c] = sum_k dcol[(l-k+KW/2)*B+b][c*KW+k]  for rows inside [0,L); 0 at l >= lens[b]
+__global__ void col2im_k(const float* __restrict__ dcol, float* __restrict__ dx, const int* __restrict__ lens,
+                         int L, int B, int C, int KW) {
+    const long total = (long)L * B * C;
+    const long CK = (long)C * KW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / C;
+        const int c = (int)(i - row * C);
+        const int l = (int)(row / B), b = (int)(row - (long)l * B);
+        float v = 0.f;
+        if (l < lens[b]) {
+            for (int k = 0; k < KW; ++k) {
+                const int lo = l - k + KW / 2;
+                if (lo >= 0 && lo < L) v += dcol[((long)lo * B + b) * CK + (long)c * KW + k];
+            }
+        }
+        dx[i] = v;
+    }
+}
+
+// ---------------- reverse by length ----------------
+__global__ void reverse_k(const float* __restrict__ x, float* __restrict__ y, const int* __restrict__ lens,
+                          int T, int B, int C, int time_major) {
+    const long total = (long)T * B * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / C;
+        const int c = (int)(i - row * C);
+        int t, b;
+        if (time_major) { t = (int)(row / B); b = (int)(row - (long)t * B); }
+        else { b = (int)(row / T); t = (int)(row - (long)b * T); }
+        const int len = lens[b];
+        const int src = (t < len) ? (len - 1 - t) : (T - 1 + len - t);
+        const long srow = time_major ? ((long)src * B + b) : ((long)b * T + src);
+        y[i] = x[srow * C + c];
+    }
+}
+
+// ---------------- affine coupling ----------------
+__global__ void affine_fwd_k(const float* __restrict__ out, const float* __restrict__ x, float* __restrict__ z,
+                             long n_rows, int M) {
+    const long total = n_rows * M;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / M;
+        const int c = (int)(i - r * M);
+        const float ls = out[r * 2 * M + c], bb = out[r * 2 * M + M + c];
+        z[i] = expf(ls) * x[i] + bb;
+    }
+}
+__global__ void affine_bwd_k(const float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ dz,
+                             const float* __restrict__ dls_ext, float* __restrict__ dout, float* __restrict__ dx,
+                             long n_rows, int M) {
+    const long total = n_rows * M;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / M;
+        const int c = (int)(i - r * M);
+        const float s = expf(out[r * 2 * M + c]);
+        const float g = dz[i];
+        float dls = g * x[i] * s;
+        if (dls_ext) dls += dls_ext[i];
+        dout[r * 2 * M + c] = dls;
+        dout[r * 2 * M + M + c] = g;
+        if (dx) dx[i] = g * s;
+    }
+}
+__global__ void affine_inv_k(const float* __restrict__ out, const float* __restrict__ z, float* __restrict__ x,
+                             long n_rows, int M) {
+    const long total = n_rows * M;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / M;
+        const int c = (int)(i - r * M);
+        x[i] = (z[i] - out[r * 2 * M + M + c]) / expf(out[r * 2 * M + c]);
+    }
+}
+
+// ---------------- masked sums (NLL) ----------------
+__global__ void masked_sum_k(const float* __restrict__ x, long ld, const int* __restrict__ lens, float* __restrict__ acc,
+                             int square, int T, int B, int M) {
+    __shared__ float red[NT / 64];
+    const long total = (long)T * B * M;
+    float s = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / M;
+        const int c = (int)(i - row * M);
+        const int t = (int)(row / B), b = (int)(row - (long)t * B);
+        if (t < lens[b]) {
+            const float v = x[row * ld + c];
+            s += square ? v * v : v;
+        }
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+__global__ void masked_sum_bwd_k(const float* __restrict__ x, long ld, const int* __restrict__ lens,
+                                 const float* __restrict__ scale_dev, float coef, int square,
+                                 float* __restrict__ dx, long ld_dx, int T, int B, int M) {
+    const long total = (long)T * B * M;
+    const float sc = scale_dev[0] * coef;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / M;
+        const int c = (int)(i - row * M);
+        const int t = (int)(row / B), b = (int)(row - (long)t * B);
+        float v = 0.f;
+        if (t < lens[b]) v = square ? sc * x[row * ld + c] : sc;
+        dx[row * ld_dx + c] = v;
+    }
+}
+
+// ---------------- gate BCE with logits ----------------
+// loss(g,y) = max(g,0) - g*y + log1p(exp(-|g|))
+__global__ void gate_bce_fwd_k(const float* __restrict__ gate, const float* __restrict__ target, const int* __restrict__ lens,
+                               float* __restrict__ acc, int T, int B) {
+    __shared__ float red[NT / 64];
+    const long total = (long)T * B;
+    float s = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i / B), b = (int)(i - (long)t * B);
+        if (t < lens[b]) {
+            const float g = gate[i], y = target[(long)b * T + t];
+            s += fmaxf(g, 0.f) - g * y + log1pf(expf(-fabsf(g)));
+        }
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+__global__ void gate_bce_bwd_k(const float* __restrict__ gate, const float* __restrict__ target, const int* __restrict__ lens,
+                               const float* __restrict__ scale_dev, float coef, float* __restrict__ dgate, int T, int B) {
+    const long total = (long)T * B;
+    const float sc = scale_dev[0] * coef;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i / B), b = (int)(i - (long)t * B);
+        float v = 0.f;
+        if (t < lens[b]) {
+            const float g = gate[i], y = target[(long)b * T + t];
+            v = sc * (1.f / (1.f + expf(-g)) - y);
+        }
+        dgate[i] = v;
+    }
+}
+
+// ---------------- column sums ----------------
+// grid.x = column blocks of 64, grid.y = row slabs; 256 threads = 4 row-lanes x 64 columns.
+__global__ void colsum_k(const float* __restrict__ x, float* __restrict__ out, long rows, int N, long ld, long rows_per_slab) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const long r0 = (long)blockIdx.y * rows_per_slab;
+    long r1 = r0 + rows_per_slab;
+    if (r1 > rows) r1 = rows;
+    float s = 0.f;
+    if (col < N)
+        for (long r = r0 + rl; r < r1; r += 4) s += x[r * ld + col];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && col < N) atomicAdd(out + col, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+// dpre = dy * act'(pre) expressed through the saved OUTPUT y = act(pre)
+__global__ void act_bwd_k(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dpre, long n, int act) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float yy = y[i], g = dy[i];
+        float d;
+        if (act == FT_ACT_TANH) d = g * (1.f - yy * yy);
+        else if (act == FT_ACT_RELU) d = yy > 0.f ? g : 0.f;
+        else if (act == FT_ACT_SIGMOID) d = g * yy * (1.f - yy);
+        else d = g;
+        dpre[i] = d;
+    }
+}
+
+__global__ void zero_k(float* __restrict__ p, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+// ---------------- optimizer (flat arena) ----------------
+__global__ void sumsq_k(const float* __restrict__ x, float* __restrict__ acc, long n) {
+    __shared__ float red[NT / 64];
+    float s = 0.f;
+    const long n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = x4[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        s += x[i] * x[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+
+// radam.py:44-122 restated per element (fp32 state):
+//   g' = g * min(1, clip / (||g|| + 1e-6))            (torch.nn.utils.clip_grad_norm_, train.py:328)
+//   v = b2 v + (1-b2) g'^2 ; m = b1 m + (1-b1) g'
+//   p -= wd*lr*p (if wd != 0) ; N_sma >= 5: p -= step_size * m/(sqrt(v)+eps) ; else p -= step_size*m
+//   (step_size is the host-computed radam.py:95-105 value and already contains lr)
+__global__ void radam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                        long n, const float* __restrict__ gnorm_sq, float clip, float lr, float b1, float b2, float eps,
+                        float wd, float step_size, int rectified) {
+    float cs = 1.f;
+    if (gnorm_sq && clip > 0.f) {
+        const float nrm = sqrtf(gnorm_sq[0]);
+        cs = fminf(1.f, clip / (nrm + 1e-6f));
+    }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * cs;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        float pi = p[i];
+        if (wd != 0.f) pi += -wd * lr * pi;
+        if (rectified) pi += -step_size * (mi / (sqrtf(vi) + eps));
+        else pi += -step_size * mi;
+        v[i] = vi; m[i] = mi; p[i] = pi;
+    }
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int ft_embedding_fwd(const int64_t* ids, const float* W, float* out, int n, int dim, int64_t ld_out, void* stream) {
+    FT_CHECK_ARG(ids && W && out && n >= 0 && dim > 0 && ld_out >= dim);
+    if (n == 0) return FT_OK;
+    hipLaunchKernelGGL(embedding_fwd_k, dim3(grid_for((int64_t)n * dim)), dim3(NT), 0, ST(stream), ids, W, out, n, dim, (long)ld_out);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_embedding_bwd(const int64_t* ids, const float* dout, float* dW, int n, int dim, int64_t ld_dout, void* stream) {
+    FT_CHECK_ARG(ids && dout && dW && n >= 0 && dim > 0 && ld_dout >= dim);
+    if (n == 0) return FT_OK;
+    hipLaunchKernelGGL(embedding_bwd_k, dim3(grid_for((int64_t)n * dim)), dim3(NT), 0, ST(stream), ids, dout, dW, n, dim, (long)ld_dout);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_im2col(const float* x, float* col, const int32_t* lens, int L, int B, int C, int KW, void* stream) {
+    FT_CHECK_ARG(x && col && lens && L >= 0 && B >= 1 && C >= 1 && KW >= 1 && (KW & 1));
+    if (L == 0) return FT_OK;
+    hipLaunchKernelGGL(im2col_k, dim3(grid_for((int64_t)L * B * C * KW)), dim3(NT), 0, ST(stream), x, col, lens, L, B, C, KW);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_col2im(const float* dcol, float* dx, const int32_t* lens, int L, int B, int C, int KW, void* stream) {
+    FT_CHECK_ARG(dcol && dx && lens && L >= 0 && B >= 1 && C >= 1 && KW >= 1 && (KW & 1));
+    if (L == 0) return FT_OK;
+    hipLaunchKernelGGL(col2im_k, dim3(grid_for((int64_t)L * B * C)), dim3(NT), 0, ST(stream), dcol, dx, lens, L, B, C, KW);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_reverse_by_length(const float* x, float* y, const int32_t* lens, int T, int B, int C, int time_major, void* stream) {
+    FT_CHECK_ARG(x && y && lens && x != y && T >= 0 && B >= 1 && C >= 1);
+    if (T == 0) return FT_OK;
+    hipLaunchKernelGGL(reverse_k, dim3(grid_for((int64_t)T * B * C)), dim3(NT), 0, ST(stream), x, y, lens, T, B, C, time_major);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_affine_fwd(const float* out, const float* x, float* z, int64_t n_rows, int M, void* stream) {
+    FT_CHECK_ARG(out && x && z && n_rows >= 0 && M >= 1);
+    if (n_rows == 0) return FT_OK;
+    hipLaunchKernelGGL(affine_fwd_k, dim3(grid_for(n_rows * M)), dim3(NT), 0, ST(stream), out, x, z, (long)n_rows, M);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_affine_bwd(const float* out, const float* x, const float* dz, const float* dlog_s_ext,
+                             float* dout, float* dx, int64_t n_rows, int M, void* stream) {
+    FT_CHECK_ARG(out && x && dz && dout && n_rows >= 0 && M >= 1);
+    if (n_rows == 0) return FT_OK;
+    hipLaunchKernelGGL(affine_bwd_k, dim3(grid_for(n_rows * M)), dim3(NT), 0, ST(stream), out, x, dz, dlog_s_ext, dout, dx, (long)n_rows, M);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_affine_inv(const float* out, const float* z, float* x, int64_t n_rows, int M, void* stream) {
+    FT_CHECK_ARG(out && z && x && n_rows >= 0 && M >= 1);
+    if (n_rows == 0) return FT_OK;
+    hipLaunchKernelGGL(affine_inv_k, dim3(grid_for(n_rows * M)), dim3(NT), 0, ST(stream), out, z, x, (long)n_rows, M);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_masked_sum(const float* x, int64_t ld, const int32_t* lens, float* acc, int square,
+                             int T, int B, int M, void* stream) {
+    FT_CHECK_ARG(x && lens && acc && ld >= M && T >= 0 && B >= 1 && M >= 1);
+    if (T == 0) return FT_OK;
+    hipLaunchKernelGGL(masked_sum_k, dim3(grid_for((int64_t)T * B * M, NT, 1024)), dim3(NT), 0, ST(stream), x, (long)ld, lens, acc, square, T, B, M);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_masked_sum_bwd(const float* x, int64_t ld, const int32_t* lens, const float* scale_dev, float coef, int square,
+                                 float* dx, int64_t ld_dx, int T, int B, int M, void* stream) {
+    FT_CHECK_ARG(lens && scale_dev && dx && (x || !square) && ld_dx >= M && T >= 0 && B >= 1 && M >= 1);
+    if (T == 0) return FT_OK;
+    hipLaunchKernelGGL(masked_sum_bwd_k, dim3(grid_for((int64_t)T * B * M)), dim3(NT), 0, ST(stream), x, (long)ld, lens, scale_dev, coef, square, dx, (long)ld_dx, T, B, M);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_gate_bce_fwd(const float* gate, const float* target, const int32_t* lens, float* acc, int T, int B, void* stream) {
+    FT_CHECK_ARG(gate && target && lens && acc && T >= 0 && B >= 1);
+    if (T == 0) return FT_OK;
+    hipLaunchKernelGGL(gate_bce_fwd_k, dim3(grid_for((int64_t)T * B, NT, 256)), dim3(NT), 0, ST(stream), gate, target, lens, acc, T, B);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_gate_bce_bwd(const float* gate, const float* target, const int32_t* lens, const float* scale_dev, float coef,
+                               float* dgate, int T, int B, void* stream) {
+    FT_CHECK_ARG(gate && target && lens && scale_dev && dgate && T >= 0 && B >= 1);
+    if (T == 0) return FT_OK;
+    hipLaunchKernelGGL(gate_bce_bwd_k, dim3(grid_for((int64_t)T * B)), dim3(NT), 0, ST(stream), gate, target, lens, scale_dev, coef, dgate, T, B);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_colsum(const float* x, float* out, int64_t rows, int N, int64_t ld, void* stream) {
+    FT_CHECK_ARG(x && out && rows >= 0 && N >= 1 && ld >= N);
+    hipLaunchKernelGGL(zero_k, dim3(grid_for(N)), dim3(NT), 0, ST(stream), out, (long)N);
+    if (rows > 0) {
+        const int cb = cdiv(N, 64);
+        int slabs = 2048 / cb;
+        if (slabs < 1) slabs = 1;
+        if (slabs > cdiv(rows, 32)) slabs = cdiv(rows, 32);
+        const long rps = (rows + slabs - 1) / slabs;
+        hipLaunchKernelGGL(colsum_k, dim3(cb, cdiv(rows, rps)), dim3(NT), 0, ST(stream), x, out, (long)rows, N, (long)ld, rps);
+    }
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_act_bwd(const float* y, const float* dy, float* dpre, int64_t n, int act, void* stream) {
+    FT_CHECK_ARG(y && dy && dpre && n >= 0 && act >= FT_ACT_NONE && act <= FT_ACT_SIGMOID);
+    if (n == 0) return FT_OK;
+    hipLaunchKernelGGL(act_bwd_k, dim3(grid_for(n)), dim3(NT), 0, ST(stream), y, dy, dpre, (long)n, act);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_sumsq(const float* x, float* acc, int64_t n, void* stream) {
+    FT_CHECK_ARG(x && acc && n >= 0);
+    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(x) % 16 == 0);
+    if (n == 0) return FT_OK;
+    hipLaunchKernelGGL(sumsq_k, dim3(grid_for(n / 4 + 1, NT, 2048)), dim3(NT), 0, ST(stream), x, acc, (long)n);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_radam_step(float* p, const float* g, float* m, float* v, int64_t n,
+                             const float* gnorm_sq_dev, float clip, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, float step_size, int rectified, void* stream) {
+    FT_CHECK_ARG(p && g && m && v && n >= 0);
+    if (n == 0) return FT_OK;
+    hipLaunchKernelGGL(radam_k, dim3(grid_for(n, NT, 4096)), dim3(NT), 0, ST(stream), p, g, m, v, (long)n, gnorm_sq_dev, clip, lr,
+                       beta1, beta2, eps, weight_decay, step_size, rectified);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}

@@ -1,0 +1,449 @@
+"""torch.autograd.Function wrappers around the C ABI (include/flowtron_hip.h).
+
+Each Function's forward AND backward enqueue hand-written HIP kernels on torch's
+current stream through ctypes; torch supplies device memory and the autograd
+graph only.  Nothing here computes on the CPU and nothing falls back to torch
+ops for the math: a missing library or a CPU tensor raises.
+
+Layouts (reference flowtron.py internal layout after :884): activations are
+time-major [T,B,C] fp32 contiguous; lengths are int32 device tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+# --------------------------------------------------------------------------
+# raw launchers
+# --------------------------------------------------------------------------
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def gemm_raw(A, B, Cm, M, N, K, sAm, sAk, sBk, sBn, ldc, bias=None, act=L.ACT_NONE, alpha=1.0, beta=0.0,
+             batch=1, bsA=0, bsB=0, bsC=0, mode=None):
+    """C = act(alpha*A.B + beta*C + bias); A,B,Cm are tensors whose data_ptr is the operand origin."""
+    L.require_cuda(A, B, Cm, bias)
+    a = L.GemmArgs(L.ptr(A), L.ptr(B), L.ptr(Cm), L.ptr(bias), M, N, K, batch,
+                   sAm, sAk, sBk, sBn, ldc, bsA, bsB, bsC, alpha, beta, act,
+                   L.mfma_mode() if mode is None else mode)
+    L.check(L.lib().ft_gemm(C.byref(a), L.stream()), "ft_gemm")
+
+
+def colsum(x2d: torch.Tensor, rows: int, N: int, ld: int) -> torch.Tensor:
+    out = torch.empty(N, device=x2d.device, dtype=torch.float32)
+    L.check(L.lib().ft_colsum(L.ptr(x2d), L.ptr(out), rows, N, ld, L.stream()), "ft_colsum")
+    return out
+
+
+def lens32(lens: torch.Tensor) -> torch.Tensor:
+    return lens.to(dtype=torch.int32).contiguous()
+
+
+# --------------------------------------------------------------------------
+# Linear over one or two row-blocks of the weight:  y = act(sum_i x_i W[:, off_i:off_i+K_i]^T + b)
+# (nn.Linear / 1x1 Conv1d / LSTM input projection call sites, flowtron.py:568-571, :758, :767-768)
+# --------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W, bias, act, mode, *xs):
+        xs = [_c(x) for x in xs]
+        L.require_cuda(W, *xs)
+        W = _c(W)
+        N, Ktot = W.shape
+        rows = xs[0].numel() // xs[0].shape[-1]
+        y = torch.empty(xs[0].shape[:-1] + (N,), device=W.device, dtype=torch.float32)
+        off = 0
+        for i, x in enumerate(xs):
+            K = x.shape[-1]
+            last = i == len(xs) - 1
+            gemm_raw(x, W[:, off:], y, rows, N, K, K, 1, 1, Ktot, N,
+                     bias=bias if last else None, act=act if last else L.ACT_NONE,
+                     beta=0.0 if i == 0 else 1.0, mode=mode)
+            off += K
+        assert off == Ktot
+        ctx.save_for_backward(W, y if act != L.ACT_NONE else None, *xs)
+        ctx.act, ctx.mode, ctx.has_bias = act, mode, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        W, y, *xs = ctx.saved_tensors
+        dy = _c(dy)
+        N, Ktot = W.shape
+        rows = dy.numel() // N
+        if ctx.act != L.ACT_NONE:
+            dpre = torch.empty_like(dy)
+            L.check(L.lib().ft_act_bwd(L.ptr(y), L.ptr(dy), L.ptr(dpre), dy.numel(), ctx.act, L.stream()), "ft_act_bwd")
+        else:
+            dpre = dy
+        dW = torch.empty_like(W) if ctx.needs_input_grad[0] else None
+        db = colsum(dpre, rows, N, N) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        dxs = []
+        off = 0
+        for i, x in enumerate(xs):
+            K = x.shape[-1]
+            if ctx.needs_input_grad[4 + i]:
+                dx = torch.empty_like(x)
+                # dx[r,k] = sum_n dpre[r,n] W[n, off+k]
+                gemm_raw(dpre, W[:, off:], dx, rows, K, N, N, 1, Ktot, 1, K, mode=ctx.mode)
+                dxs.append(dx)
+            else:
+                dxs.append(None)
+            if dW is not None:
+                # dW[n, off+k] = sum_r dpre[r,n] x[r,k]
+                gemm_raw(dpre, x, dW[:, off:], N, K, rows, 1, N, K, 1, Ktot, mode=ctx.mode)
+            off += K
+        return (dW, db, None, None, *dxs)
+
+
+def linear(xs, W, bias=None, act=L.ACT_NONE, mode=None):
+    if isinstance(xs, torch.Tensor):
+        xs = [xs]
+    return LinearFn.apply(W, bias, act, L.mfma_mode() if mode is None else mode, *xs)
+
+
+# --------------------------------------------------------------------------
+# embedding gather (flowtron.py:873-874)
+# --------------------------------------------------------------------------
+class EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, W):
+        L.require_cuda(ids, W)
+        ids = _c(ids.reshape(-1).to(torch.int64))
+        W = _c(W)
+        out = torch.empty(ids.numel(), W.shape[1], device=W.device, dtype=torch.float32)
+        L.check(L.lib().ft_embedding_fwd(L.ptr(ids), L.ptr(W), L.ptr(out), ids.numel(), W.shape[1], W.shape[1], L.stream()),
+                "ft_embedding_fwd")
+        ctx.save_for_backward(ids)
+        ctx.wshape = W.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        dout = _c(dout)
+        dW = torch.zeros(ctx.wshape, device=dout.device, dtype=torch.float32)
+        L.check(L.lib().ft_embedding_bwd(L.ptr(ids), L.ptr(dout), L.ptr(dW), ids.numel(), ctx.wshape[1], ctx.wshape[1], L.stream()),
+                "ft_embedding_bwd")
+        return None, dW
+
+
+def embedding(ids, W):
+    return EmbeddingFn.apply(ids, W)
+
+
+# --------------------------------------------------------------------------
+# encoder conv as im2col + GEMM, masked instance norm + relu (+dropout mask)
+# --------------------------------------------------------------------------
+class Im2colFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lens, KW):
+        x = _c(x)
+        L.require_cuda(x, lens)
+        Lx, B, Cc = x.shape
+        col = torch.empty(Lx, B, Cc * KW, device=x.device, dtype=torch.float32)
+        L.check(L.lib().ft_im2col(L.ptr(x), L.ptr(col), L.ptr(lens), Lx, B, Cc, KW, L.stream()), "ft_im2col")
+        ctx.save_for_backward(lens)
+        ctx.dims = (Lx, B, Cc, KW)
+        return col
+
+    @staticmethod
+    def backward(ctx, dcol):
+        (lens,) = ctx.saved_tensors
+        Lx, B, Cc, KW = ctx.dims
+        dcol = _c(dcol)
+        dx = torch.empty(Lx, B, Cc, device=dcol.device, dtype=torch.float32)
+        L.check(L.lib().ft_col2im(L.ptr(dcol), L.ptr(dx), L.ptr(lens), Lx, B, Cc, KW, L.stream()), "ft_col2im")
+        return dx, None, None
+
+
+class InstNormReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, keep, lens, eps):
+        x, gamma, beta = _c(x), _c(gamma), _c(beta)
+        L.require_cuda(x, gamma, beta, keep, lens)
+        if keep is not None:
+            keep = _c(keep)
+        Lx, B, Cc = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(B, Cc, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        L.check(L.lib().ft_instnorm_relu_fwd(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(keep), L.ptr(lens), L.ptr(y),
+                                             L.ptr(mean), L.ptr(rstd), Lx, B, Cc, eps, L.stream()), "ft_instnorm_relu_fwd")
+        ctx.save_for_backward(x, y, gamma, keep, lens, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, keep, lens, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        Lx, B, Cc = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.empty_like(gamma)
+        db = torch.empty_like(gamma)
+        L.check(L.lib().ft_instnorm_relu_bwd(L.ptr(x), L.ptr(y), L.ptr(dy), L.ptr(gamma), L.ptr(keep), L.ptr(lens),
+                                             L.ptr(mean), L.ptr(rstd), L.ptr(dx), L.ptr(dg), L.ptr(db), Lx, B, Cc, L.stream()),
+                "ft_instnorm_relu_bwd")
+        return dx, dg, db, None, None, None
+
+
+def conv_norm_relu(x, lens, conv_w, conv_b, gamma, beta, keep=None, eps=1e-5, mode=None):
+    """x [L,B,C] -> relu(masked_instance_norm(conv1d_k5(x))) * keep  (flowtron.py:499-502)."""
+    Cout, Cin, KW = conv_w.shape
+    col = Im2colFn.apply(x, lens, KW)
+    y = linear(col, conv_w.reshape(Cout, Cin * KW), conv_b, mode=mode)
+    return InstNormReluFn.apply(y, gamma, beta, keep, lens, eps)
+
+
+# --------------------------------------------------------------------------
+# length-masked LSTM sequence (packed nn.LSTM semantics, flowtron.py:689-694, :505-512)
+# --------------------------------------------------------------------------
+class LSTMSeqFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gx, w_hh, lens, reverse, mode):
+        gx, w_hh = _c(gx), _c(w_hh)
+        L.require_cuda(gx, w_hh, lens)
+        T, B, H4 = gx.shape
+        H = H4 // 4
+        y = torch.empty(T, B, H, device=gx.device, dtype=torch.float32)
+        gates = torch.empty(T, B, H4, device=gx.device, dtype=torch.float32)
+        cell = torch.empty(T, B, H, device=gx.device, dtype=torch.float32)
+        work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=gx.device, dtype=torch.uint8)
+        L.check(L.lib().ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w_hh), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
+                                        L.ptr(work), T, B, H, int(reverse), mode, L.stream()), "ft_lstm_seq_fwd")
+        ctx.save_for_backward(w_hh, lens, y, gates, cell)
+        ctx.reverse, ctx.mode = bool(reverse), mode
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        w_hh, lens, y, gates, cell = ctx.saved_tensors
+        dy = _c(dy)
+        T, B, H = y.shape
+        dgx = torch.empty(T, B, 4 * H, device=dy.device, dtype=torch.float32)
+        work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=dy.device, dtype=torch.uint8)
+        L.check(L.lib().ft_lstm_seq_bwd(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
+                                        L.ptr(work), T, B, H, int(ctx.reverse), ctx.mode, L.stream()), "ft_lstm_seq_bwd")
+        dW = None
+        if ctx.needs_input_grad[1]:
+            dW = torch.zeros_like(w_hh)
+            if T > 1:
+                rows = (T - 1) * B
+                # dW_hh[r,j] = sum_{t,b} da_t[b,r] * h_prev(t)[b,j];  h_prev = y[t-1] (fwd) / y[t+1] (reverse)
+                da = dgx[1:] if not ctx.reverse else dgx[:-1]
+                hp = y[:-1] if not ctx.reverse else y[1:]
+                gemm_raw(da, hp, dW, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=ctx.mode)
+        return dgx, dW, None, None, None
+
+
+def lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=False, mode=None, xs_extra=None):
+    """One LSTM layer over a padded sequence: input projection for all T*B rows as one MFMA GEMM,
+    then the sequential recurrence."""
+    mode = L.mfma_mode() if mode is None else mode
+    xs = [x] if xs_extra is None else [x] + list(xs_extra)
+    gx = LinearFn.apply(w_ih, b_ih + b_hh, L.ACT_NONE, mode, *xs)
+    return LSTMSeqFn.apply(gx, w_hh, lens, reverse, mode)
+
+
+# --------------------------------------------------------------------------
+# attention (flowtron.py:544-592)
+# --------------------------------------------------------------------------
+class AttentionScoresFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Q, K, v, in_lens, prior, temperature):
+        Q, K, v = _c(Q), _c(K), _c(v.reshape(-1))
+        L.require_cuda(Q, K, v, in_lens, prior)
+        T, B, A = Q.shape
+        Lk = K.shape[0]
+        attn = torch.empty(B, T, Lk, device=Q.device, dtype=torch.float32)
+        logprob = torch.empty_like(attn)
+        p_save = None
+        if prior is not None:
+            prior = _c(prior.float())
+            p_save = torch.empty_like(attn)
+        L.check(L.lib().ft_attention_fwd(L.ptr(Q), L.ptr(K), L.ptr(v), L.ptr(in_lens), L.ptr(prior), L.ptr(attn), L.ptr(logprob),
+                                         L.ptr(p_save), T, B, Lk, A, float(temperature), L.stream()), "ft_attention_fwd")
+        ctx.save_for_backward(Q, K, v, in_lens, prior, attn, p_save)
+        ctx.temperature = float(temperature)
+        ctx.mark_non_differentiable()
+        return attn, logprob
+
+    @staticmethod
+    def backward(ctx, dattn, dlogprob):
+        Q, K, v, in_lens, prior, attn, p_save = ctx.saved_tensors
+        T, B, A = Q.shape
+        Lk = K.shape[0]
+        if dattn is None:
+            dattn = torch.zeros_like(attn)
+        dattn = _c(dattn)
+        if dlogprob is not None:
+            dlogprob = _c(dlogprob)
+        de = torch.empty_like(attn)
+        dQ = torch.empty_like(Q)
+        dK = torch.empty_like(K)
+        dv = torch.zeros_like(v)
+        L.check(L.lib().ft_attention_bwd(L.ptr(Q), L.ptr(K), L.ptr(v), L.ptr(in_lens), L.ptr(prior), L.ptr(attn), L.ptr(p_save),
+                                         L.ptr(dattn), L.ptr(dlogprob), L.ptr(de), L.ptr(dQ), L.ptr(dK), L.ptr(dv),
+                                         T, B, Lk, A, ctx.temperature, L.stream()), "ft_attention_bwd")
+        return dQ, dK, dv.reshape(1, -1), None, None, None
+
+
+class ContextFn(torch.autograd.Function):
+    """ctx[t,b,:] = sum_l attn[b,t,l] V[l,b,:]  (torch.bmm at flowtron.py:590-591) as one batched MFMA GEMM."""
+
+    @staticmethod
+    def forward(ctx, attn, V, mode):
+        attn, V = _c(attn), _c(V)
+        L.require_cuda(attn, V)
+        B, T, Lk = attn.shape
+        A = V.shape[2]
+        out = torch.empty(T, B, A, device=V.device, dtype=torch.float32)
+        gemm_raw(attn, V, out, T, A, Lk, Lk, 1, B * A, 1, B * A, batch=B, bsA=T * Lk, bsB=A, bsC=A, mode=mode)
+        ctx.save_for_backward(attn, V)
+        ctx.mode = mode
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        attn, V = ctx.saved_tensors
+        dctx = _c(dctx)
+        B, T, Lk = attn.shape
+        A = V.shape[2]
+        dattn = torch.empty_like(attn)
+        # dattn[b,t,l] = sum_a dctx[t,b,a] V[l,b,a]
+        gemm_raw(dctx, V, dattn, T, Lk, A, B * A, 1, 1, B * A, Lk, batch=B, bsA=A, bsB=A, bsC=T * Lk, mode=ctx.mode)
+        dV = torch.empty_like(V)
+        # dV[l,b,a] = sum_t attn[b,t,l] dctx[t,b,a]
+        gemm_raw(attn, dctx, dV, Lk, A, T, 1, Lk, B * A, 1, B * A, batch=B, bsA=T * Lk, bsB=A, bsC=A, mode=ctx.mode)
+        return dattn, dV, None
+
+
+# --------------------------------------------------------------------------
+# affine coupling, reverse-by-length
+# --------------------------------------------------------------------------
+class AffineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, x):
+        out, x = _c(out), _c(x)
+        L.require_cuda(out, x)
+        M = x.shape[-1]
+        rows = x.numel() // M
+        z = torch.empty_like(x)
+        L.check(L.lib().ft_affine_fwd(L.ptr(out), L.ptr(x), L.ptr(z), rows, M, L.stream()), "ft_affine_fwd")
+        ctx.save_for_backward(out, x)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        out, x = ctx.saved_tensors
+        dz = _c(dz)
+        M = x.shape[-1]
+        rows = x.numel() // M
+        dout = torch.empty_like(out)
+        dx = torch.empty_like(x)
+        L.check(L.lib().ft_affine_bwd(L.ptr(out), L.ptr(x), L.ptr(dz), None, L.ptr(dout), L.ptr(dx), rows, M, L.stream()),
+                "ft_affine_bwd")
+        return dout, dx
+
+
+class ReverseByLengthFn(torch.autograd.Function):
+    """flip + per-sample roll (flowtron.py:606-613) in closed form; an involution, so backward is the same gather."""
+
+    @staticmethod
+    def forward(ctx, x, lens, time_major):
+        x = _c(x)
+        L.require_cuda(x, lens)
+        if time_major:
+            T, B, Cc = x.shape
+        else:
+            B, T, Cc = x.shape
+        y = torch.empty_like(x)
+        L.check(L.lib().ft_reverse_by_length(L.ptr(x), L.ptr(y), L.ptr(lens), T, B, Cc, int(time_major), L.stream()),
+                "ft_reverse_by_length")
+        ctx.save_for_backward(lens)
+        ctx.time_major = time_major
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (lens,) = ctx.saved_tensors
+        return ReverseByLengthFn.apply(_c(dy), lens, ctx.time_major), None, None
+
+
+def reverse_by_length(x, lens, time_major=True):
+    return ReverseByLengthFn.apply(x, lens, time_major)
+
+
+# --------------------------------------------------------------------------
+# losses (flowtron.py:200-243)
+# --------------------------------------------------------------------------
+class NLLFn(torch.autograd.Function):
+    """[sum m z^2/(2 sigma^2) - sum_f sum m log_s_f] / (n_valid_frames * n_mel).
+    log_s tensors are strided views [T,B,M] of the coupling output [T,B,2M] (row stride 2M)."""
+
+    @staticmethod
+    def forward(ctx, z, lens, sigma, *log_s):
+        z = _c(z)
+        L.require_cuda(z, lens)
+        T, B, M = z.shape
+        acc = torch.zeros(2, device=z.device, dtype=torch.float32)
+        st = L.stream()
+        L.check(L.lib().ft_masked_sum(L.ptr(z), M, L.ptr(lens), L.ptr(acc), 1, T, B, M, st), "ft_masked_sum")
+        lds = []
+        for ls in log_s:
+            assert ls.shape == z.shape and ls.stride(2) == 1 and ls.stride(1) * B == ls.stride(0)
+            lds.append(ls.stride(1))
+            L.check(L.lib().ft_masked_sum(L.ptr(ls), ls.stride(1), L.ptr(lens), L.ptr(acc[1:]), 0, T, B, M, st), "ft_masked_sum")
+        n = lens.sum().to(torch.float32) * M
+        nll = (acc[0] / (2.0 * sigma * sigma) - acc[1]) / n
+        ctx.save_for_backward(z, lens, n)
+        ctx.sigma, ctx.n_ls = sigma, len(log_s)
+        return nll
+
+    @staticmethod
+    def backward(ctx, g):
+        z, lens, n = ctx.saved_tensors
+        T, B, M = z.shape
+        scale = (g.reshape(1).to(torch.float32) / n).contiguous()
+        st = L.stream()
+        dz = torch.empty_like(z)
+        L.check(L.lib().ft_masked_sum_bwd(L.ptr(z), M, L.ptr(lens), L.ptr(scale), 1.0 / (ctx.sigma * ctx.sigma), 1,
+                                          L.ptr(dz), M, T, B, M, st), "ft_masked_sum_bwd")
+        dls = None
+        if ctx.n_ls:
+            dls = torch.empty_like(z)
+            L.check(L.lib().ft_masked_sum_bwd(None, M, L.ptr(lens), L.ptr(scale), -1.0, 0, L.ptr(dls), M, T, B, M, st),
+                    "ft_masked_sum_bwd")
+        return (dz, None, None) + (dls,) * ctx.n_ls
+
+
+class GateBCEFn(torch.autograd.Function):
+    """sum_valid BCEWithLogits(gate, target) / n_valid_frames (flowtron.py:237-243). gate [T,B,1], target [B,T]."""
+
+    @staticmethod
+    def forward(ctx, gate, target, lens):
+        gate, target = _c(gate), _c(target.float())
+        L.require_cuda(gate, target, lens)
+        T, B = gate.shape[0], gate.shape[1]
+        acc = torch.zeros(1, device=gate.device, dtype=torch.float32)
+        L.check(L.lib().ft_gate_bce_fwd(L.ptr(gate), L.ptr(target), L.ptr(lens), L.ptr(acc), T, B, L.stream()), "ft_gate_bce_fwd")
+        n = lens.sum().to(torch.float32)
+        ctx.save_for_backward(gate, target, lens, n)
+        return (acc / n).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        gate, target, lens, n = ctx.saved_tensors
+        T, B = gate.shape[0], gate.shape[1]
+        scale = (g.reshape(1).to(torch.float32) / n).contiguous()
+        dgate = torch.empty_like(gate)
+        L.check(L.lib().ft_gate_bce_bwd(L.ptr(gate), L.ptr(target), L.ptr(lens), L.ptr(scale), 1.0, L.ptr(dgate), T, B, L.stream()),
+                "ft_gate_bce_bwd")
+        return dgate, None, None

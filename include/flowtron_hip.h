@@ -142,6 +142,10 @@ int ft_gate_bce_bwd(const float* gate, const float* target, const int32_t* lens,
  * y[t] = x[len-1-t] (t < len), x[T-1+len-t] (t >= len). */
 int ft_reverse_by_length(const float* x, float* y, const int32_t* lens, int T, int B, int C, int time_major, void* stream);
 
+/* ---- activation backward (autograd of torch.tanh after nn.Linear, flowtron.py:461-464):
+ * dpre = dy * act'(pre), written through the saved output y = act(pre).  dpre may alias dy. */
+int ft_act_bwd(const float* y, const float* dy, float* dpre, int64_t n, int act, void* stream);
+
 /* ---- column sums (bias gradients): out[n] = sum_r x[r*ld + n] -------------- */
 int ft_colsum(const float* x, float* out, int64_t rows, int N, int64_t ld, void* stream);
 

