@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""Benchmark of the Flowtron hot path on MI355X (contract: see the task description / DESIGN.md).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One step = zero_grad + Flowtron.forward + FlowtronLoss (NLL + gate + attention-CTC) + backward (with the single
+flat-arena RCCL all-reduce when N > 1) + global-norm clip + fused RAdam update, on BASELINE.json configs[1]:
+2-flow LJS config.json model, 80-bin mels, per-GPU batch 32 of LJSpeech-shaped synthetic utterances (<= 10 s),
+attention prior + CTC on, bf16 MFMA operands with fp32 accumulate/storage.  Weak scaling: every rank processes its
+own 32 utterances.  value = valid mel frames (sum of out_lens over all ranks and steps) / wall time.
+
+Rank 0 prints ONE JSON line.  It also carries `roofline` (the recurrent LSTM step kernel, live HIP-event timing),
+`cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample) and `infer_rtf`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MODEL_CONFIG = {   # reference config.json:49-66 (LJS defaults)
+    "n_speakers": 1, "n_speaker_dim": 128, "n_text": 185, "n_text_dim": 512, "n_flows": 2, "n_mel_channels": 80,
+    "n_attn_channels": 640, "n_hidden": 1024, "n_lstm_layers": 2, "mel_encoder_n_hidden": 512, "n_components": 0,
+    "mean_scale": 0.0, "fixed_gaussian": True, "dummy_speaker_embedding": False, "use_gate_layer": True,
+    "use_cumm_attention": False,
+}
+HOP, SR = 256, 22050
+
+
+def synth_batch(B, seed, t_max=862, l_max=187, n_text=185):
+    """LJSpeech-shaped synthetic batch: out_lens ~ clip(N(566,190),100,862), text length ~
+    frames/5.5, sorted by text length (data.py:200-202), log-mel-range values, beta-binomial attention prior."""
+    rs = np.random.RandomState(seed)
+    out = np.clip(np.round(rs.normal(566, 190, B)), 100, t_max).astype(int)
+    out[0] = t_max
+    inn = np.clip(np.round(out / 5.5), 12, l_max).astype(int)
+    order = np.argsort(-inn, kind="stable")
+    out, inn = out[order], inn[order]
+    T, L = int(out.max()), int(inn.max())
+    mel = np.zeros((B, 80, T), np.float32)
+    text = np.zeros((B, L), np.int64)
+    gate = np.zeros((B, T), np.float32)
+    for b in range(B):
+        t, l = int(out[b]), int(inn[b])
+        base = -5.0 + 2.0 * np.sin(np.linspace(0, 6.0, 80))[:, None]
+        walk = np.cumsum(0.15 * rs.standard_normal((1, t)), axis=1)
+        mel[b, :, :t] = np.clip(base + walk + 1.2 * rs.standard_normal((80, t)), -11.5, 1.0)
+        text[b, :l] = rs.randint(0, n_text, size=l)
+        gate[b, t - 1:] = 1.0
+    return dict(mel=torch.from_numpy(mel), text=torch.from_numpy(text), gate=torch.from_numpy(gate),
+                speaker_ids=torch.zeros(B, dtype=torch.long), in_lens=torch.from_numpy(inn.astype(np.int64)),
+                out_lens=torch.from_numpy(out.astype(np.int64)))
+
+
+def beta_binomial_prior_batch(in_lens, out_lens, T, L):
+    """data.py:31-41 closed form (lgamma), float64 on CPU once -- data-pipeline work, outside the timed region."""
+    pr = torch.zeros(len(in_lens), T, L)
+    lg = torch.lgamma
+    for b, (P, M) in enumerate(zip(in_lens.tolist(), out_lens.tolist())):
+        k = torch.arange(P, dtype=torch.float64)[None, :]
+        i = torch.arange(1, M + 1, dtype=torch.float64)[:, None]
+        a, bb = i, (M + 1 - i)
+        n = float(P - 1)
+        logp = (lg(torch.tensor(n + 1, dtype=torch.float64)) - lg(k + 1) - lg(n - k + 1) + lg(k + a) + lg(n - k + bb)
+                - lg(n + a + bb) - (lg(a) + lg(bb) - lg(a + bb)))
+        pr[b, :M, :P] = torch.exp(logp).float()
+    return pr
+
+
+def init_weights(model, seed):
+    """random-init weights of the named architecture; the coupling conv is zero-initialised by the reference
+    (flowtron.py:651-653), which would make log_s == 0 -- give it small random values so the NLL is non-trivial."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("conv.weight") and "convolutions" not in name:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.01)
+            elif name.endswith("conv.bias") and "convolutions" not in name:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+
+
+def lstm_step_roofline(B, H, T, mode):
+    """Live timing of the dominant kernel (lstm_fwd_step, flowtron_amd/csrc/lstm.hip): T launches bracketed by HIP
+    events on the launch stream.  Algorithmic bytes per launch = W_hh (4H*H) + h_prev (B*H) + gate pre-activations in
+    (B*4H) + y, h, c, cell out (4*B*H) + saved gates (B*4H), all fp32 (kernel table)."""
+    from flowtron_amd import _lib as L
+    dev = "cuda"
+    gx = torch.randn(T, B, 4 * H, device=dev) * 0.1
+    w = torch.randn(4 * H, H, device=dev) / H ** 0.5
+    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+    y = torch.empty(T, B, H, device=dev)
+    gates = torch.empty(T, B, 4 * H, device=dev)
+    cell = torch.empty(T, B, H, device=dev)
+    work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=dev, dtype=torch.uint8)
+
+    def run():
+        L.check(L.lib().ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(work),
+                                        T, B, H, 0, mode, L.stream()), "ft_lstm_seq_fwd")
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / T
+    bytes_per_launch = 4 * (4 * H * H + B * H + B * 4 * H + 4 * B * H + B * 4 * H)
+    achieved = bytes_per_launch / (us * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": "lstm_fwd_step", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 4), "traffic": None, "us_per_launch": round(us, 3),
+            "bytes_per_launch": bytes_per_launch}
+
+
+def cpu_baseline(model, batch, prior):
+    """The CPU oracle (oracle/flowtron_oracle.py = restatement of the reference, pinned to golden vectors made
+    with the real reference) on a BOUNDED sample: the 2 shortest utterances of this rank's batch, full
+    forward + loss + backward, fp32, all host cores."""
+    from oracle import flowtron_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    idx = torch.argsort(batch["out_lens"])[:2]
+    idx = idx[torch.argsort(batch["in_lens"][idx], descending=True)]
+    out_lens, in_lens = batch["out_lens"][idx], batch["in_lens"][idx]
+    T, Lk = int(out_lens.max()), int(in_lens.max())
+    mel, text = batch["mel"][idx][:, :, :T], batch["text"][idx][:, :Lk]
+    pr, gate = prior[idx][:, :T, :Lk], batch["gate"][idx][:, :T]
+    O.LSTM_IMPL["fn"] = O.lstm_seq_fast
+    try:
+        best = None
+        for it in range(2):
+            for v in sd.values():
+                v.grad = None
+            t0 = time.perf_counter()
+            out = O.forward(sd, MODEL_CONFIG, mel, batch["speaker_ids"][idx], text, in_lens, out_lens, pr)
+            nll, gl, ctc = O.loss(out, gate, in_lens, out_lens, 1.0, True, True, -8)
+            (nll + gl + 0.01 * ctc).sum().backward()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+    finally:
+        O.LSTM_IMPL["fn"] = O.lstm_cell_seq
+    frames = int(out_lens.sum())
+    return {"value": round(frames / best, 2), "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "sample": "2 shortest utterances of the batch (%d valid frames, T=%d, L=%d), fwd+loss+bwd, fp32, best of 2, %.2f s"
+                      % (frames, T, Lk, best)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
+    ap.add_argument("--mfma", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-infer", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X: the product path has no CPU fallback"
+    os.environ["FLOWTRON_MFMA"] = args.mfma
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "6000")
+    torch.cuda.set_device(local_rank)
+
+    import flowtron
+    from flowtron_amd import _lib as L
+    from flowtron_amd import dist as ftdist
+    from flowtron_amd.optim import RAdam
+    import torch.distributed as dist
+    L.lib()                                                   # fail loudly if the HIP library is missing
+    if world > 1:
+        ftdist.init_distributed(rank, world, "nccl", None)
+
+    torch.manual_seed(1234)
+    model = flowtron.Flowtron(**MODEL_CONFIG)
+    init_weights(model, 1234)
+    model = model.cuda().train()
+    criterion = flowtron.FlowtronLoss(sigma=1.0, gm_loss=False, gate_loss=True, use_ctc_loss=True, ctc_loss_weight=0.01,
+                                      blank_logprob=-8)
+    optimizer = RAdam(model.parameters(), lr=1e-3, weight_decay=1e-6)
+    if world > 1:
+        model = ftdist.apply_gradient_allreduce(model)
+
+    batch_cpu = synth_batch(args.batch, 1234 + 7 + rank)
+    T, Lk = batch_cpu["mel"].shape[2], batch_cpu["text"].shape[1]
+    prior_cpu = beta_binomial_prior_batch(batch_cpu["in_lens"], batch_cpu["out_lens"], T, Lk)
+    b = {k: v.cuda() for k, v in batch_cpu.items()}
+    prior = prior_cpu.cuda()
+    frames_rank = int(batch_cpu["out_lens"].sum())
+
+    def step():
+        optimizer.zero_grad()
+        out = model(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], prior)
+        nll, gl, ctc = criterion(out, b["gate"], b["in_lens"], b["out_lens"])
+        loss = nll + gl + criterion.ctc_loss_weight * ctc
+        loss.backward()
+        optimizer.clip_grad_norm_(1.0)
+        optimizer.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    loss_val = float(loss.item())
+    stats = torch.tensor([dt, float(frames_rank)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        fsum = stats[1:].clone()
+        dist.all_reduce(fsum, op=dist.ReduceOp.SUM)
+        dt, frames_all = float(tmax.item()), float(fsum.item())
+    else:
+        frames_all = float(frames_rank)
+
+    if rank == 0:
+        res = {
+            "metric": "mel-frames/sec training (2-flow, 80-mel)", "value": round(frames_all * args.steps / dt, 1),
+            "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.mfma == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 2-flow LJS config.json model, per-GPU batch %d, T_max=%d, L_max=%d, "
+                                   "attn-prior + CTC on, fwd+loss+bwd+clip+RAdam%s" % (args.batch, T, Lk, ", 1 flat RCCL all-reduce/step" if world > 1 else ""),
+                       "global_batch": args.batch * world, "valid_frames_per_step": int(frames_all),
+                       "padded_frames_per_step": args.batch * T * world, "parallelism": "dp%d" % world,
+                       "mfma_operands": args.mfma, "storage": "fp32", "final_loss": round(loss_val, 5)},
+        }
+        mode = L.FT_BF16 if args.mfma == "bf16" else L.FT_F32
+        try:
+            res["roofline"] = lstm_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, mode)
+        except Exception as e:                      # never lose the headline number to the side measurement
+            res["roofline"] = {"error": repr(e)}
+        if world == 1 and not args.no_infer:
+            try:
+                model.eval()
+                n_frames = 400
+                z = torch.randn(1, 80, n_frames, device="cuda") * 0.5
+                text = b["text"][:1, :69]
+                spk = b["speaker_ids"][:1]
+                model.infer(z, spk, text, gate_threshold=1.0)           # warm-up (+ hipGraph capture)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                mel, _ = model.infer(z, spk, text, gate_threshold=1.0)
+                torch.cuda.synchronize()
+                ti = time.perf_counter() - t1
+                res["infer"] = {"frames": int(mel.shape[2]), "seconds": round(ti, 5), "frames_per_s": round(mel.shape[2] / ti, 1),
+                                "rtf": round(ti / (mel.shape[2] * HOP / SR), 5), "config": "2-flow LJS, B=1, L=69, sigma=0.5, fp32 weights, gate disabled"}
+            except Exception as e:
+                res["infer"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(model, batch_cpu, prior_cpu)
+            except Exception as e:
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+"""Host-side mirror of the reference audio front end (audio_processing.py:96-134, 172-235):
+TacotronSTFT.mel_spectrogram as ONE HIP kernel (ft_stft_mel: reflect pad + windowed radix-2 FFT
+in LDS + |X| + mel filterbank + log-compression) instead of a 1026x1024 dense-DFT conv1d.
+
+The mel filterbank constants come from librosa in the reference (third-party dependency that is
+not vendored: requirements.txt:4 pins 0.6.3, Dockerfile:6 pins 0.8.0; call site
+audio_processing.py:104-105 -> htk=False, Slaney area normalisation).  librosa is not installed
+here, so `slaney_mel_filterbank` restates the published formula; if librosa IS importable it is
+used, exactly like the reference.  PARITY UNPINNED for these constants (no reference test holds them).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    with np.errstate(divide="ignore"):
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, f / f_sp)
+
+
+def _mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def slaney_mel_filterbank(sr, n_fft, n_mels, fmin=0.0, fmax=None) -> np.ndarray:
+    """[n_mels, n_fft//2+1] float32 triangular filters, Slaney mel scale, area-normalised."""
+    if fmax is None:
+        fmax = sr / 2.0
+    try:                                         # the reference's own source of these constants, when present
+        from librosa.filters import mel as librosa_mel_fn
+        return np.asarray(librosa_mel_fn(sr=sr, n_fft=n_fft, n_mels=n_mels, fmin=fmin, fmax=fmax), dtype=np.float32)
+    except Exception:
+        pass
+    fftfreqs = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    lower = -ramps[:-2] / fdiff[:-1, None]
+    upper = ramps[2:] / fdiff[1:, None]
+    w = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
+    return (w * enorm[:, None]).astype(np.float32)
+
+
+def hann_window(win_length: int, filter_length: int) -> np.ndarray:
+    """scipy.signal.get_window('hann', win_length, fftbins=True) zero-centre-padded to filter_length
+    (audio_processing.py:193-197)."""
+    n = np.arange(win_length, dtype=np.float64)
+    w = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)
+    lpad = (filter_length - win_length) // 2
+    out = np.zeros(filter_length, dtype=np.float64)
+    out[lpad:lpad + win_length] = w
+    return out.astype(np.float32)
+
+
+def dynamic_range_compression(x, C=1, clip_val=1e-5):
+    return torch.log(torch.clamp(x, min=clip_val) * C)
+
+
+def dynamic_range_decompression(x, C=1):
+    return torch.exp(x) / C
+
+
+class STFT(torch.nn.Module):
+    """Holds the analysis parameters (audio_processing.py:172-205); `transform` (magnitude only --
+    the phase output is unused on the mel path) is reached through TacotronSTFT."""
+
+    def __init__(self, filter_length=800, hop_length=200, win_length=800, window="hann"):
+        super().__init__()
+        assert window == "hann" and filter_length >= win_length
+        self.filter_length, self.hop_length, self.win_length, self.window = filter_length, hop_length, win_length, window
+        self.register_buffer("fft_window", torch.from_numpy(hann_window(win_length, filter_length)))
+
+
+class TacotronSTFT(torch.nn.Module):
+    def __init__(self, filter_length=1024, hop_length=256, win_length=1024, n_mel_channels=80, sampling_rate=22050,
+                 mel_fmin=0.0, mel_fmax=None):
+        super().__init__()
+        self.n_mel_channels = n_mel_channels
+        self.sampling_rate = sampling_rate
+        self.stft_fn = STFT(filter_length, hop_length, win_length)
+        mel_basis = torch.from_numpy(slaney_mel_filterbank(sampling_rate, filter_length, n_mel_channels, mel_fmin, mel_fmax))
+        self.register_buffer("mel_basis", mel_basis.float())
+
+    def spectral_normalize(self, magnitudes):
+        return dynamic_range_compression(magnitudes)
+
+    def spectral_de_normalize(self, magnitudes):
+        return dynamic_range_decompression(magnitudes)
+
+    def mel_spectrogram(self, y):
+        """y [B,N] float32 in [-1,1] (device tensor) -> [B, n_mel_channels, N // hop + 1]."""
+        L.require_cuda(y)
+        assert y.dim() == 2
+        # the reference asserts the value range with two host syncs (audio_processing.py:127-128); checked on
+        # device only when FLOWTRON_CHECK_AUDIO_RANGE is set, to keep the front end sync-free
+        import os
+        if os.environ.get("FLOWTRON_CHECK_AUDIO_RANGE"):
+            assert float(y.min()) >= -1 and float(y.max()) <= 1
+        y = y.contiguous().float()
+        if self.mel_basis.device != y.device:
+            self.to(y.device)
+        B, N = y.shape
+        st = self.stft_fn
+        n_frames = N // st.hop_length + 1
+        mel = torch.empty(B, self.n_mel_channels, n_frames, device=y.device, dtype=torch.float32)
+        L.check(L.lib().ft_stft_mel(L.ptr(y), L.ptr(st.fft_window), L.ptr(self.mel_basis), L.ptr(mel), B, N,
+                                    st.filter_length, st.hop_length, self.n_mel_channels, L.stream()), "ft_stft_mel")
+        return mel

@@ -1,0 +1,401 @@
+"""Host-side mirror of the reference model interface (flowtron.py): same class names, ctor
+arguments, submodule attribute names (hence identical state_dict keys) and
+forward/infer signatures -- every tensor op underneath is a HIP kernel reached through the
+C ABI (flowtron_amd.ops).  torch.nn modules are used only as PARAMETER CONTAINERS (so that
+checkpoints keep their layout); their torch forward() is never called.
+
+Reference lines are cited per class.  There is no CPU path: calling forward/infer with
+CPU tensors raises (the CPU oracle is oracle/flowtron_oracle.py, test infrastructure).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import ops
+
+# train.py-format checkpoints pickle the whole nn.Module; torch >= 2.6 refuses them under the
+# default weights_only=True, which would break the reference's unmodified train.py resume path
+# (train.py:87,112).  Same remedy the reference environment would need.
+os.environ.setdefault("TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD", "1")
+
+
+# --------------------------------------------------------------------------
+# thin wrappers (names are baked into state_dict keys) -- flowtron.py:278-309, 95-126, 453-464
+# --------------------------------------------------------------------------
+class LinearNorm(nn.Module):
+    def __init__(self, in_dim, out_dim, bias=True, w_init_gain="linear"):
+        super().__init__()
+        self.linear_layer = nn.Linear(in_dim, out_dim, bias=bias)
+        nn.init.xavier_uniform_(self.linear_layer.weight, gain=nn.init.calculate_gain(w_init_gain))
+
+    def forward(self, x, act=L.ACT_NONE):
+        return ops.linear(x, self.linear_layer.weight, self.linear_layer.bias, act)
+
+
+class ConvNorm(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=None, dilation=1,
+                 bias=True, w_init_gain="linear"):
+        super().__init__()
+        if padding is None:
+            assert kernel_size % 2 == 1
+            padding = int(dilation * (kernel_size - 1) / 2)
+        assert stride == 1 and dilation == 1, "the hot path only uses stride-1, undilated convolutions"
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                              padding=padding, dilation=dilation, bias=bias)
+        nn.init.xavier_uniform_(self.conv.weight, gain=nn.init.calculate_gain(w_init_gain))
+
+
+class MaskedInstanceNorm1d(nn.Module):
+    """Parameter holder for the length-masked instance norm (flowtron.py:95-126):
+    affine, no running statistics -> state_dict has exactly `weight` and `bias`."""
+
+    def __init__(self, num_features, eps=1e-5, affine=True, **_):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+
+
+class DenseLayer(nn.Module):
+    def __init__(self, in_dim=1024, sizes=(1024, 1024)):
+        super().__init__()
+        sizes = list(sizes)
+        in_sizes = [in_dim] + sizes[:-1]
+        self.layers = nn.ModuleList([LinearNorm(i, o, bias=True) for i, o in zip(in_sizes, sizes)])
+
+    def forward(self, x):
+        for lin in self.layers:
+            x = lin(x, L.ACT_TANH)          # GEMM with bias + tanh fused in the epilogue
+        return x
+
+
+# --------------------------------------------------------------------------
+# Encoder -- flowtron.py:467-525
+# --------------------------------------------------------------------------
+class Encoder(nn.Module):
+    def __init__(self, encoder_n_convolutions=3, encoder_embedding_dim=512, encoder_kernel_size=5,
+                 norm_fn=MaskedInstanceNorm1d):
+        super().__init__()
+        convs = []
+        for _ in range(encoder_n_convolutions):
+            convs.append(nn.Sequential(
+                ConvNorm(encoder_embedding_dim, encoder_embedding_dim, kernel_size=encoder_kernel_size, stride=1,
+                         padding=int((encoder_kernel_size - 1) / 2), dilation=1, w_init_gain="relu"),
+                norm_fn(encoder_embedding_dim, affine=True)))
+        self.convolutions = nn.ModuleList(convs)
+        self.lstm = nn.LSTM(encoder_embedding_dim, int(encoder_embedding_dim / 2), 1, batch_first=True,
+                            bidirectional=True)
+        self.dropout_masks = None     # test hook: list of 3 keep-masks [L,B,C] already scaled by 1/(1-p)
+
+    def _run(self, x, lens):
+        """x [L,B,C] time-major, lens int32 [B] -> [L,B,C]."""
+        for i, (conv, norm) in enumerate(self.convolutions):
+            keep = None
+            if self.dropout_masks is not None:
+                keep = self.dropout_masks[i]
+            elif self.training:
+                keep = (torch.rand_like(x) >= 0.5).to(x.dtype) * 2.0      # F.dropout(p=0.5) keep-mask, flowtron.py:502
+            x = ops.conv_norm_relu(x, lens, conv.conv.weight, conv.conv.bias, norm.weight, norm.bias, keep, norm.eps)
+        p = self.lstm
+        yf = ops.lstm_layer(x, lens, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, reverse=False)
+        yb = ops.lstm_layer(x, lens, p.weight_ih_l0_reverse, p.weight_hh_l0_reverse, p.bias_ih_l0_reverse,
+                            p.bias_hh_l0_reverse, reverse=True)
+        return torch.cat([yf, yb], 2)
+
+    def forward(self, x, in_lens):
+        """x [B,C,L] (reference layout) -> [B,L,C]"""
+        xt = x.permute(2, 0, 1).contiguous()
+        return self._run(xt, ops.lens32(in_lens)).transpose(0, 1)
+
+    def infer(self, x):
+        xt = x.permute(2, 0, 1).contiguous()
+        lens = torch.full((xt.shape[1],), xt.shape[0], dtype=torch.int32, device=xt.device)
+        return self._run(xt, lens).transpose(0, 1)
+
+
+# --------------------------------------------------------------------------
+# Attention -- flowtron.py:528-592
+# --------------------------------------------------------------------------
+class Attention(nn.Module):
+    def __init__(self, n_mel_channels=80, n_speaker_dim=128, n_text_channels=512, n_att_channels=128, temperature=1.0):
+        super().__init__()
+        self.temperature = temperature
+        self.query = LinearNorm(n_mel_channels, n_att_channels, bias=False, w_init_gain="tanh")
+        self.key = LinearNorm(n_text_channels + n_speaker_dim, n_att_channels, bias=False, w_init_gain="tanh")
+        self.value = LinearNorm(n_text_channels + n_speaker_dim, n_att_channels, bias=False, w_init_gain="tanh")
+        self.v = LinearNorm(n_att_channels, 1, bias=False, w_init_gain="tanh")
+        self.score_mask_value = -float("inf")
+
+    def forward(self, queries, keys, values, in_lens32, attn_prior=None):
+        """queries [T,B,H], keys/values source [L,B,E] -> ctx [T,B,A], attn [B,T,L], attn_logprob [B,T,L]."""
+        mode = L.mfma_mode()
+        K = ops.linear(keys, self.key.linear_layer.weight, None, mode=mode)
+        V = ops.linear(values, self.value.linear_layer.weight, None, mode=mode)
+        Q = ops.linear(queries, self.query.linear_layer.weight, None, mode=mode)
+        attn, logprob = ops.AttentionScoresFn.apply(Q, K, self.v.linear_layer.weight, in_lens32, attn_prior,
+                                                    self.temperature)
+        ctx = ops.ContextFn.apply(attn, V, mode)
+        return ctx, attn, logprob
+
+
+# --------------------------------------------------------------------------
+# AR_Step / AR_Back_Step -- flowtron.py:645-828, 595-642
+# --------------------------------------------------------------------------
+class AR_Step(nn.Module):
+    def __init__(self, n_mel_channels, n_speaker_dim, n_text_channels, n_in_channels, n_hidden, n_attn_channels,
+                 n_lstm_layers, add_gate, use_cumm_attention):
+        super().__init__()
+        if use_cumm_attention:
+            raise NotImplementedError("use_cumm_attention=True (off in config.json:65) is not built yet")
+        if n_lstm_layers != 2:
+            raise NotImplementedError("the HIP decoder path is built for n_lstm_layers == 2 (config.json:58)")
+        self.use_cumm_attention = use_cumm_attention
+        self.conv = nn.Conv1d(n_hidden, 2 * n_mel_channels, 1)
+        self.conv.weight.data = 0.0 * self.conv.weight.data
+        self.conv.bias.data = 0.0 * self.conv.bias.data
+        self.lstm = nn.LSTM(n_hidden + n_attn_channels, n_hidden, n_lstm_layers)
+        self.attention_lstm = nn.LSTM(n_mel_channels, n_hidden)
+        self.attention_layer = Attention(n_hidden, n_speaker_dim, n_text_channels, n_attn_channels)
+        self.dense_layer = DenseLayer(in_dim=n_hidden, sizes=[n_hidden, n_hidden])
+        if add_gate:
+            self.gate_threshold = 0.5
+            self.gate_layer = LinearNorm(n_hidden + n_attn_channels, 1, bias=True, w_init_gain="sigmoid")
+        self._decode_work = None
+
+    def forward(self, mel, text, in_lens32, out_lens32, attn_prior=None):
+        """Teacher-forced flow. mel [T,B,M], text = encoder outputs [L,B,E].
+        Returns (z [T,B,M], log_s [T,B,M], gates [T,B,1] | None, attn [B,T,L], attn_logprob [B,T,L])."""
+        T, B, M = mel.shape
+        mode = L.mfma_mode()
+        mel0 = torch.cat([mel.new_zeros(1, B, M), mel[:-1]], 0)              # flowtron.py:726-729
+        a = self.attention_lstm
+        h_att = ops.lstm_layer(mel0, out_lens32, a.weight_ih_l0, a.weight_hh_l0, a.bias_ih_l0, a.bias_hh_l0, mode=mode)
+        ctx, attn, logprob = self.attention_layer(h_att, text, text, in_lens32, attn_prior)
+        gates = None
+        if hasattr(self, "gate_layer"):
+            g = self.gate_layer.linear_layer
+            gates = ops.linear([h_att, ctx], g.weight, g.bias, mode=mode)     # Linear over [h_att ; ctx], no concat
+        p = self.lstm
+        h = ops.lstm_layer(h_att, out_lens32, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, mode=mode,
+                           xs_extra=[ctx])
+        h = ops.lstm_layer(h, out_lens32, p.weight_ih_l1, p.weight_hh_l1, p.bias_ih_l1, p.bias_hh_l1, mode=mode)
+        h = self.dense_layer(h)
+        out = ops.linear(h, self.conv.weight.reshape(self.conv.weight.shape[0], -1), self.conv.bias, mode=mode)
+        z = ops.AffineFn.apply(out, mel)                                      # z = exp(log_s) * mel + b
+        log_s = out[..., :M]
+        return z, log_s, gates, attn, logprob
+
+    def infer(self, residual, text, attns=None, attn_prior=None, use_graph=None):
+        """Sequential inverse (flowtron.py:775-828), batch 1. residual [N,1,M], text [L,1,E].
+        Returns (mel [N',1,M], list of N' attention rows [1,1,L])."""
+        if attns is not None or attn_prior is not None:
+            raise NotImplementedError("forced alignments / attention prior at inference are not built yet")
+        N, B, M = residual.shape
+        if B != 1:
+            raise ValueError("Flowtron.infer is batch-1 (flowtron.py:901-930)")
+        L.require_cuda(residual, text)
+        Lk = text.shape[0]
+        att = self.attention_layer
+        K = ops.linear(text, att.key.linear_layer.weight, None).reshape(Lk, -1).contiguous()
+        V = ops.linear(text, att.value.linear_layer.weight, None).reshape(Lk, -1).contiguous()
+        H = self.lstm.weight_hh_l0.shape[1]
+        A = K.shape[1]
+        dev = residual.device
+        res = residual.reshape(N, M).contiguous().float()
+        mel_out = torch.empty(N, M, device=dev, dtype=torch.float32)
+        attn_out = torch.zeros(N, Lk, device=dev, dtype=torch.float32)
+        n_done = torch.zeros(1, device=dev, dtype=torch.int32)
+        nbytes = L.lib().ft_decode_workspace_bytes(Lk, H, A, M)
+        if self._decode_work is None or self._decode_work.numel() < nbytes or self._decode_work.device != dev:
+            self._decode_work = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        work = self._decode_work
+        has_gate = hasattr(self, "gate_layer")
+        if use_graph is None:
+            use_graph = os.environ.get("FLOWTRON_DECODE_GRAPH", "1") != "0"
+        a, p, d = self.attention_lstm, self.lstm, self.dense_layer.layers
+        keep = [K, V, res]                      # keep temporaries alive until the launch is enqueued
+        args = L.DecodeArgs(
+            L.ptr(a.weight_ih_l0), L.ptr(a.weight_hh_l0), L.ptr(a.bias_ih_l0), L.ptr(a.bias_hh_l0),
+            L.ptr(att.query.linear_layer.weight), L.ptr(att.v.linear_layer.weight), L.ptr(K), L.ptr(V),
+            L.ptr(p.weight_ih_l0), L.ptr(p.weight_hh_l0), L.ptr(p.bias_ih_l0), L.ptr(p.bias_hh_l0),
+            L.ptr(p.weight_ih_l1), L.ptr(p.weight_hh_l1), L.ptr(p.bias_ih_l1), L.ptr(p.bias_hh_l1),
+            L.ptr(d[0].linear_layer.weight), L.ptr(d[0].linear_layer.bias),
+            L.ptr(d[1].linear_layer.weight), L.ptr(d[1].linear_layer.bias),
+            L.ptr(self.conv.weight), L.ptr(self.conv.bias),
+            L.ptr(self.gate_layer.linear_layer.weight) if has_gate else None,
+            L.ptr(self.gate_layer.linear_layer.bias) if has_gate else None,
+            L.ptr(res), L.ptr(mel_out), L.ptr(attn_out), L.ptr(n_done), L.ptr(work),
+            work.numel(), N, Lk, H, A, M, float(att.temperature),
+            float(self.gate_threshold) if has_gate else 2.0, int(bool(use_graph)))
+        L.check(L.lib().ft_decode_flow(C.byref(args), L.stream()), "ft_decode_flow")
+        n = int(n_done.item()) if has_gate else N          # single host read per flow (the reference syncs every frame)
+        del keep
+        mel = mel_out[:n].reshape(n, 1, M)
+        attn_rows = [attn_out[i].reshape(1, 1, Lk) for i in range(n)]
+        return mel, attn_rows
+
+
+class AR_Back_Step(nn.Module):
+    def __init__(self, n_mel_channels, n_speaker_dim, n_text_dim, n_in_channels, n_hidden, n_attn_channels,
+                 n_lstm_layers, add_gate, use_cumm_attention):
+        super().__init__()
+        self.ar_step = AR_Step(n_mel_channels, n_speaker_dim, n_text_dim, n_mel_channels + n_speaker_dim, n_hidden,
+                               n_attn_channels, n_lstm_layers, add_gate, use_cumm_attention)
+
+    def forward(self, mel, text, in_lens32, out_lens32, attn_prior=None):
+        # flip + per-sample roll (flowtron.py:606-613) == the reverse-by-length involution, one gather kernel, no host syncs
+        mel = ops.reverse_by_length(mel, out_lens32, True)
+        if attn_prior is not None:
+            attn_prior = ops.reverse_by_length(attn_prior, out_lens32, False)
+        z, log_s, gates, attn, logprob = self.ar_step(mel, text, in_lens32, out_lens32, attn_prior)
+        z = ops.reverse_by_length(z, out_lens32, True)
+        return z, log_s, gates, attn, logprob
+
+    def infer(self, residual, text, attns=None, attn_prior=None):
+        out, attn = self.ar_step.infer(torch.flip(residual, (0,)), text, attns, attn_prior=attn_prior)
+        return torch.flip(out, (0,)), attn
+
+
+# --------------------------------------------------------------------------
+# Flowtron -- flowtron.py:831-961
+# --------------------------------------------------------------------------
+class Flowtron(nn.Module):
+    def __init__(self, n_speakers, n_speaker_dim, n_text, n_text_dim, n_flows, n_mel_channels, n_hidden,
+                 n_attn_channels, n_lstm_layers, use_gate_layer, mel_encoder_n_hidden, n_components,
+                 fixed_gaussian, mean_scale, dummy_speaker_embedding, use_cumm_attention):
+        super().__init__()
+        norm_fn = MaskedInstanceNorm1d
+        self.speaker_embedding = nn.Embedding(n_speakers, n_speaker_dim)
+        self.embedding = nn.Embedding(n_text, n_text_dim)
+        self.flows = nn.ModuleList()
+        self.encoder = Encoder(norm_fn=norm_fn, encoder_embedding_dim=n_text_dim)
+        self.dummy_speaker_embedding = dummy_speaker_embedding
+        if n_components > 1:
+            raise NotImplementedError("the Gaussian-mixture prior (n_components > 1) is outside the hot path "
+                                      "(config.json:60 uses 0); see DESIGN.md")
+        for i in range(n_flows):
+            add_gate = bool(i == (n_flows - 1) and use_gate_layer)
+            cls = AR_Step if i % 2 == 0 else AR_Back_Step
+            self.flows.append(cls(n_mel_channels, n_speaker_dim, n_text_dim, n_mel_channels + n_speaker_dim,
+                                  n_hidden, n_attn_channels, n_lstm_layers, add_gate, use_cumm_attention))
+
+    def _encode(self, speaker_ids, text, in_lens):
+        """embeddings + encoder + speaker concat -> [L,B,E] (flowtron.py:872-887)."""
+        L.require_cuda(speaker_ids, text, self.embedding.weight)
+        if self.dummy_speaker_embedding:
+            speaker_ids = speaker_ids * 0
+        B, Lt = text.shape
+        # speaker row broadcast over L by the gather kernel itself (ids repeated), so its backward is the
+        # same atomic scatter-add kernel (flowtron.py:886-887 expand + cat)
+        spk_ids = speaker_ids.reshape(1, -1).expand(Lt, -1).reshape(-1)
+        spk = ops.embedding(spk_ids, self.speaker_embedding.weight).reshape(Lt, B, -1)          # [L,B,S]
+        emb = ops.embedding(text.t().contiguous(), self.embedding.weight).reshape(Lt, B, -1)   # time-major [L,B,C]
+        if in_lens is None:
+            lens = torch.full((B,), Lt, dtype=torch.int32, device=text.device)
+        else:
+            lens = ops.lens32(in_lens)
+        enc = self.encoder._run(emb, lens)
+        return torch.cat([enc, spk], 2), lens
+
+    def forward(self, mel, speaker_ids, text, in_lens, out_lens, attn_prior=None):
+        """mel [B,M,T], speaker_ids [B], text [B,L] (sorted by in_lens desc), in_lens/out_lens [B],
+        attn_prior [B,T,L] | None -> the reference's 8-tuple (flowtron.py:898-899)."""
+        L.require_cuda(mel, text, in_lens, out_lens, attn_prior)
+        enc, in32 = self._encode(speaker_ids, text, in_lens)
+        out32 = ops.lens32(out_lens)
+        x = mel.permute(2, 0, 1).contiguous().float()
+        if attn_prior is not None:
+            attn_prior = attn_prior.float()
+        log_s_list, attns_list, attns_logprob_list = [], [], []
+        gate = None
+        for flow in self.flows:
+            x, log_s, gate, attn, logprob = flow(x, enc, in32, out32, attn_prior)
+            log_s_list.append(log_s)
+            attns_list.append(attn)
+            attns_logprob_list.append(logprob)
+        return x, log_s_list, gate, attns_list, attns_logprob_list, None, None, None
+
+    def infer(self, residual, speaker_ids, text, temperature=1.0, gate_threshold=0.5, attns=None, attn_prior=None):
+        """residual [1,M,N], speaker_ids [1] or [1,1], text [1,L] -> (mel [1,M,N'], attention_weights)."""
+        L.require_cuda(residual, text)
+        with torch.no_grad():
+            enc, _ = self._encode(speaker_ids, text, None)
+            x = residual.permute(2, 0, 1).contiguous().float()
+            attention_weights = []
+            for i, flow in enumerate(reversed(self.flows)):
+                self.set_temperature_and_gate(flow, temperature, gate_threshold)
+                x, aw = flow.infer(x, enc, None if attns is None else attns[len(self.flows) - 1 - i], attn_prior=attn_prior)
+                attention_weights.append(aw)
+            return x.permute(1, 2, 0), attention_weights
+
+    @staticmethod
+    def set_temperature_and_gate(flow, temperature, gate_threshold):
+        flow = flow.ar_step if hasattr(flow, "ar_step") else flow
+        flow.attention_layer.temperature = temperature
+        if hasattr(flow, "gate_layer"):
+            flow.gate_threshold = gate_threshold
+
+
+# --------------------------------------------------------------------------
+# Loss -- flowtron.py:155-275
+# --------------------------------------------------------------------------
+class AttentionCTCLoss(nn.Module):
+    """flowtron.py:155-182 batched: the reference loops over samples (slice, log_softmax, CTCLoss with target
+    1..K, reduction='mean' per sample).  Here the key axis is masked (to -1e4) beyond K_b before ONE log_softmax and ONE
+    ctc_loss call over the batch with per-sample lengths; per-sample losses are divided by K_b and averaged -- the
+    same value, without F*B host synchronisations.  (torch's CTC op kept for now.)"""
+
+    def __init__(self, blank_logprob=-1):
+        super().__init__()
+        self.blank_logprob = blank_logprob
+
+    def forward(self, attn_logprob, in_lens, out_lens):
+        """attn_logprob [B,T,L] in natural time order."""
+        B, T, Lk = attn_logprob.shape
+        x = torch.nn.functional.pad(attn_logprob, (1, 0), value=self.blank_logprob)       # [B,T,L+1], blank first
+        cls = torch.arange(Lk + 1, device=x.device)[None, None, :]
+        x = x.masked_fill(cls > in_lens[:, None, None], -1.0e4)   # exp() underflows to exactly 0: same softmax, finite grads
+        lp = torch.log_softmax(x, dim=2).transpose(0, 1)                                   # [T,B,L+1]
+        targets = torch.arange(1, Lk + 1, device=x.device)[None, :].expand(B, -1)
+        loss = torch.nn.functional.ctc_loss(lp, targets, input_lengths=out_lens, target_lengths=in_lens, blank=0,
+                                            reduction="none", zero_infinity=True)
+        return (loss / in_lens.to(loss.dtype)).mean()
+
+
+class FlowtronLoss(nn.Module):
+    def __init__(self, sigma=1.0, gm_loss=False, gate_loss=True, use_ctc_loss=False, ctc_loss_weight=0.0,
+                 blank_logprob=-1):
+        super().__init__()
+        if gm_loss:
+            raise NotImplementedError("gm_loss (Gaussian-mixture prior) is outside the hot path")
+        self.sigma = sigma
+        self.gm_loss = gm_loss
+        self.gate_loss = gate_loss
+        self.use_ctc_loss = use_ctc_loss
+        self.ctc_loss_weight = ctc_loss_weight
+        self.blank_logprob = blank_logprob
+        self.attention_loss = AttentionCTCLoss(blank_logprob=self.blank_logprob)
+
+    def forward(self, model_output, gate_target, in_lengths, out_lengths, is_validation=False):
+        z, log_s_list, gate_pred, attn_list, attn_logprob_list = model_output[:5]
+        out32 = ops.lens32(out_lengths)
+        loss = ops.NLLFn.apply(z, out32, float(self.sigma), *log_s_list)
+        gate_loss = torch.zeros(1, device=z.device)
+        if self.gate_loss > 0:
+            gate_loss = ops.GateBCEFn.apply(gate_pred, gate_target, out32)
+        loss_ctc = torch.zeros_like(gate_loss)
+        if self.use_ctc_loss:
+            total = None
+            for i, lp in enumerate(attn_logprob_list):
+                if i % 2 != 0:
+                    lp = ops.reverse_by_length(lp, out32, False)       # back-step flows are in reversed time (:250-256)
+                c = self.attention_loss(lp, in_lengths, out_lengths)
+                total = c if total is None else total + c
+            loss_ctc = total / float(len(attn_logprob_list))
+        return loss, gate_loss, loss_ctc

@@ -272,7 +272,6 @@ class AttentionScoresFn(torch.autograd.Function):
                                          L.ptr(p_save), T, B, Lk, A, float(temperature), L.stream()), "ft_attention_fwd")
         ctx.save_for_backward(Q, K, v, in_lens, prior, attn, p_save)
         ctx.temperature = float(temperature)
-        ctx.mark_non_differentiable()
         return attn, logprob
 
     @staticmethod

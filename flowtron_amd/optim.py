@@ -1,0 +1,84 @@
+"""RAdam (reference radam.py:26-122) as TWO HIP kernels over the flat arenas -- a sum-of-squares
+reduction for the global grad norm (train.py:328 clip_grad_norm_) and one fused clip + moment + update
+pass -- instead of ~12 small kernels x 68 tensors.
+
+Optimizer state keeps the reference's per-parameter keys (`step`, `exp_avg`, `exp_avg_sq`; radam.py:63-66)
+as views into flat moment arenas, so `optimizer.state_dict()` stays checkpoint-compatible (train.py:123,138).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch.optim.optimizer import Optimizer
+
+from . import _lib as L
+from .dist import FlatArena
+
+
+class RAdam(Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, arena: FlatArena = None):
+        params = list(params)
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("the fused RAdam runs one flat arena = one param group")
+        plist = [p for p in self.param_groups[0]["params"] if p.requires_grad]
+        if arena is None:
+            arena = FlatArena.for_params(plist, flatten_params=True)
+        else:
+            assert [id(p) for p in arena.params] == [id(p) for p in plist], "arena / optimizer parameter order differs"
+        self.arena = arena
+        self.flat_m = torch.zeros_like(arena.flat_grad)
+        self.flat_v = torch.zeros_like(arena.flat_grad)
+        self.gnorm_sq = torch.zeros(1, device=arena.flat_grad.device, dtype=torch.float32)
+        off = 0
+        for p in plist:
+            k = p.numel()
+            self.state[p] = {"step": 0, "exp_avg": self.flat_m[off:off + k].view_as(p.data),
+                             "exp_avg_sq": self.flat_v[off:off + k].view_as(p.data)}
+            off += k
+        self._step = 0
+
+    @staticmethod
+    def step_size_for(step, lr, beta1, beta2):
+        """radam.py:82-106 (the 10-slot buffer there is only a cache of this closed form)."""
+        beta2_t = beta2 ** step
+        n_sma_max = 2 / (1 - beta2) - 1
+        n_sma = n_sma_max - 2 * step * beta2_t / (1 - beta2_t)
+        if n_sma >= 5:
+            ss = lr * math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_sma_max - 4) * (n_sma - 2) / n_sma * n_sma_max /
+                                (n_sma_max - 2)) / (1 - beta1 ** step)
+            return ss, True
+        return lr / (1 - beta1 ** step), False
+
+    def clip_grad_norm_(self, max_norm: float):
+        """Enqueue ||g||^2 on device and remember the clip for the next step(); returns the device scalar ||g||^2
+        (no host sync -- torch.nn.utils.clip_grad_norm_ at train.py:328 does 68 norms and a sync)."""
+        a = self.arena
+        a.adopt_stray_grads(copy=True)
+        self.gnorm_sq.zero_()
+        L.check(L.lib().ft_sumsq(L.ptr(a.flat_grad), L.ptr(self.gnorm_sq), a.numel, L.stream()), "ft_sumsq")
+        self._clip = float(max_norm)
+        return self.gnorm_sq
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        a = self.arena
+        a.adopt_stray_grads(copy=True)
+        self._step += 1
+        beta1, beta2 = g["betas"]
+        ss, rect = self.step_size_for(self._step, g["lr"], beta1, beta2)
+        clip = getattr(self, "_clip", 0.0)
+        L.check(L.lib().ft_radam_step(L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.flat_m), L.ptr(self.flat_v),
+                                      a.numel, L.ptr(self.gnorm_sq) if clip > 0 else None, clip, g["lr"], beta1, beta2,
+                                      g["eps"], g["weight_decay"], ss, int(rect), L.stream()), "ft_radam_step")
+        self._clip = 0.0
+        for p in a.params:
+            self.state[p]["step"] = self._step
+        return loss
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.arena.zero_grad()

@@ -1,0 +1,211 @@
+"""Model-level parity (-m gpu): flowtron.Flowtron / FlowtronLoss (HIP path through the C ABI) against
+ (a) the committed golden vectors that tests/golden/make_golden.py produced by running the REAL reference, and
+ (b) the CPU oracle on fresh seeded inputs, plus size-independent properties (invertibility, padding
+     invariance) at the full 2-flow config.  fp32 tolerances follow SURVEY 8c."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    return torch.load(os.path.join(GOLDEN, name), weights_only=False)
+
+
+def mad(a, b):
+    return (a.detach().float().cpu() - b.detach().float().cpu()).abs().max().item()
+
+
+def build(cfg, seed, mode="f32"):
+    import flowtron
+    from oracle import synth
+    os.environ["FLOWTRON_MFMA"] = mode
+    m = flowtron.Flowtron(**cfg)
+    sd = synth.make_state_dict(cfg, seed=seed)
+    m.load_state_dict(sd)
+    return m.cuda().eval(), sd
+
+
+def cuda_batch(b):
+    return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+
+
+@pytest.mark.parametrize("name", ["small_f2.pt", "small_f3.pt"])
+def test_forward_loss_grads_vs_reference_golden(name):
+    import flowtron
+    from oracle import synth
+    g = _load(name)
+    cfg = g["cfg"]
+    m, _ = build(cfg, g["seed"])
+    b = cuda_batch(synth.make_batch(cfg, g["out_lens"], g["in_lens"], seed=g["seed"], with_prior=g["with_prior"]))
+    out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+    assert mad(out[0], g["z"]) < 1e-4
+    assert mad(out[2], g["gate"]) < 1e-4
+    for i in range(cfg["n_flows"]):
+        assert mad(out[1][i], g["log_s"][i]) < 1e-4, i
+        assert mad(out[3][i], g["attn"][i]) < 1e-5, i
+        assert mad(out[4][i], g["logprob"][i]) < 5e-4, i
+    crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)
+    nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+    assert abs(nll.item() - g["nll"].item()) < 1e-5 * abs(g["nll"].item())
+    assert abs(gl.item() - g["gate_loss"].item()) < 1e-5
+    assert abs(ctc.item() - g["ctc"].item()) < 1e-4 * max(1.0, abs(g["ctc"].item()))
+    (nll + gl + 0.01 * ctc).sum().backward()
+    worst = ("", 0.0)
+    for k, p in m.named_parameters():
+        ref = g["grads"][k]
+        assert p.grad is not None, k
+        denom = max(ref.norm().item(), 1e-5 * ref.numel() ** 0.5)
+        r = (p.grad.cpu() - ref).norm().item() / denom
+        if r > worst[1]:
+            worst = (k, r)
+    assert worst[1] < 1e-3, worst
+
+
+@pytest.mark.parametrize("name", ["small_f2.pt", "small_f3.pt"])
+@pytest.mark.parametrize("use_graph", ["0", "1"])
+def test_infer_vs_reference_golden(name, use_graph):
+    from oracle import synth
+    os.environ["FLOWTRON_DECODE_GRAPH"] = use_graph
+    g = _load(name)
+    cfg = g["cfg"]
+    m, _ = build(cfg, g["seed"])
+    b = synth.make_batch(cfg, g["out_lens"], g["in_lens"], seed=g["seed"], with_prior=g["with_prior"])
+    n = g["infer_mel"].shape[2]
+    rs = np.random.RandomState(g["seed"] + 11)
+    residual = torch.from_numpy(rs.standard_normal((1, cfg["n_mel_channels"], n)).astype(np.float32)) * 0.5
+    txt, spk = b["text"][:1, : g["in_lens"][0]].cuda(), b["speaker_ids"][:1].cuda()
+    mel, attns = m.infer(residual.cuda(), spk, txt, gate_threshold=1.0)
+    assert mel.shape == g["infer_mel"].shape
+    assert mad(mel, g["infer_mel"]) < 1e-4
+    for a, ra in zip(attns, g["infer_attn"]):
+        assert mad(torch.cat(a)[:, 0], ra) < 1e-5
+    mel_g, _ = m.infer(residual.cuda(), spk, txt, gate_threshold=0.5)
+    assert mel_g.shape[2] == g["infer_gated_frames"]
+    assert mad(mel_g, g["infer_mel"][:, :, : mel_g.shape[2]]) < 1e-4 or cfg["n_flows"] > 1
+
+
+def test_cfg1_full_size_vs_reference_golden():
+    """BASELINE config 1: 1-flow, n_text=148, B=2, T=800/650, L=148/120, fp32, prior + CTC on."""
+    import flowtron
+    from oracle import synth
+    g = _load("cfg1_full.pt")
+    cfg = g["cfg"]
+    m, _ = build(cfg, g["seed"])
+    b = cuda_batch(synth.make_batch(cfg, g["out_lens"], g["in_lens"], seed=g["seed"], with_prior=True))
+    out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+    crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)
+    nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+    st = g["stride"]
+    assert mad(out[0][::st], g["z"]) < 2e-4
+    assert mad(out[1][0][::st], g["log_s"][0]) < 2e-4
+    assert mad(out[3][0][:, ::st], g["attn"][0]) < 2e-5
+    assert abs(nll.item() - g["nll"].item()) < 2e-5 * abs(g["nll"].item())
+    assert abs(gl.item() - g["gate_loss"].item()) < 2e-5
+    assert abs(ctc.item() - g["ctc"].item()) < 2e-4 * max(1.0, abs(g["ctc"].item()))
+    (nll + gl + 0.01 * ctc).sum().backward()
+    bad = []
+    for k, p in m.named_parameters():
+        ref_n = g["grad_norm"][k]
+        samp = g["grad_sample"][k]
+        mine = p.grad.cpu().flatten()[:: max(1, p.numel() // 64)][:64]
+        scale = max(ref_n / p.numel() ** 0.5, 1e-7)
+        if abs(p.grad.norm().item() - ref_n) > 2e-3 * max(ref_n, 1e-5 * p.numel() ** 0.5) or (mine - samp).abs().max().item() > 2e-2 * scale + 1e-7:
+            bad.append((k, p.grad.norm().item(), ref_n, (mine - samp).abs().max().item(), scale))
+    assert not bad, bad[:5]
+    n = g["infer_mel"].shape[2]
+    rs = np.random.RandomState(g["seed"] + 11)
+    residual = torch.from_numpy(rs.standard_normal((1, 80, n)).astype(np.float32)) * 0.5
+    mel, _ = m.infer(residual.cuda(), b["speaker_ids"][:1], b["text"][:1, : g["in_lens"][0]], gate_threshold=1.0)
+    assert mad(mel, g["infer_mel"]) < 2e-4
+
+
+def test_full_config_invertibility_and_padding_invariance():
+    """2-flow default config (config.json): forward(infer(z)) == z (the reference's own, broken,
+    test_invertibility bound is 1e-5 'or less', flowtron.py:932-954), and a sample's valid outputs do not
+    depend on what it is batched with."""
+    from oracle import synth
+    cfg = dict(synth.DEFAULT_MODEL_CONFIG)
+    m, _ = build(cfg, 77)
+    rs = np.random.RandomState(5)
+    N, Lt = 96, 30
+    z = torch.from_numpy(rs.standard_normal((1, 80, N)).astype(np.float32)).cuda() * 0.5
+    text = torch.from_numpy(rs.randint(0, cfg["n_text"], (1, Lt))).cuda()
+    spk = torch.zeros(1, dtype=torch.long).cuda()
+    mel, _ = m.infer(z, spk, text, gate_threshold=1.0)
+    assert mel.shape == (1, 80, N)
+    lens_in, lens_out = torch.tensor([Lt]).cuda(), torch.tensor([N]).cuda()
+    out = m(mel, spk, text, lens_in, lens_out)
+    zr = out[0].permute(1, 2, 0)
+    assert mad(zr, z) < 5e-5, mad(zr, z)
+    # same utterance inside a padded batch of 3
+    mel3 = torch.zeros(3, 80, N + 17).cuda()
+    mel3[0] = torch.from_numpy(rs.standard_normal((80, N + 17)).astype(np.float32)).cuda()
+    mel3[1, :, :N] = mel[0]
+    mel3[2, :, :40] = mel[0, :, :40]
+    text3 = torch.zeros(3, Lt + 6, dtype=torch.long).cuda()
+    text3[0] = torch.from_numpy(rs.randint(0, cfg["n_text"], (Lt + 6,))).cuda()
+    text3[1, :Lt] = text[0]
+    text3[2, :11] = text[0, :11]
+    out3 = m(mel3, torch.zeros(3, dtype=torch.long).cuda(), text3, torch.tensor([Lt + 6, Lt, 11]).cuda(),
+             torch.tensor([N + 17, N, 40]).cuda())
+    assert mad(out3[0][:N, 1], out[0][:, 0]) < 5e-5
+    assert mad(out3[1][0][:N, 1], out[1][0][:, 0]) < 5e-5
+    assert mad(out3[3][0][1, :N, :Lt], out[3][0][0]) < 1e-5
+
+
+def test_bf16_mode_close_to_fp32():
+    """bf16 MFMA operands, fp32 accumulate/storage: NLL within 2e-2 relative of the fp32 path."""
+    import flowtron
+    from oracle import synth
+    cfg = dict(synth.DEFAULT_MODEL_CONFIG, n_text=148, n_flows=2)
+    out_lens, in_lens = [120, 96, 64], [30, 24, 18]
+    b = cuda_batch(synth.make_batch(cfg, out_lens, in_lens, seed=3, with_prior=True))
+    res = {}
+    try:
+        for mode in ("f32", "bf16"):
+            m, _ = build(cfg, 3, mode)
+            out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+            nll, gl, _ = flowtron.FlowtronLoss(1.0, False, True, False, 0.0, -8)(out, b["gate_target"], b["in_lens"], b["out_lens"])
+            res[mode] = (nll.item(), gl.item(), out[0].detach())
+    finally:
+        os.environ["FLOWTRON_MFMA"] = "f32"
+    assert abs(res["bf16"][0] - res["f32"][0]) < 2e-2 * abs(res["f32"][0])
+    assert abs(res["bf16"][1] - res["f32"][1]) < 5e-2
+    assert mad(res["bf16"][2], res["f32"][2]) < 0.25
+
+
+def test_oracle_agrees_on_fresh_inputs():
+    """HIP forward vs the CPU oracle on a new seed (not a stored fixture), 2 flows, ragged batch, no prior."""
+    from oracle import flowtron_oracle as O
+    from oracle import synth
+    cfg = dict(synth.SMALL_MODEL_CONFIG, n_hidden=128, n_attn_channels=64)
+    m, sd = build(cfg, 21)
+    bc = synth.make_batch(cfg, [37, 30, 12, 5], [14, 9, 9, 3], seed=21, with_prior=False)
+    ref = O.forward(sd, cfg, bc["mel"], bc["speaker_ids"], bc["text"], bc["in_lens"], bc["out_lens"], None)
+    b = cuda_batch(bc)
+    out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], None)
+    assert mad(out[0], ref[0]) < 1e-4
+    assert mad(out[2], ref[2]) < 1e-4
+    for i in range(2):
+        assert mad(out[3][i], ref[3][i]) < 1e-5
+        assert mad(out[4][i], ref[4][i]) < 5e-4
+
+
+def test_stft_mel_vs_reference_golden():
+    import audio_processing
+    from oracle import synth
+    g = _load("stft_mel.pt")
+    y = torch.stack([synth.make_audio(g["n_samples"], seed=s) for s in g["seeds"]]).cuda()
+    stft = audio_processing.TacotronSTFT(1024, 256, 1024, 80, 22050, 0.0, 8000.0)
+    mel = stft.mel_spectrogram(y)
+    assert mel.shape == g["mel"].shape
+    assert mad(mel, g["mel"]) < 5e-4
+    # full 10 s clip: shape contract N//hop + 1 (audio_processing.py:221-225)
+    y10 = synth.make_audio(220500, seed=3)[None].cuda()
+    assert stft.mel_spectrogram(y10).shape == (1, 80, 862)

@@ -1,0 +1,292 @@
+"""Per-kernel parity tests (-m gpu): every C-ABI entry point of the training path is called through
+flowtron_amd.ops (ctypes -> libflowtron_hip.so) and compared with a plain fp32 restatement --
+the CPU oracle (oracle/flowtron_oracle.py) or a few lines of torch -- on the same seeded inputs.
+fp32 MFMA mode (FT_F32, exact fp32 products); tolerances are written next to each check."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from flowtron_amd import _lib as L
+    from flowtron_amd import ops
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    L.lib()
+    return L, ops
+
+
+def g(t):
+    return t.cuda() if t is not None else None
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+
+def mad(a, b):
+    return (a.detach().float().cpu() - b.detach().float().cpu()).abs().max().item()
+
+
+# ---------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("mode,tol", [(0, 2e-6), (1, 1.2e-2)])
+@pytest.mark.parametrize("M,N,K,batch", [(128, 128, 32, 1), (37, 45, 19, 1), (300, 160, 1024, 1), (65, 7, 130, 3), (1, 4096, 80, 1), (513, 1, 1664, 1)])
+def test_gemm_layouts(env, mode, tol, M, N, K, batch):
+    L, ops = env
+    torch.manual_seed(M * 7 + N)
+    for ta in (False, True):
+        for tb in (False, True):
+            A = torch.randn(batch, K, M) if ta else torch.randn(batch, M, K)
+            Bm = torch.randn(batch, N, K) if tb else torch.randn(batch, K, N)
+            bias = torch.randn(N)
+            C0 = torch.randn(batch, M, N)
+            Am = A.transpose(1, 2) if ta else A
+            Bk = Bm.transpose(1, 2) if tb else Bm
+            ref = torch.tanh(0.5 * (Am.double() @ Bk.double()) + 0.25 * C0.double() + bias.double()).float()
+            Ad, Bd, Cd, bd = g(A), g(Bm), g(C0.clone()), g(bias)
+            sAm, sAk = (1, M) if ta else (K, 1)
+            sBk, sBn = (1, K) if tb else (N, 1)
+            ops.gemm_raw(Ad, Bd, Cd, M, N, K, sAm, sAk, sBk, sBn, N, bias=bd, act=L.ACT_TANH, alpha=0.5, beta=0.25,
+                         batch=batch, bsA=M * K, bsB=K * N, bsC=M * N, mode=mode)
+            torch.cuda.synchronize()
+            assert mad(Cd, ref) < tol * max(1.0, math.sqrt(K) / 4), (ta, tb, mad(Cd, ref))
+
+
+def test_gemm_strided_views(env):
+    """row-block of a wider weight and a strided output (the no-concat decoder input path)."""
+    L, ops = env
+    torch.manual_seed(3)
+    x = torch.randn(50, 24)
+    W = torch.randn(40, 24 + 12)
+    y = torch.zeros(50, 40)
+    xd, Wd, yd = g(x), g(W), g(y)
+    ops.gemm_raw(xd, Wd[:, 12:], yd, 50, 40, 24, 24, 1, 1, 36, 40, mode=0)
+    torch.cuda.synchronize()
+    assert mad(yd, x @ W[:, 12:].t()) < 1e-5
+
+
+# ---------------------------------------------------------------- Linear autograd
+@pytest.mark.parametrize("act", [0, 1])
+def test_linear_two_inputs_autograd(env, act):
+    L, ops = env
+    torch.manual_seed(11)
+    x1 = torch.randn(9, 5, 64, requires_grad=True)
+    x2 = torch.randn(9, 5, 48, requires_grad=True)
+    W = (torch.randn(33, 112) * 0.1).requires_grad_(True)
+    b = torch.randn(33, requires_grad=True)
+    pre = torch.cat([x1, x2], 2) @ W.t() + b
+    ref = torch.tanh(pre) if act else pre
+    go = torch.randn_like(ref)
+    ref.backward(go)
+    d = [t.detach().cuda().requires_grad_(True) for t in (x1, x2, W, b)]
+    out = ops.linear([d[0], d[1]], d[2], d[3], act=act, mode=0)
+    out.backward(go.cuda())
+    torch.cuda.synchronize()
+    assert mad(out, ref) < 1e-5
+    for mine, r, name in zip(d, (x1, x2, W, b), "x1 x2 W b".split()):
+        assert rel(mine.grad, r.grad) < 1e-5, name
+
+
+# ---------------------------------------------------------------- elementwise family
+def test_embedding(env):
+    L, ops = env
+    torch.manual_seed(0)
+    W = torch.randn(17, 24, requires_grad=True)
+    ids = torch.randint(0, 17, (9, 4))
+    ref = W[ids.reshape(-1)]
+    go = torch.randn_like(ref)
+    ref.backward(go)
+    Wd = W.detach().cuda().requires_grad_(True)
+    out = ops.embedding(g(ids), Wd)
+    out.backward(g(go))
+    assert torch.equal(out.cpu(), ref.detach())
+    assert mad(Wd.grad, W.grad) < 1e-5
+
+
+def test_reverse_by_length(env):
+    L, ops = env
+    from oracle import flowtron_oracle as O
+    torch.manual_seed(1)
+    lens = torch.tensor([9, 4, 1, 7])
+    x = torch.randn(9, 4, 5)
+    y = ops.reverse_by_length(g(x), g(lens.int()), True)
+    assert torch.equal(y.cpu(), O.reverse_by_length(x, lens, 0, 1))
+    xb = torch.randn(4, 9, 6)
+    yb = ops.reverse_by_length(g(xb), g(lens.int()), False)
+    assert torch.equal(yb.cpu(), O.reverse_by_length(xb, lens, 1, 0))
+    assert torch.equal(ops.reverse_by_length(yb, g(lens.int()), False).cpu(), xb)       # involution
+
+
+def test_affine_and_losses(env):
+    L, ops = env
+    from oracle import flowtron_oracle as O
+    torch.manual_seed(2)
+    T, B, M = 13, 3, 80
+    lens = torch.tensor([13, 9, 4])
+    out = (torch.randn(T, B, 2 * M) * 0.3).requires_grad_(True)
+    x = torch.randn(T, B, M, requires_grad=True)
+    gate = torch.randn(T, B, 1, requires_grad=True)
+    target = torch.zeros(B, T)
+    for b in range(B):
+        target[b, lens[b] - 1:] = 1
+    z = torch.exp(out[..., :M]) * x + out[..., M:]
+    nll, gl, _ = O.loss((z, [out[..., :M]], gate, None, None), target, None, lens, 1.0, True, False)
+    (nll + gl).sum().backward()
+    od, xd, gd = (t.detach().cuda().requires_grad_(True) for t in (out, x, gate))
+    l32 = g(lens.int())
+    zd = ops.AffineFn.apply(od, xd)
+    nll_d = ops.NLLFn.apply(zd, l32, 1.0, od[..., :M])
+    gl_d = ops.GateBCEFn.apply(gd, g(target), l32)
+    (nll_d + gl_d).backward()
+    assert mad(zd, z) < 1e-5
+    assert abs(nll_d.item() - nll.item()) < 1e-5 * abs(nll.item())
+    assert abs(gl_d.item() - gl.item()) < 1e-5
+    assert rel(od.grad, out.grad) < 1e-5 and rel(xd.grad, x.grad) < 1e-5 and rel(gd.grad, gate.grad) < 1e-5
+    # inverse coupling
+    xi = torch.empty_like(zd)
+    L.check(L.lib().ft_affine_inv(L.ptr(od.detach()), L.ptr(zd.detach().contiguous()), L.ptr(xi), T * B, M, L.stream()), "inv")
+    assert mad(xi, x) < 2e-5
+
+
+def test_conv_norm_relu(env):
+    L, ops = env
+    from oracle import flowtron_oracle as O
+    torch.manual_seed(4)
+    Lx, B, Cc = 11, 3, 32
+    lens = torch.tensor([11, 7, 3])
+    x = torch.randn(B, Cc, Lx)
+    m = O.length_mask(lens, Lx)[:, None, :].float()
+    x = (x * m).requires_grad_(True)
+    w = (torch.randn(Cc, Cc, 5) * 0.2).requires_grad_(True)
+    bconv = torch.randn(Cc, requires_grad=True)
+    gam = (1 + 0.1 * torch.randn(Cc)).requires_grad_(True)
+    bet = (0.1 * torch.randn(Cc)).requires_grad_(True)
+    keep = (torch.rand(B, Cc, Lx) > 0.5).float() * 2
+    ref = torch.relu(O.masked_instance_norm(F.conv1d(x * m, w, bconv, padding=2), m, gam, bet)) * keep
+    go = torch.randn_like(ref) * m
+    ref.backward(go)
+    d = [t.detach().cuda().requires_grad_(True) for t in (x.permute(2, 0, 1).contiguous(), w, bconv, gam, bet)]
+    out = ops.conv_norm_relu(d[0], g(lens.int()), d[1], d[2], d[3], d[4], g(keep.permute(2, 0, 1).contiguous()), 1e-5, mode=0)
+    out.backward(g(go.permute(2, 0, 1).contiguous()))
+    refm = (ref * m).permute(2, 0, 1)
+    assert mad(out, refm) < 2e-5
+    assert rel(d[0].grad, x.grad.permute(2, 0, 1)) < 2e-5
+    assert rel(d[1].grad, w.grad) < 2e-5
+    assert rel(d[3].grad, gam.grad) < 2e-5 and rel(d[4].grad, bet.grad) < 2e-5
+    assert mad(d[2].grad, bconv.grad) < 1e-4          # analytically zero (the norm removes the mean)
+
+
+# ---------------------------------------------------------------- LSTM
+@pytest.mark.parametrize("T,B,I,H,lens", [(9, 3, 20, 64, [9, 5, 2]), (23, 5, 16, 256, [23, 23, 11, 4, 1]),
+                                           (6, 33, 12, 32, None), (5, 1, 8, 16, [5])])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_lstm_seq(env, T, B, I, H, lens, reverse):
+    L, ops = env
+    from oracle import flowtron_oracle as O
+    torch.manual_seed(T + B)
+    lens = torch.tensor(lens) if lens is not None else torch.randint(1, T + 1, (B,))
+    lens[0] = T
+    x = torch.randn(T, B, I, requires_grad=True)
+    k = 1.0 / math.sqrt(H)
+    w_ih, w_hh = [(torch.rand(4 * H, n) * 2 * k - k).requires_grad_(True) for n in (I, H)]
+    b_ih, b_hh = [(torch.rand(4 * H) * 2 * k - k).requires_grad_(True) for _ in range(2)]
+    ref = O.lstm_cell_seq(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=reverse)
+    go = torch.randn_like(ref)
+    ref.backward(go)
+    d = [t.detach().cuda().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
+    out = ops.lstm_layer(d[0], g(lens.int()), d[1], d[2], d[3], d[4], reverse=reverse, mode=0)
+    out.backward(g(go))
+    assert mad(out, ref) < 2e-5, mad(out, ref)
+    for mine, r, name in zip(d, (x, w_ih, w_hh, b_ih, b_hh), "x w_ih w_hh b_ih b_hh".split()):
+        assert rel(mine.grad, r.grad) < 5e-5, (name, rel(mine.grad, r.grad))
+
+
+def test_lstm_seq_bf16_close(env):
+    L, ops = env
+    from oracle import flowtron_oracle as O
+    torch.manual_seed(5)
+    T, B, I, H = 12, 4, 24, 128
+    lens = torch.tensor([12, 9, 9, 3])
+    x = torch.randn(T, B, I)
+    k = 1.0 / math.sqrt(H)
+    w_ih, w_hh = [(torch.rand(4 * H, n) * 2 * k - k) for n in (I, H)]
+    b = torch.zeros(4 * H)
+    ref = O.lstm_cell_seq(x, lens, w_ih, w_hh, b, b)
+    out = ops.lstm_layer(g(x), g(lens.int()), g(w_ih), g(w_hh), g(b), g(b), mode=1)
+    assert mad(out, ref) < 3e-2
+
+
+# ---------------------------------------------------------------- attention
+@pytest.mark.parametrize("T,B,Lk,A,E,prior,with_dlp", [(19, 3, 11, 48, 40, True, True), (40, 2, 37, 640, 64, False, True),
+                                                        (33, 4, 150, 64, 32, True, False), (5, 1, 3, 20, 8, False, False)])
+def test_attention(env, T, B, Lk, A, E, prior, with_dlp):
+    L, ops = env
+    torch.manual_seed(T * 3 + Lk)
+    in_lens = torch.randint(max(1, Lk // 2), Lk + 1, (B,))
+    in_lens[0] = Lk
+    Q = (torch.randn(T, B, A) * 0.7).requires_grad_(True)
+    K = (torch.randn(Lk, B, A) * 0.7).requires_grad_(True)
+    V = torch.randn(Lk, B, A, requires_grad=True)
+    v = (torch.randn(1, A) * 0.3).requires_grad_(True)
+    pr = None
+    if prior:
+        pr = torch.rand(B, T, Lk) ** 3
+        pr[0, 0, 0] = 0.0
+    temp = 0.9
+    pad = ~(torch.arange(Lk)[None, :] < in_lens[:, None])
+    e = (torch.tanh(Q.transpose(0, 1)[:, :, None, :] + K.transpose(0, 1)[:, None, :, :]) @ v[0]) / temp
+    e = e.masked_fill(pad[:, None, :], -float("inf"))
+    p = torch.softmax(e, 2)
+    if prior:
+        u = torch.log(p + 1e-20) + torch.log(pr + 1e-20)
+        lp = u.clone()
+        attn = torch.softmax(u.masked_fill(pad[:, None, :], -float("inf")), 2)
+    else:
+        attn, lp = p, torch.log(p + 1e-8)
+    ctx = torch.bmm(attn, V.transpose(0, 1)).transpose(0, 1)
+    go = torch.randn_like(ctx)
+    valid = (~pad)[:, None, :].float()
+    glp = torch.randn_like(lp) * 0.1 * valid
+    loss = (ctx * go).sum() + ((lp * glp).sum() if with_dlp else 0.0)
+    loss.backward()
+    d = [t.detach().cuda().requires_grad_(True) for t in (Q, K, V, v)]
+    attn_d, lp_d = ops.AttentionScoresFn.apply(d[0], d[1], d[3], g(in_lens.int()), g(pr), temp)
+    ctx_d = ops.ContextFn.apply(attn_d, d[2], 0)
+    loss_d = (ctx_d * g(go)).sum() + ((lp_d * g(glp)).sum() if with_dlp else 0.0)
+    loss_d.backward()
+    assert mad(attn_d, attn) < 2e-6, mad(attn_d, attn)
+    assert mad(lp_d, lp) < 2e-4, mad(lp_d, lp)
+    assert mad(ctx_d, ctx) < 2e-5
+    for mine, r, name in zip(d, (Q, K, V, v), "Q K V v".split()):
+        assert rel(mine.grad, r.grad) < 1e-4, (name, rel(mine.grad, r.grad))
+
+
+# ---------------------------------------------------------------- optimizer kernels
+def test_sumsq_radam_colsum(env):
+    L, ops = env
+    torch.manual_seed(9)
+    n = 100003
+    p, gr, m, v = torch.randn(n), torch.randn(n) * 3, torch.randn(n) * 0.1, torch.rand(n) * 0.01
+    pd, gd, md, vd = g(p), g(gr), g(m), g(v)
+    acc = torch.zeros(1, device="cuda")
+    L.check(L.lib().ft_sumsq(L.ptr(gd), L.ptr(acc), n, L.stream()), "sumsq")
+    assert abs(acc.item() - (gr.double() ** 2).sum().item()) < 1e-4 * acc.item()
+    clip, lr, b1, b2, eps, wd, step_size = 1.0, 1e-3, 0.9, 0.999, 1e-8, 1e-6, 2.5e-3
+    L.check(L.lib().ft_radam_step(L.ptr(pd), L.ptr(gd), L.ptr(md), L.ptr(vd), n, L.ptr(acc), clip, lr, b1, b2, eps, wd,
+                                  step_size, 1, L.stream()), "radam")
+    cs = min(1.0, clip / (gr.norm().item() + 1e-6))
+    g2 = gr * cs
+    v2 = v * b2 + (1 - b2) * g2 * g2
+    m2 = m * b1 + (1 - b1) * g2
+    p2 = p - wd * lr * p
+    p2 = p2 - step_size * m2 / (v2.sqrt() + eps)
+    assert mad(pd, p2) < 1e-6 and mad(md, m2) < 1e-6 and mad(vd, v2) < 1e-7
+    x = torch.randn(1000, 37)
+    cs_ = ops.colsum(g(x), 1000, 37, 37)
+    assert mad(cs_, x.sum(0)) < 1e-3
