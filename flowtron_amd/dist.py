@@ -77,21 +77,25 @@ class FlatArena:
         self.params = [p for p in params if p.requires_grad]
         assert self.params, "no trainable parameters"
         dev, dt = self.params[0].device, torch.float32
-        n = sum(p.numel() for p in self.params)
-        # pad to a multiple of 4 floats: the optimizer kernels run float4
-        self.numel = n
-        self.flat_grad = torch.zeros((n + 3) // 4 * 4, device=dev, dtype=dt)
-        self.flat_param = None
+        # every tensor starts on a 256-byte boundary inside the arena: the HIP kernels read weights with 16-byte
+        # vector loads (W_hh rows, GEMV rows), and a [1]-element bias must not misalign what follows it.  The gaps
+        # are zero in params, grads and moments, so reductions/updates over the whole arena are unaffected.
+        ALIGN = 64
+        self.offsets = []
         off = 0
-        if flatten_params:
-            self.flat_param = torch.zeros_like(self.flat_grad)
         for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.n_params = sum(p.numel() for p in self.params)
+        self.numel = off                                   # arena length incl. alignment gaps
+        self.flat_grad = torch.zeros(off, device=dev, dtype=dt)
+        self.flat_param = torch.zeros_like(self.flat_grad) if flatten_params else None
+        for p, off in zip(self.params, self.offsets):
             k = p.numel()
             if flatten_params:
                 self.flat_param[off:off + k].copy_(p.data.reshape(-1))
                 p.data = self.flat_param[off:off + k].view_as(p.data)
             p.grad = self.flat_grad[off:off + k].view_as(p.data)
-            off += k
         self._ptr_lo = self.flat_grad.data_ptr()
         self._ptr_hi = self._ptr_lo + self.flat_grad.numel() * 4
         for p in self.params:
@@ -114,18 +118,14 @@ class FlatArena:
     def adopt_stray_grads(self, copy=True):
         """If something replaced p.grad (e.g. zero_grad(set_to_none=True) followed by backward), pull it back
         into the arena so the single-collective path stays valid."""
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             k = p.numel()
             g = p.grad
-            view = self.flat_grad[off:off + k].view_as(p.data)
-            if g is None:
-                p.grad = view
-            elif not (self._ptr_lo <= g.data_ptr() < self._ptr_hi):
-                if copy:
+            if g is None or not (self._ptr_lo <= g.data_ptr() < self._ptr_hi):
+                view = self.flat_grad[off:off + k].view_as(p.data)
+                if g is not None and copy:
                     view.copy_(g)
                 p.grad = view
-            off += k
 
 
 def apply_gradient_allreduce(module):

@@ -32,12 +32,10 @@ class RAdam(Optimizer):
         self.flat_m = torch.zeros_like(arena.flat_grad)
         self.flat_v = torch.zeros_like(arena.flat_grad)
         self.gnorm_sq = torch.zeros(1, device=arena.flat_grad.device, dtype=torch.float32)
-        off = 0
-        for p in plist:
+        for p, off in zip(arena.params, arena.offsets):
             k = p.numel()
             self.state[p] = {"step": 0, "exp_avg": self.flat_m[off:off + k].view_as(p.data),
                              "exp_avg_sq": self.flat_v[off:off + k].view_as(p.data)}
-            off += k
         self._step = 0
 
     @staticmethod

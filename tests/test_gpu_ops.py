@@ -35,7 +35,7 @@ def mad(a, b):
 
 
 # ---------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("mode,tol", [(0, 2e-6), (1, 1.2e-2)])
+@pytest.mark.parametrize("mode,tol", [(0, 5e-6), (1, 2e-2)])
 @pytest.mark.parametrize("M,N,K,batch", [(128, 128, 32, 1), (37, 45, 19, 1), (300, 160, 1024, 1), (65, 7, 130, 3), (1, 4096, 80, 1), (513, 1, 1664, 1)])
 def test_gemm_layouts(env, mode, tol, M, N, K, batch):
     L, ops = env
@@ -48,14 +48,15 @@ def test_gemm_layouts(env, mode, tol, M, N, K, batch):
             C0 = torch.randn(batch, M, N)
             Am = A.transpose(1, 2) if ta else A
             Bk = Bm.transpose(1, 2) if tb else Bm
-            ref = torch.tanh(0.5 * (Am.double() @ Bk.double()) + 0.25 * C0.double() + bias.double()).float()
+            alpha = 1.0 / math.sqrt(K)                 # keeps the pre-activation O(1): bf16 operand rounding ~ 4e-3 abs
+            ref = torch.tanh(alpha * (Am.double() @ Bk.double()) + 0.25 * C0.double() + bias.double()).float()
             Ad, Bd, Cd, bd = g(A), g(Bm), g(C0.clone()), g(bias)
             sAm, sAk = (1, M) if ta else (K, 1)
             sBk, sBn = (1, K) if tb else (N, 1)
-            ops.gemm_raw(Ad, Bd, Cd, M, N, K, sAm, sAk, sBk, sBn, N, bias=bd, act=L.ACT_TANH, alpha=0.5, beta=0.25,
+            ops.gemm_raw(Ad, Bd, Cd, M, N, K, sAm, sAk, sBk, sBn, N, bias=bd, act=L.ACT_TANH, alpha=alpha, beta=0.25,
                          batch=batch, bsA=M * K, bsB=K * N, bsC=M * N, mode=mode)
             torch.cuda.synchronize()
-            assert mad(Cd, ref) < tol * max(1.0, math.sqrt(K) / 4), (ta, tb, mad(Cd, ref))
+            assert mad(Cd, ref) < tol, (ta, tb, mad(Cd, ref))
 
 
 def test_gemm_strided_views(env):
