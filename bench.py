@@ -122,41 +122,78 @@ def lstm_step_roofline(B, H, T, mode):
             "bytes_per_launch": bytes_per_launch}
 
 
-def cpu_baseline(model, batch, prior):
+def usable_cores():
+    """Host cores this process may actually use: affinity mask, further limited by a cgroup CPU quota (a container
+    that reports 200 cpus but is throttled to 16 would otherwise oversubscribe OpenMP by 10x)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline_worker(batch_size, seed):
     """The CPU oracle (oracle/flowtron_oracle.py = restatement of the reference, pinned to golden vectors made
-    with the real reference) on a BOUNDED sample: the 2 shortest utterances of this rank's batch, full
-    forward + loss + backward, fp32, all host cores."""
+    with the real reference) on a BOUNDED sample: the 2 shortest utterances of rank 0's batch, full
+    forward + loss + backward, fp32, all usable host cores.  Runs in its own process (no GPU context)."""
     from oracle import flowtron_oracle as O
-    cores = os.cpu_count() or 1
+    import flowtron
+    cores = usable_cores()
     torch.set_num_threads(cores)
-    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    torch.manual_seed(1234)
+    model = flowtron.Flowtron(**MODEL_CONFIG)
+    init_weights(model, 1234)
+    batch = synth_batch(batch_size, seed)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     idx = torch.argsort(batch["out_lens"])[:2]
     idx = idx[torch.argsort(batch["in_lens"][idx], descending=True)]
     out_lens, in_lens = batch["out_lens"][idx], batch["in_lens"][idx]
     T, Lk = int(out_lens.max()), int(in_lens.max())
     mel, text = batch["mel"][idx][:, :, :T], batch["text"][idx][:, :Lk]
-    pr, gate = prior[idx][:, :T, :Lk], batch["gate"][idx][:, :T]
+    pr = beta_binomial_prior_batch(in_lens, out_lens, T, Lk)
+    gate = batch["gate"][idx][:, :T]
     O.LSTM_IMPL["fn"] = O.lstm_seq_fast
-    try:
-        best = None
-        for it in range(2):
-            for v in sd.values():
-                v.grad = None
-            t0 = time.perf_counter()
-            out = O.forward(sd, MODEL_CONFIG, mel, batch["speaker_ids"][idx], text, in_lens, out_lens, pr)
-            nll, gl, ctc = O.loss(out, gate, in_lens, out_lens, 1.0, True, True, -8)
-            (nll + gl + 0.01 * ctc).sum().backward()
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
-    finally:
-        O.LSTM_IMPL["fn"] = O.lstm_cell_seq
+    best = None
+    for it in range(2):
+        for v in sd.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        out = O.forward(sd, MODEL_CONFIG, mel, batch["speaker_ids"][idx], text, in_lens, out_lens, pr)
+        nll, gl, ctc = O.loss(out, gate, in_lens, out_lens, 1.0, True, True, -8)
+        (nll + gl + 0.01 * ctc).sum().backward()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
     frames = int(out_lens.sum())
     return {"value": round(frames / best, 2), "unit": "mel-frames/s", "cores": cores, "kind": "port",
             "sample": "2 shortest utterances of the batch (%d valid frames, T=%d, L=%d), fwd+loss+bwd, fp32, best of 2, %.2f s"
                       % (frames, T, Lk, best)}
 
 
+def cpu_baseline(batch_size, seed, timeout_s=420):
+    import subprocess
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(batch_size), str(seed)],
+                           capture_output=True, text=True, timeout=timeout_s, env=env)
+    except subprocess.TimeoutExpired:
+        return {"error": "cpu oracle sample did not finish in %d s" % timeout_s}
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    return {"error": "worker failed: " + (r.stderr or "")[-400:]}
+
+
+def log(msg):
+    print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
+
+
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
+        print(json.dumps(cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]))), flush=True)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -213,6 +250,7 @@ def main():
         optimizer.step()
         return loss
 
+    log("model + batch ready (%d valid frames/step); warm-up" % frames_rank)
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
@@ -227,6 +265,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    log("timed region done: %.1f ms/step" % (dt / max(args.steps, 1) * 1e3))
     loss_val = float(loss.item())
     stats = torch.tensor([dt, float(frames_rank)], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -251,12 +290,14 @@ def main():
                        "mfma_operands": args.mfma, "storage": "fp32", "final_loss": round(loss_val, 5)},
         }
         mode = L.FT_BF16 if args.mfma == "bf16" else L.FT_F32
+        log("roofline kernel timing ...")
         try:
             res["roofline"] = lstm_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, mode)
         except Exception as e:                      # never lose the headline number to the side measurement
             res["roofline"] = {"error": repr(e)}
         if world == 1 and not args.no_infer:
             try:
+                log("inference RTF ...")
                 model.eval()
                 n_frames = 400
                 z = torch.randn(1, 80, n_frames, device="cuda") * 0.5
@@ -274,7 +315,8 @@ def main():
                 res["infer"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(model, batch_cpu, prior_cpu)
+                log("cpu baseline (oracle, bounded sample) ...")
+                res["cpu_baseline"] = cpu_baseline(args.batch, 1234 + 7 + rank)
             except Exception as e:
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)

@@ -232,6 +232,29 @@ __global__ void act_bwd_k(const float* __restrict__ y, const float* __restrict__
     }
 }
 
+// ---------------- beta-binomial attention prior (data.py:31-41) ----------------
+// prior[b][t][k] = BetaBinom(k; n = P_b-1, alpha = s*(t+1), beta = s*(M_b-t))   t < M_b = out_lens[b], k < P_b = in_lens[b]
+// evaluated in float64 through lgamma like scipy.stats.betabinom.pmf, rounded to fp32; 0 in the padding.
+__global__ void beta_binomial_prior_k(const int* __restrict__ in_lens, const int* __restrict__ out_lens,
+                                      float* __restrict__ prior, int B, int T, int L, double scaling) {
+    const long total = (long)B * T * L;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % L);
+        const long r = i / L;
+        const int t = (int)(r % T), b = (int)(r / T);
+        const int P = in_lens[b], M = out_lens[b];
+        float v = 0.f;
+        if (t < M && k < P) {
+            const double n = (double)(P - 1), kk = (double)k;
+            const double a = scaling * (double)(t + 1), bb = scaling * (double)(M - t);
+            const double lp = lgamma(n + 1.0) - lgamma(kk + 1.0) - lgamma(n - kk + 1.0) + lgamma(kk + a) + lgamma(n - kk + bb) -
+                              lgamma(n + a + bb) - (lgamma(a) + lgamma(bb) - lgamma(a + bb));
+            v = (float)exp(lp);
+        }
+        prior[i] = v;
+    }
+}
+
 __global__ void zero_k(float* __restrict__ p, long n) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0.f;
 }
@@ -387,6 +410,14 @@ extern "C" int ft_act_bwd(const float* y, const float* dy, float* dpre, int64_t 
     FT_CHECK_ARG(y && dy && dpre && n >= 0 && act >= FT_ACT_NONE && act <= FT_ACT_SIGMOID);
     if (n == 0) return FT_OK;
     hipLaunchKernelGGL(act_bwd_k, dim3(grid_for(n)), dim3(NT), 0, ST(stream), y, dy, dpre, (long)n, act);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_beta_binomial_prior(const int32_t* in_lens, const int32_t* out_lens, float* prior,
+                                      int B, int T, int L, float scaling, void* stream) {
+    FT_CHECK_ARG(in_lens && out_lens && prior && B >= 1 && T >= 1 && L >= 1 && scaling > 0.f);
+    hipLaunchKernelGGL(beta_binomial_prior_k, dim3(grid_for((int64_t)B * T * L)), dim3(NT), 0, ST(stream), in_lens, out_lens, prior,
+                       B, T, L, (double)scaling);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

@@ -1,72 +1,89 @@
 // Length-masked LSTM recurrence for training: one kernel launch per time step
-// (a kernel boundary is the cheapest chip-wide barrier on gfx950, ~1.5 us, and
-// cannot deadlock), each launch spreading the [B,H]x[H,4H] recurrent product
-// over H/4 workgroups so every CU streams only its own 16 rows of W_hh (which
-// stay resident in its XCD's L2 across steps: blockIdx -> XCD is stable).
+// (a dependent kernel boundary is the cheapest chip-wide barrier on gfx950, ~1.5 us, and
+// cannot deadlock), each launch spreading the [B,H]x[H,4H] recurrent product over H/4
+// workgroups so every CU touches only its own 16 gate rows of W_hh (which stay resident in
+// its XCD's L2 across steps: blockIdx -> XCD placement is stable).
 //
 //   fwd step : block j owns hidden units 4j..4j+3 = 16 gate rows (i,f,g,o x 4).
-//              4 waves split K=H; skinny MFMA tiles (M = batch rows, N = 16 rows);
+//              4 waves split K=H; skinny MFMA tiles (M = batch rows, N = 16 gate rows);
 //              cross-wave reduce in LDS; the i/f/g/o nonlinearity, cell update,
 //              length masking and all stores are fused in the same launch.
 //   bwd step : pointwise kernel (dgates from dh, dc) + split-K skinny MFMA
 //              dh_rec = dgates . W_hh (against a once-transposed W_hh^T).
 // Weight gradients and dx are plain GEMMs over all T*B rows afterwards.
+//
+// Two operand paths:
+//   FT_F32  (parity): fp32 W_hh / h straight from global, v_mfma_f32_16x16x4_f32.
+//   FT_BF16 (speed) : once per sequence W_hh (and W_hh^T for backward) is rounded to bf16 and
+//              re-laid out in MFMA FRAGMENT ORDER [block][k-chunk][lane][8], and the step kernels
+//              keep h_t (resp. dgates_t) in the same fragment order, so every operand load of a
+//              step is one fully coalesced 1 KiB global_load_dwordx4 per wave and the per-step L2
+//              traffic halves; v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Needs H % 32 == 0.
 #include "common.h"
 
 namespace {
 
 // ---- skinny  D[b][n] += sum_k A[b][k] * W[n][k]  over k-chunks c = c0, c0+cs, ... ----
 // fp32 : chunk = 16 k, lane (li,kg) loads float4 at k = c*16 + kg*4, 4 x mfma_16x16x4f32
-// bf16 : chunk = 32 k, lane loads 8 floats at k = c*32 + kg*8, 1 x mfma_16x16x32_bf16
-template <int MODE, int MT>
-__device__ __forceinline__ void skinny_nt(const float* const (&arow)[MT], const float* wrow, int K,
-                                          int c0, int cs, int kg, f32x4 (&acc)[MT]) {
-    constexpr int KC = (MODE == 0) ? 16 : 32;
-    const int nchunk = (K + KC - 1) / KC;
+template <int MT>
+__device__ __forceinline__ void skinny_f32(const float* const (&arow)[MT], const float* wrow, int K,
+                                           int c0, int cs, int kg, f32x4 (&acc)[MT]) {
+    const int nchunk = (K + 15) / 16;
     for (int c = c0; c < nchunk; c += cs) {
-        if constexpr (MODE == 0) {
-            const int k = c * 16 + kg * 4;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (wrow && k < K) w = *reinterpret_cast<const float4*>(wrow + k);
+        const int k = c * 16 + kg * 4;
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wrow && k < K) w = *reinterpret_cast<const float4*>(wrow + k);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (arow[m] && k < K) a = *reinterpret_cast<const float4*>(arow[m] + k);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc[m], 0, 0, 0);
-            }
-        } else {
-            const int k = c * 32 + kg * 8;
-            float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
-            if (wrow && k < K) w0 = *reinterpret_cast<const float4*>(wrow + k);
-            if (wrow && k + 4 < K) w1 = *reinterpret_cast<const float4*>(wrow + k + 4);
-            bf16x8 wb;
-            wb[0] = f2bf(w0.x); wb[1] = f2bf(w0.y); wb[2] = f2bf(w0.z); wb[3] = f2bf(w0.w);
-            wb[4] = f2bf(w1.x); wb[5] = f2bf(w1.y); wb[6] = f2bf(w1.z); wb[7] = f2bf(w1.w);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-                if (arow[m] && k < K) a0 = *reinterpret_cast<const float4*>(arow[m] + k);
-                if (arow[m] && k + 4 < K) a1 = *reinterpret_cast<const float4*>(arow[m] + k + 4);
-                bf16x8 ab;
-                ab[0] = f2bf(a0.x); ab[1] = f2bf(a0.y); ab[2] = f2bf(a0.z); ab[3] = f2bf(a0.w);
-                ab[4] = f2bf(a1.x); ab[5] = f2bf(a1.y); ab[6] = f2bf(a1.z); ab[7] = f2bf(a1.w);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, wb, acc[m], 0, 0, 0);
-            }
+        for (int m = 0; m < MT; ++m) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (arow[m] && k < K) a = *reinterpret_cast<const float4*>(arow[m] + k);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc[m], 0, 0, 0);
         }
     }
+}
+
+// bf16 fragment-order operands: wfrag -> [nchunk][64 lanes][8 bf16], afrag -> [nchunk][MT][64][8].
+// Chunks c0, c0+cs, ... ; G chunks are loaded back-to-back (all loads in flight) before their MFMAs issue, so a
+// wave pays the L2 round trip once per group instead of once per chunk.  Needs ((nchunk - c0) / cs) % G == 0.
+template <int MT, int G>
+__device__ __forceinline__ void skinny_bf16(const bf16x8* __restrict__ afrag, const bf16x8* __restrict__ wfrag,
+                                            int nchunk, int c0, int cs, int lane, f32x4 (&acc)[MT]) {
+    for (int cb = c0; cb < nchunk; cb += cs * G) {
+        bf16x8 w[G], a[G][MT];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const size_t c = (size_t)(cb + i * cs);
+            w[i] = wfrag[c * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[i][m] = afrag[(c * MT + m) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep all G*(1+MT) loads in flight: hipcc otherwise sinks them between the MFMAs
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w[i], acc[m], 0, 0, 0);
+    }
+}
+
+// element (b, k) of a [B, K] activation in fragment order
+__device__ __forceinline__ size_t frag_index(int b, int k, int MT) {
+    const int c = k >> 5, kg = (k >> 3) & 3, e = k & 7, m = b >> 4, li = b & 15;
+    return (((size_t)c * MT + m) * 64 + kg * 16 + li) * 8 + e;
 }
 
 struct FwdP {
     const float* gx; const float* w_hh; const int* lens;
     const float* hprev; float* hnext; float* cstate;
     float* y; long ldy; float* gates; float* cell;
+    const unsigned short* wfrag;            // bf16 path: [H/4][H/32][64][8]
+    const unsigned short* hfrag_prev; unsigned short* hfrag_next;   // bf16 path: [H/32][MT][64][8]
     int s, T, B, H, reverse;
 };
 
-template <int MODE, int MT>
+template <int MODE, int MT, int G>
 __global__ __launch_bounds__(256) void lstm_fwd_step(FwdP p) {
     __shared__ float red[4][MT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,71 +91,98 @@ __global__ __launch_bounds__(256) void lstm_fwd_step(FwdP p) {
     const int u0 = blockIdx.x * 4;
     const int H = p.H, B = p.B;
 
-    // B operand row for this lane: n = li = gate*4 + ul  ->  W_hh row gate*H + u0 + ul
-    const int wu = u0 + (li & 3);
-    const float* wrow = (wu < H) ? p.w_hh + (size_t)((li >> 2) * H + wu) * H : nullptr;
-    const float* arow[MT];
+    // epilogue role of this thread: batch row b, unit u -- issue its gx / c loads before the matmul
+    const int eb = tid >> 2, ul = tid & 3, eu = u0 + ul;
+    const bool ev = eb < B && eu < H;
+    int len = 0, t = 0;
+    bool active = false;
+    float gxv[4] = {0.f, 0.f, 0.f, 0.f};
+    float c_old = 0.f;
+    if (ev) {
+        len = p.lens[eb];
+        active = p.s < len;
+        if (active) {
+            t = p.reverse ? (len - 1 - p.s) : p.s;
+            const float* gp = p.gx + ((size_t)t * B + eb) * 4 * H + eu;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        int b = m * 16 + li;
-        arow[m] = (b < B) ? p.hprev + (size_t)b * H : nullptr;
+            for (int g = 0; g < 4; ++g) gxv[g] = gp[(size_t)g * H];
+            c_old = p.cstate[(size_t)eb * H + eu];
+        }
     }
+
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    skinny_nt<MODE, MT>(arow, wrow, H, wave, 4, kg, acc);
+    if constexpr (MODE == 0) {
+        // B operand row for this lane: n = li = gate*4 + ul  ->  W_hh row gate*H + u0 + ul
+        const int wu = u0 + (li & 3);
+        const float* wrow = (wu < H) ? p.w_hh + (size_t)((li >> 2) * H + wu) * H : nullptr;
+        const float* arow[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            int b = m * 16 + li;
+            arow[m] = (b < B) ? p.hprev + (size_t)b * H : nullptr;
+        }
+        skinny_f32<MT>(arow, wrow, H, wave, 4, kg, acc);
+    } else {
+        const int nchunk = H >> 5;
+        skinny_bf16<MT, G>(reinterpret_cast<const bf16x8*>(p.hfrag_prev),
+                           reinterpret_cast<const bf16x8*>(p.wfrag) + (size_t)blockIdx.x * nchunk * 64, nchunk, wave, 4, lane, acc);
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][m * 16 + kg * 4 + r][li] = acc[m][r];
     __syncthreads();
 
-    const int b = tid >> 2, ul = tid & 3, u = u0 + ul;
-    if (b >= B || u >= H) return;
-    const int len = p.lens[b];
-    const bool active = p.s < len;
-    const size_t bu = (size_t)b * H + u;
+    if (!ev) return;
+    const size_t bu = (size_t)eb * H + eu;
     if (!active) {                               // sample finished: pad row of y is zero, state frozen
-        p.y[((size_t)p.s * B + b) * p.ldy + u] = 0.f;
-        p.hnext[bu] = p.hprev[bu];
+        p.y[((size_t)p.s * B + eb) * p.ldy + eu] = 0.f;
+        if constexpr (MODE == 0) p.hnext[bu] = p.hprev[bu];
+        else p.hfrag_next[frag_index(eb, eu, MT)] = p.hfrag_prev[frag_index(eb, eu, MT)];
         return;
     }
-    const int t = p.reverse ? (len - 1 - p.s) : p.s;
-    const size_t row = (size_t)t * B + b;
+    const size_t row = (size_t)t * B + eb;
     float pre[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        int n = g * 4 + ul;
-        pre[g] = red[0][b][n] + red[1][b][n] + red[2][b][n] + red[3][b][n] + p.gx[row * 4 * H + (size_t)g * H + u];
+        const int n = g * 4 + ul;
+        pre[g] = red[0][eb][n] + red[1][eb][n] + red[2][eb][n] + red[3][eb][n] + gxv[g];
     }
     const float ig = 1.f / (1.f + expf(-pre[0]));
     const float fg = 1.f / (1.f + expf(-pre[1]));
     const float gg = tanhf(pre[2]);
     const float og = 1.f / (1.f + expf(-pre[3]));
-    const float c_new = fg * p.cstate[bu] + ig * gg;
+    const float c_new = fg * c_old + ig * gg;
     const float h_new = og * tanhf(c_new);
     p.cstate[bu] = c_new;
-    p.hnext[bu] = h_new;
-    p.y[row * p.ldy + u] = h_new;
+    if constexpr (MODE == 0) p.hnext[bu] = h_new;
+    else p.hfrag_next[frag_index(eb, eu, MT)] = f2bf(h_new);
+    p.y[row * p.ldy + eu] = h_new;
     if (p.gates) {
-        float* gp = p.gates + row * 4 * H + u;
+        float* gp = p.gates + row * 4 * H + eu;
         gp[0] = ig; gp[(size_t)H] = fg; gp[(size_t)2 * H] = gg; gp[(size_t)3 * H] = og;
-        p.cell[row * H + u] = c_new;
+        p.cell[row * H + eu] = c_new;
     }
 }
 
 struct BwdP {
     const float* dy; long ldy; const int* lens;
     const float* gates; const float* cell;
-    const float* part;      // [4][B][H] partial dh_rec from step s+1
+    const float* part;      // fp32 path: [4][B][H] partial dh_rec from step s+1
     float* dc_carry;        // [B][H]
-    float* da_cur;          // [B][4H]
+    float* da_cur;          // fp32 path: [B][4H]
     float* dgx;             // [T][B][4H]
-    const float* wT;        // [H][4H]
-    float* part_out;        // [4][B][H]
+    const float* wT;        // fp32 path: [H][4H]
+    float* part_out;        // fp32 path: [4][B][H]
+    const unsigned short* dafrag_prev;  // bf16 path: dgates of step s+1, fragment order over K = 4H: [4H/32][MT][64][8]
+    unsigned short* dafrag_next;        // bf16 path: dgates of step s (ping-pong)
+    const unsigned short* wTfrag;       // bf16 path: [H/16][4H/32][64][8]
     int s, T, B, H, reverse;
 };
 
+// ------------------------------------------------------------------ fp32 (parity) path: two launches per step
 __global__ void lstm_bwd_pointwise(BwdP p) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int H = p.H, B = p.B;
@@ -176,7 +220,7 @@ __global__ void lstm_bwd_pointwise(BwdP p) {
 }
 
 // part_out[ks][b][j] = sum_{r in K-slice ks} da_cur[b][r] * wT[j][r]
-template <int MODE, int MT>
+template <int MT>
 __global__ __launch_bounds__(256) void lstm_bwd_matmul(BwdP p) {
     __shared__ float red[4][MT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -184,6 +228,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_matmul(BwdP p) {
     const int H = p.H, B = p.B, K4 = 4 * p.H;
     const int j0 = blockIdx.x * 16, ks = blockIdx.y;
     const int KR = K4 / 4;                         // K-slice length (= H), multiple of 4
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int j = j0 + li;
     const float* wrow = (j < H) ? p.wT + (size_t)j * K4 + (size_t)ks * KR : nullptr;
     const float* arow[MT];
@@ -192,10 +239,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_matmul(BwdP p) {
         int b = m * 16 + li;
         arow[m] = (b < B) ? p.da_cur + (size_t)b * K4 + (size_t)ks * KR : nullptr;
     }
-    f32x4 acc[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    skinny_nt<MODE, MT>(arow, wrow, KR, wave, 4, kg, acc);
+    skinny_f32<MT>(arow, wrow, KR, wave, 4, kg, acc);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -205,6 +249,79 @@ __global__ __launch_bounds__(256) void lstm_bwd_matmul(BwdP p) {
         int b = i >> 4, n = i & 15;
         if (b < B && j0 + n < H)
             p.part_out[((size_t)ks * B + b) * H + j0 + n] = red[0][b][n] + red[1][b][n] + red[2][b][n] + red[3][b][n];
+    }
+}
+
+// ------------------------------------------------------------------ bf16 path: ONE launch per step
+// Block jt owns 16 hidden units for the whole sequence (64 blocks at H = 1024), 16 waves split K = 4H:
+//   phase 1: dh_rec[b][j] = sum_r dgates_{s+1}[b][r] * W_hh[r][j]      (fragment-order bf16 operands, full K)
+//   phase 2: the LSTM cell backward of step s for the SAME 16 units (they need only this block's dh_rec), writing
+//            dgx (fp32, for the batched weight/input-gradient GEMMs) and dgates_s in fragment order for the next launch.
+// The gate/cell/dy loads of phase 2 stream from HBM and are issued before phase 1 so their latency hides under it.
+template <int MT, int G>
+__global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) {
+    __shared__ float red[16][MT * 16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    const int H = p.H, B = p.B;
+    const int j0 = blockIdx.x * 16;
+
+    const int eb = tid >> 4, jl = tid & 15, eu = j0 + jl;
+    const bool ev = (tid < MT * 256) && eb < B;
+    bool active = false;
+    int t = p.s;
+    float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c_t = 0.f, c_prev = 0.f, dyv = 0.f, dcc = 0.f;
+    if (ev) {
+        const int len = p.lens[eb];
+        active = p.s < len;
+        if (active) {
+            t = p.reverse ? (len - 1 - p.s) : p.s;
+            const size_t row = (size_t)t * B + eb;
+            const float* gp = p.gates + row * 4 * H + eu;
+            ig = gp[0]; fg = gp[(size_t)H]; gg = gp[(size_t)2 * H]; og = gp[(size_t)3 * H];
+            c_t = p.cell[row * H + eu];
+            if (p.s > 0) {
+                const int tp = p.reverse ? t + 1 : t - 1;
+                c_prev = p.cell[((size_t)tp * B + eb) * H + eu];
+            }
+            dyv = p.dy[row * p.ldy + eu];
+            dcc = p.dc_carry[(size_t)eb * H + eu];
+        }
+    }
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        const int nchunk = (4 * H) >> 5;
+        skinny_bf16<MT, G>(reinterpret_cast<const bf16x8*>(p.dafrag_prev),
+                           reinterpret_cast<const bf16x8*>(p.wTfrag) + (size_t)blockIdx.x * nchunk * 64, nchunk, wave, 16, lane, acc);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][m * 16 + kg * 4 + r][li] = acc[m][r];
+    __syncthreads();
+    if (!ev) return;
+
+    float da[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        float dh = dyv;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) dh += red[w][eb][jl];
+        const float tc = tanhf(c_t);
+        const float dc = dh * og * (1.f - tc * tc) + dcc;
+        p.dc_carry[(size_t)eb * H + eu] = dc * fg;
+        da[0] = dc * gg * ig * (1.f - ig);
+        da[1] = dc * c_prev * fg * (1.f - fg);
+        da[2] = dc * ig * (1.f - gg * gg);
+        da[3] = dh * tc * og * (1.f - og);
+    }
+    float* dg = p.dgx + ((size_t)t * B + eb) * 4 * H + eu;      // inactive: t == s is a pad row -> zeros
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        dg[(size_t)g * H] = da[g];
+        p.dafrag_next[frag_index(eb, g * H + eu, MT)] = f2bf(da[g]);
     }
 }
 
@@ -223,25 +340,80 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
     }
 }
 
-template <int MODE>
-void launch_fwd(const FwdP& p, int mt, dim3 grid, hipStream_t st) {
-    if (mt == 1) hipLaunchKernelGGL((lstm_fwd_step<MODE, 1>), grid, dim3(256), 0, st, p);
-    else if (mt == 2) hipLaunchKernelGGL((lstm_fwd_step<MODE, 2>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((lstm_fwd_step<MODE, 4>), grid, dim3(256), 0, st, p);
+// W_hh [4H][H] fp32 -> forward fragment image [H/4][H/32][64][8] bf16:
+//   block jb, chunk c, lane (kg,li), e  <-  W_hh[(li>>2)*H + jb*4 + (li&3)][c*32 + kg*8 + e]
+__global__ void make_wfrag_fwd(const float* __restrict__ w, unsigned short* __restrict__ out, int H) {
+    const size_t total = (size_t)4 * H * H;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const size_t rest = i >> 9;
+        const int nchunk = H >> 5;
+        const int c = (int)(rest % nchunk), jb = (int)(rest / nchunk);
+        const int li = lane & 15, kg = lane >> 4;
+        const size_t row = (size_t)(li >> 2) * H + jb * 4 + (li & 3);
+        out[i] = f2bf(w[row * H + c * 32 + kg * 8 + e]);
+    }
 }
-template <int MODE>
+// W_hh [4H][H] fp32 -> backward fragment image [H/16][4H/32][64][8] bf16:
+//   tile jt, chunk c (over r = 0..4H), lane (kg,li), e  <-  W_hh[c*32 + kg*8 + e][jt*16 + li]
+__global__ void make_wfrag_bwd(const float* __restrict__ w, unsigned short* __restrict__ out, int H) {
+    const size_t total = (size_t)4 * H * H;
+    const int nchunk = (4 * H) >> 5;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const size_t rest = i >> 9;
+        const int c = (int)(rest % nchunk), jt = (int)(rest / nchunk);
+        const int li = lane & 15, kg = lane >> 4;
+        const size_t r = (size_t)c * 32 + kg * 8 + e;
+        out[i] = f2bf(w[r * H + jt * 16 + li]);
+    }
+}
+
+template <int MODE, int G>
+void launch_fwd_g(const FwdP& p, int mt, dim3 grid, hipStream_t st) {
+    if (mt == 1) hipLaunchKernelGGL((lstm_fwd_step<MODE, 1, G>), grid, dim3(256), 0, st, p);
+    else if (mt == 2) hipLaunchKernelGGL((lstm_fwd_step<MODE, 2, G>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((lstm_fwd_step<MODE, 4, G>), grid, dim3(256), 0, st, p);
+}
+void launch_fwd(const FwdP& p, bool fast, int g, int mt, dim3 grid, hipStream_t st) {
+    if (!fast) { launch_fwd_g<0, 1>(p, mt, grid, st); return; }
+    if (g == 8 && mt <= 2) launch_fwd_g<1, 8>(p, mt, grid, st);     // 8 chunks x MT<=2 fragments fit the 256-thread VGPR budget
+    else if (g >= 4) launch_fwd_g<1, 4>(p, mt, grid, st);
+    else if (g == 2) launch_fwd_g<1, 2>(p, mt, grid, st);
+    else launch_fwd_g<1, 1>(p, mt, grid, st);
+}
+template <int G>
+void launch_bwd_fused_g(const BwdP& p, int mt, dim3 grid, hipStream_t st) {
+    if (mt == 1) hipLaunchKernelGGL((lstm_bwd_step_bf16<1, G>), grid, dim3(1024), 0, st, p);
+    else if (mt == 2) hipLaunchKernelGGL((lstm_bwd_step_bf16<2, G>), grid, dim3(1024), 0, st, p);
+    else hipLaunchKernelGGL((lstm_bwd_step_bf16<4, G>), grid, dim3(1024), 0, st, p);
+}
+void launch_bwd_fused(const BwdP& p, int g, int mt, dim3 grid, hipStream_t st) {
+    if (g >= 4 && mt <= 2) launch_bwd_fused_g<4>(p, mt, grid, st);
+    else if (g >= 2) launch_bwd_fused_g<2>(p, mt, grid, st);
+    else launch_bwd_fused_g<1>(p, mt, grid, st);
+}
 void launch_bwd_mm(const BwdP& p, int mt, dim3 grid, hipStream_t st) {
-    if (mt == 1) hipLaunchKernelGGL((lstm_bwd_matmul<MODE, 1>), grid, dim3(256), 0, st, p);
-    else if (mt == 2) hipLaunchKernelGGL((lstm_bwd_matmul<MODE, 2>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((lstm_bwd_matmul<MODE, 4>), grid, dim3(256), 0, st, p);
+    if (mt == 1) hipLaunchKernelGGL((lstm_bwd_matmul<1>), grid, dim3(256), 0, st, p);
+    else if (mt == 2) hipLaunchKernelGGL((lstm_bwd_matmul<2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((lstm_bwd_matmul<4>), grid, dim3(256), 0, st, p);
 }
+
+inline size_t al256(size_t v) { return (v + 255) & ~size_t(255); }
+// fragment path: every wave gets the same number of 32-wide k-chunks (fwd: H/32 over 4 waves, bwd: 4H/32 over 16 waves)
+inline bool fast_bf16(int mode, int H) { return mode == FT_BF16 && (H % 128) == 0; }
+inline int group_of(int per_wave) { return (per_wave % 8 == 0) ? 8 : (per_wave % 4 == 0) ? 4 : (per_wave % 2 == 0) ? 2 : 1; }
 
 }  // namespace
 
 extern "C" size_t ft_lstm_workspace_bytes(int B, int H) {
-    size_t fwd = (size_t)3 * B * H;
-    size_t bwd = (size_t)B * 4 * H + (size_t)4 * B * H + (size_t)B * H + (size_t)4 * H * H;
-    return sizeof(float) * (fwd > bwd ? fwd : bwd);
+    const size_t BH = (size_t)B * H;
+    const int mt = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    const size_t frag_act = (size_t)mt * 16 * H * 2;                 // one [B_pad, H] bf16 fragment image
+    const size_t wfrag = (size_t)4 * H * H * 2;
+    const size_t fwd = al256(3 * BH * 4) + al256(2 * frag_act) + al256(wfrag);
+    const size_t bwd = al256(9 * BH * 4) + al256((size_t)4 * H * H * 4) + al256(8 * frag_act) + al256(wfrag);
+    return fwd > bwd ? fwd : bwd;
 }
 
 extern "C" int ft_lstm_seq_fwd(const float* gx, const float* w_hh, const int32_t* lens,
@@ -251,19 +423,27 @@ extern "C" int ft_lstm_seq_fwd(const float* gx, const float* w_hh, const int32_t
     FT_CHECK_ARG(T >= 0 && B >= 1 && B <= 64 && H >= 4 && H % 4 == 0 && ldy >= H);
     FT_CHECK_ARG((gates == nullptr) == (cell == nullptr));
     FT_CHECK_ARG(mode == FT_F32 || mode == FT_BF16);
-    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(w_hh) % 16 == 0 && reinterpret_cast<uintptr_t>(work) % 16 == 0);
+    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(w_hh) % 16 == 0 && reinterpret_cast<uintptr_t>(work) % 256 == 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    float* w = reinterpret_cast<float*>(work);
     const size_t BH = (size_t)B * H;
+    const int mt = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    const bool fast = fast_bf16(mode, H);
+    const int g = group_of((H >> 5) / 4);
+    char* base = reinterpret_cast<char*>(work);
+    float* w = reinterpret_cast<float*>(base);
     float* hbuf[2] = {w, w + BH};
     float* cstate = w + 2 * BH;
-    FT_CHECK_HIP(hipMemsetAsync(w, 0, 3 * BH * sizeof(float), st));
-    const int mt = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    const size_t frag_act = (size_t)mt * 16 * H * 2;
+    unsigned short* hfrag[2] = {reinterpret_cast<unsigned short*>(base + al256(3 * BH * 4)),
+                                reinterpret_cast<unsigned short*>(base + al256(3 * BH * 4) + frag_act)};
+    unsigned short* wfrag = reinterpret_cast<unsigned short*>(base + al256(3 * BH * 4) + al256(2 * frag_act));
+    FT_CHECK_HIP(hipMemsetAsync(base, 0, al256(3 * BH * 4) + al256(2 * frag_act), st));
+    if (fast) hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H);
     dim3 grid(cdiv(H, 4));
     for (int s = 0; s < T; ++s) {
-        FwdP p{gx, w_hh, lens, hbuf[s & 1], hbuf[(s + 1) & 1], cstate, y, (long)ldy, gates, cell, s, T, B, H, reverse};
-        if (mode == FT_F32) launch_fwd<0>(p, mt, grid, st);
-        else launch_fwd<1>(p, mt, grid, st);
+        FwdP p{gx, w_hh, lens, hbuf[s & 1], hbuf[(s + 1) & 1], cstate, y, (long)ldy, gates, cell,
+               wfrag, hfrag[s & 1], hfrag[(s + 1) & 1], s, T, B, H, reverse};
+        launch_fwd(p, fast, g, mt, grid, st);
     }
     FT_CHECK_LAUNCH();
     return FT_OK;
@@ -275,24 +455,40 @@ extern "C" int ft_lstm_seq_bwd(const float* dy, int64_t ldy, const float* w_hh, 
     FT_CHECK_ARG(dy && w_hh && lens && gates && cell && dgx && work);
     FT_CHECK_ARG(T >= 0 && B >= 1 && B <= 64 && H >= 4 && H % 4 == 0 && ldy >= H);
     FT_CHECK_ARG(mode == FT_F32 || mode == FT_BF16);
-    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(work) % 16 == 0);
+    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(work) % 256 == 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    float* w = reinterpret_cast<float*>(work);
     const size_t BH = (size_t)B * H;
+    const int mt = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    const bool fast = fast_bf16(mode, H);
+    const int g = group_of(((4 * H) >> 5) / 16);
+    char* base = reinterpret_cast<char*>(work);
+    float* w = reinterpret_cast<float*>(base);
     float* da_cur = w;                 // [B][4H]
     float* part = w + 4 * BH;          // [4][B][H]
     float* dc_carry = w + 8 * BH;      // [B][H]
-    float* wT = w + 9 * BH;            // [H][4H]
-    FT_CHECK_HIP(hipMemsetAsync(w, 0, 9 * BH * sizeof(float), st));
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(H, 32), cdiv(4 * H, 32)), dim3(32, 8), 0, st, w_hh, wT, 4 * H, H);
-    const int mt = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
-    dim3 grid_pw(cdiv((int64_t)B * H, 256)), grid_mm(cdiv(H, 16), 4);
-    for (int s = T - 1; s >= 0; --s) {
-        BwdP p{dy, (long)ldy, lens, gates, cell, part, dc_carry, da_cur, dgx, wT, part, s, T, B, H, reverse};
-        hipLaunchKernelGGL(lstm_bwd_pointwise, grid_pw, dim3(256), 0, st, p);
-        if (s > 0) {
-            if (mode == FT_F32) launch_bwd_mm<0>(p, mt, grid_mm, st);
-            else launch_bwd_mm<1>(p, mt, grid_mm, st);
+    float* wT = reinterpret_cast<float*>(base + al256(9 * BH * 4));            // [H][4H]
+    const size_t frag_act = (size_t)mt * 16 * H * 2;
+    char* fr = base + al256(9 * BH * 4) + al256((size_t)4 * H * H * 4);
+    unsigned short* dafrag[2] = {reinterpret_cast<unsigned short*>(fr), reinterpret_cast<unsigned short*>(fr + 4 * frag_act)};
+    unsigned short* wTfrag = reinterpret_cast<unsigned short*>(fr + al256(8 * frag_act));
+    FT_CHECK_HIP(hipMemsetAsync(base, 0, al256(9 * BH * 4), st));
+    if (fast) {
+        FT_CHECK_HIP(hipMemsetAsync(fr, 0, al256(8 * frag_act), st));
+        hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H);
+        dim3 grid(H / 16);
+        for (int s = T - 1; s >= 0; --s) {
+            BwdP p{dy, (long)ldy, lens, gates, cell, part, dc_carry, da_cur, dgx, wT, part,
+                   dafrag[(s + 1) & 1], dafrag[s & 1], wTfrag, s, T, B, H, reverse};
+            launch_bwd_fused(p, g, mt, grid, st);
+        }
+    } else {
+        hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(H, 32), cdiv(4 * H, 32)), dim3(32, 8), 0, st, w_hh, wT, 4 * H, H);
+        dim3 grid_pw(cdiv((int64_t)B * H, 256)), grid_mm(cdiv(H, 16), 4);
+        for (int s = T - 1; s >= 0; --s) {
+            BwdP p{dy, (long)ldy, lens, gates, cell, part, dc_carry, da_cur, dgx, wT, part,
+                   nullptr, nullptr, nullptr, s, T, B, H, reverse};
+            hipLaunchKernelGGL(lstm_bwd_pointwise, grid_pw, dim3(256), 0, st, p);
+            if (s > 0) launch_bwd_mm(p, mt, grid_mm, st);
         }
     }
     FT_CHECK_LAUNCH();

@@ -446,3 +446,21 @@ class GateBCEFn(torch.autograd.Function):
         L.check(L.lib().ft_gate_bce_bwd(L.ptr(gate), L.ptr(target), L.ptr(lens), L.ptr(scale), 1.0, L.ptr(dgate), T, B, L.stream()),
                 "ft_gate_bce_bwd")
         return dgate, None, None
+
+
+# --------------------------------------------------------------------------
+# beta-binomial attention prior on device (data.py:31-41; the reference spends ~0.45 s/utterance in scipy)
+# --------------------------------------------------------------------------
+def beta_binomial_prior(in_lens, out_lens, T=None, Lk=None, scaling=1.0):
+    """-> [B,T,L] fp32 prior for a whole batch, zero padded like DataCollate (data.py:225-243)."""
+    L.require_cuda(in_lens, out_lens)
+    i32, o32 = lens32(in_lens), lens32(out_lens)
+    B = i32.numel()
+    if T is None:
+        T = int(out_lens.max())
+    if Lk is None:
+        Lk = int(in_lens.max())
+    prior = torch.empty(B, T, Lk, device=i32.device, dtype=torch.float32)
+    L.check(L.lib().ft_beta_binomial_prior(L.ptr(i32), L.ptr(o32), L.ptr(prior), B, T, Lk, float(scaling), L.stream()),
+            "ft_beta_binomial_prior")
+    return prior

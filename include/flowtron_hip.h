@@ -176,6 +176,12 @@ int ft_decode_flow(const ft_decode_args* a, void* stream);
 int ft_stft_mel(const float* y, const float* window, const float* fb, float* mel,
                 int B, int N, int n_fft, int hop, int n_mel, void* stream);
 
+/* ---- beta-binomial attention prior (data.py:31-41, 111-141) --------
+ * prior[b,t,k] = BetaBinom.pmf(k; n = in_lens[b]-1, a = scaling*(t+1), b = scaling*(out_lens[b]-t)) for
+ * t < out_lens[b], k < in_lens[b]; 0 in the padding.  [B,T,L] fp32, float64 lgamma inside. */
+int ft_beta_binomial_prior(const int32_t* in_lens, const int32_t* out_lens, float* prior,
+                           int B, int T, int L, float scaling, void* stream);
+
 /* ---- fused RAdam over a flat arena (radam.py:44-122) + grad-norm clip ---------- */
 int ft_sumsq(const float* x, float* acc, int64_t n, void* stream);
 int ft_radam_step(float* p, const float* g, float* m, float* v, int64_t n,

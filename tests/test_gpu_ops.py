@@ -208,19 +208,33 @@ def test_lstm_seq(env, T, B, I, H, lens, reverse):
         assert rel(mine.grad, r.grad) < 5e-5, (name, rel(mine.grad, r.grad))
 
 
-def test_lstm_seq_bf16_close(env):
+@pytest.mark.parametrize("T,B,H,reverse", [(12, 4, 128, False), (9, 20, 256, True), (7, 32, 1024, False), (5, 33, 512, False),
+                                             (6, 3, 96, False)])
+def test_lstm_seq_bf16_fragment_path(env, T, B, H, reverse):
+    """bf16-operand path (fragment-order W_hh / h / dgates, fused single-launch backward; H % 128 == 0) against the
+    fp32 oracle: bf16 operand rounding (2^-9 relative) bounds the error; H = 96 exercises the fp32 fall-back."""
     L, ops = env
     from oracle import flowtron_oracle as O
-    torch.manual_seed(5)
-    T, B, I, H = 12, 4, 24, 128
-    lens = torch.tensor([12, 9, 9, 3])
-    x = torch.randn(T, B, I)
+    torch.manual_seed(5 + H)
+    I = 24
+    lens = torch.randint(1, T + 1, (B,))
+    lens[0] = T
+    x = torch.randn(T, B, I, requires_grad=True)
     k = 1.0 / math.sqrt(H)
-    w_ih, w_hh = [(torch.rand(4 * H, n) * 2 * k - k) for n in (I, H)]
-    b = torch.zeros(4 * H)
-    ref = O.lstm_cell_seq(x, lens, w_ih, w_hh, b, b)
-    out = ops.lstm_layer(g(x), g(lens.int()), g(w_ih), g(w_hh), g(b), g(b), mode=1)
-    assert mad(out, ref) < 3e-2
+    w_ih, w_hh = [(torch.rand(4 * H, n) * 2 * k - k).requires_grad_(True) for n in (I, H)]
+    b_ih, b_hh = [(torch.rand(4 * H) * 2 * k - k).requires_grad_(True) for _ in range(2)]
+    O.LSTM_IMPL["fn"] = O.lstm_cell_seq
+    ref = O.lstm_cell_seq(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=reverse)
+    go = torch.randn_like(ref)
+    ref.backward(go)
+    d = [t.detach().cuda().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
+    out = ops.lstm_layer(d[0], g(lens.int()), d[1], d[2], d[3], d[4], reverse=reverse, mode=1)
+    out.backward(g(go))
+    assert mad(out, ref) < 3e-2, mad(out, ref)
+    m = O.length_mask(lens, T).t()[..., None]
+    assert float((out.cpu() * (~m)).abs().max()) == 0.0                 # pad rows are exactly zero
+    for mine, r, name in zip(d, (x, w_ih, w_hh, b_ih, b_hh), "x w_ih w_hh b_ih b_hh".split()):
+        assert rel(mine.grad, r.grad) < 3e-2, (name, rel(mine.grad, r.grad))
 
 
 # ---------------------------------------------------------------- attention
@@ -291,3 +305,16 @@ def test_sumsq_radam_colsum(env):
     x = torch.randn(1000, 37)
     cs_ = ops.colsum(g(x), 1000, 37, 37)
     assert mad(cs_, x.sum(0)) < 1e-3
+
+
+def test_beta_binomial_prior_vs_scipy_golden(env):
+    """data.py:31-41: golden values produced with scipy.stats.betabinom (tests/golden/make_golden.py)."""
+    import os
+    L, ops = env
+    gold = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prior.pt"), weights_only=False)
+    pr = ops.beta_binomial_prior(torch.tensor([13, 148]).cuda(), torch.tensor([40, 800]).cuda(), 800, 148)
+    assert pr.shape == (2, 800, 148)
+    assert mad(pr[0, :40, :13], gold["p13_m40"].float()) < 1e-7
+    assert float(pr[0, 40:].abs().max()) == 0.0 and float(pr[0, :, 13:].abs().max()) == 0.0
+    ref = gold["p148_m800_s50"].float()
+    assert ((pr[1, ::50].cpu() - ref).abs() / (ref + 1e-30)).max().item() < 1e-5       # relative: spans 170 decades
