@@ -38,12 +38,14 @@ static inline int ft_fail(int code, const char* fmt, ...) {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 
-// round-to-nearest-even fp32 -> bf16 (bit pattern in the low 16 bits)
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned int u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+// round-to-nearest-even fp32 -> bf16 through the gfx950 hardware converter (v_cvt_pk_bf16_f32)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+typedef __attribute__((ext_vector_type(2))) float f32x2_hw;
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    const f32x2_hw v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_hw));
 }
+__device__ __forceinline__ unsigned short f2bf(float f) { return (unsigned short)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 

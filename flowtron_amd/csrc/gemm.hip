@@ -24,6 +24,7 @@ struct GemmP {
     long sAm, sAk, sBk, sBn, ldc, bsA, bsB, bsC;
     float alpha, beta;
     int act, amode, bmode;
+    int gx, gy, splits, kchunk;   // tile grid, split-K factor and K elements per split (multiple of BK)
 };
 
 // Load one 128 x 32 operand tile (rows r0.., reduction k0..) into 16 registers/thread.
@@ -90,8 +91,8 @@ __device__ __forceinline__ void store_tile(void* lds, int tid, const float (&reg
             } else {
                 unsigned short* p = reinterpret_cast<unsigned short*>(lds) + row * LDH + kc;
                 uint2 w;
-                w.x = (unsigned)f2bf(reg[j * 4]) | ((unsigned)f2bf(reg[j * 4 + 1]) << 16);
-                w.y = (unsigned)f2bf(reg[j * 4 + 2]) | ((unsigned)f2bf(reg[j * 4 + 3]) << 16);
+                w.x = pack_bf16x2(reg[j * 4], reg[j * 4 + 1]);
+                w.y = pack_bf16x2(reg[j * 4 + 2], reg[j * 4 + 3]);
                 *reinterpret_cast<uint2*>(p) = w;
             }
         }
@@ -117,7 +118,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, kg = lane >> 4;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroup L runs on XCD L % 8 (observed round-robin dispatch); give every XCD a
+    // contiguous run of tiles (x fastest) so the tiles that share an A row-panel hit the same 4 MiB L2.
+    int tile = blockIdx.x;
+    {
+        const int total = p.gx * p.gy, q = total >> 3, r = total & 7;
+        const int xcd = tile & 7, idx = tile >> 3;
+        tile = xcd * q + (xcd < r ? xcd : r) + idx;
+    }
+    const int m0 = (tile / p.gx) * BM, n0 = (tile % p.gx) * BN;
+    const int kbeg = blockIdx.y * p.kchunk;
+    const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
     const long bz = blockIdx.z;
     const float* A = p.A + bz * p.bsA;
     const float* B = p.B + bz * p.bsB;
@@ -130,17 +141,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float ra[16], rb[16];
-    load_tile<AMODE>(A, p.sAm, p.sAk, p.M, p.K, m0, 0, tid, ra);
-    load_tile<BMODE>(B, p.sBn, p.sBk, p.N, p.K, n0, 0, tid, rb);
+    load_tile<AMODE>(A, p.sAm, p.sAk, p.M, kend, m0, kbeg, tid, ra);
+    load_tile<BMODE>(B, p.sBn, p.sBk, p.N, kend, n0, kbeg, tid, rb);
 
-    for (int k0 = 0; k0 < p.K; k0 += BK) {
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();                         // previous tile fully consumed
         store_tile<MODE, AMODE>(As, tid, ra);
         store_tile<MODE, BMODE>(Bs, tid, rb);
         __syncthreads();
-        if (k0 + BK < p.K) {                     // prefetch next tile while computing
-            load_tile<AMODE>(A, p.sAm, p.sAk, p.M, p.K, m0, k0 + BK, tid, ra);
-            load_tile<BMODE>(B, p.sBn, p.sBk, p.N, p.K, n0, k0 + BK, tid, rb);
+        if (k0 + BK < kend) {                    // prefetch next tile while computing
+            load_tile<AMODE>(A, p.sAm, p.sAk, p.M, kend, m0, k0 + BK, tid, ra);
+            load_tile<BMODE>(B, p.sBn, p.sBk, p.N, kend, n0, k0 + BK, tid, rb);
         }
         if constexpr (MODE == 0) {
             const float* Af = reinterpret_cast<const float*>(As) + (wm * 64 + li) * LDF + kg * 4;
@@ -191,6 +202,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 if (col >= p.N) continue;
                 float* cp = C + (long)row * p.ldc + col;
                 float v = p.alpha * acc[i][j][r];
+                if (p.splits > 1) {              // split-K: C was zeroed (beta == 0) or holds the addend (beta == 1)
+                    if (p.bias && blockIdx.y == 0) v += p.bias[col];
+                    atomicAdd(cp, v);
+                    continue;
+                }
                 if (p.beta != 0.f) v += p.beta * (*cp);
                 if (p.bias) v += p.bias[col];
                 if (p.act == FT_ACT_TANH) v = tanhf_(v);
@@ -244,9 +260,25 @@ extern "C" int ft_gemm(const ft_gemm_args* a, void* stream) {
     p.alpha = a->alpha; p.beta = a->beta; p.act = a->act;
     p.amode = pick_mode(a->A, a->sAm, a->sAk, a->bsA, a->batch);
     p.bmode = pick_mode(a->B, a->sBn, a->sBk, a->bsB, a->batch);
-    dim3 grid(cdiv(a->N, BN), cdiv(a->M, BM), a->batch);
-    FT_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535);
+    p.gx = cdiv(a->N, BN); p.gy = cdiv(a->M, BM);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // split-K for GEMMs with few output tiles and a long reduction (weight gradients: K = T*B rows): partial
+    // products are combined with fp32 global atomics into a zeroed (beta 0) or pre-loaded (beta 1) C.
+    p.splits = 1;
+    const long tiles = (long)p.gx * p.gy * a->batch;
+    if (a->act == FT_ACT_NONE && (a->beta == 0.f || a->beta == 1.f) && a->batch == 1 && a->K >= 2048 && tiles < 512) {
+        long s = 768 / tiles;
+        const long smax = a->K / 512;
+        if (s > smax) s = smax;
+        if (s > 64) s = 64;
+        if (s > 1) p.splits = (int)s;
+    }
+    p.kchunk = cdiv(cdiv(a->K, BK), p.splits) * BK;
+    p.splits = cdiv(a->K, p.kchunk);
+    if (p.splits > 1 && a->beta == 0.f)
+        FT_CHECK_HIP(hipMemset2DAsync(a->C, sizeof(float) * a->ldc, 0, sizeof(float) * a->N, a->M, st));
+    dim3 grid(p.gx * p.gy, p.splits, a->batch);
+    FT_CHECK_ARG(grid.z <= 65535);
     if (a->mode == FT_F32) launch_a<0>(p, grid, st);
     else launch_a<1>(p, grid, st);
     FT_CHECK_LAUNCH();

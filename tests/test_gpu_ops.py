@@ -318,3 +318,20 @@ def test_beta_binomial_prior_vs_scipy_golden(env):
     assert float(pr[0, 40:].abs().max()) == 0.0 and float(pr[0, :, 13:].abs().max()) == 0.0
     ref = gold["p148_m800_s50"].float()
     assert ((pr[1, ::50].cpu() - ref).abs() / (ref + 1e-30)).max().item() < 1e-5       # relative: spans 170 decades
+
+
+@pytest.mark.parametrize("beta", [0.0, 1.0])
+def test_gemm_split_k_weight_gradient_shape(env, beta):
+    """few output tiles + long reduction (dW = dpre^T x over T*B rows) takes the split-K / atomic path."""
+    L, ops = env
+    torch.manual_seed(12)
+    rows, N, K = 6000, 130, 200                       # C [N,K] = A^T B, reduction over rows
+    dpre, x = torch.randn(rows, N), torch.randn(rows, K)
+    bias = torch.randn(K)
+    C0 = torch.randn(N, K + 7)                         # strided output (row-block of a wider weight gradient)
+    ref = (dpre.double().t() @ x.double()).float() / 64 + bias + beta * C0[:, 3:3 + K]
+    Cd = g(C0.clone())
+    ops.gemm_raw(g(dpre), g(x), Cd[:, 3:], N, K, rows, 1, N, K, 1, K + 7, bias=g(bias), alpha=1.0 / 64, beta=beta, mode=0)
+    torch.cuda.synchronize()
+    assert mad(Cd[:, 3:3 + K], ref) < 2e-4
+    assert torch.equal(Cd[:, :3].cpu(), C0[:, :3]) and torch.equal(Cd[:, 3 + K:].cpu(), C0[:, 3 + K:])   # neighbours untouched
