@@ -51,6 +51,37 @@ __device__ __forceinline__ float dot_seg(const float* __restrict__ w, const floa
     return s;
 }
 
+// Four weight rows (stride gstride floats apart) against one activation segment, all U*5 16-byte loads of a pass in
+// flight before the FMAs (a decode GEMV is a pure weight stream: bytes in flight per CU decide the rate).
+// Requires K % 4 == 0 and 16-byte aligned w / x.  Out-of-range lanes read element 0 against a zero activation.
+template <int U>
+__device__ __forceinline__ void dot4_seg(const float* __restrict__ w, size_t gstride, const float* __restrict__ x, int K,
+                                         int lane, float (&acc)[4]) {
+    const int K4 = K >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int kb = 0; kb < K4; kb += 64 * U) {
+        float4 xv[U], wv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = kb + u * 64 + lane;
+            const bool ok = k < K4;
+            const int kk = ok ? k : 0;
+            xv[u] = x4[kk];
+            if (!ok) xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wv[u][g] = reinterpret_cast<const float4*>(w + (size_t)g * gstride)[kk];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                acc[g] += wv[u][g].x * xv[u].x + wv[u][g].y * xv[u].y + wv[u][g].z * xv[u].z + wv[u][g].w * xv[u].w;
+    }
+}
+
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 __device__ __forceinline__ bool frame_live(const DecodeDev* P, int& i) {
     i = P->ctl[0];
     return (P->ctl[1] == 0) && (i < P->N);
@@ -82,13 +113,27 @@ __global__ __launch_bounds__(256) void dec_lstm_k(const DecodeDev* __restrict__ 
     const float* hold = hbuf + par * H;
     const int Kin = K0 + K1;
     float pre[4];
+    const bool vec = (((Kin | K0 | K1 | H) & 3) == 0) && aligned16(w_ih) && aligned16(w_hh) && aligned16(x0) &&
+                     aligned16(hold) && (K1 == 0 || aligned16(x1));
+    if (vec) {           // the four gate rows of unit u stream together
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        dot4_seg<4>(w_ih + (size_t)u * Kin, (size_t)H * Kin, x0, K0, lane, acc);
+        if (K1) dot4_seg<4>(w_ih + (size_t)u * Kin + K0, (size_t)H * Kin, x1, K1, lane, acc);
+        dot4_seg<4>(w_hh + (size_t)u * H, (size_t)H * H, hold, H, lane, acc);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const size_t row = (size_t)g * H + u;
-        float s = dot_seg(w_ih + row * Kin, x0, K0, lane);
-        if (K1) s += dot_seg(w_ih + row * Kin + K0, x1, K1, lane);
-        s += dot_seg(w_hh + row * H, hold, H, lane);
-        pre[g] = wave_sum(s) + b_ih[row] + b_hh[row];
+        for (int g = 0; g < 4; ++g) {
+            const size_t row = (size_t)g * H + u;
+            pre[g] = wave_sum(acc[g]) + b_ih[row] + b_hh[row];
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const size_t row = (size_t)g * H + u;
+            float s = dot_seg(w_ih + row * Kin, x0, K0, lane);
+            if (K1) s += dot_seg(w_ih + row * Kin + K0, x1, K1, lane);
+            s += dot_seg(w_hh + row * H, hold, H, lane);
+            pre[g] = wave_sum(s) + b_ih[row] + b_hh[row];
+        }
     }
     if (lane == 0) {
         const float ig = 1.f / (1.f + expf(-pre[0]));
