@@ -48,11 +48,11 @@ __device__ __forceinline__ void skinny_f32(const float* const (&arow)[MT], const
 // bf16 fragment-order operands: wfrag -> [nchunk][64 lanes][8 bf16], afrag -> [nchunk][MT][64][8].
 // Chunks c0, c0+cs, ... ; G chunks are loaded back-to-back (all loads in flight) before their MFMAs issue, so a
 // wave pays the L2 round trip once per group instead of once per chunk.  Needs ((nchunk - c0) / cs) % G == 0.
-template <int MT, int G>
+template <int MT, int G, typename Hook>
 __device__ __forceinline__ void skinny_bf16(const bf16x8* __restrict__ afrag, const bf16x8* __restrict__ wfrag,
-                                            int nchunk, int c0, int cs, int lane, f32x4 (&acc)[MT]) {
-    for (int cb = c0; cb < nchunk; cb += cs * G) {
-        bf16x8 w[G], a[G][MT];
+                                            int nchunk, int c0, int cs, int lane, f32x4 (&acc)[MT], Hook&& after_last_loads) {
+    bf16x8 w[G], a[G][MT];
+    auto load_group = [&](int cb) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const size_t c = (size_t)(cb + i * cs);
@@ -60,12 +60,24 @@ __device__ __forceinline__ void skinny_bf16(const bf16x8* __restrict__ afrag, co
 #pragma unroll
             for (int m = 0; m < MT; ++m) a[i][m] = afrag[(c * MT + m) * 64 + lane];
         }
-        __builtin_amdgcn_sched_barrier(0);      // keep all G*(1+MT) loads in flight: hipcc otherwise sinks them between the MFMAs
+    };
+    auto mfma_group = [&]() {
 #pragma unroll
         for (int i = 0; i < G; ++i)
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w[i], acc[m], 0, 0, 0);
+    };
+    load_group(c0);
+    for (int cb = c0 + cs * G; cb < nchunk; cb += cs * G) {      // (H = 1024: a single group, this loop is empty)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group();
+        load_group(cb);
     }
+    // Straight-line from here: the caller's (HBM-latency) loads are issued BEHIND the last fragment group.  vmcnt
+    // retires in order, so no fragment wait below ever includes them, and the compiler can count them exactly.
+    after_last_loads();
+    __builtin_amdgcn_sched_barrier(0);      // keep every load above in flight: hipcc otherwise sinks them between the MFMAs
+    mfma_group();
 }
 
 // element (b, k) of a [B, K] activation in fragment order
@@ -83,7 +95,7 @@ struct FwdP {
     int s, T, B, H, reverse;
 };
 
-template <int MODE, int MT, int G>
+template <int MODE, int MT, int G, bool REV>
 __global__ __launch_bounds__(256) void lstm_fwd_step(FwdP p) {
     __shared__ float red[4][MT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -91,29 +103,36 @@ __global__ __launch_bounds__(256) void lstm_fwd_step(FwdP p) {
     const int u0 = blockIdx.x * 4;
     const int H = p.H, B = p.B;
 
-    // epilogue role of this thread: batch row b, unit u -- issue its gx / c loads before the matmul
-    const int eb = tid >> 2, ul = tid & 3, eu = u0 + ul;
-    const bool ev = eb < B && eu < H;
-    int len = 0, t = 0;
-    bool active = false;
-    float gxv[4] = {0.f, 0.f, 0.f, 0.f};
-    float c_old = 0.f;
-    if (ev) {
-        len = p.lens[eb];
-        active = p.s < len;
-        if (active) {
-            t = p.reverse ? (len - 1 - p.s) : p.s;
-            const float* gp = p.gx + ((size_t)t * B + eb) * 4 * H + eu;
+    // Roles.  Threads 0..MT*64-1 own one (batch row, unit) of the cell update; their operands (gx row, cell state)
+    // stream from HBM.  With B <= 32 the upper half of the workgroup has no cell role: it touches the gx sectors of
+    // step s+1 instead, so that the SAME workgroup (same XCD, same L2) finds them in L2 one launch later.
+    // Every thread issues the SAME five loads (addresses clamped in range, no divergent branch): the compiler can then
+    // count them, and because vmcnt retires in order and they are issued BEHIND the fragment loads, no fragment wait
+    // ever includes their HBM round trip.
+    constexpr int NROLE = MT * 64;
+    const bool pf_role = (MT <= 2) && tid >= NROLE;
+    const int rr = pf_role ? tid - NROLE : tid;
+    const int eb = rr >> 2, ul = rr & 3, eu = u0 + ul;
+    const bool ev = !pf_role && tid < NROLE && eb < B && eu < H;
+    const int ebc = eb < B ? eb : B - 1, euc = eu < H ? eu : H - 1;
+    int len;
+    float gxv[4], c_old;
+    auto issue_epilogue_loads = [&]() {
+        len = p.lens[ebc];
+        int t_ld;                                 // forward direction: row s (s+1 for the warm-up lanes), independent of len
+        if constexpr (!REV) t_ld = (pf_role && p.s + 1 < p.T) ? p.s + 1 : p.s;
+        else t_ld = (p.s < len) ? (len - 1 - p.s) : 0;
+        const float* gp = p.gx + ((size_t)t_ld * B + ebc) * 4 * H + euc;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) gxv[g] = gp[(size_t)g * H];
-            c_old = p.cstate[(size_t)eb * H + eu];
-        }
-    }
+        for (int g = 0; g < 4; ++g) gxv[g] = gp[(size_t)g * H];
+        c_old = p.cstate[(size_t)ebc * H + euc];
+    };
 
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (MODE == 0) {
+        issue_epilogue_loads();
         // B operand row for this lane: n = li = gate*4 + ul  ->  W_hh row gate*H + u0 + ul
         const int wu = u0 + (li & 3);
         const float* wrow = (wu < H) ? p.w_hh + (size_t)((li >> 2) * H + wu) * H : nullptr;
@@ -127,13 +146,17 @@ __global__ __launch_bounds__(256) void lstm_fwd_step(FwdP p) {
     } else {
         const int nchunk = H >> 5;
         skinny_bf16<MT, G>(reinterpret_cast<const bf16x8*>(p.hfrag_prev),
-                           reinterpret_cast<const bf16x8*>(p.wfrag) + (size_t)blockIdx.x * nchunk * 64, nchunk, wave, 4, lane, acc);
+                           reinterpret_cast<const bf16x8*>(p.wfrag) + (size_t)blockIdx.x * nchunk * 64, nchunk, wave, 4, lane, acc,
+                           issue_epilogue_loads);
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][m * 16 + kg * 4 + r][li] = acc[m][r];
     __syncthreads();
+    asm volatile("" ::"v"(gxv[0]), "v"(gxv[1]), "v"(gxv[2]), "v"(gxv[3]), "v"(c_old));   // prefetch lanes: keep the loads
+    const bool active = p.s < len;
+    const int t = REV ? (active ? (len - 1 - p.s) : 0) : p.s;
 
     if (!ev) return;
     const size_t bu = (size_t)eb * H + eu;
@@ -258,7 +281,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_matmul(BwdP p) {
 //   phase 2: the LSTM cell backward of step s for the SAME 16 units (they need only this block's dh_rec), writing
 //            dgx (fp32, for the batched weight/input-gradient GEMMs) and dgates_s in fragment order for the next launch.
 // The gate/cell/dy loads of phase 2 stream from HBM and are issued before phase 1 so their latency hides under it.
-template <int MT, int G>
+template <int MT, int G, bool REV>
 __global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) {
     __shared__ float red[16][MT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -266,28 +289,31 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) {
     const int H = p.H, B = p.B;
     const int j0 = blockIdx.x * 16;
 
-    const int eb = tid >> 4, jl = tid & 15, eu = j0 + jl;
-    const bool ev = (tid < MT * 256) && eb < B;
-    bool active = false;
-    int t = p.s;
-    float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c_t = 0.f, c_prev = 0.f, dyv = 0.f, dcc = 0.f;
-    if (ev) {
-        const int len = p.lens[eb];
-        active = p.s < len;
-        if (active) {
-            t = p.reverse ? (len - 1 - p.s) : p.s;
-            const size_t row = (size_t)t * B + eb;
-            const float* gp = p.gates + row * 4 * H + eu;
-            ig = gp[0]; fg = gp[(size_t)H]; gg = gp[(size_t)2 * H]; og = gp[(size_t)3 * H];
-            c_t = p.cell[row * H + eu];
-            if (p.s > 0) {
-                const int tp = p.reverse ? t + 1 : t - 1;
-                c_prev = p.cell[((size_t)tp * B + eb) * H + eu];
-            }
-            dyv = p.dy[row * p.ldy + eu];
-            dcc = p.dc_carry[(size_t)eb * H + eu];
-        }
-    }
+    // Roles as in the forward kernel: threads 0..MT*256-1 own one (batch row, unit) of the cell backward of step s; the
+    // remaining waves (B <= 32) run the identical load sequence for step s-1 to warm this XCD's L2 for the next launch.
+    constexpr int NROLE = MT * 256;
+    const bool pf_role = (MT <= 2) && tid >= NROLE;
+    const int rr = pf_role ? tid - NROLE : tid;
+    const int eb = rr >> 4, jl = rr & 15, eu = j0 + jl;
+    const bool ev = !pf_role && tid < NROLE && eb < B;
+    const int ebc = eb < B ? eb : B - 1;
+    int len;
+    float ig, fg, gg, og, c_t, c_prev, dyv, dcc;
+    auto issue_epilogue_loads = [&]() {          // saved gates / cell / dy stream from HBM: issued behind the fragment loads
+        len = p.lens[ebc];
+        int t_ld;                                 // forward direction: row s (s-1 for the warm-up lanes), independent of len
+        if constexpr (!REV) t_ld = (pf_role && p.s >= 1) ? p.s - 1 : p.s;
+        else t_ld = (p.s < len) ? (len - 1 - p.s) : p.s;
+        int tp = REV ? t_ld + 1 : t_ld - 1;                 // previous step's time index (for c_{t-1})
+        tp = tp < 0 ? 0 : (tp > p.T - 1 ? p.T - 1 : tp);
+        const size_t row = (size_t)t_ld * B + ebc;
+        const float* gp = p.gates + row * 4 * H + eu;
+        ig = gp[0]; fg = gp[(size_t)H]; gg = gp[(size_t)2 * H]; og = gp[(size_t)3 * H];
+        c_t = p.cell[row * H + eu];
+        c_prev = p.cell[((size_t)tp * B + ebc) * H + eu];
+        dyv = p.dy[row * p.ldy + eu];
+        dcc = p.dc_carry[(size_t)ebc * H + eu];
+    };
 
     f32x4 acc[MT];
 #pragma unroll
@@ -295,14 +321,19 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) {
     {
         const int nchunk = (4 * H) >> 5;
         skinny_bf16<MT, G>(reinterpret_cast<const bf16x8*>(p.dafrag_prev),
-                           reinterpret_cast<const bf16x8*>(p.wTfrag) + (size_t)blockIdx.x * nchunk * 64, nchunk, wave, 16, lane, acc);
+                           reinterpret_cast<const bf16x8*>(p.wTfrag) + (size_t)blockIdx.x * nchunk * 64, nchunk, wave, 16, lane, acc,
+                           issue_epilogue_loads);
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][m * 16 + kg * 4 + r][li] = acc[m][r];
     __syncthreads();
+    asm volatile("" ::"v"(ig), "v"(fg), "v"(gg), "v"(og), "v"(c_t), "v"(c_prev), "v"(dyv), "v"(dcc));   // prefetch lanes: keep the loads
     if (!ev) return;
+    if (p.s == 0) c_prev = 0.f;
+    const bool active = p.s < len;
+    int t = REV ? (active ? (len - 1 - p.s) : p.s) : p.s;
 
     float da[4] = {0.f, 0.f, 0.f, 0.f};
     if (active) {
@@ -317,7 +348,8 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) {
         da[2] = dc * ig * (1.f - gg * gg);
         da[3] = dh * tc * og * (1.f - og);
     }
-    float* dg = p.dgx + ((size_t)t * B + eb) * 4 * H + eu;      // inactive: t == s is a pad row -> zeros
+    if (!active) t = p.s;                                        // inactive: row s is a pad row -> zeros
+    float* dg = p.dgx + ((size_t)t * B + eb) * 4 * H + eu;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         dg[(size_t)g * H] = da[g];
@@ -369,11 +401,16 @@ __global__ void make_wfrag_bwd(const float* __restrict__ w, unsigned short* __re
     }
 }
 
+template <int MODE, int G, bool REV>
+void launch_fwd_r(const FwdP& p, int mt, dim3 grid, hipStream_t st) {
+    if (mt == 1) hipLaunchKernelGGL((lstm_fwd_step<MODE, 1, G, REV>), grid, dim3(256), 0, st, p);
+    else if (mt == 2) hipLaunchKernelGGL((lstm_fwd_step<MODE, 2, G, REV>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((lstm_fwd_step<MODE, 4, G, REV>), grid, dim3(256), 0, st, p);
+}
 template <int MODE, int G>
 void launch_fwd_g(const FwdP& p, int mt, dim3 grid, hipStream_t st) {
-    if (mt == 1) hipLaunchKernelGGL((lstm_fwd_step<MODE, 1, G>), grid, dim3(256), 0, st, p);
-    else if (mt == 2) hipLaunchKernelGGL((lstm_fwd_step<MODE, 2, G>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((lstm_fwd_step<MODE, 4, G>), grid, dim3(256), 0, st, p);
+    if (p.reverse) launch_fwd_r<MODE, G, true>(p, mt, grid, st);
+    else launch_fwd_r<MODE, G, false>(p, mt, grid, st);
 }
 void launch_fwd(const FwdP& p, bool fast, int g, int mt, dim3 grid, hipStream_t st) {
     if (!fast) { launch_fwd_g<0, 1>(p, mt, grid, st); return; }
@@ -382,14 +419,19 @@ void launch_fwd(const FwdP& p, bool fast, int g, int mt, dim3 grid, hipStream_t 
     else if (g == 2) launch_fwd_g<1, 2>(p, mt, grid, st);
     else launch_fwd_g<1, 1>(p, mt, grid, st);
 }
+template <int G, bool REV>
+void launch_bwd_fused_r(const BwdP& p, int mt, dim3 grid, hipStream_t st) {
+    if (mt == 1) hipLaunchKernelGGL((lstm_bwd_step_bf16<1, G, REV>), grid, dim3(1024), 0, st, p);
+    else if (mt == 2) hipLaunchKernelGGL((lstm_bwd_step_bf16<2, G, REV>), grid, dim3(1024), 0, st, p);
+    else hipLaunchKernelGGL((lstm_bwd_step_bf16<4, G, REV>), grid, dim3(1024), 0, st, p);
+}
 template <int G>
 void launch_bwd_fused_g(const BwdP& p, int mt, dim3 grid, hipStream_t st) {
-    if (mt == 1) hipLaunchKernelGGL((lstm_bwd_step_bf16<1, G>), grid, dim3(1024), 0, st, p);
-    else if (mt == 2) hipLaunchKernelGGL((lstm_bwd_step_bf16<2, G>), grid, dim3(1024), 0, st, p);
-    else hipLaunchKernelGGL((lstm_bwd_step_bf16<4, G>), grid, dim3(1024), 0, st, p);
+    if (p.reverse) launch_bwd_fused_r<G, true>(p, mt, grid, st);
+    else launch_bwd_fused_r<G, false>(p, mt, grid, st);
 }
 void launch_bwd_fused(const BwdP& p, int g, int mt, dim3 grid, hipStream_t st) {
-    if (g >= 4 && mt <= 2) launch_bwd_fused_g<4>(p, mt, grid, st);
+    if (g >= 4 && mt <= 2) launch_bwd_fused_g<4>(p, mt, grid, st);   // G = 8 sits at the 128-VGPR cap of a 1024-thread block
     else if (g >= 2) launch_bwd_fused_g<2>(p, mt, grid, st);
     else launch_bwd_fused_g<1>(p, mt, grid, st);
 }
