@@ -1,0 +1,17 @@
+"""Aggregate a rocprofv3 --pmc counter_collection.csv into per-kernel averages (keeps profiles/ small)."""
+import csv, json, sys, collections
+path, out = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+with open(path) as f:
+    for r in csv.DictReader(f):
+        name = r.get("Kernel_Name") or r.get("Kernel Name") or r.get("kernel_name")
+        cn, cv = r.get("Counter_Name") or r.get("Counter Name"), r.get("Counter_Value") or r.get("Counter Value")
+        if name is None or cn is None:
+            continue
+        a = acc[name][cn]
+        a[0] += float(cv); a[1] += 1
+res = {k: {c: {"avg": v[0] / v[1], "dispatches": v[1]} for c, v in d.items()} for k, d in acc.items()}
+top = dict(sorted(res.items(), key=lambda kv: -max(x["avg"] * x["dispatches"] for x in kv[1].values()))[:25])
+json.dump(top, open(out, "w"), indent=1)
+for k, d in list(top.items())[:8]:
+    print(k[:90], {c: (round(v["avg"], 2), v["dispatches"]) for c, v in d.items()})
