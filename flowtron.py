@@ -9,10 +9,11 @@ flowtron_amd/ (HIP kernels behind the C ABI in include/flowtron_hip.h); there is
 """
 import torch
 
-from flowtron_amd.model import (AR_Back_Step, AR_Step, Attention, AttentionCTCLoss, ConvNorm, DenseLayer, Encoder,
+from flowtron_amd.model import (AR_Back_Step, AR_Step, Attention, AttentionConditioningLayer, AttentionCTCLoss, ConvNorm,
+                                DenseLayer, Encoder,
                                 Flowtron, FlowtronLoss, LinearNorm, MaskedInstanceNorm1d)
 
-for _cls in (AR_Back_Step, AR_Step, Attention, AttentionCTCLoss, ConvNorm, DenseLayer, Encoder, Flowtron,
+for _cls in (AR_Back_Step, AR_Step, Attention, AttentionConditioningLayer, AttentionCTCLoss, ConvNorm, DenseLayer, Encoder, Flowtron,
              FlowtronLoss, LinearNorm, MaskedInstanceNorm1d):
     _cls.__module__ = "flowtron"          # pickled checkpoints resolve `flowtron.<Class>`
 

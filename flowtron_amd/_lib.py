@@ -36,7 +36,8 @@ class DecodeArgs(C.Structure):
         "d0_w", "d0_b", "d1_w", "d1_b", "conv_w", "conv_b", "gate_w", "gate_b",
         "residual", "mel_out", "attn_out", "n_done_dev", "work")] + [
         ("work_bytes", _sz), ("N", _i), ("L", _i), ("H", _i), ("A", _i), ("M", _i),
-        ("temperature", _f), ("gate_threshold", _f), ("use_graph", _i)]
+        ("temperature", _f), ("gate_threshold", _f), ("use_graph", _i)] + [
+        (n, _p) for n in ("cond_w1", "cond_b1", "cond_w2", "cond_b2", "w_key", "enc")] + [("E", _i)]
 
 
 # name -> argtypes (every symbol include/flowtron_hip.h declares; checked by tests/test_abi.py)
@@ -64,8 +65,9 @@ SIGNATURES = {
     "ft_gate_bce_bwd": ([_p, _p, _p, _p, _f, _p, _i, _i, _p], _i),
     "ft_reverse_by_length": ([_p, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_act_bwd": ([_p, _p, _p, _l, _i, _p], _i),
+    "ft_eltwise": ([_p, _p, _p, _l, _i, _p], _i),
     "ft_colsum": ([_p, _p, _l, _i, _l, _p], _i),
-    "ft_decode_workspace_bytes": ([_i, _i, _i, _i], _sz),
+    "ft_decode_workspace_bytes": ([_i, _i, _i, _i, _i], _sz),
     "ft_decode_flow": ([C.POINTER(DecodeArgs), _p], _i),
     "ft_stft_mel": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "ft_beta_binomial_prior": ([_p, _p, _p, _i, _i, _i, _f, _p], _i),

@@ -30,8 +30,11 @@ struct DecodeDev {
     const float* residual; float* mel_out; float* attn_out; int* n_done_dev;
     float *h_att, *c_att, *h0, *c0, *h1, *c1;   // h_*: [2][H] ping-pong by frame parity
     float *q, *ctx, *u1, *u2, *prev;
+    // cumulative (location-sensitive) attention, flowtron.py:129-152, :793-806 -- all null when use_cumm_attention is off
+    const float *cond_w1, *cond_b1, *cond_w2, *cond_b2, *w_key, *enc;
+    float *cumm, *prev_attn, *keyin, *Kdyn;
     int* ctl;                                    // [0] frame index, [1] done flag
-    int N, L, H, A, M;
+    int N, L, H, A, M, E;
     float inv_temp, gate_threshold;
 };
 
@@ -181,8 +184,9 @@ __global__ __launch_bounds__(1024) void dec_attn_k(const DecodeDev* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int a = tid; a < A; a += 1024) qs[a] = P->q[a];
     __syncthreads();
+    const float* Kmat = P->Kdyn ? P->Kdyn : P->K;
     for (int l = wave; l < L; l += 16) {
-        const float* kr = P->K + (size_t)l * A;
+        const float* kr = Kmat + (size_t)l * A;
         float s = 0.f;
         for (int a = lane; a < A; a += 64) s += P->v[a] * tanhf(qs[a] + kr[a]);
         s = wave_sum(s);
@@ -207,7 +211,11 @@ __global__ __launch_bounds__(1024) void dec_attn_k(const DecodeDev* __restrict__
 #pragma unroll
     for (int w = 0; w < 16; ++w) s += red[w];
     float* arow = P->attn_out + (size_t)i * L;
-    for (int l = tid; l < L; l += 1024) arow[l] = e[l] / s;
+    for (int l = tid; l < L; l += 1024) {
+        const float pl = e[l] / s;
+        arow[l] = pl;
+        if (P->cumm) { P->prev_attn[l] = pl; P->cumm[l] += pl; }      // read by the NEXT frame's dec_cond_k
+    }
     const float inv = 1.f / s;
     for (int a = tid; a < A; a += 1024) {
         float c = 0.f;
@@ -215,6 +223,56 @@ __global__ __launch_bounds__(1024) void dec_attn_k(const DecodeDev* __restrict__
         P->ctx[a] = c;
     }
     (void)inv;
+}
+
+// Location features -> key modulation for text position l (one workgroup per l):
+//   h1[l'][c] = relu(b1[c] + sum_{ch<2,k<5} w1[c][ch][k] * x_ch[l'+k-2]),  x_0 = cumulative attention, x_1 = previous attention
+//   cond[l][e] = sigmoid(b2[e] + sum_{c<32,k<3} w2[e][c][k] * h1[l+k-1][c]);   keyin[l][e] = enc[l][e] * cond[l][e]
+__global__ __launch_bounds__(256) void dec_cond_k(const DecodeDev* __restrict__ P) {
+    __shared__ float h1[3][32];
+    int i;
+    if (!frame_live(P, i)) return;
+    const int L = P->L, E = P->E, l = blockIdx.x, tid = threadIdx.x;
+    if (tid < 96) {
+        const int j = tid >> 5, c = tid & 31, lp = l + j - 1;
+        float v = 0.f;
+        if (lp >= 0 && lp < L) {
+            v = P->cond_b1[c];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int ls = lp + k - 2;
+                if (ls >= 0 && ls < L) v += P->cond_w1[(c * 2 + 0) * 5 + k] * P->cumm[ls] + P->cond_w1[(c * 2 + 1) * 5 + k] * P->prev_attn[ls];
+            }
+            v = fmaxf(v, 0.f);
+        }
+        h1[j][c] = v;                      // zero outside [0,L): Conv1d zero padding of the second conv
+    }
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) {
+        float v = P->cond_b2[e];
+        const float* w = P->cond_w2 + (size_t)e * 96;
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v += w[c * 3 + k] * h1[k][c];
+        const float cond = 1.f / (1.f + expf(-v));
+        P->keyin[(size_t)l * E + e] = P->enc[(size_t)l * E + e] * cond;
+    }
+}
+
+// Kdyn[l][a] = sum_e w_key[a][e] * keyin[l][e]; grid (L, ceil(A/16)), one wave per 4 rows a
+__global__ __launch_bounds__(256) void dec_key_k(const DecodeDev* __restrict__ P) {
+    int i;
+    if (!frame_live(P, i)) return;
+    const int A = P->A, E = P->E, l = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* x = P->keyin + (size_t)l * E;
+    for (int r = 0; r < 4; ++r) {
+        const int a = blockIdx.y * 16 + wave * 4 + r;
+        if (a >= A) break;
+        const float s = wave_sum(dot_seg(P->w_key + (size_t)a * E, x, E, lane));
+        if (lane == 0) P->Kdyn[(size_t)l * A + a] = s;
+    }
 }
 
 // 1x1 conv (2M rows) + inverse affine + gate + frame bookkeeping, one workgroup of 1024 threads
@@ -262,10 +320,10 @@ __global__ __launch_bounds__(1024) void dec_out_k(const DecodeDev* __restrict__ 
 
 struct Layout {
     size_t off_dev, off_state, n_state, off_ctl, total;
-    size_t h_att, c_att, h0, c0, h1, c1, q, ctx, u1, u2, prev;
+    size_t h_att, c_att, h0, c0, h1, c1, q, ctx, u1, u2, prev, cumm, prev_attn, keyin, Kdyn;
 };
 
-Layout make_layout(int H, int A, int M) {
+Layout make_layout(int H, int A, int M, int L, int E) {
     Layout l{};
     auto up = [](size_t v) { return (v + 63) & ~size_t(63); };
     l.off_dev = 0;
@@ -274,6 +332,7 @@ Layout make_layout(int H, int A, int M) {
     auto take = [&](size_t n) { size_t o = f; f += (n + 15) & ~size_t(15); return o; };
     l.h_att = take(2 * H); l.c_att = take(H); l.h0 = take(2 * H); l.c0 = take(H); l.h1 = take(2 * H); l.c1 = take(H);
     l.q = take(A); l.ctx = take(A); l.u1 = take(H); l.u2 = take(H); l.prev = take(M);
+    l.cumm = take(L); l.prev_attn = take(L); l.keyin = take((size_t)L * E); l.Kdyn = take((size_t)L * A);
     l.n_state = f;
     l.off_ctl = l.off_state + f * sizeof(float);
     l.total = l.off_ctl + 64;
@@ -284,10 +343,14 @@ constexpr int GRAPH_FRAMES = 8;
 std::mutex g_graph_mu;
 std::unordered_map<uint64_t, hipGraphExec_t> g_graph_cache;
 
-int enqueue_frame(const DecodeDev* dP, int H, int A, int L, int M, hipStream_t st) {
+int enqueue_frame(const DecodeDev* dP, int H, int A, int L, int M, bool cumm, hipStream_t st) {
     const dim3 b256(256), b1024(1024);
     hipLaunchKernelGGL(dec_lstm_k<0>, dim3(cdiv(H, 4)), b256, 0, st, dP);
     hipLaunchKernelGGL(dec_gemv_k<0>, dim3(cdiv(A, 4)), b256, 0, st, dP);
+    if (cumm) {
+        hipLaunchKernelGGL(dec_cond_k, dim3(L), b256, 0, st, dP);
+        hipLaunchKernelGGL(dec_key_k, dim3(L, cdiv(A, 16)), b256, 0, st, dP);
+    }
     hipLaunchKernelGGL(dec_attn_k, dim3(1), b1024, sizeof(float) * (L + 32 + A), st, dP);
     hipLaunchKernelGGL(dec_lstm_k<1>, dim3(cdiv(H, 4)), b256, 0, st, dP);
     hipLaunchKernelGGL(dec_lstm_k<2>, dim3(cdiv(H, 4)), b256, 0, st, dP);
@@ -299,9 +362,8 @@ int enqueue_frame(const DecodeDev* dP, int H, int A, int L, int M, hipStream_t s
 
 }  // namespace
 
-extern "C" size_t ft_decode_workspace_bytes(int L, int H, int A, int M) {
-    (void)L;
-    return make_layout(H, A, M).total;
+extern "C" size_t ft_decode_workspace_bytes(int L, int H, int A, int M, int E) {
+    return make_layout(H, A, M, L, E).total;
 }
 
 extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
@@ -313,7 +375,9 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
     FT_CHECK_ARG(a->residual && a->mel_out && a->attn_out && a->n_done_dev && a->work);
     FT_CHECK_ARG(a->N >= 0 && a->L >= 1 && a->H >= 1 && a->A >= 1 && a->M >= 1 && a->temperature > 0.f);
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(a->work) % 64 == 0);
-    const Layout lay = make_layout(a->H, a->A, a->M);
+    const bool cumm = a->cond_w1 != nullptr;
+    FT_CHECK_ARG(!cumm || (a->cond_b1 && a->cond_w2 && a->cond_b2 && a->w_key && a->enc && a->E >= 1));
+    const Layout lay = make_layout(a->H, a->A, a->M, a->L, cumm ? a->E : 1);
     FT_CHECK_ARG(a->work_bytes >= lay.total);
     if (sizeof(float) * ((size_t)a->L + 32 + a->A) > 160 * 1024)
         return ft_fail(FT_EUNSUPPORTED, "ft_decode_flow: L=%d A=%d exceed the LDS score tile", a->L, a->A);
@@ -332,6 +396,11 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
     h.h_att = fs + lay.h_att; h.c_att = fs + lay.c_att; h.h0 = fs + lay.h0; h.c0 = fs + lay.c0; h.h1 = fs + lay.h1; h.c1 = fs + lay.c1;
     h.q = fs + lay.q; h.ctx = fs + lay.ctx; h.u1 = fs + lay.u1; h.u2 = fs + lay.u2; h.prev = fs + lay.prev;
     h.ctl = reinterpret_cast<int*>(base + lay.off_ctl);
+    if (cumm) {
+        h.cond_w1 = a->cond_w1; h.cond_b1 = a->cond_b1; h.cond_w2 = a->cond_w2; h.cond_b2 = a->cond_b2; h.w_key = a->w_key; h.enc = a->enc;
+        h.cumm = fs + lay.cumm; h.prev_attn = fs + lay.prev_attn; h.keyin = fs + lay.keyin; h.Kdyn = fs + lay.Kdyn;
+    }
+    h.E = a->E;
     h.N = a->N; h.L = a->L; h.H = a->H; h.A = a->A; h.M = a->M;
     h.inv_temp = 1.0f / a->temperature; h.gate_threshold = a->gate_threshold;
 
@@ -344,13 +413,13 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
     FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
     if (!a->use_graph) {
-        for (int i = 0; i < a->N; ++i) enqueue_frame(dP, a->H, a->A, a->L, a->M, st);
+        for (int i = 0; i < a->N; ++i) enqueue_frame(dP, a->H, a->A, a->L, a->M, cumm, st);
         FT_CHECK_LAUNCH();
         return FT_OK;
     }
     // hipGraph path: GRAPH_FRAMES frames per graph; kernels past frame N or past the stop flag are no-ops.
     const uint64_t key = (reinterpret_cast<uint64_t>(dP) * 1000003ull) ^ ((uint64_t)a->H << 40) ^ ((uint64_t)a->A << 28) ^
-                         ((uint64_t)a->L << 12) ^ (uint64_t)a->M;
+                         ((uint64_t)a->L << 12) ^ (uint64_t)a->M ^ (cumm ? (1ull << 63) : 0ull);
     hipGraphExec_t exec = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
@@ -362,7 +431,7 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
             hipGraph_t graph = nullptr;
             hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
-                for (int f = 0; f < GRAPH_FRAMES; ++f) enqueue_frame(dP, a->H, a->A, a->L, a->M, cs);
+                for (int f = 0; f < GRAPH_FRAMES; ++f) enqueue_frame(dP, a->H, a->A, a->L, a->M, cumm, cs);
                 e = hipStreamEndCapture(cs, &graph);
             }
             if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);

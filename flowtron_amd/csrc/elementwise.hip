@@ -255,6 +255,12 @@ __global__ void beta_binomial_prior_k(const int* __restrict__ in_lens, const int
     }
 }
 
+// out = a (+|*) b  -- the key modulation text*cond and the running attention sum of the cumulative-attention branch
+__global__ void eltwise_k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n, int op) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = op ? a[i] * b[i] : a[i] + b[i];
+}
+
 __global__ void zero_k(float* __restrict__ p, long n) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0.f;
 }
@@ -418,6 +424,13 @@ extern "C" int ft_beta_binomial_prior(const int32_t* in_lens, const int32_t* out
     FT_CHECK_ARG(in_lens && out_lens && prior && B >= 1 && T >= 1 && L >= 1 && scaling > 0.f);
     hipLaunchKernelGGL(beta_binomial_prior_k, dim3(grid_for((int64_t)B * T * L)), dim3(NT), 0, ST(stream), in_lens, out_lens, prior,
                        B, T, L, (double)scaling);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_eltwise(const float* a, const float* b, float* out, int64_t n, int op, void* stream) {
+    FT_CHECK_ARG(a && b && out && n >= 0 && (op == 0 || op == 1));
+    if (n == 0) return FT_OK;
+    hipLaunchKernelGGL(eltwise_k, dim3(grid_for(n)), dim3(NT), 0, ST(stream), a, b, out, (long)n, op);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

@@ -145,14 +145,38 @@ class Attention(nn.Module):
 
 
 # --------------------------------------------------------------------------
+# AttentionConditioningLayer -- flowtron.py:129-152 (location-sensitive / cumulative attention features)
+# --------------------------------------------------------------------------
+class AttentionConditioningLayer(nn.Module):
+    """Conv1d(2->32,k5)+ReLU+Conv1d(32->attention_dim,k3)+Sigmoid over [cumulative attention ; previous attention].
+    Same registration as the reference (the nn.Sequential re-registers both convs, so the state_dict carries the
+    `location_conv_*` AND `conv_layers.{0,2}` aliases).  Evaluated as im2col + GEMM with the activation fused in the
+    GEMM epilogue, directly in the time-major [L,B,C] layout the key modulation needs."""
+
+    def __init__(self, input_dim=2, attention_n_filters=32, attention_kernel_sizes=(5, 3), attention_dim=640):
+        super().__init__()
+        self.location_conv_hidden = ConvNorm(input_dim, attention_n_filters, kernel_size=attention_kernel_sizes[0],
+                                             padding=None, bias=True, stride=1, dilation=1, w_init_gain="relu")
+        self.location_conv_out = ConvNorm(attention_n_filters, attention_dim, kernel_size=attention_kernel_sizes[1],
+                                          padding=None, bias=True, stride=1, dilation=1, w_init_gain="sigmoid")
+        self.conv_layers = nn.Sequential(self.location_conv_hidden, nn.ReLU(), self.location_conv_out, nn.Sigmoid())
+
+    def forward(self, attn_cat_lbc, full_lens):
+        """attn_cat_lbc [L,B,2] time-major, full_lens int32 [B] (== L: Conv1d zero-pads only at the ends) -> [L,B,attention_dim]."""
+        c1, c2 = self.location_conv_hidden.conv, self.location_conv_out.conv
+        col = ops.Im2colFn.apply(attn_cat_lbc, full_lens, c1.weight.shape[2])
+        h = ops.linear(col, c1.weight.reshape(c1.weight.shape[0], -1), c1.bias, act=L.ACT_RELU)
+        col = ops.Im2colFn.apply(h, full_lens, c2.weight.shape[2])
+        return ops.linear(col, c2.weight.reshape(c2.weight.shape[0], -1), c2.bias, act=L.ACT_SIGMOID)
+
+
+# --------------------------------------------------------------------------
 # AR_Step / AR_Back_Step -- flowtron.py:645-828, 595-642
 # --------------------------------------------------------------------------
 class AR_Step(nn.Module):
     def __init__(self, n_mel_channels, n_speaker_dim, n_text_channels, n_in_channels, n_hidden, n_attn_channels,
                  n_lstm_layers, add_gate, use_cumm_attention):
         super().__init__()
-        if use_cumm_attention:
-            raise NotImplementedError("use_cumm_attention=True (off in config.json:65) is not built yet")
         if n_lstm_layers != 2:
             raise NotImplementedError("the HIP decoder path is built for n_lstm_layers == 2 (config.json:58)")
         self.use_cumm_attention = use_cumm_attention
@@ -162,6 +186,10 @@ class AR_Step(nn.Module):
         self.lstm = nn.LSTM(n_hidden + n_attn_channels, n_hidden, n_lstm_layers)
         self.attention_lstm = nn.LSTM(n_mel_channels, n_hidden)
         self.attention_layer = Attention(n_hidden, n_speaker_dim, n_text_channels, n_attn_channels)
+        if self.use_cumm_attention:
+            self.attn_cond_layer = AttentionConditioningLayer(input_dim=2, attention_n_filters=32,
+                                                              attention_kernel_sizes=[5, 3],
+                                                              attention_dim=n_text_channels + n_speaker_dim)
         self.dense_layer = DenseLayer(in_dim=n_hidden, sizes=[n_hidden, n_hidden])
         if add_gate:
             self.gate_threshold = 0.5
@@ -176,7 +204,10 @@ class AR_Step(nn.Module):
         mel0 = torch.cat([mel.new_zeros(1, B, M), mel[:-1]], 0)              # flowtron.py:726-729
         a = self.attention_lstm
         h_att = ops.lstm_layer(mel0, out_lens32, a.weight_ih_l0, a.weight_hh_l0, a.bias_ih_l0, a.bias_hh_l0, mode=mode)
-        ctx, attn, logprob = self.attention_layer(h_att, text, text, in_lens32, attn_prior)
+        if self.use_cumm_attention:
+            ctx, attn, logprob = self.run_cumm_attn_sequence(h_att, text, in_lens32)   # drops the prior like flowtron.py:742-743
+        else:
+            ctx, attn, logprob = self.attention_layer(h_att, text, text, in_lens32, attn_prior)
         gates = None
         if hasattr(self, "gate_layer"):
             g = self.gate_layer.linear_layer
@@ -190,6 +221,31 @@ class AR_Step(nn.Module):
         z = ops.AffineFn.apply(out, mel)                                      # z = exp(log_s) * mel + b
         log_s = out[..., :M]
         return z, log_s, gates, attn, logprob
+
+    def run_cumm_attn_sequence(self, h_att, text, in_lens32):
+        """flowtron.py:697-723: the location features of frame i depend on the attention of frames < i, so the reference
+        (and this mirror) walks the frames; every operation inside is a HIP kernel (im2col+GEMM convs, key modulation,
+        per-frame key projection, fused score/softmax kernel with T = 1, context GEMM)."""
+        T, B, _ = h_att.shape
+        Lk = text.shape[0]
+        mode = L.mfma_mode()
+        att = self.attention_layer
+        V = ops.linear(text, att.value.linear_layer.weight, None, mode=mode)
+        Q = ops.linear(h_att, att.query.linear_layer.weight, None, mode=mode)
+        full = torch.full((B,), Lk, dtype=torch.int32, device=text.device)
+        cumm = text.new_zeros(Lk, B)
+        prev = text.new_zeros(Lk, B)
+        ctxs, attns, lps = [], [], []
+        for i in range(T):
+            cond = self.attn_cond_layer(torch.stack([cumm, prev], 2), full)                 # [L,B,E]
+            K = ops.linear(ops.MulFn.apply(text, cond), att.key.linear_layer.weight, None, mode=mode)
+            a, lp = ops.AttentionScoresFn.apply(Q[i:i + 1], K, att.v.linear_layer.weight, in_lens32, None, att.temperature)
+            ctxs.append(ops.ContextFn.apply(a, V, mode))
+            attns.append(a)
+            lps.append(lp)
+            prev = a[:, 0, :].t()
+            cumm = ops.AddFn.apply(cumm, prev)
+        return torch.cat(ctxs, 0), torch.cat(attns, 1), torch.cat(lps, 1)
 
     def infer(self, residual, text, attns=None, attn_prior=None, use_graph=None):
         """Sequential inverse (flowtron.py:775-828), batch 1. residual [N,1,M], text [L,1,E].
@@ -211,7 +267,10 @@ class AR_Step(nn.Module):
         mel_out = torch.empty(N, M, device=dev, dtype=torch.float32)
         attn_out = torch.zeros(N, Lk, device=dev, dtype=torch.float32)
         n_done = torch.zeros(1, device=dev, dtype=torch.int32)
-        nbytes = L.lib().ft_decode_workspace_bytes(Lk, H, A, M)
+        cumm = self.use_cumm_attention
+        E = text.shape[2]
+        enc2d = text.reshape(Lk, E).contiguous()
+        nbytes = L.lib().ft_decode_workspace_bytes(Lk, H, A, M, E if cumm else 1)
         if self._decode_work is None or self._decode_work.numel() < nbytes or self._decode_work.device != dev:
             self._decode_work = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         work = self._decode_work
@@ -219,7 +278,8 @@ class AR_Step(nn.Module):
         if use_graph is None:
             use_graph = os.environ.get("FLOWTRON_DECODE_GRAPH", "1") != "0"
         a, p, d = self.attention_lstm, self.lstm, self.dense_layer.layers
-        keep = [K, V, res]                      # keep temporaries alive until the launch is enqueued
+        keep = [K, V, res, enc2d]               # keep temporaries alive until the launch is enqueued
+        cc = self.attn_cond_layer if cumm else None
         args = L.DecodeArgs(
             L.ptr(a.weight_ih_l0), L.ptr(a.weight_hh_l0), L.ptr(a.bias_ih_l0), L.ptr(a.bias_hh_l0),
             L.ptr(att.query.linear_layer.weight), L.ptr(att.v.linear_layer.weight), L.ptr(K), L.ptr(V),
@@ -232,7 +292,10 @@ class AR_Step(nn.Module):
             L.ptr(self.gate_layer.linear_layer.bias) if has_gate else None,
             L.ptr(res), L.ptr(mel_out), L.ptr(attn_out), L.ptr(n_done), L.ptr(work),
             work.numel(), N, Lk, H, A, M, float(att.temperature),
-            float(self.gate_threshold) if has_gate else 2.0, int(bool(use_graph)))
+            float(self.gate_threshold) if has_gate else 2.0, int(bool(use_graph)),
+            L.ptr(cc.location_conv_hidden.conv.weight) if cumm else None, L.ptr(cc.location_conv_hidden.conv.bias) if cumm else None,
+            L.ptr(cc.location_conv_out.conv.weight) if cumm else None, L.ptr(cc.location_conv_out.conv.bias) if cumm else None,
+            L.ptr(att.key.linear_layer.weight) if cumm else None, L.ptr(enc2d) if cumm else None, E)
         L.check(L.lib().ft_decode_flow(C.byref(args), L.stream()), "ft_decode_flow")
         n = int(n_done.item()) if has_gate else N          # single host read per flow (the reference syncs every frame)
         del keep

@@ -464,3 +464,41 @@ def beta_binomial_prior(in_lens, out_lens, T=None, Lk=None, scaling=1.0):
     L.check(L.lib().ft_beta_binomial_prior(L.ptr(i32), L.ptr(o32), L.ptr(prior), B, T, Lk, float(scaling), L.stream()),
             "ft_beta_binomial_prior")
     return prior
+
+
+# --------------------------------------------------------------------------
+# elementwise add / mul (cumulative-attention branch, flowtron.py:712, :719)
+# --------------------------------------------------------------------------
+def _elt(a, b, op):
+    out = torch.empty_like(a)
+    L.check(L.lib().ft_eltwise(L.ptr(a), L.ptr(b), L.ptr(out), a.numel(), op, L.stream()), "ft_eltwise")
+    return out
+
+
+class MulFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        L.require_cuda(a, b)
+        assert a.shape == b.shape
+        ctx.save_for_backward(a, b)
+        return _elt(a, b, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _c(g)
+        return (_elt(g, b, 1) if ctx.needs_input_grad[0] else None), (_elt(g, a, 1) if ctx.needs_input_grad[1] else None)
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        L.require_cuda(a, b)
+        assert a.shape == b.shape
+        return _elt(a, b, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g

@@ -146,6 +146,10 @@ int ft_reverse_by_length(const float* x, float* y, const int32_t* lens, int T, i
  * dpre = dy * act'(pre), written through the saved output y = act(pre).  dpre may alias dy. */
 int ft_act_bwd(const float* y, const float* dy, float* dpre, int64_t n, int act, void* stream);
 
+/* ---- elementwise out = a + b (op 0) or a * b (op 1): key modulation text*cond (flowtron.py:712) and the running
+ * attention sum (:719) of the cumulative-attention branch.  out may alias a or b. */
+int ft_eltwise(const float* a, const float* b, float* out, int64_t n, int op, void* stream);
+
 /* ---- column sums (bias gradients): out[n] = sum_r x[r*ld + n] -------------- */
 int ft_colsum(const float* x, float* out, int64_t rows, int N, int64_t ld, void* stream);
 
@@ -166,8 +170,13 @@ typedef struct {
     int N, L, H, A, M;
     float temperature, gate_threshold;
     int use_graph;
+    /* cumulative / location-sensitive attention (flowtron.py:129-152, :793-806); all NULL when use_cumm_attention is off:
+     * Conv1d(2->32,k5)+ReLU, Conv1d(32->E,k3)+Sigmoid over [cumulative attn ; previous attn]; the result scales the
+     * encoder outputs enc [L,E] before the key projection w_key [A,E], every frame.  K is then ignored. */
+    const float *cond_w1, *cond_b1, *cond_w2, *cond_b2, *w_key, *enc;
+    int E;
 } ft_decode_args;
-size_t ft_decode_workspace_bytes(int L, int H, int A, int M);
+size_t ft_decode_workspace_bytes(int L, int H, int A, int M, int E);
 int ft_decode_flow(const ft_decode_args* a, void* stream);
 
 /* ---- STFT magnitude + mel + log (audio_processing.py:117-134, 207-235) -------

@@ -218,12 +218,39 @@ def attention(sd: SD, pfx: str, queries, enc, pad_mask, attn_prior, temperature=
 # --------------------------------------------------------------------------
 # one AR flow, teacher forced (flowtron.py:725-773)
 # --------------------------------------------------------------------------
+def attn_cond(sd: SD, pfx: str, cumm, prev):
+    """AttentionConditioningLayer (flowtron.py:129-152): cumm, prev [B,1,L] -> key modulation [L,B,E]."""
+    x = torch.cat([cumm, prev], 1)
+    x = torch.relu(F.conv1d(x, sd[pfx + "location_conv_hidden.conv.weight"], sd[pfx + "location_conv_hidden.conv.bias"], padding=2))
+    x = torch.sigmoid(F.conv1d(x, sd[pfx + "location_conv_out.conv.weight"], sd[pfx + "location_conv_out.conv.bias"], padding=1))
+    return x.permute(2, 0, 1)
+
+
+def cumm_attention_sequence(sd: SD, pfx: str, h_att, enc, pad_mask):
+    """run_cumm_attn_sequence (flowtron.py:697-723): per-frame loop, keys modulated by the location features, values
+    not; NB the reference drops the attention prior on this branch (:742-743)."""
+    T, B, _ = h_att.shape
+    Lk = enc.shape[0]
+    cumm = enc.new_zeros(B, 1, Lk)
+    prev = enc.new_zeros(B, 1, Lk)
+    ctxs, attns, lps = [], [], []
+    for i in range(T):
+        cond = attn_cond(sd, pfx + "attn_cond_layer.", cumm, prev)
+        ctx, prev, lp = attention(sd, pfx + "attention_layer.", h_att[i:i + 1], enc, pad_mask, None, key_scale=cond)
+        ctxs.append(ctx); attns.append(prev); lps.append(lp)
+        cumm = cumm + prev
+    return torch.cat(ctxs, 0), torch.cat(attns, 1), torch.cat(lps, 1)
+
+
 def ar_step_forward(sd: SD, pfx: str, mel, enc, pad_mask, out_lens, attn_prior, has_gate: bool):
     """mel [T,B,M] -> (z, log_s, gate|None, attn, attn_logprob)."""
     T, B, M = mel.shape
     mel0 = torch.cat([mel.new_zeros(1, B, M), mel[:-1]], 0)
     h_att = _lstm(mel0, out_lens, sd, pfx + "attention_lstm.", 0)
-    ctx, attn, logprob = attention(sd, pfx + "attention_layer.", h_att, enc, pad_mask, attn_prior)
+    if (pfx + "attn_cond_layer.location_conv_hidden.conv.weight") in sd:
+        ctx, attn, logprob = cumm_attention_sequence(sd, pfx, h_att, enc, pad_mask)
+    else:
+        ctx, attn, logprob = attention(sd, pfx + "attention_layer.", h_att, enc, pad_mask, attn_prior)
     dec_in = torch.cat([h_att, ctx], 2)
     gate = None
     if has_gate:
@@ -347,14 +374,23 @@ def ar_step_infer(sd: SD, pfx: str, residual, enc, has_gate, temperature=1.0, ga
     h0, c0, h1, c1 = z(B, H), z(B, H), z(B, H), z(B, H)
     prev = z(B, M)
     outs, attns = [], []
+    cumm_on = (pfx + "attn_cond_layer.location_conv_hidden.conv.weight") in sd
+    if cumm_on:
+        cumm, prev_attn = z(B, 1, enc.shape[0]), z(B, 1, enc.shape[0])
+        wk = sd[ap + "key.linear_layer.weight"]
     for i in range(N):
         ha, ca = _lstm_step(prev, ha, ca, sd[pfx + "attention_lstm.weight_ih_l0"], sd[pfx + "attention_lstm.weight_hh_l0"],
                             sd[pfx + "attention_lstm.bias_ih_l0"], sd[pfx + "attention_lstm.bias_hh_l0"])
         q = ha @ sd[ap + "query.linear_layer.weight"].t()                  # [B,A]
+        if cumm_on:                                                        # flowtron.py:793-803
+            K = ((enc * attn_cond(sd, pfx + "attn_cond_layer.", cumm, prev_attn)) @ wk.t()).transpose(0, 1)
         e = torch.tanh(q[:, None, :] + K) @ v / temperature               # [B,L]
         p = torch.softmax(e, dim=1)
         if attn_prior is not None:
             p = torch.softmax(torch.log(p + 1e-20) + torch.log(attn_prior[:, i].float() + 1e-20), dim=1)
+        if cumm_on:
+            prev_attn = p[:, None, :]
+            cumm = cumm + prev_attn
         ctx = torch.bmm(p[:, None, :], V)[:, 0]                           # [B,A]
         d = torch.cat([ha, ctx], 1)
         h0, c0 = _lstm_step(d, h0, c0, sd[pfx + "lstm.weight_ih_l0"], sd[pfx + "lstm.weight_hh_l0"],

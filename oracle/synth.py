@@ -41,6 +41,10 @@ def state_dict_spec(cfg: dict):
                  (p + "attention_layer.key.linear_layer.weight", (A, E)),
                  (p + "attention_layer.value.linear_layer.weight", (A, E)),
                  (p + "attention_layer.v.linear_layer.weight", (1, A))]
+        if cfg.get("use_cumm_attention", False):      # flowtron.py:658-662; nn.Sequential re-registers the two convs
+            for nm in ("location_conv_hidden", "location_conv_out", "conv_layers.0", "conv_layers.2"):
+                shp = (32, 2, 5) if nm in ("location_conv_hidden", "conv_layers.0") else (E, 32, 3)
+                spec += [(p + "attn_cond_layer.%s.conv.weight" % nm, shp), (p + "attn_cond_layer.%s.conv.bias" % nm, (shp[0],))]
         for j in range(2):
             spec += [(p + "dense_layer.layers.%d.linear_layer.weight" % j, (H, H)),
                      (p + "dense_layer.layers.%d.linear_layer.bias" % j, (H,))]
@@ -79,6 +83,11 @@ def make_state_dict(cfg: dict, seed: int = 1234, coupling_scale: float = 0.02) -
             if "attention_layer.v." in k:
                 w = w * 4.0
         sd[k] = torch.from_numpy(np.ascontiguousarray(w)).float()
+    for k in list(sd):                                # aliases of the same module (nn.Sequential view) share values
+        if ".conv_layers.0." in k:
+            sd[k] = sd[k.replace("conv_layers.0", "location_conv_hidden")].clone()
+        elif ".conv_layers.2." in k:
+            sd[k] = sd[k.replace("conv_layers.2", "location_conv_out")].clone()
     return sd
 
 

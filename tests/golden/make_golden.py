@@ -7,6 +7,7 @@ stored: they are rebuilt from seeds by oracle/synth.py (numpy RandomState).
 Fixtures:
   small_f2.pt   2-flow small model: every forward output, 3 losses, all grads, infer mel
   small_f3.pt   3-flow small model, no prior (odd last flow, log(p+1e-8) branch)
+  small_cumm.pt 2-flow small model with use_cumm_attention=True (location-sensitive attention, flowtron.py:129-152, 697-723)
   cfg1_full.pt  BASELINE config 1 (1-flow, n_text=148, B=2, T=800/650, L=148/120, fp32):
                 losses, strided z / log_s / attn slices, grad norms, 48-frame infer mel
   stft_mel.pt   reference STFT/TacotronSTFT with a stub librosa (filterbank = oracle's
@@ -105,6 +106,8 @@ def main():
     small = dict(synth.SMALL_MODEL_CONFIG)
     torch.save(run_model_case(R, small, [23, 17, 20], [9, 7, 5], True, 5, True, 14), os.path.join(HERE, "small_f2.pt"))
     torch.save(run_model_case(R, dict(small, n_flows=3), [15, 11], [6, 6], False, 6, True, 10), os.path.join(HERE, "small_f3.pt"))
+    torch.save(run_model_case(R, dict(small, use_cumm_attention=True), [13, 9, 11], [7, 5, 4], True, 8, True, 9),
+               os.path.join(HERE, "small_cumm.pt"))
     cfg1 = dict(synth.DEFAULT_MODEL_CONFIG, n_flows=1, n_text=148)
     torch.save(run_model_case(R, cfg1, [800, 650], [148, 120], True, 1234, False, 48), os.path.join(HERE, "cfg1_full.pt"))
 

@@ -31,7 +31,8 @@ def test_library_exports_every_declared_symbol():
 def test_state_dict_layout_matches_reference_spec():
     import flowtron
     from oracle import synth
-    for cfg in (synth.DEFAULT_MODEL_CONFIG, dict(synth.DEFAULT_MODEL_CONFIG, n_flows=3, n_speakers=123), synth.SMALL_MODEL_CONFIG):
+    for cfg in (synth.DEFAULT_MODEL_CONFIG, dict(synth.DEFAULT_MODEL_CONFIG, n_flows=3, n_speakers=123), synth.SMALL_MODEL_CONFIG,
+                dict(synth.SMALL_MODEL_CONFIG, use_cumm_attention=True)):
         m = flowtron.Flowtron(**cfg)
         sd = m.state_dict()
         spec = synth.state_dict_spec(cfg)
