@@ -115,11 +115,31 @@ def lstm_step_roofline(B, H, T, mode):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / T
-    bytes_per_launch = 4 * (4 * H * H + B * H + B * 4 * H + 4 * B * H + B * 4 * H)
+    wb = 2 if mode == 1 else 4      # bf16 path streams W_hh and h_{t-1} as bf16 fragment images
+    # per launch: W_hh + h_{t-1} in; gx row in (fp32); y, saved gates, saved cell out (fp32); cell state in+out (fp32);
+    # h_t out in the operand format
+    bytes_per_launch = wb * (4 * H * H + B * H) + 4 * (B * 4 * H) + 4 * (B * H + B * 4 * H + B * H) + 4 * (2 * B * H) + wb * B * H
     achieved = bytes_per_launch / (us * 1e-6) / 1e9
     return {"bound": "hbm", "kernel": "lstm_fwd_step", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(achieved / 8000.0, 4), "traffic": None, "us_per_launch": round(us, 3),
+            "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic("lstm_fwd_step"), "us_per_launch": round(us, 3),
             "bytes_per_launch": bytes_per_launch}
+
+
+def pmc_traffic(kernel_substr):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE and
+    WRITE_SIZE runs of scripts/exp/lstm_only.py, profiles/r01_pmc_lstm_*.json), with the gfx950 correction of
+    MI355X_MICROARCH.md (FETCH_SIZE reads 1/2 of a wide coalesced 16 B/lane stream; counters are KiB).  bench.py cannot
+    run rocprofv3 on itself, so this is the last measured value, or null when the files are absent."""
+    try:
+        vals = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_lstm_%s.json" % c)))
+            for k, v in d.items():
+                if kernel_substr in k:
+                    vals[c] = v[c]["avg"]
+        return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+    except Exception:
+        return None
 
 
 def usable_cores():
