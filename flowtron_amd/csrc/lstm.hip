@@ -50,7 +50,8 @@ __device__ __forceinline__ void skinny_f32(const float* const (&arow)[MT], const
 // wave pays the L2 round trip once per group instead of once per chunk.  Needs ((nchunk - c0) / cs) % G == 0.
 template <int MT, int G, typename Hook>
 __device__ __forceinline__ void skinny_bf16(const bf16x8* __restrict__ afrag, const bf16x8* __restrict__ wfrag,
-                                            int nchunk, int c0, int cs, int lane, f32x4 (&acc)[MT], Hook&& after_last_loads) {
+                                            int nchunk, int c0, int cs, int lane, f32x4 (&acc)[MT], Hook&& after_last_loads,
+                                            int a_mt = MT) {          // a_mt = m-tiles per k-chunk in the A image (>= MT)
     bf16x8 w[G], a[G][MT];
     auto load_group = [&](int cb) {
 #pragma unroll
@@ -58,7 +59,7 @@ __device__ __forceinline__ void skinny_bf16(const bf16x8* __restrict__ afrag, co
             const size_t c = (size_t)(cb + i * cs);
             w[i] = wfrag[c * 64 + lane];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) a[i][m] = afrag[(c * MT + m) * 64 + lane];
+            for (int m = 0; m < MT; ++m) a[i][m] = afrag[(c * a_mt + m) * 64 + lane];
         }
     };
     auto mfma_group = [&]() {
@@ -202,7 +203,7 @@ struct BwdP {
     const unsigned short* dafrag_prev;  // bf16 path: dgates of step s+1, fragment order over K = 4H: [4H/32][MT][64][8]
     unsigned short* dafrag_next;        // bf16 path: dgates of step s (ping-pong)
     const unsigned short* wTfrag;       // bf16 path: [H/16][4H/32][64][8]
-    int s, T, B, H, reverse;
+    int s, T, B, H, reverse, MT;        // MT = 16-row batch tiles in the fragment images
 };
 
 // ------------------------------------------------------------------ fp32 (parity) path: two launches per step
@@ -281,6 +282,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_matmul(BwdP p) {
 //   phase 2: the LSTM cell backward of step s for the SAME 16 units (they need only this block's dh_rec), writing
 //            dgx (fp32, for the batched weight/input-gradient GEMMs) and dgates_s in fragment order for the next launch.
 // The gate/cell/dy loads of phase 2 stream from HBM and are issued before phase 1 so their latency hides under it.
+// grid = (H/16 unit tiles, MT_total/MT batch tiles): with B = 32 the two 16-row batch halves of a unit tile run as two
+// workgroups (same XCD: linear id = y*gridDim.x + x keeps x % 8), each streaming W (128 KB) + HALF of dgates (128 KB)
+// instead of one workgroup streaming 384 KB -- the step is bound by bytes per CU.
 template <int MT, int G, bool REV>
 __global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) {
     __shared__ float red[16][MT * 16][17];
@@ -288,13 +292,14 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) {
     const int li = lane & 15, kg = lane >> 4;
     const int H = p.H, B = p.B;
     const int j0 = blockIdx.x * 16;
+    const int m_base = blockIdx.y * MT, b_base = m_base * 16;
 
     // Roles as in the forward kernel: threads 0..MT*256-1 own one (batch row, unit) of the cell backward of step s; the
     // remaining waves (B <= 32) run the identical load sequence for step s-1 to warm this XCD's L2 for the next launch.
     constexpr int NROLE = MT * 256;
     const bool pf_role = (MT <= 2) && tid >= NROLE;
     const int rr = pf_role ? tid - NROLE : tid;
-    const int eb = rr >> 4, jl = rr & 15, eu = j0 + jl;
+    const int ebl = rr >> 4, eb = b_base + ebl, jl = rr & 15, eu = j0 + jl;
     const bool ev = !pf_role && tid < NROLE && eb < B;
     const int ebc = eb < B ? eb : B - 1;
     int len;
@@ -320,9 +325,9 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) {
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
         const int nchunk = (4 * H) >> 5;
-        skinny_bf16<MT, G>(reinterpret_cast<const bf16x8*>(p.dafrag_prev),
+        skinny_bf16<MT, G>(reinterpret_cast<const bf16x8*>(p.dafrag_prev) + (size_t)m_base * 64,
                            reinterpret_cast<const bf16x8*>(p.wTfrag) + (size_t)blockIdx.x * nchunk * 64, nchunk, wave, 16, lane, acc,
-                           issue_epilogue_loads);
+                           issue_epilogue_loads, p.MT);
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) {
     if (active) {
         float dh = dyv;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) dh += red[w][eb][jl];
+        for (int w = 0; w < 16; ++w) dh += red[w][ebl][jl];
         const float tc = tanhf(c_t);
         const float dc = dh * og * (1.f - tc * tc) + dcc;
         p.dc_carry[(size_t)eb * H + eu] = dc * fg;
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         dg[(size_t)g * H] = da[g];
-        p.dafrag_next[frag_index(eb, g * H + eu, MT)] = f2bf(da[g]);
+        p.dafrag_next[frag_index(eb, g * H + eu, p.MT)] = f2bf(da[g]);
     }
 }
 
@@ -421,9 +426,8 @@ void launch_fwd(const FwdP& p, bool fast, int g, int mt, dim3 grid, hipStream_t 
 }
 template <int G, bool REV>
 void launch_bwd_fused_r(const BwdP& p, int mt, dim3 grid, hipStream_t st) {
-    if (mt == 1) hipLaunchKernelGGL((lstm_bwd_step_bf16<1, G, REV>), grid, dim3(1024), 0, st, p);
-    else if (mt == 2) hipLaunchKernelGGL((lstm_bwd_step_bf16<2, G, REV>), grid, dim3(1024), 0, st, p);
-    else hipLaunchKernelGGL((lstm_bwd_step_bf16<4, G, REV>), grid, dim3(1024), 0, st, p);
+    // one 16-row batch tile per workgroup: (H/16) x mt workgroups
+    hipLaunchKernelGGL((lstm_bwd_step_bf16<1, G, REV>), dim3(grid.x, mt), dim3(1024), 0, st, p);
 }
 template <int G>
 void launch_bwd_fused_g(const BwdP& p, int mt, dim3 grid, hipStream_t st) {
@@ -431,7 +435,8 @@ void launch_bwd_fused_g(const BwdP& p, int mt, dim3 grid, hipStream_t st) {
     else launch_bwd_fused_r<G, false>(p, mt, grid, st);
 }
 void launch_bwd_fused(const BwdP& p, int g, int mt, dim3 grid, hipStream_t st) {
-    if (g >= 4 && mt <= 2) launch_bwd_fused_g<4>(p, mt, grid, st);   // G = 8 sits at the 128-VGPR cap of a 1024-thread block
+    if (g == 8) launch_bwd_fused_g<8>(p, mt, grid, st);              // one m-tile per workgroup: 8 x 2 fragments = 64 VGPRs
+    else if (g >= 4) launch_bwd_fused_g<4>(p, mt, grid, st);
     else if (g >= 2) launch_bwd_fused_g<2>(p, mt, grid, st);
     else launch_bwd_fused_g<1>(p, mt, grid, st);
 }
@@ -520,7 +525,7 @@ extern "C" int ft_lstm_seq_bwd(const float* dy, int64_t ldy, const float* w_hh, 
         dim3 grid(H / 16);
         for (int s = T - 1; s >= 0; --s) {
             BwdP p{dy, (long)ldy, lens, gates, cell, part, dc_carry, da_cur, dgx, wT, part,
-                   dafrag[(s + 1) & 1], dafrag[s & 1], wTfrag, s, T, B, H, reverse};
+                   dafrag[(s + 1) & 1], dafrag[s & 1], wTfrag, s, T, B, H, reverse, mt};
             launch_bwd_fused(p, g, mt, grid, st);
         }
     } else {
@@ -528,7 +533,7 @@ extern "C" int ft_lstm_seq_bwd(const float* dy, int64_t ldy, const float* w_hh, 
         dim3 grid_pw(cdiv((int64_t)B * H, 256)), grid_mm(cdiv(H, 16), 4);
         for (int s = T - 1; s >= 0; --s) {
             BwdP p{dy, (long)ldy, lens, gates, cell, part, dc_carry, da_cur, dgx, wT, part,
-                   nullptr, nullptr, nullptr, s, T, B, H, reverse};
+                   nullptr, nullptr, nullptr, s, T, B, H, reverse, mt};
             hipLaunchKernelGGL(lstm_bwd_pointwise, grid_pw, dim3(256), 0, st, p);
             if (s > 0) launch_bwd_mm(p, mt, grid_mm, st);
         }

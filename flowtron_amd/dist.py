@@ -38,19 +38,21 @@ def init_distributed(rank, num_gpus, dist_backend="nccl", dist_url=None):
         torch.cuda.set_device(local)
     master_ip = os.getenv("MASTER_ADDR", "127.0.0.1")
     master_port = os.getenv("MASTER_PORT", "6000")
-    dist.init_process_group(backend=backend, world_size=num_gpus, rank=rank,
-                            init_method="tcp://" + master_ip + ":" + master_port)
+    if os.getenv("TORCHELASTIC_RUN_ID") is not None or os.getenv("TORCHELASTIC_USE_AGENT_STORE") is not None:
+        # launched by torch.distributed.run: its agent already serves the store on MASTER_PORT, so rank 0 must NOT
+        # open a second TCP store there (tcp:// would); env:// joins the agent's store.
+        dist.init_process_group(backend=backend, world_size=num_gpus, rank=rank, init_method="env://")
+    else:
+        dist.init_process_group(backend=backend, world_size=num_gpus, rank=rank,
+                                init_method="tcp://" + master_ip + ":" + master_port)
 
 
 def _avg_all_reduce(flat: torch.Tensor):
     ws = dist.get_world_size()
     if ws == 1:
         return
-    if dist.get_backend() == "nccl":
-        dist.all_reduce(flat, op=dist.ReduceOp.AVG)          # RCCL folds the 1/N into the reduction
-    else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat /= ws
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)              # one in-place ring/mesh reduction of the whole arena
+    flat /= ws
 
 
 def reduce_tensor(tensor, num_gpus):

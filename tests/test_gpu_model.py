@@ -208,3 +208,22 @@ def test_stft_mel_vs_reference_golden():
     # full 10 s clip: shape contract N//hop + 1 (audio_processing.py:221-225)
     y10 = synth.make_audio(220500, seed=3)[None].cuda()
     assert stft.mel_spectrogram(y10).shape == (1, 80, 862)
+
+
+def test_device_collate_matches_host_collate_and_prior_kernel():
+    """flowtron_amd.data.DataCollate(device=cuda): pinned async H2D + the batch prior kernel == host collate + oracle prior."""
+    from flowtron_amd.data import DataCollate
+    from oracle import flowtron_oracle as O
+    torch.manual_seed(3)
+    items = [(torch.randn(80, t), torch.tensor([t % 3]), torch.randint(0, 100, (l,))) for t, l in ((37, 9), (52, 14), (20, 14), (45, 3))]
+    host = DataCollate(1, False)(items)
+    dev = DataCollate(1, True, device="cuda", betab_scaling_factor=1.0)(items)
+    for a, b in zip(host[:6], dev[:6]):
+        assert b.is_cuda and torch.equal(a, b.cpu())
+    pr = dev[6].cpu()
+    assert pr.shape == (4, 52, 14)
+    for i in range(4):
+        L_i, T_i = int(host[3][i]), int(host[4][i])
+        ref = O.beta_binomial_prior(L_i, T_i).float()
+        assert (pr[i, :T_i, :L_i] - ref).abs().max().item() < 1e-6
+        assert float(pr[i, T_i:].abs().max() if T_i < 52 else 0.0) == 0.0

@@ -157,3 +157,36 @@ def test_mel_filterbank_and_window_match_oracle():
     assert (fb - O.mel_filterbank()).abs().max().item() < 1e-7
     assert fb.shape == (80, 513) and float(fb.min()) >= 0
     assert (torch.from_numpy(hann_window(1024, 1024)) - O.hann_periodic(1024).float()).abs().max().item() < 1e-7
+
+
+def _reference_class(path, name):
+    """Extract ONE class from a reference module without importing the module (data.py pulls in librosa etc.)."""
+    import ast
+    src = open(path).read()
+    tree = ast.parse(src)
+    node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == name)
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    return ns[name]
+
+
+def test_datacollate_matches_reference_wire_format():
+    from flowtron_amd.data import DataCollate
+    ref_path = "/root/reference/data.py"
+    torch.manual_seed(3)
+    batch = []
+    for t, l in ((37, 9), (52, 14), (20, 14), (45, 3)):
+        batch.append((torch.randn(80, t), torch.tensor([t % 3]), torch.randint(0, 100, (l,)), torch.rand(t, l)))
+    mine = DataCollate(1, True)(batch)
+    assert mine[0].shape == (4, 80, 52) and mine[2].shape == (4, 14) and mine[6].shape == (4, 52, 14)
+    assert mine[3].tolist() == sorted(mine[3].tolist(), reverse=True)
+    assert all(float(mine[5][i, int(mine[4][i]) - 1]) == 1.0 and float(mine[5][i, : int(mine[4][i]) - 1].sum()) == 0.0 for i in range(4))
+    if os.path.exists(ref_path):
+        ref = _reference_class(ref_path, "DataCollate")(1, True)(batch)
+        for a, b in zip(mine, ref):
+            assert torch.equal(a, b)
+        ref2 = _reference_class(ref_path, "DataCollate")(4, False)([x[:3] for x in batch])
+        mine2 = DataCollate(4, False)([x[:3] for x in batch])
+        assert mine2[6] is None and ref2[6] is None
+        for a, b in zip(mine2[:6], ref2[:6]):
+            assert torch.equal(a, b)
