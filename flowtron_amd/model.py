@@ -18,6 +18,7 @@ from torch import nn
 
 from . import _lib as L
 from . import ops
+from . import pipeline
 
 # train.py-format checkpoints pickle the whole nn.Module; torch >= 2.6 refuses them under the
 # default weights_only=True, which would break the reference's unmodified train.py resume path
@@ -201,6 +202,8 @@ class AR_Step(nn.Module):
         Returns (z [T,B,M], log_s [T,B,M], gates [T,B,1] | None, attn [B,T,L], attn_logprob [B,T,L])."""
         T, B, M = mel.shape
         mode = L.mfma_mode()
+        if not self.use_cumm_attention and torch.is_grad_enabled() and pipeline.enabled(T):
+            return pipeline.ar_step_forward_pipelined(self, mel, text, in_lens32, out_lens32, attn_prior)
         mel0 = torch.cat([mel.new_zeros(1, B, M), mel[:-1]], 0)              # flowtron.py:726-729
         a = self.attention_lstm
         h_att = ops.lstm_layer(mel0, out_lens32, a.weight_ih_l0, a.weight_hh_l0, a.bias_ih_l0, a.bias_hh_l0, mode=mode)

@@ -97,6 +97,17 @@ int ft_lstm_seq_bwd(const float* dy, int64_t ldy, const float* w_hh, const int32
                     const float* gates, const float* cell, float* dgx, void* work,
                     int T, int B, int H, int reverse, int mode, void* stream);
 
+/* Chunked form for stream-pipelined recurrences: process steps [s_begin, s_end) of the SAME sequence; `work` (and for
+ * backward the carries inside it) must persist between the calls of one sequence.  State is initialised when
+ * s_begin == 0 (forward) / s_end == T (backward, which sweeps s_end-1 .. s_begin).  All buffers are the full [T,...]
+ * buffers.  use_graph != 0 replays the launch chain of a chunk as one cached hipGraph (keyed by every argument). */
+int ft_lstm_seq_fwd_range(const float* gx, const float* w_hh, const int32_t* lens,
+                          float* y, int64_t ldy, float* gates, float* cell, void* work,
+                          int T, int B, int H, int reverse, int mode, int s_begin, int s_end, int use_graph, void* stream);
+int ft_lstm_seq_bwd_range(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens,
+                          const float* gates, const float* cell, float* dgx, void* work,
+                          int T, int B, int H, int reverse, int mode, int s_begin, int s_end, int use_graph, void* stream);
+
 /* ---- additive attention scores + softmax + prior posterior (flowtron.py:544-583)
  * Q [T,B,A] (time-major), K [L,B,A], v [A], in_lens [B], prior [B,T,L] or NULL.
  * e[b,t,l] = sum_a v[a] tanh(Q[t,b,a]+K[l,b,a]) / temperature, -inf at l >= in_lens[b];
