@@ -266,7 +266,8 @@ extern "C" int ft_gemm(const ft_gemm_args* a, void* stream) {
     // products are combined with fp32 global atomics into a zeroed (beta 0) or pre-loaded (beta 1) C.
     p.splits = 1;
     const long tiles = (long)p.gx * p.gy * a->batch;
-    if (a->act == FT_ACT_NONE && (a->beta == 0.f || a->beta == 1.f) && a->batch == 1 && a->K >= 2048 && tiles < 512) {
+    if ((a->flags & FT_GEMM_SPLITK) && a->act == FT_ACT_NONE && (a->beta == 0.f || a->beta == 1.f) && a->batch == 1 &&
+        a->K >= 2048 && tiles < 512) {
         long s = 768 / tiles;
         const long smax = a->K / 512;
         if (s > smax) s = smax;

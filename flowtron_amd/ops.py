@@ -27,12 +27,13 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 
 
 def gemm_raw(A, B, Cm, M, N, K, sAm, sAk, sBk, sBn, ldc, bias=None, act=L.ACT_NONE, alpha=1.0, beta=0.0,
-             batch=1, bsA=0, bsB=0, bsC=0, mode=None):
-    """C = act(alpha*A.B + beta*C + bias); A,B,Cm are tensors whose data_ptr is the operand origin."""
+             batch=1, bsA=0, bsB=0, bsC=0, mode=None, splitk=False):
+    """C = act(alpha*A.B + beta*C + bias); A,B,Cm are tensors whose data_ptr is the operand origin.
+    splitk=True (weight-gradient GEMMs only) allows the atomic split-K path."""
     L.require_cuda(A, B, Cm, bias)
     a = L.GemmArgs(L.ptr(A), L.ptr(B), L.ptr(Cm), L.ptr(bias), M, N, K, batch,
                    sAm, sAk, sBk, sBn, ldc, bsA, bsB, bsC, alpha, beta, act,
-                   L.mfma_mode() if mode is None else mode)
+                   L.mfma_mode() if mode is None else mode, L.GEMM_SPLITK if splitk else 0)
     L.check(L.lib().ft_gemm(C.byref(a), L.stream()), "ft_gemm")
 
 
@@ -98,7 +99,7 @@ class LinearFn(torch.autograd.Function):
                 dxs.append(None)
             if dW is not None:
                 # dW[n, off+k] = sum_r dpre[r,n] x[r,k]
-                gemm_raw(dpre, x, dW[:, off:], N, K, rows, 1, N, K, 1, Ktot, mode=ctx.mode)
+                gemm_raw(dpre, x, dW[:, off:], N, K, rows, 1, N, K, 1, Ktot, mode=ctx.mode, splitk=True)
             off += K
         return (dW, db, None, None, *dxs)
 
@@ -239,7 +240,7 @@ class LSTMSeqFn(torch.autograd.Function):
                 # dW_hh[r,j] = sum_{t,b} da_t[b,r] * h_prev(t)[b,j];  h_prev = y[t-1] (fwd) / y[t+1] (reverse)
                 da = dgx[1:] if not ctx.reverse else dgx[:-1]
                 hp = y[:-1] if not ctx.reverse else y[1:]
-                gemm_raw(da, hp, dW, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=ctx.mode)
+                gemm_raw(da, hp, dW, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=ctx.mode, splitk=True)
         return dgx, dW, None, None, None
 
 

@@ -107,7 +107,7 @@ class LSTMChunkFn(torch.autograd.Function):
         if s0 == 0 and ctx.needs_input_grad[1]:          # last chunk of the backward sweep: dgx is complete for all T
             dW = torch.zeros_like(w_hh)
             if T > 1:
-                ops.gemm_raw(st.dgx[1:], st.y[:-1], dW, 4 * H, H, (T - 1) * B, 1, 4 * H, H, 1, H, mode=ctx.mode)
+                ops.gemm_raw(st.dgx[1:], st.y[:-1], dW, 4 * H, H, (T - 1) * B, 1, 4 * H, H, 1, H, mode=ctx.mode, splitk=True)
         return st.dgx[s0:s1], dW, torch.zeros(1, device=dy_c.device), None, None, None, None, None
 
 

@@ -331,7 +331,7 @@ def test_gemm_split_k_weight_gradient_shape(env, beta):
     C0 = torch.randn(N, K + 7)                         # strided output (row-block of a wider weight gradient)
     ref = (dpre.double().t() @ x.double()).float() / 64 + bias + beta * C0[:, 3:3 + K]
     Cd = g(C0.clone())
-    ops.gemm_raw(g(dpre), g(x), Cd[:, 3:], N, K, rows, 1, N, K, 1, K + 7, bias=g(bias), alpha=1.0 / 64, beta=beta, mode=0)
+    ops.gemm_raw(g(dpre), g(x), Cd[:, 3:], N, K, rows, 1, N, K, 1, K + 7, bias=g(bias), alpha=1.0 / 64, beta=beta, mode=0, splitk=True)
     torch.cuda.synchronize()
     assert mad(Cd[:, 3:3 + K], ref) < 2e-4
     assert torch.equal(Cd[:, :3].cpu(), C0[:, :3]) and torch.equal(Cd[:, 3 + K:].cpu(), C0[:, 3 + K:])   # neighbours untouched
