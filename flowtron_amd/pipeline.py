@@ -71,7 +71,7 @@ def enabled(T: int) -> bool:
         return False
     if v in ("1", "on", "true"):
         return T >= 2
-    return T >= 4 * chunk_len()          # auto: only when there are enough chunks to fill the four stages
+    return False      # auto = off: measured (scripts/exp/pipe_timing*.py, profiles/) the chains do not overlap inside a training step yet
 
 
 def chunk_len() -> int:
