@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step(FwdP p) {
         else t_ld = (p.s < len) ? (len - 1 - p.s) : 0;
         const float* gp = p.gx + ((size_t)t_ld * B + ebc) * 4 * H + euc;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gxv[g] = __builtin_nontemporal_load(gp + (size_t)g * H);   // streamed once: keep W_hh/h in cache instead
+        for (int g = 0; g < 4; ++g) gxv[g] = gp[(size_t)g * H];
         c_old = p.cstate[(size_t)ebc * H + euc];
     };
 
@@ -232,14 +232,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_step(FwdP p) {
     p.cstate[bu] = c_new;
     if constexpr (MODE == 0) p.hnext[bu] = h_new;
     else p.hfrag_next[frag_index(eb, eu, MT)] = f2bf(h_new);
-    __builtin_nontemporal_store(h_new, p.y + row * p.ldy + eu);
-    if (p.gates) {           // saved for backward: written once, read ~T steps later -> non-temporal
+    p.y[row * p.ldy + eu] = h_new;
+    if (p.gates) {
         float* gp = p.gates + row * 4 * H + eu;
-        __builtin_nontemporal_store(ig, gp);
-        __builtin_nontemporal_store(fg, gp + (size_t)H);
-        __builtin_nontemporal_store(gg, gp + (size_t)2 * H);
-        __builtin_nontemporal_store(og, gp + (size_t)3 * H);
-        __builtin_nontemporal_store(c_new, p.cell + row * H + eu);
+        gp[0] = ig; gp[(size_t)H] = fg; gp[(size_t)2 * H] = gg; gp[(size_t)3 * H] = og;
+        p.cell[row * H + eu] = c_new;
     }
 }
 
@@ -365,11 +362,10 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) {
         tp = tp < 0 ? 0 : (tp > p.T - 1 ? p.T - 1 : tp);
         const size_t row = (size_t)t_ld * B + ebc;
         const float* gp = p.gates + row * 4 * H + eu;
-        ig = __builtin_nontemporal_load(gp); fg = __builtin_nontemporal_load(gp + (size_t)H);
-        gg = __builtin_nontemporal_load(gp + (size_t)2 * H); og = __builtin_nontemporal_load(gp + (size_t)3 * H);
+        ig = gp[0]; fg = gp[(size_t)H]; gg = gp[(size_t)2 * H]; og = gp[(size_t)3 * H];
         c_t = p.cell[row * H + eu];
         c_prev = p.cell[((size_t)tp * B + ebc) * H + eu];
-        dyv = __builtin_nontemporal_load(p.dy + row * p.ldy + eu);
+        dyv = p.dy[row * p.ldy + eu];
         dcc = p.dc_carry[(size_t)ebc * H + eu];
     };
 
@@ -410,7 +406,7 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) {
     float* dg = p.dgx + ((size_t)t * B + eb) * 4 * H + eu;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        __builtin_nontemporal_store(da[g], dg + (size_t)g * H);
+        dg[(size_t)g * H] = da[g];
         p.dafrag_next[frag_index(eb, g * H + eu, p.MT)] = f2bf(da[g]);
     }
 }
