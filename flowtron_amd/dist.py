@@ -146,6 +146,8 @@ def apply_gradient_allreduce(module):
         if module.needs_reduction:
             module.needs_reduction = False
             arena.adopt_stray_grads(copy=True)
+            from . import ops
+            ops.join_side_stream()                               # side-stream weight-gradient GEMMs write into the arena
             _avg_all_reduce(arena.flat_grad)                     # C2: the only per-step collective
 
     def allreduce_hook(*unused):

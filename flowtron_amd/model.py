@@ -373,6 +373,9 @@ class Flowtron(nn.Module):
         """mel [B,M,T], speaker_ids [B], text [B,L] (sorted by in_lens desc), in_lens/out_lens [B],
         attn_prior [B,T,L] | None -> the reference's 8-tuple (flowtron.py:898-899)."""
         L.require_cuda(mel, text, in_lens, out_lens, attn_prior)
+        # the per-frame cumulative-attention loop reuses weight matrices T times per step: their gradients must go through
+        # autograd's accumulation, not the single-consumer side-stream path (ops._side_dw_target)
+        ops.set_side_dw(not any(getattr(f.ar_step if hasattr(f, "ar_step") else f, "use_cumm_attention", False) for f in self.flows))
         enc, in32 = self._encode(speaker_ids, text, in_lens)
         out32 = ops.lens32(out_lens)
         x = mel.permute(2, 0, 1).contiguous().float()

@@ -37,6 +37,56 @@ def gemm_raw(A, B, Cm, M, N, K, sAm, sAk, sBk, sBn, ldc, bias=None, act=L.ACT_NO
     L.check(L.lib().ft_gemm(C.byref(a), L.stream()), "ft_gemm")
 
 
+# --------------------------------------------------------------------------
+# weight-gradient GEMMs on a side stream
+# --------------------------------------------------------------------------
+# dW = dpre^T x is needed only by the optimizer, never by the rest of the backward pass, while the backward critical path
+# is a chain of ~5 us LSTM launches that leaves the chip mostly idle.  When the weight is a leaf whose .grad already
+# exists (the flat gradient arena of flowtron_amd.dist / optim), the dW GEMM accumulates straight into it (beta = 1) on a
+# side stream and the Function returns None for dW; the calling stream re-joins the side stream once, at the end of
+# backward (engine callback), before the all-reduce / optimizer read the arena.  Each weight matrix must then have a single
+# consumer per step (true for the default model; Flowtron.forward disables it for the per-frame cumulative-attention loop).
+_SIDE = {"enabled": True, "streams": {}, "pending": set()}
+
+
+def set_side_dw(enabled: bool):
+    _SIDE["enabled"] = bool(enabled)
+
+
+def join_side_stream():
+    """Make the current stream wait for every outstanding side-stream weight-gradient GEMM."""
+    for dev in list(_SIDE["pending"]):
+        torch.cuda.current_stream(dev).wait_stream(_SIDE["streams"][dev])
+    _SIDE["pending"].clear()
+
+
+def _side_dw_target(W):
+    import os
+    if not _SIDE["enabled"] or os.environ.get("FLOWTRON_DW_STREAM", "1") == "0":
+        return None
+    if not (W.is_leaf and W.requires_grad and W.grad is not None and W.grad.is_contiguous() and W.grad.shape == W.shape):
+        return None
+    return W.grad
+
+
+def _on_side(dev, fn, *tensors):
+    side = _SIDE["streams"].get(dev)
+    if side is None:
+        side = _SIDE["streams"][dev] = torch.cuda.Stream(device=dev)
+    cur = torch.cuda.current_stream(dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        fn()
+    for t in tensors:
+        t.record_stream(side)
+    if dev not in _SIDE["pending"]:
+        _SIDE["pending"].add(dev)
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
+        except RuntimeError:          # not inside a backward pass (direct call of .backward of a Function in a test)
+            join_side_stream()
+
+
 def colsum(x2d: torch.Tensor, rows: int, N: int, ld: int) -> torch.Tensor:
     out = torch.empty(N, device=x2d.device, dtype=torch.float32)
     L.check(L.lib().ft_colsum(L.ptr(x2d), L.ptr(out), rows, N, ld, L.stream()), "ft_colsum")
@@ -56,6 +106,7 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, W, bias, act, mode, *xs):
         xs = [_c(x) for x in xs]
         L.require_cuda(W, *xs)
+        W_in = W
         W = _c(W)
         N, Ktot = W.shape
         rows = xs[0].numel() // xs[0].shape[-1]
@@ -71,6 +122,7 @@ class LinearFn(torch.autograd.Function):
         assert off == Ktot
         ctx.save_for_backward(W, y if act != L.ACT_NONE else None, *xs)
         ctx.act, ctx.mode, ctx.has_bias = act, mode, bias is not None
+        ctx.W_leaf = W_in if (W_in.is_leaf and W_in.is_contiguous()) else None
         return y
 
     @staticmethod
@@ -84,7 +136,8 @@ class LinearFn(torch.autograd.Function):
             L.check(L.lib().ft_act_bwd(L.ptr(y), L.ptr(dy), L.ptr(dpre), dy.numel(), ctx.act, L.stream()), "ft_act_bwd")
         else:
             dpre = dy
-        dW = torch.empty_like(W) if ctx.needs_input_grad[0] else None
+        gW = _side_dw_target(ctx.W_leaf) if (ctx.needs_input_grad[0] and ctx.W_leaf is not None) else None
+        dW = torch.empty_like(W) if (ctx.needs_input_grad[0] and gW is None) else None
         db = colsum(dpre, rows, N, N) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
         dxs = []
         off = 0
@@ -100,6 +153,9 @@ class LinearFn(torch.autograd.Function):
             if dW is not None:
                 # dW[n, off+k] = sum_r dpre[r,n] x[r,k]
                 gemm_raw(dpre, x, dW[:, off:], N, K, rows, 1, N, K, 1, Ktot, mode=ctx.mode, splitk=True)
+            elif gW is not None:
+                _on_side(dpre.device, lambda x=x, off=off, K=K: gemm_raw(dpre, x, gW[:, off:], N, K, rows, 1, N, K, 1, Ktot,
+                                                                        beta=1.0, mode=ctx.mode, splitk=True), dpre, x)
             off += K
         return (dW, db, None, None, *dxs)
 
@@ -209,6 +265,7 @@ def conv_norm_relu(x, lens, conv_w, conv_b, gamma, beta, keep=None, eps=1e-5, mo
 class LSTMSeqFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gx, w_hh, lens, reverse, mode):
+        ctx.w_leaf = w_hh if (w_hh.is_leaf and w_hh.is_contiguous()) else None
         gx, w_hh = _c(gx), _c(w_hh)
         L.require_cuda(gx, w_hh, lens)
         T, B, H4 = gx.shape
@@ -234,13 +291,19 @@ class LSTMSeqFn(torch.autograd.Function):
                                         L.ptr(work), T, B, H, int(ctx.reverse), ctx.mode, L.stream()), "ft_lstm_seq_bwd")
         dW = None
         if ctx.needs_input_grad[1]:
-            dW = torch.zeros_like(w_hh)
-            if T > 1:
-                rows = (T - 1) * B
-                # dW_hh[r,j] = sum_{t,b} da_t[b,r] * h_prev(t)[b,j];  h_prev = y[t-1] (fwd) / y[t+1] (reverse)
-                da = dgx[1:] if not ctx.reverse else dgx[:-1]
-                hp = y[:-1] if not ctx.reverse else y[1:]
-                gemm_raw(da, hp, dW, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=ctx.mode, splitk=True)
+            # dW_hh[r,j] = sum_{t,b} da_t[b,r] * h_prev(t)[b,j];  h_prev = y[t-1] (fwd) / y[t+1] (reverse)
+            rows = (T - 1) * B
+            da = dgx[1:] if not ctx.reverse else dgx[:-1]
+            hp = y[:-1] if not ctx.reverse else y[1:]
+            gW = _side_dw_target(ctx.w_leaf) if ctx.w_leaf is not None else None
+            if gW is not None:
+                if T > 1:
+                    _on_side(dy.device, lambda: gemm_raw(da, hp, gW, 4 * H, H, rows, 1, 4 * H, H, 1, H, beta=1.0, mode=ctx.mode,
+                                                         splitk=True), dgx, y)
+            else:
+                dW = torch.zeros_like(w_hh)
+                if T > 1:
+                    gemm_raw(da, hp, dW, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=ctx.mode, splitk=True)
         return dgx, dW, None, None, None
 
 

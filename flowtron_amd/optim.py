@@ -54,6 +54,8 @@ class RAdam(Optimizer):
         """Enqueue ||g||^2 on device and remember the clip for the next step(); returns the device scalar ||g||^2
         (no host sync -- torch.nn.utils.clip_grad_norm_ at train.py:328 does 68 norms and a sync)."""
         a = self.arena
+        from . import ops
+        ops.join_side_stream()
         a.adopt_stray_grads(copy=True)
         self.gnorm_sq.zero_()
         L.check(L.lib().ft_sumsq(L.ptr(a.flat_grad), L.ptr(self.gnorm_sq), a.numel, L.stream()), "ft_sumsq")
@@ -65,6 +67,8 @@ class RAdam(Optimizer):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
         a = self.arena
+        from . import ops
+        ops.join_side_stream()
         a.adopt_stray_grads(copy=True)
         self._step += 1
         beta1, beta2 = g["betas"]
