@@ -62,7 +62,7 @@ def join_side_stream():
 
 def _side_dw_target(W):
     import os
-    if not _SIDE["enabled"] or os.environ.get("FLOWTRON_DW_STREAM", "1") == "0":
+    if not _SIDE["enabled"] or os.environ.get("FLOWTRON_DW_STREAM", "0") != "1":     # opt-in: measured neutral
         return None
     if not (W.is_leaf and W.requires_grad and W.grad is not None and W.grad.is_contiguous() and W.grad.shape == W.shape):
         return None

@@ -304,6 +304,7 @@ def test_side_stream_weight_gradients_into_arena_vs_reference_golden():
     g = _load("small_f2.pt")
     cfg = g["cfg"]
     m, _ = build(cfg, g["seed"])
+    os.environ["FLOWTRON_DW_STREAM"] = "1"
     opt = RAdam(m.parameters(), lr=1e-3)
     b = cuda_batch(synth.make_batch(cfg, g["out_lens"], g["in_lens"], seed=g["seed"], with_prior=g["with_prior"]))
     crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)
@@ -319,5 +320,6 @@ def test_side_stream_weight_gradients_into_arena_vs_reference_golden():
             if r > worst[1]:
                 worst = (k, r)
         assert worst[1] < 1e-3, (it, worst)
+    os.environ["FLOWTRON_DW_STREAM"] = "0"
     arena = opt.arena
     assert all(arena._ptr_lo <= p.grad.data_ptr() < arena._ptr_hi for p in m.parameters())
