@@ -6,9 +6,9 @@
 // fills the chip with one wave per output row (or per hidden unit: the four i/f/g/o gate rows
 // of a unit are reduced by the same wave so the cell update fuses into the GEMV):
 //
-//   S1 attention_lstm step      S2 query projection      S3 scores+softmax+context (1 WG)
+//   S1 attention_lstm step      S2 query projection      S3a scores (wave per text position)  S3b softmax + context
 //   S4 lstm layer 0 step        S5 lstm layer 1 step     S6/S7 dense tanh x2
-//   S8 1x1 conv -> (log_s,b), inverse coupling, gate sigmoid/threshold, frame counter
+//   S8a 1x1 conv -> (log_s,b)   S8b inverse coupling, gate sigmoid/threshold, frame counter
 //
 // Nothing returns to the host inside the loop: the frame index and the stop flag live in
 // device memory (the reference's python `if sigmoid(gate) > thr: break`, flowtron.py:823-826,
@@ -33,6 +33,7 @@ struct DecodeDev {
     // cumulative (location-sensitive) attention, flowtron.py:129-152, :793-806 -- all null when use_cumm_attention is off
     const float *cond_w1, *cond_b1, *cond_w2, *cond_b2, *w_key, *enc;
     float *cumm, *prev_attn, *keyin, *Kdyn;
+    float *escore, *obuf;                        // attention scores [L], 1x1 conv output [2M] (stage hand-offs)
     int* ctl;                                    // [0] frame index, [1] done flag
     int N, L, H, A, M, E;
     float inv_temp, gate_threshold;
@@ -172,57 +173,62 @@ __global__ __launch_bounds__(256) void dec_gemv_k(const DecodeDev* __restrict__ 
     }
 }
 
-// scores + softmax + context, one workgroup of 1024 threads (16 waves)
-__global__ __launch_bounds__(1024) void dec_attn_k(const DecodeDev* __restrict__ P) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // [L] scores, [16] reduction, [A] q
+// S3a  attention scores: one wave per text position l (grid = ceil(L/4)); e[l] = (1/temp) sum_a v[a] tanh(q[a] + K[l][a])
+__global__ __launch_bounds__(256) void dec_score_k(const DecodeDev* __restrict__ P) {
+    int i;
+    if (!frame_live(P, i)) return;
+    const int L = P->L, A = P->A;
+    const int lane = threadIdx.x & 63, l = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (l >= L) return;
+    const float* Kmat = P->Kdyn ? P->Kdyn : P->K;
+    const float* kr = Kmat + (size_t)l * A;
+    float s = 0.f;
+    for (int a = lane; a < A; a += 64) s += P->v[a] * tanhf(P->q[a] + kr[a]);
+    s = wave_sum(s);
+    if (lane == 0) P->escore[l] = s * P->inv_temp;
+}
+
+// S3b  softmax over L (recomputed by every workgroup: L floats) + context for 64 channels per workgroup (grid = ceil(A/64));
+//      workgroup 0 also stores the attention row and advances the cumulative-attention state.
+__global__ __launch_bounds__(256) void dec_ctx_k(const DecodeDev* __restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [L] probabilities, [4] reduction, [4][64] partial context
     int i;
     if (!frame_live(P, i)) return;
     const int L = P->L, A = P->A;
     float* e = sm;
     float* red = sm + L;
-    float* qs = red + 32;
+    float* part = red + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int a = tid; a < A; a += 1024) qs[a] = P->q[a];
-    __syncthreads();
-    const float* Kmat = P->Kdyn ? P->Kdyn : P->K;
-    for (int l = wave; l < L; l += 16) {
-        const float* kr = Kmat + (size_t)l * A;
-        float s = 0.f;
-        for (int a = lane; a < A; a += 64) s += P->v[a] * tanhf(qs[a] + kr[a]);
-        s = wave_sum(s);
-        if (lane == 0) e[l] = s * P->inv_temp;
-    }
-    __syncthreads();
     float m = -INFINITY;
-    for (int l = tid; l < L; l += 1024) m = fmaxf(m, e[l]);
+    for (int l = tid; l < L; l += 256) { const float x = P->escore[l]; e[l] = x; m = fmaxf(m, x); }
     m = wave_max(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
-    m = red[0];
-#pragma unroll
-    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float s = 0.f;
-    for (int l = tid; l < L; l += 1024) { const float p = expf(e[l] - m); e[l] = p; s += p; }
+    for (int l = tid; l < L; l += 256) { const float p = expf(e[l] - m); e[l] = p; s += p; }
     s = wave_sum(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
-    s = 0.f;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) s += red[w];
-    float* arow = P->attn_out + (size_t)i * L;
-    for (int l = tid; l < L; l += 1024) {
-        const float pl = e[l] / s;
-        arow[l] = pl;
-        if (P->cumm) { P->prev_attn[l] = pl; P->cumm[l] += pl; }      // read by the NEXT frame's dec_cond_k
+    s = red[0] + red[1] + red[2] + red[3];
+    for (int l = tid; l < L; l += 256) e[l] = e[l] / s;
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        float* arow = P->attn_out + (size_t)i * L;
+        for (int l = tid; l < L; l += 256) {
+            const float pl = e[l];
+            arow[l] = pl;
+            if (P->cumm) { P->prev_attn[l] = pl; P->cumm[l] += pl; }      // read by the NEXT frame's dec_cond_k
+        }
     }
-    const float inv = 1.f / s;
-    for (int a = tid; a < A; a += 1024) {
-        float c = 0.f;
-        for (int l = 0; l < L; ++l) c += (e[l] / s) * P->V[(size_t)l * A + a];
-        P->ctx[a] = c;
-    }
-    (void)inv;
+    const int a = blockIdx.x * 64 + lane;
+    float c = 0.f;
+    if (a < A)
+        for (int l = wave; l < L; l += 4) c += e[l] * P->V[(size_t)l * A + a];
+    part[wave * 64 + lane] = c;
+    __syncthreads();
+    if (wave == 0 && a < A) P->ctx[a] = part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane];
 }
 
 // Location features -> key modulation for text position l (one workgroup per l):
@@ -275,40 +281,42 @@ __global__ __launch_bounds__(256) void dec_key_k(const DecodeDev* __restrict__ P
     }
 }
 
-// 1x1 conv (2M rows) + inverse affine + gate + frame bookkeeping, one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void dec_out_k(const DecodeDev* __restrict__ P) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // [2M] conv outputs, [16] reduction
+// S8a  1x1 conv: one wave per output row n < 2M (grid = ceil(2M/4)); obuf[n] = conv_w[n,:].u2 + conv_b[n]
+__global__ __launch_bounds__(256) void dec_conv_k(const DecodeDev* __restrict__ P) {
+    int i;
+    if (!frame_live(P, i)) return;
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= 2 * P->M) return;
+    const float s = wave_sum(dot_seg(P->conv_w + (size_t)n * P->H, P->u2, P->H, lane));
+    if (lane == 0) P->obuf[n] = s + P->conv_b[n];
+}
+
+// S8b  inverse affine coupling, gate sigmoid/threshold (flowtron.py:823-826), frame bookkeeping -- one small workgroup
+__global__ __launch_bounds__(256) void dec_fin_k(const DecodeDev* __restrict__ P) {
+    __shared__ float red[4];
     int i;
     if (!frame_live(P, i)) return;
     const int M = P->M, H = P->H, A = P->A;
-    float* o = sm;
-    float* red = sm + 2 * M;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int par = i & 1;
-    for (int n = wave; n < 2 * M; n += 16) {
-        const float s = wave_sum(dot_seg(P->conv_w + (size_t)n * H, P->u2, H, lane));
-        if (lane == 0) o[n] = s + P->conv_b[n];
-    }
     float g = 0.f;
     if (P->gate_w) {
         const float* hn = P->h_att + (par ^ 1) * H;
-        for (int k = tid; k < H; k += 1024) g += P->gate_w[k] * hn[k];
-        for (int k = tid; k < A; k += 1024) g += P->gate_w[H + k] * P->ctx[k];
+        for (int k = tid; k < H; k += 256) g += P->gate_w[k] * hn[k];
+        for (int k = tid; k < A; k += 256) g += P->gate_w[H + k] * P->ctx[k];
         g = wave_sum(g);
         if (lane == 0) red[wave] = g;
     }
     __syncthreads();
-    for (int c = tid; c < M; c += 1024) {
-        const float x = (P->residual[(size_t)i * M + c] - o[M + c]) / expf(o[c]);
+    for (int c = tid; c < M; c += 256) {
+        const float x = (P->residual[(size_t)i * M + c] - P->obuf[M + c]) / expf(P->obuf[c]);
         P->mel_out[(size_t)i * M + c] = x;
         P->prev[c] = x;
     }
     if (tid == 0) {
         int done = 0;
         if (P->gate_w) {
-            float gs = P->gate_b[0];
-#pragma unroll
-            for (int w = 0; w < 16; ++w) gs += red[w];
+            const float gs = P->gate_b[0] + red[0] + red[1] + red[2] + red[3];
             const float sg = 1.f / (1.f + expf(-gs));
             if (sg > P->gate_threshold) done = 1;
         }
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(1024) void dec_out_k(const DecodeDev* __restrict__ 
 
 struct Layout {
     size_t off_dev, off_state, n_state, off_ctl, total;
-    size_t h_att, c_att, h0, c0, h1, c1, q, ctx, u1, u2, prev, cumm, prev_attn, keyin, Kdyn;
+    size_t h_att, c_att, h0, c0, h1, c1, q, ctx, u1, u2, prev, cumm, prev_attn, keyin, Kdyn, escore, obuf;
 };
 
 Layout make_layout(int H, int A, int M, int L, int E) {
@@ -333,6 +341,7 @@ Layout make_layout(int H, int A, int M, int L, int E) {
     l.h_att = take(2 * H); l.c_att = take(H); l.h0 = take(2 * H); l.c0 = take(H); l.h1 = take(2 * H); l.c1 = take(H);
     l.q = take(A); l.ctx = take(A); l.u1 = take(H); l.u2 = take(H); l.prev = take(M);
     l.cumm = take(L); l.prev_attn = take(L); l.keyin = take((size_t)L * E); l.Kdyn = take((size_t)L * A);
+    l.escore = take(L); l.obuf = take(2 * (size_t)M);
     l.n_state = f;
     l.off_ctl = l.off_state + f * sizeof(float);
     l.total = l.off_ctl + 64;
@@ -351,12 +360,14 @@ int enqueue_frame(const DecodeDev* dP, int H, int A, int L, int M, bool cumm, hi
         hipLaunchKernelGGL(dec_cond_k, dim3(L), b256, 0, st, dP);
         hipLaunchKernelGGL(dec_key_k, dim3(L, cdiv(A, 16)), b256, 0, st, dP);
     }
-    hipLaunchKernelGGL(dec_attn_k, dim3(1), b1024, sizeof(float) * (L + 32 + A), st, dP);
+    hipLaunchKernelGGL(dec_score_k, dim3(cdiv(L, 4)), b256, 0, st, dP);
+    hipLaunchKernelGGL(dec_ctx_k, dim3(cdiv(A, 64)), b256, sizeof(float) * (L + 4 + 256), st, dP);
     hipLaunchKernelGGL(dec_lstm_k<1>, dim3(cdiv(H, 4)), b256, 0, st, dP);
     hipLaunchKernelGGL(dec_lstm_k<2>, dim3(cdiv(H, 4)), b256, 0, st, dP);
     hipLaunchKernelGGL(dec_gemv_k<1>, dim3(cdiv(H, 4)), b256, 0, st, dP);
     hipLaunchKernelGGL(dec_gemv_k<2>, dim3(cdiv(H, 4)), b256, 0, st, dP);
-    hipLaunchKernelGGL(dec_out_k, dim3(1), b1024, sizeof(float) * (2 * M + 32), st, dP);
+    hipLaunchKernelGGL(dec_conv_k, dim3(cdiv(2 * M, 4)), b256, 0, st, dP);
+    hipLaunchKernelGGL(dec_fin_k, dim3(1), b256, 0, st, dP);
     return 0;
 }
 
@@ -379,8 +390,8 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
     FT_CHECK_ARG(!cumm || (a->cond_b1 && a->cond_w2 && a->cond_b2 && a->w_key && a->enc && a->E >= 1));
     const Layout lay = make_layout(a->H, a->A, a->M, a->L, cumm ? a->E : 1);
     FT_CHECK_ARG(a->work_bytes >= lay.total);
-    if (sizeof(float) * ((size_t)a->L + 32 + a->A) > 160 * 1024)
-        return ft_fail(FT_EUNSUPPORTED, "ft_decode_flow: L=%d A=%d exceed the LDS score tile", a->L, a->A);
+    if (sizeof(float) * ((size_t)a->L + 4 + 256) > 160 * 1024)
+        return ft_fail(FT_EUNSUPPORTED, "ft_decode_flow: L=%d exceeds the LDS probability tile", a->L);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char* base = reinterpret_cast<char*>(a->work);
     float* fs = reinterpret_cast<float*>(base + lay.off_state);
@@ -396,6 +407,7 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
     h.h_att = fs + lay.h_att; h.c_att = fs + lay.c_att; h.h0 = fs + lay.h0; h.c0 = fs + lay.c0; h.h1 = fs + lay.h1; h.c1 = fs + lay.c1;
     h.q = fs + lay.q; h.ctx = fs + lay.ctx; h.u1 = fs + lay.u1; h.u2 = fs + lay.u2; h.prev = fs + lay.prev;
     h.ctl = reinterpret_cast<int*>(base + lay.off_ctl);
+    h.escore = fs + lay.escore; h.obuf = fs + lay.obuf;
     if (cumm) {
         h.cond_w1 = a->cond_w1; h.cond_b1 = a->cond_b1; h.cond_w2 = a->cond_w2; h.cond_b2 = a->cond_b2; h.w_key = a->w_key; h.enc = a->enc;
         h.cumm = fs + lay.cumm; h.prev_attn = fs + lay.prev_attn; h.keyin = fs + lay.keyin; h.Kdyn = fs + lay.Kdyn;
@@ -410,7 +422,7 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
     FT_CHECK_HIP(hipMemsetAsync(a->n_done_dev, 0, sizeof(int), st));
     FT_CHECK_HIP(hipMemcpyAsync(base + lay.off_dev, &h, sizeof(DecodeDev), hipMemcpyHostToDevice, st));
     const DecodeDev* dP = reinterpret_cast<const DecodeDev*>(base + lay.off_dev);
-    FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_ctx_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
     if (!a->use_graph) {
         for (int i = 0; i < a->N; ++i) enqueue_frame(dP, a->H, a->A, a->L, a->M, cumm, st);
