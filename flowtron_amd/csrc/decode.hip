@@ -12,9 +12,10 @@
 //
 // Nothing returns to the host inside the loop: the frame index and the stop flag live in
 // device memory (the reference's python `if sigmoid(gate) > thr: break`, flowtron.py:823-826,
-// becomes a device flag every later stage tests first).  All kernels take one pointer to a
-// device-resident parameter block, so a chunk of frames can be captured ONCE into a hipGraph
-// and replayed for every chunk of every utterance that reuses the same workspace.
+// becomes a device flag every stage tests).  All kernels take the same parameter block BY VALUE
+// (kernarg segment: weight addresses are known at wave start, so the weight stream is in flight
+// before the frame counter has even been read), and a chunk of frames is captured ONCE into a
+// hipGraph that is replayed for every chunk of every utterance that reuses the same buffers.
 #include <mutex>
 #include <unordered_map>
 
@@ -86,33 +87,33 @@ __device__ __forceinline__ void dot4_seg(const float* __restrict__ w, size_t gst
 
 __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-__device__ __forceinline__ bool frame_live(const DecodeDev* P, int& i) {
-    i = P->ctl[0];
-    return (P->ctl[1] == 0) && (i < P->N);
+__device__ __forceinline__ bool frame_live(const DecodeDev& P, int& i) {
+    i = P.ctl[0];
+    return (P.ctl[1] == 0) && (i < P.N);
 }
 
 // One wave per hidden unit u: gates_g = W_ih[g*H+u,:].x (+ second input segment) + W_hh[g*H+u,:].h + b
 template <int WHICH>   // 0 attention_lstm, 1 lstm l0, 2 lstm l1
-__global__ __launch_bounds__(256) void dec_lstm_k(const DecodeDev* __restrict__ P) {
+__global__ __launch_bounds__(256) void dec_lstm_k(const DecodeDev P) {
     int i;
-    if (!frame_live(P, i)) return;
-    const int lane = threadIdx.x & 63;
+    const bool live = frame_live(P, i);        // the exit is taken AFTER the GEMV: weight addresses do not depend on the
+    const int lane = threadIdx.x & 63;         // frame counter, so their loads are in flight while ctl is still on its way
     const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int H = P->H;
+    const int H = P.H;
     if (u >= H) return;
     const int par = i & 1;
     const float *w_ih, *w_hh, *b_ih, *b_hh, *x0, *x1 = nullptr;
     float *hbuf, *cbuf;
     int K0, K1 = 0;
     if (WHICH == 0) {
-        w_ih = P->att_w_ih; w_hh = P->att_w_hh; b_ih = P->att_b_ih; b_hh = P->att_b_hh;
-        x0 = P->prev; K0 = P->M; hbuf = P->h_att; cbuf = P->c_att;
+        w_ih = P.att_w_ih; w_hh = P.att_w_hh; b_ih = P.att_b_ih; b_hh = P.att_b_hh;
+        x0 = P.prev; K0 = P.M; hbuf = P.h_att; cbuf = P.c_att;
     } else if (WHICH == 1) {
-        w_ih = P->l0_w_ih; w_hh = P->l0_w_hh; b_ih = P->l0_b_ih; b_hh = P->l0_b_hh;
-        x0 = P->h_att + (par ^ 1) * H; K0 = H; x1 = P->ctx; K1 = P->A; hbuf = P->h0; cbuf = P->c0;
+        w_ih = P.l0_w_ih; w_hh = P.l0_w_hh; b_ih = P.l0_b_ih; b_hh = P.l0_b_hh;
+        x0 = P.h_att + (par ^ 1) * H; K0 = H; x1 = P.ctx; K1 = P.A; hbuf = P.h0; cbuf = P.c0;
     } else {
-        w_ih = P->l1_w_ih; w_hh = P->l1_w_hh; b_ih = P->l1_b_ih; b_hh = P->l1_b_hh;
-        x0 = P->h0 + (par ^ 1) * H; K0 = H; hbuf = P->h1; cbuf = P->c1;
+        w_ih = P.l1_w_ih; w_hh = P.l1_w_hh; b_ih = P.l1_b_ih; b_hh = P.l1_b_hh;
+        x0 = P.h0 + (par ^ 1) * H; K0 = H; hbuf = P.h1; cbuf = P.c1;
     }
     const float* hold = hbuf + par * H;
     const int Kin = K0 + K1;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void dec_lstm_k(const DecodeDev* __restrict__ 
             pre[g] = wave_sum(s) + b_ih[row] + b_hh[row];
         }
     }
-    if (lane == 0) {
+    if (live && lane == 0) {
         const float ig = 1.f / (1.f + expf(-pre[0]));
         const float fg = 1.f / (1.f + expf(-pre[1]));
         const float gg = tanhf(pre[2]);
@@ -152,55 +153,55 @@ __global__ __launch_bounds__(256) void dec_lstm_k(const DecodeDev* __restrict__ 
 
 // y[n] = act(W[n,:].x + b[n]), one wave per row.  WHICH: 0 query (x = new h_att), 1 dense0 (x = new h1), 2 dense1 (x = u1)
 template <int WHICH>
-__global__ __launch_bounds__(256) void dec_gemv_k(const DecodeDev* __restrict__ P) {
+__global__ __launch_bounds__(256) void dec_gemv_k(const DecodeDev P) {
     int i;
-    if (!frame_live(P, i)) return;
+    const bool live = frame_live(P, i);
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int H = P->H;
+    const int H = P.H;
     const int par = i & 1;
     const float *W, *b = nullptr, *x;
     float* y;
     int N, K;
-    if (WHICH == 0) { W = P->w_query; x = P->h_att + (par ^ 1) * H; y = P->q; N = P->A; K = H; }
-    else if (WHICH == 1) { W = P->d0_w; b = P->d0_b; x = P->h1 + (par ^ 1) * H; y = P->u1; N = H; K = H; }
-    else { W = P->d1_w; b = P->d1_b; x = P->u1; y = P->u2; N = H; K = H; }
+    if (WHICH == 0) { W = P.w_query; x = P.h_att + (par ^ 1) * H; y = P.q; N = P.A; K = H; }
+    else if (WHICH == 1) { W = P.d0_w; b = P.d0_b; x = P.h1 + (par ^ 1) * H; y = P.u1; N = H; K = H; }
+    else { W = P.d1_w; b = P.d1_b; x = P.u1; y = P.u2; N = H; K = H; }
     if (n >= N) return;
     float s = wave_sum(dot_seg(W + (size_t)n * K, x, K, lane));
-    if (lane == 0) {
+    if (live && lane == 0) {
         if (WHICH != 0) s = tanhf(s + b[n]);
         y[n] = s;
     }
 }
 
 // S3a  attention scores: one wave per text position l (grid = ceil(L/4)); e[l] = (1/temp) sum_a v[a] tanh(q[a] + K[l][a])
-__global__ __launch_bounds__(256) void dec_score_k(const DecodeDev* __restrict__ P) {
+__global__ __launch_bounds__(256) void dec_score_k(const DecodeDev P) {
     int i;
     if (!frame_live(P, i)) return;
-    const int L = P->L, A = P->A;
+    const int L = P.L, A = P.A;
     const int lane = threadIdx.x & 63, l = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (l >= L) return;
-    const float* Kmat = P->Kdyn ? P->Kdyn : P->K;
+    const float* Kmat = P.Kdyn ? P.Kdyn : P.K;
     const float* kr = Kmat + (size_t)l * A;
     float s = 0.f;
-    for (int a = lane; a < A; a += 64) s += P->v[a] * tanhf(P->q[a] + kr[a]);
+    for (int a = lane; a < A; a += 64) s += P.v[a] * tanhf(P.q[a] + kr[a]);
     s = wave_sum(s);
-    if (lane == 0) P->escore[l] = s * P->inv_temp;
+    if (lane == 0) P.escore[l] = s * P.inv_temp;
 }
 
 // S3b  softmax over L (recomputed by every workgroup: L floats) + context for 64 channels per workgroup (grid = ceil(A/64));
 //      workgroup 0 also stores the attention row and advances the cumulative-attention state.
-__global__ __launch_bounds__(256) void dec_ctx_k(const DecodeDev* __restrict__ P) {
+__global__ __launch_bounds__(256) void dec_ctx_k(const DecodeDev P) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [L] probabilities, [4] reduction, [4][64] partial context
     int i;
     if (!frame_live(P, i)) return;
-    const int L = P->L, A = P->A;
+    const int L = P.L, A = P.A;
     float* e = sm;
     float* red = sm + L;
     float* part = red + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float m = -INFINITY;
-    for (int l = tid; l < L; l += 256) { const float x = P->escore[l]; e[l] = x; m = fmaxf(m, x); }
+    for (int l = tid; l < L; l += 256) { const float x = P.escore[l]; e[l] = x; m = fmaxf(m, x); }
     m = wave_max(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
@@ -215,39 +216,39 @@ __global__ __launch_bounds__(256) void dec_ctx_k(const DecodeDev* __restrict__ P
     for (int l = tid; l < L; l += 256) e[l] = e[l] / s;
     __syncthreads();
     if (blockIdx.x == 0) {
-        float* arow = P->attn_out + (size_t)i * L;
+        float* arow = P.attn_out + (size_t)i * L;
         for (int l = tid; l < L; l += 256) {
             const float pl = e[l];
             arow[l] = pl;
-            if (P->cumm) { P->prev_attn[l] = pl; P->cumm[l] += pl; }      // read by the NEXT frame's dec_cond_k
+            if (P.cumm) { P.prev_attn[l] = pl; P.cumm[l] += pl; }      // read by the NEXT frame's dec_cond_k
         }
     }
     const int a = blockIdx.x * 64 + lane;
     float c = 0.f;
     if (a < A)
-        for (int l = wave; l < L; l += 4) c += e[l] * P->V[(size_t)l * A + a];
+        for (int l = wave; l < L; l += 4) c += e[l] * P.V[(size_t)l * A + a];
     part[wave * 64 + lane] = c;
     __syncthreads();
-    if (wave == 0 && a < A) P->ctx[a] = part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane];
+    if (wave == 0 && a < A) P.ctx[a] = part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane];
 }
 
 // Location features -> key modulation for text position l (one workgroup per l):
 //   h1[l'][c] = relu(b1[c] + sum_{ch<2,k<5} w1[c][ch][k] * x_ch[l'+k-2]),  x_0 = cumulative attention, x_1 = previous attention
 //   cond[l][e] = sigmoid(b2[e] + sum_{c<32,k<3} w2[e][c][k] * h1[l+k-1][c]);   keyin[l][e] = enc[l][e] * cond[l][e]
-__global__ __launch_bounds__(256) void dec_cond_k(const DecodeDev* __restrict__ P) {
+__global__ __launch_bounds__(256) void dec_cond_k(const DecodeDev P) {
     __shared__ float h1[3][32];
     int i;
     if (!frame_live(P, i)) return;
-    const int L = P->L, E = P->E, l = blockIdx.x, tid = threadIdx.x;
+    const int L = P.L, E = P.E, l = blockIdx.x, tid = threadIdx.x;
     if (tid < 96) {
         const int j = tid >> 5, c = tid & 31, lp = l + j - 1;
         float v = 0.f;
         if (lp >= 0 && lp < L) {
-            v = P->cond_b1[c];
+            v = P.cond_b1[c];
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 const int ls = lp + k - 2;
-                if (ls >= 0 && ls < L) v += P->cond_w1[(c * 2 + 0) * 5 + k] * P->cumm[ls] + P->cond_w1[(c * 2 + 1) * 5 + k] * P->prev_attn[ls];
+                if (ls >= 0 && ls < L) v += P.cond_w1[(c * 2 + 0) * 5 + k] * P.cumm[ls] + P.cond_w1[(c * 2 + 1) * 5 + k] * P.prev_attn[ls];
             }
             v = fmaxf(v, 0.f);
         }
@@ -255,74 +256,74 @@ __global__ __launch_bounds__(256) void dec_cond_k(const DecodeDev* __restrict__ 
     }
     __syncthreads();
     for (int e = tid; e < E; e += 256) {
-        float v = P->cond_b2[e];
-        const float* w = P->cond_w2 + (size_t)e * 96;
+        float v = P.cond_b2[e];
+        const float* w = P.cond_w2 + (size_t)e * 96;
 #pragma unroll
         for (int c = 0; c < 32; ++c)
 #pragma unroll
             for (int k = 0; k < 3; ++k) v += w[c * 3 + k] * h1[k][c];
         const float cond = 1.f / (1.f + expf(-v));
-        P->keyin[(size_t)l * E + e] = P->enc[(size_t)l * E + e] * cond;
+        P.keyin[(size_t)l * E + e] = P.enc[(size_t)l * E + e] * cond;
     }
 }
 
 // Kdyn[l][a] = sum_e w_key[a][e] * keyin[l][e]; grid (L, ceil(A/16)), one wave per 4 rows a
-__global__ __launch_bounds__(256) void dec_key_k(const DecodeDev* __restrict__ P) {
+__global__ __launch_bounds__(256) void dec_key_k(const DecodeDev P) {
     int i;
     if (!frame_live(P, i)) return;
-    const int A = P->A, E = P->E, l = blockIdx.x;
+    const int A = P.A, E = P.E, l = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* x = P->keyin + (size_t)l * E;
+    const float* x = P.keyin + (size_t)l * E;
     for (int r = 0; r < 4; ++r) {
         const int a = blockIdx.y * 16 + wave * 4 + r;
         if (a >= A) break;
-        const float s = wave_sum(dot_seg(P->w_key + (size_t)a * E, x, E, lane));
-        if (lane == 0) P->Kdyn[(size_t)l * A + a] = s;
+        const float s = wave_sum(dot_seg(P.w_key + (size_t)a * E, x, E, lane));
+        if (lane == 0) P.Kdyn[(size_t)l * A + a] = s;
     }
 }
 
 // S8a  1x1 conv: one wave per output row n < 2M (grid = ceil(2M/4)); obuf[n] = conv_w[n,:].u2 + conv_b[n]
-__global__ __launch_bounds__(256) void dec_conv_k(const DecodeDev* __restrict__ P) {
+__global__ __launch_bounds__(256) void dec_conv_k(const DecodeDev P) {
     int i;
     if (!frame_live(P, i)) return;
     const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= 2 * P->M) return;
-    const float s = wave_sum(dot_seg(P->conv_w + (size_t)n * P->H, P->u2, P->H, lane));
-    if (lane == 0) P->obuf[n] = s + P->conv_b[n];
+    if (n >= 2 * P.M) return;
+    const float s = wave_sum(dot_seg(P.conv_w + (size_t)n * P.H, P.u2, P.H, lane));
+    if (lane == 0) P.obuf[n] = s + P.conv_b[n];
 }
 
 // S8b  inverse affine coupling, gate sigmoid/threshold (flowtron.py:823-826), frame bookkeeping -- one small workgroup
-__global__ __launch_bounds__(256) void dec_fin_k(const DecodeDev* __restrict__ P) {
+__global__ __launch_bounds__(256) void dec_fin_k(const DecodeDev P) {
     __shared__ float red[4];
     int i;
     if (!frame_live(P, i)) return;
-    const int M = P->M, H = P->H, A = P->A;
+    const int M = P.M, H = P.H, A = P.A;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int par = i & 1;
     float g = 0.f;
-    if (P->gate_w) {
-        const float* hn = P->h_att + (par ^ 1) * H;
-        for (int k = tid; k < H; k += 256) g += P->gate_w[k] * hn[k];
-        for (int k = tid; k < A; k += 256) g += P->gate_w[H + k] * P->ctx[k];
+    if (P.gate_w) {
+        const float* hn = P.h_att + (par ^ 1) * H;
+        for (int k = tid; k < H; k += 256) g += P.gate_w[k] * hn[k];
+        for (int k = tid; k < A; k += 256) g += P.gate_w[H + k] * P.ctx[k];
         g = wave_sum(g);
         if (lane == 0) red[wave] = g;
     }
     __syncthreads();
     for (int c = tid; c < M; c += 256) {
-        const float x = (P->residual[(size_t)i * M + c] - P->obuf[M + c]) / expf(P->obuf[c]);
-        P->mel_out[(size_t)i * M + c] = x;
-        P->prev[c] = x;
+        const float x = (P.residual[(size_t)i * M + c] - P.obuf[M + c]) / expf(P.obuf[c]);
+        P.mel_out[(size_t)i * M + c] = x;
+        P.prev[c] = x;
     }
     if (tid == 0) {
         int done = 0;
-        if (P->gate_w) {
-            const float gs = P->gate_b[0] + red[0] + red[1] + red[2] + red[3];
+        if (P.gate_w) {
+            const float gs = P.gate_b[0] + red[0] + red[1] + red[2] + red[3];
             const float sg = 1.f / (1.f + expf(-gs));
-            if (sg > P->gate_threshold) done = 1;
+            if (sg > P.gate_threshold) done = 1;
         }
-        P->ctl[0] = i + 1;
-        P->n_done_dev[0] = i + 1;
-        if (done) P->ctl[1] = 1;
+        P.ctl[0] = i + 1;
+        P.n_done_dev[0] = i + 1;
+        if (done) P.ctl[1] = 1;
     }
 }
 
@@ -352,7 +353,7 @@ constexpr int GRAPH_FRAMES = 8;
 std::mutex g_graph_mu;
 std::unordered_map<uint64_t, hipGraphExec_t> g_graph_cache;
 
-int enqueue_frame(const DecodeDev* dP, int H, int A, int L, int M, bool cumm, hipStream_t st) {
+int enqueue_frame(const DecodeDev& dP, int H, int A, int L, int M, bool cumm, hipStream_t st) {
     const dim3 b256(256), b1024(1024);
     hipLaunchKernelGGL(dec_lstm_k<0>, dim3(cdiv(H, 4)), b256, 0, st, dP);
     hipLaunchKernelGGL(dec_gemv_k<0>, dim3(cdiv(A, 4)), b256, 0, st, dP);
@@ -420,8 +421,7 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
     // pageable host memory stages the bytes before returning, so `h` may live on this stack frame.
     FT_CHECK_HIP(hipMemsetAsync(base + lay.off_state, 0, lay.total - lay.off_state, st));
     FT_CHECK_HIP(hipMemsetAsync(a->n_done_dev, 0, sizeof(int), st));
-    FT_CHECK_HIP(hipMemcpyAsync(base + lay.off_dev, &h, sizeof(DecodeDev), hipMemcpyHostToDevice, st));
-    const DecodeDev* dP = reinterpret_cast<const DecodeDev*>(base + lay.off_dev);
+    const DecodeDev& dP = h;       // passed to every stage kernel by value (kernarg segment)
     FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_ctx_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
     if (!a->use_graph) {
@@ -430,14 +430,20 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
         return FT_OK;
     }
     // hipGraph path: GRAPH_FRAMES frames per graph; kernels past frame N or past the stop flag are no-ops.
-    const uint64_t key = (reinterpret_cast<uint64_t>(dP) * 1000003ull) ^ ((uint64_t)a->H << 40) ^ ((uint64_t)a->A << 28) ^
-                         ((uint64_t)a->L << 12) ^ (uint64_t)a->M ^ (cumm ? (1ull << 63) : 0ull);
+    // the graph bakes the by-value parameter block: key = every byte of it (value-initialised, so padding is zero).
+    // Callers that keep their buffers persistent (model.AR_Step.infer does) replay the same graph for every utterance.
+    uint64_t key = 1469598103934665603ull;
+    {
+        const unsigned char* c = reinterpret_cast<const unsigned char*>(&h);
+        for (size_t k = 0; k < sizeof(DecodeDev); ++k) { key ^= c[k]; key *= 1099511628211ull; }
+    }
     hipGraphExec_t exec = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graph_cache.find(key);
         if (it != g_graph_cache.end()) exec = it->second;
         if (!exec) {
+            if (g_graph_cache.size() > 512) return ft_fail(FT_EHIP, "ft_decode_flow: graph cache overflow (unstable buffer addresses)");
             hipStream_t cs;
             FT_CHECK_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             hipGraph_t graph = nullptr;

@@ -261,22 +261,32 @@ class AR_Step(nn.Module):
         L.require_cuda(residual, text)
         Lk = text.shape[0]
         att = self.attention_layer
-        K = ops.linear(text, att.key.linear_layer.weight, None).reshape(Lk, -1).contiguous()
-        V = ops.linear(text, att.value.linear_layer.weight, None).reshape(Lk, -1).contiguous()
         H = self.lstm.weight_hh_l0.shape[1]
-        A = K.shape[1]
+        A = att.key.linear_layer.weight.shape[0]
         dev = residual.device
-        res = residual.reshape(N, M).contiguous().float()
-        mel_out = torch.empty(N, M, device=dev, dtype=torch.float32)
-        attn_out = torch.zeros(N, Lk, device=dev, dtype=torch.float32)
-        n_done = torch.zeros(1, device=dev, dtype=torch.int32)
+        # persistent per-(N, L) buffers: the decode hipGraph bakes every pointer, so stable addresses = one capture,
+        # replayed for every later utterance of this shape
+        key = (N, Lk, str(dev))
+        bufs = self._decode_bufs.get(key) if hasattr(self, "_decode_bufs") else None
+        if bufs is None:
+            if not hasattr(self, "_decode_bufs"):
+                self._decode_bufs = {}
+            f32 = dict(device=dev, dtype=torch.float32)
+            bufs = self._decode_bufs[key] = dict(K=torch.empty(Lk, A, **f32), V=torch.empty(Lk, A, **f32), res=torch.empty(N, M, **f32),
+                                                 mel=torch.empty(N, M, **f32), attn=torch.empty(N, Lk, **f32),
+                                                 n_done=torch.zeros(1, device=dev, dtype=torch.int32))
+        K, V, res, mel_out, attn_out, n_done = (bufs[k] for k in ("K", "V", "res", "mel", "attn", "n_done"))
+        K.copy_(ops.linear(text, att.key.linear_layer.weight, None).reshape(Lk, A))
+        V.copy_(ops.linear(text, att.value.linear_layer.weight, None).reshape(Lk, A))
+        res.copy_(residual.reshape(N, M))
+        attn_out.zero_()
         cumm = self.use_cumm_attention
         E = text.shape[2]
         enc2d = text.reshape(Lk, E).contiguous()
         nbytes = L.lib().ft_decode_workspace_bytes(Lk, H, A, M, E if cumm else 1)
-        if self._decode_work is None or self._decode_work.numel() < nbytes or self._decode_work.device != dev:
-            self._decode_work = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        work = self._decode_work
+        work = bufs.get("work")
+        if work is None or work.numel() < nbytes:
+            work = bufs["work"] = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         has_gate = hasattr(self, "gate_layer")
         if use_graph is None:
             use_graph = os.environ.get("FLOWTRON_DECODE_GRAPH", "1") != "0"
@@ -302,8 +312,9 @@ class AR_Step(nn.Module):
         L.check(L.lib().ft_decode_flow(C.byref(args), L.stream()), "ft_decode_flow")
         n = int(n_done.item()) if has_gate else N          # single host read per flow (the reference syncs every frame)
         del keep
-        mel = mel_out[:n].reshape(n, 1, M)
-        attn_rows = [attn_out[i].reshape(1, 1, Lk) for i in range(n)]
+        mel = mel_out[:n].clone().reshape(n, 1, M)          # the persistent buffers are overwritten by the next call
+        attn_all = attn_out[:n].clone()
+        attn_rows = [attn_all[i].reshape(1, 1, Lk) for i in range(n)]
         return mel, attn_rows
 
 
