@@ -1,0 +1,191 @@
+// Attention-CTC loss of Flowtron (reference flowtron.py:155-182, 245-274) as a banded dynamic programme.
+//
+// The reference loops over samples: pad a blank column (logit `blank_logprob`), slice [:T_b, :K_b+1], log_softmax over the
+// K_b+1 classes, nn.CTCLoss(blank=0, reduction='mean', zero_infinity=True) against the trivial target 1..K_b, then
+// averages over the batch.  Because the target labels are all distinct, the extended label sequence
+// (blank,1,blank,2,...,K,blank) has 2K+1 states with the plain CTC transitions (stay, +1, and +2 into a label state), and
+// every label class owns exactly ONE state -- so the gradient needs no per-class reduction.
+//
+// One workgroup per sample, one thread per state, the time recursion is the only sequential dimension:
+//   forward : lse[t] (log-softmax normaliser, one wave per frame), alpha[t][s] in LDS (double buffer) + saved to HBM,
+//             nll_b = -logsumexp(alpha[T-1][2K], alpha[T-1][2K-1]);  loss += nll_b / K_b / B
+//   backward: beta recursion in LDS; d loss / d logit[t][k] = (softmax[t][k] - exp(alpha+beta+nll-logp)[state 2k-1]) * g/(K_b B)
+// The next frame's logits are prefetched into registers before the barrier of the current frame, so the per-frame cost is
+// one LDS round trip + three exp/log, not a global-memory round trip.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    if (m == -INFINITY) return -INFINITY;
+    return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+__device__ __forceinline__ float lse2(float a, float b) {
+    const float m = fmaxf(a, b);
+    if (m == -INFINITY) return -INFINITY;
+    return m + logf(expf(a - m) + expf(b - m));
+}
+
+// lse[b][t] = log(exp(blank) + sum_{k<K_b} exp(lp[b][t][k])) for t < T_b  (grid: (ceil(T/4), B), one wave per frame)
+__global__ __launch_bounds__(256) void ctc_lse_k(const float* __restrict__ lp, const int* __restrict__ in_lens,
+                                                 const int* __restrict__ out_lens, float blank, float* __restrict__ lse,
+                                                 int T, int L) {
+    const int b = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int K = min(in_lens[b], L), Tb = min(out_lens[b], T);
+    if (t >= Tb) return;
+    const float* row = lp + ((size_t)b * T + t) * L;
+    float m = blank;
+    for (int k = lane; k < K; k += 64) m = fmaxf(m, row[k]);
+    m = wave_max(m);
+    float s = (lane == 0) ? expf(blank - m) : 0.f;
+    for (int k = lane; k < K; k += 64) s += expf(row[k] - m);
+    s = wave_sum(s);
+    if (lane == 0) lse[(size_t)b * T + t] = m + logf(s);
+}
+
+// one workgroup per sample, thread s = extended state
+__global__ __launch_bounds__(1024) void ctc_alpha_k(const float* __restrict__ lp, const int* __restrict__ in_lens,
+                                                    const int* __restrict__ out_lens, float blank, const float* __restrict__ lse,
+                                                    float* __restrict__ alpha, float* __restrict__ nll, float* __restrict__ loss,
+                                                    int B, int T, int L) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // 2 x (S + 2), two -inf guard cells in front of each
+    const int b = blockIdx.x, s = threadIdx.x;
+    const int K = min(in_lens[b], L), Tb = min(out_lens[b], T);
+    const int S = 2 * K + 1, SP = 2 * L + 1 + 2;
+    float* buf[2] = {sm + 2, sm + SP + 2};
+    if (s < 2) { sm[s] = -INFINITY; sm[SP + s] = -INFINITY; }
+    const bool on = s < S;
+    const bool lab = (s & 1) != 0;
+    const int k = (s - 1) >> 1;
+    const float* lpb = lp + (size_t)b * T * L;
+    const float* lseb = lse + (size_t)b * T;
+    float* ab = alpha + (size_t)b * T * (2 * L + 1);
+    // t = 0
+    float logit = (on && lab) ? lpb[k] : blank;
+    float norm = (Tb > 0) ? lseb[0] : 0.f;
+    float a = -INFINITY;
+    if (on && s < 2) a = logit - norm;
+    if (on) { buf[0][s] = a; if (Tb > 0) ab[s] = a; }
+    // prefetch t = 1
+    float logit_n = blank, norm_n = 0.f;
+    if (Tb > 1) { if (on && lab) logit_n = lpb[(size_t)L + k]; norm_n = lseb[1]; }
+    __syncthreads();
+    int cur = 0;
+    for (int t = 1; t < Tb; ++t) {
+        logit = logit_n; norm = norm_n;
+        if (t + 1 < Tb) { if (on && lab) logit_n = lpb[(size_t)(t + 1) * L + k]; norm_n = lseb[t + 1]; }
+        if (on) {
+            const float* pv = buf[cur];
+            const float x2 = (lab && s >= 3) ? pv[s - 2] : -INFINITY;
+            a = lse3(pv[s], pv[s - 1], x2) + (lab ? logit : blank) - norm;
+            buf[cur ^ 1][s] = a;
+            ab[(size_t)t * (2 * L + 1) + s] = a;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (s == 0) {
+        float v = INFINITY;
+        if (Tb > 0 && K > 0) v = -lse2(buf[cur][S - 1], buf[cur][S - 2]);
+        nll[b] = v;
+        if (v != INFINITY && K > 0) atomicAdd(loss, v / (float)K / (float)B);      // zero_infinity=True, reduction='mean', batch mean
+    }
+}
+
+__global__ __launch_bounds__(1024) void ctc_beta_grad_k(const float* __restrict__ lp, const int* __restrict__ in_lens,
+                                                        const int* __restrict__ out_lens, float blank, const float* __restrict__ lse,
+                                                        const float* __restrict__ alpha, const float* __restrict__ nll,
+                                                        const float* __restrict__ gout, float* __restrict__ dlp, int B, int T, int L) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // 2 x (S + 2), two -inf guard cells BEHIND each
+    const int b = blockIdx.x, s = threadIdx.x;
+    const int K = min(in_lens[b], L), Tb = min(out_lens[b], T);
+    const float nl = nll[b];
+    if (nl == INFINITY || Tb <= 0 || K <= 0) return;               // zero_infinity: dlp stays zero (memset by the host)
+    const int S = 2 * K + 1, SP = 2 * L + 1 + 2;
+    float* buf[2] = {sm, sm + SP};
+    if (s < 2) { sm[S + s] = -INFINITY; sm[SP + S + s] = -INFINITY; }
+    const bool on = s < S;
+    const bool lab = (s & 1) != 0;
+    const int k = (s - 1) >> 1;
+    const float* lpb = lp + (size_t)b * T * L;
+    const float* lseb = lse + (size_t)b * T;
+    const float* ab = alpha + (size_t)b * T * (2 * L + 1);
+    float* db = dlp + (size_t)b * T * L;
+    const float scale = gout[0] / (float)K / (float)B;
+    int t = Tb - 1;
+    float logit = (on && lab) ? lpb[(size_t)t * L + k] : blank;
+    float norm = lseb[t];
+    float al = on ? ab[(size_t)t * (2 * L + 1) + s] : -INFINITY;
+    float be = -INFINITY;
+    if (on && s >= S - 2) be = logit - norm;
+    if (on) {
+        buf[0][s] = be;
+        if (lab) { const float logp = logit - norm; db[(size_t)t * L + k] = (expf(logp) - expf(al + be + nl - logp)) * scale; }
+    }
+    float logit_n = blank, norm_n = 0.f, al_n = -INFINITY;
+    if (t - 1 >= 0) {
+        if (on && lab) logit_n = lpb[(size_t)(t - 1) * L + k];
+        norm_n = lseb[t - 1];
+        if (on) al_n = ab[(size_t)(t - 1) * (2 * L + 1) + s];
+    }
+    __syncthreads();
+    int cur = 0;
+    for (t = Tb - 2; t >= 0; --t) {
+        logit = logit_n; norm = norm_n; al = al_n;
+        if (t - 1 >= 0) {
+            if (on && lab) logit_n = lpb[(size_t)(t - 1) * L + k];
+            norm_n = lseb[t - 1];
+            if (on) al_n = ab[(size_t)(t - 1) * (2 * L + 1) + s];
+        }
+        if (on) {
+            const float* nx = buf[cur];
+            const float x2 = (lab && s + 2 < S) ? nx[s + 2] : -INFINITY;
+            const float logp = (lab ? logit : blank) - norm;
+            be = lse3(nx[s], nx[s + 1], x2) + logp;
+            buf[cur ^ 1][s] = be;
+            if (lab) db[(size_t)t * L + k] = (expf(logp) - expf(al + be + nl - logp)) * scale;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t ft_attn_ctc_workspace_floats(int B, int T, int L) {
+    return (size_t)B * T * (2 * (size_t)L + 1) + (size_t)B * T + (size_t)B;        // alpha | lse | nll
+}
+
+extern "C" int ft_attn_ctc_fwd(const float* lp, const int32_t* in_lens, const int32_t* out_lens, float blank_logprob,
+                               float* work, float* loss, int B, int T, int L, void* stream) {
+    FT_CHECK_ARG(lp && in_lens && out_lens && work && loss && B >= 1 && T >= 1 && L >= 1);
+    if (2 * L + 1 > 1024) return ft_fail(FT_EUNSUPPORTED, "ft_attn_ctc_fwd: L=%d needs more than 1024 states", L);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* alpha = work;
+    float* lse = alpha + (size_t)B * T * (2 * (size_t)L + 1);
+    float* nll = lse + (size_t)B * T;
+    const int threads = cdiv(2 * L + 1, 64) * 64;
+    FT_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
+    hipLaunchKernelGGL(ctc_lse_k, dim3(cdiv(T, 4), B), dim3(256), 0, st, lp, in_lens, out_lens, blank_logprob, lse, T, L);
+    hipLaunchKernelGGL(ctc_alpha_k, dim3(B), dim3(threads), sizeof(float) * 2 * (2 * L + 3), st, lp, in_lens, out_lens, blank_logprob,
+                       lse, alpha, nll, loss, B, T, L);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+
+extern "C" int ft_attn_ctc_bwd(const float* lp, const int32_t* in_lens, const int32_t* out_lens, float blank_logprob,
+                               const float* work, const float* gout_dev, float* dlp, int B, int T, int L, void* stream) {
+    FT_CHECK_ARG(lp && in_lens && out_lens && work && gout_dev && dlp && B >= 1 && T >= 1 && L >= 1);
+    if (2 * L + 1 > 1024) return ft_fail(FT_EUNSUPPORTED, "ft_attn_ctc_bwd: L=%d needs more than 1024 states", L);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const float* alpha = work;
+    const float* lse = alpha + (size_t)B * T * (2 * (size_t)L + 1);
+    const float* nll = lse + (size_t)B * T;
+    const int threads = cdiv(2 * L + 1, 64) * 64;
+    FT_CHECK_HIP(hipMemsetAsync(dlp, 0, sizeof(float) * (size_t)B * T * L, st));
+    hipLaunchKernelGGL(ctc_beta_grad_k, dim3(B), dim3(threads), sizeof(float) * 2 * (2 * L + 3), st, lp, in_lens, out_lens, blank_logprob,
+                       lse, alpha, nll, gout_dev, dlp, B, T, L);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}

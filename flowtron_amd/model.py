@@ -426,10 +426,10 @@ class Flowtron(nn.Module):
 # Loss -- flowtron.py:155-275
 # --------------------------------------------------------------------------
 class AttentionCTCLoss(nn.Module):
-    """flowtron.py:155-182 batched: the reference loops over samples (slice, log_softmax, CTCLoss with target
-    1..K, reduction='mean' per sample).  Here the key axis is masked (to -1e4) beyond K_b before ONE log_softmax and ONE
-    ctc_loss call over the batch with per-sample lengths; per-sample losses are divided by K_b and averaged -- the
-    same value, without F*B host synchronisations.  (torch's CTC op kept for now.)"""
+    """flowtron.py:155-182: the reference loops over samples (slice, log_softmax, CTCLoss with target 1..K,
+    reduction='mean' per sample, F*B host synchronisations per step).  Device tensors go through ONE pair of HIP kernels
+    for the whole batch (ft_attn_ctc_fwd/bwd: log-softmax normaliser + banded alpha/beta recursion, one workgroup per
+    sample).  The torch formulation below the early return is the same computation for CPU tensors (host-side tests)."""
 
     def __init__(self, blank_logprob=-1):
         super().__init__()
@@ -437,6 +437,9 @@ class AttentionCTCLoss(nn.Module):
 
     def forward(self, attn_logprob, in_lens, out_lens):
         """attn_logprob [B,T,L] in natural time order."""
+        if attn_logprob.is_cuda:          # product path: banded-DP HIP kernel (csrc/ctc.hip), no torch math
+            return ops.AttnCTCFn.apply(attn_logprob, ops.lens32(in_lens), ops.lens32(out_lens), self.blank_logprob)
+        # host restatement (CPU tensors only: used by the CPU test-suite to pin the batching against the per-sample loop)
         B, T, Lk = attn_logprob.shape
         x = torch.nn.functional.pad(attn_logprob, (1, 0), value=self.blank_logprob)       # [B,T,L+1], blank first
         cls = torch.arange(Lk + 1, device=x.device)[None, None, :]

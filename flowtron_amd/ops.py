@@ -566,3 +566,31 @@ class AddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g, g
+
+
+# --------------------------------------------------------------------------
+# attention-CTC loss (flowtron.py:155-182): banded DP kernel, one workgroup per sample
+# --------------------------------------------------------------------------
+class AttnCTCFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lp, in_lens32, out_lens32, blank_logprob):
+        lp = _c(lp.float())
+        L.require_cuda(lp, in_lens32, out_lens32)
+        B, T, Lk = lp.shape
+        work = torch.empty(L.lib().ft_attn_ctc_workspace_floats(B, T, Lk), device=lp.device, dtype=torch.float32)
+        loss = torch.empty(1, device=lp.device, dtype=torch.float32)
+        L.check(L.lib().ft_attn_ctc_fwd(L.ptr(lp), L.ptr(in_lens32), L.ptr(out_lens32), float(blank_logprob), L.ptr(work),
+                                        L.ptr(loss), B, T, Lk, L.stream()), "ft_attn_ctc_fwd")
+        ctx.save_for_backward(lp, in_lens32, out_lens32, work)
+        ctx.blank = float(blank_logprob)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lp, in32, out32, work = ctx.saved_tensors
+        B, T, Lk = lp.shape
+        gd = g.reshape(1).to(torch.float32).contiguous()
+        dlp = torch.empty_like(lp)
+        L.check(L.lib().ft_attn_ctc_bwd(L.ptr(lp), L.ptr(in32), L.ptr(out32), ctx.blank, L.ptr(work), L.ptr(gd), L.ptr(dlp),
+                                        B, T, Lk, L.stream()), "ft_attn_ctc_bwd")
+        return dlp, None, None, None

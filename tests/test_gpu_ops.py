@@ -335,3 +335,33 @@ def test_gemm_split_k_weight_gradient_shape(env, beta):
     torch.cuda.synchronize()
     assert mad(Cd[:, 3:3 + K], ref) < 2e-4
     assert torch.equal(Cd[:, :3].cpu(), C0[:, :3]) and torch.equal(Cd[:, 3 + K:].cpu(), C0[:, 3 + K:])   # neighbours untouched
+
+
+@pytest.mark.parametrize("blank", [-8.0, -1.0])
+def test_attention_ctc_kernel_vs_oracle(env, blank):
+    """ft_attn_ctc_fwd/bwd against the oracle's per-sample loop (flowtron.py:162-182 restated, pinned by the golden CTC values)."""
+    L, ops = env
+    from oracle import flowtron_oracle as O
+    torch.manual_seed(21)
+    B, T, Lk = 5, 41, 13
+    in_lens = torch.tensor([13, 9, 9, 4, 1])
+    out_lens = torch.tensor([41, 30, 9, 25, 6])                    # sample 2: T == K (single feasible path)
+    lp = torch.log_softmax(torch.randn(B, T, Lk) * 2, 2).requires_grad_(True)
+    ref = O.attention_ctc_loss(lp, in_lens, out_lens, blank_logprob=blank)
+    (ref * 0.37).backward()
+    lpd = lp.detach().cuda().requires_grad_(True)
+    mine = ops.AttnCTCFn.apply(lpd, g(in_lens.int()), g(out_lens.int()), blank)
+    (mine * 0.37).backward()
+    assert abs(mine.item() - ref.item()) < 2e-5 * abs(ref.item()), (mine.item(), ref.item())
+    assert mad(lpd.grad, lp.grad) < 2e-6, mad(lpd.grad, lp.grad)
+    # infeasible sample (more labels than frames): zero_infinity -> contributes 0 loss and 0 gradient
+    out2 = torch.tensor([41, 30, 5, 25, 6])
+    lp2 = lp.detach().clone().requires_grad_(True)
+    ref2 = O.attention_ctc_loss(lp2, in_lens, out2, blank_logprob=blank)
+    ref2.backward()
+    lpd2 = lp.detach().cuda().requires_grad_(True)
+    mine2 = ops.AttnCTCFn.apply(lpd2, g(in_lens.int()), g(out2.int()), blank)
+    mine2.backward()
+    assert abs(mine2.item() - ref2.item()) < 2e-5 * abs(ref2.item())
+    assert mad(lpd2.grad, torch.nan_to_num(lp2.grad)) < 2e-6
+    assert float(lpd2.grad[2].abs().max()) == 0.0
