@@ -266,26 +266,33 @@ __global__ __launch_bounds__(256) void attn_dq_k(const float* __restrict__ Q, co
     }
 }
 
-// dK[l,b,a] = v[a] * sum_t de[b,t,l] * (1 - tanh^2(Q+K))
+// dK[l,b,a] = v[a] * sum_t de[b,t,l] * (1 - tanh^2(Q+K)).  grid = (ceil(L/16), B, TS): the time axis is cut into TS
+// slices so that (L/16)*B*TS workgroups fill the chip (10 x 32 alone leave CUs idle for a 862-frame loop); slices combine
+// with fp32 atomics into the zero-initialised dK (TS == 1: plain stores).
 __global__ __launch_bounds__(256) void attn_dk_k(const float* __restrict__ Q, const float* __restrict__ K,
                                                  const float* __restrict__ v, const int* __restrict__ in_lens,
                                                  const float* __restrict__ de, float* __restrict__ dK,
-                                                 int T, int B, int L, int A) {
+                                                 int T_full, int B, int L, int A, int t_slice) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* de_s = smem;   // [T][16]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = blockIdx.y, l0 = blockIdx.x * 16;
     const int len = min(in_lens[b], L);
-    if (l0 >= len) {      // whole tile is padding: zero gradient
-        for (int idx = tid; idx < 16 * A; idx += 256) {
-            const int j = idx / A, a = idx - j * A;
-            if (l0 + j < L) dK[((long)(l0 + j) * B + b) * A + a] = 0.f;
-        }
+    const bool split = gridDim.z > 1;
+    const int tb = blockIdx.z * t_slice;
+    const int T = min(t_slice, T_full - tb);                 // frames of this slice
+    if (l0 >= len || T <= 0) {      // whole tile is padding: zero gradient (already zero when split)
+        if (!split)
+            for (int idx = tid; idx < 16 * A; idx += 256) {
+                const int j = idx / A, a = idx - j * A;
+                if (l0 + j < L) dK[((long)(l0 + j) * B + b) * A + a] = 0.f;
+            }
         return;
     }
+    Q += (long)tb * B * A;
     for (int idx = tid; idx < T * 16; idx += 256) {
         const int j = idx & 15, t = idx >> 4;
-        de_s[idx] = (l0 + j < len) ? de[((long)b * T + t) * L + l0 + j] : 0.f;
+        de_s[idx] = (l0 + j < len) ? de[((long)b * T_full + tb + t) * L + l0 + j] : 0.f;
     }
     __syncthreads();
     const long qs = (long)B * A;
@@ -331,7 +338,10 @@ __global__ __launch_bounds__(256) void attn_dk_k(const float* __restrict__ Q, co
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int l = l0 + w * 4 + j;
-                if (l < L) dK[((long)l * B + b) * A + a] = dk[j] * va;
+                if (l < L) {
+                    if (split) atomicAdd(dK + ((long)l * B + b) * A + a, dk[j] * va);
+                    else dK[((long)l * B + b) * A + a] = dk[j] * va;
+                }
             }
         }
     }
@@ -373,7 +383,10 @@ extern "C" int ft_attention_bwd(const float* Q, const float* K, const float* v, 
     FT_CHECK_ARG(prior == nullptr || p_save != nullptr);
     FT_CHECK_ARG(B <= 65535);
     const size_t lds_q = sizeof(float) * ((size_t)L * 32 + 256);
-    const size_t lds_k = sizeof(float) * ((size_t)T * 16);
+    int ts = 1;                                             // time slices of the dK kernel
+    while (ts < 8 && (long)cdiv(L, 16) * B * ts < 1024 && cdiv(T, ts * 2) >= 64) ts *= 2;
+    const int t_slice = cdiv(T, ts);
+    const size_t lds_k = sizeof(float) * ((size_t)t_slice * 16);
     if (lds_q > (size_t)MAX_LDS || lds_k > (size_t)MAX_LDS)
         return ft_fail(FT_EUNSUPPORTED, "ft_attention_bwd: T=%d L=%d exceed the LDS tiles (%zu / %zu B)", T, L, lds_k, lds_q);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -386,7 +399,8 @@ extern "C" int ft_attention_bwd(const float* Q, const float* K, const float* v, 
     FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dq_k), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
     FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dk_k), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
     hipLaunchKernelGGL(attn_dq_k, dim3(cdiv(T, 32), B), dim3(256), lds_q, st, Q, K, v, in_lens, de_work, dQ, dv, T, B, L, A);
-    hipLaunchKernelGGL(attn_dk_k, dim3(cdiv(L, 16), B), dim3(256), lds_k, st, Q, K, v, in_lens, de_work, dK, T, B, L, A);
+    if (ts > 1) FT_CHECK_HIP(hipMemsetAsync(dK, 0, sizeof(float) * (size_t)L * B * A, st));
+    hipLaunchKernelGGL(attn_dk_k, dim3(cdiv(L, 16), B, cdiv(T, t_slice)), dim3(256), lds_k, st, Q, K, v, in_lens, de_work, dK, T, B, L, A, t_slice);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

@@ -239,7 +239,8 @@ def test_lstm_seq_bf16_fragment_path(env, T, B, H, reverse):
 
 # ---------------------------------------------------------------- attention
 @pytest.mark.parametrize("T,B,Lk,A,E,prior,with_dlp", [(19, 3, 11, 48, 40, True, True), (40, 2, 37, 640, 64, False, True),
-                                                        (33, 4, 150, 64, 32, True, False), (5, 1, 3, 20, 8, False, False)])
+                                                        (33, 4, 150, 64, 32, True, False), (5, 1, 3, 20, 8, False, False),
+                                                        (300, 2, 20, 64, 16, True, True)])      # long T: time-sliced dK kernel
 def test_attention(env, T, B, Lk, A, E, prior, with_dlp):
     L, ops = env
     torch.manual_seed(T * 3 + Lk)
