@@ -57,6 +57,10 @@ SIGNATURES = {
     "ft_lstm_seq_bwd": ([_p, _l, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "ft_lstm_seq_fwd_range": ([_p, _p, _p, _p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "ft_lstm_seq_bwd_range": ([_p, _l, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "ft_lstm2_supported": ([_i, _i], _i),
+    "ft_lstm2_workspace_bytes": ([_i, _i], _sz),
+    "ft_lstm2_seq_fwd": ([_p] * 13 + [_i, _i, _i, _p], _i),
+    "ft_lstm2_seq_bwd": ([_p] * 12 + [_i, _i, _i, _p], _i),
     "ft_attention_fwd": ([_p] * 8 + [_i, _i, _i, _i, _f, _p], _i),
     "ft_attention_bwd": ([_p] * 13 + [_i, _i, _i, _i, _f, _p], _i),
     "ft_affine_fwd": ([_p, _p, _p, _l, _i, _p], _i),

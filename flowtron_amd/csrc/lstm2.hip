@@ -1,0 +1,380 @@
+// Two stacked LSTM layers as ONE launch chain (the decoder `lstm` of AR_Step: nn.LSTM(1664 -> 1024, num_layers = 2),
+// reference flowtron.py:654, :760-765).
+//
+// A recurrence step is a ~5 us launch that is bound by fixed latency (dispatch, one memory-side round trip for the
+// fragment images, LDS reduce, epilogue), not by work: the chip is nearly idle while it runs.  Layer 1 at time
+// t-1 and layer 0 at time t are independent once h0[t-1] exists, so they are issued as TWO WORKGROUP GROUPS OF THE SAME
+// LAUNCH (a software wavefront): T+1 launches drive both layers instead of 2T, and the per-step input projection of
+// layer 1 rides along as a second fragment stream -- its A operand is exactly the bf16 fragment image of h0 that layer 0
+// wrote one launch earlier, so the batched gx1 GEMM disappears from the forward pass.
+//
+//   forward  launch s : group 0 = layer 0 step s          gates = gx0[s] + h0[s-1] W_hh0^T
+//                       group 1 = layer 1 step s-1        gates = b1 + h0[s-1] W_ih1^T + h1[s-2] W_hh1^T
+//   backward launch s : group 0 = layer 1 step s          dh1 = dy1[s] + dgates1[s+1] W_hh1
+//   (s = T-1 .. -1)     group 1 = layer 0 step s+1        dh0 = dgates1[s+1] W_ih1 + dgates0[s+2] W_hh0
+//
+// bf16 fragment-order operands, fp32 accumulate / state / saved tensors (same conventions as lstm.hip, FT_BF16 path).
+// Requires H % 128 == 0 and B <= 64; callers fall back to two ft_lstm_seq_* sequences otherwise.
+#include "common.h"
+
+namespace {
+
+template <int MT, int G, typename Hook>
+__device__ __forceinline__ void skinny_bf16(const bf16x8* __restrict__ afrag, const bf16x8* __restrict__ wfrag,
+                                            int nchunk, int c0, int cs, int lane, f32x4 (&acc)[MT], Hook&& after_last_loads,
+                                            int a_mt) {
+    bf16x8 w[G], a[G][MT];
+    auto load_group = [&](int cb) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const size_t c = (size_t)(cb + i * cs);
+            w[i] = wfrag[c * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[i][m] = afrag[(c * a_mt + m) * 64 + lane];
+        }
+    };
+    auto mfma_group = [&]() {
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w[i], acc[m], 0, 0, 0);
+    };
+    load_group(c0);
+    for (int cb = c0 + cs * G; cb < nchunk; cb += cs * G) {
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group();
+        load_group(cb);
+    }
+    after_last_loads();                      // younger loads: never delay a fragment wait (vmcnt retires in order)
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group();
+}
+
+__device__ __forceinline__ size_t frag_index(int b, int k, int MT) {
+    const int c = k >> 5, kg = (k >> 3) & 3, e = k & 7, m = b >> 4, li = b & 15;
+    return (((size_t)c * MT + m) * 64 + kg * 16 + li) * 8 + e;
+}
+
+// forward weight image of ONE layer over a K-concatenation [Wa | Wb] (Wa may be null: K = H only):
+//   out[jb][c][lane(kg,li)][e] = W[(li>>2)*H + jb*4 + (li&3)][c*32 + kg*8 + e],  W[r][k] = k < Ka ? Wa[r][k] : Wb[r][k-Ka]
+__global__ void make_wfrag_fwd_cat(const float* __restrict__ wa, int Ka, const float* __restrict__ wb, int Kb,
+                                   unsigned short* __restrict__ out, int H) {
+    const int K = Ka + Kb, nchunk = K >> 5;
+    const size_t total = (size_t)4 * H * K;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const size_t rest = i >> 9;
+        const int c = (int)(rest % nchunk), jb = (int)(rest / nchunk);
+        const int li = lane & 15, kg = lane >> 4;
+        const size_t row = (size_t)(li >> 2) * H + jb * 4 + (li & 3);
+        const int k = c * 32 + kg * 8 + e;
+        out[i] = f2bf(k < Ka ? wa[row * Ka + k] : wb[row * Kb + (k - Ka)]);
+    }
+}
+// backward image of W [4H][Kc]: out[jt][c][lane][e] = W[c*32 + kg*8 + e][jt*16 + li]   (jt over Kc/16 column tiles)
+__global__ void make_wfrag_bwd_t(const float* __restrict__ w, unsigned short* __restrict__ out, int H, int Kc) {
+    const size_t total = (size_t)4 * H * Kc;
+    const int nchunk = (4 * H) >> 5;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const size_t rest = i >> 9;
+        const int c = (int)(rest % nchunk), jt = (int)(rest / nchunk);
+        const int li = lane & 15, kg = lane >> 4;
+        const size_t r = (size_t)c * 32 + kg * 8 + e;
+        out[i] = f2bf(w[r * Kc + jt * 16 + li]);
+    }
+}
+
+struct L2FwdP {
+    const float* gx0; const float* bias1; const int* lens;
+    float *c0, *y0, *gates0, *cell0;
+    float *c1, *y1, *gates1, *cell1;
+    const unsigned short *w0frag, *w1frag;      // [H/4][H/32][64][8], [H/4][2H/32][64][8]
+    unsigned short *h0frag[2], *h1frag[2];      // [H/32][MT][64][8] ping-pong
+    int s, T, B, H;
+};
+
+template <int MT, int G>
+__global__ __launch_bounds__(256) void lstm2_fwd_step(L2FwdP p) {
+    __shared__ float red[4][MT * 16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    const int H = p.H, B = p.B, nblk = H >> 2;
+    const bool L1 = (int)blockIdx.x >= nblk;
+    const int blk = L1 ? blockIdx.x - nblk : blockIdx.x;
+    const int s = L1 ? p.s - 1 : p.s;                      // this layer's time step
+    if (s < 0 || s >= p.T) return;                          // uniform per workgroup
+    const int u0 = blk * 4;
+    const int nchunk = H >> 5;
+
+    constexpr int NROLE = MT * 64;
+    const bool pf_role = (MT <= 2) && tid >= NROLE;
+    const int rr = pf_role ? tid - NROLE : tid;
+    const int eb = rr >> 2, ul = rr & 3, eu = u0 + ul;
+    const bool ev = !pf_role && tid < NROLE && eb < B;
+    const int ebc = eb < B ? eb : B - 1;
+    float* cst = L1 ? p.c1 : p.c0;
+    int len;
+    float gxv[4], c_old;
+    auto issue_epilogue_loads = [&]() {
+        len = p.lens[ebc];
+        if (L1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gxv[g] = p.bias1[(size_t)g * H + eu];
+        } else {
+            const int t_ld = (pf_role && s + 1 < p.T) ? s + 1 : s;          // role-less waves warm L2 with the next gx0 row
+            const float* gp = p.gx0 + ((size_t)t_ld * B + ebc) * 4 * H + eu;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gxv[g] = gp[(size_t)g * H];
+        }
+        c_old = cst[(size_t)ebc * H + eu];
+    };
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!L1) {
+        skinny_bf16<MT, G>(reinterpret_cast<const bf16x8*>(p.h0frag[s & 1]),
+                           reinterpret_cast<const bf16x8*>(p.w0frag) + (size_t)blk * nchunk * 64, nchunk, wave, 4, lane, acc,
+                           issue_epilogue_loads, MT);
+    } else {
+        const bf16x8* wf = reinterpret_cast<const bf16x8*>(p.w1frag) + (size_t)blk * 2 * nchunk * 64;
+        // input segment: h0 of THIS time step = what layer 0 wrote one launch ago = the buffer layer 0 reads in this launch
+        skinny_bf16<MT, G>(reinterpret_cast<const bf16x8*>(p.h0frag[(s + 1) & 1]), wf, nchunk, wave, 4, lane, acc, []() {}, MT);
+        skinny_bf16<MT, G>(reinterpret_cast<const bf16x8*>(p.h1frag[s & 1]), wf + (size_t)nchunk * 64, nchunk, wave, 4, lane, acc,
+                           issue_epilogue_loads, MT);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][m * 16 + kg * 4 + r][li] = acc[m][r];
+    __syncthreads();
+    asm volatile("" ::"v"(gxv[0]), "v"(gxv[1]), "v"(gxv[2]), "v"(gxv[3]), "v"(c_old));
+    if (!ev) return;
+
+    const bool active = s < len;
+    float* y = L1 ? p.y1 : p.y0;
+    unsigned short* hnext = L1 ? p.h1frag[(s + 1) & 1] : p.h0frag[(s + 1) & 1];
+    const unsigned short* hprev = L1 ? p.h1frag[s & 1] : p.h0frag[s & 1];
+    const size_t row = (size_t)s * B + eb;
+    if (!active) {                                           // finished sample: zero pad row, frozen state
+        y[row * H + eu] = 0.f;
+        hnext[frag_index(eb, eu, MT)] = hprev[frag_index(eb, eu, MT)];
+        return;
+    }
+    float pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = g * 4 + ul;
+        pre[g] = red[0][eb][n] + red[1][eb][n] + red[2][eb][n] + red[3][eb][n] + gxv[g];
+    }
+    const float ig = 1.f / (1.f + expf(-pre[0]));
+    const float fg = 1.f / (1.f + expf(-pre[1]));
+    const float gg = tanhf(pre[2]);
+    const float og = 1.f / (1.f + expf(-pre[3]));
+    const float c_new = fg * c_old + ig * gg;
+    const float h_new = og * tanhf(c_new);
+    cst[(size_t)eb * H + eu] = c_new;
+    hnext[frag_index(eb, eu, MT)] = f2bf(h_new);
+    y[row * H + eu] = h_new;
+    float* gp = (L1 ? p.gates1 : p.gates0) + row * 4 * H + eu;
+    gp[0] = ig; gp[(size_t)H] = fg; gp[(size_t)2 * H] = gg; gp[(size_t)3 * H] = og;
+    (L1 ? p.cell1 : p.cell0)[row * H + eu] = c_new;
+}
+
+struct L2BwdP {
+    const float* dy1; const int* lens;
+    const float *gates1, *cell1, *gates0, *cell0;
+    float *dc1, *dc0, *dgx1, *dgx0;
+    const unsigned short *wT1frag, *wT0frag, *wTi1frag;     // W_hh1^T, W_hh0^T, W_ih1^T images [H/16][4H/32][64][8]
+    unsigned short *da1frag[2], *da0frag[2];                // dgates images over K = 4H: [4H/32][MT][64][8]
+    int s, T, B, H, MT;
+};
+
+// grid = (2 * H/16, MT): x < H/16 -> layer 1 step s ; x >= H/16 -> layer 0 step s+1.  One 16-row batch tile per workgroup.
+template <int G>
+__global__ __launch_bounds__(1024) void lstm2_bwd_step(L2BwdP p) {
+    __shared__ float red[16][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    const int H = p.H, B = p.B, ntile = H >> 4;
+    const bool L0 = (int)blockIdx.x >= ntile;
+    const int jt = L0 ? blockIdx.x - ntile : blockIdx.x;
+    const int s = L0 ? p.s + 1 : p.s;                       // this layer's time step
+    if (s < 0 || s >= p.T) return;
+    const int j0 = jt * 16;
+    const int m_base = blockIdx.y, b_base = m_base * 16;
+    const int nchunk = (4 * H) >> 5;
+
+    const bool pf_role = tid >= 256;
+    const int rr = pf_role ? tid - 256 : tid;
+    const int ebl = rr >> 4, eb = b_base + ebl, jl = rr & 15, eu = j0 + jl;
+    const bool ev = !pf_role && eb < B;
+    const int ebc = eb < B ? eb : B - 1;
+    const float* gates = L0 ? p.gates0 : p.gates1;
+    const float* cell = L0 ? p.cell0 : p.cell1;
+    float* dcar = L0 ? p.dc0 : p.dc1;
+    int len;
+    float ig, fg, gg, og, c_t, c_prev, dyv, dcc;
+    auto issue_epilogue_loads = [&]() {
+        len = p.lens[ebc];
+        const int t_ld = (pf_role && s >= 1) ? s - 1 : s;               // role-less waves: next launch's rows
+        int tp = t_ld - 1;
+        tp = tp < 0 ? 0 : tp;
+        const size_t row = (size_t)t_ld * B + ebc;
+        const float* gp = gates + row * 4 * H + eu;
+        ig = gp[0]; fg = gp[(size_t)H]; gg = gp[(size_t)2 * H]; og = gp[(size_t)3 * H];
+        c_t = cell[row * H + eu];
+        c_prev = cell[((size_t)tp * B + ebc) * H + eu];
+        dyv = L0 ? 0.f : p.dy1[row * H + eu];                            // layer 0 feeds only layer 1: no external dy
+        dcc = dcar[(size_t)ebc * H + eu];
+    };
+
+    f32x4 acc[1];
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!L0) {
+        skinny_bf16<1, G>(reinterpret_cast<const bf16x8*>(p.da1frag[(s + 1) & 1]) + (size_t)m_base * 64,
+                          reinterpret_cast<const bf16x8*>(p.wT1frag) + (size_t)jt * nchunk * 64, nchunk, wave, 16, lane, acc,
+                          issue_epilogue_loads, p.MT);
+    } else {
+        // dh0[s] = dgates1[s] W_ih1 + dgates0[s+1] W_hh0 ; dgates1[s] was written one launch ago into da1frag[s & 1]
+        skinny_bf16<1, G>(reinterpret_cast<const bf16x8*>(p.da1frag[s & 1]) + (size_t)m_base * 64,
+                          reinterpret_cast<const bf16x8*>(p.wTi1frag) + (size_t)jt * nchunk * 64, nchunk, wave, 16, lane, acc,
+                          []() {}, p.MT);
+        skinny_bf16<1, G>(reinterpret_cast<const bf16x8*>(p.da0frag[(s + 1) & 1]) + (size_t)m_base * 64,
+                          reinterpret_cast<const bf16x8*>(p.wT0frag) + (size_t)jt * nchunk * 64, nchunk, wave, 16, lane, acc,
+                          issue_epilogue_loads, p.MT);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][kg * 4 + r][li] = acc[0][r];
+    __syncthreads();
+    asm volatile("" ::"v"(ig), "v"(fg), "v"(gg), "v"(og), "v"(c_t), "v"(c_prev), "v"(dyv), "v"(dcc));
+    if (!ev) return;
+    if (s == 0) c_prev = 0.f;
+    const bool active = s < len;
+
+    float da[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        float dh = dyv;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) dh += red[w][ebl][jl];
+        const float tc = tanhf(c_t);
+        const float dc = dh * og * (1.f - tc * tc) + dcc;
+        dcar[(size_t)eb * H + eu] = dc * fg;
+        da[0] = dc * gg * ig * (1.f - ig);
+        da[1] = dc * c_prev * fg * (1.f - fg);
+        da[2] = dc * ig * (1.f - gg * gg);
+        da[3] = dh * tc * og * (1.f - og);
+    }
+    float* dg = (L0 ? p.dgx0 : p.dgx1) + ((size_t)s * B + eb) * 4 * H + eu;     // inactive: pad row -> zeros
+    unsigned short* dan = L0 ? p.da0frag[s & 1] : p.da1frag[s & 1];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        dg[(size_t)g * H] = da[g];
+        dan[frag_index(eb, g * H + eu, p.MT)] = f2bf(da[g]);
+    }
+}
+
+inline size_t al256(size_t v) { return (v + 255) & ~size_t(255); }
+inline int group_of(int per_wave) { return (per_wave % 8 == 0) ? 8 : (per_wave % 4 == 0) ? 4 : (per_wave % 2 == 0) ? 2 : 1; }
+inline int mt_of(int B) { return B <= 16 ? 1 : (B <= 32 ? 2 : 4); }
+
+struct Carve {
+    char* p;
+    template <class T> T* take(size_t bytes) { T* r = reinterpret_cast<T*>(p); p += al256(bytes); return r; }
+};
+
+template <int G>
+void launch_fwd2(const L2FwdP& p, int mt, dim3 grid, hipStream_t st) {
+    if (mt == 1) hipLaunchKernelGGL((lstm2_fwd_step<1, G>), grid, dim3(256), 0, st, p);
+    else if (mt == 2) hipLaunchKernelGGL((lstm2_fwd_step<2, G>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((lstm2_fwd_step<4, (G > 4 ? 4 : G)>), grid, dim3(256), 0, st, p);
+}
+
+}  // namespace
+
+extern "C" int ft_lstm2_supported(int B, int H) { return (B >= 1 && B <= 64 && H >= 128 && H % 128 == 0) ? 1 : 0; }
+
+extern "C" size_t ft_lstm2_workspace_bytes(int B, int H) {
+    const int mt = mt_of(B);
+    const size_t BH = (size_t)B * H, frag_act = (size_t)mt * 16 * H * 2, wimg = (size_t)4 * H * H * 2;
+    const size_t fwd = 2 * al256(BH * 4) + 4 * al256(frag_act) + al256(wimg) + al256(2 * wimg);
+    const size_t bwd = 2 * al256(BH * 4) + 4 * al256(4 * frag_act) + 3 * al256(wimg);
+    return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int ft_lstm2_seq_fwd(const float* gx0, const float* w_hh0, const float* w_ih1, const float* bias1, const float* w_hh1,
+                                const int32_t* lens, float* y0, float* gates0, float* cell0, float* y1, float* gates1, float* cell1,
+                                void* work, int T, int B, int H, void* stream) {
+    FT_CHECK_ARG(gx0 && w_hh0 && w_ih1 && bias1 && w_hh1 && lens && y0 && gates0 && cell0 && y1 && gates1 && cell1 && work);
+    FT_CHECK_ARG(T >= 0 && reinterpret_cast<uintptr_t>(work) % 256 == 0);
+    if (!ft_lstm2_supported(B, H)) return ft_fail(FT_EUNSUPPORTED, "ft_lstm2_seq_fwd: needs H %% 128 == 0 and B <= 64 (H=%d B=%d)", H, B);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int mt = mt_of(B);
+    const size_t BH = (size_t)B * H, frag_act = (size_t)mt * 16 * H * 2, wimg = (size_t)4 * H * H * 2;
+    Carve cv{reinterpret_cast<char*>(work)};
+    L2FwdP p{};
+    p.gx0 = gx0; p.bias1 = bias1; p.lens = lens;
+    p.c0 = cv.take<float>(BH * 4); p.c1 = cv.take<float>(BH * 4);
+    p.h0frag[0] = cv.take<unsigned short>(frag_act); p.h0frag[1] = cv.take<unsigned short>(frag_act);
+    p.h1frag[0] = cv.take<unsigned short>(frag_act); p.h1frag[1] = cv.take<unsigned short>(frag_act);
+    const size_t state_bytes = cv.p - reinterpret_cast<char*>(work);
+    unsigned short* w0 = cv.take<unsigned short>(wimg);
+    unsigned short* w1 = cv.take<unsigned short>(2 * wimg);
+    p.w0frag = w0; p.w1frag = w1;
+    p.y0 = y0; p.gates0 = gates0; p.cell0 = cell0; p.y1 = y1; p.gates1 = gates1; p.cell1 = cell1;
+    p.T = T; p.B = B; p.H = H;
+    FT_CHECK_HIP(hipMemsetAsync(work, 0, state_bytes, st));
+    hipLaunchKernelGGL(make_wfrag_fwd_cat, dim3(2048), dim3(256), 0, st, (const float*)nullptr, 0, w_hh0, H, w0, H);
+    hipLaunchKernelGGL(make_wfrag_fwd_cat, dim3(2048), dim3(256), 0, st, w_ih1, H, w_hh1, H, w1, H);
+    const int g = group_of((H >> 5) / 4);
+    dim3 grid(2 * (H >> 2));
+    for (int s = 0; s <= T; ++s) {
+        p.s = s;
+        if (g == 8) launch_fwd2<8>(p, mt, grid, st);
+        else if (g == 4) launch_fwd2<4>(p, mt, grid, st);
+        else if (g == 2) launch_fwd2<2>(p, mt, grid, st);
+        else launch_fwd2<1>(p, mt, grid, st);
+    }
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+
+extern "C" int ft_lstm2_seq_bwd(const float* dy1, const float* w_hh0, const float* w_ih1, const float* w_hh1, const int32_t* lens,
+                                const float* gates0, const float* cell0, const float* gates1, const float* cell1,
+                                float* dgx0, float* dgx1, void* work, int T, int B, int H, void* stream) {
+    FT_CHECK_ARG(dy1 && w_hh0 && w_ih1 && w_hh1 && lens && gates0 && cell0 && gates1 && cell1 && dgx0 && dgx1 && work);
+    FT_CHECK_ARG(T >= 0 && reinterpret_cast<uintptr_t>(work) % 256 == 0);
+    if (!ft_lstm2_supported(B, H)) return ft_fail(FT_EUNSUPPORTED, "ft_lstm2_seq_bwd: needs H %% 128 == 0 and B <= 64 (H=%d B=%d)", H, B);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int mt = mt_of(B);
+    const size_t BH = (size_t)B * H, frag_act = (size_t)mt * 16 * H * 2, wimg = (size_t)4 * H * H * 2;
+    Carve cv{reinterpret_cast<char*>(work)};
+    L2BwdP p{};
+    p.dy1 = dy1; p.lens = lens; p.gates1 = gates1; p.cell1 = cell1; p.gates0 = gates0; p.cell0 = cell0;
+    p.dc1 = cv.take<float>(BH * 4); p.dc0 = cv.take<float>(BH * 4);
+    p.da1frag[0] = cv.take<unsigned short>(4 * frag_act); p.da1frag[1] = cv.take<unsigned short>(4 * frag_act);
+    p.da0frag[0] = cv.take<unsigned short>(4 * frag_act); p.da0frag[1] = cv.take<unsigned short>(4 * frag_act);
+    const size_t state_bytes = cv.p - reinterpret_cast<char*>(work);
+    unsigned short* t1 = cv.take<unsigned short>(wimg);
+    unsigned short* t0 = cv.take<unsigned short>(wimg);
+    unsigned short* ti = cv.take<unsigned short>(wimg);
+    p.wT1frag = t1; p.wT0frag = t0; p.wTi1frag = ti;
+    p.dgx1 = dgx1; p.dgx0 = dgx0;
+    p.T = T; p.B = B; p.H = H; p.MT = mt;
+    FT_CHECK_HIP(hipMemsetAsync(work, 0, state_bytes, st));
+    hipLaunchKernelGGL(make_wfrag_bwd_t, dim3(2048), dim3(256), 0, st, w_hh1, t1, H, H);
+    hipLaunchKernelGGL(make_wfrag_bwd_t, dim3(2048), dim3(256), 0, st, w_hh0, t0, H, H);
+    hipLaunchKernelGGL(make_wfrag_bwd_t, dim3(2048), dim3(256), 0, st, w_ih1, ti, H, H);
+    const int g = group_of(((4 * H) >> 5) / 16);
+    dim3 grid(2 * (H >> 4), mt);
+    for (int s = T - 1; s >= -1; --s) {
+        p.s = s;
+        if (g == 8) hipLaunchKernelGGL(lstm2_bwd_step<8>, grid, dim3(1024), 0, st, p);
+        else if (g == 4) hipLaunchKernelGGL(lstm2_bwd_step<4>, grid, dim3(1024), 0, st, p);
+        else if (g == 2) hipLaunchKernelGGL(lstm2_bwd_step<2>, grid, dim3(1024), 0, st, p);
+        else hipLaunchKernelGGL(lstm2_bwd_step<1>, grid, dim3(1024), 0, st, p);
+    }
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}

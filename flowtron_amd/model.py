@@ -216,9 +216,14 @@ class AR_Step(nn.Module):
             g = self.gate_layer.linear_layer
             gates = ops.linear([h_att, ctx], g.weight, g.bias, mode=mode)     # Linear over [h_att ; ctx], no concat
         p = self.lstm
-        h = ops.lstm_layer(h_att, out_lens32, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, mode=mode,
-                           xs_extra=[ctx])
-        h = ops.lstm_layer(h, out_lens32, p.weight_ih_l1, p.weight_hh_l1, p.bias_ih_l1, p.bias_hh_l1, mode=mode)
+        if ops.lstm2_supported(B, p.weight_hh_l0.shape[1], mode):
+            # both decoder layers as one software-wavefront launch chain (csrc/lstm2.hip)
+            gx0 = ops.LinearFn.apply(p.weight_ih_l0, p.bias_ih_l0 + p.bias_hh_l0, L.ACT_NONE, mode, h_att, ctx)
+            h = ops.LSTM2SeqFn.apply(gx0, p.weight_hh_l0, p.weight_ih_l1, p.bias_ih_l1, p.bias_hh_l1, p.weight_hh_l1, out_lens32)
+        else:
+            h = ops.lstm_layer(h_att, out_lens32, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, mode=mode,
+                               xs_extra=[ctx])
+            h = ops.lstm_layer(h, out_lens32, p.weight_ih_l1, p.weight_hh_l1, p.bias_ih_l1, p.bias_hh_l1, mode=mode)
         h = self.dense_layer(h)
         out = ops.linear(h, self.conv.weight.reshape(self.conv.weight.shape[0], -1), self.conv.bias, mode=mode)
         z = ops.AffineFn.apply(out, mel)                                      # z = exp(log_s) * mel + b

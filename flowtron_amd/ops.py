@@ -594,3 +594,57 @@ class AttnCTCFn(torch.autograd.Function):
         L.check(L.lib().ft_attn_ctc_bwd(L.ptr(lp), L.ptr(in32), L.ptr(out32), ctx.blank, L.ptr(work), L.ptr(gd), L.ptr(dlp),
                                         B, T, Lk, L.stream()), "ft_attn_ctc_bwd")
         return dlp, None, None, None
+
+
+# --------------------------------------------------------------------------
+# two stacked LSTM layers as one launch chain (csrc/lstm2.hip)
+# --------------------------------------------------------------------------
+class LSTM2SeqFn(torch.autograd.Function):
+    """y1 = LSTM_l1(LSTM_l0(gx0)); gx0 = x W_ih0^T + b0 comes from LinearFn.  bf16 MFMA operands, forward direction."""
+
+    @staticmethod
+    def forward(ctx, gx0, w_hh0, w_ih1, b_ih1, b_hh1, w_hh1, lens):
+        gx0, w_hh0, w_ih1, w_hh1 = _c(gx0), _c(w_hh0), _c(w_ih1), _c(w_hh1)
+        L.require_cuda(gx0, w_hh0, w_ih1, w_hh1, lens)
+        T, B, H4 = gx0.shape
+        H = H4 // 4
+        f = dict(device=gx0.device, dtype=torch.float32)
+        y0, y1 = torch.empty(T, B, H, **f), torch.empty(T, B, H, **f)
+        gates0, gates1 = torch.empty(T, B, H4, **f), torch.empty(T, B, H4, **f)
+        cell0, cell1 = torch.empty(T, B, H, **f), torch.empty(T, B, H, **f)
+        bias1 = (b_ih1 + b_hh1).contiguous()
+        work = torch.empty(L.lib().ft_lstm2_workspace_bytes(B, H), device=gx0.device, dtype=torch.uint8)
+        L.check(L.lib().ft_lstm2_seq_fwd(L.ptr(gx0), L.ptr(w_hh0), L.ptr(w_ih1), L.ptr(bias1), L.ptr(w_hh1), L.ptr(lens), L.ptr(y0),
+                                         L.ptr(gates0), L.ptr(cell0), L.ptr(y1), L.ptr(gates1), L.ptr(cell1), L.ptr(work), T, B, H,
+                                         L.stream()), "ft_lstm2_seq_fwd")
+        ctx.save_for_backward(w_hh0, w_ih1, w_hh1, lens, y0, gates0, cell0, y1, gates1, cell1)
+        return y1
+
+    @staticmethod
+    def backward(ctx, dy1):
+        w_hh0, w_ih1, w_hh1, lens, y0, gates0, cell0, y1, gates1, cell1 = ctx.saved_tensors
+        dy1 = _c(dy1)
+        T, B, H = y1.shape
+        dgx0 = torch.empty(T, B, 4 * H, device=dy1.device, dtype=torch.float32)
+        dgx1 = torch.empty_like(dgx0)
+        work = torch.empty(L.lib().ft_lstm2_workspace_bytes(B, H), device=dy1.device, dtype=torch.uint8)
+        L.check(L.lib().ft_lstm2_seq_bwd(L.ptr(dy1), L.ptr(w_hh0), L.ptr(w_ih1), L.ptr(w_hh1), L.ptr(lens), L.ptr(gates0), L.ptr(cell0),
+                                         L.ptr(gates1), L.ptr(cell1), L.ptr(dgx0), L.ptr(dgx1), L.ptr(work), T, B, H, L.stream()),
+                "ft_lstm2_seq_bwd")
+        mode = L.FT_BF16
+        rows = T * B
+        dW_hh0 = torch.zeros_like(w_hh0)
+        dW_hh1 = torch.zeros_like(w_hh1)
+        dW_ih1 = torch.empty_like(w_ih1)
+        if T > 1:
+            r1 = (T - 1) * B
+            gemm_raw(dgx0[1:], y0[:-1], dW_hh0, 4 * H, H, r1, 1, 4 * H, H, 1, H, mode=mode, splitk=True)
+            gemm_raw(dgx1[1:], y1[:-1], dW_hh1, 4 * H, H, r1, 1, 4 * H, H, 1, H, mode=mode, splitk=True)
+        gemm_raw(dgx1, y0, dW_ih1, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=mode, splitk=True)
+        db1 = colsum(dgx1, rows, 4 * H, 4 * H)
+        return dgx0, dW_hh0, dW_ih1, db1, db1, dW_hh1, None
+
+
+def lstm2_supported(B, H, mode):
+    import os
+    return (mode == L.FT_BF16 and os.environ.get("FLOWTRON_LSTM2", "1") != "0" and bool(L.lib().ft_lstm2_supported(B, H)))

@@ -112,6 +112,22 @@ int ft_lstm_seq_bwd_range(const float* dy, int64_t ldy, const float* w_hh, const
                           const float* gates, const float* cell, float* dgx, void* work,
                           int T, int B, int H, int reverse, int mode, int s_begin, int s_end, int use_graph, void* stream);
 
+/* Two stacked layers (the decoder nn.LSTM(.., num_layers=2), flowtron.py:654, :760-765) as ONE launch chain: layer 1 at
+ * time t-1 and layer 0 at time t are two workgroup groups of the same launch, and layer 1's input projection
+ * (h0 W_ih1^T) rides along as a second bf16 fragment stream, so T+1 launches replace 2T + a batched GEMM.
+ * gx0 [T,B,4H] = x W_ih0^T + b0 (from ft_gemm), bias1 [4H] = b_ih1 + b_hh1; forward direction, bf16 MFMA operands.
+ * Saves y/gates/cell of BOTH layers; backward returns dgx0 and dgx1 [T,B,4H] (weight/bias gradients follow as GEMMs /
+ * column sums over all T*B rows: dW_hh0 = dgx0[1:]^T y0[:-1], dW_ih1 = dgx1^T y0, dW_hh1 = dgx1[1:]^T y1[:-1]).
+ * Only for ft_lstm2_supported(B,H) (H % 128 == 0, B <= 64); work: ft_lstm2_workspace_bytes(B,H), 256-byte aligned. */
+int ft_lstm2_supported(int B, int H);
+size_t ft_lstm2_workspace_bytes(int B, int H);
+int ft_lstm2_seq_fwd(const float* gx0, const float* w_hh0, const float* w_ih1, const float* bias1, const float* w_hh1,
+                     const int32_t* lens, float* y0, float* gates0, float* cell0, float* y1, float* gates1, float* cell1,
+                     void* work, int T, int B, int H, void* stream);
+int ft_lstm2_seq_bwd(const float* dy1, const float* w_hh0, const float* w_ih1, const float* w_hh1, const int32_t* lens,
+                     const float* gates0, const float* cell0, const float* gates1, const float* cell1,
+                     float* dgx0, float* dgx1, void* work, int T, int B, int H, void* stream);
+
 /* ---- additive attention scores + softmax + prior posterior (flowtron.py:544-583)
  * Q [T,B,A] (time-major), K [L,B,A], v [A], in_lens [B], prior [B,T,L] or NULL.
  * e[b,t,l] = sum_a v[a] tanh(Q[t,b,a]+K[l,b,a]) / temperature, -inf at l >= in_lens[b];

@@ -366,3 +366,49 @@ def test_attention_ctc_kernel_vs_oracle(env, blank):
     assert abs(mine2.item() - ref2.item()) < 2e-5 * abs(ref2.item())
     assert mad(lpd2.grad, torch.nan_to_num(lp2.grad)) < 2e-6
     assert float(lpd2.grad[2].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("T,B,H", [(9, 20, 256), (7, 32, 1024), (6, 33, 128), (11, 3, 128)])
+def test_lstm2_wavefront_chain_vs_oracle_and_unfused(env, T, B, H):
+    """csrc/lstm2.hip: both decoder layers as one launch chain (layer 1 one step behind layer 0, input projection of
+    layer 1 fused as a second fragment stream) against (a) the fp32 oracle, bf16-operand tolerance, and (b) the unfused
+    bf16 path (two ft_lstm_seq_* sequences + a batched GEMM), which differs only by accumulation order."""
+    L, ops = env
+    from oracle import flowtron_oracle as O
+    torch.manual_seed(31 + H)
+    I = 40
+    lens = torch.randint(1, T + 1, (B,))
+    lens[0] = T
+    x = torch.randn(T, B, I, requires_grad=True)
+    k = 1.0 / math.sqrt(H)
+    mk = lambda *shape: (torch.rand(*shape) * 2 * k - k).requires_grad_(True)
+    w_ih0, w_hh0, b_ih0, b_hh0 = mk(4 * H, I), mk(4 * H, H), mk(4 * H), mk(4 * H)
+    w_ih1, w_hh1, b_ih1, b_hh1 = mk(4 * H, H), mk(4 * H, H), mk(4 * H), mk(4 * H)
+    cpu = [x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1]
+    h0 = O.lstm_cell_seq(x, lens, w_ih0, w_hh0, b_ih0, b_hh0)
+    ref = O.lstm_cell_seq(h0, lens, w_ih1, w_hh1, b_ih1, b_hh1)
+    go = torch.randn_like(ref)
+    ref.backward(go)
+    l32 = g(lens.int())
+
+    def run(fused):
+        d = [t.detach().cuda().requires_grad_(True) for t in cpu]
+        if fused:
+            gx0 = ops.LinearFn.apply(d[1], d[3] + d[4], L.ACT_NONE, 1, d[0])
+            y = ops.LSTM2SeqFn.apply(gx0, d[2], d[5], d[7], d[8], d[6], l32)
+        else:
+            y0 = ops.lstm_layer(d[0], l32, d[1], d[2], d[3], d[4], mode=1)
+            y = ops.lstm_layer(y0, l32, d[5], d[6], d[7], d[8], mode=1)
+        y.backward(g(go))
+        return y, d
+
+    yf, df = run(True)
+    yu, du = run(False)
+    assert mad(yf, ref) < 3e-2 and mad(yu, ref) < 3e-2
+    assert mad(yf, yu) < 5e-3, mad(yf, yu)
+    m = O.length_mask(lens, T).t()[..., None]
+    assert float((yf.detach().cpu() * (~m)).abs().max()) == 0.0
+    names = "x w_ih0 w_hh0 b_ih0 b_hh0 w_ih1 w_hh1 b_ih1 b_hh1".split()
+    for a, u, r, name in zip(df, du, cpu, names):
+        assert rel(a.grad, r.grad) < 4e-2, (name, "fused vs oracle", rel(a.grad, r.grad))
+        assert rel(a.grad, u.grad) < 2e-2, (name, "fused vs unfused", rel(a.grad, u.grad))
