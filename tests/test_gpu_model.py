@@ -275,7 +275,7 @@ def test_stream_pipelined_flow_matches_sequential_bf16_full_width():
     res = {}
     try:
         for pipe in ("0", "1"):
-            os.environ.update(FLOWTRON_PIPELINE=pipe, FLOWTRON_CHUNK="16", FLOWTRON_LSTM_GRAPH="1")
+            os.environ.update(FLOWTRON_PIPELINE=pipe, FLOWTRON_CHUNK="16", FLOWTRON_LSTM_GRAPH="1", FLOWTRON_LSTM2="0")
             m, _ = build(cfg, 4, "bf16")
             crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)
             for it in range(2):
@@ -286,7 +286,7 @@ def test_stream_pipelined_flow_matches_sequential_bf16_full_width():
             torch.cuda.synchronize()
             res[pipe] = (out[0].detach().cpu(), nll.item(), {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()})
     finally:
-        os.environ.update(FLOWTRON_PIPELINE="auto", FLOWTRON_CHUNK="96", FLOWTRON_MFMA="f32")
+        os.environ.update(FLOWTRON_PIPELINE="auto", FLOWTRON_CHUNK="96", FLOWTRON_MFMA="f32", FLOWTRON_LSTM2="1")
     assert mad(res["0"][0], res["1"][0]) < 1e-5           # forward GEMMs never take the atomic split-K path: bit-stable
     assert abs(res["0"][1] - res["1"][1]) < 1e-6 * abs(res["0"][1])
     for k in res["0"][2]:
