@@ -1,7 +1,9 @@
 // Strided batched GEMM with fused epilogue on the gfx950 matrix cores.
 //   C = act(alpha * A.B + beta * C + bias)
-// 128x128x32 block tile, 4 waves (2x2), each wave a 64x64 sub-tile = 4x4 MFMA
-// tiles of 16x16.  MODE 0: fp32 operands, v_mfma_f32_16x16x4_f32 (exact fp32).
+// Two tile shapes: 128x128x32 with 4 waves (2x2, each wave 64x64 = 4x4 MFMA tiles of 16x16), and -- bf16 path, both
+// output dims >= 512 -- 256x256x32 with 8 waves (2x4, each wave 128x64 = 8x4 tiles).  The operands are fp32 in HBM, so
+// a 128^2 tile needs 125 B/clk/CU of operand traffic at the full MFMA rate, twice what the L2 delivers; the 256^2 tile
+// halves the re-reads (62 B/clk/CU) without a separate conversion pass.  MODE 0: fp32 operands, v_mfma_f32_16x16x4_f32 (exact fp32).
 // MODE 1: operands rounded to bf16 while being staged into LDS,
 // v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Global operands are always fp32.
 //
@@ -27,14 +29,14 @@ struct GemmP {
     int gx, gy, splits, kchunk;   // tile grid, split-K factor and K elements per split (multiple of BK)
 };
 
-// Load one 128 x 32 operand tile (rows r0.., reduction k0..) into 16 registers/thread.
-template <int LMODE>
+// Load one (NT/2) x 32 operand tile (rows r0.., reduction k0..) into 16 registers/thread (NT threads).
+template <int LMODE, int NT>
 __device__ __forceinline__ void load_tile(const float* __restrict__ X, long sr, long sk, int R, int K,
                                           int r0, int k0, int tid, float (&reg)[16]) {
     if constexpr (LMODE == 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int idx = tid + 256 * j;
+            int idx = tid + NT * j;
             int r = r0 + (idx >> 3), k = k0 + (idx & 7) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < R) {
@@ -49,7 +51,8 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ X, long sr, 
             reg[j * 4 + 0] = v.x; reg[j * 4 + 1] = v.y; reg[j * 4 + 2] = v.z; reg[j * 4 + 3] = v.w;
         }
     } else if constexpr (LMODE == 2) {
-        int rq = tid & 31, kq = tid >> 5;
+        constexpr int RQ = NT / 8;                      // row quads per tile: 32 (128 rows) or 64 (256 rows)
+        int rq = tid % RQ, kq = tid / RQ;
         int r = r0 + rq * 4;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -70,21 +73,21 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ X, long sr, 
     } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            int idx = tid + 256 * j;
+            int idx = tid + NT * j;
             int r = r0 + (idx >> 5), k = k0 + (idx & 31);
             reg[j] = (r < R && k < K) ? X[(long)r * sr + (long)k * sk] : 0.f;
         }
     }
 }
 
-template <int MODE, int LMODE>
+template <int MODE, int LMODE, int NT>
 __device__ __forceinline__ void store_tile(void* lds, int tid, const float (&reg)[16]) {
     if constexpr (LMODE == 1 || LMODE == 2) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int row, kc;
-            if constexpr (LMODE == 1) { int idx = tid + 256 * j; row = idx >> 3; kc = (idx & 7) * 4; }
-            else { row = (tid & 31) * 4 + j; kc = (tid >> 5) * 4; }
+            if constexpr (LMODE == 1) { int idx = tid + NT * j; row = idx >> 3; kc = (idx & 7) * 4; }
+            else { row = (tid % (NT / 8)) * 4 + j; kc = (tid / (NT / 8)) * 4; }
             if constexpr (MODE == 0) {
                 float* p = reinterpret_cast<float*>(lds) + row * LDF + kc;
                 *reinterpret_cast<float4*>(p) = make_float4(reg[j * 4], reg[j * 4 + 1], reg[j * 4 + 2], reg[j * 4 + 3]);
@@ -99,7 +102,7 @@ __device__ __forceinline__ void store_tile(void* lds, int tid, const float (&reg
     } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            int idx = tid + 256 * j;
+            int idx = tid + NT * j;
             int row = idx >> 5, kc = idx & 31;
             if constexpr (MODE == 0) reinterpret_cast<float*>(lds)[row * LDF + kc] = reg[j];
             else reinterpret_cast<unsigned short*>(lds)[row * LDH + kc] = f2bf(reg[j]);
@@ -107,16 +110,21 @@ __device__ __forceinline__ void store_tile(void* lds, int tid, const float (&reg
     }
 }
 
-template <int MODE, int AMODE, int BMODE>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
-    constexpr int TILE_BYTES = (MODE == 0) ? BM * LDF * 4 : BM * LDH * 2;
+// NT = 256: 128x128 tile, waves 2(M) x 2(N), wave tile 64x64 (TI = 4 x TJ = 4 MFMA tiles)
+// NT = 512: 256x256 tile, waves 2(M) x 4(N), wave tile 128x64 (TI = 8 x TJ = 4)
+template <int MODE, int AMODE, int BMODE, int NT>
+__global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
+    constexpr int BMT = NT / 2, BNT = NT / 2;               // tile rows / cols
+    constexpr int TI = (NT == 256) ? 4 : 8, TJ = 4;
+    constexpr int WN = (NT == 256) ? 2 : 4;                  // waves along N
+    constexpr int TILE_BYTES = (MODE == 0) ? BMT * LDF * 4 : BMT * LDH * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
     void* As = smem;
     void* Bs = smem + TILE_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, kg = lane >> 4;
     // XCD-aware tile order: workgroup L runs on XCD L % 8 (observed round-robin dispatch); give every XCD a
     // contiguous run of tiles (x fastest) so the tiles that share an A row-panel hit the same 4 MiB L2.
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         const int xcd = tile & 7, idx = tile >> 3;
         tile = xcd * q + (xcd < r ? xcd : r) + idx;
     }
-    const int m0 = (tile / p.gx) * BM, n0 = (tile % p.gx) * BN;
+    const int m0 = (tile / p.gx) * BMT, n0 = (tile % p.gx) * BNT;
     const int kbeg = blockIdx.y * p.kchunk;
     const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
     const long bz = blockIdx.z;
@@ -134,39 +142,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     const float* B = p.B + bz * p.bsB;
     float* C = p.C + bz * p.bsC;
 
-    f32x4 acc[4][4];
+    f32x4 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float ra[16], rb[16];
-    load_tile<AMODE>(A, p.sAm, p.sAk, p.M, kend, m0, kbeg, tid, ra);
-    load_tile<BMODE>(B, p.sBn, p.sBk, p.N, kend, n0, kbeg, tid, rb);
+    load_tile<AMODE, NT>(A, p.sAm, p.sAk, p.M, kend, m0, kbeg, tid, ra);
+    load_tile<BMODE, NT>(B, p.sBn, p.sBk, p.N, kend, n0, kbeg, tid, rb);
 
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();                         // previous tile fully consumed
-        store_tile<MODE, AMODE>(As, tid, ra);
-        store_tile<MODE, BMODE>(Bs, tid, rb);
+        store_tile<MODE, AMODE, NT>(As, tid, ra);
+        store_tile<MODE, BMODE, NT>(Bs, tid, rb);
         __syncthreads();
         if (k0 + BK < kend) {                    // prefetch next tile while computing
-            load_tile<AMODE>(A, p.sAm, p.sAk, p.M, kend, m0, k0 + BK, tid, ra);
-            load_tile<BMODE>(B, p.sBn, p.sBk, p.N, kend, n0, k0 + BK, tid, rb);
+            load_tile<AMODE, NT>(A, p.sAm, p.sAk, p.M, kend, m0, k0 + BK, tid, ra);
+            load_tile<BMODE, NT>(B, p.sBn, p.sBk, p.N, kend, n0, k0 + BK, tid, rb);
         }
         if constexpr (MODE == 0) {
-            const float* Af = reinterpret_cast<const float*>(As) + (wm * 64 + li) * LDF + kg * 4;
-            const float* Bf = reinterpret_cast<const float*>(Bs) + (wn * 64 + li) * LDF + kg * 4;
+            const float* Af = reinterpret_cast<const float*>(As) + (wm * (TI * 16) + li) * LDF + kg * 4;
+            const float* Bf = reinterpret_cast<const float*>(Bs) + (wn * (TJ * 16) + li) * LDF + kg * 4;
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 16) {
-                float4 a[4], b[4];
+                float4 a[TI], b[TJ];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float4*>(Af + i * 16 * LDF + kk);
+                for (int i = 0; i < TI; ++i) a[i] = *reinterpret_cast<const float4*>(Af + i * 16 * LDF + kk);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const float4*>(Bf + j * 16 * LDF + kk);
+                for (int j = 0; j < TJ; ++j) b[j] = *reinterpret_cast<const float4*>(Bf + j * 16 * LDF + kk);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < TI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < TJ; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
@@ -174,31 +182,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                     }
             }
         } else {
-            const unsigned short* Ah = reinterpret_cast<const unsigned short*>(As) + (wm * 64 + li) * LDH + kg * 8;
-            const unsigned short* Bh = reinterpret_cast<const unsigned short*>(Bs) + (wn * 64 + li) * LDH + kg * 8;
-            bf16x8 a[4], b[4];
+            const unsigned short* Ah = reinterpret_cast<const unsigned short*>(As) + (wm * (TI * 16) + li) * LDH + kg * 8;
+            const unsigned short* Bh = reinterpret_cast<const unsigned short*>(Bs) + (wn * (TJ * 16) + li) * LDH + kg * 8;
+            bf16x8 a[TI], b[TJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Ah + i * 16 * LDH);
+            for (int i = 0; i < TI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Ah + i * 16 * LDH);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Bh + j * 16 * LDH);
+            for (int j = 0; j < TJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Bh + j * 16 * LDH);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
 
     // epilogue: D tile (16x16): col = lane&15, row = (lane>>4)*4 + r
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TI; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int row = m0 + wm * 64 + i * 16 + kg * 4 + r;
+            int row = m0 + wm * (TI * 16) + i * 16 + kg * 4 + r;
             if (row >= p.M) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int col = n0 + wn * 64 + j * 16 + li;
+            for (int j = 0; j < TJ; ++j) {
+                int col = n0 + wn * (TJ * 16) + j * 16 + li;
                 if (col >= p.N) continue;
                 float* cp = C + (long)row * p.ldc + col;
                 float v = p.alpha * acc[i][j][r];
@@ -219,19 +227,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 }
 
 template <int MODE, int AMODE>
-void launch_b(const GemmP& p, dim3 grid, hipStream_t st) {
+void launch_b(const GemmP& p, dim3 grid, hipStream_t st, bool big) {
+    if constexpr (MODE == 1 && AMODE != 0) {
+        if (big && p.bmode != 0) {                 // 256x256 tile, 512 threads (bf16 operands, vectorised staging only)
+            if (p.bmode == 1) hipLaunchKernelGGL((gemm_kernel<1, AMODE, 1, 512>), grid, dim3(512), 0, st, p);
+            else hipLaunchKernelGGL((gemm_kernel<1, AMODE, 2, 512>), grid, dim3(512), 0, st, p);
+            return;
+        }
+    }
     switch (p.bmode) {
-        case 1: hipLaunchKernelGGL((gemm_kernel<MODE, AMODE, 1>), grid, dim3(256), 0, st, p); break;
-        case 2: hipLaunchKernelGGL((gemm_kernel<MODE, AMODE, 2>), grid, dim3(256), 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_kernel<MODE, AMODE, 0>), grid, dim3(256), 0, st, p); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<MODE, AMODE, 1, 256>), grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<MODE, AMODE, 2, 256>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_kernel<MODE, AMODE, 0, 256>), grid, dim3(256), 0, st, p); break;
     }
 }
 template <int MODE>
-void launch_a(const GemmP& p, dim3 grid, hipStream_t st) {
+void launch_a(const GemmP& p, dim3 grid, hipStream_t st, bool big) {
     switch (p.amode) {
-        case 1: launch_b<MODE, 1>(p, grid, st); break;
-        case 2: launch_b<MODE, 2>(p, grid, st); break;
-        default: launch_b<MODE, 0>(p, grid, st); break;
+        case 1: launch_b<MODE, 1>(p, grid, st, big); break;
+        case 2: launch_b<MODE, 2>(p, grid, st, big); break;
+        default: launch_b<MODE, 0>(p, grid, st, big); break;
     }
 }
 
@@ -260,14 +275,21 @@ extern "C" int ft_gemm(const ft_gemm_args* a, void* stream) {
     p.alpha = a->alpha; p.beta = a->beta; p.act = a->act;
     p.amode = pick_mode(a->A, a->sAm, a->sAk, a->bsA, a->batch);
     p.bmode = pick_mode(a->B, a->sBn, a->sBk, a->bsB, a->batch);
-    p.gx = cdiv(a->N, BN); p.gy = cdiv(a->M, BM);
+    // 256x256 tile when both output dims are large, the operands take a vectorised staging path and the tile grid still
+    // fills the chip (split-K below multiplies the workgroup count for the long-reduction weight gradients)
+    const bool can_split = (a->flags & FT_GEMM_SPLITK) && a->act == FT_ACT_NONE && (a->beta == 0.f || a->beta == 1.f) &&
+                           a->batch == 1 && a->K >= 2048;
+    const long tiles_big = (long)cdiv(a->M, 256) * cdiv(a->N, 256) * a->batch;
+    const bool big = a->mode == FT_BF16 && p.amode != 0 && p.bmode != 0 && a->M >= 512 && a->N >= 512 &&
+                     (tiles_big >= 192 || (can_split && tiles_big >= 24));
+    const int TM = big ? 256 : BM, TN = big ? 256 : BN;
+    p.gx = cdiv(a->N, TN); p.gy = cdiv(a->M, TM);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // split-K for GEMMs with few output tiles and a long reduction (weight gradients: K = T*B rows): partial
     // products are combined with fp32 global atomics into a zeroed (beta 0) or pre-loaded (beta 1) C.
     p.splits = 1;
     const long tiles = (long)p.gx * p.gy * a->batch;
-    if ((a->flags & FT_GEMM_SPLITK) && a->act == FT_ACT_NONE && (a->beta == 0.f || a->beta == 1.f) && a->batch == 1 &&
-        a->K >= 2048 && tiles < 512) {
+    if (can_split && tiles < 512) {
         long s = 768 / tiles;
         const long smax = a->K / 512;
         if (s > smax) s = smax;
@@ -280,8 +302,8 @@ extern "C" int ft_gemm(const ft_gemm_args* a, void* stream) {
         FT_CHECK_HIP(hipMemset2DAsync(a->C, sizeof(float) * a->ldc, 0, sizeof(float) * a->N, a->M, st));
     dim3 grid(p.gx * p.gy, p.splits, a->batch);
     FT_CHECK_ARG(grid.z <= 65535);
-    if (a->mode == FT_F32) launch_a<0>(p, grid, st);
-    else launch_a<1>(p, grid, st);
+    if (a->mode == FT_F32) launch_a<0>(p, grid, st, false);
+    else launch_a<1>(p, grid, st, big);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }
