@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libflowtron_hip.so")
 
 FT_F32, FT_BF16 = 0, 1
-GEMM_SPLITK = 1
+GEMM_SPLITK, GEMM_TILE256 = 1, 2
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 
 _p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t

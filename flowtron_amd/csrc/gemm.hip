@@ -280,8 +280,10 @@ extern "C" int ft_gemm(const ft_gemm_args* a, void* stream) {
     const bool can_split = (a->flags & FT_GEMM_SPLITK) && a->act == FT_ACT_NONE && (a->beta == 0.f || a->beta == 1.f) &&
                            a->batch == 1 && a->K >= 2048;
     const long tiles_big = (long)cdiv(a->M, 256) * cdiv(a->N, 256) * a->batch;
-    const bool big = a->mode == FT_BF16 && p.amode != 0 && p.bmode != 0 && a->M >= 512 && a->N >= 512 &&
-                     (tiles_big >= 192 || (can_split && tiles_big >= 24));
+    // opt-in (FT_GEMM_TILE256): measured 4 ms/step SLOWER on the training step than the 128^2 tile at 3 workgroups/CU --
+    // one 512-thread workgroup per CU with a single LDS stage hides less memory latency than it saves in re-reads
+    const bool big = (a->flags & FT_GEMM_TILE256) && a->mode == FT_BF16 && p.amode != 0 && p.bmode != 0 && a->M >= 512 &&
+                     a->N >= 512 && (tiles_big >= 192 || (can_split && tiles_big >= 24));
     const int TM = big ? 256 : BM, TN = big ? 256 : BN;
     p.gx = cdiv(a->N, TN); p.gy = cdiv(a->M, TM);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -27,13 +27,13 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 
 
 def gemm_raw(A, B, Cm, M, N, K, sAm, sAk, sBk, sBn, ldc, bias=None, act=L.ACT_NONE, alpha=1.0, beta=0.0,
-             batch=1, bsA=0, bsB=0, bsC=0, mode=None, splitk=False):
+             batch=1, bsA=0, bsB=0, bsC=0, mode=None, splitk=False, tile256=False):
     """C = act(alpha*A.B + beta*C + bias); A,B,Cm are tensors whose data_ptr is the operand origin.
     splitk=True (weight-gradient GEMMs only) allows the atomic split-K path."""
     L.require_cuda(A, B, Cm, bias)
     a = L.GemmArgs(L.ptr(A), L.ptr(B), L.ptr(Cm), L.ptr(bias), M, N, K, batch,
                    sAm, sAk, sBk, sBn, ldc, bsA, bsB, bsC, alpha, beta, act,
-                   L.mfma_mode() if mode is None else mode, L.GEMM_SPLITK if splitk else 0)
+                   L.mfma_mode() if mode is None else mode, (L.GEMM_SPLITK if splitk else 0) | (L.GEMM_TILE256 if tile256 else 0))
     L.check(L.lib().ft_gemm(C.byref(a), L.stream()), "ft_gemm")
 
 

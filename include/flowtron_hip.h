@@ -36,7 +36,7 @@ extern "C" {
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1 };
 enum { FT_ACT_NONE = 0, FT_ACT_TANH = 1, FT_ACT_RELU = 2, FT_ACT_SIGMOID = 3 };
-enum { FT_GEMM_SPLITK = 1 };
+enum { FT_GEMM_SPLITK = 1, FT_GEMM_TILE256 = 2 };
 
 int ft_abi_version(void);
 const char* ft_last_error(void);
@@ -58,7 +58,8 @@ typedef struct {
     int act, mode;
     int flags;   /* FT_GEMM_SPLITK: allow split-K with fp32 atomics when the output has few tiles and K is long (weight
                   * gradients over T*B rows).  Summation order is then not reproducible bit-for-bit, so the forward path
-                  * never sets it. */
+                  * never sets it.  FT_GEMM_TILE256: use the 256x256x32 / 512-thread tile when the problem is large (opt-in:
+                  * slower than the default 128x128 tile at 3 workgroups/CU on the training workload). */
 } ft_gemm_args;
 int ft_gemm(const ft_gemm_args* a, void* stream);
 

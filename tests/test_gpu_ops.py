@@ -430,7 +430,7 @@ def test_gemm_256_tile_bf16(env, M, N, K, splitk):
             Cd = torch.full((M, N), 7.0, device="cuda")
             sAm, sAk = (1, M) if ta else (K, 1)
             sBk, sBn = (1, K) if tb else (N, 1)
-            ops.gemm_raw(g(A), g(Bm), Cd, M, N, K, sAm, sAk, sBk, sBn, N, alpha=alpha, mode=1, splitk=splitk)
+            ops.gemm_raw(g(A), g(Bm), Cd, M, N, K, sAm, sAk, sBk, sBn, N, alpha=alpha, mode=1, splitk=splitk, tile256=True)
             torch.cuda.synchronize()
             assert mad(Cd, ref) < 3e-2, (ta, tb, mad(Cd, ref))
             assert rel(Cd, ref) < 6e-3, (ta, tb, rel(Cd, ref))
