@@ -38,7 +38,7 @@ class DecodeArgs(C.Structure):
         "residual", "mel_out", "attn_out", "n_done_dev", "work")] + [
         ("work_bytes", _sz), ("N", _i), ("L", _i), ("H", _i), ("A", _i), ("M", _i),
         ("temperature", _f), ("gate_threshold", _f), ("use_graph", _i)] + [
-        (n, _p) for n in ("cond_w1", "cond_b1", "cond_w2", "cond_b2", "w_key", "enc")] + [("E", _i)]
+        (n, _p) for n in ("cond_w1", "cond_b1", "cond_w2", "cond_b2", "w_key", "enc")] + [("E", _i), ("prior", _p), ("forced", _p)]
 
 
 # name -> argtypes (every symbol include/flowtron_hip.h declares; checked by tests/test_abi.py)

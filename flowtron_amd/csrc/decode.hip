@@ -33,6 +33,7 @@ struct DecodeDev {
     float *q, *ctx, *u1, *u2, *prev;
     // cumulative (location-sensitive) attention, flowtron.py:129-152, :793-806 -- all null when use_cumm_attention is off
     const float *cond_w1, *cond_b1, *cond_w2, *cond_b2, *w_key, *enc;
+    const float *prior, *forced;                 // [N,L] attention prior (posterior, flowtron.py:544-557) / forced alignment (:585-588)
     float *cumm, *prev_attn, *keyin, *Kdyn;
     float *escore, *obuf;                        // attention scores [L], 1x1 conv output [2M] (stage hand-offs)
     int* ctl;                                    // [0] frame index, [1] done flag
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void dec_score_k(const DecodeDev P) {
     if (!frame_live(P, i)) return;
     const int L = P.L, A = P.A;
     const int lane = threadIdx.x & 63, l = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (l >= L) return;
+    if (l >= L || P.forced) return;             // forced alignment: the scores are not used
     const float* Kmat = P.Kdyn ? P.Kdyn : P.K;
     const float* kr = Kmat + (size_t)l * A;
     float s = 0.f;
@@ -200,21 +201,36 @@ __global__ __launch_bounds__(256) void dec_ctx_k(const DecodeDev P) {
     float* red = sm + L;
     float* part = red + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float m = -INFINITY;
-    for (int l = tid; l < L; l += 256) { const float x = P.escore[l]; e[l] = x; m = fmaxf(m, x); }
-    m = wave_max(m);
-    if (lane == 0) red[wave] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float s = 0.f;
-    for (int l = tid; l < L; l += 256) { const float p = expf(e[l] - m); e[l] = p; s += p; }
-    s = wave_sum(s);
-    if (lane == 0) red[wave] = s;
-    __syncthreads();
-    s = red[0] + red[1] + red[2] + red[3];
-    for (int l = tid; l < L; l += 256) e[l] = e[l] / s;
-    __syncthreads();
+    auto softmax_inplace = [&]() {              // e[0..L) <- softmax(e), all 256 threads
+        float m = -INFINITY;
+        for (int l = tid; l < L; l += 256) m = fmaxf(m, e[l]);
+        m = wave_max(m);
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        float s = 0.f;
+        for (int l = tid; l < L; l += 256) { const float p = expf(e[l] - m); e[l] = p; s += p; }
+        s = wave_sum(s);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        s = red[0] + red[1] + red[2] + red[3];
+        for (int l = tid; l < L; l += 256) e[l] = e[l] / s;
+        __syncthreads();
+    };
+    if (P.forced) {
+        for (int l = tid; l < L; l += 256) e[l] = P.forced[(size_t)i * L + l];
+        __syncthreads();
+    } else {
+        for (int l = tid; l < L; l += 256) e[l] = P.escore[l];
+        __syncthreads();
+        softmax_inplace();
+        if (P.prior) {                            // posterior with the prior row of this frame, then a second softmax
+            for (int l = tid; l < L; l += 256) e[l] = logf(e[l] + 1e-20f) + logf(P.prior[(size_t)i * L + l] + 1e-20f);
+            __syncthreads();
+            softmax_inplace();
+        }
+    }
     if (blockIdx.x == 0) {
         float* arow = P.attn_out + (size_t)i * L;
         for (int l = tid; l < L; l += 256) {
@@ -409,6 +425,7 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
     h.q = fs + lay.q; h.ctx = fs + lay.ctx; h.u1 = fs + lay.u1; h.u2 = fs + lay.u2; h.prev = fs + lay.prev;
     h.ctl = reinterpret_cast<int*>(base + lay.off_ctl);
     h.escore = fs + lay.escore; h.obuf = fs + lay.obuf;
+    h.prior = a->prior; h.forced = a->forced;
     if (cumm) {
         h.cond_w1 = a->cond_w1; h.cond_b1 = a->cond_b1; h.cond_w2 = a->cond_w2; h.cond_b2 = a->cond_b2; h.w_key = a->w_key; h.enc = a->enc;
         h.cumm = fs + lay.cumm; h.prev_attn = fs + lay.prev_attn; h.keyin = fs + lay.keyin; h.Kdyn = fs + lay.Kdyn;

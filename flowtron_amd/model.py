@@ -258,8 +258,6 @@ class AR_Step(nn.Module):
     def infer(self, residual, text, attns=None, attn_prior=None, use_graph=None):
         """Sequential inverse (flowtron.py:775-828), batch 1. residual [N,1,M], text [L,1,E].
         Returns (mel [N',1,M], list of N' attention rows [1,1,L])."""
-        if attns is not None or attn_prior is not None:
-            raise NotImplementedError("forced alignments / attention prior at inference are not built yet")
         N, B, M = residual.shape
         if B != 1:
             raise ValueError("Flowtron.infer is batch-1 (flowtron.py:901-930)")
@@ -285,6 +283,15 @@ class AR_Step(nn.Module):
         V.copy_(ops.linear(text, att.value.linear_layer.weight, None).reshape(Lk, A))
         res.copy_(residual.reshape(N, M))
         attn_out.zero_()
+        prior_rows = forced_rows = None
+        if attn_prior is not None:              # [1, N, L] (flowtron.py:799 takes attn_prior[:, i])
+            prior_rows = attn_prior.reshape(-1, Lk)[:N].contiguous().float()
+            assert prior_rows.shape[0] == N, "attn_prior must cover every residual frame"
+        if attns is not None:                   # N rows of [L] (flowtron.py:798 takes attns[i])
+            forced_rows = (torch.stack([a_.reshape(-1) for a_ in attns]) if isinstance(attns, (list, tuple)) else attns.reshape(-1, Lk))
+            forced_rows = forced_rows[:N].contiguous().float()
+            assert forced_rows.shape == (N, Lk), "attns must hold one attention row per residual frame"
+        L.require_cuda(prior_rows, forced_rows)
         cumm = self.use_cumm_attention
         E = text.shape[2]
         enc2d = text.reshape(Lk, E).contiguous()
@@ -296,7 +303,7 @@ class AR_Step(nn.Module):
         if use_graph is None:
             use_graph = os.environ.get("FLOWTRON_DECODE_GRAPH", "1") != "0"
         a, p, d = self.attention_lstm, self.lstm, self.dense_layer.layers
-        keep = [K, V, res, enc2d]               # keep temporaries alive until the launch is enqueued
+        keep = [K, V, res, enc2d, prior_rows, forced_rows]   # keep temporaries alive until the launch is enqueued
         cc = self.attn_cond_layer if cumm else None
         args = L.DecodeArgs(
             L.ptr(a.weight_ih_l0), L.ptr(a.weight_hh_l0), L.ptr(a.bias_ih_l0), L.ptr(a.bias_hh_l0),
@@ -313,7 +320,8 @@ class AR_Step(nn.Module):
             float(self.gate_threshold) if has_gate else 2.0, int(bool(use_graph)),
             L.ptr(cc.location_conv_hidden.conv.weight) if cumm else None, L.ptr(cc.location_conv_hidden.conv.bias) if cumm else None,
             L.ptr(cc.location_conv_out.conv.weight) if cumm else None, L.ptr(cc.location_conv_out.conv.bias) if cumm else None,
-            L.ptr(att.key.linear_layer.weight) if cumm else None, L.ptr(enc2d) if cumm else None, E)
+            L.ptr(att.key.linear_layer.weight) if cumm else None, L.ptr(enc2d) if cumm else None, E,
+            L.ptr(prior_rows), L.ptr(forced_rows))
         L.check(L.lib().ft_decode_flow(C.byref(args), L.stream()), "ft_decode_flow")
         n = int(n_done.item()) if has_gate else N          # single host read per flow (the reference syncs every frame)
         del keep
@@ -340,6 +348,8 @@ class AR_Back_Step(nn.Module):
         return z, log_s, gates, attn, logprob
 
     def infer(self, residual, text, attns=None, attn_prior=None):
+        if attn_prior is not None:
+            attn_prior = torch.flip(attn_prior, (1,))                     # flowtron.py:631-633 (batch 1: flip only)
         out, attn = self.ar_step.infer(torch.flip(residual, (0,)), text, attns, attn_prior=attn_prior)
         return torch.flip(out, (0,)), attn
 
@@ -415,6 +425,8 @@ class Flowtron(nn.Module):
             attention_weights = []
             for i, flow in enumerate(reversed(self.flows)):
                 self.set_temperature_and_gate(flow, temperature, gate_threshold)
+                # attns: one forced alignment per flow, in flows order (the reference indexes `reversed(attns)[i]`, which
+                # raises TypeError -- flowtron.py:925; the evident intent is implemented)
                 x, aw = flow.infer(x, enc, None if attns is None else attns[len(self.flows) - 1 - i], attn_prior=attn_prior)
                 attention_weights.append(aw)
             return x.permute(1, 2, 0), attention_weights

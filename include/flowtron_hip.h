@@ -207,6 +207,9 @@ typedef struct {
      * encoder outputs enc [L,E] before the key projection w_key [A,E], every frame.  K is then ignored. */
     const float *cond_w1, *cond_b1, *cond_w2, *cond_b2, *w_key, *enc;
     int E;
+    /* optional [N,L] rows: attention prior (attn = softmax(log(p+1e-20)+log(prior+1e-20)), flowtron.py:544-557, :799) and
+     * forced alignment (the given row replaces the computed attention, :585-588, :798); NULL = off */
+    const float *prior, *forced;
 } ft_decode_args;
 size_t ft_decode_workspace_bytes(int L, int H, int A, int M, int E);
 int ft_decode_flow(const ft_decode_args* a, void* stream);

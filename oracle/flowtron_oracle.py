@@ -361,7 +361,7 @@ def _lstm_step(x, h, c, w_ih, w_hh, b_ih, b_hh):
 
 
 def ar_step_infer(sd: SD, pfx: str, residual, enc, has_gate, temperature=1.0, gate_threshold=0.5,
-                  attn_prior=None):
+                  attn_prior=None, attns=None):
     """residual [N,1,M], enc [L,1,E] -> (mel [N',1,M], attn [N',L]) (flowtron.py:775-828)."""
     N, B, M = residual.shape
     H = sd[pfx + "lstm.weight_hh_l0"].shape[1]
@@ -373,7 +373,7 @@ def ar_step_infer(sd: SD, pfx: str, residual, enc, has_gate, temperature=1.0, ga
     ha, ca = z(B, H), z(B, H)
     h0, c0, h1, c1 = z(B, H), z(B, H), z(B, H), z(B, H)
     prev = z(B, M)
-    outs, attns = [], []
+    outs, attn_rows = [], []
     cumm_on = (pfx + "attn_cond_layer.location_conv_hidden.conv.weight") in sd
     if cumm_on:
         cumm, prev_attn = z(B, 1, enc.shape[0]), z(B, 1, enc.shape[0])
@@ -386,7 +386,9 @@ def ar_step_infer(sd: SD, pfx: str, residual, enc, has_gate, temperature=1.0, ga
             K = ((enc * attn_cond(sd, pfx + "attn_cond_layer.", cumm, prev_attn)) @ wk.t()).transpose(0, 1)
         e = torch.tanh(q[:, None, :] + K) @ v / temperature               # [B,L]
         p = torch.softmax(e, dim=1)
-        if attn_prior is not None:
+        if attns is not None:                                              # forced alignment, flowtron.py:585-588
+            p = attns[i].reshape(1, -1)
+        elif attn_prior is not None:
             p = torch.softmax(torch.log(p + 1e-20) + torch.log(attn_prior[:, i].float() + 1e-20), dim=1)
         if cumm_on:
             prev_attn = p[:, None, :]
@@ -405,30 +407,33 @@ def ar_step_infer(sd: SD, pfx: str, residual, enc, has_gate, temperature=1.0, ga
         log_s, b = o[:, :M], o[:, M:]
         prev = (residual[i] - b) / torch.exp(log_s)
         outs.append(prev)
-        attns.append(p[0])
+        attn_rows.append(p[0])
         if has_gate:
             g = d @ sd[pfx + "gate_layer.linear_layer.weight"].t() + sd[pfx + "gate_layer.linear_layer.bias"]
             if float(torch.sigmoid(g)) > gate_threshold:
                 break
-    return torch.stack(outs, 0), torch.stack(attns, 0)
+    return torch.stack(outs, 0), torch.stack(attn_rows, 0)
 
 
-def infer(sd: SD, cfg: dict, residual, speaker_ids, text, temperature=1.0, gate_threshold=0.5):
-    """Flowtron.infer (flowtron.py:901-930). residual [1,M,N] -> (mel [1,M,N'], [attn per flow])."""
+def infer(sd: SD, cfg: dict, residual, speaker_ids, text, temperature=1.0, gate_threshold=0.5, attn_prior=None, attns=None):
+    """Flowtron.infer (flowtron.py:901-930). residual [1,M,N] -> (mel [1,M,N'], [attn per flow]).
+    attn_prior [1,N,L]; attns: per flow (flows order) an [N,L] forced alignment in that flow's own time order."""
     n_flows = cfg["n_flows"]
     enc = embed_and_encode(sd, speaker_ids, text, None, cfg.get("dummy_speaker_embedding", False))
     x = residual.permute(2, 0, 1)
-    attns = []
+    attn_out = []
     for i in reversed(range(n_flows)):
         has_gate = (i == n_flows - 1) and bool(cfg.get("use_gate_layer", True))
         pfx = flow_prefix(i)
+        fa = None if attns is None else attns[i]
         if i % 2 == 1:
-            xr, a = ar_step_infer(sd, pfx, torch.flip(x, (0,)), enc, has_gate, temperature, gate_threshold)
+            pr = None if attn_prior is None else torch.flip(attn_prior, (1,))
+            xr, a = ar_step_infer(sd, pfx, torch.flip(x, (0,)), enc, has_gate, temperature, gate_threshold, pr, fa)
             x = torch.flip(xr, (0,))
         else:
-            x, a = ar_step_infer(sd, pfx, x, enc, has_gate, temperature, gate_threshold)
-        attns.append(a)
-    return x.permute(1, 2, 0), attns
+            x, a = ar_step_infer(sd, pfx, x, enc, has_gate, temperature, gate_threshold, attn_prior, fa)
+        attn_out.append(a)
+    return x.permute(1, 2, 0), attn_out
 
 
 # --------------------------------------------------------------------------

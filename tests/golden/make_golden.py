@@ -76,6 +76,11 @@ def run_model_case(R, cfg, out_lens, in_lens, with_prior, seed, full_dump, n_inf
         mel, att = m.infer(residual.clone(), spk, txt, gate_threshold=1.0)
         mel_g, _ = m.infer(residual.clone(), spk, txt, gate_threshold=0.5)
     res.update(infer_mel=mel, infer_attn=[torch.cat(a)[:, 0] for a in att], infer_gated_frames=mel_g.shape[2])
+    if not cfg.get("use_cumm_attention", False):
+        pr = O.beta_binomial_prior(in_lens[0], n_infer).float()[None]          # [1, N, L] prior at inference (flowtron.py:799)
+        with torch.no_grad():
+            mel_p, att_p = m.infer(residual.clone(), spk, txt, gate_threshold=1.0, attn_prior=pr)
+        res.update(infer_prior_mel=mel_p, infer_prior_attn=[torch.cat(a)[:, 0] for a in att_p])
     return res
 
 

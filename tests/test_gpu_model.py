@@ -87,6 +87,17 @@ def test_infer_vs_reference_golden(name, use_graph):
         assert mad(torch.cat(a)[:, 0], ra) < 1e-5
     mel_g, _ = m.infer(residual.cuda(), spk, txt, gate_threshold=0.5)
     assert mel_g.shape[2] == g["infer_gated_frames"]
+    if "infer_prior_mel" in g:                          # attention prior at inference (flowtron.py:799), real-reference golden
+        from oracle import flowtron_oracle as O
+        pr = O.beta_binomial_prior(g["in_lens"][0], n).float()[None].cuda()
+        mel_p, attns_p = m.infer(residual.cuda(), spk, txt, gate_threshold=1.0, attn_prior=pr)
+        assert mad(mel_p, g["infer_prior_mel"]) < 1e-4
+        for a, ra in zip(attns_p, g["infer_prior_attn"]):
+            assert mad(torch.cat(a)[:, 0], ra) < 1e-5
+        # forced alignment (flowtron.py:798): a free run's own attention rows, given back per flow, reproduce its mel
+        forced = [torch.cat(a)[:, 0] for a in attns][::-1]
+        mel_f, _ = m.infer(residual.cuda(), spk, txt, gate_threshold=1.0, attns=forced)
+        assert mad(mel_f, mel) < 1e-5
 
 
 def test_cfg1_full_size_vs_reference_golden():

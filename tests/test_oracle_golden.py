@@ -64,6 +64,15 @@ def test_infer_small(golden_dir, name):
         assert _maxdiff(a, ra) < TOL
     mel_g, _ = O.infer(sd, cfg, residual, spk, txt, gate_threshold=0.5)
     assert mel_g.shape[2] == g["infer_gated_frames"]
+    if "infer_prior_mel" in g:
+        pr = O.beta_binomial_prior(g["in_lens"][0], n).float()[None]
+        mel_p, attns_p = O.infer(sd, cfg, residual, spk, txt, gate_threshold=1.0, attn_prior=pr)
+        assert _maxdiff(mel_p, g["infer_prior_mel"]) < TOL
+        for a, ra in zip(attns_p, g["infer_prior_attn"]):
+            assert _maxdiff(a, ra) < TOL
+        # forced alignment: feeding a free run's own attention back reproduces it (flows order = reversed output order)
+        mel_f, _ = O.infer(sd, cfg, residual, spk, txt, gate_threshold=1.0, attns=attns[::-1])
+        assert _maxdiff(mel_f, mel) < 1e-6
 
 
 def test_cfg1_full_size(golden_dir):
