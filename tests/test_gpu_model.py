@@ -334,3 +334,78 @@ def test_side_stream_weight_gradients_into_arena_vs_reference_golden():
     os.environ["FLOWTRON_DW_STREAM"] = "0"
     arena = opt.arena
     assert all(arena._ptr_lo <= p.grad.data_ptr() < arena._ptr_hi for p in m.parameters())
+
+
+def _oracle_fwd_bwd(cfg, sd, bc, use_ctc=True):
+    from oracle import flowtron_oracle as O
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.forward(sdg, cfg, bc["mel"], bc["speaker_ids"], bc["text"], bc["in_lens"], bc["out_lens"], bc["attn_prior"])
+    rn, rg, rc = O.loss(ref, bc["gate_target"], bc["in_lens"], bc["out_lens"], 1.0, True, use_ctc, -8)
+    (rn + rg + 0.01 * rc).sum().backward()
+    return ref, (rn, rg, rc), sdg
+
+
+def test_batch_of_one_training_matches_oracle():
+    """B = 1: the reference takes the UNMASKED instance-norm / unpacked branch (flowtron.py:498, 117-121); forward, the
+    three losses and every gradient against the oracle (fp32 MFMA mode)."""
+    import flowtron
+    from oracle import synth
+    cfg = dict(synth.SMALL_MODEL_CONFIG, n_hidden=128, n_attn_channels=64)
+    m, sd = build(cfg, 13)
+    bc = synth.make_batch(cfg, [27], [10], seed=13, with_prior=True)
+    ref, (rn, rg, rc), sdg = _oracle_fwd_bwd(cfg, sd, bc)
+    b = cuda_batch(bc)
+    out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+    nll, gl, ctc = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)(out, b["gate_target"], b["in_lens"], b["out_lens"])
+    (nll + gl + 0.01 * ctc).backward()
+    assert mad(out[0], ref[0]) < 1e-4 and mad(out[3][1], ref[3][1]) < 1e-5
+    assert abs(nll.item() - rn.item()) < 1e-5 * abs(rn.item()) and abs(gl.item() - rg.item()) < 1e-5
+    assert abs(ctc.item() - rc.item()) < 1e-4 * max(1.0, abs(rc.item()))
+    for k, p in m.named_parameters():
+        r = sdg[k].grad
+        assert (p.grad.cpu() - r).norm().item() / max(r.norm().item(), 1e-5 * r.numel() ** 0.5) < 1e-3, k
+
+
+def test_long_text_many_speakers_ragged_matches_oracle():
+    """LibriTTS-shaped edge: 123 speakers, text up to 237 tokens (two 128-column score tiles, 475 CTC states), ragged
+    lengths incl. a 1-token / 1-frame-margin sample, T not a multiple of the 32-row attention tile; no prior."""
+    import flowtron
+    from oracle import synth
+    cfg = dict(synth.SMALL_MODEL_CONFIG, n_speakers=123, n_text=185, n_hidden=64, n_attn_channels=48)
+    m, sd = build(cfg, 17)
+    out_lens, in_lens = [243, 240, 77, 9], [237, 130, 33, 1]
+    bc = synth.make_batch(cfg, out_lens, in_lens, seed=17, with_prior=False, n_speakers=123)
+    ref, (rn, rg, rc), sdg = _oracle_fwd_bwd(cfg, sd, bc)
+    b = cuda_batch(bc)
+    out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], None)
+    nll, gl, ctc = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)(out, b["gate_target"], b["in_lens"], b["out_lens"])
+    (nll + gl + 0.01 * ctc).backward()
+    assert mad(out[0], ref[0]) < 2e-4
+    for i in range(2):
+        assert mad(out[3][i], ref[3][i]) < 1e-5 and mad(out[4][i], ref[4][i]) < 1e-3
+    assert abs(nll.item() - rn.item()) < 1e-5 * abs(rn.item())
+    assert abs(ctc.item() - rc.item()) < 2e-4 * max(1.0, abs(rc.item()))
+    worst = ("", 0.0)
+    for k, p in m.named_parameters():
+        r = sdg[k].grad
+        e = (p.grad.cpu() - r).norm().item() / max(r.norm().item(), 1e-5 * r.numel() ** 0.5)
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < 2e-3, worst
+
+
+def test_unsupported_sizes_fail_loudly():
+    """error behaviour of the C ABI: a clear message instead of a silent wrong answer or a fallback."""
+    from flowtron_amd import _lib as L
+    from flowtron_amd import ops
+    x = torch.randn(4, 70, 16, device="cuda")                       # B = 70 > 64 rows per LSTM step
+    w = torch.randn(64, 16, device="cuda")
+    with pytest.raises(RuntimeError, match="ft_lstm_seq_fwd"):
+        ops.LSTMSeqFn.apply(torch.randn(4, 70, 64, device="cuda"), torch.randn(64, 16, device="cuda"),
+                            torch.full((70,), 4, dtype=torch.int32, device="cuda"), False, 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.linear(torch.randn(3, 16), w.cpu())
+    Q = torch.randn(2, 1, 8, device="cuda")
+    with pytest.raises(RuntimeError, match="LDS"):                 # L = 2000 text positions exceed the LDS score tile
+        ops.AttentionScoresFn.apply(Q, torch.randn(2000, 1, 8, device="cuda"), torch.randn(1, 8, device="cuda"),
+                                    torch.tensor([2000], dtype=torch.int32, device="cuda"), None, 1.0)

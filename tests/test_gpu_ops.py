@@ -434,3 +434,22 @@ def test_gemm_256_tile_bf16(env, M, N, K, splitk):
             torch.cuda.synchronize()
             assert mad(Cd, ref) < 3e-2, (ta, tb, mad(Cd, ref))
             assert rel(Cd, ref) < 6e-3, (ta, tb, rel(Cd, ref))
+
+
+def test_lstm2_batch_64_four_tiles(env):
+    """B = 64 (four 16-row MFMA tiles, the C ABI maximum) through the two-layer wavefront chain."""
+    L, ops = env
+    from oracle import flowtron_oracle as O
+    torch.manual_seed(77)
+    T, B, H, I = 5, 64, 128, 24
+    lens = torch.randint(1, T + 1, (B,))
+    lens[0] = T
+    x = torch.randn(T, B, I)
+    k = 1.0 / math.sqrt(H)
+    mk = lambda *shape: torch.rand(*shape) * 2 * k - k
+    w = [mk(4 * H, I), mk(4 * H, H), mk(4 * H), mk(4 * H), mk(4 * H, H), mk(4 * H, H), mk(4 * H), mk(4 * H)]
+    ref = O.lstm_cell_seq(O.lstm_cell_seq(x, lens, w[0], w[1], w[2], w[3]), lens, w[4], w[5], w[6], w[7])
+    d = [g(t) for t in w]
+    gx0 = ops.linear(g(x), d[0], d[2] + d[3], mode=1)
+    y = ops.LSTM2SeqFn.apply(gx0, d[1], d[4], d[6], d[7], d[5], g(lens.int()))
+    assert mad(y, ref) < 3e-2
