@@ -27,7 +27,8 @@ class GemmArgs(C.Structure):
                 ("M", _i), ("N", _i), ("K", _i), ("batch", _i),
                 ("sAm", _l), ("sAk", _l), ("sBk", _l), ("sBn", _l), ("ldc", _l),
                 ("bsA", _l), ("bsB", _l), ("bsC", _l),
-                ("alpha", _f), ("beta", _f), ("act", _i), ("mode", _i), ("flags", _i)]
+                ("alpha", _f), ("beta", _f), ("act", _i), ("mode", _i), ("flags", _i),
+                ("work", _p), ("work_bytes", _sz)]
 
 
 class DecodeArgs(C.Structure):
@@ -46,6 +47,7 @@ SIGNATURES = {
     "ft_abi_version": ([], _i),
     "ft_last_error": ([], C.c_char_p),
     "ft_gemm": ([C.POINTER(GemmArgs), _p], _i),
+    "ft_gemm_workspace_bytes": ([C.POINTER(GemmArgs)], _sz),
     "ft_embedding_fwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
     "ft_embedding_bwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
     "ft_im2col": ([_p, _p, _p, _i, _i, _i, _i, _p], _i),
@@ -101,7 +103,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argt
             fn.restype = rest
-        if l.ft_abi_version() != 1:
+        if l.ft_abi_version() != 2:
             raise RuntimeError("libflowtron_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -66,4 +66,7 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// gemm_bf16.hip: 1 = handled, 0 = not applicable (use the staging kernel), < 0 = error
+int ftint_gemm_bf16(const ft_gemm_args* a, hipStream_t st);
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -267,6 +267,10 @@ extern "C" int ft_gemm(const ft_gemm_args* a, void* stream) {
     FT_CHECK_ARG(a->mode == FT_F32 || a->mode == FT_BF16);
     if (a->M == 0 || a->N == 0) return FT_OK;
     FT_CHECK_ARG(a->K > 0);
+    if (a->work) {                               // bf16 operand images + DMA-staged kernel (gemm_bf16.hip)
+        const int took = ftint_gemm_bf16(a, reinterpret_cast<hipStream_t>(stream));
+        if (took != 0) return took < 0 ? took : FT_OK;
+    }
     GemmP p;
     p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias;
     p.M = a->M; p.N = a->N; p.K = a->K;

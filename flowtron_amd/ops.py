@@ -26,6 +26,10 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+import os as _os
+_BF16_IMAGES = _os.environ.get("FLOWTRON_GEMM_IMAGES", "1") != "0"
+
+
 def gemm_raw(A, B, Cm, M, N, K, sAm, sAk, sBk, sBn, ldc, bias=None, act=L.ACT_NONE, alpha=1.0, beta=0.0,
              batch=1, bsA=0, bsB=0, bsC=0, mode=None, splitk=False, tile256=False):
     """C = act(alpha*A.B + beta*C + bias); A,B,Cm are tensors whose data_ptr is the operand origin.
@@ -33,7 +37,13 @@ def gemm_raw(A, B, Cm, M, N, K, sAm, sAk, sBk, sBn, ldc, bias=None, act=L.ACT_NO
     L.require_cuda(A, B, Cm, bias)
     a = L.GemmArgs(L.ptr(A), L.ptr(B), L.ptr(Cm), L.ptr(bias), M, N, K, batch,
                    sAm, sAk, sBk, sBn, ldc, bsA, bsB, bsC, alpha, beta, act,
-                   L.mfma_mode() if mode is None else mode, (L.GEMM_SPLITK if splitk else 0) | (L.GEMM_TILE256 if tile256 else 0))
+                   L.mfma_mode() if mode is None else mode, (L.GEMM_SPLITK if splitk else 0) | (L.GEMM_TILE256 if tile256 else 0),
+                   None, 0)
+    if _BF16_IMAGES:
+        need = L.lib().ft_gemm_workspace_bytes(C.byref(a))
+        if need:                      # large bf16-mode GEMM: bf16 operand images + DMA-staged kernel (gemm_bf16.hip)
+            work = torch.empty(need, device=Cm.device, dtype=torch.uint8)     # stream-ordered by the caching allocator
+            a.work, a.work_bytes = L.ptr(work), need
     L.check(L.lib().ft_gemm(C.byref(a), L.stream()), "ft_gemm")
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 1
+#define FT_ABI_VERSION 2
 
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1 };
@@ -60,7 +60,13 @@ typedef struct {
                   * gradients over T*B rows).  Summation order is then not reproducible bit-for-bit, so the forward path
                   * never sets it.  FT_GEMM_TILE256: use the 256x256x32 / 512-thread tile when the problem is large (opt-in:
                   * slower than the default 128x128 tile at 3 workgroups/CU on the training workload). */
+    void* work;  /* optional scratch (256-byte aligned) of ft_gemm_workspace_bytes() bytes.  When given (FT_BF16, batch 1,
+                  * problem large enough for the query to be non-zero) the operands are first rewritten once as zero-padded
+                  * bf16 images with the reduction dimension innermost and the GEMM runs from those through direct
+                  * global->LDS DMA; same rounding (RNE to bf16, fp32 accumulate) as the staging path taken when it is NULL. */
+    size_t work_bytes;
 } ft_gemm_args;
+size_t ft_gemm_workspace_bytes(const ft_gemm_args* a);
 int ft_gemm(const ft_gemm_args* a, void* stream);
 
 /* ---- embedding gather (flowtron.py:873-874) ------------------------------

@@ -453,3 +453,62 @@ def test_lstm2_batch_64_four_tiles(env):
     gx0 = ops.linear(g(x), d[0], d[2] + d[3], mode=1)
     y = ops.LSTM2SeqFn.apply(gx0, d[1], d[4], d[6], d[7], d[5], g(lens.int()))
     assert mad(y, ref) < 3e-2
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 160, 1024), (1000, 257, 333), (129, 4096, 80), (2048, 1664, 1100), (33, 40, 2000)])
+def test_gemm_bf16_image_path(env, M, N, K):
+    """gemm_bf16.hip: operand images (k-contiguous / transposing / generic-stride pre-pass) + the DMA-staged NT kernel,
+    against an fp64 product of the bf16-ROUNDED operands -- the only error left is fp32 accumulation order (tol 2e-4 of
+    an O(1) result), so a wrong swizzle, a missed pad or a stale LDS stage cannot hide inside bf16 rounding noise."""
+    L, ops = env
+    assert ops._BF16_IMAGES
+    torch.manual_seed(M + N + K)
+    for ta in (False, True):
+        for tb in (False, True):
+            A = torch.randn(K, M) if ta else torch.randn(M, K)
+            Bm = torch.randn(N, K) if tb else torch.randn(K, N)
+            bias, C0 = torch.randn(N), torch.randn(M, N)
+            Am = A.t() if ta else A
+            Bk = Bm.t() if tb else Bm
+            alpha = 1.0 / math.sqrt(K)
+            ref = (alpha * (_bf16_round(Am) @ _bf16_round(Bk)) + 0.5 * C0.double() + bias.double()).float()
+            Cd = g(C0.clone())
+            sAm, sAk = (1, M) if ta else (K, 1)
+            sBk, sBn = (1, K) if tb else (N, 1)
+            a_args = (g(A), g(Bm), Cd, M, N, K, sAm, sAk, sBk, sBn, N)
+            ops.gemm_raw(*a_args, bias=g(bias), alpha=alpha, beta=0.5, mode=1)
+            torch.cuda.synchronize()
+            assert mad(Cd, ref) < 2e-4, (ta, tb, mad(Cd, ref))
+    # generic strides (every 2nd column of a wider matrix) and a source that is only 4-byte aligned
+    Aw, Bw = torch.randn(M, 2 * K + 1), torch.randn(N * K + 1)
+    Av, Bv = Aw[:, 1::2][:, :K], Bw[1:].view(N, K)
+    ref = (_bf16_round(Av) @ _bf16_round(Bv).t()).float() / math.sqrt(K)
+    Awd, Bwd = g(Aw), g(Bw)
+    Cd = torch.empty(M, N, device="cuda")
+    ops.gemm_raw(Awd[:, 1:], Bwd[1:], Cd, M, N, K, 2 * K + 1, 2, 1, K, N, alpha=1.0 / math.sqrt(K), mode=1)
+    torch.cuda.synchronize()
+    assert mad(Cd, ref) < 2e-4
+
+
+def test_gemm_bf16_image_path_split_k_and_fallback_agree(env):
+    """weight-gradient shape through the image path with atomic split-K; and the staging kernel (no workspace) gives
+    the same numbers up to summation order."""
+    L, ops = env
+    torch.manual_seed(5)
+    rows, N, K = 9000, 256, 384
+    dpre, x = torch.randn(rows, N), torch.randn(rows, K)
+    ref = (_bf16_round(dpre).t() @ _bf16_round(x)).float() / 64
+    C1, C2 = torch.empty(N, K, device="cuda"), torch.empty(N, K, device="cuda")
+    dd, xd = g(dpre), g(x)
+    ops.gemm_raw(dd, xd, C1, N, K, rows, 1, N, K, 1, K, alpha=1.0 / 64, mode=1, splitk=True)
+    ops._BF16_IMAGES = False
+    try:
+        ops.gemm_raw(dd, xd, C2, N, K, rows, 1, N, K, 1, K, alpha=1.0 / 64, mode=1, splitk=True)
+    finally:
+        ops._BF16_IMAGES = True
+    torch.cuda.synchronize()
+    assert mad(C1, ref) < 3e-4 and mad(C2, ref) < 3e-4
