@@ -211,6 +211,9 @@ class AR_Step(nn.Module):
             ctx, attn, logprob = self.run_cumm_attn_sequence(h_att, text, in_lens32)   # drops the prior like flowtron.py:742-743
         else:
             ctx, attn, logprob = self.attention_layer(h_att, text, text, in_lens32, attn_prior)
+        # attention-CTC (value + gradient) on a side stream, under the decoder-LSTM launch chain (no-op unless a
+        # FlowtronLoss with the CTC term exists; flowtron.py:245-274 evaluates it at loss time)
+        ops.ctc_prefetch(logprob, in_lens32, out_lens32, getattr(self, "_time_reversed", False))
         gates = None
         if hasattr(self, "gate_layer"):
             g = self.gate_layer.linear_layer
@@ -337,6 +340,7 @@ class AR_Back_Step(nn.Module):
         super().__init__()
         self.ar_step = AR_Step(n_mel_channels, n_speaker_dim, n_text_dim, n_mel_channels + n_speaker_dim, n_hidden,
                                n_attn_channels, n_lstm_layers, add_gate, use_cumm_attention)
+        self.ar_step._time_reversed = True
 
     def forward(self, mel, text, in_lens32, out_lens32, attn_prior=None):
         # flip + per-sample roll (flowtron.py:606-613) == the reverse-by-length involution, one gather kernel, no host syncs
@@ -481,6 +485,8 @@ class FlowtronLoss(nn.Module):
         self.ctc_loss_weight = ctc_loss_weight
         self.blank_logprob = blank_logprob
         self.attention_loss = AttentionCTCLoss(blank_logprob=self.blank_logprob)
+        # let the model's forward start the CTC recursion early, on a side stream (ops.ctc_prefetch)
+        ops.set_ctc_prefetch(self.blank_logprob if (use_ctc_loss and ctc_loss_weight) else None)
 
     def forward(self, model_output, gate_target, in_lengths, out_lengths, is_validation=False):
         z, log_s_list, gate_pred, attn_list, attn_logprob_list = model_output[:5]
@@ -493,9 +499,11 @@ class FlowtronLoss(nn.Module):
         if self.use_ctc_loss:
             total = None
             for i, lp in enumerate(attn_logprob_list):
-                if i % 2 != 0:
-                    lp = ops.reverse_by_length(lp, out32, False)       # back-step flows are in reversed time (:250-256)
-                c = self.attention_loss(lp, in_lengths, out_lengths)
+                c = ops.ctc_prefetched(lp, self.blank_logprob, i % 2 != 0) if lp.is_cuda else None
+                if c is None:
+                    if i % 2 != 0:
+                        lp = ops.reverse_by_length(lp, out32, False)   # back-step flows are in reversed time (:250-256)
+                    c = self.attention_loss(lp, in_lengths, out_lengths)
                 total = c if total is None else total + c
             loss_ctc = total / float(len(attn_logprob_list))
         return loss, gate_loss, loss_ctc

@@ -606,6 +606,90 @@ class AttnCTCFn(torch.autograd.Function):
         return dlp, None, None, None
 
 
+# ---- attention-CTC computed AHEAD of the loss, on a side stream -------------------------------------------------
+# The banded DP is one workgroup per sample (32 of 256 CUs busy for ~1.2 ms per flow, forward + gradient) and depends only
+# on the attention log-probabilities, which exist long before the loss is evaluated.  When a FlowtronLoss with the CTC term
+# has been constructed, AR_Step.forward launches alpha AND the beta/gradient sweep right after the attention kernel on a
+# side stream, where it overlaps the decoder-LSTM launch chain (which leaves the chip mostly idle); the loss later joins the
+# stream and its backward is a scale of the stored gradient.  Same kernels, same numbers as AttnCTCFn.
+_CTC_PREFETCH = {"blank": None, "streams": {}}
+
+
+def set_ctc_prefetch(blank_logprob):
+    """blank_logprob of the FlowtronLoss that will consume the prefetched value, or None to switch prefetching off."""
+    _CTC_PREFETCH["blank"] = None if blank_logprob is None else float(blank_logprob)
+
+
+def _reverse_raw(x, lens32, time_major):
+    y = torch.empty_like(x)
+    if time_major:
+        T, B, Cc = x.shape
+    else:
+        B, T, Cc = x.shape
+    L.check(L.lib().ft_reverse_by_length(L.ptr(x), L.ptr(y), L.ptr(lens32), T, B, Cc, int(time_major), L.stream()),
+            "ft_reverse_by_length")
+    return y
+
+
+def ctc_prefetch(lp, in_lens32, out_lens32, time_reversed):
+    """lp [B,T,L] attention log-probabilities of one flow (time-reversed for back-step flows, flowtron.py:250-256)."""
+    import os
+    blank = _CTC_PREFETCH["blank"]
+    if (blank is None or not lp.is_cuda or not torch.is_grad_enabled() or not lp.requires_grad
+            or os.environ.get("FLOWTRON_CTC_PREFETCH", "1") == "0"):
+        return
+    dev = lp.device
+    side = _CTC_PREFETCH["streams"].get(dev)
+    if side is None:
+        side = _CTC_PREFETCH["streams"][dev] = torch.cuda.Stream(device=dev)
+    cur = torch.cuda.current_stream(dev)
+    side.wait_stream(cur)
+    src = _c(lp.detach().float())
+    with torch.cuda.stream(side):
+        x = _reverse_raw(src, out_lens32, False) if time_reversed else src
+        B, T, Lk = x.shape
+        work = torch.empty(L.lib().ft_attn_ctc_workspace_floats(B, T, Lk), device=dev, dtype=torch.float32)
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        one = torch.ones(1, device=dev, dtype=torch.float32)
+        dlp = torch.empty_like(x)
+        L.check(L.lib().ft_attn_ctc_fwd(L.ptr(x), L.ptr(in_lens32), L.ptr(out_lens32), blank, L.ptr(work), L.ptr(loss),
+                                        B, T, Lk, L.stream()), "ft_attn_ctc_fwd")
+        L.check(L.lib().ft_attn_ctc_bwd(L.ptr(x), L.ptr(in_lens32), L.ptr(out_lens32), blank, L.ptr(work), L.ptr(one), L.ptr(dlp),
+                                        B, T, Lk, L.stream()), "ft_attn_ctc_bwd")
+        if time_reversed:
+            dlp = _reverse_raw(dlp, out_lens32, False)       # gradient back in the flow's own (reversed) time order
+        ev = torch.cuda.Event()
+        ev.record(side)
+    for t in (src, in_lens32, out_lens32):
+        t.record_stream(side)
+    lp._ctc_pre = dict(blank=blank, reversed=bool(time_reversed), loss=loss, dlp=dlp, event=ev)
+
+
+class CTCPrefetchedFn(torch.autograd.Function):
+    """joins the side stream; value and gradient were computed by ctc_prefetch()."""
+
+    @staticmethod
+    def forward(ctx, lp, pre):
+        cur = torch.cuda.current_stream(lp.device)
+        cur.wait_event(pre["event"])
+        pre["loss"].record_stream(cur)
+        pre["dlp"].record_stream(cur)
+        ctx.dlp = pre["dlp"]
+        return pre["loss"].reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.dlp * g, None
+
+
+def ctc_prefetched(lp, blank_logprob, time_reversed):
+    """the prefetched CTC term of `lp` if ctc_prefetch() ran for it with the same blank / time order, else None."""
+    pre = getattr(lp, "_ctc_pre", None)
+    if pre is None or pre["blank"] != float(blank_logprob) or pre["reversed"] != bool(time_reversed):
+        return None
+    return CTCPrefetchedFn.apply(lp, pre)
+
+
 # --------------------------------------------------------------------------
 # two stacked LSTM layers as one launch chain (csrc/lstm2.hip)
 # --------------------------------------------------------------------------

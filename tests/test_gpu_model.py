@@ -409,3 +409,32 @@ def test_unsupported_sizes_fail_loudly():
     with pytest.raises(RuntimeError, match="LDS"):                 # L = 2000 text positions exceed the LDS score tile
         ops.AttentionScoresFn.apply(Q, torch.randn(2000, 1, 8, device="cuda"), torch.randn(1, 8, device="cuda"),
                                     torch.tensor([2000], dtype=torch.int32, device="cuda"), None, 1.0)
+
+
+def test_ctc_prefetch_on_side_stream_matches_loss_time_evaluation():
+    """ops.ctc_prefetch (alpha + gradient sweep launched from AR_Step.forward on a side stream) gives the loss-time
+    AttnCTCFn numbers: same CTC value bit for bit, parameter gradients to fp32 rounding of one extra multiply."""
+    import flowtron
+    from flowtron_amd import ops
+    from oracle import synth
+    cfg = dict(synth.SMALL_MODEL_CONFIG)
+    m, sd = build(cfg, 29)
+    bc = synth.make_batch(cfg, [31, 24, 9], [12, 7, 3], seed=29, with_prior=True)
+    b = cuda_batch(bc)
+    res = []
+    for prefetch in (True, False):
+        crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)           # ctor arms the prefetch
+        if not prefetch:
+            ops.set_ctc_prefetch(None)
+        m.zero_grad(set_to_none=True)
+        out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+        assert all(hasattr(lp, "_ctc_pre") == prefetch for lp in out[4])
+        nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+        (nll + gl + 0.5 * ctc).backward()
+        torch.cuda.synchronize()
+        res.append((ctc.item(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    ops.set_ctc_prefetch(-8)
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        a, r = res[0][1][k], res[1][1][k]
+        assert (a - r).norm().item() <= 1e-5 * max(r.norm().item(), 1e-6), k
