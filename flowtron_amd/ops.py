@@ -612,6 +612,7 @@ class AttnCTCFn(torch.autograd.Function):
 # has been constructed, AR_Step.forward launches alpha AND the beta/gradient sweep right after the attention kernel on a
 # side stream, where it overlaps the decoder-LSTM launch chain (which leaves the chip mostly idle); the loss later joins the
 # stream and its backward is a scale of the stored gradient.  Same kernels, same numbers as AttnCTCFn.
+# MEASURED NEUTRAL on the training step (79.1 vs 78.8 ms): kept as an opt-in (FLOWTRON_CTC_PREFETCH=1) with its parity test.
 _CTC_PREFETCH = {"blank": None, "streams": {}}
 
 
@@ -636,7 +637,7 @@ def ctc_prefetch(lp, in_lens32, out_lens32, time_reversed):
     import os
     blank = _CTC_PREFETCH["blank"]
     if (blank is None or not lp.is_cuda or not torch.is_grad_enabled() or not lp.requires_grad
-            or os.environ.get("FLOWTRON_CTC_PREFETCH", "1") == "0"):
+            or os.environ.get("FLOWTRON_CTC_PREFETCH", "0") != "1"):          # opt-in: measured neutral (79.1 vs 78.8 ms/step)
         return
     dev = lp.device
     side = _CTC_PREFETCH["streams"].get(dev)

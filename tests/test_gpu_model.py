@@ -411,7 +411,7 @@ def test_unsupported_sizes_fail_loudly():
                                     torch.tensor([2000], dtype=torch.int32, device="cuda"), None, 1.0)
 
 
-def test_ctc_prefetch_on_side_stream_matches_loss_time_evaluation():
+def test_ctc_prefetch_on_side_stream_matches_loss_time_evaluation(monkeypatch):
     """ops.ctc_prefetch (alpha + gradient sweep launched from AR_Step.forward on a side stream) gives the loss-time
     AttnCTCFn numbers: same CTC value bit for bit, parameter gradients to fp32 rounding of one extra multiply."""
     import flowtron
@@ -422,6 +422,7 @@ def test_ctc_prefetch_on_side_stream_matches_loss_time_evaluation():
     bc = synth.make_batch(cfg, [31, 24, 9], [12, 7, 3], seed=29, with_prior=True)
     b = cuda_batch(bc)
     res = []
+    monkeypatch.setenv("FLOWTRON_CTC_PREFETCH", "1")                              # opt-in path
     for prefetch in (True, False):
         crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)           # ctor arms the prefetch
         if not prefetch:
