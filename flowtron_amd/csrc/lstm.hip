@@ -146,7 +146,7 @@ struct FwdP {
 };
 
 template <int MODE, int MT, int G, bool REV>
-__global__ __launch_bounds__(256) void lstm_fwd_step(FwdP p) {
+__device__ __forceinline__ void lstm_fwd_body(const FwdP& p) {
     __shared__ float red[4][MT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_matmul(BwdP p) {
 // workgroups (same XCD: linear id = y*gridDim.x + x keeps x % 8), each streaming W (128 KB) + HALF of dgates (128 KB)
 // instead of one workgroup streaming 384 KB -- the step is bound by bytes per CU.
 template <int MT, int G, bool REV>
-__global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) {
+__device__ __forceinline__ void lstm_bwd_body_bf16(const BwdP& p) {
     __shared__ float red[16][MT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
@@ -409,6 +409,25 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) {
         dg[(size_t)g * H] = da[g];
         p.dafrag_next[frag_index(eb, g * H + eu, p.MT)] = f2bf(da[g]);
     }
+}
+
+template <int MODE, int MT, int G, bool REV>
+__global__ __launch_bounds__(256) void lstm_fwd_step(FwdP p) { lstm_fwd_body<MODE, MT, G, REV>(p); }
+template <int MT, int G, bool REV>
+__global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) { lstm_bwd_body_bf16<MT, G, REV>(p); }
+
+// Both directions of a bidirectional layer (the encoder BiLSTM, flowtron.py:488, :505-512) as ONE launch per step: the
+// two recurrences are independent, a step is latency-bound, so grid.z = 2 halves the launch count (z = 0 forward in time,
+// z = 1 reverse).  bf16 fragment path only.
+template <int MT, int G>
+__global__ __launch_bounds__(256) void lstm_fwd_pair(FwdP pf, FwdP pr) {
+    if (blockIdx.z == 0) lstm_fwd_body<1, MT, G, false>(pf);
+    else lstm_fwd_body<1, MT, G, true>(pr);
+}
+template <int G>
+__global__ __launch_bounds__(1024) void lstm_bwd_pair(BwdP pf, BwdP pr) {
+    if (blockIdx.z == 0) lstm_bwd_body_bf16<1, G, false>(pf);
+    else lstm_bwd_body_bf16<1, G, true>(pr);
 }
 
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Ccols) {
@@ -632,4 +651,109 @@ extern "C" int ft_lstm_seq_bwd(const float* dy, int64_t ldy, const float* w_hh, 
                                const float* gates, const float* cell, float* dgx, void* work,
                                int T, int B, int H, int reverse, int mode, void* stream) {
     return ft_lstm_seq_bwd_range(dy, ldy, w_hh, lens, gates, cell, dgx, work, T, B, H, reverse, mode, 0, T, 0, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bidirectional layer: both directions in one launch per step (lstm_fwd_pair / lstm_bwd_pair)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct FwdCarve { float* hbuf[2]; float* cstate; unsigned short* hfrag[2]; unsigned short* wfrag; size_t state_bytes; };
+FwdCarve carve_fwd(void* work, int B, int H, int mt) {
+    const size_t BH = (size_t)B * H, frag_act = (size_t)mt * 16 * H * 2;
+    char* base = reinterpret_cast<char*>(work);
+    float* w = reinterpret_cast<float*>(base);
+    FwdCarve c;
+    c.hbuf[0] = w; c.hbuf[1] = w + BH; c.cstate = w + 2 * BH;
+    c.hfrag[0] = reinterpret_cast<unsigned short*>(base + al256(3 * BH * 4));
+    c.hfrag[1] = reinterpret_cast<unsigned short*>(base + al256(3 * BH * 4) + frag_act);
+    c.wfrag = reinterpret_cast<unsigned short*>(base + al256(3 * BH * 4) + al256(2 * frag_act));
+    c.state_bytes = al256(3 * BH * 4) + al256(2 * frag_act);
+    return c;
+}
+struct BwdCarve { float* da_cur; float* part; float* dc_carry; float* wT; char* fr; unsigned short* dafrag[2]; unsigned short* wTfrag;
+                  size_t carry_bytes, frag_bytes; };
+BwdCarve carve_bwd(void* work, int B, int H, int mt) {
+    const size_t BH = (size_t)B * H, frag_act = (size_t)mt * 16 * H * 2;
+    char* base = reinterpret_cast<char*>(work);
+    float* w = reinterpret_cast<float*>(base);
+    BwdCarve c;
+    c.da_cur = w; c.part = w + 4 * BH; c.dc_carry = w + 8 * BH;
+    c.wT = reinterpret_cast<float*>(base + al256(9 * BH * 4));
+    c.fr = base + al256(9 * BH * 4) + al256((size_t)4 * H * H * 4);
+    c.dafrag[0] = reinterpret_cast<unsigned short*>(c.fr);
+    c.dafrag[1] = reinterpret_cast<unsigned short*>(c.fr + 4 * frag_act);
+    c.wTfrag = reinterpret_cast<unsigned short*>(c.fr + al256(8 * frag_act));
+    c.carry_bytes = al256(9 * BH * 4); c.frag_bytes = al256(8 * frag_act);
+    return c;
+}
+template <int G>
+void launch_fwd_pair(const FwdP& pf, const FwdP& pr, int mt, dim3 grid, hipStream_t st) {
+    if (mt == 1) hipLaunchKernelGGL((lstm_fwd_pair<1, G>), grid, dim3(256), 0, st, pf, pr);
+    else if (mt == 2) hipLaunchKernelGGL((lstm_fwd_pair<2, G>), grid, dim3(256), 0, st, pf, pr);
+    else hipLaunchKernelGGL((lstm_fwd_pair<4, (G > 4 ? 4 : G)>), grid, dim3(256), 0, st, pf, pr);
+}
+}  // namespace
+
+extern "C" int ft_lstm_bidir_supported(int B, int H) { return (B >= 1 && B <= 64 && H >= 128 && H % 128 == 0) ? 1 : 0; }
+
+extern "C" int ft_lstm_bidir_seq_fwd(const float* gx_f, const float* gx_r, const float* w_hh_f, const float* w_hh_r,
+                                     const int32_t* lens, float* y, int64_t ldy, float* gates_f, float* gates_r,
+                                     float* cell_f, float* cell_r, void* work_f, void* work_r, int T, int B, int H, void* stream) {
+    FT_CHECK_ARG(gx_f && gx_r && w_hh_f && w_hh_r && lens && y && gates_f && gates_r && cell_f && cell_r && work_f && work_r);
+    FT_CHECK_ARG(T >= 0 && ldy >= 2 * (int64_t)H);
+    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(work_f) % 256 == 0 && reinterpret_cast<uintptr_t>(work_r) % 256 == 0);
+    if (!ft_lstm_bidir_supported(B, H)) return ft_fail(FT_EUNSUPPORTED, "ft_lstm_bidir_seq_fwd: needs H %% 128 == 0 and B <= 64 (H=%d B=%d)", H, B);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int mt = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    const int g = group_of((H >> 5) / 4);
+    FwdCarve cf = carve_fwd(work_f, B, H, mt), cr = carve_fwd(work_r, B, H, mt);
+    FT_CHECK_HIP(hipMemsetAsync(work_f, 0, cf.state_bytes, st));
+    FT_CHECK_HIP(hipMemsetAsync(work_r, 0, cr.state_bytes, st));
+    hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh_f, cf.wfrag, H);
+    hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh_r, cr.wfrag, H);
+    dim3 grid(H / 4, 1, 2);
+    for (int s = 0; s < T; ++s) {
+        FwdP pf{gx_f, w_hh_f, lens, cf.hbuf[s & 1], cf.hbuf[(s + 1) & 1], cf.cstate, y, (long)ldy, gates_f, cell_f,
+                cf.wfrag, cf.hfrag[s & 1], cf.hfrag[(s + 1) & 1], s, T, B, H, 0};
+        FwdP pr{gx_r, w_hh_r, lens, cr.hbuf[s & 1], cr.hbuf[(s + 1) & 1], cr.cstate, y + H, (long)ldy, gates_r, cell_r,
+                cr.wfrag, cr.hfrag[s & 1], cr.hfrag[(s + 1) & 1], s, T, B, H, 1};
+        if (g == 8 && mt <= 2) launch_fwd_pair<8>(pf, pr, mt, grid, st);
+        else if (g >= 4) launch_fwd_pair<4>(pf, pr, mt, grid, st);
+        else if (g == 2) launch_fwd_pair<2>(pf, pr, mt, grid, st);
+        else launch_fwd_pair<1>(pf, pr, mt, grid, st);
+    }
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+
+extern "C" int ft_lstm_bidir_seq_bwd(const float* dy, int64_t ldy, const float* w_hh_f, const float* w_hh_r, const int32_t* lens,
+                                     const float* gates_f, const float* gates_r, const float* cell_f, const float* cell_r,
+                                     float* dgx_f, float* dgx_r, void* work_f, void* work_r, int T, int B, int H, void* stream) {
+    FT_CHECK_ARG(dy && w_hh_f && w_hh_r && lens && gates_f && gates_r && cell_f && cell_r && dgx_f && dgx_r && work_f && work_r);
+    FT_CHECK_ARG(T >= 0 && ldy >= 2 * (int64_t)H);
+    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(work_f) % 256 == 0 && reinterpret_cast<uintptr_t>(work_r) % 256 == 0);
+    if (!ft_lstm_bidir_supported(B, H)) return ft_fail(FT_EUNSUPPORTED, "ft_lstm_bidir_seq_bwd: needs H %% 128 == 0 and B <= 64 (H=%d B=%d)", H, B);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int mt = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    const int g = group_of(((4 * H) >> 5) / 16);
+    BwdCarve cf = carve_bwd(work_f, B, H, mt), cr = carve_bwd(work_r, B, H, mt);
+    FT_CHECK_HIP(hipMemsetAsync(work_f, 0, cf.carry_bytes, st));
+    FT_CHECK_HIP(hipMemsetAsync(work_r, 0, cr.carry_bytes, st));
+    FT_CHECK_HIP(hipMemsetAsync(cf.fr, 0, cf.frag_bytes, st));
+    FT_CHECK_HIP(hipMemsetAsync(cr.fr, 0, cr.frag_bytes, st));
+    hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh_f, cf.wTfrag, H);
+    hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh_r, cr.wTfrag, H);
+    dim3 grid(H / 16, mt, 2);
+    for (int s = T - 1; s >= 0; --s) {
+        BwdP pf{dy, (long)ldy, lens, gates_f, cell_f, cf.part, cf.dc_carry, cf.da_cur, dgx_f, cf.wT, cf.part,
+                cf.dafrag[(s + 1) & 1], cf.dafrag[s & 1], cf.wTfrag, s, T, B, H, 0, mt};
+        BwdP pr{dy + H, (long)ldy, lens, gates_r, cell_r, cr.part, cr.dc_carry, cr.da_cur, dgx_r, cr.wT, cr.part,
+                cr.dafrag[(s + 1) & 1], cr.dafrag[s & 1], cr.wTfrag, s, T, B, H, 1, mt};
+        if (g == 8) hipLaunchKernelGGL(lstm_bwd_pair<8>, grid, dim3(1024), 0, st, pf, pr);
+        else if (g >= 4) hipLaunchKernelGGL(lstm_bwd_pair<4>, grid, dim3(1024), 0, st, pf, pr);
+        else if (g >= 2) hipLaunchKernelGGL(lstm_bwd_pair<2>, grid, dim3(1024), 0, st, pf, pr);
+        else hipLaunchKernelGGL(lstm_bwd_pair<1>, grid, dim3(1024), 0, st, pf, pr);
+    }
+    FT_CHECK_LAUNCH();
+    return FT_OK;
 }

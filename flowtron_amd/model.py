@@ -104,10 +104,9 @@ class Encoder(nn.Module):
                 keep = (torch.rand_like(x) >= 0.5).to(x.dtype) * 2.0      # F.dropout(p=0.5) keep-mask, flowtron.py:502
             x = ops.conv_norm_relu(x, lens, conv.conv.weight, conv.conv.bias, norm.weight, norm.bias, keep, norm.eps)
         p = self.lstm
-        yf = ops.lstm_layer(x, lens, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, reverse=False)
-        yb = ops.lstm_layer(x, lens, p.weight_ih_l0_reverse, p.weight_hh_l0_reverse, p.bias_ih_l0_reverse,
-                            p.bias_hh_l0_reverse, reverse=True)
-        return torch.cat([yf, yb], 2)
+        # both directions in one launch chain when the fragment path applies (ops.bilstm_layer)
+        return ops.bilstm_layer(x, lens, (p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0),
+                                (p.weight_ih_l0_reverse, p.weight_hh_l0_reverse, p.bias_ih_l0_reverse, p.bias_hh_l0_reverse))
 
     def forward(self, x, in_lens):
         """x [B,C,L] (reference layout) -> [B,L,C]"""
@@ -497,13 +496,22 @@ class FlowtronLoss(nn.Module):
             gate_loss = ops.GateBCEFn.apply(gate_pred, gate_target, out32)
         loss_ctc = torch.zeros_like(gate_loss)
         if self.use_ctc_loss:
-            total = None
+            total, pending = None, []
             for i, lp in enumerate(attn_logprob_list):
                 c = ops.ctc_prefetched(lp, self.blank_logprob, i % 2 != 0) if lp.is_cuda else None
                 if c is None:
                     if i % 2 != 0:
                         lp = ops.reverse_by_length(lp, out32, False)   # back-step flows are in reversed time (:250-256)
+                    if lp.is_cuda and len(attn_logprob_list) > 1:
+                        pending.append(lp)                             # all flows go through ONE kernel pair below
+                        continue
                     c = self.attention_loss(lp, in_lengths, out_lengths)
+                total = c if total is None else total + c
+            if pending:
+                # the DP is one workgroup per sample and latency-bound in T: F flows stacked along the batch cost the time
+                # of one (F*B of 256 CUs busy).  mean over F*B samples * F == sum over flows of the per-flow batch means.
+                F_ = len(pending)
+                c = self.attention_loss(torch.cat(pending, 0), in_lengths.repeat(F_), out_lengths.repeat(F_)) * float(F_)
                 total = c if total is None else total + c
             loss_ctc = total / float(len(attn_logprob_list))
         return loss, gate_loss, loss_ctc

@@ -326,6 +326,68 @@ def lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=False, mode=None, xs_ext
     return LSTMSeqFn.apply(gx, w_hh, lens, reverse, mode)
 
 
+class BiLSTMSeqFn(torch.autograd.Function):
+    """[h_fwd | h_rev] of a bidirectional layer, both recurrences in one launch chain (csrc/lstm.hip lstm_*_pair)."""
+
+    @staticmethod
+    def forward(ctx, gx_f, gx_r, w_f, w_r, lens):
+        gx_f, gx_r, w_f, w_r = _c(gx_f), _c(gx_r), _c(w_f), _c(w_r)
+        L.require_cuda(gx_f, gx_r, w_f, w_r, lens)
+        T, B, H4 = gx_f.shape
+        H = H4 // 4
+        f = dict(device=gx_f.device, dtype=torch.float32)
+        y = torch.empty(T, B, 2 * H, **f)
+        gates = [torch.empty(T, B, H4, **f) for _ in range(2)]
+        cell = [torch.empty(T, B, H, **f) for _ in range(2)]
+        nb = L.lib().ft_lstm_workspace_bytes(B, H)
+        work = [torch.empty(nb, device=gx_f.device, dtype=torch.uint8) for _ in range(2)]
+        L.check(L.lib().ft_lstm_bidir_seq_fwd(L.ptr(gx_f), L.ptr(gx_r), L.ptr(w_f), L.ptr(w_r), L.ptr(lens), L.ptr(y), 2 * H,
+                                              L.ptr(gates[0]), L.ptr(gates[1]), L.ptr(cell[0]), L.ptr(cell[1]),
+                                              L.ptr(work[0]), L.ptr(work[1]), T, B, H, L.stream()), "ft_lstm_bidir_seq_fwd")
+        ctx.save_for_backward(w_f, w_r, lens, y, gates[0], gates[1], cell[0], cell[1])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        w_f, w_r, lens, y, g0, g1, c0, c1 = ctx.saved_tensors
+        dy = _c(dy)
+        T, B, H2 = y.shape
+        H = H2 // 2
+        f = dict(device=dy.device, dtype=torch.float32)
+        dgx = [torch.empty(T, B, 4 * H, **f) for _ in range(2)]
+        nb = L.lib().ft_lstm_workspace_bytes(B, H)
+        work = [torch.empty(nb, device=dy.device, dtype=torch.uint8) for _ in range(2)]
+        L.check(L.lib().ft_lstm_bidir_seq_bwd(L.ptr(dy), 2 * H, L.ptr(w_f), L.ptr(w_r), L.ptr(lens), L.ptr(g0), L.ptr(g1),
+                                              L.ptr(c0), L.ptr(c1), L.ptr(dgx[0]), L.ptr(dgx[1]), L.ptr(work[0]), L.ptr(work[1]),
+                                              T, B, H, L.stream()), "ft_lstm_bidir_seq_bwd")
+        dWs = [None, None]
+        rows = (T - 1) * B
+        for d in range(2):
+            if ctx.needs_input_grad[2 + d]:
+                dWs[d] = torch.zeros_like(w_f)
+                if T > 1:
+                    # dW_hh[r,j] = sum da_t[b,r] h_prev(t)[b,j];  h_prev = y[t-1] (forward) / y[t+1] (reverse), y row stride 2H
+                    da = dgx[d][1:] if d == 0 else dgx[d][:-1]
+                    hp = y[:-1, :, :H] if d == 0 else y[1:, :, H:]
+                    gemm_raw(da, hp, dWs[d], 4 * H, H, rows, 1, 4 * H, 2 * H, 1, H, mode=L.FT_BF16, splitk=True)
+        return dgx[0], dgx[1], dWs[0], dWs[1], None
+
+
+def bilstm_layer(x, lens, wf, wr, mode=None):
+    """Bidirectional LSTM layer.  wf / wr = (w_ih, w_hh, b_ih, b_hh) of the two directions.  Returns [T,B,2H]."""
+    mode = L.mfma_mode() if mode is None else mode
+    T, B, _ = x.shape
+    H = wf[1].shape[1]
+    import os
+    if mode == L.FT_BF16 and os.environ.get("FLOWTRON_BILSTM", "1") != "0" and L.lib().ft_lstm_bidir_supported(B, H):
+        gx_f = LinearFn.apply(wf[0], wf[2] + wf[3], L.ACT_NONE, mode, x)
+        gx_r = LinearFn.apply(wr[0], wr[2] + wr[3], L.ACT_NONE, mode, x)
+        return BiLSTMSeqFn.apply(gx_f, gx_r, wf[1], wr[1], lens)
+    yf = lstm_layer(x, lens, *wf, reverse=False, mode=mode)
+    yb = lstm_layer(x, lens, *wr, reverse=True, mode=mode)
+    return torch.cat([yf, yb], 2)
+
+
 # --------------------------------------------------------------------------
 # attention (flowtron.py:544-592)
 # --------------------------------------------------------------------------

@@ -135,6 +135,19 @@ int ft_lstm2_seq_bwd(const float* dy1, const float* w_hh0, const float* w_ih1, c
                      const float* gates0, const float* cell0, const float* gates1, const float* cell1,
                      float* dgx0, float* dgx1, void* work, int T, int B, int H, void* stream);
 
+/* Both directions of a bidirectional layer (the encoder nn.LSTM(.., bidirectional=True), flowtron.py:488, :505-512) as ONE
+ * launch chain: the forward-in-time and the reverse recurrence are independent and each step is latency-bound, so they run
+ * as the two z-slices of the same launch (T launches instead of 2T).  bf16 MFMA operands; ft_lstm_bidir_supported(B,H):
+ * H % 128 == 0, B <= 64.  y [T,B,ldy] with ldy >= 2H receives [h_fwd | h_rev]; dy has the same layout.  gx_*, gates_*,
+ * cell_*, dgx_* as in ft_lstm_seq_*; work_f / work_r: ft_lstm_workspace_bytes(B,H) each, 256-byte aligned. */
+int ft_lstm_bidir_supported(int B, int H);
+int ft_lstm_bidir_seq_fwd(const float* gx_f, const float* gx_r, const float* w_hh_f, const float* w_hh_r,
+                          const int32_t* lens, float* y, int64_t ldy, float* gates_f, float* gates_r,
+                          float* cell_f, float* cell_r, void* work_f, void* work_r, int T, int B, int H, void* stream);
+int ft_lstm_bidir_seq_bwd(const float* dy, int64_t ldy, const float* w_hh_f, const float* w_hh_r, const int32_t* lens,
+                          const float* gates_f, const float* gates_r, const float* cell_f, const float* cell_r,
+                          float* dgx_f, float* dgx_r, void* work_f, void* work_r, int T, int B, int H, void* stream);
+
 /* ---- additive attention scores + softmax + prior posterior (flowtron.py:544-583)
  * Q [T,B,A] (time-major), K [L,B,A], v [A], in_lens [B], prior [B,T,L] or NULL.
  * e[b,t,l] = sum_a v[a] tanh(Q[t,b,a]+K[l,b,a]) / temperature, -inf at l >= in_lens[b];

@@ -512,3 +512,34 @@ def test_gemm_bf16_image_path_split_k_and_fallback_agree(env):
         ops._BF16_IMAGES = True
     torch.cuda.synchronize()
     assert mad(C1, ref) < 3e-4 and mad(C2, ref) < 3e-4
+
+
+@pytest.mark.parametrize("B,T", [(5, 7), (32, 19), (40, 3)])
+def test_bidirectional_pair_chain_equals_two_chains(env, monkeypatch, B, T):
+    """ft_lstm_bidir_seq_fwd/bwd (both directions as the two z-slices of one launch per step) must reproduce the two
+    independent ft_lstm_seq_* chains bit for bit -- same kernel bodies, same operands -- outputs and every gradient;
+    and the pair against the oracle's bidirectional LSTM (bf16 tolerance)."""
+    L, ops = env
+    from oracle import flowtron_oracle as O
+    torch.manual_seed(B * 100 + T)
+    H, I = 128, 48
+    lens = torch.randint(1, T + 1, (B,))
+    lens[0] = T
+    x = torch.randn(T, B, I)
+    k = 1.0 / math.sqrt(H)
+    mk = lambda *shape: torch.rand(*shape) * 2 * k - k
+    ws = [[mk(4 * H, I), mk(4 * H, H), mk(4 * H), mk(4 * H)] for _ in range(2)]
+    go = torch.randn(T, B, 2 * H)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FLOWTRON_BILSTM", flag)
+        xd = g(x).requires_grad_(True)
+        wd = [[g(t).requires_grad_(True) for t in w] for w in ws]
+        y = ops.bilstm_layer(xd, g(lens.int()), tuple(wd[0]), tuple(wd[1]), mode=1)
+        y.backward(g(go))
+        torch.cuda.synchronize()
+        res.append([y.detach(), xd.grad] + [t.grad for w in wd for t in w])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    ref = torch.cat([O.lstm_cell_seq(x, lens, *ws[0]), O.lstm_cell_seq(x, lens, *ws[1], reverse=True)], 2)
+    assert mad(res[0][0], ref) < 3e-2
