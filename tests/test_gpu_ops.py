@@ -539,7 +539,11 @@ def test_bidirectional_pair_chain_equals_two_chains(env, monkeypatch, B, T):
         y.backward(g(go))
         torch.cuda.synchronize()
         res.append([y.detach(), xd.grad] + [t.grad for w in wd for t in w])
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
+    names = ["y", "dx"] + [f"{n}_{d}" for d in "fr" for n in ("dw_ih", "dw_hh", "db_ih", "db_hh")]
+    for name, a, b in zip(names, *res):
+        if name.startswith("db"):               # ft_colsum combines row blocks with fp32 atomics: order-dependent last bit
+            assert mad(a, b) < 1e-5, (name, mad(a, b))
+        else:
+            assert torch.equal(a, b), (name, mad(a, b))
     ref = torch.cat([O.lstm_cell_seq(x, lens, *ws[0]), O.lstm_cell_seq(x, lens, *ws[1], reverse=True)], 2)
     assert mad(res[0][0], ref) < 3e-2
