@@ -4,9 +4,10 @@
 // operands through L2 -> VGPR -> cvt -> ds_write: 125 B/clk/CU at the full MFMA rate, twice what the L2 delivers, and the
 // transposed operands of the weight gradients pay a register transpose on top.  Here the rounding happens ONCE per
 // operand in a streaming pre-pass that also puts the reduction dimension innermost and zero-pads to whole tiles:
-//     A(m,k) -> Aimg [ceil128(M)][ceil64(K)] bf16,   B(k,n) -> Bimg [ceil128(N)][ceil64(K)] bf16
-// (three source layouts: k contiguous, row contiguous = tiled transpose through LDS, generic strides), and the GEMM
-// proper is an "NT" kernel with no bounds checks in its main loop:
+//     k contiguous source  -> image [ceil128(rows)][ceil32(K)]      (also generic strides)
+//     row contiguous source -> image [ceil32(K)][ceil128(rows)]     (k-major: NO transpose, the kernel reads it with
+//                                                                    the LDS transpose-read ds_read_b64_tr_b16)
+// and the GEMM proper (templated on the layout of each operand) has no bounds checks in its main loop:
 //   * 128x128 tile, 32-wide k stages (64 optional), 4 waves (2x2, 64x64 per wave = 4x4 MFMA 16x16x32 tiles per stage),
 //   * operands go global -> LDS by `global_load_lds_dwordx4` (no VGPR staging, no ds_write pass), two LDS stages so the
 //     DMA of step t+1 is in flight under the MFMAs of step t, one barrier per step, 4 workgroups per CU (32 KiB LDS each),
@@ -21,12 +22,11 @@
 namespace {
 
 constexpr int TB = 128;          // tile rows / cols
-constexpr int KS = 64;           // k elements per step
 
 inline size_t up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
 // ---------------------------------------------------------------------------------------------------------------
-// operand images
+// operand images: dst[r][c] = bf16(src(r,c)) for r < R, c < Cc, zero elsewhere; dst is [Rp][Cp] (Cp % 8 == 0)
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
     uint4 o;
@@ -35,88 +35,33 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
     return o;
 }
 
-// src(r,k) = src[r*sr + k]   (k contiguous)
-__global__ __launch_bounds__(256) void img_rows_k(const float* __restrict__ src, long sr, int R, int K,
-                                                  unsigned short* __restrict__ dst, int Rp, int Kp, int vec) {
-    const int kq = Kp >> 3;
-    const size_t total = (size_t)Rp * kq;
+// src(r,c) = src[r*sr + c*sc]; vec: sc == 1, 16-byte aligned rows
+__global__ __launch_bounds__(256) void img_rows_k(const float* __restrict__ src, long sr, long sc, int R, int Cc,
+                                                  unsigned short* __restrict__ dst, int Rp, int Cp, int vec) {
+    const int cq = Cp >> 3;
+    const size_t total = (size_t)Rp * cq;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / kq), k = (int)(i % kq) * 8;
+        const int r = (int)(i / cq), c = (int)(i % cq) * 8;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (r < R && k < K) {
-            const float* p = src + (size_t)r * sr + k;
-            if (vec && k + 7 < K) {
+        if (r < R && c < Cc) {
+            const float* p = src + (size_t)r * sr + (size_t)c * sc;
+            if (vec && c + 7 < Cc) {
                 const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
                 v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) if (k + e < K) v[e] = p[e];
+                for (int e = 0; e < 8; ++e) if (c + e < Cc) v[e] = p[(size_t)e * sc];
             }
         }
-        *reinterpret_cast<uint4*>(dst + (size_t)r * Kp + k) = pack8(v);
+        *reinterpret_cast<uint4*>(dst + (size_t)r * Cp + c) = pack8(v);
     }
 }
 
-// src(r,k) = src[k*sk + r]   (row dim contiguous): 64 x 64 tiled transpose through LDS.  grid (Rp/64, Kp/64)
-__global__ __launch_bounds__(256) void img_tr_k(const float* __restrict__ src, long sk, int R, int K,
-                                                unsigned short* __restrict__ dst, int Kp, int vec) {
-    __shared__ float t[64][65];
-    const int tid = threadIdx.x;
-    const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-    const int rq = (tid & 15) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int kk = (tid >> 4) + 16 * j, k = k0 + kk, r = r0 + rq;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < K && r < R) {
-            const float* p = src + (size_t)k * sk + r;
-            if (vec && r + 3 < R) v = *reinterpret_cast<const float4*>(p);
-            else {
-                v.x = p[0];
-                if (r + 1 < R) v.y = p[1];
-                if (r + 2 < R) v.z = p[2];
-                if (r + 3 < R) v.w = p[3];
-            }
-        }
-        t[kk][rq] = v.x; t[kk][rq + 1] = v.y; t[kk][rq + 2] = v.z; t[kk][rq + 3] = v.w;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = tid + 256 * j, row = c >> 3, kc = (c & 7) * 8;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = t[kc + e][row];
-        *reinterpret_cast<uint4*>(dst + (size_t)(r0 + row) * Kp + k0 + kc) = pack8(v);
-    }
-}
-
-// generic strides
-__global__ __launch_bounds__(256) void img_generic_k(const float* __restrict__ src, long sr, long sk, int R, int K,
-                                                     unsigned short* __restrict__ dst, int Rp, int Kp) {
-    const int kq = Kp >> 3;
-    const size_t total = (size_t)Rp * kq;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / kq), k = (int)(i % kq) * 8;
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (r < R)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (k + e < K) v[e] = src[(size_t)r * sr + (size_t)(k + e) * sk];
-        *reinterpret_cast<uint4*>(dst + (size_t)r * Kp + k) = pack8(v);
-    }
-}
-
-void make_image(const float* src, long sr, long sk, int R, int K, unsigned short* dst, int Rp, int Kp, hipStream_t st) {
-    const bool al = reinterpret_cast<uintptr_t>(src) % 16 == 0;
-    const size_t chunks = (size_t)Rp * (Kp >> 3);
+void make_image(const float* src, long sr, long sc, int R, int Cc, unsigned short* dst, int Rp, int Cp, hipStream_t st) {
+    const bool vec = sc == 1 && reinterpret_cast<uintptr_t>(src) % 16 == 0 && sr % 4 == 0;
+    const size_t chunks = (size_t)Rp * (Cp >> 3);
     const int blocks = (int)((chunks + 255) / 256 < 16384 ? (chunks + 255) / 256 : 16384);
-    if (sk == 1) {
-        hipLaunchKernelGGL(img_rows_k, dim3(blocks), dim3(256), 0, st, src, sr, R, K, dst, Rp, Kp, (al && sr % 4 == 0) ? 1 : 0);
-    } else if (sr == 1) {
-        hipLaunchKernelGGL(img_tr_k, dim3(Rp / 64, Kp / 64), dim3(256), 0, st, src, sk, R, K, dst, Kp, (al && sk % 4 == 0) ? 1 : 0);
-    } else {
-        hipLaunchKernelGGL(img_generic_k, dim3(blocks), dim3(256), 0, st, src, sr, sk, R, K, dst, Rp, Kp);
-    }
+    hipLaunchKernelGGL(img_rows_k, dim3(blocks), dim3(256), 0, st, src, sr, sc, R, Cc, dst, Rp, Cp, vec ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -124,22 +69,87 @@ void make_image(const float* src, long sr, long sk, int R, int K, unsigned short
 // ---------------------------------------------------------------------------------------------------------------
 struct BfP {
     const unsigned short* A; const unsigned short* B; float* C; const float* bias;
-    int M, N, Kp;
-    long ldc;
+    int M, N, nk;                           // nk = number of 32-wide k-steps
+    long lda, ldb, ldc;                     // image row strides in elements, C in floats
     float alpha, beta;
-    int act, gx, gy, splits, ksteps;        // tile grid, split-K factor, k-steps (of the kernel's KSTEP) per split
+    int act, gx, gy, splits, ksteps;        // tile grid, split-K factor, k-steps per split
     int vec_c;                              // C rows are 16-byte aligned: float4 epilogue
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
 
-// KSTEP = k elements per LDS stage (32 or 64), two stages; MINB = workgroups per CU the register budget is held to.
-template <int KSTEP, int MINB, bool SPLIT>
-__global__ __launch_bounds__(256, MINB) void gemm_bf16_nt(BfP p) {
-    constexpr int KH = KSTEP / 32;                     // 32-wide k-halves per stage
-    constexpr int STG = 2 * 8 * KH * 1024;             // bytes per stage: (A + B) x 8 row groups x KH sub-tiles of 1 KiB
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STG];
+// One operand = a 128 (rows: m or n) x 32 (k) tile per stage, 8 KiB, as eight 1 KiB sub-tiles = eight wave-wide DMAs.
+//   KM = false (k contiguous in the image, [row][k]):  sub-tile rg = [16 rows][32 k]; fragment by ds_read_b128.
+//   KM = true  (k-major image, [k][row]):              sub-tile (mb, kq) = [8 k][64 rows] (128-byte image rows, so the DMA
+//        reads whole 128-byte lines); the MFMA fragment (8 consecutive k of one row per lane) is two ds_read_b64_tr_b16:
+//        in a 16-lane group, lane 4j+q supplies the address of [k = 4h+j][rows 4q..4q+3] and lane c receives the four k of
+//        row c (probed on gfx950: scripts/exp/tr_probe.hip).  Bank swizzle on the DMA source: the 16-byte piece c of image
+//        row (kq, r) lands in slot c ^ 2*s, s = ((r>>1)&1) ^ ((kq&1)<<1), which spreads the four k-rows of a read and the two
+//        k-groups of a 32-lane half over distinct 32-byte bank groups.
+template <bool KM>
+struct Operand {
+    const unsigned short* src[2];          // this lane's DMA source for its wave's two sub-tiles (k-step 0)
+    size_t kstride;                        // elements to advance per k-step
+    int dst[2];                            // byte offsets of the two sub-tiles inside the operand's stage buffer
+    int roff;                              // this lane's fragment read offset (without the tile term)
+    __device__ __forceinline__ void init(const unsigned short* img, long ld, int r0, int wave, int lane, int wsel) {
+        const int li = lane & 15, kg = lane >> 4;
+        if constexpr (!KM) {
+            const int srow = lane >> 2, skp = (lane & 3) ^ ((lane >> 4) & 2);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                src[g] = img + (size_t)(r0 + wave * 32 + g * 16 + srow) * ld + skp * 8;
+                dst[g] = (wave * 2 + g) << 10;
+            }
+            kstride = 32;
+            roff = (wsel * 4 << 10) + (li * 4 + (kg ^ ((li >> 2) & 2))) * 16;
+        } else {
+            const int r = lane >> 3, kq = wave;
+            const int s = ((lane >> 4) & 1) ^ ((kq & 1) << 1);
+            const int c = (lane & 7) ^ (2 * s);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                src[g] = img + (size_t)(kq * 8 + r) * ld + r0 + g * 64 + c * 8;
+                dst[g] = (g * 4 + kq) << 10;
+            }
+            kstride = (size_t)32 * ld;
+            const int sr = ((li >> 3) & 1) ^ ((kg & 1) << 1);
+            roff = ((wsel * 4 + kg) << 10) + (li >> 2) * 128 + sr * 32 + (li & 3) * 8;
+        }
+    }
+    __device__ __forceinline__ void issue(unsigned char* sbuf, int t) const {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            __builtin_amdgcn_global_load_lds((glb_void*)(src[g] + (size_t)t * kstride), (lds_void*)(sbuf + dst[g]), 16, 0, 0);
+    }
+    // k-contiguous image: the whole fragment is one ds_read_b128 (compiler-scheduled)
+    __device__ __forceinline__ bf16x8 frag(const unsigned char* sbuf, int i) const {
+        return *reinterpret_cast<const bf16x8*>(sbuf + roff + (i << 10));
+    }
+    // k-major image: issue the two transpose-reads of fragment i.  Inline asm on purpose: behind the builtin hipcc waits
+    // vmcnt(0) before the first LDS read of every k-step, which drains the DMAs of the NEXT stage that were just issued; the
+    // caller retires the reads with tr_wait() (the "+v" operands order every consumer behind the wait).
+    __device__ __forceinline__ void tr_issue(const unsigned char* sbuf, int i, bf16x4& lo, bf16x4& hi) const {
+        const unsigned int a = (unsigned int)(size_t)(lds_void*)(sbuf + (roff ^ (i * 32)));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(hi) : "v"(a));
+    }
+};
+
+__device__ __forceinline__ void tr_wait(bf16x4 (&t)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+}
+__device__ __forceinline__ void tr_wait(bf16x4 (&t)[8], bf16x4 (&u)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
+                 "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]));
+}
+
+template <bool AKM, bool BKM, bool SPLIT>
+__global__ __launch_bounds__(256, 4) void gemm_bf16_k(BfP p) {
+    constexpr int OPB = 8192;                          // bytes per operand per stage
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * OPB];     // [stage][A | B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, kg = lane >> 4;
@@ -150,28 +160,13 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_nt(BfP p) {
         tile = xcd * q + (xcd < r ? xcd : r) + idx;
     }
     const int m0 = (tile / p.gx) * TB, n0 = (tile % p.gx) * TB;
-    const int nk = p.Kp / KSTEP;
     const int t0 = blockIdx.y * p.ksteps;
-    const int t1 = (t0 + p.ksteps < nk) ? t0 + p.ksteps : nk;
+    const int t1 = (t0 + p.ksteps < p.nk) ? t0 + p.ksteps : p.nk;
 
-    // DMA source of this lane: LDS slot `lane` of a [16][32] sub-tile holds (row lane>>2, k-part (lane&3) ^ swz(row))
-    const int srow = lane >> 2, skp = (lane & 3) ^ ((lane >> 4) & 2);
-    const unsigned short* ga = p.A + (size_t)(m0 + wave * 32 + srow) * p.Kp + skp * 8;
-    const unsigned short* gb = p.B + (size_t)(n0 + wave * 32 + srow) * p.Kp + skp * 8;
-    const size_t rstep = (size_t)16 * p.Kp;
-    auto issue = [&](int stage, int t) {
-        unsigned char* sa = smem + stage * STG;
-        unsigned char* sb = sa + STG / 2;
-        const size_t ko = (size_t)t * KSTEP;
-#pragma unroll
-        for (int kh = 0; kh < KH; ++kh)
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int sub = (kh * 8 + wave * 2 + g) << 10;
-                __builtin_amdgcn_global_load_lds((glb_void*)(ga + g * rstep + ko + kh * 32), (lds_void*)(sa + sub), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_void*)(gb + g * rstep + ko + kh * 32), (lds_void*)(sb + sub), 16, 0, 0);
-            }
-    };
+    Operand<AKM> oa;
+    Operand<BKM> ob;
+    oa.init(p.A, p.lda, m0, wave, lane, wm);
+    ob.init(p.B, p.ldb, n0, wave, lane, wn);
 
     // !SPLIT: acc[i][j] holds C^T: lane (li, kg), register r  <->  C[m = i*16 + li][n = j*16 + kg*4 + r]  (operands swapped
     //         in the MFMA so that a lane owns four CONSECUTIVE output columns: float4 stores / loads in the epilogue)
@@ -183,30 +178,54 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_nt(BfP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int rslot = (li * 4 + (kg ^ ((li >> 2) & 2))) * 16;      // this lane's fragment slot inside a sub-tile
-    if (t0 < t1) issue(0, t0);
+    if (t0 < t1) { oa.issue(smem, t0); ob.issue(smem + OPB, t0); }
     for (int t = t0; t < t1; ++t) {
         const int stage = (t - t0) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my DMAs of step t have landed
         __syncthreads();                                            // ... everyone's have; stage^1 is no longer being read
-        if (t + 1 < t1) issue(stage ^ 1, t + 1);
-        const unsigned char* sa = smem + stage * STG + rslot;
-        const unsigned char* sb = sa + STG / 2;
-#pragma unroll
-        for (int kh = 0; kh < KH; ++kh) {
-            bf16x8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sa + ((kh * 8 + wm * 4 + i) << 10));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + ((kh * 8 + wn * 4 + j) << 10));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (SPLIT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-                }
+        if (t + 1 < t1) {
+            unsigned char* nx = smem + (stage ^ 1) * 2 * OPB;
+            oa.issue(nx, t + 1);
+            ob.issue(nx + OPB, t + 1);
         }
+        const unsigned char* sa = smem + stage * 2 * OPB;
+        const unsigned char* sb = sa + OPB;
+        bf16x8 a[4], b[4];
+        bf16x4 ta[8], tb[8];
+        if constexpr (!AKM) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = oa.frag(sa, i);
+        }
+        if constexpr (!BKM) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = ob.frag(sb, j);
+        }
+        if constexpr (AKM) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) oa.tr_issue(sa, i, ta[2 * i], ta[2 * i + 1]);
+        }
+        if constexpr (BKM) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ob.tr_issue(sb, j, tb[2 * j], tb[2 * j + 1]);
+        }
+        if constexpr (AKM && BKM) tr_wait(ta, tb);
+        else if constexpr (AKM) tr_wait(ta);
+        else if constexpr (BKM) tr_wait(tb);
+        if constexpr (AKM) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = __builtin_shufflevector(ta[2 * i], ta[2 * i + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        if constexpr (BKM) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = __builtin_shufflevector(tb[2 * j], tb[2 * j + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (SPLIT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
     }
 
     if constexpr (SPLIT) {          // C was zeroed (beta == 0) or holds the addend (beta == 1)
@@ -258,62 +277,75 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_nt(BfP p) {
     }
 }
 
+template <bool AKM, bool BKM>
+void launch_s(const BfP& p, dim3 grid, hipStream_t st) {
+    if (p.splits > 1) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false>), grid, dim3(256), 0, st, p);
+}
+
+// images -> C.  a_km / b_km: the operand image is k-major ([k][row]) instead of k-contiguous ([row][k]).
+int run_images(const unsigned short* A, long lda, int a_km, const unsigned short* B, long ldb, int b_km, float* C, long ldc,
+               const float* bias, int M, int N, int K, float alpha, float beta, int act, int flags, hipStream_t st) {
+    BfP p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias;
+    p.M = M; p.N = N; p.nk = cdiv(K, 32); p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.alpha = alpha; p.beta = beta; p.act = act;
+    p.gx = cdiv(N, TB); p.gy = cdiv(M, TB);
+    p.vec_c = (reinterpret_cast<uintptr_t>(C) % 16 == 0 && ldc % 4 == 0) ? 1 : 0;
+    const bool can_split = (flags & FT_GEMM_SPLITK) && act == FT_ACT_NONE && (beta == 0.f || beta == 1.f) && K >= 2048;
+    const long tiles = (long)p.gx * p.gy;
+    long s = 1;
+    if (can_split && tiles < 512) {
+        s = 768 / tiles;
+        const long smax = K / 512;
+        if (s > smax) s = smax;
+        if (s > 64) s = 64;
+        if (s < 1) s = 1;
+    }
+    p.ksteps = cdiv(p.nk, s);
+    p.splits = cdiv(p.nk, p.ksteps);
+    if (p.splits > 1 && beta == 0.f) FT_CHECK_HIP(hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, st));
+    const dim3 grid(p.gx * p.gy, p.splits);
+    if (a_km) { if (b_km) launch_s<true, true>(p, grid, st); else launch_s<true, false>(p, grid, st); }
+    else      { if (b_km) launch_s<false, true>(p, grid, st); else launch_s<false, false>(p, grid, st); }
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+
 bool qualifies(const ft_gemm_args* a) {
     return a->mode == FT_BF16 && a->batch == 1 && a->M >= 32 && a->N >= 32 && a->K >= 16 &&
            (double)a->M * a->N * a->K >= (double)(1 << 20);
+}
+
+// image geometry of one ft_gemm operand: rows index `R` (m or n) with stride sr, reduction stride sk
+struct ImgGeo { int km; int rows, cols; long sr, sc; int Rp, Cp; size_t bytes; };
+ImgGeo geo(long sr, long sk, int R, int K) {
+    ImgGeo g;
+    g.km = (sr == 1 && sk != 1) ? 1 : 0;               // row dim contiguous in the source: keep it k-major, no transpose
+    if (g.km) { g.rows = K; g.cols = R; g.sr = sk; g.sc = 1; g.Rp = (int)up(K, 32); g.Cp = (int)up(R, TB); }
+    else      { g.rows = R; g.cols = K; g.sr = sr; g.sc = sk; g.Rp = (int)up(R, TB); g.Cp = (int)up(K, 32); }
+    g.bytes = up((size_t)g.Rp * g.Cp * 2, 256);
+    return g;
 }
 
 }  // namespace
 
 extern "C" size_t ft_gemm_workspace_bytes(const ft_gemm_args* a) {
     if (!a || !qualifies(a)) return 0;
-    const size_t Mp = up(a->M, TB), Np = up(a->N, TB), Kp = up(a->K, KS);
-    return up(Mp * Kp * 2, 256) + up(Np * Kp * 2, 256);
+    return geo(a->sAm, a->sAk, a->M, a->K).bytes + geo(a->sBn, a->sBk, a->N, a->K).bytes;
 }
 
 // returns 1 when the call was taken by this path, 0 when the caller should use the fp32-staging kernel, < 0 on error
 int ftint_gemm_bf16(const ft_gemm_args* a, hipStream_t st) {
     if (!qualifies(a) || !a->work) return 0;
-    const size_t need = ft_gemm_workspace_bytes(a);
-    if (a->work_bytes < need) return 0;
+    const ImgGeo ga = geo(a->sAm, a->sAk, a->M, a->K), gb = geo(a->sBn, a->sBk, a->N, a->K);
+    if (a->work_bytes < ga.bytes + gb.bytes) return 0;
     if (reinterpret_cast<uintptr_t>(a->work) % 256 != 0) return ft_fail(FT_EINVAL, "ft_gemm: work must be 256-byte aligned");
-    const int Mp = (int)up(a->M, TB), Np = (int)up(a->N, TB), Kp = (int)up(a->K, KS);
     unsigned short* Aimg = reinterpret_cast<unsigned short*>(a->work);
-    unsigned short* Bimg = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(a->work) + up((size_t)Mp * Kp * 2, 256));
-    make_image(a->A, a->sAm, a->sAk, a->M, a->K, Aimg, Mp, Kp, st);
-    make_image(a->B, a->sBn, a->sBk, a->N, a->K, Bimg, Np, Kp, st);
-
-    BfP p;
-    p.A = Aimg; p.B = Bimg; p.C = a->C; p.bias = a->bias;
-    p.M = a->M; p.N = a->N; p.Kp = Kp; p.ldc = a->ldc;
-    p.alpha = a->alpha; p.beta = a->beta; p.act = a->act;
-    p.gx = Np / TB; p.gy = Mp / TB;
-    static const int variant = [] { const char* e = getenv("FT_GEMM_BF16_VARIANT"); return e ? atoi(e) : 0; }();
-    const int kstep = (variant == 0) ? 32 : 64;        // default: 32-wide stages, 4 workgroups/CU (measured 3-15 % faster than 64 / 2)
-    const int nk = Kp / kstep;
-    p.vec_c = (reinterpret_cast<uintptr_t>(a->C) % 16 == 0 && a->ldc % 4 == 0) ? 1 : 0;
-    const bool can_split = (a->flags & FT_GEMM_SPLITK) && a->act == FT_ACT_NONE && (a->beta == 0.f || a->beta == 1.f) && a->K >= 2048;
-    const long tiles = (long)p.gx * p.gy;
-    long s = 1;
-    if (can_split && tiles < 512) {
-        s = 768 / tiles;
-        const long smax = a->K / 512;
-        if (s > smax) s = smax;
-        if (s > 64) s = 64;
-        if (s < 1) s = 1;
-    }
-    p.ksteps = cdiv(nk, s);
-    p.splits = cdiv(nk, p.ksteps);
-    if (p.splits > 1 && a->beta == 0.f)
-        FT_CHECK_HIP(hipMemset2DAsync(a->C, sizeof(float) * a->ldc, 0, sizeof(float) * a->N, a->M, st));
-    const dim3 grid(p.gx * p.gy, p.splits);
-    if (variant == 0) {
-        if (p.splits > 1) hipLaunchKernelGGL((gemm_bf16_nt<32, 4, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_bf16_nt<32, 4, false>), grid, dim3(256), 0, st, p);
-    } else {
-        if (p.splits > 1) hipLaunchKernelGGL((gemm_bf16_nt<64, 2, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_bf16_nt<64, 2, false>), grid, dim3(256), 0, st, p);
-    }
-    FT_CHECK_LAUNCH();
-    return 1;
+    unsigned short* Bimg = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(a->work) + ga.bytes);
+    make_image(a->A, ga.sr, ga.sc, ga.rows, ga.cols, Aimg, ga.Rp, ga.Cp, st);
+    make_image(a->B, gb.sr, gb.sc, gb.rows, gb.cols, Bimg, gb.Rp, gb.Cp, st);
+    const int rc = run_images(Aimg, ga.Cp, ga.km, Bimg, gb.Cp, gb.km, a->C, a->ldc, a->bias, a->M, a->N, a->K, a->alpha, a->beta,
+                              a->act, a->flags, st);
+    return rc < 0 ? rc : 1;
 }
