@@ -31,6 +31,12 @@ class GemmArgs(C.Structure):
                 ("work", _p), ("work_bytes", _sz)]
 
 
+class GemmImgArgs(C.Structure):
+    _fields_ = [("A", _p), ("B", _p), ("C", _p), ("bias", _p), ("M", _i), ("N", _i), ("K", _i),
+                ("lda", _l), ("ldb", _l), ("ldc", _l), ("a_kmajor", _i), ("b_kmajor", _i),
+                ("alpha", _f), ("beta", _f), ("act", _i), ("flags", _i)]
+
+
 class DecodeArgs(C.Structure):
     _fields_ = [(n, _p) for n in (
         "att_w_ih", "att_w_hh", "att_b_ih", "att_b_hh", "w_query", "v", "K", "V",
@@ -48,6 +54,9 @@ SIGNATURES = {
     "ft_last_error": ([], C.c_char_p),
     "ft_gemm": ([C.POINTER(GemmArgs), _p], _i),
     "ft_gemm_workspace_bytes": ([C.POINTER(GemmArgs)], _sz),
+    "ft_bf16_image_bytes": ([_l, _l], _sz),
+    "ft_bf16_image": ([_p, _l, _l, _l, _p, _p], _i),
+    "ft_gemm_img": ([C.POINTER(GemmImgArgs), _p], _i),
     "ft_embedding_fwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
     "ft_embedding_bwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
     "ft_im2col": ([_p, _p, _p, _i, _i, _i, _i, _p], _i),

@@ -349,3 +349,31 @@ int ftint_gemm_bf16(const ft_gemm_args* a, hipStream_t st) {
                               a->act, a->flags, st);
     return rc < 0 ? rc : 1;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// explicit images: the caller converts each fp32 matrix ONCE and feeds it to every GEMM that reads it -- an activation to
+// its forward GEMM and its weight-gradient GEMM, an output gradient to the input-gradient and the weight-gradient GEMM, a
+// weight to forward and backward -- in whichever role (k-contiguous or k-major) that GEMM needs.
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" size_t ft_bf16_image_bytes(int64_t rows, int64_t cols) {
+    if (rows < 1 || cols < 1) return 0;
+    return up(up((size_t)rows + 32, TB) * up((size_t)cols, TB) * 2, 256);
+}
+
+extern "C" int ft_bf16_image(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, void* stream) {
+    FT_CHECK_ARG(src && dst && rows >= 1 && cols >= 1 && ld >= cols && rows < (1ll << 31) - 256 && cols < (1ll << 31) - 256);
+    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);
+    make_image(src, ld, 1, (int)rows, (int)cols, reinterpret_cast<unsigned short*>(dst), (int)up((size_t)rows + 32, TB),
+               (int)up((size_t)cols, TB), reinterpret_cast<hipStream_t>(stream));
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+
+extern "C" int ft_gemm_img(const ft_gemm_img_args* a, void* stream) {
+    FT_CHECK_ARG(a != nullptr);
+    FT_CHECK_ARG(a->A && a->B && a->C && a->M >= 1 && a->N >= 1 && a->K >= 1);
+    FT_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0 && reinterpret_cast<uintptr_t>(a->A) % 16 == 0 && reinterpret_cast<uintptr_t>(a->B) % 16 == 0);
+    return run_images(reinterpret_cast<const unsigned short*>(a->A), a->lda, a->a_kmajor, reinterpret_cast<const unsigned short*>(a->B),
+                      a->ldb, a->b_kmajor, a->C, a->ldc, a->bias, a->M, a->N, a->K, a->alpha, a->beta, a->act, a->flags,
+                      reinterpret_cast<hipStream_t>(stream));
+}

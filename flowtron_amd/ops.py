@@ -48,6 +48,66 @@ def gemm_raw(A, B, Cm, M, N, K, sAm, sAk, sBk, sBn, ldc, bias=None, act=L.ACT_NO
 
 
 # --------------------------------------------------------------------------
+# bf16 operand images (csrc/gemm_bf16.hip): every fp32 matrix that feeds a large bf16-mode GEMM is rounded ONCE and the
+# image serves all its GEMMs -- x: forward + dW, dY: dX + dW, W: forward + dX, LSTM dgates: dW_hh + dW_ih (+ dX) --
+# k-contiguous or k-major as the GEMM needs (k-major fragments come from the LDS transpose-read, so nothing is transposed).
+# --------------------------------------------------------------------------
+class Bf16Image:
+    __slots__ = ("buf", "rows", "cols", "ld")
+
+    def __init__(self, t2d):
+        """t2d: fp32 CUDA matrix [rows, cols], unit column stride."""
+        assert t2d.dim() == 2 and t2d.stride(1) == 1 and t2d.dtype == torch.float32
+        L.require_cuda(t2d)
+        self.rows, self.cols = int(t2d.shape[0]), int(t2d.shape[1])
+        self.ld = (self.cols + 127) // 128 * 128
+        self.buf = torch.empty(L.lib().ft_bf16_image_bytes(self.rows, self.cols), device=t2d.device, dtype=torch.uint8)
+        L.check(L.lib().ft_bf16_image(L.ptr(t2d), int(t2d.stride(0)), self.rows, self.cols, L.ptr(self.buf), L.stream()), "ft_bf16_image")
+
+    def ptr(self, row_off=0, col_off=0):
+        assert col_off % 8 == 0
+        return self.buf.data_ptr() + 2 * (row_off * self.ld + col_off)
+
+
+def images_apply(mode, M, N, K):
+    """same rule as ft_gemm_workspace_bytes: bf16 mode and a GEMM large enough to amortise the image passes."""
+    return _BF16_IMAGES and mode == L.FT_BF16 and M >= 32 and N >= 32 and K >= 16 and M * N * K >= (1 << 20)
+
+
+def gemm_img(A, a_km, a_ptr, B, b_km, b_ptr, Cm, M, N, K, ldc, bias=None, act=L.ACT_NONE, alpha=1.0, beta=0.0, splitk=False):
+    """C[M,N] = act(alpha * A.B + beta*C + bias) from images.  a_ptr / b_ptr: A.ptr(...) / B.ptr(...) (may point inside)."""
+    L.require_cuda(Cm, bias)
+    a = L.GemmImgArgs(a_ptr, b_ptr, L.ptr(Cm), L.ptr(bias), M, N, K, A.ld, B.ld, ldc, int(a_km), int(b_km),
+                      alpha, beta, act, L.GEMM_SPLITK if splitk else 0)
+    L.check(L.lib().ft_gemm_img(C.byref(a), L.stream()), "ft_gemm_img")
+
+
+# hand-off of an output-gradient image between two autograd nodes of the SAME backward pass (the LSTM backward builds the
+# image of dgates for its own dW_hh GEMM; the input projection's LinearFn.backward receives that very tensor as dy).
+# Keyed by (data_ptr, shape); cleared by an engine callback at the end of the pass, so an address can never match stale data.
+_HANDOFF = {"imgs": {}, "armed": False}
+
+
+def _handoff_clear():
+    _HANDOFF["imgs"].clear()
+    _HANDOFF["armed"] = False
+
+
+def _handoff_put(t, img):
+    if not _HANDOFF["armed"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_handoff_clear)
+        except RuntimeError:            # not inside a backward pass: no consumer can follow
+            return
+        _HANDOFF["armed"] = True
+    _HANDOFF["imgs"][(t.data_ptr(), tuple(t.shape))] = img
+
+
+def _handoff_take(t):
+    return _HANDOFF["imgs"].pop((t.data_ptr(), tuple(t.shape)), None)
+
+
+# --------------------------------------------------------------------------
 # weight-gradient GEMMs on a side stream
 # --------------------------------------------------------------------------
 # dW = dpre^T x is needed only by the optimizer, never by the rest of the backward pass, while the backward critical path
@@ -121,13 +181,23 @@ class LinearFn(torch.autograd.Function):
         N, Ktot = W.shape
         rows = xs[0].numel() // xs[0].shape[-1]
         y = torch.empty(xs[0].shape[:-1] + (N,), device=W.device, dtype=torch.float32)
+        use_img = all(images_apply(mode, rows, N, x.shape[-1]) for x in xs) and all((x.shape[-1] % 8 == 0) for x in xs[:-1])
+        ctx.imgs = None
+        if use_img:
+            w_img = Bf16Image(W)
+            x_imgs = [Bf16Image(x.reshape(rows, x.shape[-1])) for x in xs]
+            ctx.imgs = (w_img, x_imgs)          # reused by backward (dX reads W k-major, dW reads x k-major)
         off = 0
         for i, x in enumerate(xs):
             K = x.shape[-1]
             last = i == len(xs) - 1
-            gemm_raw(x, W[:, off:], y, rows, N, K, K, 1, 1, Ktot, N,
-                     bias=bias if last else None, act=act if last else L.ACT_NONE,
-                     beta=0.0 if i == 0 else 1.0, mode=mode)
+            if use_img:
+                gemm_img(x_imgs[i], 0, x_imgs[i].ptr(), w_img, 0, w_img.ptr(0, off), y, rows, N, K, N,
+                         bias=bias if last else None, act=act if last else L.ACT_NONE, beta=0.0 if i == 0 else 1.0)
+            else:
+                gemm_raw(x, W[:, off:], y, rows, N, K, K, 1, 1, Ktot, N,
+                         bias=bias if last else None, act=act if last else L.ACT_NONE,
+                         beta=0.0 if i == 0 else 1.0, mode=mode)
             off += K
         assert off == Ktot
         ctx.save_for_backward(W, y if act != L.ACT_NONE else None, *xs)
@@ -151,22 +221,35 @@ class LinearFn(torch.autograd.Function):
         db = colsum(dpre, rows, N, N) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
         dxs = []
         off = 0
+        imgs = ctx.imgs if (ctx.imgs is not None and gW is None) else None
+        if imgs is not None:
+            w_img, x_imgs = imgs
+            d_img = _handoff_take(dpre) if ctx.act == L.ACT_NONE else None      # e.g. the LSTM backward already made it
+            if d_img is None:
+                d_img = Bf16Image(dpre.reshape(rows, N))
         for i, x in enumerate(xs):
             K = x.shape[-1]
             if ctx.needs_input_grad[4 + i]:
                 dx = torch.empty_like(x)
                 # dx[r,k] = sum_n dpre[r,n] W[n, off+k]
-                gemm_raw(dpre, W[:, off:], dx, rows, K, N, N, 1, Ktot, 1, K, mode=ctx.mode)
+                if imgs is not None:
+                    gemm_img(d_img, 0, d_img.ptr(), w_img, 1, w_img.ptr(0, off), dx, rows, K, N, K)
+                else:
+                    gemm_raw(dpre, W[:, off:], dx, rows, K, N, N, 1, Ktot, 1, K, mode=ctx.mode)
                 dxs.append(dx)
             else:
                 dxs.append(None)
             if dW is not None:
                 # dW[n, off+k] = sum_r dpre[r,n] x[r,k]
-                gemm_raw(dpre, x, dW[:, off:], N, K, rows, 1, N, K, 1, Ktot, mode=ctx.mode, splitk=True)
+                if imgs is not None:
+                    gemm_img(d_img, 1, d_img.ptr(), x_imgs[i], 1, x_imgs[i].ptr(), dW[:, off:], N, K, rows, Ktot, splitk=True)
+                else:
+                    gemm_raw(dpre, x, dW[:, off:], N, K, rows, 1, N, K, 1, Ktot, mode=ctx.mode, splitk=True)
             elif gW is not None:
                 _on_side(dpre.device, lambda x=x, off=off, K=K: gemm_raw(dpre, x, gW[:, off:], N, K, rows, 1, N, K, 1, Ktot,
                                                                         beta=1.0, mode=ctx.mode, splitk=True), dpre, x)
             off += K
+        ctx.imgs = None
         return (dW, db, None, None, *dxs)
 
 
@@ -312,7 +395,13 @@ class LSTMSeqFn(torch.autograd.Function):
                                                          splitk=True), dgx, y)
             else:
                 dW = torch.zeros_like(w_hh)
-                if T > 1:
+                if T > 1 and images_apply(ctx.mode, 4 * H, H, rows):
+                    # images of dgates / outputs over all T*B rows; the one-step shift is a row offset into them
+                    d_img, y_img = Bf16Image(dgx.reshape(T * B, 4 * H)), Bf16Image(y.reshape(T * B, H))
+                    fwd = not ctx.reverse
+                    gemm_img(d_img, 1, d_img.ptr(B if fwd else 0), y_img, 1, y_img.ptr(0 if fwd else B), dW, 4 * H, H, rows, H, splitk=True)
+                    _handoff_put(dgx, d_img)        # the input projection's backward reads the same dgates
+                elif T > 1:
                     gemm_raw(da, hp, dW, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=ctx.mode, splitk=True)
         return dgx, dW, None, None, None
 
@@ -793,11 +882,21 @@ class LSTM2SeqFn(torch.autograd.Function):
         dW_hh0 = torch.zeros_like(w_hh0)
         dW_hh1 = torch.zeros_like(w_hh1)
         dW_ih1 = torch.empty_like(w_ih1)
-        if T > 1:
-            r1 = (T - 1) * B
-            gemm_raw(dgx0[1:], y0[:-1], dW_hh0, 4 * H, H, r1, 1, 4 * H, H, 1, H, mode=mode, splitk=True)
-            gemm_raw(dgx1[1:], y1[:-1], dW_hh1, 4 * H, H, r1, 1, 4 * H, H, 1, H, mode=mode, splitk=True)
-        gemm_raw(dgx1, y0, dW_ih1, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=mode, splitk=True)
+        r1 = (T - 1) * B
+        if T > 1 and images_apply(mode, 4 * H, H, r1):
+            # four images serve the three weight-gradient GEMMs (the one-step shift is a row offset) and, through the
+            # hand-off, the dX / dW GEMMs of the layer-0 input projection
+            d0, d1 = Bf16Image(dgx0.reshape(rows, 4 * H)), Bf16Image(dgx1.reshape(rows, 4 * H))
+            i0, i1 = Bf16Image(y0.reshape(rows, H)), Bf16Image(y1.reshape(rows, H))
+            gemm_img(d0, 1, d0.ptr(B), i0, 1, i0.ptr(), dW_hh0, 4 * H, H, r1, H, splitk=True)
+            gemm_img(d1, 1, d1.ptr(B), i1, 1, i1.ptr(), dW_hh1, 4 * H, H, r1, H, splitk=True)
+            gemm_img(d1, 1, d1.ptr(), i0, 1, i0.ptr(), dW_ih1, 4 * H, H, rows, H, splitk=True)
+            _handoff_put(dgx0, d0)
+        else:
+            if T > 1:
+                gemm_raw(dgx0[1:], y0[:-1], dW_hh0, 4 * H, H, r1, 1, 4 * H, H, 1, H, mode=mode, splitk=True)
+                gemm_raw(dgx1[1:], y1[:-1], dW_hh1, 4 * H, H, r1, 1, 4 * H, H, 1, H, mode=mode, splitk=True)
+            gemm_raw(dgx1, y0, dW_ih1, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=mode, splitk=True)
         db1 = colsum(dgx1, rows, 4 * H, 4 * H)
         return dgx0, dW_hh0, dW_ih1, db1, db1, dW_hh1, None
 

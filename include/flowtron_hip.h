@@ -69,6 +69,27 @@ typedef struct {
 size_t ft_gemm_workspace_bytes(const ft_gemm_args* a);
 int ft_gemm(const ft_gemm_args* a, void* stream);
 
+/* bf16 operand images (FT_BF16 training path): a row-major fp32 matrix [rows][cols] (row stride ld) is rounded ONCE to a
+ * zero-padded bf16 image [ceil128(rows + 32)][ceil128(cols)] (ft_bf16_image_bytes bytes, 256-byte aligned) and then feeds
+ * every GEMM that reads it, in either role:
+ *   k-contiguous operand (a_kmajor / b_kmajor = 0): image rows are the operand's m (or n) index, columns the reduction;
+ *   k-major operand (= 1): image rows are the reduction index, columns the m (or n) index -- read through the LDS
+ *   transpose-read, so the weight-gradient GEMMs dW = dY^T X (both operands k-major) need no transposed copies.
+ * A / B may point INSIDE an image (row offset * ld for a time shift, column offset % 8 == 0 for a column block of a
+ * weight); whatever lies beyond the logical extent must be finite and is multiplied by the partner's zero padding (k) or
+ * dropped by the epilogue (m, n).  lda / ldb = image row stride in elements = ceil128(cols).  Epilogue as ft_gemm. */
+typedef struct {
+    const void* A; const void* B; float* C; const float* bias;
+    int M, N, K;
+    int64_t lda, ldb, ldc;
+    int a_kmajor, b_kmajor;
+    float alpha, beta;
+    int act, flags;
+} ft_gemm_img_args;
+size_t ft_bf16_image_bytes(int64_t rows, int64_t cols);
+int ft_bf16_image(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, void* stream);
+int ft_gemm_img(const ft_gemm_img_args* a, void* stream);
+
 /* ---- embedding gather (flowtron.py:873-874) ------------------------------
  * out[r][0:dim] = W[ids[r]] for r < n (out row stride ld_out).  bwd: dW[ids[r]] += dout[r]. */
 int ft_embedding_fwd(const int64_t* ids, const float* W, float* out, int n, int dim, int64_t ld_out, void* stream);
