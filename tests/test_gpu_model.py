@@ -439,3 +439,47 @@ def test_ctc_prefetch_on_side_stream_matches_loss_time_evaluation(monkeypatch):
     for k in res[0][1]:
         a, r = res[0][1][k], res[1][1][k]
         assert (a - r).norm().item() <= 1e-5 * max(r.norm().item(), 1e-6), k
+
+
+def test_bf16_mode_gradients_track_fp32_full_width():
+    """Every gradient of the full-width model (H = 1024) in bf16 mode -- two-layer wavefront chain, shared bf16 operand
+    images with the dgates hand-off, k-major transpose-read GEMMs, bidirectional pair chain -- against (a) the same model on
+    the plain bf16 paths (fp32-staging GEMM, one chain per layer and direction) and (b) the fp32-MFMA run.  A wrong row
+    offset / layout flag / stale image shows up as an O(1) error; bf16 operand rounding as ~1e-2.  The encoder conv stack
+    is excluded from (b): its gradients pass three masked instance norms and differ by 0.2-0.4 between bf16 and fp32
+    operands on EVERY bf16 path (scripts/exp/bf16_grad_diag.py) -- conditioning, not a kernel property."""
+    import flowtron
+    from flowtron_amd import ops
+    from oracle import synth
+    cfg = dict(synth.DEFAULT_MODEL_CONFIG, n_text=60)
+    b = cuda_batch(synth.make_batch(cfg, [48, 41, 17, 48], [14, 12, 12, 5], seed=6, with_prior=True))
+    res = {}
+    try:
+        for name, mode, new_paths in (("f32", "f32", True), ("bf16", "bf16", True), ("bf16_plain", "bf16", False)):
+            ops._BF16_IMAGES = new_paths
+            os.environ.update(FLOWTRON_LSTM2="1" if new_paths else "0", FLOWTRON_BILSTM="1" if new_paths else "0")
+            m, _ = build(cfg, 6, mode)
+            crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)
+            out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+            nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+            (nll + gl + 0.01 * ctc).sum().backward()
+            torch.cuda.synchronize()
+            res[name] = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+    finally:
+        ops._BF16_IMAGES = True
+        os.environ.update(FLOWTRON_MFMA="f32", FLOWTRON_LSTM2="1", FLOWTRON_BILSTM="1")
+
+    def worst(a, r, skip=()):
+        w = ("", 0.0)
+        for k in r:
+            if any(k.startswith(p_) for p_ in skip):
+                continue
+            e = (a[k] - r[k]).norm().item() / max(r[k].norm().item(), 1e-4 * r[k].numel() ** 0.5)
+            if e > w[1]:
+                w = (k, e)
+        return w
+
+    w1 = worst(res["bf16"], res["bf16_plain"])
+    assert w1[1] < 2e-2, w1
+    w2 = worst(res["bf16"], res["f32"], skip=("encoder.convolutions", "embedding."))
+    assert w2[1] < 6e-2, w2
