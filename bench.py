@@ -125,6 +125,47 @@ def lstm_step_roofline(B, H, T, mode):
             "bytes_per_launch": bytes_per_launch}
 
 
+def lstm2_step_roofline(B, H, T):
+    """Live timing of THE dominant kernel of the step (lstm2_fwd_step, flowtron_amd/csrc/lstm2.hip: ~21 % of the step):
+    T+1 launches of the two-layer wavefront chain bracketed by HIP events on the launch stream.  Algorithmic bytes per
+    launch (steady state, DESIGN.md kernel table): bf16 fragment images of W_hh0 and [W_ih1|W_hh1] (4H*H*2 + 4H*2H*2),
+    bf16 images of h0[s-1] and h1[s-2] in, gx0 row + bias1 in (fp32), cell state of both layers in+out (fp32), and per layer
+    y, saved gates, saved cell (fp32) + the bf16 image of h out."""
+    from flowtron_amd import _lib as L
+    dev = "cuda"
+    f = dict(device=dev, dtype=torch.float32)
+    gx = torch.randn(T, B, 4 * H, **f) * 0.1
+    w0, wi1, w1 = (torch.randn(4 * H, H, **f) / H ** 0.5 for _ in range(3))
+    b1 = torch.zeros(4 * H, **f)
+    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+    y0, y1 = torch.empty(T, B, H, **f), torch.empty(T, B, H, **f)
+    g0, g1 = torch.empty(T, B, 4 * H, **f), torch.empty(T, B, 4 * H, **f)
+    c0, c1 = torch.empty(T, B, H, **f), torch.empty(T, B, H, **f)
+    work = torch.empty(L.lib().ft_lstm2_workspace_bytes(B, H), device=dev, dtype=torch.uint8)
+
+    def run():
+        L.check(L.lib().ft_lstm2_seq_fwd(L.ptr(gx), L.ptr(w0), L.ptr(wi1), L.ptr(b1), L.ptr(w1), L.ptr(lens), L.ptr(y0), L.ptr(g0),
+                                         L.ptr(c0), L.ptr(y1), L.ptr(g1), L.ptr(c1), L.ptr(work), T, B, H, L.stream()), "ft_lstm2_seq_fwd")
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (T + 1)
+    bp = (B + 15) // 16 * 16
+    bytes_per_launch = (2 * (4 * H * H + 4 * H * 2 * H)            # weight images
+                        + 2 * 2 * bp * H                           # h0[s-1], h1[s-2] images in
+                        + 4 * (B * 4 * H + 4 * H)                  # gx0 row, bias1
+                        + 2 * 2 * 4 * B * H                        # cell state of both layers in + out
+                        + 2 * (4 * (B * H + B * 4 * H + B * H) + 2 * bp * H))   # per layer: y, gates, cell out + h image out
+    achieved = bytes_per_launch / (us * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": "lstm2_fwd_step", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic("lstm2_fwd_step"), "us_per_launch": round(us, 3),
+            "bytes_per_launch": bytes_per_launch}
+
+
 def pmc_traffic(kernel_substr):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE and
     WRITE_SIZE runs of scripts/exp/lstm_only.py, profiles/r01_pmc_lstm_*.json), with the gfx950 correction of
@@ -312,7 +353,15 @@ def main():
         mode = L.FT_BF16 if args.mfma == "bf16" else L.FT_F32
         log("roofline kernel timing ...")
         try:
-            res["roofline"] = lstm_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, mode)
+            single = lstm_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, mode)
+            from flowtron_amd import ops as _ops
+            if _ops.lstm2_supported(args.batch, MODEL_CONFIG["n_hidden"], mode):
+                # dominant kernel of the step: the two-layer wavefront launch; the single-layer step kernel (attention LSTM,
+                # second by time) is reported beside it
+                res["roofline"] = lstm2_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T)
+                res["roofline_second_kernel"] = single
+            else:
+                res["roofline"] = single
         except Exception as e:                      # never lose the headline number to the side measurement
             res["roofline"] = {"error": repr(e)}
         if world == 1 and not args.no_infer:
