@@ -13,6 +13,7 @@
 //              dK (workgroup per (b, 16 l)) kernels that recompute tanh with lane <-> a, so
 //              every gradient element is owned by exactly one thread (no atomics on dQ/dK).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -26,6 +27,11 @@ __device__ __forceinline__ float tanh_fast(float x) {
     const float e = __expf(2.0f * x);
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
+// The hot loops use the same identity with the argument scale folded into the operands once: with q' = C2*q, k' = C2*k
+// (C2 = 2*log2(e)),  r = 1 / (2^(q'+k') + 1),  tanh = 1 - 2r,  1 - tanh^2 = 4 r (1 - r): one add, v_exp_f32, one add,
+// v_rcp_f32 per element, and sum_a v[a]*tanh = sum_a v[a] - 2 sum_a v[a]*r keeps a single FMA in the forward loop.
+constexpr float C2 = 2.8853900817779268f;
+__device__ __forceinline__ float rsig(float x) { return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x) + 1.0f); }
 
 template <bool HAS_PRIOR>
 __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ Q, const float* __restrict__ K,
@@ -54,6 +60,7 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ Q, c
         bool jact[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) jact[j] = (lt * LT + j * 32) < len;
+        float vsum = 0.f;
 
         for (int a0 = 0; a0 < A; a0 += AC) {
             __syncthreads();
@@ -62,20 +69,21 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ Q, c
                 const int idx = tid + 256 * r;
                 const int row = idx >> 6, col = idx & 63;
                 const int t = t0 + row, a = a0 + col;
-                qs[row * LDA + col] = (t < T && a < A) ? Q[((long)t * B + b) * A + a] : 0.f;
+                qs[row * LDA + col] = (t < T && a < A) ? C2 * Q[((long)t * B + b) * A + a] : 0.f;
             }
 #pragma unroll 4
             for (int r = 0; r < (LT * AC) / 256; ++r) {
                 const int idx = tid + 256 * r;
                 const int row = idx >> 6, col = idx & 63;
                 const int l = lt * LT + row, a = a0 + col;
-                ks[row * LDA + col] = (l < len && a < A) ? K[((long)l * B + b) * A + a] : 0.f;
+                ks[row * LDA + col] = (l < len && a < A) ? C2 * K[((long)l * B + b) * A + a] : 0.f;
             }
             if (tid < AC) vs[tid] = (a0 + tid < A) ? v[a0 + tid] : 0.f;
             __syncthreads();
 #pragma unroll 2
             for (int a4 = 0; a4 < AC / 4; ++a4) {
                 const float4 vv = *reinterpret_cast<const float4*>(vs + a4 * 4);
+                vsum += (vv.x + vv.y) + (vv.z + vv.w);
                 float4 q[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const float4*>(qs + (tg * 4 + i) * LDA + a4 * 4);
@@ -85,8 +93,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ Q, c
                         const float4 kk = *reinterpret_cast<const float4*>(ks + (j * 32 + tl) * LDA + a4 * 4);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            acc[i][j] += vv.x * tanh_fast(q[i].x + kk.x) + vv.y * tanh_fast(q[i].y + kk.y) +
-                                         vv.z * tanh_fast(q[i].z + kk.z) + vv.w * tanh_fast(q[i].w + kk.w);
+                            acc[i][j] += vv.x * rsig(q[i].x + kk.x) + vv.y * rsig(q[i].y + kk.y) +
+                                         vv.z * rsig(q[i].z + kk.z) + vv.w * rsig(q[i].w + kk.w);
                         }
                     }
                 }
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ Q, c
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (jact[j]) es[(tg * 4 + i) * LP + lt * LT + j * 32 + tl] = acc[i][j] * inv_temp;
+                if (jact[j]) es[(tg * 4 + i) * LP + lt * LT + j * 32 + tl] = (vsum - 2.f * acc[i][j]) * inv_temp;
     }
     __syncthreads();
 
@@ -347,6 +355,72 @@ __global__ __launch_bounds__(256) void attn_dk_k(const float* __restrict__ Q, co
     }
 }
 
+// dQ, dK and dv from ONE evaluation of the tanh tensor.  grid = (ceil(T/32), B, ceil(A/256)); lane <-> a (one 64-wide
+// a-chunk per wave), every thread keeps 32 query rows in registers and walks the keys:
+//   g[t,l,a] = de[b,t,l] * r(1-r),  dQ[t,a] = 4 v[a] sum_l g   (owned by one thread: plain store),
+//   dK[l,a] += 4 v[a] sum_{t in tile} g   (one fp32 atomic per (l, a) per 32-row tile; dK must be zeroed),
+//   dv[a]  += sum_{t,l} de * tanh.
+__global__ __launch_bounds__(256) void attn_dqdk_k(const float* __restrict__ Q, const float* __restrict__ K,
+                                                   const float* __restrict__ v, const int* __restrict__ in_lens,
+                                                   const float* __restrict__ de, float* __restrict__ dQ, float* __restrict__ dK,
+                                                   float* __restrict__ dv, int T, int B, int L, int A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* de_s = smem;                 // [len][32]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.y, t0 = blockIdx.x * 32;
+    const int len = min(in_lens[b], L);
+    for (int idx = tid; idx < len * 32; idx += 256) {
+        const int r = idx & 31, l = idx >> 5;
+        de_s[idx] = (t0 + r < T) ? de[((long)b * T + t0 + r) * L + l] : 0.f;
+    }
+    __syncthreads();
+    const int aw = blockIdx.z * 256 + w * 64;
+    if (aw >= A) return;                // wave-uniform
+    const int a = aw + lane;
+    const bool av = a < A;
+    const int ac = av ? a : A - 1;      // clamp: keeps the loads unconditional, results of idle lanes are dropped
+    float q[32], dq[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int t = min(t0 + i, T - 1);
+        q[i] = C2 * Q[((long)t * B + b) * A + ac];
+        dq[i] = 0.f;
+    }
+    float dva = 0.f;
+    const float* kp = K + (long)b * A + ac;
+    const long ks = (long)B * A;
+    const float va4 = 4.f * v[ac];
+    float kv_next = (len > 0) ? C2 * kp[0] : 0.f;
+    for (int l = 0; l < len; ++l) {
+        const float kv = kv_next;
+        if (l + 1 < len) kv_next = C2 * kp[(long)(l + 1) * ks];
+        float dkp = 0.f;
+#pragma unroll
+        for (int i4 = 0; i4 < 8; ++i4) {
+            const float4 d4 = *reinterpret_cast<const float4*>(de_s + l * 32 + i4 * 4);     // same address in every lane: broadcast
+            const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i4 * 4 + j;
+                const float r = rsig(q[i] + kv);
+                const float u = fmaf(-r, r, r);              // r (1 - r) = (1 - tanh^2) / 4
+                dq[i] = fmaf(d[j], u, dq[i]);
+                dkp = fmaf(d[j], u, dkp);
+                dva = fmaf(d[j], fmaf(-2.f, r, 1.f), dva);
+            }
+        }
+        if (av) atomicAdd(dK + ((long)l * B + b) * A + a, dkp * va4);
+    }
+    if (av) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int t = t0 + i;
+            if (t < T) dQ[((long)t * B + b) * A + a] = dq[i] * va4;
+        }
+        atomicAdd(dv + a, dva);
+    }
+}
+
 constexpr int MAX_LDS = 160 * 1024;
 
 }  // namespace
@@ -396,6 +470,15 @@ extern "C" int ft_attention_bwd(const float* Q, const float* K, const float* v, 
         hipLaunchKernelGGL(attn_softmax_bwd_k<true>, dim3(rows_grid), dim3(256), 0, st, attn, p_save, dattn, dlogprob, in_lens, de_work, T, B, L, inv_temp);
     else
         hipLaunchKernelGGL(attn_softmax_bwd_k<false>, dim3(rows_grid), dim3(256), 0, st, attn, p_save, dattn, dlogprob, in_lens, de_work, T, B, L, inv_temp);
+    static const bool split_kernels = [] { const char* e = getenv("FT_ATTN_BWD_SPLIT"); return e && e[0] == '1'; }();
+    if (!split_kernels) {                                   // one tanh pass for dQ, dK and dv
+        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dqdk_k), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+        FT_CHECK_HIP(hipMemsetAsync(dK, 0, sizeof(float) * (size_t)L * B * A, st));
+        hipLaunchKernelGGL(attn_dqdk_k, dim3(cdiv(T, 32), B, cdiv(A, 256)), dim3(256), sizeof(float) * (size_t)L * 32, st,
+                           Q, K, v, in_lens, de_work, dQ, dK, dv, T, B, L, A);
+        FT_CHECK_LAUNCH();
+        return FT_OK;
+    }
     FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dq_k), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
     FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dk_k), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
     hipLaunchKernelGGL(attn_dq_k, dim3(cdiv(T, 32), B), dim3(256), lds_q, st, Q, K, v, in_lens, de_work, dQ, dv, T, B, L, A);
