@@ -56,6 +56,7 @@ SIGNATURES = {
     "ft_gemm_workspace_bytes": ([C.POINTER(GemmArgs)], _sz),
     "ft_bf16_image_bytes": ([_l, _l], _sz),
     "ft_bf16_image": ([_p, _l, _l, _l, _p, _p], _i),
+    "ft_bf16_image_colsum": ([_p, _l, _l, _l, _p, _p, _p], _i),
     "ft_gemm_img": ([C.POINTER(GemmImgArgs), _p], _i),
     "ft_embedding_fwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
     "ft_embedding_bwd": ([_p, _p, _p, _i, _i, _l, _p], _i),

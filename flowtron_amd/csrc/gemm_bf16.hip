@@ -57,6 +57,49 @@ __global__ __launch_bounds__(256) void img_rows_k(const float* __restrict__ src,
     }
 }
 
+// same image, plus the fp32 column sums of the SOURCE (bias gradients: the conversion pass reads the output gradient
+// anyway, so ft_colsum's second sweep over it disappears).  Block = 32 column groups x 8 row lanes over a 256-row slab;
+// grid (Cp/256, Rp/256); colsum [Cc] must be zero on entry, slabs combine with fp32 atomics (as ft_colsum does).
+__global__ __launch_bounds__(256) void img_rows_sum_k(const float* __restrict__ src, long sr, int R, int Cc,
+                                                      unsigned short* __restrict__ dst, int Rp, int Cp, int vec,
+                                                      float* __restrict__ colsum) {
+    __shared__ float red[8][32][9];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = (blockIdx.x * 32 + tx) * 8;
+    const int r0 = blockIdx.y * 256;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < Cp) {
+#pragma unroll 4
+        for (int k = 0; k < 32; ++k) {
+            const int r = r0 + ty + 8 * k;
+            if (r >= Rp) break;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (r < R && c < Cc) {
+                const float* p = src + (size_t)r * sr + c;
+                if (vec && c + 7 < Cc) {
+                    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (c + e < Cc) v[e] = p[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            *reinterpret_cast<uint4*>(dst + (size_t)r * Cp + c) = pack8(v);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ty][tx][e] = acc[e];
+    __syncthreads();
+    const int cx = threadIdx.x >> 3, e = threadIdx.x & 7;          // 32 column groups x 8 elements = 256 columns
+    float s8 = 0.f;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) s8 += red[y][cx][e];
+    const int col = (blockIdx.x * 32 + cx) * 8 + e;
+    if (col < Cc) atomicAdd(colsum + col, s8);
+}
+
 void make_image(const float* src, long sr, long sc, int R, int Cc, unsigned short* dst, int Rp, int Cp, hipStream_t st) {
     const bool vec = sc == 1 && reinterpret_cast<uintptr_t>(src) % 16 == 0 && sr % 4 == 0;
     const size_t chunks = (size_t)Rp * (Cp >> 3);
@@ -365,6 +408,19 @@ extern "C" int ft_bf16_image(const float* src, int64_t ld, int64_t rows, int64_t
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);
     make_image(src, ld, 1, (int)rows, (int)cols, reinterpret_cast<unsigned short*>(dst), (int)up((size_t)rows + 32, TB),
                (int)up((size_t)cols, TB), reinterpret_cast<hipStream_t>(stream));
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+
+extern "C" int ft_bf16_image_colsum(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, float* colsum, void* stream) {
+    FT_CHECK_ARG(src && dst && colsum && rows >= 1 && cols >= 1 && ld >= cols && rows < (1ll << 31) - 256 && cols < (1ll << 31) - 256);
+    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int Rp = (int)up((size_t)rows + 32, TB), Cp = (int)up((size_t)cols, TB);
+    const int vec = (reinterpret_cast<uintptr_t>(src) % 16 == 0 && ld % 4 == 0) ? 1 : 0;
+    FT_CHECK_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)cols, st));
+    hipLaunchKernelGGL(img_rows_sum_k, dim3(cdiv(Cp, 256), cdiv(Rp, 256)), dim3(256), 0, st, src, (long)ld, (int)rows, (int)cols,
+                       reinterpret_cast<unsigned short*>(dst), Rp, Cp, vec, colsum);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

@@ -53,16 +53,23 @@ def gemm_raw(A, B, Cm, M, N, K, sAm, sAk, sBk, sBn, ldc, bias=None, act=L.ACT_NO
 # k-contiguous or k-major as the GEMM needs (k-major fragments come from the LDS transpose-read, so nothing is transposed).
 # --------------------------------------------------------------------------
 class Bf16Image:
-    __slots__ = ("buf", "rows", "cols", "ld")
+    __slots__ = ("buf", "rows", "cols", "ld", "colsum")
 
-    def __init__(self, t2d):
-        """t2d: fp32 CUDA matrix [rows, cols], unit column stride."""
+    def __init__(self, t2d, colsum=False):
+        """t2d: fp32 CUDA matrix [rows, cols], unit column stride.  colsum=True also returns the fp32 column sums of t2d
+        (self.colsum) from the same pass -- the bias gradient when t2d is an output gradient."""
         assert t2d.dim() == 2 and t2d.stride(1) == 1 and t2d.dtype == torch.float32
         L.require_cuda(t2d)
         self.rows, self.cols = int(t2d.shape[0]), int(t2d.shape[1])
         self.ld = (self.cols + 127) // 128 * 128
         self.buf = torch.empty(L.lib().ft_bf16_image_bytes(self.rows, self.cols), device=t2d.device, dtype=torch.uint8)
-        L.check(L.lib().ft_bf16_image(L.ptr(t2d), int(t2d.stride(0)), self.rows, self.cols, L.ptr(self.buf), L.stream()), "ft_bf16_image")
+        self.colsum = None
+        if colsum:
+            self.colsum = torch.empty(self.cols, device=t2d.device, dtype=torch.float32)
+            L.check(L.lib().ft_bf16_image_colsum(L.ptr(t2d), int(t2d.stride(0)), self.rows, self.cols, L.ptr(self.buf), L.ptr(self.colsum),
+                                                 L.stream()), "ft_bf16_image_colsum")
+        else:
+            L.check(L.lib().ft_bf16_image(L.ptr(t2d), int(t2d.stride(0)), self.rows, self.cols, L.ptr(self.buf), L.stream()), "ft_bf16_image")
 
     def ptr(self, row_off=0, col_off=0):
         assert col_off % 8 == 0
@@ -218,7 +225,8 @@ class LinearFn(torch.autograd.Function):
             dpre = dy
         gW = _side_dw_target(ctx.W_leaf) if (ctx.needs_input_grad[0] and ctx.W_leaf is not None) else None
         dW = torch.empty_like(W) if (ctx.needs_input_grad[0] and gW is None) else None
-        db = colsum(dpre, rows, N, N) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        want_db = ctx.has_bias and ctx.needs_input_grad[1]
+        db = None
         dxs = []
         off = 0
         imgs = ctx.imgs if (ctx.imgs is not None and gW is None) else None
@@ -226,7 +234,10 @@ class LinearFn(torch.autograd.Function):
             w_img, x_imgs = imgs
             d_img = _handoff_take(dpre) if ctx.act == L.ACT_NONE else None      # e.g. the LSTM backward already made it
             if d_img is None:
-                d_img = Bf16Image(dpre.reshape(rows, N))
+                d_img = Bf16Image(dpre.reshape(rows, N), colsum=want_db)          # bias gradient rides on the conversion pass
+            db = d_img.colsum
+        if want_db and db is None:
+            db = colsum(dpre, rows, N, N)
         for i, x in enumerate(xs):
             K = x.shape[-1]
             if ctx.needs_input_grad[4 + i]:
@@ -397,7 +408,7 @@ class LSTMSeqFn(torch.autograd.Function):
                 dW = torch.zeros_like(w_hh)
                 if T > 1 and images_apply(ctx.mode, 4 * H, H, rows):
                     # images of dgates / outputs over all T*B rows; the one-step shift is a row offset into them
-                    d_img, y_img = Bf16Image(dgx.reshape(T * B, 4 * H)), Bf16Image(y.reshape(T * B, H))
+                    d_img, y_img = Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True), Bf16Image(y.reshape(T * B, H))
                     fwd = not ctx.reverse
                     gemm_img(d_img, 1, d_img.ptr(B if fwd else 0), y_img, 1, y_img.ptr(0 if fwd else B), dW, 4 * H, H, rows, H, splitk=True)
                     _handoff_put(dgx, d_img)        # the input projection's backward reads the same dgates
@@ -883,21 +894,24 @@ class LSTM2SeqFn(torch.autograd.Function):
         dW_hh1 = torch.zeros_like(w_hh1)
         dW_ih1 = torch.empty_like(w_ih1)
         r1 = (T - 1) * B
+        db1 = None
         if T > 1 and images_apply(mode, 4 * H, H, r1):
             # four images serve the three weight-gradient GEMMs (the one-step shift is a row offset) and, through the
             # hand-off, the dX / dW GEMMs of the layer-0 input projection
-            d0, d1 = Bf16Image(dgx0.reshape(rows, 4 * H)), Bf16Image(dgx1.reshape(rows, 4 * H))
+            d0, d1 = Bf16Image(dgx0.reshape(rows, 4 * H), colsum=True), Bf16Image(dgx1.reshape(rows, 4 * H), colsum=True)
             i0, i1 = Bf16Image(y0.reshape(rows, H)), Bf16Image(y1.reshape(rows, H))
             gemm_img(d0, 1, d0.ptr(B), i0, 1, i0.ptr(), dW_hh0, 4 * H, H, r1, H, splitk=True)
             gemm_img(d1, 1, d1.ptr(B), i1, 1, i1.ptr(), dW_hh1, 4 * H, H, r1, H, splitk=True)
             gemm_img(d1, 1, d1.ptr(), i0, 1, i0.ptr(), dW_ih1, 4 * H, H, rows, H, splitk=True)
             _handoff_put(dgx0, d0)
+            db1 = d1.colsum
         else:
             if T > 1:
                 gemm_raw(dgx0[1:], y0[:-1], dW_hh0, 4 * H, H, r1, 1, 4 * H, H, 1, H, mode=mode, splitk=True)
                 gemm_raw(dgx1[1:], y1[:-1], dW_hh1, 4 * H, H, r1, 1, 4 * H, H, 1, H, mode=mode, splitk=True)
             gemm_raw(dgx1, y0, dW_ih1, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=mode, splitk=True)
-        db1 = colsum(dgx1, rows, 4 * H, 4 * H)
+        if db1 is None:
+            db1 = colsum(dgx1, rows, 4 * H, 4 * H)
         return dgx0, dW_hh0, dW_ih1, db1, db1, dW_hh1, None
 
 

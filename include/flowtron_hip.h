@@ -88,6 +88,9 @@ typedef struct {
 } ft_gemm_img_args;
 size_t ft_bf16_image_bytes(int64_t rows, int64_t cols);
 int ft_bf16_image(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, void* stream);
+/* the same image plus colsum[c] = sum_r src[r][c] in fp32 (bias gradients ride on the conversion pass of the output
+ * gradient; colsum [cols] is overwritten; row slabs combine with fp32 atomics like ft_colsum) */
+int ft_bf16_image_colsum(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, float* colsum, void* stream);
 int ft_gemm_img(const ft_gemm_img_args* a, void* stream);
 
 /* ---- embedding gather (flowtron.py:873-874) ------------------------------

@@ -547,3 +547,24 @@ def test_bidirectional_pair_chain_equals_two_chains(env, monkeypatch, B, T):
             assert torch.equal(a, b), (name, mad(a, b))
     ref = torch.cat([O.lstm_cell_seq(x, lens, *ws[0]), O.lstm_cell_seq(x, lens, *ws[1], reverse=True)], 2)
     assert mad(res[0][0], ref) < 3e-2
+
+
+@pytest.mark.parametrize("rows,cols,off", [(1000, 300, 0), (257, 4096, 0), (31, 80, 1), (2050, 136, 0)])
+def test_bf16_image_and_fused_column_sums(env, rows, cols, off):
+    """ft_bf16_image / ft_bf16_image_colsum: the image is bit-identical to torch's RNE bf16 cast, zero outside the
+    logical extent ([ceil128(rows+32)][ceil128(cols)]); the fused column sums equal the fp32 sums of the SOURCE
+    (tolerance: fp32 summation order over <= 2050 rows)."""
+    L, ops = env
+    torch.manual_seed(rows + cols)
+    wide = torch.randn(rows, cols + off + 3)
+    src = g(wide)[:, off:off + cols]                       # strided view; off = 1 makes the rows only 4-byte aligned
+    for with_sum in (False, True):
+        img = ops.Bf16Image(src, colsum=with_sum)
+        Rp, ld = (rows + 32 + 127) // 128 * 128, (cols + 127) // 128 * 128
+        assert img.ld == ld and img.buf.numel() >= Rp * ld * 2
+        raw = img.buf[:Rp * ld * 2].view(torch.int16).view(Rp, ld).cpu()
+        ref = wide[:, off:off + cols].to(torch.bfloat16).view(torch.int16)
+        assert torch.equal(raw[:rows, :cols], ref)
+        assert int(raw[rows:].abs().max()) == 0 and (cols == ld or int(raw[:, cols:].abs().max()) == 0)
+        if with_sum:
+            assert mad(img.colsum, wide[:, off:off + cols].double().sum(0).float()) < 2e-4 * math.sqrt(rows)
