@@ -50,6 +50,43 @@ __device__ __forceinline__ void skinny_bf16(const bf16x8* __restrict__ afrag, co
     mfma_group();
 }
 
+// Two K-segments (two activation images, one K-concatenated weight image), one group of G chunks per wave and segment.
+// The weight fragments are the cold stream (every workgroup owns a private slice that comes from the memory side each
+// launch); the activation images are 64 KiB that all workgroups read, i.e. hot in L2.  So BOTH segments' weight fragments
+// are requested up front, and only the second segment's activation fragments -- a short L2 round trip -- are fetched
+// after the first segment's MFMAs, into the same registers (two back-to-back skinny_bf16 calls pay the long round trip
+// twice; holding both segments' activations as well does not fit the register budget of two workgroups per CU).
+template <int MT, int G, typename Hook>
+__device__ __forceinline__ void skinny_bf16_dualw(const bf16x8* __restrict__ afrag0, const bf16x8* __restrict__ afrag1,
+                                                  const bf16x8* __restrict__ wfrag0, const bf16x8* __restrict__ wfrag1,
+                                                  int c0, int cs, int lane, f32x4 (&acc)[MT], Hook&& after_last_loads, int a_mt) {
+    bf16x8 w0[G], w1[G], a[G][MT];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const size_t c = (size_t)(c0 + i * cs);
+        w0[i] = wfrag0[c * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[i][m] = afrag0[(c * a_mt + m) * 64 + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i) w1[i] = wfrag1[(size_t)(c0 + i * cs) * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w0[i], acc[m], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[i][m] = afrag1[((size_t)(c0 + i * cs) * a_mt + m) * 64 + lane];
+    after_last_loads();                      // younger loads: never delay a fragment wait (vmcnt retires in order)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w1[i], acc[m], 0, 0, 0);
+}
+
 __device__ __forceinline__ size_t frag_index(int b, int k, int MT) {
     const int c = k >> 5, kg = (k >> 3) & 3, e = k & 7, m = b >> 4, li = b & 15;
     return (((size_t)c * MT + m) * 64 + kg * 16 + li) * 8 + e;
@@ -94,9 +131,11 @@ struct L2FwdP {
     int s, T, B, H;
 };
 
-template <int MT, int G>
-__global__ __launch_bounds__(256) void lstm2_fwd_step(L2FwdP p) {
-    __shared__ float red[4][MT * 16][17];
+// NW waves per workgroup split the k-chunks (4: G chunks per wave and segment; 8: half as many, so that the layer-1 group
+// can hold BOTH segments' fragments in flight inside the 128-VGPR budget of two 512-thread workgroups per CU)
+template <int MT, int G, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void lstm2_fwd_step(L2FwdP p) {
+    __shared__ float red[NW][MT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
     const int H = p.H, B = p.B, nblk = H >> 2;
@@ -135,14 +174,20 @@ __global__ __launch_bounds__(256) void lstm2_fwd_step(L2FwdP p) {
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!L1) {
         skinny_bf16<MT, G>(reinterpret_cast<const bf16x8*>(p.h0frag[s & 1]),
-                           reinterpret_cast<const bf16x8*>(p.w0frag) + (size_t)blk * nchunk * 64, nchunk, wave, 4, lane, acc,
+                           reinterpret_cast<const bf16x8*>(p.w0frag) + (size_t)blk * nchunk * 64, nchunk, wave, NW, lane, acc,
                            issue_epilogue_loads, MT);
     } else {
         const bf16x8* wf = reinterpret_cast<const bf16x8*>(p.w1frag) + (size_t)blk * 2 * nchunk * 64;
-        // input segment: h0 of THIS time step = what layer 0 wrote one launch ago = the buffer layer 0 reads in this launch
-        skinny_bf16<MT, G>(reinterpret_cast<const bf16x8*>(p.h0frag[(s + 1) & 1]), wf, nchunk, wave, 4, lane, acc, []() {}, MT);
-        skinny_bf16<MT, G>(reinterpret_cast<const bf16x8*>(p.h1frag[s & 1]), wf + (size_t)nchunk * 64, nchunk, wave, 4, lane, acc,
-                           issue_epilogue_loads, MT);
+        // input segment: h0 of THIS time step = what layer 0 wrote one launch ago = the buffer layer 0 reads in this launch;
+        // recurrent segment: h1 of the previous step
+        const bf16x8* a0 = reinterpret_cast<const bf16x8*>(p.h0frag[(s + 1) & 1]);
+        const bf16x8* a1 = reinterpret_cast<const bf16x8*>(p.h1frag[s & 1]);
+        if (nchunk == NW * G) {             // one group per wave and segment (H = 1024 with G = 8): both weight groups up front
+            skinny_bf16_dualw<MT, G>(a0, a1, wf, wf + (size_t)nchunk * 64, wave, NW, lane, acc, issue_epilogue_loads, MT);
+        } else {
+            skinny_bf16<MT, G>(a0, wf, nchunk, wave, NW, lane, acc, []() {}, MT);
+            skinny_bf16<MT, G>(a1, wf + (size_t)nchunk * 64, nchunk, wave, NW, lane, acc, issue_epilogue_loads, MT);
+        }
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -166,7 +211,10 @@ __global__ __launch_bounds__(256) void lstm2_fwd_step(L2FwdP p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int n = g * 4 + ul;
-        pre[g] = red[0][eb][n] + red[1][eb][n] + red[2][eb][n] + red[3][eb][n] + gxv[g];
+        float sum = gxv[g];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += red[w][eb][n];
+        pre[g] = sum;
     }
     const float ig = 1.f / (1.f + expf(-pre[0]));
     const float fg = 1.f / (1.f + expf(-pre[1]));
@@ -238,12 +286,16 @@ __global__ __launch_bounds__(1024) void lstm2_bwd_step(L2BwdP p) {
                           issue_epilogue_loads, p.MT);
     } else {
         // dh0[s] = dgates1[s] W_ih1 + dgates0[s+1] W_hh0 ; dgates1[s] was written one launch ago into da1frag[s & 1]
-        skinny_bf16<1, G>(reinterpret_cast<const bf16x8*>(p.da1frag[s & 1]) + (size_t)m_base * 64,
-                          reinterpret_cast<const bf16x8*>(p.wTi1frag) + (size_t)jt * nchunk * 64, nchunk, wave, 16, lane, acc,
-                          []() {}, p.MT);
-        skinny_bf16<1, G>(reinterpret_cast<const bf16x8*>(p.da0frag[(s + 1) & 1]) + (size_t)m_base * 64,
-                          reinterpret_cast<const bf16x8*>(p.wT0frag) + (size_t)jt * nchunk * 64, nchunk, wave, 16, lane, acc,
-                          issue_epilogue_loads, p.MT);
+        const bf16x8* a0 = reinterpret_cast<const bf16x8*>(p.da1frag[s & 1]) + (size_t)m_base * 64;
+        const bf16x8* a1 = reinterpret_cast<const bf16x8*>(p.da0frag[(s + 1) & 1]) + (size_t)m_base * 64;
+        const bf16x8* w0 = reinterpret_cast<const bf16x8*>(p.wTi1frag) + (size_t)jt * nchunk * 64;
+        const bf16x8* w1 = reinterpret_cast<const bf16x8*>(p.wT0frag) + (size_t)jt * nchunk * 64;
+        if (nchunk == 16 * G) {            // one group per wave and segment: both weight groups in flight up front
+            skinny_bf16_dualw<1, G>(a0, a1, w0, w1, wave, 16, lane, acc, issue_epilogue_loads, p.MT);
+        } else {
+            skinny_bf16<1, G>(a0, w0, nchunk, wave, 16, lane, acc, []() {}, p.MT);
+            skinny_bf16<1, G>(a1, w1, nchunk, wave, 16, lane, acc, issue_epilogue_loads, p.MT);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][kg * 4 + r][li] = acc[0][r];
@@ -286,9 +338,15 @@ struct Carve {
 
 template <int G>
 void launch_fwd2(const L2FwdP& p, int mt, dim3 grid, hipStream_t st) {
-    if (mt == 1) hipLaunchKernelGGL((lstm2_fwd_step<1, G>), grid, dim3(256), 0, st, p);
-    else if (mt == 2) hipLaunchKernelGGL((lstm2_fwd_step<2, G>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((lstm2_fwd_step<4, (G > 4 ? 4 : G)>), grid, dim3(256), 0, st, p);
+    if (mt == 1) hipLaunchKernelGGL((lstm2_fwd_step<1, G, 4>), grid, dim3(256), 0, st, p);
+    else if (mt == 2) hipLaunchKernelGGL((lstm2_fwd_step<2, G, 4>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((lstm2_fwd_step<4, (G > 4 ? 4 : G), 4>), grid, dim3(256), 0, st, p);
+}
+// 8-wave workgroups: H/32 chunks over 8 waves, GW = chunks per wave and segment
+template <int GW>
+void launch_fwd2_w8(const L2FwdP& p, int mt, dim3 grid, hipStream_t st) {
+    if (mt == 1) hipLaunchKernelGGL((lstm2_fwd_step<1, GW, 8>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((lstm2_fwd_step<2, GW, 8>), grid, dim3(512), 0, st, p);
 }
 
 }  // namespace
@@ -329,9 +387,16 @@ extern "C" int ft_lstm2_seq_fwd(const float* gx0, const float* w_hh0, const floa
     hipLaunchKernelGGL(make_wfrag_fwd_cat, dim3(2048), dim3(256), 0, st, w_ih1, H, w_hh1, H, w1, H);
     const int g = group_of((H >> 5) / 4);
     dim3 grid(2 * (H >> 2));
+    const int per8 = (H >> 5) / 8;          // chunks per wave with 8 waves (exact when H % 256 == 0)
+    const bool w8 = false && (H % 256 == 0) && mt <= 2 && (per8 == 4 || per8 == 2 || per8 == 1);   // measured? no: 128-VGPR budget spills
     for (int s = 0; s <= T; ++s) {
         p.s = s;
-        if (g == 8) launch_fwd2<8>(p, mt, grid, st);
+        if (w8) {
+            if (per8 == 4) launch_fwd2_w8<4>(p, mt, grid, st);
+            else if (per8 == 2) launch_fwd2_w8<2>(p, mt, grid, st);
+            else launch_fwd2_w8<1>(p, mt, grid, st);
+        }
+        else if (g == 8) launch_fwd2<8>(p, mt, grid, st);
         else if (g == 4) launch_fwd2<4>(p, mt, grid, st);
         else if (g == 2) launch_fwd2<2>(p, mt, grid, st);
         else launch_fwd2<1>(p, mt, grid, st);
