@@ -282,7 +282,9 @@ def main():
     import torch.distributed as dist
     L.lib()                                                   # fail loudly if the HIP library is missing
     if world > 1:
-        ftdist.init_distributed(rank, world, "nccl", None)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):          # the reference-style "> initializing distributed" chatter
+            ftdist.init_distributed(rank, world, "nccl", None)
 
     torch.manual_seed(1234)
     model = flowtron.Flowtron(**MODEL_CONFIG)

@@ -483,3 +483,55 @@ def test_bf16_mode_gradients_track_fp32_full_width():
     assert w1[1] < 2e-2, w1
     w2 = worst(res["bf16"], res["f32"], skip=("encoder.convolutions", "embedding."))
     assert w2[1] < 6e-2, w2
+
+
+def test_rccl_process_group_single_rank_step():
+    """torch.distributed backend "nccl" (= RCCL) on the GPU box: init through flowtron_amd.dist exactly as bench.py / train.py
+    do, the flat-arena wrapper around a small model, one forward/backward, the explicit collectives of the step
+    (all_reduce SUM / MAX, broadcast, reduce_tensors) on device tensors.  One rank -- the box has one GPU -- so this pins
+    library loading, stream ordering and the hook/callback plumbing, not the wire; the 2-rank numerics are covered on CPU
+    with gloo (tests/test_dist_cpu.py).  Runs in a subprocess: a process group is process-global state."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, os.getcwd())
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", FLOWTRON_MFMA="f32")
+        import flowtron
+        from flowtron_amd import dist as ftdist
+        from flowtron_amd.optim import RAdam
+        from oracle import synth
+        ftdist.init_distributed(0, 1, "nccl", None)
+        assert dist.get_backend() == "nccl"
+        cfg = dict(synth.SMALL_MODEL_CONFIG)
+        m = flowtron.Flowtron(**cfg)
+        m.load_state_dict(synth.make_state_dict(cfg, seed=1))
+        m = ftdist.apply_gradient_allreduce(m.cuda().eval())
+        opt = RAdam(m.parameters(), lr=1e-3)
+        bc = synth.make_batch(cfg, [21, 13], [9, 4], seed=1, with_prior=True)
+        b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in bc.items()}
+        crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)
+        for _ in range(2):
+            m.zero_grad()
+            out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+            nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+            (nll + gl + 0.01 * ctc).backward()
+            opt.clip_grad_norm_(1.0)
+            opt.step()
+        g = m._grad_arena.flat_grad
+        ref = g.clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)              # the step's collective on the real arena (1 rank: identity)
+        t = torch.tensor([3.0, 5.0], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.broadcast(m._grad_arena.flat_param, 0)
+        r = ftdist.reduce_tensors([nll, gl, ctc], 1)
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert torch.equal(g, ref) and t.tolist() == [3.0, 5.0] and abs(r[0].item() - nll.item()) < 1e-6
+        assert torch.isfinite(nll).item()
+        dist.destroy_process_group()
+        print("RCCL_OK", nll.item())
+    ''')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
