@@ -93,8 +93,8 @@ SIGNATURES = {
     "ft_decode_flow": ([C.POINTER(DecodeArgs), _p], _i),
     "ft_stft_mel": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "ft_attn_ctc_workspace_floats": ([_i, _i, _i], _sz),
-    "ft_attn_ctc_fwd": ([_p, _p, _p, _f, _p, _p, _i, _i, _i, _p], _i),
-    "ft_attn_ctc_bwd": ([_p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _p], _i),
+    "ft_attn_ctc_fwd": ([_p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _p], _i),
+    "ft_attn_ctc_bwd": ([_p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_beta_binomial_prior": ([_p, _p, _p, _i, _i, _i, _f, _p], _i),
     "ft_sumsq": ([_p, _p, _l, _p], _i),
     "ft_radam_step": ([_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _f, _f, _f, _i, _p], _i),

@@ -8,8 +8,11 @@
 //
 // One workgroup per sample, one thread per state, the time recursion is the only sequential dimension:
 //   forward : lse[t] (log-softmax normaliser, one wave per frame), alpha[t][s] in LDS (double buffer) + saved to HBM,
-//             nll_b = -logsumexp(alpha[T-1][2K], alpha[T-1][2K-1]);  loss += nll_b / K_b / B
-//   backward: beta recursion in LDS; d loss / d logit[t][k] = (softmax[t][k] - exp(alpha+beta+nll-logp)[state 2k-1]) * g/(K_b B)
+//             nll_b = -logsumexp(alpha[T-1][2K], alpha[T-1][2K-1]);  loss += nll_b / K_b / B.
+//             When a gradient will be wanted the beta recursion runs IN THE SAME LAUNCH as a second workgroup per sample
+//             (grid (B, 2): the two recursions are independent and each is latency-bound in T), saving beta to HBM.
+//   backward: d loss / d logit[t][k] = (softmax[t][k] - exp(alpha+beta+nll-logp)[state 2k-1]) * g/(K_b B), an elementwise
+//             kernel over (b, t, k) -- no recursion left in the backward pass.
 // The next frame's logits are prefetched into registers before the barrier of the current frame, so the per-frame cost is
 // one LDS round trip + three exp/log, not a global-memory round trip.
 #include "common.h"
@@ -45,11 +48,11 @@ __global__ __launch_bounds__(256) void ctc_lse_k(const float* __restrict__ lp, c
 }
 
 // one workgroup per sample, thread s = extended state
-__global__ __launch_bounds__(1024) void ctc_alpha_k(const float* __restrict__ lp, const int* __restrict__ in_lens,
-                                                    const int* __restrict__ out_lens, float blank, const float* __restrict__ lse,
-                                                    float* __restrict__ alpha, float* __restrict__ nll, float* __restrict__ loss,
-                                                    int B, int T, int L) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];     // 2 x (S + 2), two -inf guard cells in front of each
+__device__ __forceinline__ void ctc_alpha_body(const float* __restrict__ lp, const int* __restrict__ in_lens,
+                                               const int* __restrict__ out_lens, float blank, const float* __restrict__ lse,
+                                               float* __restrict__ alpha, float* __restrict__ nll, float* __restrict__ loss,
+                                               int B, int T, int L, float* sm) {
+    // sm: 2 x (S + 2), two -inf guard cells in front of each
     const int b = blockIdx.x, s = threadIdx.x;
     const int K = min(in_lens[b], L), Tb = min(out_lens[b], T);
     const int S = 2 * K + 1, SP = 2 * L + 1 + 2;
@@ -93,15 +96,14 @@ __global__ __launch_bounds__(1024) void ctc_alpha_k(const float* __restrict__ lp
     }
 }
 
-__global__ __launch_bounds__(1024) void ctc_beta_grad_k(const float* __restrict__ lp, const int* __restrict__ in_lens,
-                                                        const int* __restrict__ out_lens, float blank, const float* __restrict__ lse,
-                                                        const float* __restrict__ alpha, const float* __restrict__ nll,
-                                                        const float* __restrict__ gout, float* __restrict__ dlp, int B, int T, int L) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];     // 2 x (S + 2), two -inf guard cells BEHIND each
+// beta[t][s] (emission of frame t included, like alpha), saved to HBM; same thread <-> state mapping as alpha
+__device__ __forceinline__ void ctc_beta_body(const float* __restrict__ lp, const int* __restrict__ in_lens,
+                                              const int* __restrict__ out_lens, float blank, const float* __restrict__ lse,
+                                              float* __restrict__ beta, int B, int T, int L, float* sm) {
+    // sm: 2 x (S + 2), two -inf guard cells BEHIND each
     const int b = blockIdx.x, s = threadIdx.x;
     const int K = min(in_lens[b], L), Tb = min(out_lens[b], T);
-    const float nl = nll[b];
-    if (nl == INFINITY || Tb <= 0 || K <= 0) return;               // zero_infinity: dlp stays zero (memset by the host)
+    if (Tb <= 0 || K <= 0) return;
     const int S = 2 * K + 1, SP = 2 * L + 1 + 2;
     float* buf[2] = {sm, sm + SP};
     if (s < 2) { sm[S + s] = -INFINITY; sm[SP + S + s] = -INFINITY; }
@@ -110,82 +112,126 @@ __global__ __launch_bounds__(1024) void ctc_beta_grad_k(const float* __restrict_
     const int k = (s - 1) >> 1;
     const float* lpb = lp + (size_t)b * T * L;
     const float* lseb = lse + (size_t)b * T;
-    const float* ab = alpha + (size_t)b * T * (2 * L + 1);
-    float* db = dlp + (size_t)b * T * L;
-    const float scale = gout[0] / (float)K / (float)B;
+    float* bb = beta + (size_t)b * T * (2 * L + 1);
     int t = Tb - 1;
     float logit = (on && lab) ? lpb[(size_t)t * L + k] : blank;
     float norm = lseb[t];
-    float al = on ? ab[(size_t)t * (2 * L + 1) + s] : -INFINITY;
     float be = -INFINITY;
     if (on && s >= S - 2) be = logit - norm;
-    if (on) {
-        buf[0][s] = be;
-        if (lab) { const float logp = logit - norm; db[(size_t)t * L + k] = (expf(logp) - expf(al + be + nl - logp)) * scale; }
-    }
-    float logit_n = blank, norm_n = 0.f, al_n = -INFINITY;
+    if (on) { buf[0][s] = be; bb[(size_t)t * (2 * L + 1) + s] = be; }
+    float logit_n = blank, norm_n = 0.f;
     if (t - 1 >= 0) {
         if (on && lab) logit_n = lpb[(size_t)(t - 1) * L + k];
         norm_n = lseb[t - 1];
-        if (on) al_n = ab[(size_t)(t - 1) * (2 * L + 1) + s];
     }
     __syncthreads();
     int cur = 0;
     for (t = Tb - 2; t >= 0; --t) {
-        logit = logit_n; norm = norm_n; al = al_n;
+        logit = logit_n; norm = norm_n;
         if (t - 1 >= 0) {
             if (on && lab) logit_n = lpb[(size_t)(t - 1) * L + k];
             norm_n = lseb[t - 1];
-            if (on) al_n = ab[(size_t)(t - 1) * (2 * L + 1) + s];
         }
         if (on) {
             const float* nx = buf[cur];
             const float x2 = (lab && s + 2 < S) ? nx[s + 2] : -INFINITY;
-            const float logp = (lab ? logit : blank) - norm;
-            be = lse3(nx[s], nx[s + 1], x2) + logp;
+            be = lse3(nx[s], nx[s + 1], x2) + (lab ? logit : blank) - norm;
             buf[cur ^ 1][s] = be;
-            if (lab) db[(size_t)t * L + k] = (expf(logp) - expf(al + be + nl - logp)) * scale;
+            bb[(size_t)t * (2 * L + 1) + s] = be;
         }
         __syncthreads();
         cur ^= 1;
     }
 }
 
+// grid (B, 1 or 2): y = 0 alpha recursion (+ loss), y = 1 beta recursion -- independent, both latency-bound in T
+__global__ __launch_bounds__(1024) void ctc_alpha_beta_k(const float* __restrict__ lp, const int* __restrict__ in_lens,
+                                                         const int* __restrict__ out_lens, float blank, const float* __restrict__ lse,
+                                                         float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ nll,
+                                                         float* __restrict__ loss, int B, int T, int L) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    if (blockIdx.y == 0) ctc_alpha_body(lp, in_lens, out_lens, blank, lse, alpha, nll, loss, B, T, L, sm);
+    else ctc_beta_body(lp, in_lens, out_lens, blank, lse, beta, B, T, L, sm);
+}
+__global__ __launch_bounds__(1024) void ctc_beta_k(const float* __restrict__ lp, const int* __restrict__ in_lens,
+                                                   const int* __restrict__ out_lens, float blank, const float* __restrict__ lse,
+                                                   float* __restrict__ beta, int B, int T, int L) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    ctc_beta_body(lp, in_lens, out_lens, blank, lse, beta, B, T, L, sm);
+}
+
+// dlp[b][t][k] for every (b, t, k): grid (ceil(T/4), B), one wave per frame, lanes over labels
+__global__ __launch_bounds__(256) void ctc_grad_k(const float* __restrict__ lp, const int* __restrict__ in_lens,
+                                                  const int* __restrict__ out_lens, const float* __restrict__ lse,
+                                                  const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                  const float* __restrict__ nll, const float* __restrict__ gout,
+                                                  float* __restrict__ dlp, int B, int T, int L) {
+    const int b = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= T) return;
+    const int K = min(in_lens[b], L), Tb = min(out_lens[b], T);
+    float* drow = dlp + ((size_t)b * T + t) * L;
+    const float nl = nll[b];
+    if (t >= Tb || K <= 0 || nl == INFINITY) {                    // padding frame / zero_infinity: zero gradient
+        for (int k = lane; k < L; k += 64) drow[k] = 0.f;
+        return;
+    }
+    const float* row = lp + ((size_t)b * T + t) * L;
+    const float* ar = alpha + ((size_t)b * T + t) * (2 * L + 1);
+    const float* br = beta + ((size_t)b * T + t) * (2 * L + 1);
+    const float norm = lse[(size_t)b * T + t];
+    const float scale = gout[0] / (float)K / (float)B;
+    for (int k = lane; k < L; k += 64) {
+        float g = 0.f;
+        if (k < K) {
+            const float logp = row[k] - norm;
+            g = (expf(logp) - expf(ar[2 * k + 1] + br[2 * k + 1] + nl - logp)) * scale;
+        }
+        drow[k] = g;
+    }
+}
+
 }  // namespace
 
 extern "C" size_t ft_attn_ctc_workspace_floats(int B, int T, int L) {
-    return (size_t)B * T * (2 * (size_t)L + 1) + (size_t)B * T + (size_t)B;        // alpha | lse | nll
+    return 2 * (size_t)B * T * (2 * (size_t)L + 1) + (size_t)B * T + (size_t)B;        // alpha | beta | lse | nll
 }
 
 extern "C" int ft_attn_ctc_fwd(const float* lp, const int32_t* in_lens, const int32_t* out_lens, float blank_logprob,
-                               float* work, float* loss, int B, int T, int L, void* stream) {
+                               float* work, float* loss, int B, int T, int L, int with_beta, void* stream) {
     FT_CHECK_ARG(lp && in_lens && out_lens && work && loss && B >= 1 && T >= 1 && L >= 1);
     if (2 * L + 1 > 1024) return ft_fail(FT_EUNSUPPORTED, "ft_attn_ctc_fwd: L=%d needs more than 1024 states", L);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t na = (size_t)B * T * (2 * (size_t)L + 1);
     float* alpha = work;
-    float* lse = alpha + (size_t)B * T * (2 * (size_t)L + 1);
+    float* beta = alpha + na;
+    float* lse = beta + na;
     float* nll = lse + (size_t)B * T;
     const int threads = cdiv(2 * L + 1, 64) * 64;
     FT_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
     hipLaunchKernelGGL(ctc_lse_k, dim3(cdiv(T, 4), B), dim3(256), 0, st, lp, in_lens, out_lens, blank_logprob, lse, T, L);
-    hipLaunchKernelGGL(ctc_alpha_k, dim3(B), dim3(threads), sizeof(float) * 2 * (2 * L + 3), st, lp, in_lens, out_lens, blank_logprob,
-                       lse, alpha, nll, loss, B, T, L);
+    hipLaunchKernelGGL(ctc_alpha_beta_k, dim3(B, with_beta ? 2 : 1), dim3(threads), sizeof(float) * 2 * (2 * L + 3), st, lp, in_lens,
+                       out_lens, blank_logprob, lse, alpha, beta, nll, loss, B, T, L);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }
 
 extern "C" int ft_attn_ctc_bwd(const float* lp, const int32_t* in_lens, const int32_t* out_lens, float blank_logprob,
-                               const float* work, const float* gout_dev, float* dlp, int B, int T, int L, void* stream) {
+                               float* work, const float* gout_dev, float* dlp, int B, int T, int L, int beta_ready, void* stream) {
     FT_CHECK_ARG(lp && in_lens && out_lens && work && gout_dev && dlp && B >= 1 && T >= 1 && L >= 1);
     if (2 * L + 1 > 1024) return ft_fail(FT_EUNSUPPORTED, "ft_attn_ctc_bwd: L=%d needs more than 1024 states", L);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t na = (size_t)B * T * (2 * (size_t)L + 1);
     const float* alpha = work;
-    const float* lse = alpha + (size_t)B * T * (2 * (size_t)L + 1);
+    float* beta = work + na;
+    const float* lse = beta + na;
     const float* nll = lse + (size_t)B * T;
-    const int threads = cdiv(2 * L + 1, 64) * 64;
-    FT_CHECK_HIP(hipMemsetAsync(dlp, 0, sizeof(float) * (size_t)B * T * L, st));
-    hipLaunchKernelGGL(ctc_beta_grad_k, dim3(B), dim3(threads), sizeof(float) * 2 * (2 * L + 3), st, lp, in_lens, out_lens, blank_logprob,
-                       lse, alpha, nll, gout_dev, dlp, B, T, L);
+    if (!beta_ready) {
+        const int threads = cdiv(2 * L + 1, 64) * 64;
+        hipLaunchKernelGGL(ctc_beta_k, dim3(B), dim3(threads), sizeof(float) * 2 * (2 * L + 3), st, lp, in_lens, out_lens, blank_logprob,
+                           lse, beta, B, T, L);
+    }
+    hipLaunchKernelGGL(ctc_grad_k, dim3(cdiv(T, 4), B), dim3(256), 0, st, lp, in_lens, out_lens, lse, alpha, beta, nll, gout_dev, dlp,
+                       B, T, L);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

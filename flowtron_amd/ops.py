@@ -751,8 +751,9 @@ class AttnCTCFn(torch.autograd.Function):
         B, T, Lk = lp.shape
         work = torch.empty(L.lib().ft_attn_ctc_workspace_floats(B, T, Lk), device=lp.device, dtype=torch.float32)
         loss = torch.empty(1, device=lp.device, dtype=torch.float32)
+        ctx.with_beta = int(bool(ctx.needs_input_grad[0]))       # beta recursion beside alpha, in the same launch
         L.check(L.lib().ft_attn_ctc_fwd(L.ptr(lp), L.ptr(in_lens32), L.ptr(out_lens32), float(blank_logprob), L.ptr(work),
-                                        L.ptr(loss), B, T, Lk, L.stream()), "ft_attn_ctc_fwd")
+                                        L.ptr(loss), B, T, Lk, ctx.with_beta, L.stream()), "ft_attn_ctc_fwd")
         ctx.save_for_backward(lp, in_lens32, out_lens32, work)
         ctx.blank = float(blank_logprob)
         return loss.reshape(())
@@ -764,7 +765,7 @@ class AttnCTCFn(torch.autograd.Function):
         gd = g.reshape(1).to(torch.float32).contiguous()
         dlp = torch.empty_like(lp)
         L.check(L.lib().ft_attn_ctc_bwd(L.ptr(lp), L.ptr(in32), L.ptr(out32), ctx.blank, L.ptr(work), L.ptr(gd), L.ptr(dlp),
-                                        B, T, Lk, L.stream()), "ft_attn_ctc_bwd")
+                                        B, T, Lk, ctx.with_beta, L.stream()), "ft_attn_ctc_bwd")
         return dlp, None, None, None
 
 
@@ -816,9 +817,9 @@ def ctc_prefetch(lp, in_lens32, out_lens32, time_reversed):
         one = torch.ones(1, device=dev, dtype=torch.float32)
         dlp = torch.empty_like(x)
         L.check(L.lib().ft_attn_ctc_fwd(L.ptr(x), L.ptr(in_lens32), L.ptr(out_lens32), blank, L.ptr(work), L.ptr(loss),
-                                        B, T, Lk, L.stream()), "ft_attn_ctc_fwd")
+                                        B, T, Lk, 1, L.stream()), "ft_attn_ctc_fwd")
         L.check(L.lib().ft_attn_ctc_bwd(L.ptr(x), L.ptr(in_lens32), L.ptr(out_lens32), blank, L.ptr(work), L.ptr(one), L.ptr(dlp),
-                                        B, T, Lk, L.stream()), "ft_attn_ctc_bwd")
+                                        B, T, Lk, 1, L.stream()), "ft_attn_ctc_bwd")
         if time_reversed:
             dlp = _reverse_raw(dlp, out_lens32, False)       # gradient back in the flow's own (reversed) time order
         ev = torch.cuda.Event()

@@ -267,13 +267,15 @@ int ft_stft_mel(const float* y, const float* window, const float* fb, float* mel
  * lp [B,T,L] = attn_logprob in natural time order.  Per sample: classes {blank (logit blank_logprob), 1..K_b} with
  * K_b = in_lens[b], frames t < out_lens[b]; log_softmax over the classes, CTC against the target 1..K_b (blank 0),
  * reduction 'mean' (divide by K_b), zero_infinity, then the batch mean.  loss[0] receives the scalar.  work holds
- * alpha [B,T,2L+1], the log-softmax normalisers [B,T] and nll [B] for backward (ft_attn_ctc_workspace_floats floats).
+ * alpha and beta [B,T,2L+1], the log-softmax normalisers [B,T] and nll [B] (ft_attn_ctc_workspace_floats floats).
+ * with_beta != 0: the beta recursion runs beside alpha in the same launch (a second workgroup per sample; both are
+ * latency-bound in T), so the backward pass is a single elementwise kernel -- pass beta_ready = with_beta to bwd.
  * bwd: dlp [B,T,L] = gout_dev[0] * d loss / d lp (overwritten; zero outside the valid [T_b, K_b] window). */
 size_t ft_attn_ctc_workspace_floats(int B, int T, int L);
 int ft_attn_ctc_fwd(const float* lp, const int32_t* in_lens, const int32_t* out_lens, float blank_logprob,
-                    float* work, float* loss, int B, int T, int L, void* stream);
+                    float* work, float* loss, int B, int T, int L, int with_beta, void* stream);
 int ft_attn_ctc_bwd(const float* lp, const int32_t* in_lens, const int32_t* out_lens, float blank_logprob,
-                    const float* work, const float* gout_dev, float* dlp, int B, int T, int L, void* stream);
+                    float* work, const float* gout_dev, float* dlp, int B, int T, int L, int beta_ready, void* stream);
 
 /* ---- beta-binomial attention prior (data.py:31-41, 111-141) --------
  * prior[b,t,k] = BetaBinom.pmf(k; n = in_lens[b]-1, a = scaling*(t+1), b = scaling*(out_lens[b]-t)) for
