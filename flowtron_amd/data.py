@@ -90,3 +90,49 @@ class DataCollate:
                 pr = pr.masked_fill(pr < self.attn_prior_threshold, 0.0)      # data.py:136-138
             out[6] = pr
         return tuple(out)
+
+
+class LengthBucketBatchSampler(torch.utils.data.Sampler):
+    """Batches of similar mel length.  The reference sorts a batch by TEXT length only and draws batches
+    uniformly at random (data.py:200-202, train.py:74-80), so B*T_max carries ~30 % padding at LJSpeech lengths -- and every
+    recurrence of the hot path runs T_max launches whatever the short utterances need.  This sampler keeps the epoch a
+    random permutation, but forms batches inside shuffled buckets of `bucket_batches * batch_size * world_size` utterances
+    sorted by length, then shuffles the batch order and deals batches to ranks round-robin (every rank gets the same number
+    of batches, equal-cost batches in the same step).  Opt-in: `DataLoader(dataset, batch_sampler=LengthBucketBatchSampler(
+    lengths, batch_size, rank=rank, world_size=n), collate_fn=DataCollate(...))` instead of `sampler=DistributedSampler`.
+    `drop_last` semantics as train.py:79 (incomplete batches / uneven tails are dropped)."""
+
+    def __init__(self, lengths: Sequence[int], batch_size: int, bucket_batches: int = 16, rank: int = 0, world_size: int = 1,
+                 shuffle: bool = True, seed: int = 1234):
+        self.lengths = torch.as_tensor(list(lengths), dtype=torch.int64)
+        assert batch_size >= 1 and bucket_batches >= 1 and 0 <= rank < world_size
+        self.batch_size, self.bucket_batches = int(batch_size), int(bucket_batches)
+        self.rank, self.world_size, self.shuffle, self.seed, self.epoch = int(rank), int(world_size), bool(shuffle), int(seed), 0
+        self.n_batches = (len(self.lengths) // self.batch_size) // self.world_size      # per rank
+
+    def set_epoch(self, epoch: int):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        return self.n_batches
+
+    def _all_batches(self):
+        n = len(self.lengths)
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        order = torch.randperm(n, generator=g) if self.shuffle else torch.arange(n)
+        bucket = self.batch_size * self.bucket_batches * self.world_size
+        batches = []
+        for s in range(0, n, bucket):
+            idx = order[s:s + bucket]
+            idx = idx[torch.argsort(self.lengths[idx], descending=True, stable=True)]
+            for b in range(0, len(idx) - self.batch_size + 1, self.batch_size):
+                batches.append(idx[b:b + self.batch_size])
+        if self.shuffle:                                  # keep groups of world_size consecutive (similar-length) batches
+            groups = [batches[i:i + self.world_size] for i in range(0, len(batches) - self.world_size + 1, self.world_size)]
+            perm = torch.randperm(len(groups), generator=g).tolist()
+            batches = [bt for k in perm for bt in groups[k]]
+        return batches[:self.n_batches * self.world_size]
+
+    def __iter__(self):
+        for bt in self._all_batches()[self.rank::self.world_size]:
+            yield bt.tolist()

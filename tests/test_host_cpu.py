@@ -190,3 +190,36 @@ def test_datacollate_matches_reference_wire_format():
         assert mine2[6] is None and ref2[6] is None
         for a, b in zip(mine2[:6], ref2[:6]):
             assert torch.equal(a, b)
+
+
+def test_length_bucket_batch_sampler_partitions_and_cuts_padding():
+    """batches of similar mel length.  Every utterance is used at most once per epoch, all ranks get the
+    same number of batches, epochs differ, and the padded-frame fraction drops well below random batching."""
+    from flowtron_amd.data import LengthBucketBatchSampler
+    g = torch.Generator().manual_seed(0)
+    lengths = (torch.randn(5000, generator=g) * 190 + 566).clamp(100, 862).round().long()
+    B, W = 32, 4
+    seen, per_rank = [], []
+    for r in range(W):
+        s = LengthBucketBatchSampler(lengths, B, rank=r, world_size=W, seed=7)
+        batches = list(s)
+        assert len(batches) == len(s) == (5000 // B) // W and all(len(b) == B for b in batches)
+        per_rank.append(batches)
+        seen += [i for b in batches for i in b]
+    assert len(seen) == len(set(seen))                                   # disjoint across ranks and batches
+    valid = sum(int(lengths[b].sum()) for bs in per_rank for b in bs)
+    padded = sum(int(lengths[b].max()) * B for bs in per_rank for b in bs)
+    rnd = torch.randperm(5000, generator=g)[:4992].view(-1, B)
+    frac_rnd = float(lengths[rnd].sum()) / float((lengths[rnd].max(1).values * B).sum())
+    assert valid / padded > 0.93 and frac_rnd < 0.75, (valid / padded, frac_rnd)
+    # same step, all ranks: similar cost -- the slowest rank's T_max summed over the epoch is within 8 % of the mean rank's
+    slow = mean = 0.0
+    for k in range(len(per_rank[0])):
+        mx = [int(lengths[per_rank[r][k]].max()) for r in range(W)]
+        slow += max(mx)
+        mean += sum(mx) / W
+    assert slow <= 1.08 * mean, (slow, mean)
+    s0 = LengthBucketBatchSampler(lengths, B, seed=7)
+    e0 = list(s0)
+    s0.set_epoch(1)
+    assert list(s0) != e0 and list(LengthBucketBatchSampler(lengths, B, seed=7)) == e0
