@@ -198,7 +198,7 @@ def usable_cores():
 
 def cpu_baseline_worker(batch_size, seed):
     """The CPU oracle (oracle/flowtron_oracle.py = restatement of the reference, pinned to golden vectors made
-    with the real reference) on a BOUNDED sample: the 2 shortest utterances of rank 0's batch, full
+    with the real reference) on a BOUNDED sample: the 4 shortest utterances of rank 0's batch (~10 s of CPU work), full
     forward + loss + backward, fp32, all usable host cores.  Runs in its own process (no GPU context)."""
     from oracle import flowtron_oracle as O
     import flowtron
@@ -209,7 +209,8 @@ def cpu_baseline_worker(batch_size, seed):
     init_weights(model, 1234)
     batch = synth_batch(batch_size, seed)
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-    idx = torch.argsort(batch["out_lens"])[:2]
+    n_utt = 4
+    idx = torch.argsort(batch["out_lens"])[:n_utt]
     idx = idx[torch.argsort(batch["in_lens"][idx], descending=True)]
     out_lens, in_lens = batch["out_lens"][idx], batch["in_lens"][idx]
     T, Lk = int(out_lens.max()), int(in_lens.max())
@@ -227,10 +228,12 @@ def cpu_baseline_worker(batch_size, seed):
         (nll + gl + 0.01 * ctc).sum().backward()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
+        if dt > 20.0:                       # slow host: one pass is already a sample of the intended size
+            break
     frames = int(out_lens.sum())
     return {"value": round(frames / best, 2), "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "sample": "2 shortest utterances of the batch (%d valid frames, T=%d, L=%d), fwd+loss+bwd, fp32, best of 2, %.2f s"
-                      % (frames, T, Lk, best)}
+            "sample": "%d shortest utterances of the batch (%d valid frames, T=%d, L=%d), fwd+loss+bwd, fp32, best of <=2, %.2f s"
+                      % (n_utt, frames, T, Lk, best)}
 
 
 def cpu_baseline(batch_size, seed, timeout_s=420):
