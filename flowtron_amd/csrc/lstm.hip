@@ -521,6 +521,7 @@ inline int group_of(int per_wave) { return (per_wave % 8 == 0) ? 8 : (per_wave %
 
 }  // namespace
 
+#ifndef FT_LSTM_NO_ENTRY
 extern "C" size_t ft_lstm_workspace_bytes(int B, int H) {
     const size_t BH = (size_t)B * H;
     const int mt = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
@@ -653,6 +654,8 @@ extern "C" int ft_lstm_seq_bwd(const float* dy, int64_t ldy, const float* w_hh, 
     return ft_lstm_seq_bwd_range(dy, ldy, w_hh, lens, gates, cell, dgx, work, T, B, H, reverse, mode, 0, T, 0, stream);
 }
 
+#endif  // FT_LSTM_NO_ENTRY
+
 // ---------------------------------------------------------------------------------------------------------------
 // bidirectional layer: both directions in one launch per step (lstm_fwd_pair / lstm_bwd_pair)
 // ---------------------------------------------------------------------------------------------------------------
@@ -694,6 +697,7 @@ void launch_fwd_pair(const FwdP& pf, const FwdP& pr, int mt, dim3 grid, hipStrea
 }
 }  // namespace
 
+#ifndef FT_LSTM_NO_ENTRY
 extern "C" int ft_lstm_bidir_supported(int B, int H) { return (B >= 1 && B <= 64 && H >= 128 && H % 128 == 0) ? 1 : 0; }
 
 extern "C" int ft_lstm_bidir_seq_fwd(const float* gx_f, const float* gx_r, const float* w_hh_f, const float* w_hh_r,
@@ -757,3 +761,4 @@ extern "C" int ft_lstm_bidir_seq_bwd(const float* dy, int64_t ldy, const float* 
     FT_CHECK_LAUNCH();
     return FT_OK;
 }
+#endif  // FT_LSTM_NO_ENTRY

@@ -134,7 +134,7 @@ struct L2FwdP {
 // NW waves per workgroup split the k-chunks (4: G chunks per wave and segment; 8: half as many, so that the layer-1 group
 // can hold BOTH segments' fragments in flight inside the 128-VGPR budget of two 512-thread workgroups per CU)
 template <int MT, int G, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 2) void lstm2_fwd_step(L2FwdP p) {
+__device__ __forceinline__ void lstm2_fwd_body(const L2FwdP& p) {
     __shared__ float red[NW][MT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
@@ -241,7 +241,7 @@ struct L2BwdP {
 
 // grid = (2 * H/16, MT): x < H/16 -> layer 1 step s ; x >= H/16 -> layer 0 step s+1.  One 16-row batch tile per workgroup.
 template <int G>
-__global__ __launch_bounds__(1024) void lstm2_bwd_step(L2BwdP p) {
+__device__ __forceinline__ void lstm2_bwd_body(const L2BwdP& p) {
     __shared__ float red[16][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
@@ -327,6 +327,11 @@ __global__ __launch_bounds__(1024) void lstm2_bwd_step(L2BwdP p) {
     }
 }
 
+template <int MT, int G, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void lstm2_fwd_step(L2FwdP p) { lstm2_fwd_body<MT, G, NW>(p); }
+template <int G>
+__global__ __launch_bounds__(1024) void lstm2_bwd_step(L2BwdP p) { lstm2_bwd_body<G>(p); }
+
 inline size_t al256(size_t v) { return (v + 255) & ~size_t(255); }
 inline int group_of(int per_wave) { return (per_wave % 8 == 0) ? 8 : (per_wave % 4 == 0) ? 4 : (per_wave % 2 == 0) ? 2 : 1; }
 inline int mt_of(int B) { return B <= 16 ? 1 : (B <= 32 ? 2 : 4); }
@@ -349,8 +354,43 @@ void launch_fwd2_w8(const L2FwdP& p, int mt, dim3 grid, hipStream_t st) {
     else hipLaunchKernelGGL((lstm2_fwd_step<2, GW, 8>), grid, dim3(512), 0, st, p);
 }
 
+// workspace carving shared by the sequence entry points and the fused three-group chain (lstm3.hip)
+struct Fwd2Setup { L2FwdP p; size_t state_bytes; unsigned short* w0; unsigned short* w1; };
+inline Fwd2Setup setup_fwd2(void* work, int B, int H) {
+    const int mt = mt_of(B);
+    const size_t BH = (size_t)B * H, frag_act = (size_t)mt * 16 * H * 2, wimg = (size_t)4 * H * H * 2;
+    Carve cv{reinterpret_cast<char*>(work)};
+    Fwd2Setup u{};
+    u.p.c0 = cv.take<float>(BH * 4); u.p.c1 = cv.take<float>(BH * 4);
+    u.p.h0frag[0] = cv.take<unsigned short>(frag_act); u.p.h0frag[1] = cv.take<unsigned short>(frag_act);
+    u.p.h1frag[0] = cv.take<unsigned short>(frag_act); u.p.h1frag[1] = cv.take<unsigned short>(frag_act);
+    u.state_bytes = cv.p - reinterpret_cast<char*>(work);
+    u.w0 = cv.take<unsigned short>(wimg);
+    u.w1 = cv.take<unsigned short>(2 * wimg);
+    u.p.w0frag = u.w0; u.p.w1frag = u.w1;
+    return u;
+}
+struct Bwd2Setup { L2BwdP p; size_t state_bytes; unsigned short *t1, *t0, *ti; };
+inline Bwd2Setup setup_bwd2(void* work, int B, int H) {
+    const int mt = mt_of(B);
+    const size_t BH = (size_t)B * H, frag_act = (size_t)mt * 16 * H * 2, wimg = (size_t)4 * H * H * 2;
+    Carve cv{reinterpret_cast<char*>(work)};
+    Bwd2Setup u{};
+    u.p.dc1 = cv.take<float>(BH * 4); u.p.dc0 = cv.take<float>(BH * 4);
+    u.p.da1frag[0] = cv.take<unsigned short>(4 * frag_act); u.p.da1frag[1] = cv.take<unsigned short>(4 * frag_act);
+    u.p.da0frag[0] = cv.take<unsigned short>(4 * frag_act); u.p.da0frag[1] = cv.take<unsigned short>(4 * frag_act);
+    u.state_bytes = cv.p - reinterpret_cast<char*>(work);
+    u.t1 = cv.take<unsigned short>(wimg);
+    u.t0 = cv.take<unsigned short>(wimg);
+    u.ti = cv.take<unsigned short>(wimg);
+    u.p.wT1frag = u.t1; u.p.wT0frag = u.t0; u.p.wTi1frag = u.ti;
+    u.p.MT = mt;
+    return u;
+}
+
 }  // namespace
 
+#ifndef FT_LSTM_NO_ENTRY
 extern "C" int ft_lstm2_supported(int B, int H) { return (B >= 1 && B <= 64 && H >= 128 && H % 128 == 0) ? 1 : 0; }
 
 extern "C" size_t ft_lstm2_workspace_bytes(int B, int H) {
@@ -369,17 +409,11 @@ extern "C" int ft_lstm2_seq_fwd(const float* gx0, const float* w_hh0, const floa
     if (!ft_lstm2_supported(B, H)) return ft_fail(FT_EUNSUPPORTED, "ft_lstm2_seq_fwd: needs H %% 128 == 0 and B <= 64 (H=%d B=%d)", H, B);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int mt = mt_of(B);
-    const size_t BH = (size_t)B * H, frag_act = (size_t)mt * 16 * H * 2, wimg = (size_t)4 * H * H * 2;
-    Carve cv{reinterpret_cast<char*>(work)};
-    L2FwdP p{};
+    Fwd2Setup u = setup_fwd2(work, B, H);
+    L2FwdP& p = u.p;
+    unsigned short *w0 = u.w0, *w1 = u.w1;
+    const size_t state_bytes = u.state_bytes;
     p.gx0 = gx0; p.bias1 = bias1; p.lens = lens;
-    p.c0 = cv.take<float>(BH * 4); p.c1 = cv.take<float>(BH * 4);
-    p.h0frag[0] = cv.take<unsigned short>(frag_act); p.h0frag[1] = cv.take<unsigned short>(frag_act);
-    p.h1frag[0] = cv.take<unsigned short>(frag_act); p.h1frag[1] = cv.take<unsigned short>(frag_act);
-    const size_t state_bytes = cv.p - reinterpret_cast<char*>(work);
-    unsigned short* w0 = cv.take<unsigned short>(wimg);
-    unsigned short* w1 = cv.take<unsigned short>(2 * wimg);
-    p.w0frag = w0; p.w1frag = w1;
     p.y0 = y0; p.gates0 = gates0; p.cell0 = cell0; p.y1 = y1; p.gates1 = gates1; p.cell1 = cell1;
     p.T = T; p.B = B; p.H = H;
     FT_CHECK_HIP(hipMemsetAsync(work, 0, state_bytes, st));
@@ -413,20 +447,13 @@ extern "C" int ft_lstm2_seq_bwd(const float* dy1, const float* w_hh0, const floa
     if (!ft_lstm2_supported(B, H)) return ft_fail(FT_EUNSUPPORTED, "ft_lstm2_seq_bwd: needs H %% 128 == 0 and B <= 64 (H=%d B=%d)", H, B);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int mt = mt_of(B);
-    const size_t BH = (size_t)B * H, frag_act = (size_t)mt * 16 * H * 2, wimg = (size_t)4 * H * H * 2;
-    Carve cv{reinterpret_cast<char*>(work)};
-    L2BwdP p{};
+    Bwd2Setup u = setup_bwd2(work, B, H);
+    L2BwdP& p = u.p;
+    unsigned short *t1 = u.t1, *t0 = u.t0, *ti = u.ti;
+    const size_t state_bytes = u.state_bytes;
     p.dy1 = dy1; p.lens = lens; p.gates1 = gates1; p.cell1 = cell1; p.gates0 = gates0; p.cell0 = cell0;
-    p.dc1 = cv.take<float>(BH * 4); p.dc0 = cv.take<float>(BH * 4);
-    p.da1frag[0] = cv.take<unsigned short>(4 * frag_act); p.da1frag[1] = cv.take<unsigned short>(4 * frag_act);
-    p.da0frag[0] = cv.take<unsigned short>(4 * frag_act); p.da0frag[1] = cv.take<unsigned short>(4 * frag_act);
-    const size_t state_bytes = cv.p - reinterpret_cast<char*>(work);
-    unsigned short* t1 = cv.take<unsigned short>(wimg);
-    unsigned short* t0 = cv.take<unsigned short>(wimg);
-    unsigned short* ti = cv.take<unsigned short>(wimg);
-    p.wT1frag = t1; p.wT0frag = t0; p.wTi1frag = ti;
     p.dgx1 = dgx1; p.dgx0 = dgx0;
-    p.T = T; p.B = B; p.H = H; p.MT = mt;
+    p.T = T; p.B = B; p.H = H;
     FT_CHECK_HIP(hipMemsetAsync(work, 0, state_bytes, st));
     hipLaunchKernelGGL(make_wfrag_bwd_t, dim3(2048), dim3(256), 0, st, w_hh1, t1, H, H);
     hipLaunchKernelGGL(make_wfrag_bwd_t, dim3(2048), dim3(256), 0, st, w_hh0, t0, H, H);
@@ -443,3 +470,4 @@ extern "C" int ft_lstm2_seq_bwd(const float* dy1, const float* w_hh0, const floa
     FT_CHECK_LAUNCH();
     return FT_OK;
 }
+#endif  // FT_LSTM_NO_ENTRY
