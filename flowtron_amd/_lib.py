@@ -76,8 +76,6 @@ SIGNATURES = {
     "ft_lstm_bidir_supported": ([_i, _i], _i),
     "ft_lstm_bidir_seq_fwd": ([_p] * 6 + [_l] + [_p] * 6 + [_i, _i, _i, _p], _i),
     "ft_lstm_bidir_seq_bwd": ([_p, _l] + [_p] * 11 + [_i, _i, _i, _p], _i),
-    "ft_lstm3_supported": ([_i, _i], _i),
-    "ft_lstm3_chunk_fwd": ([_p] * 6 + [_i, _i] + [_p] * 12 + [_i, _i, _p, _i, _i, _i, _p], _i),
     "ft_attention_fwd": ([_p] * 8 + [_i, _i, _i, _i, _f, _p], _i),
     "ft_attention_bwd": ([_p] * 13 + [_i, _i, _i, _i, _f, _p], _i),
     "ft_affine_fwd": ([_p, _p, _p, _l, _i, _p], _i),

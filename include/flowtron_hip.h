@@ -172,20 +172,6 @@ int ft_lstm_bidir_seq_bwd(const float* dy, int64_t ldy, const float* w_hh_f, con
                           const float* gates_f, const float* gates_r, const float* cell_f, const float* cell_r,
                           float* dgx_f, float* dgx_r, void* work_f, void* work_r, int T, int B, int H, void* stream);
 
-/* The three recurrences of a flow as ONE forward launch chain over a time chunk (lstm3.hip): launch i runs step a0+i of the
- * attention LSTM (single layer: gx_a [T,B,4H], w_hh_a; outputs y_a/gates_a/cell_a as ft_lstm_seq_fwd) beside launch b0+i of
- * the two-layer wavefront chain (arguments as ft_lstm2_seq_fwd; a whole sequence is launches 0..T) as co-resident
- * workgroups -- the decoder depends on the attention LSTM only through the per-chunk attention, so chunk c+1 of the one runs
- * under chunk c of the other.  Either range may be empty (then the plain step kernel is launched).  State persists in
- * work_a (ft_lstm_workspace_bytes) / work_2 (ft_lstm2_workspace_bytes) between calls; it is initialised when a0 == 0 resp.
- * b0 == 0.  bf16 fragment path; ft_lstm3_supported(B,H): H % 1024 == 0, B <= 32. */
-int ft_lstm3_supported(int B, int H);
-int ft_lstm3_chunk_fwd(const float* gx_a, const float* w_hh_a, float* y_a, float* gates_a, float* cell_a, void* work_a,
-                       int a0, int a1,
-                       const float* gx0, const float* w_hh0, const float* w_ih1, const float* bias1, const float* w_hh1,
-                       float* y0, float* gates0, float* cell0, float* y1, float* gates1, float* cell1, void* work_2,
-                       int b0, int b1, const int32_t* lens, int T, int B, int H, void* stream);
-
 /* ---- additive attention scores + softmax + prior posterior (flowtron.py:544-583)
  * Q [T,B,A] (time-major), K [L,B,A], v [A], in_lens [B], prior [B,T,L] or NULL.
  * e[b,t,l] = sum_a v[a] tanh(Q[t,b,a]+K[l,b,a]) / temperature, -inf at l >= in_lens[b];
