@@ -15,6 +15,8 @@
 //
 // bf16 fragment-order operands, fp32 accumulate / state / saved tensors (same conventions as lstm.hip, FT_BF16 path).
 // Requires H % 128 == 0 and B <= 64; callers fall back to two ft_lstm_seq_* sequences otherwise.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -230,6 +232,131 @@ __device__ __forceinline__ void lstm2_fwd_body(const L2FwdP& p) {
     (L1 ? p.cell1 : p.cell0)[row * H + eu] = c_new;
 }
 
+// Both layers in ONE workgroup per 4 hidden units (grid H/4, one workgroup per CU at H = 1024).  The step kernels are bound
+// by the bytes each CU pulls through its vector-memory path (~40 GB/s per CU whatever the source: the chunk-skew experiment
+// priced a launch at ~2.5 us + 0.33 us per MB per... see DESIGN.md), and in the two-group layout every CU hosts one workgroup
+// of each group: 32 + 64 KiB of weight fragments plus THREE 64 KiB activation images (h0 twice, h1 once).  Here a wave
+// loads its h0 fragments once and feeds them to both W_hh0 (layer 0, step s) and W_ih1 (layer 1, step s-1): 224 KiB per CU
+// instead of 288.  Same per-wave accumulation order as the two-group kernel, hence bit-identical results.
+// Threads [0, MT*64) finish layer 0, [MT*64, 2*MT*64) layer 1 (MT <= 2).  One group of G = H/128 chunks per wave.
+template <int MT, int G>
+__global__ __launch_bounds__(256) void lstm2_fwd_both(L2FwdP p) {
+    __shared__ float red[2][4][MT * 16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    const int H = p.H, B = p.B;
+    const int blk = blockIdx.x, u0 = blk * 4, nchunk = H >> 5;
+    const int s0 = p.s, s1 = p.s - 1;                        // layer 0 / layer 1 time step of this launch
+    const bool on0 = s0 < p.T, on1 = s1 >= 0;                // uniform
+
+    constexpr int NROLE = MT * 64;
+    const bool L1 = tid >= NROLE;
+    const int rr = L1 ? tid - NROLE : tid;
+    const int eb = rr >> 2, ul = rr & 3, eu = u0 + ul;
+    const int s = L1 ? s1 : s0;
+    const bool ev = tid < 2 * NROLE && eb < B && (L1 ? on1 : on0);
+    const int ebc = eb < B ? eb : B - 1;
+    float* cst = L1 ? p.c1 : p.c0;
+    int len;
+    float gxv[4], c_old;
+    auto issue_epilogue_loads = [&]() {
+        len = p.lens[ebc];
+        if (L1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gxv[g] = p.bias1[(size_t)g * H + eu];
+        } else {
+            const int t_ld = on0 ? s0 : p.T - 1;
+            const float* gp = p.gx0 + ((size_t)t_ld * B + ebc) * 4 * H + eu;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gxv[g] = gp[(size_t)g * H];
+        }
+        c_old = cst[(size_t)ebc * H + eu];
+    };
+
+    f32x4 acc0[MT], acc1[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { acc0[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    {
+        const bf16x8* a0 = reinterpret_cast<const bf16x8*>(p.h0frag[s0 & 1]);          // h0[s0-1]: layer 0 recurrent = layer 1 input
+        const bf16x8* a1 = reinterpret_cast<const bf16x8*>(p.h1frag[(s1 + 2) & 1]);    // h1[s1-1]  ((s1+2)&1 == s1&1, >= 0)
+        const bf16x8* wf0 = reinterpret_cast<const bf16x8*>(p.w0frag) + (size_t)blk * nchunk * 64;
+        const bf16x8* wfi = reinterpret_cast<const bf16x8*>(p.w1frag) + (size_t)blk * 2 * nchunk * 64;
+        const bf16x8* wf1 = wfi + (size_t)nchunk * 64;
+        bf16x8 w0[G], wi[G], w1[G], a[G][MT];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const size_t c = (size_t)(wave + i * 4);
+            w0[i] = wf0[c * 64 + lane];
+            wi[i] = wfi[c * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[i][m] = a0[(c * MT + m) * 64 + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) w1[i] = wf1[(size_t)(wave + i * 4) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc0[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w0[i], acc0[m], 0, 0, 0);
+                acc1[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], wi[i], acc1[m], 0, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[i][m] = a1[((size_t)(wave + i * 4) * MT + m) * 64 + lane];
+        issue_epilogue_loads();                  // younger loads: never delay a fragment wait (vmcnt retires in order)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc1[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w1[i], acc1[m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[0][wave][m * 16 + kg * 4 + r][li] = acc0[m][r];
+            red[1][wave][m * 16 + kg * 4 + r][li] = acc1[m][r];
+        }
+    __syncthreads();
+    asm volatile("" ::"v"(gxv[0]), "v"(gxv[1]), "v"(gxv[2]), "v"(gxv[3]), "v"(c_old));
+    if (!ev) return;
+
+    const bool active = s < len;
+    float* y = L1 ? p.y1 : p.y0;
+    unsigned short* hnext = L1 ? p.h1frag[(s + 1) & 1] : p.h0frag[(s + 1) & 1];
+    const unsigned short* hprev = L1 ? p.h1frag[s & 1] : p.h0frag[s & 1];
+    const size_t row = (size_t)s * B + eb;
+    if (!active) {                                           // finished sample: zero pad row, frozen state
+        y[row * H + eu] = 0.f;
+        hnext[frag_index(eb, eu, MT)] = hprev[frag_index(eb, eu, MT)];
+        return;
+    }
+    const int lay = L1 ? 1 : 0;
+    float pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = g * 4 + ul;
+        float sum = gxv[g];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += red[lay][w][eb][n];
+        pre[g] = sum;
+    }
+    const float ig = 1.f / (1.f + expf(-pre[0]));
+    const float fg = 1.f / (1.f + expf(-pre[1]));
+    const float gg = tanhf(pre[2]);
+    const float og = 1.f / (1.f + expf(-pre[3]));
+    const float c_new = fg * c_old + ig * gg;
+    const float h_new = og * tanhf(c_new);
+    cst[(size_t)eb * H + eu] = c_new;
+    hnext[frag_index(eb, eu, MT)] = f2bf(h_new);
+    y[row * H + eu] = h_new;
+    float* gp = (L1 ? p.gates1 : p.gates0) + row * 4 * H + eu;
+    gp[0] = ig; gp[(size_t)H] = fg; gp[(size_t)2 * H] = gg; gp[(size_t)3 * H] = og;
+    (L1 ? p.cell1 : p.cell0)[row * H + eu] = c_new;
+}
+
 struct L2BwdP {
     const float* dy1; const int* lens;
     const float *gates1, *cell1, *gates0, *cell0;
@@ -423,9 +550,15 @@ extern "C" int ft_lstm2_seq_fwd(const float* gx0, const float* w_hh0, const floa
     dim3 grid(2 * (H >> 2));
     const int per8 = (H >> 5) / 8;          // chunks per wave with 8 waves (exact when H % 256 == 0)
     const bool w8 = false && (H % 256 == 0) && mt <= 2 && (per8 == 4 || per8 == 2 || per8 == 1);   // measured? no: 128-VGPR budget spills
+    static const bool both_off = [] { const char* e = getenv("FT_LSTM2_BOTH"); return e && e[0] == '0'; }();
+    const bool both = !both_off && mt <= 2 && (H >> 5) == 32;           // one group of 8 chunks per wave (H = 1024)
     for (int s = 0; s <= T; ++s) {
         p.s = s;
-        if (w8) {
+        if (both) {
+            if (mt == 1) hipLaunchKernelGGL((lstm2_fwd_both<1, 8>), dim3(H >> 2), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((lstm2_fwd_both<2, 8>), dim3(H >> 2), dim3(256), 0, st, p);
+        }
+        else if (w8) {
             if (per8 == 4) launch_fwd2_w8<4>(p, mt, grid, st);
             else if (per8 == 2) launch_fwd2_w8<2>(p, mt, grid, st);
             else launch_fwd2_w8<1>(p, mt, grid, st);
