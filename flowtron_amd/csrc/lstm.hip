@@ -97,35 +97,25 @@ __device__ __forceinline__ void skinny_f32(const float* const (&arow)[MT], const
 // bf16 fragment-order operands: wfrag -> [nchunk][64 lanes][8 bf16], afrag -> [nchunk][MT][64][8].
 // Chunks c0, c0+cs, ... ; G chunks are loaded back-to-back (all loads in flight) before their MFMAs issue, so a
 // wave pays the L2 round trip once per group instead of once per chunk.  Needs ((nchunk - c0) / cs) % G == 0.
-// wlane / wvalid: which lane slot of the weight image this lane reads and whether it reads at all -- a workgroup that owns
-// only 8 of the 16 columns of an image tile (HALF tiles of the backward step) touches 512 B per chunk (lanes 8..15 of a
-// 16-lane group repeat the addresses of lanes 0..7) and multiplies zeros in the other 8 MFMA columns.
 template <int MT, int G, typename Hook>
 __device__ __forceinline__ void skinny_bf16(const bf16x8* __restrict__ afrag, const bf16x8* __restrict__ wfrag,
                                             int nchunk, int c0, int cs, int lane, f32x4 (&acc)[MT], Hook&& after_last_loads,
-                                            int a_mt = MT, int wlane = -1, bool wvalid = true) {   // a_mt = m-tiles per k-chunk in the A image
-    if (wlane < 0) wlane = lane;
+                                            int a_mt = MT) {          // a_mt = m-tiles per k-chunk in the A image (>= MT)
     bf16x8 w[G], a[G][MT];
     auto load_group = [&](int cb) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const size_t c = (size_t)(cb + i * cs);
-            w[i] = wfrag[c * 64 + wlane];       // unconditional (a lane-masked load makes hipcc wait vmcnt(0) per load)
+            w[i] = wfrag[c * 64 + lane];
 #pragma unroll
             for (int m = 0; m < MT; ++m) a[i][m] = afrag[(c * a_mt + m) * 64 + lane];
         }
     };
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    const unsigned int mk = wvalid ? 0xffffffffu : 0u;       // bitwise mask, NOT a select: no lane-divergent control flow near MFMA
-    const u32x4 wmask = {mk, mk, mk, mk};
     auto mfma_group = [&]() {
 #pragma unroll
-        for (int i = 0; i < G; ++i) {
-            // lanes outside a half tile: duplicate address above, zero column here
-            const bf16x8 wv = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, w[i]) & wmask);
+        for (int i = 0; i < G; ++i)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], wv, acc[m], 0, 0, 0);
-        }
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w[i], acc[m], 0, 0, 0);
     };
     load_group(c0);
     for (int cb = c0 + cs * G; cb < nchunk; cb += cs * G) {      // (H = 1024: a single group, this loop is empty)
@@ -344,26 +334,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_matmul(BwdP p) {
 // grid = (H/16 unit tiles, MT_total/MT batch tiles): with B = 32 the two 16-row batch halves of a unit tile run as two
 // workgroups (same XCD: linear id = y*gridDim.x + x keeps x % 8), each streaming W (128 KB) + HALF of dgates (128 KB)
 // instead of one workgroup streaming 384 KB -- the step is bound by bytes per CU.
-// HALF: the workgroup owns 8 instead of 16 hidden units (grid.x = H/8).  The step is bound by the bytes a CU pulls through
-// its vector-memory path (W^T slice + the dgates image of its batch tile); with H/16 x mt = 128 workgroups half the chip
-// idles while each busy CU streams 128 + 128 KiB -- 256 half-tile workgroups stream 64 + 128 KiB each.
-template <int MT, int G, bool REV, bool HALF = false>
+template <int MT, int G, bool REV>
 __device__ __forceinline__ void lstm_bwd_body_bf16(const BwdP& p) {
     __shared__ float red[16][MT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
     const int H = p.H, B = p.B;
-    constexpr int NC = HALF ? 8 : 16;                      // hidden units (MFMA columns in use) per workgroup
-    const int j0 = blockIdx.x * NC;
-    const int tile16 = HALF ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int j0 = blockIdx.x * 16;
     const int m_base = blockIdx.y * MT, b_base = m_base * 16;
 
     // Roles as in the forward kernel: threads 0..MT*256-1 own one (batch row, unit) of the cell backward of step s; the
     // remaining waves (B <= 32) run the identical load sequence for step s-1 to warm this XCD's L2 for the next launch.
-    constexpr int NROLE = MT * 16 * NC;
+    constexpr int NROLE = MT * 256;
     const bool pf_role = (MT <= 2) && tid >= NROLE;
-    const int rr = pf_role ? (tid - NROLE) % NROLE : tid;
-    const int ebl = rr / NC, eb = b_base + ebl, jl = rr % NC, eu = j0 + jl;
+    const int rr = pf_role ? tid - NROLE : tid;
+    const int ebl = rr >> 4, eb = b_base + ebl, jl = rr & 15, eu = j0 + jl;
     const bool ev = !pf_role && tid < NROLE && eb < B;
     const int ebc = eb < B ? eb : B - 1;
     int len;
@@ -389,10 +374,9 @@ __device__ __forceinline__ void lstm_bwd_body_bf16(const BwdP& p) {
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
         const int nchunk = (4 * H) >> 5;
-        const int wl = HALF ? (kg * 16 + (int)(blockIdx.x & 1) * 8 + (li & 7)) : lane;
         skinny_bf16<MT, G>(reinterpret_cast<const bf16x8*>(p.dafrag_prev) + (size_t)m_base * 64,
-                           reinterpret_cast<const bf16x8*>(p.wTfrag) + (size_t)tile16 * nchunk * 64, nchunk, wave, 16, lane, acc,
-                           issue_epilogue_loads, p.MT, wl, !HALF || li < 8);
+                           reinterpret_cast<const bf16x8*>(p.wTfrag) + (size_t)blockIdx.x * nchunk * 64, nchunk, wave, 16, lane, acc,
+                           issue_epilogue_loads, p.MT);
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -429,8 +413,8 @@ __device__ __forceinline__ void lstm_bwd_body_bf16(const BwdP& p) {
 
 template <int MODE, int MT, int G, bool REV>
 __global__ __launch_bounds__(256) void lstm_fwd_step(FwdP p) { lstm_fwd_body<MODE, MT, G, REV>(p); }
-template <int MT, int G, bool REV, bool HALF>
-__global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) { lstm_bwd_body_bf16<MT, G, REV, HALF>(p); }
+template <int MT, int G, bool REV>
+__global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) { lstm_bwd_body_bf16<MT, G, REV>(p); }
 
 // Both directions of a bidirectional layer (the encoder BiLSTM, flowtron.py:488, :505-512) as ONE launch per step: the
 // two recurrences are independent, a step is latency-bound, so grid.z = 2 halves the launch count (z = 0 forward in time,
@@ -440,10 +424,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_pair(FwdP pf, FwdP pr) {
     if (blockIdx.z == 0) lstm_fwd_body<1, MT, G, false>(pf);
     else lstm_fwd_body<1, MT, G, true>(pr);
 }
-template <int G, bool HALF>
+template <int G>
 __global__ __launch_bounds__(1024) void lstm_bwd_pair(BwdP pf, BwdP pr) {
-    if (blockIdx.z == 0) lstm_bwd_body_bf16<1, G, false, HALF>(pf);
-    else lstm_bwd_body_bf16<1, G, true, HALF>(pr);
+    if (blockIdx.z == 0) lstm_bwd_body_bf16<1, G, false>(pf);
+    else lstm_bwd_body_bf16<1, G, true>(pr);
 }
 
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Ccols) {
@@ -510,10 +494,8 @@ void launch_fwd(const FwdP& p, bool fast, int g, int mt, dim3 grid, hipStream_t 
 }
 template <int G, bool REV>
 void launch_bwd_fused_r(const BwdP& p, int mt, dim3 grid, hipStream_t st) {
-    // one 16-row batch tile per workgroup: (H/16) x mt workgroups, or (H/8) x mt half-tile workgroups while that still
-    // fits one workgroup per CU (256): fewer bytes per CU and no idle CUs
-    if (grid.x * mt <= 128) hipLaunchKernelGGL((lstm_bwd_step_bf16<1, G, REV, true>), dim3(grid.x * 2, mt), dim3(1024), 0, st, p);
-    else hipLaunchKernelGGL((lstm_bwd_step_bf16<1, G, REV, false>), dim3(grid.x, mt), dim3(1024), 0, st, p);
+    // one 16-row batch tile per workgroup: (H/16) x mt workgroups
+    hipLaunchKernelGGL((lstm_bwd_step_bf16<1, G, REV>), dim3(grid.x, mt), dim3(1024), 0, st, p);
 }
 template <int G>
 void launch_bwd_fused_g(const BwdP& p, int mt, dim3 grid, hipStream_t st) {
@@ -766,24 +748,15 @@ extern "C" int ft_lstm_bidir_seq_bwd(const float* dy, int64_t ldy, const float* 
     hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh_f, cf.wTfrag, H);
     hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh_r, cr.wTfrag, H);
     dim3 grid(H / 16, mt, 2);
-    const bool half = (H / 16) * mt * 2 <= 128;        // half-tile workgroups while they still fit one per CU
     for (int s = T - 1; s >= 0; --s) {
         BwdP pf{dy, (long)ldy, lens, gates_f, cell_f, cf.part, cf.dc_carry, cf.da_cur, dgx_f, cf.wT, cf.part,
                 cf.dafrag[(s + 1) & 1], cf.dafrag[s & 1], cf.wTfrag, s, T, B, H, 0, mt};
         BwdP pr{dy + H, (long)ldy, lens, gates_r, cell_r, cr.part, cr.dc_carry, cr.da_cur, dgx_r, cr.wT, cr.part,
                 cr.dafrag[(s + 1) & 1], cr.dafrag[s & 1], cr.wTfrag, s, T, B, H, 1, mt};
-        if (half) {
-            const dim3 gh(grid.x * 2, grid.y, 2);
-            if (g == 8) hipLaunchKernelGGL((lstm_bwd_pair<8, true>), gh, dim3(1024), 0, st, pf, pr);
-            else if (g >= 4) hipLaunchKernelGGL((lstm_bwd_pair<4, true>), gh, dim3(1024), 0, st, pf, pr);
-            else if (g >= 2) hipLaunchKernelGGL((lstm_bwd_pair<2, true>), gh, dim3(1024), 0, st, pf, pr);
-            else hipLaunchKernelGGL((lstm_bwd_pair<1, true>), gh, dim3(1024), 0, st, pf, pr);
-        } else {
-            if (g == 8) hipLaunchKernelGGL((lstm_bwd_pair<8, false>), grid, dim3(1024), 0, st, pf, pr);
-            else if (g >= 4) hipLaunchKernelGGL((lstm_bwd_pair<4, false>), grid, dim3(1024), 0, st, pf, pr);
-            else if (g >= 2) hipLaunchKernelGGL((lstm_bwd_pair<2, false>), grid, dim3(1024), 0, st, pf, pr);
-            else hipLaunchKernelGGL((lstm_bwd_pair<1, false>), grid, dim3(1024), 0, st, pf, pr);
-        }
+        if (g == 8) hipLaunchKernelGGL(lstm_bwd_pair<8>, grid, dim3(1024), 0, st, pf, pr);
+        else if (g >= 4) hipLaunchKernelGGL(lstm_bwd_pair<4>, grid, dim3(1024), 0, st, pf, pr);
+        else if (g >= 2) hipLaunchKernelGGL(lstm_bwd_pair<2>, grid, dim3(1024), 0, st, pf, pr);
+        else hipLaunchKernelGGL(lstm_bwd_pair<1>, grid, dim3(1024), 0, st, pf, pr);
     }
     FT_CHECK_LAUNCH();
     return FT_OK;
