@@ -363,6 +363,7 @@ struct L2BwdP {
     float *dc1, *dc0, *dgx1, *dgx0;
     const unsigned short *wT1frag, *wT0frag, *wTi1frag;     // W_hh1^T, W_hh0^T, W_ih1^T images [H/16][4H/32][64][8]
     unsigned short *da1frag[2], *da0frag[2];                // dgates images over K = 4H: [4H/32][MT][64][8]
+    float* pbuf[2];                                         // skew-2 kernel: dgates1[t] W_ih1 for layer 0 step t, [MT*16][H] fp32 ping-pong
     int s, T, B, H, MT;
 };
 
@@ -459,6 +460,129 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void lstm2_fwd_step(L2FwdP p) { ls
 template <int G>
 __global__ __launch_bounds__(1024) void lstm2_bwd_step(L2BwdP p) { lstm2_bwd_body<G>(p); }
 
+// Backward wavefront with a skew of TWO launches.  In lstm2_bwd_body the layer-0 workgroups stream two K = 4H segments
+// (dgates1 W_ih1 + dgates0 W_hh0: 2 x 128 KiB of W^T and 2 x 128 KiB of dgates images) while the layer-1 workgroups stream
+// one -- and a step is bound by the bytes the busiest CU pulls through its vector-memory path.  The layer-1 workgroup
+// already holds the dgates1 image in registers, so it also multiplies it with its W_ih1^T tile and hands the product
+// (16 x 16 fp32) to layer 0 through memory; layer 0 picks it up one launch later (hence launch s = layer 1 step s,
+// layer 0 step s+2, T+2 launches).  Per workgroup: layer 1 128 + 256 KiB, layer 0 128 + 128 KiB, instead of 256 / 512.
+// Needs one group of G chunks per wave (4H/32 == 16 G).  grid = (2 * H/16, MT), 1024 threads.
+template <int G>
+__global__ __launch_bounds__(1024) void lstm2_bwd_skew2(L2BwdP p) {
+    __shared__ float red[16][16][17];
+    __shared__ float redp[16][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    const int H = p.H, B = p.B, ntile = H >> 4;
+    const bool L0 = (int)blockIdx.x >= ntile;
+    const int jt = L0 ? blockIdx.x - ntile : blockIdx.x;
+    const int s = L0 ? p.s + 2 : p.s;                       // this layer's time step
+    if (s < 0 || s >= p.T) return;
+    const int j0 = jt * 16;
+    const int m_base = blockIdx.y, b_base = m_base * 16;
+    const int nchunk = (4 * H) >> 5;
+
+    const int role = tid >> 8;                              // 0: cell backward, 1: (layer 1) hand-off writer, 2-3: L2 warm-up of the next rows
+    const int rr = tid & 255;
+    const int ebl = rr >> 4, eb = b_base + ebl, jl = rr & 15, eu = j0 + jl;
+    const bool ev = role == 0 && eb < B;
+    const int ebc = eb < B ? eb : B - 1;
+    const float* gates = L0 ? p.gates0 : p.gates1;
+    const float* cell = L0 ? p.cell0 : p.cell1;
+    float* dcar = L0 ? p.dc0 : p.dc1;
+    int len;
+    float ig, fg, gg, og, c_t, c_prev, dyv, dcc;
+    auto issue_epilogue_loads = [&]() {
+        len = p.lens[ebc];
+        const int t_ld = (role >= 2 && s >= 1) ? s - 1 : s;               // role-less waves: next launch's rows
+        int tp = t_ld - 1;
+        tp = tp < 0 ? 0 : tp;
+        const size_t row = (size_t)t_ld * B + ebc;
+        const float* gp = gates + row * 4 * H + eu;
+        ig = gp[0]; fg = gp[(size_t)H]; gg = gp[(size_t)2 * H]; og = gp[(size_t)3 * H];
+        c_t = cell[row * H + eu];
+        c_prev = cell[((size_t)tp * B + ebc) * H + eu];
+        // layer 1: external gradient; layer 0: the dgates1[s] W_ih1 product that layer 1 left one launch ago
+        dyv = L0 ? p.pbuf[(s + 1) & 1][(size_t)(b_base + ebl) * H + eu] : p.dy1[row * H + eu];
+        dcc = dcar[(size_t)ebc * H + eu];
+    };
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accp = {0.f, 0.f, 0.f, 0.f};
+    {
+        bf16x8 a[G], w0[G], w1[G];
+        if (!L0) {
+            const bf16x8* af = reinterpret_cast<const bf16x8*>(p.da1frag[(s + 1) & 1]) + (size_t)m_base * 64;   // dgates1[s+1]
+            const bf16x8* wa = reinterpret_cast<const bf16x8*>(p.wT1frag) + (size_t)jt * nchunk * 64;          // W_hh1^T
+            const bf16x8* wb = reinterpret_cast<const bf16x8*>(p.wTi1frag) + (size_t)jt * nchunk * 64;         // W_ih1^T
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const size_t c = (size_t)(wave + i * 16);
+                w0[i] = wa[c * 64 + lane];
+                a[i] = af[c * p.MT * 64 + lane];
+            }
+#pragma unroll
+            for (int i = 0; i < G; ++i) w1[i] = wb[(size_t)(wave + i * 16) * 64 + lane];
+            issue_epilogue_loads();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < G; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], w0[i], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < G; ++i) accp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], w1[i], accp, 0, 0, 0);
+        } else {
+            const bf16x8* af = reinterpret_cast<const bf16x8*>(p.da0frag[(s + 1) & 1]) + (size_t)m_base * 64;   // dgates0[s+1]
+            const bf16x8* wa = reinterpret_cast<const bf16x8*>(p.wT0frag) + (size_t)jt * nchunk * 64;          // W_hh0^T
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const size_t c = (size_t)(wave + i * 16);
+                w0[i] = wa[c * 64 + lane];
+                a[i] = af[c * p.MT * 64 + lane];
+            }
+            issue_epilogue_loads();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < G; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], w0[i], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[wave][kg * 4 + r][li] = acc[r];
+        redp[wave][kg * 4 + r][li] = accp[r];
+    }
+    __syncthreads();
+    asm volatile("" ::"v"(ig), "v"(fg), "v"(gg), "v"(og), "v"(c_t), "v"(c_prev), "v"(dyv), "v"(dcc));
+    if (role == 1 && !L0) {                                 // hand dgates1[s+1] W_ih1 (for layer 0 step s+1) to the next launch
+        float pv = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) pv += redp[w][ebl][jl];
+        p.pbuf[s & 1][(size_t)(b_base + ebl) * H + eu] = pv;
+        return;
+    }
+    if (!ev) return;
+    if (s == 0) c_prev = 0.f;
+    const bool active = s < len;
+
+    float da[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        float dh = dyv;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) dh += red[w][ebl][jl];
+        const float tc = tanhf(c_t);
+        const float dc = dh * og * (1.f - tc * tc) + dcc;
+        dcar[(size_t)eb * H + eu] = dc * fg;
+        da[0] = dc * gg * ig * (1.f - ig);
+        da[1] = dc * c_prev * fg * (1.f - fg);
+        da[2] = dc * ig * (1.f - gg * gg);
+        da[3] = dh * tc * og * (1.f - og);
+    }
+    float* dg = (L0 ? p.dgx0 : p.dgx1) + ((size_t)s * B + eb) * 4 * H + eu;     // inactive: pad row -> zeros
+    unsigned short* dan = L0 ? p.da0frag[s & 1] : p.da1frag[s & 1];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        dg[(size_t)g * H] = da[g];
+        dan[frag_index(eb, g * H + eu, p.MT)] = f2bf(da[g]);
+    }
+}
+
 inline size_t al256(size_t v) { return (v + 255) & ~size_t(255); }
 inline int group_of(int per_wave) { return (per_wave % 8 == 0) ? 8 : (per_wave % 4 == 0) ? 4 : (per_wave % 2 == 0) ? 2 : 1; }
 inline int mt_of(int B) { return B <= 16 ? 1 : (B <= 32 ? 2 : 4); }
@@ -506,6 +630,7 @@ inline Bwd2Setup setup_bwd2(void* work, int B, int H) {
     u.p.dc1 = cv.take<float>(BH * 4); u.p.dc0 = cv.take<float>(BH * 4);
     u.p.da1frag[0] = cv.take<unsigned short>(4 * frag_act); u.p.da1frag[1] = cv.take<unsigned short>(4 * frag_act);
     u.p.da0frag[0] = cv.take<unsigned short>(4 * frag_act); u.p.da0frag[1] = cv.take<unsigned short>(4 * frag_act);
+    u.p.pbuf[0] = cv.take<float>((size_t)mt * 16 * H * 4); u.p.pbuf[1] = cv.take<float>((size_t)mt * 16 * H * 4);
     u.state_bytes = cv.p - reinterpret_cast<char*>(work);
     u.t1 = cv.take<unsigned short>(wimg);
     u.t0 = cv.take<unsigned short>(wimg);
@@ -524,7 +649,7 @@ extern "C" size_t ft_lstm2_workspace_bytes(int B, int H) {
     const int mt = mt_of(B);
     const size_t BH = (size_t)B * H, frag_act = (size_t)mt * 16 * H * 2, wimg = (size_t)4 * H * H * 2;
     const size_t fwd = 2 * al256(BH * 4) + 4 * al256(frag_act) + al256(wimg) + al256(2 * wimg);
-    const size_t bwd = 2 * al256(BH * 4) + 4 * al256(4 * frag_act) + 3 * al256(wimg);
+    const size_t bwd = 2 * al256(BH * 4) + 4 * al256(4 * frag_act) + 2 * al256((size_t)mt * 16 * H * 4) + 3 * al256(wimg);
     return fwd > bwd ? fwd : bwd;
 }
 
@@ -593,6 +718,15 @@ extern "C" int ft_lstm2_seq_bwd(const float* dy1, const float* w_hh0, const floa
     hipLaunchKernelGGL(make_wfrag_bwd_t, dim3(2048), dim3(256), 0, st, w_ih1, ti, H, H);
     const int g = group_of(((4 * H) >> 5) / 16);
     dim3 grid(2 * (H >> 4), mt);
+    static const bool skew_off = [] { const char* e = getenv("FT_LSTM2_SKEW2"); return e && e[0] == '0'; }();
+    if (!skew_off && g == 8 && ((4 * H) >> 5) == 16 * 8) {     // one group of 8 chunks per wave (H = 1024): skew-2 hand-off kernel
+        for (int s = T - 1; s >= -2; --s) {
+            p.s = s;
+            hipLaunchKernelGGL(lstm2_bwd_skew2<8>, grid, dim3(1024), 0, st, p);
+        }
+        FT_CHECK_LAUNCH();
+        return FT_OK;
+    }
     for (int s = T - 1; s >= -1; --s) {
         p.s = s;
         if (g == 8) hipLaunchKernelGGL(lstm2_bwd_step<8>, grid, dim3(1024), 0, st, p);
