@@ -477,7 +477,9 @@ __global__ __launch_bounds__(1024) void lstm2_bwd_skew2(L2BwdP p) {
     const bool L0 = (int)blockIdx.x >= ntile;
     const int jt = L0 ? blockIdx.x - ntile : blockIdx.x;
     const int s = L0 ? p.s + 2 : p.s;                       // this layer's time step
-    if (s < 0 || s >= p.T) return;
+    // layer 1 also runs one launch past its last step (s = -1): layer 0 step 0 still needs dgates1[0] W_ih1
+    if (s >= p.T || s < (L0 ? 0 : -1)) return;
+    const bool cellwork = s >= 0;
     const int j0 = jt * 16;
     const int m_base = blockIdx.y, b_base = m_base * 16;
     const int nchunk = (4 * H) >> 5;
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(1024) void lstm2_bwd_skew2(L2BwdP p) {
     float ig, fg, gg, og, c_t, c_prev, dyv, dcc;
     auto issue_epilogue_loads = [&]() {
         len = p.lens[ebc];
-        const int t_ld = (role >= 2 && s >= 1) ? s - 1 : s;               // role-less waves: next launch's rows
+        const int t_ld = (role >= 2 && s >= 1) ? s - 1 : (s < 0 ? 0 : s);  // role-less waves: next launch's rows
         int tp = t_ld - 1;
         tp = tp < 0 ? 0 : tp;
         const size_t row = (size_t)t_ld * B + ebc;
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(1024) void lstm2_bwd_skew2(L2BwdP p) {
         p.pbuf[s & 1][(size_t)(b_base + ebl) * H + eu] = pv;
         return;
     }
-    if (!ev) return;
+    if (!ev || !cellwork) return;
     if (s == 0) c_prev = 0.f;
     const bool active = s < len;
 
