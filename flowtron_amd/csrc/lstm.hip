@@ -130,41 +130,6 @@ __device__ __forceinline__ void skinny_bf16(const bf16x8* __restrict__ afrag, co
     mfma_group();
 }
 
-// Half-tile variant (one m-tile, ONE group of G chunks per wave, G even): the workgroup owns 8 of the 16 columns of a
-// weight-image tile.  What bounds a step is the bytes RETURNED to a CU's lanes (lanes that merely repeat an address still
-// cost their 16 bytes), so the 8 idle lanes of each 16-lane group fetch the same columns of the NEXT chunk instead and hand
-// them over with a DPP row shift: G/2 weight loads instead of G.  half = which 8 columns.
-template <int G, typename Hook>
-__device__ __forceinline__ void skinny_bf16_half(const bf16x8* __restrict__ afrag, const bf16x8* __restrict__ wfrag,
-                                                 int c0, int cs, int lane, int half, f32x4& acc, Hook&& after_last_loads, int a_mt) {
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    const int li = lane & 15, kg = lane >> 4;
-    const int wl = kg * 16 + half * 8 + (li & 7);
-    const int hi = li >> 3;                                  // 0: this lane fetches the even chunk of a pair, 1: the odd one
-    u32x4 wp[G / 2];
-    bf16x8 a[G];
-#pragma unroll
-    for (int j = 0; j < G / 2; ++j) {
-        wp[j] = __builtin_bit_cast(u32x4, wfrag[(size_t)(c0 + (2 * j + hi) * cs) * 64 + wl]);
-        a[2 * j] = afrag[(size_t)(c0 + 2 * j * cs) * a_mt * 64 + lane];
-        a[2 * j + 1] = afrag[(size_t)(c0 + (2 * j + 1) * cs) * a_mt * 64 + lane];
-    }
-    after_last_loads();
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned int mk = hi ? 0u : 0xffffffffu;
-#pragma unroll
-    for (int j = 0; j < G / 2; ++j) {
-        u32x4 we, wo;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            we[d] = wp[j][d] & mk;                                                                  // even chunk: lanes 0..7 keep their own
-            wo[d] = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)wp[j][d], 0x108, 0xf, 0xf, true);   // row_shl:8: lane i <- lane i+8, else 0
-        }
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2 * j], __builtin_bit_cast(bf16x8, we), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2 * j + 1], __builtin_bit_cast(bf16x8, wo), acc, 0, 0, 0);
-    }
-}
-
 // element (b, k) of a [B, K] activation in fragment order
 __device__ __forceinline__ size_t frag_index(int b, int k, int MT) {
     const int c = k >> 5, kg = (k >> 3) & 3, e = k & 7, m = b >> 4, li = b & 15;
@@ -369,26 +334,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_matmul(BwdP p) {
 // grid = (H/16 unit tiles, MT_total/MT batch tiles): with B = 32 the two 16-row batch halves of a unit tile run as two
 // workgroups (same XCD: linear id = y*gridDim.x + x keeps x % 8), each streaming W (128 KB) + HALF of dgates (128 KB)
 // instead of one workgroup streaming 384 KB -- the step is bound by bytes per CU.
-// HALF: the workgroup owns 8 instead of 16 hidden units (grid.x = H/8).  The step is bound by the bytes a CU pulls through
-// its vector-memory path (W^T slice + the dgates image of its batch tile); with H/16 x mt = 128 workgroups half the chip
-// idles while each busy CU streams 128 + 128 KiB -- 256 half-tile workgroups stream 64 + 128 KiB each.
-template <int MT, int G, bool REV, bool HALF = false>
+template <int MT, int G, bool REV>
 __device__ __forceinline__ void lstm_bwd_body_bf16(const BwdP& p) {
     __shared__ float red[16][MT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
     const int H = p.H, B = p.B;
-    constexpr int NC = HALF ? 8 : 16;                      // hidden units (MFMA columns in use) per workgroup
-    const int j0 = blockIdx.x * NC;
-    const int tile16 = HALF ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int j0 = blockIdx.x * 16;
     const int m_base = blockIdx.y * MT, b_base = m_base * 16;
 
     // Roles as in the forward kernel: threads 0..MT*256-1 own one (batch row, unit) of the cell backward of step s; the
     // remaining waves (B <= 32) run the identical load sequence for step s-1 to warm this XCD's L2 for the next launch.
-    constexpr int NROLE = MT * 16 * NC;
+    constexpr int NROLE = MT * 256;
     const bool pf_role = (MT <= 2) && tid >= NROLE;
-    const int rr = pf_role ? (tid - NROLE) % NROLE : tid;
-    const int ebl = rr / NC, eb = b_base + ebl, jl = rr % NC, eu = j0 + jl;
+    const int rr = pf_role ? tid - NROLE : tid;
+    const int ebl = rr >> 4, eb = b_base + ebl, jl = rr & 15, eu = j0 + jl;
     const bool ev = !pf_role && tid < NROLE && eb < B;
     const int ebc = eb < B ? eb : B - 1;
     int len;
@@ -414,14 +374,9 @@ __device__ __forceinline__ void lstm_bwd_body_bf16(const BwdP& p) {
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
         const int nchunk = (4 * H) >> 5;
-        const bf16x8* af = reinterpret_cast<const bf16x8*>(p.dafrag_prev) + (size_t)m_base * 64;
-        const bf16x8* wf = reinterpret_cast<const bf16x8*>(p.wTfrag) + (size_t)tile16 * nchunk * 64;
-        if constexpr (HALF) {
-            static_assert(MT == 1 && G % 2 == 0, "half tiles: one m-tile, even group");
-            skinny_bf16_half<G>(af, wf, wave, 16, lane, (int)(blockIdx.x & 1), acc[0], issue_epilogue_loads, p.MT);   // needs nchunk == 16 G
-        } else {
-            skinny_bf16<MT, G>(af, wf, nchunk, wave, 16, lane, acc, issue_epilogue_loads, p.MT);
-        }
+        skinny_bf16<MT, G>(reinterpret_cast<const bf16x8*>(p.dafrag_prev) + (size_t)m_base * 64,
+                           reinterpret_cast<const bf16x8*>(p.wTfrag) + (size_t)blockIdx.x * nchunk * 64, nchunk, wave, 16, lane, acc,
+                           issue_epilogue_loads, p.MT);
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -458,8 +413,8 @@ __device__ __forceinline__ void lstm_bwd_body_bf16(const BwdP& p) {
 
 template <int MODE, int MT, int G, bool REV>
 __global__ __launch_bounds__(256) void lstm_fwd_step(FwdP p) { lstm_fwd_body<MODE, MT, G, REV>(p); }
-template <int MT, int G, bool REV, bool HALF>
-__global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) { lstm_bwd_body_bf16<MT, G, REV, HALF>(p); }
+template <int MT, int G, bool REV>
+__global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) { lstm_bwd_body_bf16<MT, G, REV>(p); }
 
 // Both directions of a bidirectional layer (the encoder BiLSTM, flowtron.py:488, :505-512) as ONE launch per step: the
 // two recurrences are independent, a step is latency-bound, so grid.z = 2 halves the launch count (z = 0 forward in time,
@@ -469,10 +424,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_pair(FwdP pf, FwdP pr) {
     if (blockIdx.z == 0) lstm_fwd_body<1, MT, G, false>(pf);
     else lstm_fwd_body<1, MT, G, true>(pr);
 }
-template <int G, bool HALF>
+template <int G>
 __global__ __launch_bounds__(1024) void lstm_bwd_pair(BwdP pf, BwdP pr) {
-    if (blockIdx.z == 0) lstm_bwd_body_bf16<1, G, false, HALF>(pf);
-    else lstm_bwd_body_bf16<1, G, true, HALF>(pr);
+    if (blockIdx.z == 0) lstm_bwd_body_bf16<1, G, false>(pf);
+    else lstm_bwd_body_bf16<1, G, true>(pr);
 }
 
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Ccols) {
@@ -539,15 +494,8 @@ void launch_fwd(const FwdP& p, bool fast, int g, int mt, dim3 grid, hipStream_t 
 }
 template <int G, bool REV>
 void launch_bwd_fused_r(const BwdP& p, int mt, dim3 grid, hipStream_t st) {
-    // one 16-row batch tile per workgroup: (H/16) x mt workgroups, or (H/8) x mt half-tile workgroups while that still
-    // fits one workgroup per CU (256): fewer bytes per CU and no idle CUs
-    if constexpr (G % 2 == 0) {
-        if (grid.x * mt <= 128 && ((4 * p.H) >> 5) == 16 * G) {
-            hipLaunchKernelGGL((lstm_bwd_step_bf16<1, G, REV, true>), dim3(grid.x * 2, mt), dim3(1024), 0, st, p);
-            return;
-        }
-    }
-    hipLaunchKernelGGL((lstm_bwd_step_bf16<1, G, REV, false>), dim3(grid.x, mt), dim3(1024), 0, st, p);
+    // one 16-row batch tile per workgroup: (H/16) x mt workgroups
+    hipLaunchKernelGGL((lstm_bwd_step_bf16<1, G, REV>), dim3(grid.x, mt), dim3(1024), 0, st, p);
 }
 template <int G>
 void launch_bwd_fused_g(const BwdP& p, int mt, dim3 grid, hipStream_t st) {
@@ -800,24 +748,15 @@ extern "C" int ft_lstm_bidir_seq_bwd(const float* dy, int64_t ldy, const float* 
     hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh_f, cf.wTfrag, H);
     hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh_r, cr.wTfrag, H);
     dim3 grid(H / 16, mt, 2);
-    // half-tile workgroups while they still fit one per CU (single group of an even number of chunks per wave)
-    const bool half = (H / 16) * mt * 2 <= 128 && (g == 8 || g == 4 || g == 2) && ((4 * H) >> 5) == 16 * g;
     for (int s = T - 1; s >= 0; --s) {
         BwdP pf{dy, (long)ldy, lens, gates_f, cell_f, cf.part, cf.dc_carry, cf.da_cur, dgx_f, cf.wT, cf.part,
                 cf.dafrag[(s + 1) & 1], cf.dafrag[s & 1], cf.wTfrag, s, T, B, H, 0, mt};
         BwdP pr{dy + H, (long)ldy, lens, gates_r, cell_r, cr.part, cr.dc_carry, cr.da_cur, dgx_r, cr.wT, cr.part,
                 cr.dafrag[(s + 1) & 1], cr.dafrag[s & 1], cr.wTfrag, s, T, B, H, 1, mt};
-        if (half) {
-            const dim3 gh(grid.x * 2, grid.y, 2);
-            if (g == 8) hipLaunchKernelGGL((lstm_bwd_pair<8, true>), gh, dim3(1024), 0, st, pf, pr);
-            else if (g >= 4) hipLaunchKernelGGL((lstm_bwd_pair<4, true>), gh, dim3(1024), 0, st, pf, pr);
-            else hipLaunchKernelGGL((lstm_bwd_pair<2, true>), gh, dim3(1024), 0, st, pf, pr);
-        } else {
-            if (g == 8) hipLaunchKernelGGL((lstm_bwd_pair<8, false>), grid, dim3(1024), 0, st, pf, pr);
-            else if (g >= 4) hipLaunchKernelGGL((lstm_bwd_pair<4, false>), grid, dim3(1024), 0, st, pf, pr);
-            else if (g >= 2) hipLaunchKernelGGL((lstm_bwd_pair<2, false>), grid, dim3(1024), 0, st, pf, pr);
-            else hipLaunchKernelGGL((lstm_bwd_pair<1, false>), grid, dim3(1024), 0, st, pf, pr);
-        }
+        if (g == 8) hipLaunchKernelGGL(lstm_bwd_pair<8>, grid, dim3(1024), 0, st, pf, pr);
+        else if (g >= 4) hipLaunchKernelGGL(lstm_bwd_pair<4>, grid, dim3(1024), 0, st, pf, pr);
+        else if (g >= 2) hipLaunchKernelGGL(lstm_bwd_pair<2>, grid, dim3(1024), 0, st, pf, pr);
+        else hipLaunchKernelGGL(lstm_bwd_pair<1>, grid, dim3(1024), 0, st, pf, pr);
     }
     FT_CHECK_LAUNCH();
     return FT_OK;
