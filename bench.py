@@ -126,7 +126,7 @@ def lstm_step_roofline(B, H, T, mode):
 
 
 def lstm2_step_roofline(B, H, T):
-    """Live timing of THE dominant kernel of the step (lstm2_fwd_step, flowtron_amd/csrc/lstm2.hip: ~21 % of the step):
+    """Live timing of THE dominant kernel of the step (lstm2_fwd_both, flowtron_amd/csrc/lstm2.hip: ~22 % of the step):
     T+1 launches of the two-layer wavefront chain bracketed by HIP events on the launch stream.  Algorithmic bytes per
     launch (steady state, DESIGN.md kernel table): bf16 fragment images of W_hh0 and [W_ih1|W_hh1] (4H*H*2 + 4H*2H*2),
     bf16 images of h0[s-1] and h1[s-2] in, gx0 row + bias1 in (fp32), cell state of both layers in+out (fp32), and per layer
@@ -161,8 +161,8 @@ def lstm2_step_roofline(B, H, T):
                         + 2 * 2 * 4 * B * H                        # cell state of both layers in + out
                         + 2 * (4 * (B * H + B * 4 * H + B * H) + 2 * bp * H))   # per layer: y, gates, cell out + h image out
     achieved = bytes_per_launch / (us * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": "lstm2_fwd_step", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic("lstm2_fwd_step"), "us_per_launch": round(us, 3),
+    return {"bound": "hbm", "kernel": "lstm2_fwd_both", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic("lstm2_fwd_both"), "us_per_launch": round(us, 3),
             "bytes_per_launch": bytes_per_launch}
 
 
