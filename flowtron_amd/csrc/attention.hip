@@ -209,12 +209,23 @@ __global__ __launch_bounds__(256) void attn_dqdk_k(const float* __restrict__ Q, 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = blockIdx.y, t0 = blockIdx.x * 32;
     const int len = min(in_lens[b], L);
+    int nz = 0;
     for (int idx = tid; idx < len * 32; idx += 256) {
         const int r = idx & 31, l = idx >> 5;
-        de_s[idx] = (t0 + r < T) ? de[((long)b * T + t0 + r) * L + l] : 0.f;
+        const float v = (t0 + r < T) ? de[((long)b * T + t0 + r) * L + l] : 0.f;
+        de_s[idx] = v;
+        nz |= (v != 0.f);
     }
-    __syncthreads();
     const int aw = blockIdx.z * 256 + w * 64;
+    if (!__syncthreads_or(nz)) {
+        // the whole 32-row tile carries no gradient (padded frames of a short utterance: ~30 % of the rows of a batch):
+        // dQ = 0, no contribution to dK / dv -- skip the tanh recomputation.  Exact: decided on the data, not on lengths.
+        const int a = aw + lane;
+        if (a < A)
+            for (int i = 0; i < 32; ++i)
+                if (t0 + i < T) dQ[((long)(t0 + i) * B + b) * A + a] = 0.f;
+        return;
+    }
     if (aw >= A) return;                // wave-uniform
     const int a = aw + lane;
     const bool av = a < A;
