@@ -308,7 +308,7 @@ extern "C" int ft_attention_bwd(const float* Q, const float* K, const float* v, 
     FT_CHECK_ARG(prior == nullptr || p_save != nullptr);
     FT_CHECK_ARG(B <= 65535);
     const size_t lds_q = sizeof(float) * ((size_t)L * 32);
-    if (lds_q > (size_t)MAX_LDS)
+    if (lds_q > (size_t)MAX_LDS - 1024)
         return ft_fail(FT_EUNSUPPORTED, "ft_attention_bwd: L=%d exceeds the LDS tile (%zu B)", L, lds_q);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float inv_temp = 1.0f / temperature;
@@ -318,7 +318,8 @@ extern "C" int ft_attention_bwd(const float* Q, const float* K, const float* v, 
     else
         hipLaunchKernelGGL(attn_softmax_bwd_k<false>, dim3(rows_grid), dim3(256), 0, st, attn, p_save, dattn, dlogprob, in_lens, de_work, T, B, L, inv_temp);
     // one tanh pass for dQ, dK and dv (separate dQ / dK kernels, each recomputing tanh: 73.8 vs 71.5 ms per training step)
-    FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dqdk_k), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+    if (lds_q > 48 * 1024)      // (the kernel also has a few static LDS bytes: ask for what this launch needs, not for all 160 KiB)
+        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dqdk_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
     FT_CHECK_HIP(hipMemsetAsync(dK, 0, sizeof(float) * (size_t)L * B * A, st));
     hipLaunchKernelGGL(attn_dqdk_k, dim3(cdiv(T, 32), B, cdiv(A, 256)), dim3(256), lds_q, st, Q, K, v, in_lens, de_work, dQ, dK, dv,
                        T, B, L, A);
