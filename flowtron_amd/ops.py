@@ -235,7 +235,7 @@ class LinearFn(torch.autograd.Function):
             d_img = _handoff_take(dpre) if ctx.act == L.ACT_NONE else None      # e.g. the LSTM backward already made it
             if d_img is None:
                 d_img = Bf16Image(dpre.reshape(rows, N), colsum=want_db)          # bias gradient rides on the conversion pass
-            db = d_img.colsum
+            db = d_img.colsum if want_db else None
         if want_db and db is None:
             db = colsum(dpre, rows, N, N)
         for i, x in enumerate(xs):
