@@ -19,7 +19,6 @@
 //              keep h_t (resp. dgates_t) in the same fragment order, so every operand load of a
 //              step is one fully coalesced 1 KiB global_load_dwordx4 per wave and the per-step L2
 //              traffic halves; v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Needs H % 32 == 0.
-#include <stdlib.h>
 #include <mutex>
 #include <unordered_map>
 
@@ -146,11 +145,9 @@ struct FwdP {
     int s, T, B, H, reverse;
 };
 
-// NW = waves per workgroup that split the k-chunks (4; 8 for the bf16 path at H = 1024: the per-CU fill rate of a step
-// grows with the number of waves that have loads in flight)
-template <int MODE, int MT, int G, bool REV, int NW = 4>
+template <int MODE, int MT, int G, bool REV>
 __device__ __forceinline__ void lstm_fwd_body(const FwdP& p) {
-    __shared__ float red[NW][MT * 16][17];
+    __shared__ float red[4][MT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
     const int u0 = blockIdx.x * 4;
@@ -163,8 +160,8 @@ __device__ __forceinline__ void lstm_fwd_body(const FwdP& p) {
     // count them, and because vmcnt retires in order and they are issued BEHIND the fragment loads, no fragment wait
     // ever includes their HBM round trip.
     constexpr int NROLE = MT * 64;
-    const bool pf_role = (MT <= 2 || NW > 4) && tid >= NROLE;
-    const int rr = pf_role ? (tid - NROLE) % NROLE : tid;
+    const bool pf_role = (MT <= 2) && tid >= NROLE;
+    const int rr = pf_role ? tid - NROLE : tid;
     const int eb = rr >> 2, ul = rr & 3, eu = u0 + ul;
     const bool ev = !pf_role && tid < NROLE && eb < B && eu < H;
     const int ebc = eb < B ? eb : B - 1, euc = eu < H ? eu : H - 1;
@@ -195,11 +192,11 @@ __device__ __forceinline__ void lstm_fwd_body(const FwdP& p) {
             int b = m * 16 + li;
             arow[m] = (b < B) ? p.hprev + (size_t)b * H : nullptr;
         }
-        skinny_f32<MT>(arow, wrow, H, wave, NW, kg, acc);
+        skinny_f32<MT>(arow, wrow, H, wave, 4, kg, acc);
     } else {
         const int nchunk = H >> 5;
         skinny_bf16<MT, G>(reinterpret_cast<const bf16x8*>(p.hfrag_prev),
-                           reinterpret_cast<const bf16x8*>(p.wfrag) + (size_t)blockIdx.x * nchunk * 64, nchunk, wave, NW, lane, acc,
+                           reinterpret_cast<const bf16x8*>(p.wfrag) + (size_t)blockIdx.x * nchunk * 64, nchunk, wave, 4, lane, acc,
                            issue_epilogue_loads);
     }
 #pragma unroll
@@ -224,10 +221,7 @@ __device__ __forceinline__ void lstm_fwd_body(const FwdP& p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int n = g * 4 + ul;
-        float sum = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) sum += red[w][eb][n];
-        pre[g] = sum + gxv[g];
+        pre[g] = red[0][eb][n] + red[1][eb][n] + red[2][eb][n] + red[3][eb][n] + gxv[g];
     }
     const float ig = 1.f / (1.f + expf(-pre[0]));
     const float fg = 1.f / (1.f + expf(-pre[1]));
@@ -419,8 +413,6 @@ __device__ __forceinline__ void lstm_bwd_body_bf16(const BwdP& p) {
 
 template <int MODE, int MT, int G, bool REV>
 __global__ __launch_bounds__(256) void lstm_fwd_step(FwdP p) { lstm_fwd_body<MODE, MT, G, REV>(p); }
-template <int MT, int G, bool REV, int NW>
-__global__ __launch_bounds__(NW * 64) void lstm_fwd_step_w(FwdP p) { lstm_fwd_body<1, MT, G, REV, NW>(p); }
 template <int MT, int G, bool REV>
 __global__ __launch_bounds__(1024) void lstm_bwd_step_bf16(BwdP p) { lstm_bwd_body_bf16<MT, G, REV>(p); }
 
@@ -493,24 +485,8 @@ void launch_fwd_g(const FwdP& p, int mt, dim3 grid, hipStream_t st) {
     if (p.reverse) launch_fwd_r<MODE, G, true>(p, mt, grid, st);
     else launch_fwd_r<MODE, G, false>(p, mt, grid, st);
 }
-template <bool REV>
-void launch_fwd_wide(const FwdP& p, int mt, int nw, dim3 grid, hipStream_t st) {
-    if (nw == 8) {
-        if (mt == 1) hipLaunchKernelGGL((lstm_fwd_step_w<1, 4, REV, 8>), grid, dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((lstm_fwd_step_w<2, 4, REV, 8>), grid, dim3(512), 0, st, p);
-    } else {
-        if (mt == 1) hipLaunchKernelGGL((lstm_fwd_step_w<1, 2, REV, 16>), grid, dim3(1024), 0, st, p);
-        else hipLaunchKernelGGL((lstm_fwd_step_w<2, 2, REV, 16>), grid, dim3(1024), 0, st, p);
-    }
-}
 void launch_fwd(const FwdP& p, bool fast, int g, int mt, dim3 grid, hipStream_t st) {
     if (!fast) { launch_fwd_g<0, 1>(p, mt, grid, st); return; }
-    static const int wide = [] { const char* e = getenv("FT_LSTM_FWD_WAVES"); return e ? atoi(e) : 4; }();
-    if ((wide == 8 || wide == 16) && mt <= 2 && (p.H >> 5) == 32) {     // H = 1024: 32 chunks over 8 / 16 waves
-        if (p.reverse) launch_fwd_wide<true>(p, mt, wide, grid, st);
-        else launch_fwd_wide<false>(p, mt, wide, grid, st);
-        return;
-    }
     if (g == 8 && mt <= 2) launch_fwd_g<1, 8>(p, mt, grid, st);     // 8 chunks x MT<=2 fragments fit the 256-thread VGPR budget
     else if (g >= 4) launch_fwd_g<1, 4>(p, mt, grid, st);
     else if (g == 2) launch_fwd_g<1, 2>(p, mt, grid, st);
