@@ -535,3 +535,38 @@ def test_rccl_process_group_single_rank_step():
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+@pytest.mark.parametrize("out_lens,in_lens", [([3, 2, 1], [2, 1, 1]), ([40] * 33, [9] * 33), ([70, 1], [13, 1])])
+def test_bf16_full_width_edge_shapes_match_plain_paths(out_lens, in_lens):
+    """Full-width model (H = 1024) in bf16 mode at awkward sizes -- T = 3, a 1-frame / 1-token utterance, B = 33 (three
+    16-row MFMA tiles: the both-layer forward kernel does not apply, the skew-2 backward runs with mt = 4) -- new paths
+    (image GEMMs, wavefront chain variants, pair chain) against the plain bf16 paths: loss and every gradient."""
+    import flowtron
+    from flowtron_amd import ops
+    from oracle import synth
+    cfg = dict(synth.DEFAULT_MODEL_CONFIG, n_text=40)
+    b = cuda_batch(synth.make_batch(cfg, out_lens, in_lens, seed=9, with_prior=True))
+    res = {}
+    try:
+        for name, new_paths in (("new", True), ("plain", False)):
+            ops._BF16_IMAGES = new_paths
+            os.environ.update(FLOWTRON_LSTM2="1" if new_paths else "0", FLOWTRON_BILSTM="1" if new_paths else "0")
+            m, _ = build(cfg, 9, "bf16")
+            crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)
+            out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+            nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+            (nll + gl + 0.01 * ctc).sum().backward()
+            torch.cuda.synchronize()
+            res[name] = (nll.item(), gl.item(), ctc.item(), {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()})
+    finally:
+        ops._BF16_IMAGES = True
+        os.environ.update(FLOWTRON_MFMA="f32", FLOWTRON_LSTM2="1", FLOWTRON_BILSTM="1")
+    for i in range(3):
+        assert abs(res["new"][i] - res["plain"][i]) <= 2e-3 * max(1.0, abs(res["plain"][i])), (i, res["new"][i], res["plain"][i])
+    worst = ("", 0.0)
+    for k, r in res["plain"][3].items():
+        e = (res["new"][3][k] - r).norm().item() / max(r.norm().item(), 1e-4 * r.numel() ** 0.5)
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < 3e-2, worst

@@ -223,3 +223,28 @@ def test_length_bucket_batch_sampler_partitions_and_cuts_padding():
     e0 = list(s0)
     s0.set_epoch(1)
     assert list(s0) != e0 and list(LengthBucketBatchSampler(lengths, B, seed=7)) == e0
+
+
+def test_workspace_size_queries_run_without_a_gpu():
+    """Pure host functions of the C ABI (no kernel launch, no device memory): the geometry they promise to callers."""
+    import ctypes as C
+    from flowtron_amd import _lib as L
+    lib = L.lib()
+    up = lambda v, m: (v + m - 1) // m * m
+    for rows, cols in ((1, 1), (27584, 4096), (300, 80), (4096, 1664)):
+        assert lib.ft_bf16_image_bytes(rows, cols) == up(up(rows + 32, 128) * up(cols, 128) * 2, 256)
+    assert lib.ft_bf16_image_bytes(0, 5) == 0
+    # ft_gemm_workspace_bytes: zero for fp32 mode / batched / small problems, image bytes of both operands otherwise
+    a = L.GemmArgs(None, None, None, None, 27584, 4096, 1664, 1, 1664, 1, 1, 1664, 4096, 0, 0, 0, 1.0, 0.0, 0, L.FT_BF16, 0, None, 0)
+    need = lib.ft_gemm_workspace_bytes(C.byref(a))
+    assert need == up(up(27584, 128) * up(1664, 32) * 2, 256) + up(up(4096, 128) * up(1664, 32) * 2, 256)
+    a.mode = L.FT_F32
+    assert lib.ft_gemm_workspace_bytes(C.byref(a)) == 0
+    a.mode, a.batch = L.FT_BF16, 4
+    assert lib.ft_gemm_workspace_bytes(C.byref(a)) == 0
+    a.batch, a.M, a.N, a.K = 1, 16, 16, 16
+    assert lib.ft_gemm_workspace_bytes(C.byref(a)) == 0
+    assert lib.ft_lstm2_supported(32, 1024) == 1 and lib.ft_lstm2_supported(65, 1024) == 0 and lib.ft_lstm2_supported(8, 100) == 0
+    assert lib.ft_lstm_bidir_supported(32, 256) == 1 and lib.ft_lstm_bidir_supported(32, 96) == 0
+    assert lib.ft_lstm2_workspace_bytes(32, 1024) > 3 * 4 * 1024 * 1024 * 2          # three bf16 weight images + state
+    assert lib.ft_attn_ctc_workspace_floats(2, 10, 5) == 2 * 2 * 10 * 11 + 2 * 10 + 2
