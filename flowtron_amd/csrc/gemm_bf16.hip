@@ -339,7 +339,7 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
     const long tiles = (long)p.gx * p.gy;
     long s = 1;
     if (can_split && tiles < 512) {
-        s = 768 / tiles;
+        s = 1024 / tiles;                  // fill all 4 workgroup slots of the 256 CUs
         const long smax = K / 512;
         if (s > smax) s = smax;
         if (s > 64) s = 64;
