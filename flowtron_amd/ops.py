@@ -76,6 +76,32 @@ class Bf16Image:
         return self.buf.data_ptr() + 2 * (row_off * self.ld + col_off)
 
 
+# images of activations are shared between every consumer of the SAME tensor (h_att feeds the query projection, the gate and
+# the decoder input projection; an LSTM output also feeds its own dW_hh GEMM in backward): keyed by tensor identity
+# (id + weakref + version), dropped with the tensor.
+import weakref as _weakref
+_IMG_CACHE = {}
+
+
+def shared_image(t, rows, cols):
+    """bf16 image of the fp32 tensor `t` viewed as [rows, cols]; one conversion per tensor (version)."""
+    key = id(t)
+    hit = _IMG_CACHE.get(key)
+    if hit is not None:
+        ref, ver, img = hit
+        if ref() is t and ver == t._version and img.rows == rows and img.cols == cols:
+            return img
+    img = Bf16Image(t.reshape(rows, cols))
+    if len(_IMG_CACHE) > 64:                     # dead entries (their tensors are gone) are swept lazily
+        for k in [k for k, (r, _, _) in _IMG_CACHE.items() if r() is None]:
+            del _IMG_CACHE[k]
+    try:
+        _IMG_CACHE[key] = (_weakref.ref(t, lambda _r, k=key: _IMG_CACHE.pop(k, None)), t._version, img)
+    except TypeError:
+        pass
+    return img
+
+
 def images_apply(mode, M, N, K):
     """same rule as ft_gemm_workspace_bytes: bf16 mode and a GEMM large enough to amortise the image passes."""
     return _BF16_IMAGES and mode == L.FT_BF16 and M >= 32 and N >= 32 and K >= 16 and M * N * K >= (1 << 20)
@@ -192,7 +218,7 @@ class LinearFn(torch.autograd.Function):
         ctx.imgs = None
         if use_img:
             w_img = Bf16Image(W)
-            x_imgs = [Bf16Image(x.reshape(rows, x.shape[-1])) for x in xs]
+            x_imgs = [shared_image(x, rows, x.shape[-1]) for x in xs]
             ctx.imgs = (w_img, x_imgs)          # reused by backward (dX reads W k-major, dW reads x k-major)
         off = 0
         for i, x in enumerate(xs):
@@ -408,7 +434,7 @@ class LSTMSeqFn(torch.autograd.Function):
                 dW = torch.zeros_like(w_hh)
                 if T > 1 and images_apply(ctx.mode, 4 * H, H, rows):
                     # images of dgates / outputs over all T*B rows; the one-step shift is a row offset into them
-                    d_img, y_img = Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True), Bf16Image(y.reshape(T * B, H))
+                    d_img, y_img = Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True), shared_image(y, T * B, H)
                     fwd = not ctx.reverse
                     gemm_img(d_img, 1, d_img.ptr(B if fwd else 0), y_img, 1, y_img.ptr(0 if fwd else B), dW, 4 * H, H, rows, H, splitk=True)
                     _handoff_put(dgx, d_img)        # the input projection's backward reads the same dgates
@@ -900,7 +926,7 @@ class LSTM2SeqFn(torch.autograd.Function):
             # four images serve the three weight-gradient GEMMs (the one-step shift is a row offset) and, through the
             # hand-off, the dX / dW GEMMs of the layer-0 input projection
             d0, d1 = Bf16Image(dgx0.reshape(rows, 4 * H), colsum=True), Bf16Image(dgx1.reshape(rows, 4 * H), colsum=True)
-            i0, i1 = Bf16Image(y0.reshape(rows, H)), Bf16Image(y1.reshape(rows, H))
+            i0, i1 = Bf16Image(y0.reshape(rows, H)), shared_image(y1, rows, H)
             gemm_img(d0, 1, d0.ptr(B), i0, 1, i0.ptr(), dW_hh0, 4 * H, H, r1, H, splitk=True)
             gemm_img(d1, 1, d1.ptr(B), i1, 1, i1.ptr(), dW_hh1, 4 * H, H, r1, H, splitk=True)
             gemm_img(d1, 1, d1.ptr(), i0, 1, i0.ptr(), dW_ih1, 4 * H, H, rows, H, splitk=True)
