@@ -131,40 +131,42 @@ typedef __attribute__((ext_vector_type(4))) short bf16x4;
 //        row c (probed on gfx950: scripts/exp/tr_probe.hip).  Bank swizzle on the DMA source: the 16-byte piece c of image
 //        row (kq, r) lands in slot c ^ 2*s, s = ((r>>1)&1) ^ ((kq&1)<<1), which spreads the four k-rows of a read and the two
 //        k-groups of a 32-lane half over distinct 32-byte bank groups.
-template <bool KM>
+template <bool KM, int RT = 128>              // RT = rows of the workgroup tile this operand covers (128, or 256 for A)
 struct Operand {
-    const unsigned short* src[2];          // this lane's DMA source for its wave's two sub-tiles (k-step 0)
-    size_t kstride;                        // elements to advance per k-step
-    int dst[2];                            // byte offsets of the two sub-tiles inside the operand's stage buffer
-    int roff;                              // this lane's fragment read offset (without the tile term)
+    static constexpr int NS = RT / 64;         // sub-tiles (DMAs) per wave and stage
+    static constexpr int WT = RT / 32;         // 16-row fragments per wave tile (wave tile = RT/2 rows)
+    const unsigned short* src[NS];             // this lane's DMA source for its wave's sub-tiles (k-step 0)
+    size_t kstride;                            // elements to advance per k-step
+    int dst[NS];                               // byte offsets of those sub-tiles inside the operand's stage buffer
+    int roff;                                  // this lane's fragment read offset (without the fragment term)
     __device__ __forceinline__ void init(const unsigned short* img, long ld, int r0, int wave, int lane, int wsel) {
         const int li = lane & 15, kg = lane >> 4;
         if constexpr (!KM) {
             const int srow = lane >> 2, skp = (lane & 3) ^ ((lane >> 4) & 2);
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                src[g] = img + (size_t)(r0 + wave * 32 + g * 16 + srow) * ld + skp * 8;
-                dst[g] = (wave * 2 + g) << 10;
+            for (int g = 0; g < NS; ++g) {
+                src[g] = img + (size_t)(r0 + (wave * NS + g) * 16 + srow) * ld + skp * 8;
+                dst[g] = (wave * NS + g) << 10;
             }
             kstride = 32;
-            roff = (wsel * 4 << 10) + (li * 4 + (kg ^ ((li >> 2) & 2))) * 16;
+            roff = (wsel * WT << 10) + (li * 4 + (kg ^ ((li >> 2) & 2))) * 16;
         } else {
             const int r = lane >> 3, kq = wave;
             const int s = ((lane >> 4) & 1) ^ ((kq & 1) << 1);
             const int c = (lane & 7) ^ (2 * s);
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < NS; ++g) {
                 src[g] = img + (size_t)(kq * 8 + r) * ld + r0 + g * 64 + c * 8;
                 dst[g] = (g * 4 + kq) << 10;
             }
             kstride = (size_t)32 * ld;
             const int sr = ((li >> 3) & 1) ^ ((kg & 1) << 1);
-            roff = ((wsel * 4 + kg) << 10) + (li >> 2) * 128 + sr * 32 + (li & 3) * 8;
+            roff = ((wsel * (WT / 4) * 4 + kg) << 10) + (li >> 2) * 128 + sr * 32 + (li & 3) * 8;
         }
     }
     __device__ __forceinline__ void issue(unsigned char* sbuf, int t) const {
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < NS; ++g)
             __builtin_amdgcn_global_load_lds((glb_void*)(src[g] + (size_t)t * kstride), (lds_void*)(sbuf + dst[g]), 16, 0, 0);
     }
     // k-contiguous image: the whole fragment is one ds_read_b128 (compiler-scheduled)
@@ -175,7 +177,7 @@ struct Operand {
     // vmcnt(0) before the first LDS read of every k-step, which drains the DMAs of the NEXT stage that were just issued; the
     // caller retires the reads with tr_wait() (the "+v" operands order every consumer behind the wait).
     __device__ __forceinline__ void tr_issue(const unsigned char* sbuf, int i, bf16x4& lo, bf16x4& hi) const {
-        const unsigned int a = (unsigned int)(size_t)(lds_void*)(sbuf + (roff ^ (i * 32)));
+        const unsigned int a = (unsigned int)(size_t)(lds_void*)(sbuf + ((roff + ((i >> 2) << 12)) ^ ((i & 3) * 32)));
         asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(hi) : "v"(a));
     }
@@ -184,15 +186,27 @@ struct Operand {
 __device__ __forceinline__ void tr_wait(bf16x4 (&t)[8]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
 }
+__device__ __forceinline__ void tr_wait(bf16x4 (&t)[16]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
+                 "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15]));
+}
+__device__ __forceinline__ void tr_wait(bf16x4 (&t)[16], bf16x4 (&u)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
+                 "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15]),
+                 "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]));
+}
 __device__ __forceinline__ void tr_wait(bf16x4 (&t)[8], bf16x4 (&u)[8]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
                  "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]));
 }
 
-template <bool AKM, bool BKM, bool SPLIT>
-__global__ __launch_bounds__(256, 4) void gemm_bf16_k(BfP p) {
-    constexpr int OPB = 8192;                          // bytes per operand per stage
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * OPB];     // [stage][A | B]
+// RTA = rows of the workgroup tile (128, or 256: wave tile 128 x 64 = 8 x 4 MFMA tiles -- 12 fragment reads feed 32 MFMAs instead of
+// 8 feeding 16, which takes the LDS pipe off the critical path; 2 workgroups per CU, 196 VGPRs)
+template <bool AKM, bool BKM, bool SPLIT, int RTA>
+__global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
+    constexpr int OPA = RTA * 64, OPB = 8192;          // bytes per operand per stage
+    constexpr int TI = RTA / 32;                       // 16-row fragments of the wave tile along M
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (OPA + OPB)];     // [stage][A | B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, kg = lane >> 4;
@@ -202,12 +216,12 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_k(BfP p) {
         const int xcd = tile & 7, idx = tile >> 3;
         tile = xcd * q + (xcd < r ? xcd : r) + idx;
     }
-    const int m0 = (tile / p.gx) * TB, n0 = (tile % p.gx) * TB;
+    const int m0 = (tile / p.gx) * RTA, n0 = (tile % p.gx) * TB;
     const int t0 = blockIdx.y * p.ksteps;
     const int t1 = (t0 + p.ksteps < p.nk) ? t0 + p.ksteps : p.nk;
 
-    Operand<AKM> oa;
-    Operand<BKM> ob;
+    Operand<AKM, RTA> oa;
+    Operand<BKM, 128> ob;
     oa.init(p.A, p.lda, m0, wave, lane, wm);
     ob.init(p.B, p.ldb, n0, wave, lane, wn);
 
@@ -215,29 +229,29 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_k(BfP p) {
     //         in the MFMA so that a lane owns four CONSECUTIVE output columns: float4 stores / loads in the epilogue)
     //  SPLIT: natural order, register r <-> C[m = i*16 + kg*4 + r][n = j*16 + li]: one atomic instruction then covers 16
     //         consecutive columns of 4 rows (4 cache lines) instead of 4 columns of 16 rows (measured 20-60 % faster)
-    f32x4 acc[4][4];
+    f32x4 acc[TI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (t0 < t1) { oa.issue(smem, t0); ob.issue(smem + OPB, t0); }
+    if (t0 < t1) { oa.issue(smem, t0); ob.issue(smem + OPA, t0); }
     for (int t = t0; t < t1; ++t) {
         const int stage = (t - t0) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my DMAs of step t have landed
         __syncthreads();                                            // ... everyone's have; stage^1 is no longer being read
         if (t + 1 < t1) {
-            unsigned char* nx = smem + (stage ^ 1) * 2 * OPB;
+            unsigned char* nx = smem + (stage ^ 1) * (OPA + OPB);
             oa.issue(nx, t + 1);
-            ob.issue(nx + OPB, t + 1);
+            ob.issue(nx + OPA, t + 1);
         }
-        const unsigned char* sa = smem + stage * 2 * OPB;
-        const unsigned char* sb = sa + OPB;
-        bf16x8 a[4], b[4];
-        bf16x4 ta[8], tb[8];
+        const unsigned char* sa = smem + stage * (OPA + OPB);
+        const unsigned char* sb = sa + OPA;
+        bf16x8 a[TI], b[4];
+        bf16x4 ta[2 * TI], tb[8];
         if constexpr (!AKM) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = oa.frag(sa, i);
+            for (int i = 0; i < TI; ++i) a[i] = oa.frag(sa, i);
         }
         if constexpr (!BKM) {
 #pragma unroll
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_k(BfP p) {
         }
         if constexpr (AKM) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) oa.tr_issue(sa, i, ta[2 * i], ta[2 * i + 1]);
+            for (int i = 0; i < TI; ++i) oa.tr_issue(sa, i, ta[2 * i], ta[2 * i + 1]);
         }
         if constexpr (BKM) {
 #pragma unroll
@@ -256,14 +270,14 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_k(BfP p) {
         else if constexpr (BKM) tr_wait(tb);
         if constexpr (AKM) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = __builtin_shufflevector(ta[2 * i], ta[2 * i + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+            for (int i = 0; i < TI; ++i) a[i] = __builtin_shufflevector(ta[2 * i], ta[2 * i + 1], 0, 1, 2, 3, 4, 5, 6, 7);
         }
         if constexpr (BKM) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = __builtin_shufflevector(tb[2 * j], tb[2 * j + 1], 0, 1, 2, 3, 4, 5, 6, 7);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if constexpr (SPLIT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
@@ -273,10 +287,10 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_k(BfP p) {
 
     if constexpr (SPLIT) {          // C was zeroed (beta == 0) or holds the addend (beta == 1)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + kg * 4 + r;
+                const int row = m0 + wm * (RTA / 2) + i * 16 + kg * 4 + r;
                 if (row >= p.M) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -292,8 +306,8 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_k(BfP p) {
 
     const bool vec = p.vec_c != 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = m0 + wm * 64 + i * 16 + li;
+    for (int i = 0; i < TI; ++i) {
+        const int row = m0 + wm * (RTA / 2) + i * 16 + li;
         if (row >= p.M) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -321,25 +335,39 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_k(BfP p) {
 }
 
 template <bool AKM, bool BKM>
-void launch_s(const BfP& p, dim3 grid, hipStream_t st) {
-    if (p.splits > 1) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false>), grid, dim3(256), 0, st, p);
+void launch_s(const BfP& p, dim3 grid, bool big, hipStream_t st) {
+    if (big) {
+        if (p.splits > 1) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, true, 256>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 256>), grid, dim3(256), 0, st, p);
+    } else {
+        if (p.splits > 1) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, true, 128>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 128>), grid, dim3(256), 0, st, p);
+    }
 }
 
 // images -> C.  a_km / b_km: the operand image is k-major ([k][row]) instead of k-contiguous ([row][k]).
+// Images are padded to multiples of 256 in both dimensions (ft_bf16_image), so either tile height may run off the logical M.
 int run_images(const unsigned short* A, long lda, int a_km, const unsigned short* B, long ldb, int b_km, float* C, long ldc,
                const float* bias, int M, int N, int K, float alpha, float beta, int act, int flags, hipStream_t st) {
+    static const int force_tile = [] { const char* e = getenv("FT_GEMM_BF16_TILE"); return e ? atoi(e) : 0; }();
     BfP p;
     p.A = A; p.B = B; p.C = C; p.bias = bias;
     p.M = M; p.N = N; p.nk = cdiv(K, 32); p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.beta = beta; p.act = act;
-    p.gx = cdiv(N, TB); p.gy = cdiv(M, TB);
-    p.vec_c = (reinterpret_cast<uintptr_t>(C) % 16 == 0 && ldc % 4 == 0) ? 1 : 0;
     const bool can_split = (flags & FT_GEMM_SPLITK) && act == FT_ACT_NONE && (beta == 0.f || beta == 1.f) && K >= 2048;
+    // 256 x 128 workgroup tiles (2 per CU) when they still fill the chip, possibly with split-K; else 128 x 128 (4 per CU)
+    const long tiles_big = (long)cdiv(M, 256) * cdiv(N, TB);
+    bool big = M >= 512 && (tiles_big >= 384 || (can_split && tiles_big * (K / 512) >= 384));
+    if (force_tile == 128) big = false;
+    if (force_tile == 256) big = M >= 256;
+    const int RTA = big ? 256 : TB;
+    const long slots = big ? 512 : 1024;
+    p.gx = cdiv(N, TB); p.gy = cdiv(M, RTA);
+    p.vec_c = (reinterpret_cast<uintptr_t>(C) % 16 == 0 && ldc % 4 == 0) ? 1 : 0;
     const long tiles = (long)p.gx * p.gy;
     long s = 1;
-    if (can_split && tiles < 512) {
-        s = 1024 / tiles;                  // fill all 4 workgroup slots of the 256 CUs
+    if (can_split && tiles < slots / 2) {
+        s = slots / tiles;                     // fill all workgroup slots of the 256 CUs
         const long smax = K / 512;
         if (s > smax) s = smax;
         if (s > 64) s = 64;
@@ -349,8 +377,8 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
     p.splits = cdiv(p.nk, p.ksteps);
     if (p.splits > 1 && beta == 0.f) FT_CHECK_HIP(hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, st));
     const dim3 grid(p.gx * p.gy, p.splits);
-    if (a_km) { if (b_km) launch_s<true, true>(p, grid, st); else launch_s<true, false>(p, grid, st); }
-    else      { if (b_km) launch_s<false, true>(p, grid, st); else launch_s<false, false>(p, grid, st); }
+    if (a_km) { if (b_km) launch_s<true, true>(p, grid, big, st); else launch_s<true, false>(p, grid, big, st); }
+    else      { if (b_km) launch_s<false, true>(p, grid, big, st); else launch_s<false, false>(p, grid, big, st); }
     FT_CHECK_LAUNCH();
     return FT_OK;
 }
@@ -365,8 +393,8 @@ struct ImgGeo { int km; int rows, cols; long sr, sc; int Rp, Cp; size_t bytes; }
 ImgGeo geo(long sr, long sk, int R, int K) {
     ImgGeo g;
     g.km = (sr == 1 && sk != 1) ? 1 : 0;               // row dim contiguous in the source: keep it k-major, no transpose
-    if (g.km) { g.rows = K; g.cols = R; g.sr = sk; g.sc = 1; g.Rp = (int)up(K, 32); g.Cp = (int)up(R, TB); }
-    else      { g.rows = R; g.cols = K; g.sr = sr; g.sc = sk; g.Rp = (int)up(R, TB); g.Cp = (int)up(K, 32); }
+    if (g.km) { g.rows = K; g.cols = R; g.sr = sk; g.sc = 1; g.Rp = (int)up(K, 32); g.Cp = (int)up(R, 256); }
+    else      { g.rows = R; g.cols = K; g.sr = sr; g.sc = sk; g.Rp = (int)up(R, 256); g.Cp = (int)up(K, 32); }
     g.bytes = up((size_t)g.Rp * g.Cp * 2, 256);
     return g;
 }
@@ -400,14 +428,14 @@ int ftint_gemm_bf16(const ft_gemm_args* a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" size_t ft_bf16_image_bytes(int64_t rows, int64_t cols) {
     if (rows < 1 || cols < 1) return 0;
-    return up(up((size_t)rows + 32, TB) * up((size_t)cols, TB) * 2, 256);
+    return up(up((size_t)rows + 32, 256) * up((size_t)cols, 256) * 2, 256);
 }
 
 extern "C" int ft_bf16_image(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, void* stream) {
     FT_CHECK_ARG(src && dst && rows >= 1 && cols >= 1 && ld >= cols && rows < (1ll << 31) - 256 && cols < (1ll << 31) - 256);
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);
-    make_image(src, ld, 1, (int)rows, (int)cols, reinterpret_cast<unsigned short*>(dst), (int)up((size_t)rows + 32, TB),
-               (int)up((size_t)cols, TB), reinterpret_cast<hipStream_t>(stream));
+    make_image(src, ld, 1, (int)rows, (int)cols, reinterpret_cast<unsigned short*>(dst), (int)up((size_t)rows + 32, 256),
+               (int)up((size_t)cols, 256), reinterpret_cast<hipStream_t>(stream));
     FT_CHECK_LAUNCH();
     return FT_OK;
 }
@@ -416,7 +444,7 @@ extern "C" int ft_bf16_image_colsum(const float* src, int64_t ld, int64_t rows, 
     FT_CHECK_ARG(src && dst && colsum && rows >= 1 && cols >= 1 && ld >= cols && rows < (1ll << 31) - 256 && cols < (1ll << 31) - 256);
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int Rp = (int)up((size_t)rows + 32, TB), Cp = (int)up((size_t)cols, TB);
+    const int Rp = (int)up((size_t)rows + 32, 256), Cp = (int)up((size_t)cols, 256);
     const int vec = (reinterpret_cast<uintptr_t>(src) % 16 == 0 && ld % 4 == 0) ? 1 : 0;
     FT_CHECK_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)cols, st));
     hipLaunchKernelGGL(img_rows_sum_k, dim3(cdiv(Cp, 256), cdiv(Rp, 256)), dim3(256), 0, st, src, (long)ld, (int)rows, (int)cols,

@@ -61,7 +61,7 @@ class Bf16Image:
         assert t2d.dim() == 2 and t2d.stride(1) == 1 and t2d.dtype == torch.float32
         L.require_cuda(t2d)
         self.rows, self.cols = int(t2d.shape[0]), int(t2d.shape[1])
-        self.ld = (self.cols + 127) // 128 * 128
+        self.ld = (self.cols + 255) // 256 * 256
         self.buf = torch.empty(L.lib().ft_bf16_image_bytes(self.rows, self.cols), device=t2d.device, dtype=torch.uint8)
         self.colsum = None
         if colsum:

@@ -70,14 +70,14 @@ size_t ft_gemm_workspace_bytes(const ft_gemm_args* a);
 int ft_gemm(const ft_gemm_args* a, void* stream);
 
 /* bf16 operand images (FT_BF16 training path): a row-major fp32 matrix [rows][cols] (row stride ld) is rounded ONCE to a
- * zero-padded bf16 image [ceil128(rows + 32)][ceil128(cols)] (ft_bf16_image_bytes bytes, 256-byte aligned) and then feeds
+ * zero-padded bf16 image [ceil256(rows + 32)][ceil256(cols)] (ft_bf16_image_bytes bytes, 256-byte aligned) and then feeds
  * every GEMM that reads it, in either role:
  *   k-contiguous operand (a_kmajor / b_kmajor = 0): image rows are the operand's m (or n) index, columns the reduction;
  *   k-major operand (= 1): image rows are the reduction index, columns the m (or n) index -- read through the LDS
  *   transpose-read, so the weight-gradient GEMMs dW = dY^T X (both operands k-major) need no transposed copies.
  * A / B may point INSIDE an image (row offset * ld for a time shift, column offset % 8 == 0 for a column block of a
  * weight); whatever lies beyond the logical extent must be finite and is multiplied by the partner's zero padding (k) or
- * dropped by the epilogue (m, n).  lda / ldb = image row stride in elements = ceil128(cols).  Epilogue as ft_gemm. */
+ * dropped by the epilogue (m, n).  lda / ldb = image row stride in elements = ceil256(cols).  Epilogue as ft_gemm. */
 typedef struct {
     const void* A; const void* B; float* C; const float* bias;
     int M, N, K;

@@ -552,7 +552,7 @@ def test_bidirectional_pair_chain_equals_two_chains(env, monkeypatch, B, T):
 @pytest.mark.parametrize("rows,cols,off", [(1000, 300, 0), (257, 4096, 0), (31, 80, 1), (2050, 136, 0)])
 def test_bf16_image_and_fused_column_sums(env, rows, cols, off):
     """ft_bf16_image / ft_bf16_image_colsum: the image is bit-identical to torch's RNE bf16 cast, zero outside the
-    logical extent ([ceil128(rows+32)][ceil128(cols)]); the fused column sums equal the fp32 sums of the SOURCE
+    logical extent ([ceil256(rows+32)][ceil256(cols)]); the fused column sums equal the fp32 sums of the SOURCE
     (tolerance: fp32 summation order over <= 2050 rows)."""
     L, ops = env
     torch.manual_seed(rows + cols)
@@ -560,7 +560,7 @@ def test_bf16_image_and_fused_column_sums(env, rows, cols, off):
     src = g(wide)[:, off:off + cols]                       # strided view; off = 1 makes the rows only 4-byte aligned
     for with_sum in (False, True):
         img = ops.Bf16Image(src, colsum=with_sum)
-        Rp, ld = (rows + 32 + 127) // 128 * 128, (cols + 127) // 128 * 128
+        Rp, ld = (rows + 32 + 255) // 256 * 256, (cols + 255) // 256 * 256
         assert img.ld == ld and img.buf.numel() >= Rp * ld * 2
         raw = img.buf[:Rp * ld * 2].view(torch.int16).view(Rp, ld).cpu()
         ref = wide[:, off:off + cols].to(torch.bfloat16).view(torch.int16)

@@ -232,12 +232,12 @@ def test_workspace_size_queries_run_without_a_gpu():
     lib = L.lib()
     up = lambda v, m: (v + m - 1) // m * m
     for rows, cols in ((1, 1), (27584, 4096), (300, 80), (4096, 1664)):
-        assert lib.ft_bf16_image_bytes(rows, cols) == up(up(rows + 32, 128) * up(cols, 128) * 2, 256)
+        assert lib.ft_bf16_image_bytes(rows, cols) == up(up(rows + 32, 256) * up(cols, 256) * 2, 256)
     assert lib.ft_bf16_image_bytes(0, 5) == 0
     # ft_gemm_workspace_bytes: zero for fp32 mode / batched / small problems, image bytes of both operands otherwise
     a = L.GemmArgs(None, None, None, None, 27584, 4096, 1664, 1, 1664, 1, 1, 1664, 4096, 0, 0, 0, 1.0, 0.0, 0, L.FT_BF16, 0, None, 0)
     need = lib.ft_gemm_workspace_bytes(C.byref(a))
-    assert need == up(up(27584, 128) * up(1664, 32) * 2, 256) + up(up(4096, 128) * up(1664, 32) * 2, 256)
+    assert need == up(up(27584, 256) * up(1664, 32) * 2, 256) + up(up(4096, 256) * up(1664, 32) * 2, 256)
     a.mode = L.FT_F32
     assert lib.ft_gemm_workspace_bytes(C.byref(a)) == 0
     a.mode, a.batch = L.FT_BF16, 4
