@@ -357,7 +357,9 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
     const bool can_split = (flags & FT_GEMM_SPLITK) && act == FT_ACT_NONE && (beta == 0.f || beta == 1.f) && K >= 2048;
     // 256 x 128 workgroup tiles (2 per CU) when they still fill the chip, possibly with split-K; else 128 x 128 (4 per CU)
     const long tiles_big = (long)cdiv(M, 256) * cdiv(N, TB);
-    bool big = M >= 512 && (tiles_big >= 384 || (can_split && tiles_big * (K / 512) >= 384));
+    // measured (scripts/exp/gemm_bench.py): the tall tile pays for the long-K weight-gradient shapes (+9 %), is neutral to
+    // slightly slower for the forward / input-gradient shapes -- those keep the 128 x 128 tile at 4 workgroups per CU
+    bool big = M >= 512 && can_split && tiles_big * (K / 512) >= 384;
     if (force_tile == 128) big = false;
     if (force_tile == 256) big = M >= 256;
     const int RTA = big ? 256 : TB;
