@@ -202,17 +202,11 @@ __device__ __forceinline__ void tr_wait(bf16x4 (&t)[8], bf16x4 (&u)[8]) {
 
 // RTA = rows of the workgroup tile (128, or 256: wave tile 128 x 64 = 8 x 4 MFMA tiles -- 12 fragment reads feed 32 MFMAs instead of
 // 8 feeding 16, which takes the LDS pipe off the critical path; 2 workgroups per CU, 196 VGPRs)
-// NST = LDS stages.  2: one DMA stage in flight under the MFMAs of the current one, plain __syncthreads (which drains the DMA
-// queue), 4 workgroups per CU hide the rest.  3 / 4: NST-1 stages in flight per workgroup -- counted s_waitcnt vmcnt(N) (DMAs
-// retire in order: N = DMAs per wave and stage x stages that may stay in flight) and a RAW s_barrier, because the fence inside
-// __syncthreads would wait vmcnt(0).
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <bool AKM, bool BKM, bool SPLIT, int RTA, int NST>
-__global__ __launch_bounds__(256, (RTA == 256 || NST == 4) ? 2 : (NST == 3 ? 3 : 4)) void gemm_bf16_k(BfP p) {
+template <bool AKM, bool BKM, bool SPLIT, int RTA>
+__global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
     constexpr int OPA = RTA * 64, OPB = 8192;          // bytes per operand per stage
     constexpr int TI = RTA / 32;                       // 16-row fragments of the wave tile along M
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * (OPA + OPB)];   // [stage][A | B]
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (OPA + OPB)];     // [stage][A | B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, kg = lane >> 4;
@@ -241,38 +235,15 @@ __global__ __launch_bounds__(256, (RTA == 256 || NST == 4) ? 2 : (NST == 3 ? 3 :
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    constexpr int PER = Operand<AKM, RTA>::NS + Operand<BKM, 128>::NS;      // DMAs per wave and stage
-    if constexpr (NST == 2) {
-        if (t0 < t1) { oa.issue(smem, t0); ob.issue(smem + OPA, t0); }
-    } else {
-#pragma unroll
-        for (int u = 0; u < NST - 1; ++u)
-            if (t0 + u < t1) { oa.issue(smem + u * (OPA + OPB), t0 + u); ob.issue(smem + u * (OPA + OPB) + OPA, t0 + u); }
-    }
-    int stage = 0;
+    if (t0 < t1) { oa.issue(smem, t0); ob.issue(smem + OPA, t0); }
     for (int t = t0; t < t1; ++t) {
-        if constexpr (NST == 2) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my DMAs of step t have landed
-            __syncthreads();                                        // ... everyone's have; the other stage is no longer being read
-            if (t + 1 < t1) {
-                unsigned char* nx = smem + (stage ^ 1) * (OPA + OPB);
-                oa.issue(nx, t + 1);
-                ob.issue(nx + OPA, t + 1);
-            }
-        } else {
-            // stages t+1 .. t+NST-2 may stay in flight (fewer at the tail), stage t must have landed
-            const int ahead = t1 - 1 - t;
-            if (ahead >= NST - 2) wait_vmcnt<(NST - 2) * PER>();
-            else if (NST == 4 && ahead == 1) wait_vmcnt<PER>();
-            else wait_vmcnt<0>();
-            asm volatile("s_barrier" ::: "memory");                 // everyone's stage t landed; stage t-1 is no longer being read
-            if (t + NST - 1 < t1) {                                 // refill the buffer of stage t-1
-                int nst = stage + NST - 1;
-                nst = nst >= NST ? nst - NST : nst;
-                unsigned char* nx = smem + nst * (OPA + OPB);
-                oa.issue(nx, t + NST - 1);
-                ob.issue(nx + OPA, t + NST - 1);
-            }
+        const int stage = (t - t0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my DMAs of step t have landed
+        __syncthreads();                                            // ... everyone's have; stage^1 is no longer being read
+        if (t + 1 < t1) {
+            unsigned char* nx = smem + (stage ^ 1) * (OPA + OPB);
+            oa.issue(nx, t + 1);
+            ob.issue(nx + OPA, t + 1);
         }
         const unsigned char* sa = smem + stage * (OPA + OPB);
         const unsigned char* sb = sa + OPA;
@@ -312,7 +283,6 @@ __global__ __launch_bounds__(256, (RTA == 256 || NST == 4) ? 2 : (NST == 3 ? 3 :
                 if constexpr (SPLIT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
                 else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
             }
-        stage = (stage + 1 == NST) ? 0 : stage + 1;
     }
 
     if constexpr (SPLIT) {          // C was zeroed (beta == 0) or holds the addend (beta == 1)
@@ -364,22 +334,15 @@ __global__ __launch_bounds__(256, (RTA == 256 || NST == 4) ? 2 : (NST == 3 ? 3 :
     }
 }
 
-template <bool AKM, bool BKM, int NST>
-void launch_n(const BfP& p, dim3 grid, bool big, hipStream_t st) {
-    if (big) {
-        if (p.splits > 1) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, true, 256, (NST > 3 ? 3 : NST)>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 256, (NST > 3 ? 3 : NST)>), grid, dim3(256), 0, st, p);
-    } else {
-        if (p.splits > 1) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, true, 128, NST>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 128, NST>), grid, dim3(256), 0, st, p);
-    }
-}
 template <bool AKM, bool BKM>
 void launch_s(const BfP& p, dim3 grid, bool big, hipStream_t st) {
-    static const int nst = [] { const char* e = getenv("FT_GEMM_BF16_STAGES"); return e ? atoi(e) : 2; }();
-    if (nst == 4) launch_n<AKM, BKM, 4>(p, grid, big, st);
-    else if (nst == 3) launch_n<AKM, BKM, 3>(p, grid, big, st);
-    else launch_n<AKM, BKM, 2>(p, grid, big, st);
+    if (big) {
+        if (p.splits > 1) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, true, 256>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 256>), grid, dim3(256), 0, st, p);
+    } else {
+        if (p.splits > 1) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, true, 128>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 128>), grid, dim3(256), 0, st, p);
+    }
 }
 
 // images -> C.  a_km / b_km: the operand image is k-major ([k][row]) instead of k-contiguous ([row][k]).
