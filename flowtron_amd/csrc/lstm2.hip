@@ -282,7 +282,9 @@ __global__ __launch_bounds__(256) void lstm2_fwd_both(L2FwdP p) {
         const bf16x8* wf0 = reinterpret_cast<const bf16x8*>(p.w0frag) + (size_t)blk * nchunk * 64;
         const bf16x8* wfi = reinterpret_cast<const bf16x8*>(p.w1frag) + (size_t)blk * 2 * nchunk * 64;
         const bf16x8* wf1 = wfi + (size_t)nchunk * 64;
-        bf16x8 w0[G], wi[G], w1[G], a[G][MT];
+        // one workgroup per CU, one wave per SIMD: the register file is this wave's alone, so EVERY fragment of the step --
+        // three weight groups and both activation images -- is requested before the first MFMA (one memory round trip)
+        bf16x8 w0[G], wi[G], w1[G], a[G][MT], ah[G][MT];
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const size_t c = (size_t)(wave + i * 4);
@@ -292,7 +294,13 @@ __global__ __launch_bounds__(256) void lstm2_fwd_both(L2FwdP p) {
             for (int m = 0; m < MT; ++m) a[i][m] = a0[(c * MT + m) * 64 + lane];
         }
 #pragma unroll
-        for (int i = 0; i < G; ++i) w1[i] = wf1[(size_t)(wave + i * 4) * 64 + lane];
+        for (int i = 0; i < G; ++i) {
+            const size_t c = (size_t)(wave + i * 4);
+            w1[i] = wf1[c * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) ah[i][m] = a1[(c * MT + m) * 64 + lane];
+        }
+        issue_epilogue_loads();                  // younger loads: never delay a fragment wait (vmcnt retires in order)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < G; ++i)
@@ -304,13 +312,7 @@ __global__ __launch_bounds__(256) void lstm2_fwd_both(L2FwdP p) {
 #pragma unroll
         for (int i = 0; i < G; ++i)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) a[i][m] = a1[((size_t)(wave + i * 4) * MT + m) * 64 + lane];
-        issue_epilogue_loads();                  // younger loads: never delay a fragment wait (vmcnt retires in order)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < G; ++i)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc1[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w1[i], acc1[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) acc1[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i][m], w1[i], acc1[m], 0, 0, 0);
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
