@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libflowtron_hip.so")
 
 FT_F32, FT_BF16 = 0, 1
-GEMM_SPLITK, GEMM_TILE256 = 1, 2
+GEMM_SPLITK = 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 
 _p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -67,8 +67,6 @@ SIGNATURES = {
     "ft_lstm_workspace_bytes": ([_i, _i], _sz),
     "ft_lstm_seq_fwd": ([_p, _p, _p, _p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "ft_lstm_seq_bwd": ([_p, _l, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
-    "ft_lstm_seq_fwd_range": ([_p, _p, _p, _p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
-    "ft_lstm_seq_bwd_range": ([_p, _l, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "ft_lstm2_supported": ([_i, _i], _i),
     "ft_lstm2_workspace_bytes": ([_i, _i], _sz),
     "ft_lstm2_seq_fwd": ([_p] * 13 + [_i, _i, _i, _p], _i),

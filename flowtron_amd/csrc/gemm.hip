@@ -1,9 +1,8 @@
 // Strided batched GEMM with fused epilogue on the gfx950 matrix cores.
 //   C = act(alpha * A.B + beta * C + bias)
-// Two tile shapes: 128x128x32 with 4 waves (2x2, each wave 64x64 = 4x4 MFMA tiles of 16x16), and -- bf16 path, both
-// output dims >= 512 -- 256x256x32 with 8 waves (2x4, each wave 128x64 = 8x4 tiles).  The operands are fp32 in HBM, so
-// a 128^2 tile needs 125 B/clk/CU of operand traffic at the full MFMA rate, twice what the L2 delivers; the 256^2 tile
-// halves the re-reads (62 B/clk/CU) without a separate conversion pass.  MODE 0: fp32 operands, v_mfma_f32_16x16x4_f32 (exact fp32).
+// Tile 128x128x32 with 4 waves (2x2, each wave 64x64 = 4x4 MFMA tiles of 16x16).  (A 256x256x32 / 512-thread tile was
+// built and measured 4 ms/step slower on the training step -- DESIGN.md "tried and measured NOT to help" -- and removed.)
+// MODE 0: fp32 operands, v_mfma_f32_16x16x4_f32 (exact fp32).
 // MODE 1: operands rounded to bf16 while being staged into LDS,
 // v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Global operands are always fp32.
 //
@@ -111,7 +110,7 @@ __device__ __forceinline__ void store_tile(void* lds, int tid, const float (&reg
 }
 
 // NT = 256: 128x128 tile, waves 2(M) x 2(N), wave tile 64x64 (TI = 4 x TJ = 4 MFMA tiles)
-// NT = 512: 256x256 tile, waves 2(M) x 4(N), wave tile 128x64 (TI = 8 x TJ = 4)
+// (NT stays a parameter of the staging helpers; only NT = 256 is instantiated)
 template <int MODE, int AMODE, int BMODE, int NT>
 __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     constexpr int BMT = NT / 2, BNT = NT / 2;               // tile rows / cols
@@ -227,14 +226,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 }
 
 template <int MODE, int AMODE>
-void launch_b(const GemmP& p, dim3 grid, hipStream_t st, bool big) {
-    if constexpr (MODE == 1 && AMODE != 0) {
-        if (big && p.bmode != 0) {                 // 256x256 tile, 512 threads (bf16 operands, vectorised staging only)
-            if (p.bmode == 1) hipLaunchKernelGGL((gemm_kernel<1, AMODE, 1, 512>), grid, dim3(512), 0, st, p);
-            else hipLaunchKernelGGL((gemm_kernel<1, AMODE, 2, 512>), grid, dim3(512), 0, st, p);
-            return;
-        }
-    }
+void launch_b(const GemmP& p, dim3 grid, hipStream_t st) {
     switch (p.bmode) {
         case 1: hipLaunchKernelGGL((gemm_kernel<MODE, AMODE, 1, 256>), grid, dim3(256), 0, st, p); break;
         case 2: hipLaunchKernelGGL((gemm_kernel<MODE, AMODE, 2, 256>), grid, dim3(256), 0, st, p); break;
@@ -242,11 +234,11 @@ void launch_b(const GemmP& p, dim3 grid, hipStream_t st, bool big) {
     }
 }
 template <int MODE>
-void launch_a(const GemmP& p, dim3 grid, hipStream_t st, bool big) {
+void launch_a(const GemmP& p, dim3 grid, hipStream_t st) {
     switch (p.amode) {
-        case 1: launch_b<MODE, 1>(p, grid, st, big); break;
-        case 2: launch_b<MODE, 2>(p, grid, st, big); break;
-        default: launch_b<MODE, 0>(p, grid, st, big); break;
+        case 1: launch_b<MODE, 1>(p, grid, st); break;
+        case 2: launch_b<MODE, 2>(p, grid, st); break;
+        default: launch_b<MODE, 0>(p, grid, st); break;
     }
 }
 
@@ -279,17 +271,9 @@ extern "C" int ft_gemm(const ft_gemm_args* a, void* stream) {
     p.alpha = a->alpha; p.beta = a->beta; p.act = a->act;
     p.amode = pick_mode(a->A, a->sAm, a->sAk, a->bsA, a->batch);
     p.bmode = pick_mode(a->B, a->sBn, a->sBk, a->bsB, a->batch);
-    // 256x256 tile when both output dims are large, the operands take a vectorised staging path and the tile grid still
-    // fills the chip (split-K below multiplies the workgroup count for the long-reduction weight gradients)
     const bool can_split = (a->flags & FT_GEMM_SPLITK) && a->act == FT_ACT_NONE && (a->beta == 0.f || a->beta == 1.f) &&
                            a->batch == 1 && a->K >= 2048;
-    const long tiles_big = (long)cdiv(a->M, 256) * cdiv(a->N, 256) * a->batch;
-    // opt-in (FT_GEMM_TILE256): measured 4 ms/step SLOWER on the training step than the 128^2 tile at 3 workgroups/CU --
-    // one 512-thread workgroup per CU with a single LDS stage hides less memory latency than it saves in re-reads
-    const bool big = (a->flags & FT_GEMM_TILE256) && a->mode == FT_BF16 && p.amode != 0 && p.bmode != 0 && a->M >= 512 &&
-                     a->N >= 512 && (tiles_big >= 192 || (can_split && tiles_big >= 24));
-    const int TM = big ? 256 : BM, TN = big ? 256 : BN;
-    p.gx = cdiv(a->N, TN); p.gy = cdiv(a->M, TM);
+    p.gx = cdiv(a->N, BN); p.gy = cdiv(a->M, BM);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // split-K for GEMMs with few output tiles and a long reduction (weight gradients: K = T*B rows): partial
     // products are combined with fp32 global atomics into a zeroed (beta 0) or pre-loaded (beta 1) C.
@@ -308,8 +292,8 @@ extern "C" int ft_gemm(const ft_gemm_args* a, void* stream) {
         FT_CHECK_HIP(hipMemset2DAsync(a->C, sizeof(float) * a->ldc, 0, sizeof(float) * a->N, a->M, st));
     dim3 grid(p.gx * p.gy, p.splits, a->batch);
     FT_CHECK_ARG(grid.z <= 65535);
-    if (a->mode == FT_F32) launch_a<0>(p, grid, st, false);
-    else launch_a<1>(p, grid, st, big);
+    if (a->mode == FT_F32) launch_a<0>(p, grid, st);
+    else launch_a<1>(p, grid, st);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

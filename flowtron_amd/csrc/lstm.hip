@@ -19,57 +19,9 @@
 //              keep h_t (resp. dgates_t) in the same fragment order, so every operand load of a
 //              step is one fully coalesced 1 KiB global_load_dwordx4 per wave and the per-step L2
 //              traffic halves; v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Needs H % 32 == 0.
-#include <mutex>
-#include <unordered_map>
-
 #include "common.h"
 
 namespace {
-
-// ---- hipGraph replay of a launch chain --------------------------------------------------------------------------
-// A time-chunk of an LSTM is 50-200 dependent launches of the same kernel with by-value arguments.  When several chunks
-// of different LSTMs are pipelined on separate streams, the host (~4.3 us per hipLaunchKernel) cannot feed three
-// concurrent chains, so a chain whose argument set (pointers, dims, step range) was seen before is replayed as ONE
-// hipGraphLaunch.  Callers keep their buffers persistent, so the key (a hash of every argument) is stable across
-// training steps; a changed pointer simply captures a new graph.
-struct GraphCache {
-    std::mutex mu;
-    std::unordered_map<uint64_t, hipGraphExec_t> map;
-    hipStream_t cap = nullptr;
-};
-GraphCache g_lstm_graphs;
-
-inline uint64_t hash_bytes(const void* p, size_t n, uint64_t h) {
-    const unsigned char* c = static_cast<const unsigned char*>(p);
-    for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; }
-    return h;
-}
-
-template <class F>
-int run_graphed(uint64_t key, hipStream_t user, F&& enqueue) {
-    hipGraphExec_t exec = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_lstm_graphs.mu);
-        auto it = g_lstm_graphs.map.find(key);
-        if (it != g_lstm_graphs.map.end()) exec = it->second;
-        if (!exec) {
-            if (g_lstm_graphs.map.size() > 4096) return ft_fail(FT_EHIP, "lstm graph cache overflow (unstable buffer addresses?)");
-            if (!g_lstm_graphs.cap) FT_CHECK_HIP(hipStreamCreateWithFlags(&g_lstm_graphs.cap, hipStreamNonBlocking));
-            hipGraph_t graph = nullptr;
-            hipError_t e = hipStreamBeginCapture(g_lstm_graphs.cap, hipStreamCaptureModeThreadLocal);
-            if (e == hipSuccess) {
-                enqueue(g_lstm_graphs.cap);
-                e = hipStreamEndCapture(g_lstm_graphs.cap, &graph);
-            }
-            if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-            if (graph) hipGraphDestroy(graph);
-            if (e != hipSuccess) return ft_fail(FT_EHIP, "lstm graph capture failed: %s", hipGetErrorString(e));
-            g_lstm_graphs.map[key] = exec;
-        }
-    }
-    FT_CHECK_HIP(hipGraphLaunch(exec, user));
-    return FT_OK;
-}
 
 
 // ---- skinny  D[b][n] += sum_k A[b][k] * W[n][k]  over k-chunks c = c0, c0+cs, ... ----
@@ -532,15 +484,13 @@ extern "C" size_t ft_lstm_workspace_bytes(int B, int H) {
     return fwd > bwd ? fwd : bwd;
 }
 
-extern "C" int ft_lstm_seq_fwd_range(const float* gx, const float* w_hh, const int32_t* lens,
-                                     float* y, int64_t ldy, float* gates, float* cell, void* work,
-                                     int T, int B, int H, int reverse, int mode, int s_begin, int s_end, int use_graph,
-                                     void* stream) {
+extern "C" int ft_lstm_seq_fwd(const float* gx, const float* w_hh, const int32_t* lens,
+                               float* y, int64_t ldy, float* gates, float* cell, void* work,
+                               int T, int B, int H, int reverse, int mode, void* stream) {
     FT_CHECK_ARG(gx && w_hh && lens && y && work);
     FT_CHECK_ARG(T >= 0 && B >= 1 && B <= 64 && H >= 4 && H % 4 == 0 && ldy >= H);
     FT_CHECK_ARG((gates == nullptr) == (cell == nullptr));
     FT_CHECK_ARG(mode == FT_F32 || mode == FT_BF16);
-    FT_CHECK_ARG(0 <= s_begin && s_begin <= s_end && s_end <= T);
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(w_hh) % 16 == 0 && reinterpret_cast<uintptr_t>(work) % 256 == 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t BH = (size_t)B * H;
@@ -555,44 +505,25 @@ extern "C" int ft_lstm_seq_fwd_range(const float* gx, const float* w_hh, const i
     unsigned short* hfrag[2] = {reinterpret_cast<unsigned short*>(base + al256(3 * BH * 4)),
                                 reinterpret_cast<unsigned short*>(base + al256(3 * BH * 4) + frag_act)};
     unsigned short* wfrag = reinterpret_cast<unsigned short*>(base + al256(3 * BH * 4) + al256(2 * frag_act));
-    if (s_begin == 0) {          // first chunk of a sequence: zero the state, build the fragment image of W_hh
-        FT_CHECK_HIP(hipMemsetAsync(base, 0, al256(3 * BH * 4) + al256(2 * frag_act), st));
-        if (fast) hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H);
-    }
+    // zero the state, build the fragment image of W_hh
+    FT_CHECK_HIP(hipMemsetAsync(base, 0, al256(3 * BH * 4) + al256(2 * frag_act), st));
+    if (fast) hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H);
     dim3 grid(cdiv(H, 4));
-    auto enqueue = [&](hipStream_t q) {
-        for (int s = s_begin; s < s_end; ++s) {
-            FwdP p{gx, w_hh, lens, hbuf[s & 1], hbuf[(s + 1) & 1], cstate, y, (long)ldy, gates, cell,
-                   wfrag, hfrag[s & 1], hfrag[(s + 1) & 1], s, T, B, H, reverse};
-            launch_fwd(p, fast, g, mt, grid, q);
-        }
-    };
-    if (use_graph && s_end - s_begin > 1) {
-        const uint64_t k[] = {(uint64_t)(uintptr_t)gx, (uint64_t)(uintptr_t)w_hh, (uint64_t)(uintptr_t)lens, (uint64_t)(uintptr_t)y,
-                              (uint64_t)ldy, (uint64_t)(uintptr_t)gates, (uint64_t)(uintptr_t)cell, (uint64_t)(uintptr_t)work,
-                              (uint64_t)T, (uint64_t)B, (uint64_t)H, (uint64_t)reverse, (uint64_t)mode, (uint64_t)s_begin,
-                              (uint64_t)s_end, 0xF0F0ull};
-        return run_graphed(hash_bytes(k, sizeof(k), 1469598103934665603ull), st, enqueue);
+    for (int s = 0; s < T; ++s) {
+        FwdP p{gx, w_hh, lens, hbuf[s & 1], hbuf[(s + 1) & 1], cstate, y, (long)ldy, gates, cell,
+               wfrag, hfrag[s & 1], hfrag[(s + 1) & 1], s, T, B, H, reverse};
+        launch_fwd(p, fast, g, mt, grid, st);
     }
-    enqueue(st);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }
 
-extern "C" int ft_lstm_seq_fwd(const float* gx, const float* w_hh, const int32_t* lens,
-                               float* y, int64_t ldy, float* gates, float* cell, void* work,
+extern "C" int ft_lstm_seq_bwd(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens,
+                               const float* gates, const float* cell, float* dgx, void* work,
                                int T, int B, int H, int reverse, int mode, void* stream) {
-    return ft_lstm_seq_fwd_range(gx, w_hh, lens, y, ldy, gates, cell, work, T, B, H, reverse, mode, 0, T, 0, stream);
-}
-
-extern "C" int ft_lstm_seq_bwd_range(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens,
-                                     const float* gates, const float* cell, float* dgx, void* work,
-                                     int T, int B, int H, int reverse, int mode, int s_begin, int s_end, int use_graph,
-                                     void* stream) {
     FT_CHECK_ARG(dy && w_hh && lens && gates && cell && dgx && work);
     FT_CHECK_ARG(T >= 0 && B >= 1 && B <= 64 && H >= 4 && H % 4 == 0 && ldy >= H);
     FT_CHECK_ARG(mode == FT_F32 || mode == FT_BF16);
-    FT_CHECK_ARG(0 <= s_begin && s_begin <= s_end && s_end <= T);
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(work) % 256 == 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t BH = (size_t)B * H;
@@ -609,49 +540,32 @@ extern "C" int ft_lstm_seq_bwd_range(const float* dy, int64_t ldy, const float* 
     char* fr = base + al256(9 * BH * 4) + al256((size_t)4 * H * H * 4);
     unsigned short* dafrag[2] = {reinterpret_cast<unsigned short*>(fr), reinterpret_cast<unsigned short*>(fr + 4 * frag_act)};
     unsigned short* wTfrag = reinterpret_cast<unsigned short*>(fr + al256(8 * frag_act));
-    if (s_end == T) {            // first (latest-in-time) chunk of the backward sweep: zero the carries, build W_hh^T images
-        FT_CHECK_HIP(hipMemsetAsync(base, 0, al256(9 * BH * 4), st));
-        if (fast) {
-            FT_CHECK_HIP(hipMemsetAsync(fr, 0, al256(8 * frag_act), st));
-            hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H);
-        } else {
-            hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(H, 32), cdiv(4 * H, 32)), dim3(32, 8), 0, st, w_hh, wT, 4 * H, H);
+    // zero the carries, build the W_hh^T images
+    FT_CHECK_HIP(hipMemsetAsync(base, 0, al256(9 * BH * 4), st));
+    if (fast) {
+        FT_CHECK_HIP(hipMemsetAsync(fr, 0, al256(8 * frag_act), st));
+        hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H);
+    } else {
+        hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(H, 32), cdiv(4 * H, 32)), dim3(32, 8), 0, st, w_hh, wT, 4 * H, H);
+    }
+    if (fast) {
+        dim3 grid(H / 16);
+        for (int s = T - 1; s >= 0; --s) {
+            BwdP p{dy, (long)ldy, lens, gates, cell, part, dc_carry, da_cur, dgx, wT, part,
+                   dafrag[(s + 1) & 1], dafrag[s & 1], wTfrag, s, T, B, H, reverse, mt};
+            launch_bwd_fused(p, g, mt, grid, st);
+        }
+    } else {
+        dim3 grid_pw(cdiv((int64_t)B * H, 256)), grid_mm(cdiv(H, 16), 4);
+        for (int s = T - 1; s >= 0; --s) {
+            BwdP p{dy, (long)ldy, lens, gates, cell, part, dc_carry, da_cur, dgx, wT, part,
+                   nullptr, nullptr, nullptr, s, T, B, H, reverse, mt};
+            hipLaunchKernelGGL(lstm_bwd_pointwise, grid_pw, dim3(256), 0, st, p);
+            if (s > 0) launch_bwd_mm(p, mt, grid_mm, st);
         }
     }
-    auto enqueue = [&](hipStream_t q) {
-        if (fast) {
-            dim3 grid(H / 16);
-            for (int s = s_end - 1; s >= s_begin; --s) {
-                BwdP p{dy, (long)ldy, lens, gates, cell, part, dc_carry, da_cur, dgx, wT, part,
-                       dafrag[(s + 1) & 1], dafrag[s & 1], wTfrag, s, T, B, H, reverse, mt};
-                launch_bwd_fused(p, g, mt, grid, q);
-            }
-        } else {
-            dim3 grid_pw(cdiv((int64_t)B * H, 256)), grid_mm(cdiv(H, 16), 4);
-            for (int s = s_end - 1; s >= s_begin; --s) {
-                BwdP p{dy, (long)ldy, lens, gates, cell, part, dc_carry, da_cur, dgx, wT, part,
-                       nullptr, nullptr, nullptr, s, T, B, H, reverse, mt};
-                hipLaunchKernelGGL(lstm_bwd_pointwise, grid_pw, dim3(256), 0, q, p);
-                if (s > 0) launch_bwd_mm(p, mt, grid_mm, q);
-            }
-        }
-    };
-    if (use_graph && s_end - s_begin > 1) {
-        const uint64_t k[] = {(uint64_t)(uintptr_t)dy, (uint64_t)ldy, (uint64_t)(uintptr_t)w_hh, (uint64_t)(uintptr_t)lens,
-                              (uint64_t)(uintptr_t)gates, (uint64_t)(uintptr_t)cell, (uint64_t)(uintptr_t)dgx, (uint64_t)(uintptr_t)work,
-                              (uint64_t)T, (uint64_t)B, (uint64_t)H, (uint64_t)reverse, (uint64_t)mode, (uint64_t)s_begin,
-                              (uint64_t)s_end, 0xB0B0ull};
-        return run_graphed(hash_bytes(k, sizeof(k), 1469598103934665603ull), st, enqueue);
-    }
-    enqueue(st);
     FT_CHECK_LAUNCH();
     return FT_OK;
-}
-
-extern "C" int ft_lstm_seq_bwd(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens,
-                               const float* gates, const float* cell, float* dgx, void* work,
-                               int T, int B, int H, int reverse, int mode, void* stream) {
-    return ft_lstm_seq_bwd_range(dy, ldy, w_hh, lens, gates, cell, dgx, work, T, B, H, reverse, mode, 0, T, 0, stream);
 }
 
 #endif  // FT_LSTM_NO_ENTRY

@@ -118,16 +118,26 @@ class FlatArena:
         self.adopt_stray_grads(copy=False)
 
     def adopt_stray_grads(self, copy=True):
-        """If something replaced p.grad (e.g. zero_grad(set_to_none=True) followed by backward), pull it back
-        into the arena so the single-collective path stays valid."""
+        """If something replaced p.grad (e.g. torch's default zero_grad(set_to_none=True) followed by backward), pull it
+        back into the arena so the single-collective path stays valid.  A parameter whose grad is None got NO gradient:
+        with copy=True its arena slice is zeroed (the slice still holds the previous iteration's values) and it is
+        reported back as (offset, numel) so that the optimizer can skip it like radam.py:57-58; its .grad stays None."""
+        skipped = []
         for p, off in zip(self.params, self.offsets):
             k = p.numel()
             g = p.grad
-            if g is None or not (self._ptr_lo <= g.data_ptr() < self._ptr_hi):
+            if g is None:
+                if copy:
+                    self.flat_grad[off:off + k].zero_()
+                    skipped.append((off, k))
+                else:
+                    p.grad = self.flat_grad[off:off + k].view_as(p.data)
+            elif not (self._ptr_lo <= g.data_ptr() < self._ptr_hi):
                 view = self.flat_grad[off:off + k].view_as(p.data)
-                if g is not None and copy:
+                if copy:
                     view.copy_(g)
                 p.grad = view
+        return skipped
 
 
 def apply_gradient_allreduce(module):
@@ -146,8 +156,6 @@ def apply_gradient_allreduce(module):
         if module.needs_reduction:
             module.needs_reduction = False
             arena.adopt_stray_grads(copy=True)
-            from . import ops
-            ops.join_side_stream()                               # side-stream weight-gradient GEMMs write into the arena
             _avg_all_reduce(arena.flat_grad)                     # C2: the only per-step collective
 
     def allreduce_hook(*unused):

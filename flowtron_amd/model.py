@@ -18,12 +18,11 @@ from torch import nn
 
 from . import _lib as L
 from . import ops
-from . import pipeline
 
-# train.py-format checkpoints pickle the whole nn.Module; torch >= 2.6 refuses them under the
-# default weights_only=True, which would break the reference's unmodified train.py resume path
-# (train.py:87,112).  Same remedy the reference environment would need.
-os.environ.setdefault("TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD", "1")
+# NOTE: train.py-format checkpoints pickle the whole nn.Module; torch >= 2.6 refuses them under the default
+# weights_only=True.  Running the reference's unmodified train.py resume path (train.py:87,112) therefore needs
+# TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD=1 in the environment of THAT process -- this package does not change
+# the process-wide torch.load safety default at import.
 
 
 # --------------------------------------------------------------------------
@@ -201,8 +200,6 @@ class AR_Step(nn.Module):
         Returns (z [T,B,M], log_s [T,B,M], gates [T,B,1] | None, attn [B,T,L], attn_logprob [B,T,L])."""
         T, B, M = mel.shape
         mode = L.mfma_mode()
-        if not self.use_cumm_attention and torch.is_grad_enabled() and pipeline.enabled(T):
-            return pipeline.ar_step_forward_pipelined(self, mel, text, in_lens32, out_lens32, attn_prior)
         mel0 = torch.cat([mel.new_zeros(1, B, M), mel[:-1]], 0)              # flowtron.py:726-729
         a = self.attention_lstm
         h_att = ops.lstm_layer(mel0, out_lens32, a.weight_ih_l0, a.weight_hh_l0, a.bias_ih_l0, a.bias_hh_l0, mode=mode)
@@ -210,9 +207,6 @@ class AR_Step(nn.Module):
             ctx, attn, logprob = self.run_cumm_attn_sequence(h_att, text, in_lens32)   # drops the prior like flowtron.py:742-743
         else:
             ctx, attn, logprob = self.attention_layer(h_att, text, text, in_lens32, attn_prior)
-        # attention-CTC (value + gradient) on a side stream, under the decoder-LSTM launch chain (no-op unless a
-        # FlowtronLoss with the CTC term exists; flowtron.py:245-274 evaluates it at loss time)
-        ops.ctc_prefetch(logprob, in_lens32, out_lens32, getattr(self, "_time_reversed", False))
         gates = None
         if hasattr(self, "gate_layer"):
             g = self.gate_layer.linear_layer
@@ -402,9 +396,6 @@ class Flowtron(nn.Module):
         """mel [B,M,T], speaker_ids [B], text [B,L] (sorted by in_lens desc), in_lens/out_lens [B],
         attn_prior [B,T,L] | None -> the reference's 8-tuple (flowtron.py:898-899)."""
         L.require_cuda(mel, text, in_lens, out_lens, attn_prior)
-        # the per-frame cumulative-attention loop reuses weight matrices T times per step: their gradients must go through
-        # autograd's accumulation, not the single-consumer side-stream path (ops._side_dw_target)
-        ops.set_side_dw(not any(getattr(f.ar_step if hasattr(f, "ar_step") else f, "use_cumm_attention", False) for f in self.flows))
         enc, in32 = self._encode(speaker_ids, text, in_lens)
         out32 = ops.lens32(out_lens)
         x = mel.permute(2, 0, 1).contiguous().float()
@@ -447,9 +438,9 @@ class Flowtron(nn.Module):
 # --------------------------------------------------------------------------
 class AttentionCTCLoss(nn.Module):
     """flowtron.py:155-182: the reference loops over samples (slice, log_softmax, CTCLoss with target 1..K,
-    reduction='mean' per sample, F*B host synchronisations per step).  Device tensors go through ONE pair of HIP kernels
-    for the whole batch (ft_attn_ctc_fwd/bwd: log-softmax normaliser + banded alpha/beta recursion, one workgroup per
-    sample).  The torch formulation below the early return is the same computation for CPU tensors (host-side tests)."""
+    reduction='mean' per sample, F*B host synchronisations per step).  Here ONE pair of HIP kernels handles the whole
+    batch (ft_attn_ctc_fwd/bwd: log-softmax normaliser + banded alpha/beta recursion, one workgroup per sample).
+    Device tensors only -- the torch restatement used to pin the batching lives in tests/test_host_cpu.py."""
 
     def __init__(self, blank_logprob=-1):
         super().__init__()
@@ -457,18 +448,8 @@ class AttentionCTCLoss(nn.Module):
 
     def forward(self, attn_logprob, in_lens, out_lens):
         """attn_logprob [B,T,L] in natural time order."""
-        if attn_logprob.is_cuda:          # product path: banded-DP HIP kernel (csrc/ctc.hip), no torch math
-            return ops.AttnCTCFn.apply(attn_logprob, ops.lens32(in_lens), ops.lens32(out_lens), self.blank_logprob)
-        # host restatement (CPU tensors only: used by the CPU test-suite to pin the batching against the per-sample loop)
-        B, T, Lk = attn_logprob.shape
-        x = torch.nn.functional.pad(attn_logprob, (1, 0), value=self.blank_logprob)       # [B,T,L+1], blank first
-        cls = torch.arange(Lk + 1, device=x.device)[None, None, :]
-        x = x.masked_fill(cls > in_lens[:, None, None], -1.0e4)   # exp() underflows to exactly 0: same softmax, finite grads
-        lp = torch.log_softmax(x, dim=2).transpose(0, 1)                                   # [T,B,L+1]
-        targets = torch.arange(1, Lk + 1, device=x.device)[None, :].expand(B, -1)
-        loss = torch.nn.functional.ctc_loss(lp, targets, input_lengths=out_lens, target_lengths=in_lens, blank=0,
-                                            reduction="none", zero_infinity=True)
-        return (loss / in_lens.to(loss.dtype)).mean()
+        L.require_cuda(attn_logprob, in_lens, out_lens)
+        return ops.AttnCTCFn.apply(attn_logprob, ops.lens32(in_lens), ops.lens32(out_lens), self.blank_logprob)
 
 
 class FlowtronLoss(nn.Module):
@@ -484,8 +465,6 @@ class FlowtronLoss(nn.Module):
         self.ctc_loss_weight = ctc_loss_weight
         self.blank_logprob = blank_logprob
         self.attention_loss = AttentionCTCLoss(blank_logprob=self.blank_logprob)
-        # let the model's forward start the CTC recursion early, on a side stream (ops.ctc_prefetch)
-        ops.set_ctc_prefetch(self.blank_logprob if (use_ctc_loss and ctc_loss_weight) else None)
 
     def forward(self, model_output, gate_target, in_lengths, out_lengths, is_validation=False):
         z, log_s_list, gate_pred, attn_list, attn_logprob_list = model_output[:5]
@@ -496,22 +475,13 @@ class FlowtronLoss(nn.Module):
             gate_loss = ops.GateBCEFn.apply(gate_pred, gate_target, out32)
         loss_ctc = torch.zeros_like(gate_loss)
         if self.use_ctc_loss:
-            total, pending = None, []
+            lps = []
             for i, lp in enumerate(attn_logprob_list):
-                c = ops.ctc_prefetched(lp, self.blank_logprob, i % 2 != 0) if lp.is_cuda else None
-                if c is None:
-                    if i % 2 != 0:
-                        lp = ops.reverse_by_length(lp, out32, False)   # back-step flows are in reversed time (:250-256)
-                    if lp.is_cuda and len(attn_logprob_list) > 1:
-                        pending.append(lp)                             # all flows go through ONE kernel pair below
-                        continue
-                    c = self.attention_loss(lp, in_lengths, out_lengths)
-                total = c if total is None else total + c
-            if pending:
-                # the DP is one workgroup per sample and latency-bound in T: F flows stacked along the batch cost the time
-                # of one (F*B of 256 CUs busy).  mean over F*B samples * F == sum over flows of the per-flow batch means.
-                F_ = len(pending)
-                c = self.attention_loss(torch.cat(pending, 0), in_lengths.repeat(F_), out_lengths.repeat(F_)) * float(F_)
-                total = c if total is None else total + c
-            loss_ctc = total / float(len(attn_logprob_list))
+                if i % 2 != 0:
+                    lp = ops.reverse_by_length(lp, out32, False)       # back-step flows are in reversed time (:250-256)
+                lps.append(lp)
+            # the DP is one workgroup per sample and latency-bound in T: F flows stacked along the batch cost the time
+            # of one (F*B of 256 CUs busy).  mean over the F*B stacked samples == mean over flows of the per-flow batch means.
+            F_ = len(lps)
+            loss_ctc = self.attention_loss(torch.cat(lps, 0) if F_ > 1 else lps[0], in_lengths.repeat(F_), out_lengths.repeat(F_))
         return loss, gate_loss, loss_ctc

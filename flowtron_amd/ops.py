@@ -31,13 +31,13 @@ _BF16_IMAGES = _os.environ.get("FLOWTRON_GEMM_IMAGES", "1") != "0"
 
 
 def gemm_raw(A, B, Cm, M, N, K, sAm, sAk, sBk, sBn, ldc, bias=None, act=L.ACT_NONE, alpha=1.0, beta=0.0,
-             batch=1, bsA=0, bsB=0, bsC=0, mode=None, splitk=False, tile256=False):
+             batch=1, bsA=0, bsB=0, bsC=0, mode=None, splitk=False):
     """C = act(alpha*A.B + beta*C + bias); A,B,Cm are tensors whose data_ptr is the operand origin.
     splitk=True (weight-gradient GEMMs only) allows the atomic split-K path."""
     L.require_cuda(A, B, Cm, bias)
     a = L.GemmArgs(L.ptr(A), L.ptr(B), L.ptr(Cm), L.ptr(bias), M, N, K, batch,
                    sAm, sAk, sBk, sBn, ldc, bsA, bsB, bsC, alpha, beta, act,
-                   L.mfma_mode() if mode is None else mode, (L.GEMM_SPLITK if splitk else 0) | (L.GEMM_TILE256 if tile256 else 0),
+                   L.mfma_mode() if mode is None else mode, L.GEMM_SPLITK if splitk else 0,
                    None, 0)
     if _BF16_IMAGES:
         need = L.lib().ft_gemm_workspace_bytes(C.byref(a))
@@ -140,56 +140,6 @@ def _handoff_take(t):
     return _HANDOFF["imgs"].pop((t.data_ptr(), tuple(t.shape)), None)
 
 
-# --------------------------------------------------------------------------
-# weight-gradient GEMMs on a side stream
-# --------------------------------------------------------------------------
-# dW = dpre^T x is needed only by the optimizer, never by the rest of the backward pass, while the backward critical path
-# is a chain of ~5 us LSTM launches that leaves the chip mostly idle.  When the weight is a leaf whose .grad already
-# exists (the flat gradient arena of flowtron_amd.dist / optim), the dW GEMM accumulates straight into it (beta = 1) on a
-# side stream and the Function returns None for dW; the calling stream re-joins the side stream once, at the end of
-# backward (engine callback), before the all-reduce / optimizer read the arena.  Each weight matrix must then have a single
-# consumer per step (true for the default model; Flowtron.forward disables it for the per-frame cumulative-attention loop).
-_SIDE = {"enabled": True, "streams": {}, "pending": set()}
-
-
-def set_side_dw(enabled: bool):
-    _SIDE["enabled"] = bool(enabled)
-
-
-def join_side_stream():
-    """Make the current stream wait for every outstanding side-stream weight-gradient GEMM."""
-    for dev in list(_SIDE["pending"]):
-        torch.cuda.current_stream(dev).wait_stream(_SIDE["streams"][dev])
-    _SIDE["pending"].clear()
-
-
-def _side_dw_target(W):
-    import os
-    if not _SIDE["enabled"] or os.environ.get("FLOWTRON_DW_STREAM", "0") != "1":     # opt-in: measured neutral (DESIGN.md)
-        return None
-    if not (W.is_leaf and W.requires_grad and W.grad is not None and W.grad.is_contiguous() and W.grad.shape == W.shape):
-        return None
-    return W.grad
-
-
-def _on_side(dev, fn, *tensors):
-    side = _SIDE["streams"].get(dev)
-    if side is None:
-        side = _SIDE["streams"][dev] = torch.cuda.Stream(device=dev)
-    cur = torch.cuda.current_stream(dev)
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        fn()
-    for t in tensors:
-        t.record_stream(side)
-    if dev not in _SIDE["pending"]:
-        _SIDE["pending"].add(dev)
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
-        except RuntimeError:          # not inside a backward pass (direct call of .backward of a Function in a test)
-            join_side_stream()
-
-
 def colsum(x2d: torch.Tensor, rows: int, N: int, ld: int) -> torch.Tensor:
     out = torch.empty(N, device=x2d.device, dtype=torch.float32)
     L.check(L.lib().ft_colsum(L.ptr(x2d), L.ptr(out), rows, N, ld, L.stream()), "ft_colsum")
@@ -209,7 +159,6 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, W, bias, act, mode, *xs):
         xs = [_c(x) for x in xs]
         L.require_cuda(W, *xs)
-        W_in = W
         W = _c(W)
         N, Ktot = W.shape
         rows = xs[0].numel() // xs[0].shape[-1]
@@ -235,7 +184,6 @@ class LinearFn(torch.autograd.Function):
         assert off == Ktot
         ctx.save_for_backward(W, y if act != L.ACT_NONE else None, *xs)
         ctx.act, ctx.mode, ctx.has_bias = act, mode, bias is not None
-        ctx.W_leaf = W_in if (W_in.is_leaf and W_in.is_contiguous()) else None
         return y
 
     @staticmethod
@@ -249,13 +197,12 @@ class LinearFn(torch.autograd.Function):
             L.check(L.lib().ft_act_bwd(L.ptr(y), L.ptr(dy), L.ptr(dpre), dy.numel(), ctx.act, L.stream()), "ft_act_bwd")
         else:
             dpre = dy
-        gW = _side_dw_target(ctx.W_leaf) if (ctx.needs_input_grad[0] and ctx.W_leaf is not None) else None
-        dW = torch.empty_like(W) if (ctx.needs_input_grad[0] and gW is None) else None
+        dW = torch.empty_like(W) if ctx.needs_input_grad[0] else None
         want_db = ctx.has_bias and ctx.needs_input_grad[1]
         db = None
         dxs = []
         off = 0
-        imgs = ctx.imgs if (ctx.imgs is not None and gW is None) else None
+        imgs = ctx.imgs
         if imgs is not None:
             w_img, x_imgs = imgs
             d_img = _handoff_take(dpre) if ctx.act == L.ACT_NONE else None      # e.g. the LSTM backward already made it
@@ -282,9 +229,6 @@ class LinearFn(torch.autograd.Function):
                     gemm_img(d_img, 1, d_img.ptr(), x_imgs[i], 1, x_imgs[i].ptr(), dW[:, off:], N, K, rows, Ktot, splitk=True)
                 else:
                     gemm_raw(dpre, x, dW[:, off:], N, K, rows, 1, N, K, 1, Ktot, mode=ctx.mode, splitk=True)
-            elif gW is not None:
-                _on_side(dpre.device, lambda x=x, off=off, K=K: gemm_raw(dpre, x, gW[:, off:], N, K, rows, 1, N, K, 1, Ktot,
-                                                                        beta=1.0, mode=ctx.mode, splitk=True), dpre, x)
             off += K
         ctx.imgs = None
         return (dW, db, None, None, *dxs)
@@ -395,7 +339,6 @@ def conv_norm_relu(x, lens, conv_w, conv_b, gamma, beta, keep=None, eps=1e-5, mo
 class LSTMSeqFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gx, w_hh, lens, reverse, mode):
-        ctx.w_leaf = w_hh if (w_hh.is_leaf and w_hh.is_contiguous()) else None
         gx, w_hh = _c(gx), _c(w_hh)
         L.require_cuda(gx, w_hh, lens)
         T, B, H4 = gx.shape
@@ -425,21 +368,15 @@ class LSTMSeqFn(torch.autograd.Function):
             rows = (T - 1) * B
             da = dgx[1:] if not ctx.reverse else dgx[:-1]
             hp = y[:-1] if not ctx.reverse else y[1:]
-            gW = _side_dw_target(ctx.w_leaf) if ctx.w_leaf is not None else None
-            if gW is not None:
-                if T > 1:
-                    _on_side(dy.device, lambda: gemm_raw(da, hp, gW, 4 * H, H, rows, 1, 4 * H, H, 1, H, beta=1.0, mode=ctx.mode,
-                                                         splitk=True), dgx, y)
-            else:
-                dW = torch.zeros_like(w_hh)
-                if T > 1 and images_apply(ctx.mode, 4 * H, H, rows):
-                    # images of dgates / outputs over all T*B rows; the one-step shift is a row offset into them
-                    d_img, y_img = Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True), shared_image(y, T * B, H)
-                    fwd = not ctx.reverse
-                    gemm_img(d_img, 1, d_img.ptr(B if fwd else 0), y_img, 1, y_img.ptr(0 if fwd else B), dW, 4 * H, H, rows, H, splitk=True)
-                    _handoff_put(dgx, d_img)        # the input projection's backward reads the same dgates
-                elif T > 1:
-                    gemm_raw(da, hp, dW, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=ctx.mode, splitk=True)
+            dW = torch.zeros_like(w_hh)
+            if T > 1 and images_apply(ctx.mode, 4 * H, H, rows):
+                # images of dgates / outputs over all T*B rows; the one-step shift is a row offset into them
+                d_img, y_img = Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True), shared_image(y, T * B, H)
+                fwd = not ctx.reverse
+                gemm_img(d_img, 1, d_img.ptr(B if fwd else 0), y_img, 1, y_img.ptr(0 if fwd else B), dW, 4 * H, H, rows, H, splitk=True)
+                _handoff_put(dgx, d_img)        # the input projection's backward reads the same dgates
+            elif T > 1:
+                gemm_raw(da, hp, dW, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=ctx.mode, splitk=True)
         return dgx, dW, None, None, None
 
 
@@ -793,91 +730,6 @@ class AttnCTCFn(torch.autograd.Function):
         L.check(L.lib().ft_attn_ctc_bwd(L.ptr(lp), L.ptr(in32), L.ptr(out32), ctx.blank, L.ptr(work), L.ptr(gd), L.ptr(dlp),
                                         B, T, Lk, ctx.with_beta, L.stream()), "ft_attn_ctc_bwd")
         return dlp, None, None, None
-
-
-# ---- attention-CTC computed AHEAD of the loss, on a side stream -------------------------------------------------
-# The banded DP is one workgroup per sample (32 of 256 CUs busy for ~1.2 ms per flow, forward + gradient) and depends only
-# on the attention log-probabilities, which exist long before the loss is evaluated.  When a FlowtronLoss with the CTC term
-# has been constructed, AR_Step.forward launches alpha AND the beta/gradient sweep right after the attention kernel on a
-# side stream, where it overlaps the decoder-LSTM launch chain (which leaves the chip mostly idle); the loss later joins the
-# stream and its backward is a scale of the stored gradient.  Same kernels, same numbers as AttnCTCFn.
-# MEASURED NEUTRAL on the training step (79.1 vs 78.8 ms): kept as an opt-in (FLOWTRON_CTC_PREFETCH=1) with its parity test.
-_CTC_PREFETCH = {"blank": None, "streams": {}}
-
-
-def set_ctc_prefetch(blank_logprob):
-    """blank_logprob of the FlowtronLoss that will consume the prefetched value, or None to switch prefetching off."""
-    _CTC_PREFETCH["blank"] = None if blank_logprob is None else float(blank_logprob)
-
-
-def _reverse_raw(x, lens32, time_major):
-    y = torch.empty_like(x)
-    if time_major:
-        T, B, Cc = x.shape
-    else:
-        B, T, Cc = x.shape
-    L.check(L.lib().ft_reverse_by_length(L.ptr(x), L.ptr(y), L.ptr(lens32), T, B, Cc, int(time_major), L.stream()),
-            "ft_reverse_by_length")
-    return y
-
-
-def ctc_prefetch(lp, in_lens32, out_lens32, time_reversed):
-    """lp [B,T,L] attention log-probabilities of one flow (time-reversed for back-step flows, flowtron.py:250-256)."""
-    import os
-    blank = _CTC_PREFETCH["blank"]
-    if (blank is None or not lp.is_cuda or not torch.is_grad_enabled() or not lp.requires_grad
-            or os.environ.get("FLOWTRON_CTC_PREFETCH", "0") != "1"):          # opt-in: measured neutral (79.1 vs 78.8 ms/step)
-        return
-    dev = lp.device
-    side = _CTC_PREFETCH["streams"].get(dev)
-    if side is None:
-        side = _CTC_PREFETCH["streams"][dev] = torch.cuda.Stream(device=dev)
-    cur = torch.cuda.current_stream(dev)
-    side.wait_stream(cur)
-    src = _c(lp.detach().float())
-    with torch.cuda.stream(side):
-        x = _reverse_raw(src, out_lens32, False) if time_reversed else src
-        B, T, Lk = x.shape
-        work = torch.empty(L.lib().ft_attn_ctc_workspace_floats(B, T, Lk), device=dev, dtype=torch.float32)
-        loss = torch.empty(1, device=dev, dtype=torch.float32)
-        one = torch.ones(1, device=dev, dtype=torch.float32)
-        dlp = torch.empty_like(x)
-        L.check(L.lib().ft_attn_ctc_fwd(L.ptr(x), L.ptr(in_lens32), L.ptr(out_lens32), blank, L.ptr(work), L.ptr(loss),
-                                        B, T, Lk, 1, L.stream()), "ft_attn_ctc_fwd")
-        L.check(L.lib().ft_attn_ctc_bwd(L.ptr(x), L.ptr(in_lens32), L.ptr(out_lens32), blank, L.ptr(work), L.ptr(one), L.ptr(dlp),
-                                        B, T, Lk, 1, L.stream()), "ft_attn_ctc_bwd")
-        if time_reversed:
-            dlp = _reverse_raw(dlp, out_lens32, False)       # gradient back in the flow's own (reversed) time order
-        ev = torch.cuda.Event()
-        ev.record(side)
-    for t in (src, in_lens32, out_lens32):
-        t.record_stream(side)
-    lp._ctc_pre = dict(blank=blank, reversed=bool(time_reversed), loss=loss, dlp=dlp, event=ev)
-
-
-class CTCPrefetchedFn(torch.autograd.Function):
-    """joins the side stream; value and gradient were computed by ctc_prefetch()."""
-
-    @staticmethod
-    def forward(ctx, lp, pre):
-        cur = torch.cuda.current_stream(lp.device)
-        cur.wait_event(pre["event"])
-        pre["loss"].record_stream(cur)
-        pre["dlp"].record_stream(cur)
-        ctx.dlp = pre["dlp"]
-        return pre["loss"].reshape(()).clone()
-
-    @staticmethod
-    def backward(ctx, g):
-        return ctx.dlp * g, None
-
-
-def ctc_prefetched(lp, blank_logprob, time_reversed):
-    """the prefetched CTC term of `lp` if ctc_prefetch() ran for it with the same blank / time order, else None."""
-    pre = getattr(lp, "_ctc_pre", None)
-    if pre is None or pre["blank"] != float(blank_logprob) or pre["reversed"] != bool(time_reversed):
-        return None
-    return CTCPrefetchedFn.apply(lp, pre)
 
 
 # --------------------------------------------------------------------------

@@ -3,7 +3,11 @@ reduction for the global grad norm (train.py:328 clip_grad_norm_) and one fused 
 pass -- instead of ~12 small kernels x 68 tensors.
 
 Optimizer state keeps the reference's per-parameter keys (`step`, `exp_avg`, `exp_avg_sq`; radam.py:63-66)
-as views into flat moment arenas, so `optimizer.state_dict()` stays checkpoint-compatible (train.py:123,138).
+as views into flat moment arenas, so `optimizer.state_dict()` stays checkpoint-compatible (train.py:123,138), and
+`load_state_dict` copies a loaded checkpoint's moments back INTO the arenas (the kernels read only the arenas).
+
+Parameters whose .grad is None at step() time are skipped like radam.py:57-58 (`if p.grad is None: continue`): no moment
+update, no weight decay; they do not enter the global norm either (torch clip_grad_norm_ ignores them).
 """
 from __future__ import annotations
 
@@ -32,11 +36,36 @@ class RAdam(Optimizer):
         self.flat_m = torch.zeros_like(arena.flat_grad)
         self.flat_v = torch.zeros_like(arena.flat_grad)
         self.gnorm_sq = torch.zeros(1, device=arena.flat_grad.device, dtype=torch.float32)
-        for p, off in zip(arena.params, arena.offsets):
-            k = p.numel()
-            self.state[p] = {"step": 0, "exp_avg": self.flat_m[off:off + k].view_as(p.data),
-                             "exp_avg_sq": self.flat_v[off:off + k].view_as(p.data)}
         self._step = 0
+        self._bind_state()
+
+    def _bind_state(self):
+        """state[p] = views into the flat moment arenas (keys of radam.py:63-66)."""
+        a = self.arena
+        for p, off in zip(a.params, a.offsets):
+            k = p.numel()
+            self.state[p] = {"step": self._step, "exp_avg": self.flat_m[off:off + k].view_as(p.data),
+                             "exp_avg_sq": self.flat_v[off:off + k].view_as(p.data)}
+
+    def load_state_dict(self, state_dict):
+        """train.py:123 resume: the base class swaps state[p] for fresh tensors; the fused kernel reads flat_m / flat_v /
+        _step, so the loaded moments are copied into the arenas and state[p] is re-pointed at the views."""
+        super().load_state_dict(state_dict)
+        a = self.arena
+        step = 0
+        with torch.no_grad():
+            for p, off in zip(a.params, a.offsets):
+                st = self.state.get(p)
+                k = p.numel()
+                if st and "exp_avg" in st:
+                    self.flat_m[off:off + k].copy_(st["exp_avg"].reshape(-1).to(self.flat_m))
+                    self.flat_v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1).to(self.flat_v))
+                    step = max(step, int(st.get("step", 0)))
+                else:                                  # parameter never stepped in the saved run (radam.py:60-66 lazy init)
+                    self.flat_m[off:off + k].zero_()
+                    self.flat_v[off:off + k].zero_()
+        self._step = step
+        self._bind_state()
 
     @staticmethod
     def step_size_for(step, lr, beta1, beta2):
@@ -54,8 +83,6 @@ class RAdam(Optimizer):
         """Enqueue ||g||^2 on device and remember the clip for the next step(); returns the device scalar ||g||^2
         (no host sync -- torch.nn.utils.clip_grad_norm_ at train.py:328 does 68 norms and a sync)."""
         a = self.arena
-        from . import ops
-        ops.join_side_stream()
         a.adopt_stray_grads(copy=True)
         self.gnorm_sq.zero_()
         L.check(L.lib().ft_sumsq(L.ptr(a.flat_grad), L.ptr(self.gnorm_sq), a.numel, L.stream()), "ft_sumsq")
@@ -67,9 +94,11 @@ class RAdam(Optimizer):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
         a = self.arena
-        from . import ops
-        ops.join_side_stream()
-        a.adopt_stray_grads(copy=True)
+        skipped = a.adopt_stray_grads(copy=True)
+        # radam.py:57-58: a parameter without a gradient is left untouched (rare: frozen / unused branches) -- the fused
+        # kernel sweeps the whole arena, so its slices are restored afterwards
+        keep = [(off, k, a.flat_param[off:off + k].clone(), self.flat_m[off:off + k].clone(), self.flat_v[off:off + k].clone())
+                for off, k in skipped]
         self._step += 1
         beta1, beta2 = g["betas"]
         ss, rect = self.step_size_for(self._step, g["lr"], beta1, beta2)
@@ -78,6 +107,10 @@ class RAdam(Optimizer):
                                       a.numel, L.ptr(self.gnorm_sq) if clip > 0 else None, clip, g["lr"], beta1, beta2,
                                       g["eps"], g["weight_decay"], ss, int(rect), L.stream()), "ft_radam_step")
         self._clip = 0.0
+        for off, k, pv, mv, vv in keep:
+            a.flat_param[off:off + k].copy_(pv)
+            self.flat_m[off:off + k].copy_(mv)
+            self.flat_v[off:off + k].copy_(vv)
         for p in a.params:
             self.state[p]["step"] = self._step
         return loss

@@ -36,7 +36,7 @@ extern "C" {
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1 };
 enum { FT_ACT_NONE = 0, FT_ACT_TANH = 1, FT_ACT_RELU = 2, FT_ACT_SIGMOID = 3 };
-enum { FT_GEMM_SPLITK = 1, FT_GEMM_TILE256 = 2 };
+enum { FT_GEMM_SPLITK = 1 };
 
 int ft_abi_version(void);
 const char* ft_last_error(void);
@@ -58,8 +58,7 @@ typedef struct {
     int act, mode;
     int flags;   /* FT_GEMM_SPLITK: allow split-K with fp32 atomics when the output has few tiles and K is long (weight
                   * gradients over T*B rows).  Summation order is then not reproducible bit-for-bit, so the forward path
-                  * never sets it.  FT_GEMM_TILE256: use the 256x256x32 / 512-thread tile when the problem is large (opt-in:
-                  * slower than the default 128x128 tile at 3 workgroups/CU on the training workload). */
+                  * never sets it. */
     void* work;  /* optional scratch (256-byte aligned) of ft_gemm_workspace_bytes() bytes.  When given (FT_BF16, batch 1,
                   * problem large enough for the query to be non-zero) the operands are first rewritten once as zero-padded
                   * bf16 images with the reduction dimension innermost and the GEMM runs from those through direct
@@ -131,17 +130,6 @@ int ft_lstm_seq_fwd(const float* gx, const float* w_hh, const int32_t* lens,
 int ft_lstm_seq_bwd(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens,
                     const float* gates, const float* cell, float* dgx, void* work,
                     int T, int B, int H, int reverse, int mode, void* stream);
-
-/* Chunked form for stream-pipelined recurrences: process steps [s_begin, s_end) of the SAME sequence; `work` (and for
- * backward the carries inside it) must persist between the calls of one sequence.  State is initialised when
- * s_begin == 0 (forward) / s_end == T (backward, which sweeps s_end-1 .. s_begin).  All buffers are the full [T,...]
- * buffers.  use_graph != 0 replays the launch chain of a chunk as one cached hipGraph (keyed by every argument). */
-int ft_lstm_seq_fwd_range(const float* gx, const float* w_hh, const int32_t* lens,
-                          float* y, int64_t ldy, float* gates, float* cell, void* work,
-                          int T, int B, int H, int reverse, int mode, int s_begin, int s_end, int use_graph, void* stream);
-int ft_lstm_seq_bwd_range(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens,
-                          const float* gates, const float* cell, float* dgx, void* work,
-                          int T, int B, int H, int reverse, int mode, int s_begin, int s_end, int use_graph, void* stream);
 
 /* Two stacked layers (the decoder nn.LSTM(.., num_layers=2), flowtron.py:654, :760-765) as ONE launch chain: layer 1 at
  * time t-1 and layer 0 at time t are two workgroup groups of the same launch, and layer 1's input projection

@@ -414,28 +414,6 @@ def test_lstm2_wavefront_chain_vs_oracle_and_unfused(env, T, B, H):
         assert rel(a.grad, u.grad) < 2e-2, (name, "fused vs unfused", rel(a.grad, u.grad))
 
 
-@pytest.mark.parametrize("M,N,K,splitk", [(4096, 3072, 96, False), (1536, 1100, 4100, True)])
-def test_gemm_256_tile_bf16(env, M, N, K, splitk):
-    """bf16 path, both output dims >= 512: the 256x256x32 / 512-thread tile (all four vectorised operand layouts)."""
-    L, ops = env
-    torch.manual_seed(M + K)
-    for ta in (False, True):
-        for tb in (False, True):
-            A = torch.randn(K, M) if ta else torch.randn(M, K)
-            Bm = torch.randn(N, K) if tb else torch.randn(K, N)
-            Am = A.t() if ta else A
-            Bk = Bm.t() if tb else Bm
-            alpha = 1.0 / math.sqrt(K)
-            ref = (alpha * (Am.double() @ Bk.double())).float()
-            Cd = torch.full((M, N), 7.0, device="cuda")
-            sAm, sAk = (1, M) if ta else (K, 1)
-            sBk, sBn = (1, K) if tb else (N, 1)
-            ops.gemm_raw(g(A), g(Bm), Cd, M, N, K, sAm, sAk, sBk, sBn, N, alpha=alpha, mode=1, splitk=splitk, tile256=True)
-            torch.cuda.synchronize()
-            assert mad(Cd, ref) < 3e-2, (ta, tb, mad(Cd, ref))
-            assert rel(Cd, ref) < 6e-3, (ta, tb, rel(Cd, ref))
-
-
 def test_lstm2_batch_64_four_tiles(env):
     """B = 64 (four 16-row MFMA tiles, the C ABI maximum) through the two-layer wavefront chain."""
     L, ops = env
