@@ -19,7 +19,7 @@ FT_F32, FT_BF16 = 0, 1
 GEMM_SPLITK = 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 
-_p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_p, _i, _l, _f, _sz, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_double
 
 
 class GemmArgs(C.Structure):
@@ -67,6 +67,10 @@ SIGNATURES = {
     "ft_lstm_workspace_bytes": ([_i, _i], _sz),
     "ft_lstm_seq_fwd": ([_p, _p, _p, _p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "ft_lstm_seq_bwd": ([_p, _l, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "ft_lstm_persist_supported": ([_i, _i], _i),
+    "ft_lstm_persist_workspace_bytes": ([_i, _i], _sz),
+    "ft_lstm_persist_fwd": ([_p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "ft_lstm_persist_bwd": ([_p, _l, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_lstm2_supported": ([_i, _i], _i),
     "ft_lstm2_workspace_bytes": ([_i, _i], _sz),
     "ft_lstm2_seq_fwd": ([_p] * 13 + [_i, _i, _i, _p], _i),
@@ -95,7 +99,7 @@ SIGNATURES = {
     "ft_attn_ctc_bwd": ([_p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_beta_binomial_prior": ([_p, _p, _p, _i, _i, _i, _f, _p], _i),
     "ft_sumsq": ([_p, _p, _l, _p], _i),
-    "ft_radam_step": ([_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _f, _f, _f, _i, _p], _i),
+    "ft_radam_step": ([_p, _p, _p, _p, _l, _p, _d, _d, _d, _d, _d, _d, _d, _i, _p], _i),
 }
 
 _lib = None
@@ -114,7 +118,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argt
             fn.restype = rest
-        if l.ft_abi_version() != 2:
+        if l.ft_abi_version() != 3:
             raise RuntimeError("libflowtron_hip.so ABI version mismatch")
         _lib = l
     return _lib

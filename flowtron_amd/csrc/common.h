@@ -55,6 +55,50 @@ __device__ __forceinline__ float tanhf_(float x) {
     return 1.0f - 2.0f / (e + 1.0f);
 }
 
+// LSTM cell update shared by every recurrence kernel (lstm.hip, lstm2.hip, lstm_persist.hip), with the product / FMA order
+// pinned (the default -ffp-contract=fast may fuse `f*c + i*g` either way in different kernels, and a 1-ulp difference is
+// amplified by the recurrence): kernels that feed it the same pre-activations produce bit-identical states.
+//   FAST = false (fp32 parity mode): libm expf / tanhf.
+//   FAST = true  (bf16 / fp16 operand modes): v_exp_f32 + v_rcp_f32 forms, |abs err| ~ 1e-7 -- two orders below the operand
+//   rounding -- which takes ~100 instructions off the per-step critical path.
+template <bool FAST>
+__device__ __forceinline__ void lstm_cell(const float (&pre)[4], float c_old, float& ig, float& fg, float& gg, float& og,
+                                          float& c_new, float& h_new) {
+    if constexpr (FAST) {
+        constexpr float L2E = 1.4426950408889634f;
+        ig = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * pre[0]));
+        fg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * pre[1]));
+        gg = 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.f * L2E * pre[2]) + 1.f);
+        og = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * pre[3]));
+        c_new = __fmaf_rn(fg, c_old, __fmul_rn(ig, gg));
+        h_new = __fmul_rn(og, 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.f * L2E * c_new) + 1.f));
+    } else {
+        ig = 1.f / (1.f + expf(-pre[0]));
+        fg = 1.f / (1.f + expf(-pre[1]));
+        gg = tanhf(pre[2]);
+        og = 1.f / (1.f + expf(-pre[3]));
+        c_new = __fmaf_rn(fg, c_old, __fmul_rn(ig, gg));
+        h_new = __fmul_rn(og, tanhf(c_new));
+    }
+}
+
+// LSTM cell backward, product order pinned like lstm_cell:
+//   dc = dh o (1 - tanh^2 c_t) + dc_carry ;  carry' = dc f ;  da_i = dc g i(1-i) ; da_f = dc c_prev f(1-f) ;
+//   da_g = dc i (1-g^2) ; da_o = dh tanh(c_t) o(1-o)
+template <bool FAST>
+__device__ __forceinline__ void lstm_cell_bwd(float dh, float dc_carry, float ig, float fg, float gg, float og, float c_t,
+                                              float c_prev, float (&da)[4], float& carry_out) {
+    float tc;
+    if constexpr (FAST) tc = 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.f * 1.4426950408889634f * c_t) + 1.f);
+    else tc = tanhf(c_t);
+    const float dc = __fmaf_rn(__fmul_rn(dh, og), __fmaf_rn(-tc, tc, 1.f), dc_carry);
+    carry_out = __fmul_rn(dc, fg);
+    da[0] = __fmul_rn(__fmul_rn(__fmul_rn(dc, gg), ig), 1.f - ig);
+    da[1] = __fmul_rn(__fmul_rn(__fmul_rn(dc, c_prev), fg), 1.f - fg);
+    da[2] = __fmul_rn(__fmul_rn(dc, ig), __fmaf_rn(-gg, gg, 1.f));
+    da[3] = __fmul_rn(__fmul_rn(__fmul_rn(dh, tc), og), 1.f - og);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -287,8 +287,8 @@ __global__ void sumsq_k(const float* __restrict__ x, float* __restrict__ acc, lo
 //   p -= wd*lr*p (if wd != 0) ; N_sma >= 5: p -= step_size * m/(sqrt(v)+eps) ; else p -= step_size*m
 //   (step_size is the host-computed radam.py:95-105 value and already contains lr)
 __global__ void radam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                        long n, const float* __restrict__ gnorm_sq, float clip, float lr, float b1, float b2, float eps,
-                        float wd, float step_size, int rectified) {
+                        long n, const float* __restrict__ gnorm_sq, float clip, float wd_lr, float b1, float b2, float omb1,
+                        float omb2, float eps, float step_size, int rectified) {
     float cs = 1.f;
     if (gnorm_sq && clip > 0.f) {
         const float nrm = sqrtf(gnorm_sq[0]);
@@ -296,10 +296,12 @@ __global__ void radam_k(float* __restrict__ p, const float* __restrict__ g, floa
     }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * cs;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        // radam.py:76-77: exp_avg_sq.mul_(beta2).addcmul_(1 - beta2, grad, grad); exp_avg.mul_(beta1).add_(1 - beta1, grad)
+        // with (1 - beta) evaluated in DOUBLE by the caller (1 - 0.999f differs from float(1 - 0.999) by 4.7e-5 relative)
+        const float vi = __fmaf_rn(omb2, __fmul_rn(gi, gi), __fmul_rn(b2, v[i]));
+        const float mi = __fmaf_rn(omb1, gi, __fmul_rn(b1, m[i]));
         float pi = p[i];
-        if (wd != 0.f) pi += -wd * lr * pi;
+        if (wd_lr != 0.f) pi = __fmaf_rn(-wd_lr, pi, pi);
         if (rectified) pi += -step_size * (mi / (sqrtf(vi) + eps));
         else pi += -step_size * mi;
         v[i] = vi; m[i] = mi; p[i] = pi;
@@ -443,12 +445,15 @@ extern "C" int ft_sumsq(const float* x, float* acc, int64_t n, void* stream) {
     return FT_OK;
 }
 extern "C" int ft_radam_step(float* p, const float* g, float* m, float* v, int64_t n,
-                             const float* gnorm_sq_dev, float clip, float lr, float beta1, float beta2, float eps,
-                             float weight_decay, float step_size, int rectified, void* stream) {
+                             const float* gnorm_sq_dev, double clip, double lr, double beta1, double beta2, double eps,
+                             double weight_decay, double step_size, int rectified, void* stream) {
     FT_CHECK_ARG(p && g && m && v && n >= 0);
     if (n == 0) return FT_OK;
-    hipLaunchKernelGGL(radam_k, dim3(grid_for(n, NT, 4096)), dim3(NT), 0, ST(stream), p, g, m, v, (long)n, gnorm_sq_dev, clip, lr,
-                       beta1, beta2, eps, weight_decay, step_size, rectified);
+    // hyper-parameters arrive in double, as the python optimizer holds them: the derived coefficients are formed in double
+    // and rounded once, like the scalars radam.py hands to mul_/add_/addcmul_
+    hipLaunchKernelGGL(radam_k, dim3(grid_for(n, NT, 4096)), dim3(NT), 0, ST(stream), p, g, m, v, (long)n, gnorm_sq_dev, (float)clip,
+                       (float)(weight_decay * lr), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
+                       (float)step_size, rectified);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

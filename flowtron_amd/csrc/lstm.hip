@@ -20,6 +20,7 @@
 //              step is one fully coalesced 1 KiB global_load_dwordx4 per wave and the per-step L2
 //              traffic halves; v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Needs H % 32 == 0.
 #include "common.h"
+#include "lstm_images.h"
 
 namespace {
 
@@ -175,12 +176,8 @@ __device__ __forceinline__ void lstm_fwd_body(const FwdP& p) {
         const int n = g * 4 + ul;
         pre[g] = red[0][eb][n] + red[1][eb][n] + red[2][eb][n] + red[3][eb][n] + gxv[g];
     }
-    const float ig = 1.f / (1.f + expf(-pre[0]));
-    const float fg = 1.f / (1.f + expf(-pre[1]));
-    const float gg = tanhf(pre[2]);
-    const float og = 1.f / (1.f + expf(-pre[3]));
-    const float c_new = fg * c_old + ig * gg;
-    const float h_new = og * tanhf(c_new);
+    float ig, fg, gg, og, c_new, h_new;
+    lstm_cell<MODE == 1>(pre, c_old, ig, fg, gg, og, c_new, h_new);
     p.cstate[bu] = c_new;
     if constexpr (MODE == 0) p.hnext[bu] = h_new;
     else p.hfrag_next[frag_index(eb, eu, MT)] = f2bf(h_new);
@@ -230,13 +227,9 @@ __global__ void lstm_bwd_pointwise(BwdP p) {
             const int tp = p.reverse ? t + 1 : t - 1;
             c_prev = p.cell[((size_t)tp * B + b) * H + u];
         }
-        const float tc = tanhf(c_t);
-        const float dc = dh * og * (1.f - tc * tc) + p.dc_carry[idx];
-        p.dc_carry[idx] = dc * fg;
-        da[0] = dc * gg * ig * (1.f - ig);
-        da[1] = dc * c_prev * fg * (1.f - fg);
-        da[2] = dc * ig * (1.f - gg * gg);
-        da[3] = dh * tc * og * (1.f - og);
+        float carry;
+        lstm_cell_bwd<false>(dh, p.dc_carry[idx], ig, fg, gg, og, c_t, c_prev, da, carry);
+        p.dc_carry[idx] = carry;
     }
     float* dg = p.dgx + ((size_t)t * B + b) * 4 * H + u;       // inactive: t == s is a pad row -> zeros
     float* dc_ = p.da_cur + (size_t)b * 4 * H + u;
@@ -346,13 +339,9 @@ __device__ __forceinline__ void lstm_bwd_body_bf16(const BwdP& p) {
         float dh = dyv;
 #pragma unroll
         for (int w = 0; w < 16; ++w) dh += red[w][ebl][jl];
-        const float tc = tanhf(c_t);
-        const float dc = dh * og * (1.f - tc * tc) + dcc;
-        p.dc_carry[(size_t)eb * H + eu] = dc * fg;
-        da[0] = dc * gg * ig * (1.f - ig);
-        da[1] = dc * c_prev * fg * (1.f - fg);
-        da[2] = dc * ig * (1.f - gg * gg);
-        da[3] = dh * tc * og * (1.f - og);
+        float carry;
+        lstm_cell_bwd<true>(dh, dcc, ig, fg, gg, og, c_t, c_prev, da, carry);
+        p.dc_carry[(size_t)eb * H + eu] = carry;
     }
     if (!active) t = p.s;                                        // inactive: row s is a pad row -> zeros
     float* dg = p.dgx + ((size_t)t * B + eb) * 4 * H + eu;
@@ -394,35 +383,6 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
     for (int i = threadIdx.y; i < 32; i += 8) {
         int c2 = blockIdx.x * 32 + i;
         if (r2 < R && c2 < Ccols) out[(size_t)c2 * R + r2] = tile[threadIdx.x][i];
-    }
-}
-
-// W_hh [4H][H] fp32 -> forward fragment image [H/4][H/32][64][8] bf16:
-//   block jb, chunk c, lane (kg,li), e  <-  W_hh[(li>>2)*H + jb*4 + (li&3)][c*32 + kg*8 + e]
-__global__ void make_wfrag_fwd(const float* __restrict__ w, unsigned short* __restrict__ out, int H) {
-    const size_t total = (size_t)4 * H * H;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
-        const size_t rest = i >> 9;
-        const int nchunk = H >> 5;
-        const int c = (int)(rest % nchunk), jb = (int)(rest / nchunk);
-        const int li = lane & 15, kg = lane >> 4;
-        const size_t row = (size_t)(li >> 2) * H + jb * 4 + (li & 3);
-        out[i] = f2bf(w[row * H + c * 32 + kg * 8 + e]);
-    }
-}
-// W_hh [4H][H] fp32 -> backward fragment image [H/16][4H/32][64][8] bf16:
-//   tile jt, chunk c (over r = 0..4H), lane (kg,li), e  <-  W_hh[c*32 + kg*8 + e][jt*16 + li]
-__global__ void make_wfrag_bwd(const float* __restrict__ w, unsigned short* __restrict__ out, int H) {
-    const size_t total = (size_t)4 * H * H;
-    const int nchunk = (4 * H) >> 5;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
-        const size_t rest = i >> 9;
-        const int c = (int)(rest % nchunk), jt = (int)(rest / nchunk);
-        const int li = lane & 15, kg = lane >> 4;
-        const size_t r = (size_t)c * 32 + kg * 8 + e;
-        out[i] = f2bf(w[r * H + jt * 16 + li]);
     }
 }
 

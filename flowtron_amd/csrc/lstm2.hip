@@ -218,12 +218,8 @@ __device__ __forceinline__ void lstm2_fwd_body(const L2FwdP& p) {
         for (int w = 0; w < NW; ++w) sum += red[w][eb][n];
         pre[g] = sum;
     }
-    const float ig = 1.f / (1.f + expf(-pre[0]));
-    const float fg = 1.f / (1.f + expf(-pre[1]));
-    const float gg = tanhf(pre[2]);
-    const float og = 1.f / (1.f + expf(-pre[3]));
-    const float c_new = fg * c_old + ig * gg;
-    const float h_new = og * tanhf(c_new);
+    float ig, fg, gg, og, c_new, h_new;
+    lstm_cell<true>(pre, c_old, ig, fg, gg, og, c_new, h_new);
     cst[(size_t)eb * H + eu] = c_new;
     hnext[frag_index(eb, eu, MT)] = f2bf(h_new);
     y[row * H + eu] = h_new;
@@ -345,12 +341,8 @@ __global__ __launch_bounds__(256) void lstm2_fwd_both(L2FwdP p) {
         for (int w = 0; w < 4; ++w) sum += red[lay][w][eb][n];
         pre[g] = sum;
     }
-    const float ig = 1.f / (1.f + expf(-pre[0]));
-    const float fg = 1.f / (1.f + expf(-pre[1]));
-    const float gg = tanhf(pre[2]);
-    const float og = 1.f / (1.f + expf(-pre[3]));
-    const float c_new = fg * c_old + ig * gg;
-    const float h_new = og * tanhf(c_new);
+    float ig, fg, gg, og, c_new, h_new;
+    lstm_cell<true>(pre, c_old, ig, fg, gg, og, c_new, h_new);
     cst[(size_t)eb * H + eu] = c_new;
     hnext[frag_index(eb, eu, MT)] = f2bf(h_new);
     y[row * H + eu] = h_new;
@@ -440,13 +432,9 @@ __device__ __forceinline__ void lstm2_bwd_body(const L2BwdP& p) {
         float dh = dyv;
 #pragma unroll
         for (int w = 0; w < 16; ++w) dh += red[w][ebl][jl];
-        const float tc = tanhf(c_t);
-        const float dc = dh * og * (1.f - tc * tc) + dcc;
-        dcar[(size_t)eb * H + eu] = dc * fg;
-        da[0] = dc * gg * ig * (1.f - ig);
-        da[1] = dc * c_prev * fg * (1.f - fg);
-        da[2] = dc * ig * (1.f - gg * gg);
-        da[3] = dh * tc * og * (1.f - og);
+        float carry;
+        lstm_cell_bwd<true>(dh, dcc, ig, fg, gg, og, c_t, c_prev, da, carry);
+        dcar[(size_t)eb * H + eu] = carry;
     }
     float* dg = (L0 ? p.dgx0 : p.dgx1) + ((size_t)s * B + eb) * 4 * H + eu;     // inactive: pad row -> zeros
     unsigned short* dan = L0 ? p.da0frag[s & 1] : p.da1frag[s & 1];
@@ -570,13 +558,9 @@ __global__ __launch_bounds__(1024) void lstm2_bwd_skew2(L2BwdP p) {
         float dh = dyv;
 #pragma unroll
         for (int w = 0; w < 16; ++w) dh += red[w][ebl][jl];
-        const float tc = tanhf(c_t);
-        const float dc = dh * og * (1.f - tc * tc) + dcc;
-        dcar[(size_t)eb * H + eu] = dc * fg;
-        da[0] = dc * gg * ig * (1.f - ig);
-        da[1] = dc * c_prev * fg * (1.f - fg);
-        da[2] = dc * ig * (1.f - gg * gg);
-        da[3] = dh * tc * og * (1.f - og);
+        float carry;
+        lstm_cell_bwd<true>(dh, dcc, ig, fg, gg, og, c_t, c_prev, da, carry);
+        dcar[(size_t)eb * H + eu] = carry;
     }
     float* dg = (L0 ? p.dgx0 : p.dgx1) + ((size_t)s * B + eb) * 4 * H + eu;     // inactive: pad row -> zeros
     unsigned short* dan = L0 ? p.da0frag[s & 1] : p.da1frag[s & 1];

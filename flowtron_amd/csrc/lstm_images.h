@@ -1,0 +1,36 @@
+// bf16 MFMA-fragment images of W_hh shared by the launch-per-step (lstm.hip) and persistent (lstm_persist.hip) recurrences.
+#pragma once
+#include "common.h"
+
+namespace {
+
+// W_hh [4H][H] fp32 -> forward fragment image [H/4][H/32][64][8] bf16:
+//   block jb, chunk c, lane (kg,li), e  <-  W_hh[(li>>2)*H + jb*4 + (li&3)][c*32 + kg*8 + e]
+__global__ void make_wfrag_fwd(const float* __restrict__ w, unsigned short* __restrict__ out, int H) {
+    const size_t total = (size_t)4 * H * H;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const size_t rest = i >> 9;
+        const int nchunk = H >> 5;
+        const int c = (int)(rest % nchunk), jb = (int)(rest / nchunk);
+        const int li = lane & 15, kg = lane >> 4;
+        const size_t row = (size_t)(li >> 2) * H + jb * 4 + (li & 3);
+        out[i] = f2bf(w[row * H + c * 32 + kg * 8 + e]);
+    }
+}
+// W_hh [4H][H] fp32 -> backward fragment image [H/16][4H/32][64][8] bf16:
+//   tile jt, chunk c (over r = 0..4H), lane (kg,li), e  <-  W_hh[c*32 + kg*8 + e][jt*16 + li]
+__global__ void make_wfrag_bwd(const float* __restrict__ w, unsigned short* __restrict__ out, int H) {
+    const size_t total = (size_t)4 * H * H;
+    const int nchunk = (4 * H) >> 5;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const size_t rest = i >> 9;
+        const int c = (int)(rest % nchunk), jt = (int)(rest / nchunk);
+        const int li = lane & 15, kg = lane >> 4;
+        const size_t r = (size_t)c * 32 + kg * 8 + e;
+        out[i] = f2bf(w[r * H + jt * 16 + li]);
+    }
+}
+
+}  // namespace

@@ -336,6 +336,34 @@ def conv_norm_relu(x, lens, conv_w, conv_b, gamma, beta, keep=None, eps=1e-5, mo
 # --------------------------------------------------------------------------
 # length-masked LSTM sequence (packed nn.LSTM semantics, flowtron.py:689-694, :505-512)
 # --------------------------------------------------------------------------
+_PERSIST_STATUS = {}
+
+
+def persist_status(device):
+    """device int32 word the persistent recurrence kernels raise when a hand-off wait times out (grid not co-resident)."""
+    st = _PERSIST_STATUS.get(device)
+    if st is None:
+        st = _PERSIST_STATUS[device] = torch.zeros(1, device=device, dtype=torch.int32)
+    return st
+
+
+def check_persist_status():
+    """Host check (one sync) of every persistent-kernel status word; raises if a sequence did not complete."""
+    for dev, st in _PERSIST_STATUS.items():
+        if int(st.item()) != 0:
+            st.zero_()
+            raise RuntimeError("persistent LSTM kernel timed out on %s: the 256-workgroup grid was not co-resident "
+                               "(set FLOWTRON_LSTM_PERSIST=0 to use the launch-per-step kernels)" % (dev,))
+
+
+def lstm_persist_groups(B, H, reverse, mode):
+    """batch groups of the persistent forward recurrence (0 = use the launch-per-step kernel)."""
+    ng = int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "0"))
+    if ng and not reverse and mode == L.FT_BF16 and L.lib().ft_lstm_persist_supported(B, H):
+        return ng
+    return 0
+
+
 class LSTMSeqFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gx, w_hh, lens, reverse, mode):
@@ -346,9 +374,16 @@ class LSTMSeqFn(torch.autograd.Function):
         y = torch.empty(T, B, H, device=gx.device, dtype=torch.float32)
         gates = torch.empty(T, B, H4, device=gx.device, dtype=torch.float32)
         cell = torch.empty(T, B, H, device=gx.device, dtype=torch.float32)
-        work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=gx.device, dtype=torch.uint8)
-        L.check(L.lib().ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w_hh), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
-                                        L.ptr(work), T, B, H, int(reverse), mode, L.stream()), "ft_lstm_seq_fwd")
+        ng = lstm_persist_groups(B, H, reverse, mode)
+        if ng:
+            work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=gx.device, dtype=torch.uint8)
+            L.check(L.lib().ft_lstm_persist_fwd(L.ptr(gx), L.ptr(w_hh), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
+                                                L.ptr(work), L.ptr(persist_status(gx.device)), T, B, H, ng, L.stream()),
+                    "ft_lstm_persist_fwd")
+        else:
+            work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=gx.device, dtype=torch.uint8)
+            L.check(L.lib().ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w_hh), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
+                                            L.ptr(work), T, B, H, int(reverse), mode, L.stream()), "ft_lstm_seq_fwd")
         ctx.save_for_backward(w_hh, lens, y, gates, cell)
         ctx.reverse, ctx.mode = bool(reverse), mode
         return y
@@ -359,9 +394,17 @@ class LSTMSeqFn(torch.autograd.Function):
         dy = _c(dy)
         T, B, H = y.shape
         dgx = torch.empty(T, B, 4 * H, device=dy.device, dtype=torch.float32)
-        work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=dy.device, dtype=torch.uint8)
-        L.check(L.lib().ft_lstm_seq_bwd(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
-                                        L.ptr(work), T, B, H, int(ctx.reverse), ctx.mode, L.stream()), "ft_lstm_seq_bwd")
+        ng = lstm_persist_groups(B, H, ctx.reverse, ctx.mode)
+        if ng:
+            ng = ng if ng in (1, 8, 4) else 8
+            work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=dy.device, dtype=torch.uint8)
+            L.check(L.lib().ft_lstm_persist_bwd(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
+                                                L.ptr(work), L.ptr(persist_status(dy.device)), T, B, H, ng, L.stream()),
+                    "ft_lstm_persist_bwd")
+        else:
+            work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=dy.device, dtype=torch.uint8)
+            L.check(L.lib().ft_lstm_seq_bwd(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
+                                            L.ptr(work), T, B, H, int(ctx.reverse), ctx.mode, L.stream()), "ft_lstm_seq_bwd")
         dW = None
         if ctx.needs_input_grad[1]:
             # dW_hh[r,j] = sum_{t,b} da_t[b,r] * h_prev(t)[b,j];  h_prev = y[t-1] (fwd) / y[t+1] (reverse)

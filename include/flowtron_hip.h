@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 2
+#define FT_ABI_VERSION 3
 
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1 };
@@ -130,6 +130,23 @@ int ft_lstm_seq_fwd(const float* gx, const float* w_hh, const int32_t* lens,
 int ft_lstm_seq_bwd(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens,
                     const float* gates, const float* cell, float* dgx, void* work,
                     int T, int B, int H, int reverse, int mode, void* stream);
+
+/* Persistent form of ft_lstm_seq_fwd (forward direction, bf16 MFMA operands, H == 1024, B <= 32, 256-CU device): ONE launch
+ * for the whole sequence.  The chip is split into `ng` (8 | 4 | 2) independent batch groups; every CU keeps the bf16 MFMA
+ * fragments of its W_hh rows in registers for all T steps and the members of a group exchange h_t through 8-byte {epoch, bf16
+ * pair} granules (write-through stores, tag-checked sc1 loads -- no fences).  ng = 1 selects the XCD-local transport: 8 groups
+ * formed at run time from the workgroups' XCC ids, hand-off through the XCD's own L2 (csrc/lstm_persist.hip).
+ * Results are bit-identical to ft_lstm_seq_fwd(FT_BF16).
+ * `status` (device int32, zeroed by the caller once) is raised to 1 if a hand-off wait times out (grid not co-resident);
+ * the caller must check it before trusting y.  work: ft_lstm_persist_workspace_bytes(), 256-byte aligned. */
+int ft_lstm_persist_supported(int B, int H);
+size_t ft_lstm_persist_workspace_bytes(int B, int H);
+int ft_lstm_persist_fwd(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
+                        float* gates, float* cell, void* work, int32_t* status, int T, int B, int H, int ng, void* stream);
+/* Persistent form of ft_lstm_seq_bwd (same restrictions; ng = 1 | 8 | 4): dgx [T,B,4H] from dy, the saved gates / cell and
+ * W_hh; bit-identical to ft_lstm_seq_bwd(FT_BF16).  Same workspace query. */
+int ft_lstm_persist_bwd(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
+                        const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng, void* stream);
 
 /* Two stacked layers (the decoder nn.LSTM(.., num_layers=2), flowtron.py:654, :760-765) as ONE launch chain: layer 1 at
  * time t-1 and layer 0 at time t are two workgroup groups of the same launch, and layer 1's input projection
@@ -271,11 +288,15 @@ int ft_attn_ctc_bwd(const float* lp, const int32_t* in_lens, const int32_t* out_
 int ft_beta_binomial_prior(const int32_t* in_lens, const int32_t* out_lens, float* prior,
                            int B, int T, int L, float scaling, void* stream);
 
-/* ---- fused RAdam over a flat arena (radam.py:44-122) + grad-norm clip ---------- */
+/* ---- fused RAdam over a flat arena (radam.py:44-122) + grad-norm clip ----------
+ * One pass: g *= min(1, clip / (sqrt(*gnorm_sq_dev) + 1e-6)) (torch clip_grad_norm_, train.py:328; skipped when clip == 0
+ * or gnorm_sq_dev == NULL), v = beta2 v + (1-beta2) g g, m = beta1 m + (1-beta1) g, p -= weight_decay*lr*p,
+ * p -= step_size * (rectified ? m / (sqrt(v) + eps) : m).  step_size is radam.py:95-105 (contains lr).  Hyper-parameters
+ * are doubles like the python optimizer's; derived coefficients are rounded to fp32 once. */
 int ft_sumsq(const float* x, float* acc, int64_t n, void* stream);
 int ft_radam_step(float* p, const float* g, float* m, float* v, int64_t n,
-                  const float* gnorm_sq_dev, float clip, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, float step_size, int rectified, void* stream);
+                  const float* gnorm_sq_dev, double clip, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, double step_size, int rectified, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,82 @@
+"""Persistent (one launch per sequence) vs launch-per-step attention-LSTM forward: B = 32, H = 1024, T = 862 (bench shape).
+Prints us/step for each variant + bit-equality of the outputs.  Run on the GPU box: python scripts/exp/lstm_persist_bench.py"""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from flowtron_amd import _lib as L
+
+T, B, H = int(os.environ.get("T", 862)), 32, 1024
+dev = "cuda"
+torch.manual_seed(0)
+gx = torch.randn(T, B, 4 * H, device=dev) * 0.5
+w = torch.randn(4 * H, H, device=dev) / H ** 0.5
+lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+lens[5:] -= torch.arange(B - 5, dtype=torch.int32, device=dev) * 7
+status = torch.zeros(1, dtype=torch.int32, device=dev)
+
+
+def bufs():
+    return (torch.empty(T, B, H, device=dev), torch.empty(T, B, 4 * H, device=dev), torch.empty(T, B, H, device=dev))
+
+
+def run_step(y, g, c, work):
+    L.check(L.lib().ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(g), L.ptr(c), L.ptr(work), T, B, H, 0, 1, L.stream()), "step")
+
+
+def run_persist(ng, y, g, c, work):
+    L.check(L.lib().ft_lstm_persist_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(g), L.ptr(c), L.ptr(work), L.ptr(status),
+                                        T, B, H, ng, L.stream()), "persist")
+
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / T)
+    return min(ts), sorted(ts)[len(ts) // 2]
+
+
+res = {}
+y0, g0, c0 = bufs()
+w0 = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=dev, dtype=torch.uint8)
+res["step"] = timeit(lambda: run_step(y0, g0, c0, w0))
+print("launch-per-step: min %.3f median %.3f us/step" % res["step"], flush=True)
+wp = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=dev, dtype=torch.uint8)
+for ng in (1, 8, 4, 2):
+    y1, g1, c1 = bufs()
+    y1.fill_(7.0)
+    r = timeit(lambda: run_persist(ng, y1, g1, c1, wp))
+    st = int(status.item())
+    act = (torch.arange(T, device=dev)[:, None] < lens[None, :])
+    eq = bool(torch.equal(y0, y1)) and bool(torch.equal(g0[act], g1[act])) and bool(torch.equal(c0[act], c1[act]))
+    res["persist%d" % ng] = r + (st, eq, float((y0 - y1).abs().max()))
+    print("persistent ng=%d (1 = XCD-local transport): min %.3f median %.3f us/step  status %d  bit-identical %s  max|dy| %.3e" % ((ng,) + res["persist%d" % ng]), flush=True)
+    status.zero_()
+# ---- backward
+dy = torch.randn(T, B, H, device=dev) * 0.1
+act3 = (torch.arange(T, device=dev)[:, None] < lens[None, :])
+d0 = torch.empty(T, B, 4 * H, device=dev)
+
+
+def run_step_bwd(dgx, work):
+    L.check(L.lib().ft_lstm_seq_bwd(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(g0), L.ptr(c0), L.ptr(dgx), L.ptr(work), T, B, H, 0, 1, L.stream()), "bstep")
+
+
+def run_persist_bwd(ng, dgx, work):
+    L.check(L.lib().ft_lstm_persist_bwd(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(g0), L.ptr(c0), L.ptr(dgx), L.ptr(work), L.ptr(status),
+                                        T, B, H, ng, L.stream()), "bpersist")
+
+
+res["bwd_step"] = timeit(lambda: run_step_bwd(d0, w0))
+print("backward launch-per-step: min %.3f median %.3f us/step" % res["bwd_step"], flush=True)
+for ng in (1, 8, 4):
+    d1 = torch.full((T, B, 4 * H), 7.0, device=dev)
+    r = timeit(lambda: run_persist_bwd(ng, d1, wp))
+    st = int(status.item())
+    res["bwd_persist%d" % ng] = r + (st, bool(torch.equal(d0, d1)), float((d0 - d1).abs().max()))
+    print("backward persistent ng=%d: min %.3f median %.3f us/step  status %d  bit-identical %s  max|d| %.3e" % ((ng,) + res["bwd_persist%d" % ng]), flush=True)
+    status.zero_()
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(res, open("gpurun_out/lstm_persist_bench.json", "w"))

@@ -240,6 +240,15 @@ def test_device_collate_matches_host_collate_and_prior_kernel():
         assert float(pr[i, T_i:].abs().max() if T_i < 52 else 0.0) == 0.0
 
 
+def _oracle_fwd_bwd(cfg, sd, bc, use_ctc=True):
+    from oracle import flowtron_oracle as O
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.forward(sdg, cfg, bc["mel"], bc["speaker_ids"], bc["text"], bc["in_lens"], bc["out_lens"], bc["attn_prior"])
+    rn, rg, rc = O.loss(ref, bc["gate_target"], bc["in_lens"], bc["out_lens"], 1.0, True, use_ctc, -8)
+    (rn + rg + 0.01 * rc).sum().backward()
+    return ref, (rn, rg, rc), sdg
+
+
 def test_batch_of_one_training_matches_oracle():
     """B = 1: the reference takes the UNMASKED instance-norm / unpacked branch (flowtron.py:498, 117-121); forward, the
     three losses and every gradient against the oracle (fp32 MFMA mode)."""

@@ -546,3 +546,79 @@ def test_bf16_image_and_fused_column_sums(env, rows, cols, off):
         assert int(raw[rows:].abs().max()) == 0 and (cols == ld or int(raw[:, cols:].abs().max()) == 0)
         if with_sum:
             assert mad(img.colsum, wide[:, off:off + cols].double().sum(0).float()) < 2e-4 * math.sqrt(rows)
+
+
+@pytest.mark.parametrize("ng", [1, 8, 4, 2])      # 1 = XCD-local transport (8 groups = 8 XCDs)
+@pytest.mark.parametrize("T,B,lens", [(37, 32, None), (9, 5, [9, 9, 4, 2, 1]), (20, 17, None)])
+def test_persistent_lstm_forward_is_bit_identical_to_launch_per_step(env, ng, T, B, lens):
+    """ft_lstm_persist_fwd (one launch per sequence, W_hh fragments resident in registers, ng independent batch groups,
+    tag-checked granule hand-off) against ft_lstm_seq_fwd(FT_BF16): same rounding and accumulation order -> bit-identical
+    y / saved gates / saved cell on every valid (t, b), zeros on pad rows, status word clean."""
+    L, _ = env
+    H = 1024
+    if not L.lib().ft_lstm_persist_supported(B, H):
+        pytest.skip("needs a 256-CU device")
+    torch.manual_seed(T * 100 + B)
+    gx = torch.randn(T, B, 4 * H, device="cuda") * 0.5
+    w = torch.randn(4 * H, H, device="cuda") / H ** 0.5
+    if lens is None:
+        lens = [max(1, T - 2 * i) for i in range(B)]
+    lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    outs = []
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for persist in (False, True):
+        y = torch.full((T, B, H), 7.0, device="cuda")
+        gates = torch.zeros(T, B, 4 * H, device="cuda")
+        cell = torch.zeros(T, B, H, device="cuda")
+        if persist:
+            work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device="cuda", dtype=torch.uint8)
+            L.check(L.lib().ft_lstm_persist_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens_t), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(work),
+                                                L.ptr(status), T, B, H, ng, L.stream()), "ft_lstm_persist_fwd")
+        else:
+            work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device="cuda", dtype=torch.uint8)
+            L.check(L.lib().ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens_t), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(work),
+                                            T, B, H, 0, 1, L.stream()), "ft_lstm_seq_fwd")
+        torch.cuda.synchronize()
+        outs.append((y, gates, cell))
+    assert int(status.item()) == 0
+    act = torch.arange(T, device="cuda")[:, None] < lens_t[None, :]
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1][act], outs[1][1][act]) and torch.equal(outs[0][2][act], outs[1][2][act])
+    assert float(outs[1][0][~act].abs().max() if (~act).any() else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("ng", [1, 8, 4])
+@pytest.mark.parametrize("T,B,lens", [(37, 32, None), (9, 5, [9, 9, 4, 2, 1]), (20, 17, None)])
+def test_persistent_lstm_backward_is_bit_identical_to_launch_per_step(env, ng, T, B, lens):
+    """ft_lstm_persist_bwd against ft_lstm_seq_bwd(FT_BF16) on the saved tensors of a real forward: same fragment rounding,
+    same 16-partial accumulation order, same pinned cell arithmetic -> bit-identical dgx, zeros on pad rows."""
+    L, _ = env
+    H = 1024
+    if not L.lib().ft_lstm_persist_supported(B, H):
+        pytest.skip("needs a 256-CU device")
+    torch.manual_seed(T * 100 + B + 1)
+    gx = torch.randn(T, B, 4 * H, device="cuda") * 0.5
+    w = torch.randn(4 * H, H, device="cuda") / H ** 0.5
+    dy = torch.randn(T, B, H, device="cuda") * 0.1
+    if lens is None:
+        lens = [max(1, T - 2 * i) for i in range(B)]
+    lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    y = torch.empty(T, B, H, device="cuda")
+    gates = torch.zeros(T, B, 4 * H, device="cuda")
+    cell = torch.zeros(T, B, H, device="cuda")
+    work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device="cuda", dtype=torch.uint8)
+    L.check(L.lib().ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens_t), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(work),
+                                    T, B, H, 0, 1, L.stream()), "ft_lstm_seq_fwd")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    d0 = torch.full((T, B, 4 * H), 7.0, device="cuda")
+    d1 = torch.full((T, B, 4 * H), 7.0, device="cuda")
+    L.check(L.lib().ft_lstm_seq_bwd(L.ptr(dy), H, L.ptr(w), L.ptr(lens_t), L.ptr(gates), L.ptr(cell), L.ptr(d0), L.ptr(work),
+                                    T, B, H, 0, 1, L.stream()), "ft_lstm_seq_bwd")
+    wp = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device="cuda", dtype=torch.uint8)
+    L.check(L.lib().ft_lstm_persist_bwd(L.ptr(dy), H, L.ptr(w), L.ptr(lens_t), L.ptr(gates), L.ptr(cell), L.ptr(d1), L.ptr(wp),
+                                        L.ptr(status), T, B, H, ng, L.stream()), "ft_lstm_persist_bwd")
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    assert torch.equal(d0, d1)
+    act = torch.arange(T, device="cuda")[:, None] < lens_t[None, :]
+    assert float(d1[~act].abs().max() if (~act).any() else 0.0) == 0.0
