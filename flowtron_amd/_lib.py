@@ -70,6 +70,7 @@ SIGNATURES = {
     "ft_lstm_persist_supported": ([_i, _i], _i),
     "ft_lstm_persist_workspace_bytes": ([_i, _i], _sz),
     "ft_lstm_persist_fwd": ([_p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "ft_lstm_persist_debug_prof": ([_p], _i),
     "ft_lstm_persist_bwd": ([_p, _l, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_lstm2_supported": ([_i, _i], _i),
     "ft_lstm2_workspace_bytes": ([_i, _i], _sz),

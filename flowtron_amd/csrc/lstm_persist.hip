@@ -40,6 +40,8 @@
 namespace {
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) void gl_void;
+typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr int PH = 1024;                 // hidden size this kernel is built for
@@ -55,41 +57,91 @@ struct PersistP {
     unsigned* census;                    // LOCAL: [8] per-XCD arrival counters (zeroed by the host before the launch)
     int T, B;
     long timeout_ticks;                  // wall_clock64 ticks (100 MHz)
+    long* prof;                          // debug: per-step phase stamps of one workgroup (ft_lstm_persist_debug_prof), or null
 };
 
-// granule index of (b, k) inside one group's buffer: [c = k>>5][kg = (k>>3)&3][b][pair = (k&7)>>1]
-template <int RPGP>
-__device__ __forceinline__ int gran_index(int b, int k) {
-    return ((((k >> 5) * 4 + ((k >> 3) & 3)) * RPGP + b) << 2) + ((k & 7) >> 1);
+// a 128-bit value with unspecified contents at no cost (registers of lanes that a masked load leaves untouched)
+__device__ __forceinline__ u32x4 undef128() {
+    u32x4 v;
+    asm volatile("" : "=v"(v));
+    return v;
 }
 
-template <int NG, bool LOCAL>
+// Granule layout of one group's state vector (K = 32 NCW k-values x RPGP rows; NCW = k-chunks per wave).  A consumer wave w
+// owns the chunks c = w + 4 ci; ONE 16-byte-per-lane load fetches CPL = 16 / RPGP of its chunks at once -- lane (kg, li) gets
+// chunk ci = lg CPL + li / RPGP, row li % RPGP, k-group kg -- so every lane of every load carries real granules (a load per
+// chunk would leave the lanes of the padding rows, 3/4 of the wave at RPGP = 4, fetching duplicates).  MFMA wants chunk j's rows
+// in lanes li < RPGP of each 16-lane row: a DPP row shift by j RPGP lanes puts them there (the other lanes are padding rows
+// whose products nobody reads).  Buffer: [w][lg][half][64 lanes][2 granules]; half = which 4 of the lane's 8 k-values.
+template <int RPGP, int NCW>
+__device__ __forceinline__ int gran_index(int b, int k) {
+    constexpr int CPL = 16 / RPGP, NLG = NCW / CPL;
+    const int c = k >> 5, w = c & 3, ci = c >> 2, kg = (k >> 3) & 3, e = k & 7;
+    const int lg = ci / CPL, j = ci % CPL, lane = kg * 16 + j * RPGP + b;
+    return ((((w * NLG + lg) * 2 + (e >> 2)) * 64 + lane) << 1) + ((e >> 1) & 1);
+}
+
+// One LDS-DMA dword per lane (global_load_lds_dword: LDS address = M0 base + 4 lane, no VGPR staging) as inline asm: hipcc
+// put an s_waitcnt vmcnt(0) in front of every builtin DMA of a burst (64 serial HBM round trips); an asm statement is not
+// counted, so the caller waits once, `s_waitcnt vmcnt(0)`, after the last one.  M0 is saved and restored in the statement
+// (cdna_hip_programming.md 5.7).  lds_addr must be wave-uniform.
+__device__ __forceinline__ void dma_dword(const float* src, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_addr) : "memory");
+}
+
+// lane l <- lane l + n of the same 16-lane row (DPP row_shl:n), n = 0 .. 15
+template <int N>
+__device__ __forceinline__ unsigned row_shl(unsigned v) {
+    if constexpr (N == 0) return v;
+    else return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xf, 0xf, true);
+}
+
+constexpr int SB = 32;                   // steps per HBM burst (LDS staging of the rows the recurrence reads from HBM)
+
+// XCD census (LOCAL transport): group = this workgroup's XCC id, slot = arrival order inside that XCD
+template <int CPG>
+__device__ __forceinline__ bool join_group_local(unsigned* census, int* status, int tid, int& grp, int& q) {
+    __shared__ int slot[2];
+    if (tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+        slot[0] = (int)(xcc & 7u);
+        slot[1] = (int)__hip_atomic_fetch_add(census + (xcc & 7u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    grp = __builtin_amdgcn_readfirstlane(slot[0]);
+    q = __builtin_amdgcn_readfirstlane(slot[1]);
+    if (q >= CPG) {                                              // more than CPG workgroups on one XCD: not the machine this is for
+        if (tid == 0) atomicExch(status, 2);
+        return false;
+    }
+    return true;
+}
+
+template <int NG, bool LOCAL, int LAUX>
 __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
     static_assert(!LOCAL || NG == 8, "the L2-local transport needs group == XCD");
     constexpr int CPG = NCU / NG;                  // CUs (workgroups) per group
     constexpr int UPC = PH / CPG;                  // hidden units per CU: 32, 16, 8
     constexpr int TPC = UPC / 4;                   // gate-row tiles per CU (= NG)
     constexpr int RPGP = 32 / NG;                  // batch rows per group (padded): 4, 8, 16
+    constexpr int NE = RPGP * UPC;                 // (row, unit) elements per CU = 128 epilogue threads
+    constexpr int CPL = 16 / RPGP, NLG = 8 / CPL;  // chunks per load, load groups per wave (x 2 halves)
     constexpr int GRAN_PER_GROUP = NCHUNK * 4 * RPGP * 4;
-    __shared__ float red[2][4][TPC][RPGP][17];
+    static_assert(NE == 128, "one epilogue element per thread of waves 0-1");
+    // LDS: 4-wave reduce (double buffered) | SB steps of gx rows [s][gate][e] | 2 steps of outputs [parity][y,i,f,g,o,c][e]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float (*red)[4][TPC][RPGP][17] = reinterpret_cast<float (*)[4][TPC][RPGP][17]>(smem);
+    float* gxs = smem + 2 * 4 * TPC * RPGP * 17;
+    float* outs = gxs + SB * 4 * NE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
     int grp, q;
     if constexpr (LOCAL) {
-        __shared__ int slot[2];
-        if (tid == 0) {
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-            slot[0] = (int)(xcc & 7u);
-            slot[1] = (int)__hip_atomic_fetch_add(p.census + (xcc & 7u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        grp = __builtin_amdgcn_readfirstlane(slot[0]); q = __builtin_amdgcn_readfirstlane(slot[1]);
-        if (q >= CPG) {                                          // more than 32 workgroups on one XCD: not the machine this is for
-            if (tid == 0) atomicExch(p.status, 2);
-            return;
-        }
+        if (!join_group_local<CPG>(p.census, p.status, tid, grp, q)) return;
     } else {
         grp = blockIdx.x % NG; q = blockIdx.x / NG;              // speed only: consecutive block ids land on different XCDs
     }
@@ -107,12 +159,11 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
     }
 
     // ---- epilogue role: thread e < 128 owns (batch row eb, unit eu) of this CU for the whole sequence
-    const bool erole = tid < RPGP * UPC;           // == 128
+    const bool erole = tid < NE;
     const int el = tid % UPC, ebl = tid / UPC;     // unit within CU, row within group
     const int eb = b0 + ebl, eu = q * UPC + el;
     const bool ev = erole && eb < B;
-    const int ebc = eb < B ? eb : B - 1;
-    const int len = erole ? p.lens[ebc] : 0;
+    const int len = ev ? p.lens[eb] : 0;
     // steps this group runs: the longest sequence among its rows (uniform per workgroup)
     int tg = 0;
 #pragma unroll
@@ -122,64 +173,94 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
     }
     tg = tg < T ? tg : T;
 
-    float c_state = 0.f, h_state = 0.f;
-    float gxv[4] = {0.f, 0.f, 0.f, 0.f};
-    auto load_gx = [&](int t) {
-        if (erole && t < T) {
-            const float* gp = p.gx + ((size_t)t * B + ebc) * 4 * PH + eu;
+    // ---- HBM traffic is kept out of the sweeping waves' way.  hipcc waits vmcnt(0) at the block joins of the poll loop, and
+    // vmcnt retires in order and counts stores, so anything in flight when a sweep starts sits in front of its first wait:
+    //   * gx rows come in bursts of SB steps by LDS-DMA (global_load_lds: no VGPR staging), one HBM round trip per SB steps;
+    //   * the saved tensors of step t-1 are stored by waves 2-3 right after the reduce barrier of step t, while waves 0-1 run
+    //     the cell update: waves 2-3 start polling before the group has published, so their first (failing) pass hides the
+    //     store acknowledgements.
+    const int wu = __builtin_amdgcn_readfirstlane(wave);         // wave id as a scalar
+    const int eh = (wave & 1) * 64 + lane;                       // burst: wave w serves elements 64 (w & 1) + lane
+    const int hb = b0 + eh / UPC, hu = q * UPC + eh % UPC;
+    const bool hvalid = hb < B;
+    auto burst = [&](int t) {                                    // t % SB == 0: gx rows of steps [t, t + SB)
+        __syncthreads();
+        const int nst = (tg - t) < SB ? (tg - t) : SB;
+        if (hvalid) {
+            const float* src0 = p.gx + ((size_t)t * B + hb) * 4 * PH + hu;
+            const unsigned dst0 = (unsigned)(size_t)(lds_void*)gxs + (unsigned)(wu & 1) * 256u;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) gxv[g] = gp[(size_t)g * PH];
+            for (int kk = 0; kk < SB * 2; ++kk) {                // pair k = (step, gate), LDS slot [k][e]; all DMAs in flight
+                const int k = 2 * kk + (wu >> 1);
+                if (k < nst * 4) dma_dword(src0 + (size_t)(k >> 2) * B * 4 * PH + (size_t)(k & 3) * PH, dst0 + (unsigned)k * NE * 4u);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the DMA writes are this wave's own VM operations
+        __syncthreads();
+    };
+    // output role of waves 2-3: thread tid >= 128 stores element e = tid - 128 of the previous step
+    const int oe = tid - NE;
+    const int ob = b0 + oe / UPC, ou = q * UPC + oe % UPC;
+    const bool ovalid = tid >= NE && ob < B;
+    const int olen = ovalid ? p.lens[ob] : 0;
+    auto store_outputs = [&](int t) {                            // saved tensors of step t from outs[t & 1]
+        if (!ovalid) return;
+        const float* o = outs + (t & 1) * 6 * NE + oe;
+        const size_t row = (size_t)t * B + ob;
+        p.y[row * p.ldy + ou] = o[0];
+        if (p.gates && t < olen) {
+            float* gp = p.gates + row * 4 * PH + ou;
+            gp[0] = o[NE]; gp[(size_t)PH] = o[2 * NE]; gp[(size_t)2 * PH] = o[3 * NE]; gp[(size_t)3 * PH] = o[4 * NE];
+            p.cell[row * PH + ou] = o[5 * NE];
         }
     };
-    load_gx(0);
 
+    float c_state = 0.f, h_state = 0.f;
     __amdgpu_buffer_rsrc_t rs[2];
 #pragma unroll
     for (int par = 0; par < 2; ++par)
         rs[par] = __builtin_amdgcn_make_buffer_rsrc(p.hgran + ((size_t)par * NG + grp) * GRAN_PER_GROUP, 0,
                                                     GRAN_PER_GROUP * 8, 0x00020000);
-    // per-lane byte offset of chunk 0 (chunk c adds c * 4 * RPGP * 32 bytes): [kg][b = li % RPGP][4 granules]
-    const int voff0 = ((kg * RPGP + (li % RPGP)) * 4) * 8, voff1 = voff0 + 16;
-    // chunk offsets ride in the scalar offset operand (wave-uniform), so the 16 loads share two address VGPRs
-    const int soff_w = __builtin_amdgcn_readfirstlane(wave) * (4 * RPGP * 32);
+    // load (lg, half) of this wave = 1 KiB at ((wave NLG + lg) 2 + half) KiB: lane offset in the VGPR, the rest scalar
+    const int voff = lane * 16;
+    const int soff_w = __builtin_amdgcn_readfirstlane(wave) * (NLG * 2048);
     const long t_start = wall_clock64();
     bool dead = false;
+    // debug stamps (100 MHz wall clock): [step][wave][0..4] = loop top, sweep+MFMA done, reduce barrier passed, published,
+    // passes of the poll loop
+    const bool prof = p.prof != nullptr && grp == 0 && q == 0 && lane == 0;
 
     for (int t = 0; t < tg; ++t) {
+        if ((t % SB) == 0) burst(t);
+        long st0 = 0, st1 = 0, st2 = 0, st3 = 0, npass = 0;
+        if (prof) st0 = wall_clock64();
         f32x4 acc[TPC];
 #pragma unroll
         for (int j = 0; j < TPC; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (t > 0) {
             // ---- sweep: this wave's 8 chunks of h_{t-1} (epoch t) straight into A fragments.  Every pass re-reads ALL chunks
-            // that have not shown the epoch yet (one round trip for the lot), and the MFMAs run in chunk ORDER (deterministic
-            // accumulation) over the ready prefix, so early chunks are multiplied while later producers still publish.
+            // that have not shown the epoch yet (one L2 round trip for the lot).  The poll loop holds loads and tag compares
+            // only; the 8 x TPC MFMAs follow as ONE straight-line block (MFMAs inside the data-dependent control flow made
+            // hipcc shuffle accumulators and weight fragments through v_accvgpr_mov on every chunk).
             const unsigned epoch = (unsigned)t;
             const int par = (t - 1) & 1;
-            u32x4 lo[8], hi[8];
+            u32x4 lo[NLG], hi[NLG];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int so = soff_w + 4 * i * (4 * RPGP * 32);
-                lo[i] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff0, so, 16);       // aux 16 = sc1: bypass L1
-                hi[i] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff1, so, 16);
+            for (int g = 0; g < NLG; ++g) {
+                lo[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, soff_w + g * 2048, LAUX);   // LAUX: 16 = sc1, 2 = nt
+                hi[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, soff_w + g * 2048 + 1024, LAUX);
             }
-            unsigned ready = 0;                    // wave-uniform bit per chunk: tags matched
-            int next = 0;                          // chunks [0, next) are already multiplied
+            unsigned ready = 0;                    // wave-uniform bit per load group: tags matched
             for (unsigned spins = 0;; ++spins) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (!((ready >> i) & 1u)) {
-                        const bool ok = (lo[i][1] == epoch) & (lo[i][3] == epoch) & (hi[i][1] == epoch) & (hi[i][3] == epoch);
-                        if (__all(ok)) ready |= 1u << i;
-                    }
-                    if (next == i && ((ready >> i) & 1u)) {
-                        const u32x4 v = {lo[i][0], lo[i][2], hi[i][0], hi[i][2]};
-                        const bf16x8 a = __builtin_bit_cast(bf16x8, v);
-#pragma unroll
-                        for (int j = 0; j < TPC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w[j][i], acc[j], 0, 0, 0);
-                        next = i + 1;
+                for (int g = 0; g < NLG; ++g) {
+                    if (!((ready >> g) & 1u)) {
+                        const bool ok = (lo[g][1] == epoch) & (lo[g][3] == epoch) & (hi[g][1] == epoch) & (hi[g][3] == epoch);
+                        if (__all(ok)) ready |= 1u << g;
                     }
                 }
-                if (next == 8) break;
+                npass = spins + 1;
+                if (ready == (1u << NLG) - 1u) break;
                 if ((spins & 15) == 15) {
                     if (wall_clock64() - t_start > p.timeout_ticks ||
                         __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
@@ -187,19 +268,37 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
                         break;
                     }
                 }
+                asm volatile("" ::: "memory");     // the builtin loads are not atomics: keep the re-reads inside the loop
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (!((ready >> i) & 1u)) {
-                        const int so = soff_w + 4 * i * (4 * RPGP * 32);
-                        lo[i] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff0, so, 16);
-                        hi[i] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff1, so, 16);
+                for (int g = 0; g < NLG; ++g) {
+                    if (!((ready >> g) & 1u)) {
+                        lo[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, soff_w + g * 2048, LAUX);
+                        hi[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, soff_w + g * 2048 + 1024, LAUX);
                     }
                 }
             }
             if (dead) break;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {          // chunk i of this wave = load group i / CPL, member i % CPL
+                constexpr int SH = RPGP;           // (shift below is (i % CPL) * RPGP lanes)
+                const int g = i / CPL;
+                u32x4 v;
+                switch (i % CPL) {
+                    case 0: v = (u32x4){lo[g][0], lo[g][2], hi[g][0], hi[g][2]}; break;
+                    case 1: v = (u32x4){row_shl<SH>(lo[g][0]), row_shl<SH>(lo[g][2]), row_shl<SH>(hi[g][0]), row_shl<SH>(hi[g][2])}; break;
+                    case 2: v = (u32x4){row_shl<(2 * SH) & 15>(lo[g][0]), row_shl<(2 * SH) & 15>(lo[g][2]), row_shl<(2 * SH) & 15>(hi[g][0]),
+                                        row_shl<(2 * SH) & 15>(hi[g][2])}; break;
+                    default: v = (u32x4){row_shl<(3 * SH) & 15>(lo[g][0]), row_shl<(3 * SH) & 15>(lo[g][2]), row_shl<(3 * SH) & 15>(hi[g][0]),
+                                         row_shl<(3 * SH) & 15>(hi[g][2])}; break;
+                }
+                const bf16x8 a = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                for (int j = 0; j < TPC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w[j][i], acc[j], 0, 0, 0);
+            }
         }
         // D[m = batch row (lane>>4)*4 + r][n = li]: rows >= RPGP are padding
         const int rb = t & 1;
+        if (prof) st1 = wall_clock64();
         if (kg * 4 < RPGP) {
 #pragma unroll
             for (int j = 0; j < TPC; ++j)
@@ -207,14 +306,17 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
                 for (int r = 0; r < 4; ++r) red[rb][wave][j][kg * 4 + r][li] = acc[j][r];
         }
         __syncthreads();
+        if (prof) st2 = wall_clock64();
+        if (t > 0) store_outputs(t - 1);
         if (erole) {
             const bool active = t < len;
             const int j = el >> 2, ul = el & 3;
+            const float* gxr = gxs + (t % SB) * 4 * NE + tid;
             float pre[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = g * 4 + ul;
-                pre[g] = red[rb][0][j][ebl][n] + red[rb][1][j][ebl][n] + red[rb][2][j][ebl][n] + red[rb][3][j][ebl][n] + gxv[g];
+                pre[g] = red[rb][0][j][ebl][n] + red[rb][1][j][ebl][n] + red[rb][2][j][ebl][n] + red[rb][3][j][ebl][n] + gxr[g * NE];
             }
             float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f;
             if (active) {
@@ -226,28 +328,28 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
             const float h_nb = __shfl_down(h_state, 1, 64);
             if ((el & 1) == 0) {
                 const unsigned long long gran = ((unsigned long long)(unsigned)(t + 1) << 32) | pack_bf16x2(h_state, h_nb);
-                unsigned long long* dst = p.hgran + ((size_t)(t & 1) * NG + grp) * GRAN_PER_GROUP + gran_index<RPGP>(ebl, eu);
+                unsigned long long* dst = p.hgran + ((size_t)(t & 1) * NG + grp) * GRAN_PER_GROUP + gran_index<RPGP, 8>(ebl, eu);
                 // LOCAL: workgroup-scope relaxed store = ONE aligned 8-byte global_store (sc0) whose line stays in this XCD's L2;
                 // otherwise agent scope = sc1, write-through to the memory side
                 if constexpr (LOCAL) __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (ev) {
-                const size_t row = (size_t)t * B + eb;
-                p.y[row * p.ldy + eu] = active ? h_state : 0.f;
-                if (active && p.gates) {
-                    float* gp = p.gates + row * 4 * PH + eu;
-                    gp[0] = ig; gp[(size_t)PH] = fg; gp[(size_t)2 * PH] = gg; gp[(size_t)3 * PH] = og;
-                    p.cell[row * PH + eu] = c_state;
-                }
-            }
-            load_gx(t + 1);
+            if (prof) st3 = wall_clock64();
+            float* o = outs + (t & 1) * 6 * NE + tid;            // waves 2-3 store it during the next step
+            o[0] = active ? h_state : 0.f;
+            o[NE] = ig; o[2 * NE] = fg; o[3 * NE] = gg; o[4 * NE] = og; o[5 * NE] = c_state;
+        }
+        if (prof && t < 1024) {
+            long* o = p.prof + ((size_t)t * 4 + wave) * 5;
+            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = npass;
         }
     }
     if (dead) {
         if (lane == 0) atomicExch(p.status, 1);
         return;
     }
+    __syncthreads();
+    if (tg > 0) store_outputs(tg - 1);
     // pad rows beyond the group's longest sequence: y = 0 (pad_packed_sequence semantics)
     if (ev)
         for (int t = tg; t < T; ++t) p.y[((size_t)t * B + eb) * p.ldy + eu] = 0.f;
@@ -260,7 +362,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
 // dgates_s (4 gates x UPC units x RPGP rows) as granules over k = gate*H + j.  The group's dgates vector is 4x the forward
 // state (RPGP x 4H bf16), so a wave sweeps its 32 chunks in 4 batches of 8 with the next batch's loads in flight.
 // Accumulation mimics lstm_bwd_step_bf16's 16-wave split (partial a of wave w = chunks w+4a, w+4a+16, ..; the 16 partials
-// are summed in wave order), so the result is bit-identical to the launch-per-step kernel.
+// are summed in wave order), so the result is bit-identical to the launch-per-step kernel.  Saved gates / cell / dy come
+// in, and dgx goes out, through the same SB-step LDS bursts as the forward kernel.
 struct PersistBwdP {
     const float* dy; long ldy; const int* lens;
     const float* gates; const float* cell; float* dgx;
@@ -269,38 +372,36 @@ struct PersistBwdP {
     int* status; unsigned* census;
     int T, B;
     long timeout_ticks;
+    long* prof;
 };
 
-template <int NG, bool LOCAL>
+template <int NG, bool LOCAL, int LAUX>
 __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     static_assert(!LOCAL || NG == 8, "the L2-local transport needs group == XCD");
     constexpr int CPG = NCU / NG;                  // workgroups per group
     constexpr int UPC = PH / CPG;                  // hidden units per CU: 32 (NG 8), 16 (NG 4)
     constexpr int TL = UPC / 16;                   // column tiles per CU
     constexpr int RPGP = 32 / NG;
+    constexpr int NE = RPGP * UPC;
     constexpr int KCH = 4 * PH / 32;               // 128 k-chunks
     constexpr int CPW = KCH / 4;                   // chunks per wave: 32
     constexpr int GRAN_PER_GROUP = KCH * 4 * RPGP * 4;
+    constexpr int CPL = 16 / RPGP, NLG = CPW / CPL; // chunks per load, load groups per wave (x 2 halves): 8 (NG 8), 16 (NG 4)
+    constexpr int NBT = NLG > 8 ? 2 : 1, LPB = NLG / NBT;   // sweep batches per step (<= 16 loads in flight each), load groups per batch
     static_assert(TL >= 1, "NG = 2 would leave half a column tile per CU");
-    __shared__ float red[2][16][TL][RPGP][17];
+    static_assert(NE == 128, "one epilogue element per thread of waves 0-1");
+    // LDS: 16-partial reduce (double buffered) | SB steps in [i][gates x4, dy][e] | SB+1 cells [i][e] | 2 steps out [parity][4][e]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float (*red)[16][TL][RPGP][17] = reinterpret_cast<float (*)[16][TL][RPGP][17]>(smem);
+    float* ins = smem + 2 * 16 * TL * RPGP * 17;
+    float* cells = ins + SB * 5 * NE;
+    float* outs = cells + (SB + 1) * NE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
     int grp, q;
     if constexpr (LOCAL) {
-        __shared__ int slot[2];
-        if (tid == 0) {
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-            slot[0] = (int)(xcc & 7u);
-            slot[1] = (int)__hip_atomic_fetch_add(p.census + (xcc & 7u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        grp = __builtin_amdgcn_readfirstlane(slot[0]); q = __builtin_amdgcn_readfirstlane(slot[1]);
-        if (q >= CPG) {
-            if (tid == 0) atomicExch(p.status, 2);
-            return;
-        }
+        if (!join_group_local<CPG>(p.census, p.status, tid, grp, q)) return;
     } else {
         grp = blockIdx.x % NG; q = blockIdx.x / NG;
     }
@@ -316,12 +417,11 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
             for (int i = 0; i < CPW; ++i) w[j][i] = wf[((size_t)(q * TL + j) * KCH + (wave + 4 * i)) * 64 + lane];
     }
 
-    const bool erole = tid < RPGP * UPC;           // == 128
+    const bool erole = tid < NE;
     const int el = tid % UPC, ebl = tid / UPC;
     const int eb = b0 + ebl, eu = q * UPC + el;
     const bool ev = erole && eb < B;
-    const int ebc = eb < B ? eb : B - 1;
-    const int len = erole ? p.lens[ebc] : 0;
+    const int len = ev ? p.lens[eb] : 0;
     int tg = 0;
 #pragma unroll
     for (int r = 0; r < RPGP; ++r) {
@@ -330,36 +430,61 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     }
     tg = tg < T ? tg : T;
 
-    // saved activations of the step being processed, and of the next one (one step of prefetch from HBM)
-    float g4[4] = {0.f, 0.f, 0.f, 0.f}, c_t = 0.f, c_prev = 0.f, dyv = 0.f;
-    float ng4[4] = {0.f, 0.f, 0.f, 0.f}, ncp = 0.f, ndy = 0.f;
-    auto load_step = [&](int s, float (&gg_)[4], float& cprev_, float& dy_) {     // gates[s], cell[s-1], dy[s]
-        if (erole && s >= 0) {
-            const size_t row = (size_t)s * B + ebc;
-            const float* gp = p.gates + row * 4 * PH + eu;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) gg_[g] = gp[(size_t)g * PH];
-            cprev_ = s > 0 ? p.cell[((size_t)(s - 1) * B + ebc) * PH + eu] : 0.f;
-            dy_ = p.dy[row * p.ldy + eu];
-        }
+    // step counter n = 0 .. tg-1 walks time s = tg-1-n downwards; burst k stages steps n in [k SB, (k+1) SB)
+    // output role of waves 2-3 (see the forward kernel): thread tid >= 128 stores the dgx row of the previous step
+    const int oe = tid - NE;
+    const int ob = b0 + oe / UPC, ou = q * UPC + oe % UPC;
+    const bool ovalid = tid >= NE && ob < B;
+    auto store_outputs = [&](int n) {                            // dgx row of step counter n from outs[n & 1]
+        if (!ovalid) return;
+        const float* o = outs + (n & 1) * 4 * NE + oe;
+        float* dg = p.dgx + ((size_t)(tg - 1 - n) * B + ob) * 4 * PH + ou;
+        dg[0] = o[0]; dg[(size_t)PH] = o[NE]; dg[(size_t)2 * PH] = o[2 * NE]; dg[(size_t)3 * PH] = o[3 * NE];
     };
-    if (erole && tg > 0) c_t = p.cell[((size_t)(tg - 1) * B + ebc) * PH + eu];
-    load_step(tg - 1, g4, c_prev, dyv);
-    load_step(tg - 2, ng4, ncp, ndy);
-    float dc_carry = 0.f;
+    auto burst = [&](int n) {                                    // n % SB == 0
+        __syncthreads();
+        const int nst = (tg - n) < SB ? (tg - n) : SB;
+        // LDS-DMA (global_load_lds_dword: no VGPR staging -- the register file belongs to the W_hh^T fragments): wave w
+        // serves elements e = 64 (w & 1) + lane of the pairs k = (w >> 1), (w >> 1) + 2, ..; LDS destination = wave-uniform
+        // base + 4 lane, i.e. exactly the [pair][e] staging layout
+        const int wu = __builtin_amdgcn_readfirstlane(wave);
+        const int eh = (wave & 1) * 64 + lane;
+        const int hb = b0 + eh / UPC, hu = q * UPC + eh % UPC;
+        const bool hvalid = hb < B;
+        if (hvalid) {                                            // straight-line asm DMAs (see the forward kernel)
+            const unsigned half_off = (unsigned)(wu & 1) * 256u;
+            const unsigned ins0 = (unsigned)(size_t)(lds_void*)ins + half_off, cells0 = (unsigned)(size_t)(lds_void*)cells + half_off;
+#pragma unroll
+            for (int kk = 0; kk < (SB * 5 + 1) / 2; ++kk) {      // gates x4, dy
+                const int k = 2 * kk + (wu >> 1), i = k / 5, f = k - i * 5, s = tg - 1 - (n + i);
+                if (k < nst * 5) {
+                    const size_t row = (size_t)s * B + hb;
+                    dma_dword(f < 4 ? p.gates + row * 4 * PH + (size_t)f * PH + hu : p.dy + row * p.ldy + hu, ins0 + (unsigned)k * NE * 4u);
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < (SB + 2) / 2; ++kk) {          // cell[s] of the staged steps and the one below (c_prev)
+                const int i = 2 * kk + (wu >> 1), s = tg - 1 - (n + i);
+                if (i <= nst && i <= SB && s >= 0) dma_dword(p.cell + ((size_t)s * B + hb) * PH + hu, cells0 + (unsigned)i * NE * 4u);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the DMA writes are this wave's own VM operations
+        __syncthreads();
+    };
 
+    float dc_carry = 0.f;
     __amdgpu_buffer_rsrc_t rs[2];
 #pragma unroll
     for (int par = 0; par < 2; ++par)
         rs[par] = __builtin_amdgcn_make_buffer_rsrc(p.dgran + ((size_t)par * NG + grp) * GRAN_PER_GROUP, 0,
                                                     GRAN_PER_GROUP * 8, 0x00020000);
-    const int voff0 = ((kg * RPGP + (li % RPGP)) * 4) * 8, voff1 = voff0 + 16;
-    constexpr int CHUNK_BYTES = 4 * RPGP * 32;
-    const int soff_w = __builtin_amdgcn_readfirstlane(wave) * CHUNK_BYTES;
+    const int voff = lane * 16;
+    const int soff_w = __builtin_amdgcn_readfirstlane(wave) * (NLG * 2048);
     const long t_start = wall_clock64();
     bool dead = false;
 
     for (int n = 0; n < tg; ++n) {                 // n-th step of the sweep: time index s = tg-1-n
+        if ((n % SB) == 0) burst(n);
         const int s = tg - 1 - n;
         f32x4 acc[TL][4];
 #pragma unroll
@@ -369,41 +494,31 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
         if (n > 0) {
             const unsigned epoch = (unsigned)n;
             const int par = (n - 1) & 1;
-            u32x4 lo[2][8], hi[2][8];
-            auto issue = [&](int bt, u32x4 (&l_)[8], u32x4 (&h_)[8]) {
+            u32x4 lo[2][LPB], hi[2][LPB];
+            auto issue = [&](int bt, u32x4 (&l_)[LPB], u32x4 (&h_)[LPB]) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int so = soff_w + 4 * (bt * 8 + i) * CHUNK_BYTES;
-                    l_[i] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff0, so, 16);
-                    h_[i] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff1, so, 16);
+                for (int g = 0; g < LPB; ++g) {
+                    const int so = soff_w + (bt * LPB + g) * 2048;
+                    l_[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, so, LAUX);
+                    h_[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, so + 1024, LAUX);
                 }
             };
             issue(0, lo[0], hi[0]);
 #pragma unroll
-            for (int bt = 0; bt < 4; ++bt) {
-                if (bt < 3) issue(bt + 1, lo[(bt + 1) & 1], hi[(bt + 1) & 1]);
-                u32x4 (&L_)[8] = lo[bt & 1];
-                u32x4 (&H_)[8] = hi[bt & 1];
+            for (int bt = 0; bt < NBT; ++bt) {
+                if (bt < NBT - 1) issue(bt + 1, lo[(bt + 1) & 1], hi[(bt + 1) & 1]);
+                u32x4 (&L_)[LPB] = lo[bt & 1];
+                u32x4 (&H_)[LPB] = hi[bt & 1];
                 unsigned ready = 0;
-                int next = 0;
-                for (unsigned spins = 0;; ++spins) {
+                for (unsigned spins = 0;; ++spins) {             // loads and tag compares only (see the forward kernel)
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        if (!((ready >> i) & 1u)) {
-                            const bool ok = (L_[i][1] == epoch) & (L_[i][3] == epoch) & (H_[i][1] == epoch) & (H_[i][3] == epoch);
-                            if (__all(ok)) ready |= 1u << i;
-                        }
-                        if (next == i && ((ready >> i) & 1u)) {
-                            const int ci = bt * 8 + i;               // this wave's ci-th chunk = global chunk wave + 4 ci
-                            const u32x4 v = {L_[i][0], L_[i][2], H_[i][0], H_[i][2]};
-                            const bf16x8 a = __builtin_bit_cast(bf16x8, v);
-#pragma unroll
-                            for (int j = 0; j < TL; ++j)
-                                acc[j][ci & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w[j][ci], acc[j][ci & 3], 0, 0, 0);
-                            next = i + 1;
+                    for (int g = 0; g < LPB; ++g) {
+                        if (!((ready >> g) & 1u)) {
+                            const bool ok = (L_[g][1] == epoch) & (L_[g][3] == epoch) & (H_[g][1] == epoch) & (H_[g][3] == epoch);
+                            if (__all(ok)) ready |= 1u << g;
                         }
                     }
-                    if (next == 8) break;
+                    if (ready == (1u << LPB) - 1u) break;
                     if ((spins & 15) == 15) {
                         if (wall_clock64() - t_start > p.timeout_ticks ||
                             __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
@@ -411,16 +526,35 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
                             break;
                         }
                     }
+                    asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        if (!((ready >> i) & 1u)) {
-                            const int so = soff_w + 4 * (bt * 8 + i) * CHUNK_BYTES;
-                            L_[i] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff0, so, 16);
-                            H_[i] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff1, so, 16);
+                    for (int g = 0; g < LPB; ++g) {
+                        if (!((ready >> g) & 1u)) {
+                            const int so = soff_w + (bt * LPB + g) * 2048;
+                            L_[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, so, LAUX);
+                            H_[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, so + 1024, LAUX);
                         }
                     }
                 }
                 if (dead) break;
+#pragma unroll
+                for (int i = 0; i < LPB * CPL; ++i) {                // chunk ci of this wave = load group ci / CPL, member ci % CPL
+                    constexpr int SH = RPGP;
+                    const int ci = bt * LPB * CPL + i, g = i / CPL;
+                    u32x4 v;
+                    switch (i % CPL) {
+                        case 0: v = (u32x4){L_[g][0], L_[g][2], H_[g][0], H_[g][2]}; break;
+                        case 1: v = (u32x4){row_shl<SH>(L_[g][0]), row_shl<SH>(L_[g][2]), row_shl<SH>(H_[g][0]), row_shl<SH>(H_[g][2])}; break;
+                        case 2: v = (u32x4){row_shl<(2 * SH) & 15>(L_[g][0]), row_shl<(2 * SH) & 15>(L_[g][2]), row_shl<(2 * SH) & 15>(H_[g][0]),
+                                            row_shl<(2 * SH) & 15>(H_[g][2])}; break;
+                        default: v = (u32x4){row_shl<(3 * SH) & 15>(L_[g][0]), row_shl<(3 * SH) & 15>(L_[g][2]), row_shl<(3 * SH) & 15>(H_[g][0]),
+                                             row_shl<(3 * SH) & 15>(H_[g][2])}; break;
+                    }
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                    for (int j = 0; j < TL; ++j)
+                        acc[j][ci & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w[j][ci], acc[j][ci & 3], 0, 0, 0);
+                }
             }
             if (dead) break;
         }
@@ -434,16 +568,20 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
                     for (int r = 0; r < 4; ++r) red[rb][wave + 4 * a][j][kg * 4 + r][li] = acc[j][a][r];
         }
         __syncthreads();
+        if (n > 0) store_outputs(n - 1);
         if (erole) {
+            const int i = n % SB;
             const bool active = s < len;
             float da[4] = {0.f, 0.f, 0.f, 0.f};
             if (active) {
                 const int j = el >> 4, nn = el & 15;
-                float dh = dyv;
+                const float* in = ins + i * 5 * NE + tid;
+                float dh = in[4 * NE];
 #pragma unroll
                 for (int w16 = 0; w16 < 16; ++w16) dh += red[rb][w16][j][ebl][nn];
+                const float c_t = cells[i * NE + tid], c_prev = s > 0 ? cells[(i + 1) * NE + tid] : 0.f;
                 float carry;
-                lstm_cell_bwd<true>(dh, dc_carry, g4[0], g4[1], g4[2], g4[3], c_t, c_prev, da, carry);
+                lstm_cell_bwd<true>(dh, dc_carry, in[0], in[NE], in[2 * NE], in[3 * NE], c_t, c_prev, da, carry);
                 dc_carry = carry;
             }
             // ---- publish dgates_s: one granule per gate per even unit (k = gate*H + unit)
@@ -452,27 +590,22 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
                 const float nb = __shfl_down(da[g], 1, 64);
                 if ((el & 1) == 0) {
                     const unsigned long long gran = ((unsigned long long)(unsigned)(n + 1) << 32) | pack_bf16x2(da[g], nb);
-                    unsigned long long* dst = p.dgran + ((size_t)(n & 1) * NG + grp) * GRAN_PER_GROUP + gran_index<RPGP>(ebl, g * PH + eu);
+                    unsigned long long* dst = p.dgran + ((size_t)(n & 1) * NG + grp) * GRAN_PER_GROUP + gran_index<RPGP, CPW>(ebl, g * PH + eu);
                     if constexpr (LOCAL) __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            if (ev) {
-                float* dg = p.dgx + ((size_t)s * B + eb) * 4 * PH + eu;
+            float* o = outs + (n & 1) * 4 * NE + tid;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) dg[(size_t)g * PH] = da[g];
-            }
-            // rotate the prefetched step in and fetch the one after
-#pragma unroll
-            for (int g = 0; g < 4; ++g) g4[g] = ng4[g];
-            c_t = c_prev; c_prev = ncp; dyv = ndy;      // cell[s-1] is c_prev of step s and c_t of step s-1
-            load_step(s - 2, ng4, ncp, ndy);
+            for (int g = 0; g < 4; ++g) o[g * NE] = da[g];
         }
     }
     if (dead) {
         if (lane == 0) atomicExch(p.status, 1);
         return;
     }
+    __syncthreads();
+    if (tg > 0) store_outputs(tg - 1);
     if (ev)                                                             // pad rows beyond the group's longest sequence
         for (int t = tg; t < T; ++t) {
             float* dg = p.dgx + ((size_t)t * B + eb) * 4 * PH + eu;
@@ -484,6 +617,10 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
 }  // namespace
 
 static inline size_t al256p(size_t v) { return (v + 255) & ~size_t(255); }
+static long* g_persist_prof = nullptr;
+// debug hook (scripts/exp/lstm_persist_bench.py): device buffer of 1024 x 4 x 5 int64 that the NEXT forward launches fill
+// with per-step phase stamps of workgroup (group 0, slot 0); nullptr switches it off
+extern "C" int ft_lstm_persist_debug_prof(void* dev_buf) { g_persist_prof = reinterpret_cast<long*>(dev_buf); return FT_OK; }
 
 extern "C" int ft_lstm_persist_supported(int B, int H) {
     if (H != PH || B < 1 || B > 32) return 0;
@@ -510,7 +647,7 @@ extern "C" int ft_lstm_persist_fwd(const float* gx, const float* w_hh, const int
     FT_CHECK_ARG(gx && w_hh && lens && y && work && status);
     FT_CHECK_ARG((gates == nullptr) == (cell == nullptr));
     FT_CHECK_ARG(T >= 0 && ldy >= H && reinterpret_cast<uintptr_t>(work) % 256 == 0);
-    FT_CHECK_ARG(ng == 1 || ng == 8 || ng == 4 || ng == 2);       // 1 = XCD-local transport (8 groups = 8 XCDs)
+    FT_CHECK_ARG(ng == 1 || ng == 9 || ng == 8 || ng == 4 || ng == 2);   // 1 / 9 = XCD-local transport (nt / sc1 loads)
     if (!ft_lstm_persist_supported(B, H))
         return ft_fail(FT_EUNSUPPORTED, "ft_lstm_persist_fwd: needs H == 1024, B <= 32 and a 256-CU device (H=%d B=%d)", H, B);
     if (T == 0) return FT_OK;
@@ -523,11 +660,21 @@ extern "C" int ft_lstm_persist_fwd(const float* gx, const float* w_hh, const int
     FT_CHECK_HIP(hipMemsetAsync(hgran, 0, gran_bytes, st));           // tags = 0: no epoch matches (epochs start at 1)
     FT_CHECK_HIP(hipMemsetAsync(census, 0, 256, st));
     hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H);
-    PersistP p{gx, lens, y, (long)ldy, gates, cell, wfrag, hgran, status, census, T, B, 100000000L / 2};   // 0.5 s
-    if (ng == 1) hipLaunchKernelGGL((lstm_persist_fwd_k<8, true>), dim3(NCU), dim3(256), 0, st, p);
-    else if (ng == 8) hipLaunchKernelGGL((lstm_persist_fwd_k<8, false>), dim3(NCU), dim3(256), 0, st, p);
-    else if (ng == 4) hipLaunchKernelGGL((lstm_persist_fwd_k<4, false>), dim3(NCU), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((lstm_persist_fwd_k<2, false>), dim3(NCU), dim3(256), 0, st, p);
+    PersistP p{gx, lens, y, (long)ldy, gates, cell, wfrag, hgran, status, census, T, B, 100000000L / 2, g_persist_prof};   // 0.5 s
+    // dynamic LDS: reduce buffers (2*4*TPC*RPGP*17 = 2*4*32*17 floats) + SB staged gx rows + 2 output rows
+    const size_t lds = sizeof(float) * ((size_t)2 * 4 * 32 * 17 + (size_t)SB * 4 * 128 + (size_t)2 * 6 * 128);
+    auto launch = [&](auto kern) -> int {
+        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(NCU), dim3(256), lds, st, p);
+        return FT_OK;
+    };
+    int rc;
+    if (ng == 1) rc = launch(lstm_persist_fwd_k<8, true, 2>);
+    else if (ng == 9) rc = launch(lstm_persist_fwd_k<8, true, 16>);
+    else if (ng == 8) rc = launch(lstm_persist_fwd_k<8, false, 16>);
+    else if (ng == 4) rc = launch(lstm_persist_fwd_k<4, false, 16>);
+    else rc = launch(lstm_persist_fwd_k<2, false, 16>);
+    if (rc != FT_OK) return rc;
     FT_CHECK_LAUNCH();
     return FT_OK;
 }
@@ -537,7 +684,7 @@ extern "C" int ft_lstm_persist_bwd(const float* dy, int64_t ldy, const float* w_
                                    void* stream) {
     FT_CHECK_ARG(dy && w_hh && lens && gates && cell && dgx && work && status);
     FT_CHECK_ARG(T >= 0 && ldy >= H && reinterpret_cast<uintptr_t>(work) % 256 == 0);
-    FT_CHECK_ARG(ng == 1 || ng == 8 || ng == 4);
+    FT_CHECK_ARG(ng == 1 || ng == 9 || ng == 8 || ng == 4);
     if (!ft_lstm_persist_supported(B, H))
         return ft_fail(FT_EUNSUPPORTED, "ft_lstm_persist_bwd: needs H == 1024, B <= 32 and a 256-CU device (H=%d B=%d)", H, B);
     if (T == 0) return FT_OK;
@@ -549,10 +696,20 @@ extern "C" int ft_lstm_persist_bwd(const float* dy, int64_t ldy, const float* w_
     unsigned* census = reinterpret_cast<unsigned*>(base + al256p((size_t)4 * H * H * 2) + gran_bytes);
     FT_CHECK_HIP(hipMemsetAsync(dgran, 0, gran_bytes + 256, st));
     hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H);
-    PersistBwdP p{dy, (long)ldy, lens, gates, cell, dgx, wTfrag, dgran, status, census, T, B, 100000000L / 2};
-    if (ng == 1) hipLaunchKernelGGL((lstm_persist_bwd_k<8, true>), dim3(NCU), dim3(256), 0, st, p);
-    else if (ng == 8) hipLaunchKernelGGL((lstm_persist_bwd_k<8, false>), dim3(NCU), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((lstm_persist_bwd_k<4, false>), dim3(NCU), dim3(256), 0, st, p);
+    PersistBwdP p{dy, (long)ldy, lens, gates, cell, dgx, wTfrag, dgran, status, census, T, B, 100000000L / 2, nullptr};
+    // dynamic LDS: 16-partial reduce (2 x 16 x 32 unit-rows... = 2*16*TL*RPGP*17 = 2*16*8*17 floats) + staged steps
+    const size_t lds = sizeof(float) * ((size_t)2 * 16 * 8 * 17 + (size_t)SB * 5 * 128 + (size_t)(SB + 1) * 128 + (size_t)2 * 4 * 128);
+    auto launch = [&](auto kern) -> int {
+        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(NCU), dim3(256), lds, st, p);
+        return FT_OK;
+    };
+    int rc;
+    if (ng == 1) rc = launch(lstm_persist_bwd_k<8, true, 2>);
+    else if (ng == 9) rc = launch(lstm_persist_bwd_k<8, true, 16>);
+    else if (ng == 8) rc = launch(lstm_persist_bwd_k<8, false, 16>);
+    else rc = launch(lstm_persist_bwd_k<4, false, 16>);
+    if (rc != FT_OK) return rc;
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

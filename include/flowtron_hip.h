@@ -143,6 +143,9 @@ int ft_lstm_persist_supported(int B, int H);
 size_t ft_lstm_persist_workspace_bytes(int B, int H);
 int ft_lstm_persist_fwd(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
                         float* gates, float* cell, void* work, int32_t* status, int T, int B, int H, int ng, void* stream);
+/* debug: device buffer [1024][4][5] int64 that subsequent ft_lstm_persist_fwd launches fill with per-step phase stamps
+ * (100 MHz wall clock) of one workgroup; NULL switches it off (scripts/exp/lstm_persist_bench.py). */
+int ft_lstm_persist_debug_prof(void* dev_buf);
 /* Persistent form of ft_lstm_seq_bwd (same restrictions; ng = 1 | 8 | 4): dgx [T,B,4H] from dy, the saved gates / cell and
  * W_hh; bit-identical to ft_lstm_seq_bwd(FT_BF16).  Same workspace query. */
 int ft_lstm_persist_bwd(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,

@@ -44,7 +44,7 @@ w0 = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=dev, dtype=torch.
 res["step"] = timeit(lambda: run_step(y0, g0, c0, w0))
 print("launch-per-step: min %.3f median %.3f us/step" % res["step"], flush=True)
 wp = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=dev, dtype=torch.uint8)
-for ng in (1, 8, 4, 2):
+for ng in (1, 9, 8, 4):
     y1, g1, c1 = bufs()
     y1.fill_(7.0)
     r = timeit(lambda: run_persist(ng, y1, g1, c1, wp))
@@ -52,8 +52,22 @@ for ng in (1, 8, 4, 2):
     act = (torch.arange(T, device=dev)[:, None] < lens[None, :])
     eq = bool(torch.equal(y0, y1)) and bool(torch.equal(g0[act], g1[act])) and bool(torch.equal(c0[act], c1[act]))
     res["persist%d" % ng] = r + (st, eq, float((y0 - y1).abs().max()))
-    print("persistent ng=%d (1 = XCD-local transport): min %.3f median %.3f us/step  status %d  bit-identical %s  max|dy| %.3e" % ((ng,) + res["persist%d" % ng]), flush=True)
+    print("persistent ng=%d (1 = XCD-local nt loads, 9 = XCD-local sc1 loads): min %.3f median %.3f us/step  status %d  bit-identical %s  max|dy| %.3e" % ((ng,) + res["persist%d" % ng]), flush=True)
     status.zero_()
+# ---- phase stamps of one workgroup (forward, XCD-local transport)
+prof = torch.zeros(1024 * 4 * 5, dtype=torch.int64, device=dev)
+L.lib().ft_lstm_persist_debug_prof(L.ptr(prof))
+yp, gp_, cp = bufs()
+run_persist(1, yp, gp_, cp, wp)
+torch.cuda.synchronize()
+L.lib().ft_lstm_persist_debug_prof(None)
+pr = prof.cpu().reshape(1024, 4, 5)[100:800].double()
+for wv in range(4):
+    top, swp, bar, pub, npass = (pr[:, wv, k] for k in range(5))
+    step = (top[1:] - top[:-1]).mean() * 10
+    print("wave %d: step %.0f ns | sweep+mfma %.0f | reduce+barrier %.0f | epilogue->publish %.0f | publish->next top %.0f | poll passes %.2f"
+          % (wv, step, ((swp - top).mean()) * 10, ((bar - swp).mean()) * 10, ((pub - bar).mean()) * 10 if wv < 2 else 0.0,
+             ((top[1:] - (pub if wv < 2 else bar)[:-1]).mean()) * 10, npass.mean()), flush=True)
 # ---- backward
 dy = torch.randn(T, B, H, device=dev) * 0.1
 act3 = (torch.arange(T, device=dev)[:, None] < lens[None, :])
@@ -71,7 +85,7 @@ def run_persist_bwd(ng, dgx, work):
 
 res["bwd_step"] = timeit(lambda: run_step_bwd(d0, w0))
 print("backward launch-per-step: min %.3f median %.3f us/step" % res["bwd_step"], flush=True)
-for ng in (1, 8, 4):
+for ng in (1, 9, 8):
     d1 = torch.full((T, B, 4 * H), 7.0, device=dev)
     r = timeit(lambda: run_persist_bwd(ng, d1, wp))
     st = int(status.item())

@@ -548,7 +548,7 @@ def test_bf16_image_and_fused_column_sums(env, rows, cols, off):
             assert mad(img.colsum, wide[:, off:off + cols].double().sum(0).float()) < 2e-4 * math.sqrt(rows)
 
 
-@pytest.mark.parametrize("ng", [1, 8, 4, 2])      # 1 = XCD-local transport (8 groups = 8 XCDs)
+@pytest.mark.parametrize("ng", [1, 9, 8, 4, 2])   # 1 | 9 = XCD-local transport with nt | sc1 loads (8 groups = 8 XCDs)
 @pytest.mark.parametrize("T,B,lens", [(37, 32, None), (9, 5, [9, 9, 4, 2, 1]), (20, 17, None)])
 def test_persistent_lstm_forward_is_bit_identical_to_launch_per_step(env, ng, T, B, lens):
     """ft_lstm_persist_fwd (one launch per sequence, W_hh fragments resident in registers, ng independent batch groups,
@@ -587,7 +587,7 @@ def test_persistent_lstm_forward_is_bit_identical_to_launch_per_step(env, ng, T,
     assert float(outs[1][0][~act].abs().max() if (~act).any() else 0.0) == 0.0
 
 
-@pytest.mark.parametrize("ng", [1, 8, 4])
+@pytest.mark.parametrize("ng", [1, 9, 8, 4])
 @pytest.mark.parametrize("T,B,lens", [(37, 32, None), (9, 5, [9, 9, 4, 2, 1]), (20, 17, None)])
 def test_persistent_lstm_backward_is_bit_identical_to_launch_per_step(env, ng, T, B, lens):
     """ft_lstm_persist_bwd against ft_lstm_seq_bwd(FT_BF16) on the saved tensors of a real forward: same fragment rounding,
