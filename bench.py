@@ -166,21 +166,84 @@ def lstm2_step_roofline(B, H, T):
             "bytes_per_launch": bytes_per_launch}
 
 
+def persist_roofline(B, H, T, lens_cpu):
+    """Live timing of the dominant kernels of the step when the persistent recurrence path is active (csrc/lstm_persist.hip:
+    ONE launch per sequence; six such launches per flow per step -- attention LSTM + the two decoder layers, forward and
+    backward): HIP events on the launch stream around one sequence of the bench's own shape and lengths.  Algorithmic HBM
+    bytes per launch: the bf16 fragment image of W_hh once (4H*H*2) + per VALID (t, b) row the fp32 rows the
+    recurrence must read and write -- forward: gx row in (4H) + y, saved gates, saved cell out (H + 4H + H); backward: saved
+    gates, cell, dy in (4H + H + H) + dgx out (4H).  The kernel is bound by the per-step dependency (an L2 hand-off + the
+    cell update per step), not by bandwidth: `frac` is small by construction and `us_per_step` is the figure of merit; the
+    launch-per-step kernel it replaces is timed beside it."""
+    from flowtron_amd import _lib as L
+    from flowtron_amd import ops
+    dev = "cuda"
+    f = dict(device=dev, dtype=torch.float32)
+    torch.manual_seed(0)
+    gx = torch.randn(T, B, 4 * H, **f) * 0.5
+    w = torch.randn(4 * H, H, **f) / H ** 0.5
+    dy = torch.randn(T, B, H, **f) * 0.1
+    lens = lens_cpu.to(device=dev, dtype=torch.int32)
+    y, gates, cell, dgx = torch.empty(T, B, H, **f), torch.empty(T, B, 4 * H, **f), torch.empty(T, B, H, **f), torch.empty(T, B, 4 * H, **f)
+    wp = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=dev, dtype=torch.uint8)
+    ws = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=dev, dtype=torch.uint8)
+    st = ops.persist_status(torch.device("cuda", torch.cuda.current_device()))
+    ng = int(os.environ.get("FLOWTRON_LSTM_PERSIST", "1"))
+    lib = L.lib()
+    runs = {
+        "lstm_persist_fwd_k": lambda: L.check(lib.ft_lstm_persist_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
+                                                                        L.ptr(wp), L.ptr(st), T, B, H, ng, L.stream()), "persist fwd"),
+        "lstm_persist_bwd_k": lambda: L.check(lib.ft_lstm_persist_bwd(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
+                                                                        L.ptr(wp), L.ptr(st), T, B, H, ng, L.stream()), "persist bwd"),
+        "lstm_fwd_step": lambda: L.check(lib.ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(ws),
+                                                              T, B, H, 0, 1, L.stream()), "step fwd"),
+        "lstm_bwd_step_bf16": lambda: L.check(lib.ft_lstm_seq_bwd(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
+                                                                   L.ptr(ws), T, B, H, 0, 1, L.stream()), "step bwd"),
+    }
+    us = {}
+    for name, fn in runs.items():
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        us[name] = sorted(ts)[1]
+    ops.check_persist_status()
+    rows = int(lens_cpu.sum())
+    out = {}
+    for name, per_row, repl in (("lstm_persist_bwd_k", 4 * (4 * H + H + H + 4 * H), "lstm_bwd_step_bf16"),
+                                ("lstm_persist_fwd_k", 4 * (4 * H + H + 4 * H + H), "lstm_fwd_step")):
+        nbytes = 2 * 4 * H * H + rows * per_row
+        ach = nbytes / (us[name] * 1e-6) / 1e9
+        out[name] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(ach / 8000.0, 4), "traffic": pmc_traffic(name), "us_per_launch": round(us[name], 1),
+                     "bytes_per_launch": nbytes, "steps_per_launch": T, "us_per_step": round(us[name] / T, 3),
+                     "replaces": {"kernel": repl, "us_per_step": round(us[repl] / T, 3)},
+                     "note": "one launch = one whole sequence (T dependent steps); latency-bound by the per-step L2 hand-off, "
+                             "W_hh stays in registers (the launch-per-step kernel re-streams 8.4 MB of it every step)"}
+    return out["lstm_persist_bwd_k"], out["lstm_persist_fwd_k"]
+
+
 def pmc_traffic(kernel_substr):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE and
-    WRITE_SIZE runs of scripts/exp/lstm_only.py, profiles/r01_pmc_lstm_*.json), with the gfx950 correction of
-    MI355X_MICROARCH.md (FETCH_SIZE reads 1/2 of a wide coalesced 16 B/lane stream; counters are KiB).  bench.py cannot
-    run rocprofv3 on itself, so this is the last measured value, or null when the files are absent."""
-    try:
-        vals = {}
-        for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_lstm_%s.json" % c)))
-            for k, v in d.items():
-                if kernel_substr in k:
-                    vals[c] = v[c]["avg"]
-        return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
-    except Exception:
-        return None
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE and WRITE_SIZE
+    runs, profiles/r02_pmc_*.json, else the round-1 files), with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE
+    reads 1/2 of a wide coalesced 16 B/lane stream; counters are KiB).  bench.py cannot run rocprofv3 on itself, so this is
+    the last measured value, or null when the files are absent."""
+    for prefix in ("r02_pmc_", "r01_pmc_lstm_"):
+        try:
+            vals = {}
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = json.load(open(os.path.join(ROOT, "profiles", "%s%s.json" % (prefix, c))))
+                for k, v in d.items():
+                    if kernel_substr in k:
+                        vals[c] = v[c]["avg"]
+            return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+        except Exception:
+            continue
+    return None
 
 
 def usable_cores():
@@ -392,6 +455,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     log("timed region done: %.1f ms/step" % (dt / max(args.steps, 1) * 1e3))
+    from flowtron_amd import ops as _ops_chk
+    _ops_chk.check_persist_status()                              # a persistent recurrence that timed out would have produced garbage
     loss_val = float(loss.item())
     stats = torch.tensor([dt, float(frames_rank)], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -418,15 +483,18 @@ def main():
         mode = L.FT_BF16 if args.mfma == "bf16" else L.FT_F32
         log("roofline kernel timing ...")
         try:
-            single = lstm_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, mode)
             from flowtron_amd import ops as _ops
-            if _ops.lstm2_supported(args.batch, MODEL_CONFIG["n_hidden"], mode):
+            if _ops.lstm_persist_groups(args.batch, MODEL_CONFIG["n_hidden"], False, mode, torch.device("cuda", torch.cuda.current_device())):
+                # dominant kernels of the step: the persistent recurrences (backward first: 6 launches per flow, ~60 % of the step)
+                res["roofline"], res["roofline_second_kernel"] = persist_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, batch_cpu["out_lens"])
+            elif _ops.lstm2_supported(args.batch, MODEL_CONFIG["n_hidden"], mode):
+                single = lstm_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, mode)
                 # dominant kernel of the step: the two-layer wavefront launch; the single-layer step kernel (attention LSTM,
                 # second by time) is reported beside it
                 res["roofline"] = lstm2_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T)
                 res["roofline_second_kernel"] = single
             else:
-                res["roofline"] = single
+                res["roofline"] = lstm_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, mode)
         except Exception as e:                      # never lose the headline number to the side measurement
             res["roofline"] = {"error": repr(e)}
         # the whole step against the MFMA roof -- valid frames/s x 325 MFLOP (2 flows, fwd + bwd) / 2.5 PFLOP/s

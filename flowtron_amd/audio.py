@@ -76,15 +76,50 @@ def dynamic_range_decompression(x, C=1):
     return torch.exp(x) / C
 
 
+def filterbank_csr(mel_basis: np.ndarray):
+    """[n_mel, n_bins] triangular filterbank -> (first bin per band int32[n_mel], row pointer int32[n_mel+1], weights fp32[nnz]):
+    every band's non-zeros are one run of consecutive bins (a triangle), ~1 000 weights instead of 80 x 513."""
+    bin0, ptr, w = [], [0], []
+    for row in np.asarray(mel_basis, dtype=np.float32):
+        nz = np.nonzero(row)[0]
+        if len(nz) == 0:
+            bin0.append(0)
+            ptr.append(ptr[-1])
+            continue
+        bin0.append(int(nz[0]))
+        w.extend(row[nz[0]:nz[-1] + 1].tolist())
+        ptr.append(len(w))
+    return np.asarray(bin0, np.int32), np.asarray(ptr, np.int32), np.asarray(w, np.float32)
+
+
 class STFT(torch.nn.Module):
-    """Holds the analysis parameters (audio_processing.py:172-205); `transform` (magnitude only --
-    the phase output is unused on the mel path) is reached through TacotronSTFT."""
+    """Analysis half of the reference STFT (audio_processing.py:172-235): `transform(y)` -> (magnitude, phase), both
+    [B, n_fft/2+1, N // hop + 1], one HIP kernel (real FFT, csrc/stft_r8.hip).  The inverse (Griffin-Lim side) is out of scope."""
 
     def __init__(self, filter_length=800, hop_length=200, win_length=800, window="hann"):
         super().__init__()
         assert window == "hann" and filter_length >= win_length
         self.filter_length, self.hop_length, self.win_length, self.window = filter_length, hop_length, win_length, window
         self.register_buffer("fft_window", torch.from_numpy(hann_window(win_length, filter_length)))
+
+    def fast_path(self):
+        return self.filter_length == 1024 and self.hop_length <= 256
+
+    def transform(self, input_data):
+        """audio_processing.py:207-235."""
+        L.require_cuda(input_data)
+        if not self.fast_path():
+            raise NotImplementedError("STFT.transform is built for filter_length 1024 / hop <= 256 (config.json:32-34)")
+        y = input_data.contiguous().float()
+        if self.fft_window.device != y.device:
+            self.to(y.device)
+        B, N = y.shape
+        n_frames = N // self.hop_length + 1
+        mag = torch.empty(B, self.filter_length // 2 + 1, n_frames, device=y.device, dtype=torch.float32)
+        phase = torch.empty_like(mag)
+        L.check(L.lib().ft_stft_r8(L.ptr(y), L.ptr(self.fft_window), None, None, None, None, L.ptr(mag), L.ptr(phase), B, N,
+                                   self.hop_length, 0, L.stream()), "ft_stft_r8")
+        return mag, phase
 
 
 class TacotronSTFT(torch.nn.Module):
@@ -94,8 +129,12 @@ class TacotronSTFT(torch.nn.Module):
         self.n_mel_channels = n_mel_channels
         self.sampling_rate = sampling_rate
         self.stft_fn = STFT(filter_length, hop_length, win_length)
-        mel_basis = torch.from_numpy(slaney_mel_filterbank(sampling_rate, filter_length, n_mel_channels, mel_fmin, mel_fmax))
-        self.register_buffer("mel_basis", mel_basis.float())
+        basis = slaney_mel_filterbank(sampling_rate, filter_length, n_mel_channels, mel_fmin, mel_fmax)
+        self.register_buffer("mel_basis", torch.from_numpy(basis).float())
+        bin0, ptr, w = filterbank_csr(basis)          # sparse form of the same matrix for the rFFT kernel (not in the state_dict)
+        self.register_buffer("fb_bin0", torch.from_numpy(bin0), persistent=False)
+        self.register_buffer("fb_ptr", torch.from_numpy(ptr), persistent=False)
+        self.register_buffer("fb_w", torch.from_numpy(w), persistent=False)
 
     def spectral_normalize(self, magnitudes):
         return dynamic_range_compression(magnitudes)
@@ -119,6 +158,11 @@ class TacotronSTFT(torch.nn.Module):
         st = self.stft_fn
         n_frames = N // st.hop_length + 1
         mel = torch.empty(B, self.n_mel_channels, n_frames, device=y.device, dtype=torch.float32)
-        L.check(L.lib().ft_stft_mel(L.ptr(y), L.ptr(st.fft_window), L.ptr(self.mel_basis), L.ptr(mel), B, N,
-                                    st.filter_length, st.hop_length, self.n_mel_channels, L.stream()), "ft_stft_mel")
+        if st.fast_path() and self.n_mel_channels <= 128 and N > st.filter_length // 2:
+            # rFFT (512-point complex FFT + split) + sparse triangular filterbank, one wave per frame (csrc/stft_r8.hip)
+            L.check(L.lib().ft_stft_r8(L.ptr(y), L.ptr(st.fft_window), L.ptr(self.fb_bin0), L.ptr(self.fb_ptr), L.ptr(self.fb_w),
+                                       L.ptr(mel), None, None, B, N, st.hop_length, self.n_mel_channels, L.stream()), "ft_stft_r8")
+        else:                                           # general n_fft: complex radix-2 FFT + dense filterbank (csrc/stft.hip)
+            L.check(L.lib().ft_stft_mel(L.ptr(y), L.ptr(st.fft_window), L.ptr(self.mel_basis), L.ptr(mel), B, N,
+                                        st.filter_length, st.hop_length, self.n_mel_channels, L.stream()), "ft_stft_mel")
         return mel

@@ -23,6 +23,8 @@
 
 namespace {
 
+typedef unsigned short bf16_t;
+
 struct DecodeDev {
     const float *att_w_ih, *att_w_hh, *att_b_ih, *att_b_hh;
     const float *w_query, *v, *K, *V;
@@ -37,9 +39,42 @@ struct DecodeDev {
     float *cumm, *prev_attn, *keyin, *Kdyn;
     float *escore, *obuf;                        // attention scores [L], 1x1 conv output [2M] (stage hand-offs)
     int* ctl;                                    // [0] frame index, [1] done flag
+    // bf16 images of the weight matrices (null = stream the fp32 originals)
+    const bf16_t *att_w_ih16, *att_w_hh16, *w_query16, *l0_w_ih16, *l0_w_hh16, *l1_w_ih16, *l1_w_hh16, *d0_w16, *d1_w16, *conv_w16;
     int N, L, H, A, M, E;
     float inv_temp, gate_threshold;
 };
+
+// ---- bf16 weight images (bf16 operand mode): every weight matrix of the flow is rounded ONCE per ft_decode_flow call into a
+// bf16 copy (53.7 MB instead of 107.4 MB per frame and flow; the copy stays in the Infinity Cache across frames) and the
+// GEMVs stream those; activations and accumulation stay fp32.  16-byte loads = 8 weights per lane.
+__device__ __forceinline__ float dot8(const uint4 w, const float4 xa, const float4 xb) {
+    return __uint_as_float(w.x << 16) * xa.x + __uint_as_float(w.x & 0xffff0000u) * xa.y + __uint_as_float(w.y << 16) * xa.z +
+           __uint_as_float(w.y & 0xffff0000u) * xa.w + __uint_as_float(w.z << 16) * xb.x + __uint_as_float(w.z & 0xffff0000u) * xb.y +
+           __uint_as_float(w.w << 16) * xb.z + __uint_as_float(w.w & 0xffff0000u) * xb.w;
+}
+// one weight row against an fp32 activation segment; K % 8 == 0, 16-byte aligned (checked by the host for the bf16 path)
+__device__ __forceinline__ float dot_seg(const bf16_t* __restrict__ w, const float* __restrict__ x, int K, int lane) {
+    const uint4* w8 = reinterpret_cast<const uint4*>(w);
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const int K8 = K >> 3;
+    float s = 0.f;
+    for (int kb = 0; kb < K8; kb += 256) {                       // 4 loads per lane in flight
+        uint4 wv[4];
+        float4 xa[4], xb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = kb + u * 64 + lane;
+            const bool ok = k < K8;
+            const int kk = ok ? k : 0;
+            wv[u] = ok ? w8[kk] : make_uint4(0u, 0u, 0u, 0u);
+            xa[u] = x4[2 * kk]; xb[u] = x4[2 * kk + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += dot8(wv[u], xa[u], xb[u]);
+    }
+    return s;
+}
 
 __device__ __forceinline__ float dot_seg(const float* __restrict__ w, const float* __restrict__ x, int K, int lane) {
     float s = 0.f;
@@ -152,6 +187,50 @@ __global__ __launch_bounds__(256) void dec_lstm_k(const DecodeDev P) {
     }
 }
 
+// bf16-weight form: ONE WORKGROUP PER HIDDEN UNIT, wave g streams gate row g (all of its 16-byte loads in flight): H workgroups
+// = 4 per CU = 16 waves per CU pulling weights, instead of 4 -- a decode GEMV is bound by the bytes a CU has in flight.
+template <int WHICH>
+__global__ __launch_bounds__(256) void dec_lstm16_k(const DecodeDev P) {
+    __shared__ float pre_s[4];
+    int i;
+    const bool live = frame_live(P, i);
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int u = blockIdx.x, H = P.H;
+    const int par = i & 1;
+    const bf16_t *w_ih, *w_hh;
+    const float *b_ih, *b_hh, *x0, *x1 = nullptr;
+    float *hbuf, *cbuf;
+    int K0, K1 = 0;
+    if (WHICH == 0) {
+        w_ih = P.att_w_ih16; w_hh = P.att_w_hh16; b_ih = P.att_b_ih; b_hh = P.att_b_hh;
+        x0 = P.prev; K0 = P.M; hbuf = P.h_att; cbuf = P.c_att;
+    } else if (WHICH == 1) {
+        w_ih = P.l0_w_ih16; w_hh = P.l0_w_hh16; b_ih = P.l0_b_ih; b_hh = P.l0_b_hh;
+        x0 = P.h_att + (par ^ 1) * H; K0 = H; x1 = P.ctx; K1 = P.A; hbuf = P.h0; cbuf = P.c0;
+    } else {
+        w_ih = P.l1_w_ih16; w_hh = P.l1_w_hh16; b_ih = P.l1_b_ih; b_hh = P.l1_b_hh;
+        x0 = P.h0 + (par ^ 1) * H; K0 = H; hbuf = P.h1; cbuf = P.c1;
+    }
+    const float* hold = hbuf + par * H;
+    const int Kin = K0 + K1;
+    const size_t row = (size_t)g * H + u;
+    float s = dot_seg(w_ih + row * Kin, x0, K0, lane);
+    if (K1) s += dot_seg(w_ih + row * Kin + K0, x1, K1, lane);
+    s += dot_seg(w_hh + row * H, hold, H, lane);
+    s = wave_sum(s);
+    if (lane == 0) pre_s[g] = s + b_ih[row] + b_hh[row];
+    __syncthreads();
+    if (live && threadIdx.x == 0) {
+        const float ig = 1.f / (1.f + expf(-pre_s[0]));
+        const float fg = 1.f / (1.f + expf(-pre_s[1]));
+        const float gg = tanhf(pre_s[2]);
+        const float og = 1.f / (1.f + expf(-pre_s[3]));
+        const float c = fg * cbuf[u] + ig * gg;
+        cbuf[u] = c;
+        hbuf[(par ^ 1) * H + u] = og * tanhf(c);
+    }
+}
+
 // y[n] = act(W[n,:].x + b[n]), one wave per row.  WHICH: 0 query (x = new h_att), 1 dense0 (x = new h1), 2 dense1 (x = u1)
 template <int WHICH>
 __global__ __launch_bounds__(256) void dec_gemv_k(const DecodeDev P) {
@@ -168,7 +247,8 @@ __global__ __launch_bounds__(256) void dec_gemv_k(const DecodeDev P) {
     else if (WHICH == 1) { W = P.d0_w; b = P.d0_b; x = P.h1 + (par ^ 1) * H; y = P.u1; N = H; K = H; }
     else { W = P.d1_w; b = P.d1_b; x = P.u1; y = P.u2; N = H; K = H; }
     if (n >= N) return;
-    float s = wave_sum(dot_seg(W + (size_t)n * K, x, K, lane));
+    const bf16_t* W16 = WHICH == 0 ? P.w_query16 : (WHICH == 1 ? P.d0_w16 : P.d1_w16);
+    float s = wave_sum(W16 ? dot_seg(W16 + (size_t)n * K, x, K, lane) : dot_seg(W + (size_t)n * K, x, K, lane));
     if (live && lane == 0) {
         if (WHICH != 0) s = tanhf(s + b[n]);
         y[n] = s;
@@ -304,7 +384,8 @@ __global__ __launch_bounds__(256) void dec_conv_k(const DecodeDev P) {
     if (!frame_live(P, i)) return;
     const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= 2 * P.M) return;
-    const float s = wave_sum(dot_seg(P.conv_w + (size_t)n * P.H, P.u2, P.H, lane));
+    const float s = wave_sum(P.conv_w16 ? dot_seg(P.conv_w16 + (size_t)n * P.H, P.u2, P.H, lane)
+                                         : dot_seg(P.conv_w + (size_t)n * P.H, P.u2, P.H, lane));
     if (lane == 0) P.obuf[n] = s + P.conv_b[n];
 }
 
@@ -369,9 +450,18 @@ constexpr int GRAPH_FRAMES = 8;
 std::mutex g_graph_mu;
 std::unordered_map<uint64_t, hipGraphExec_t> g_graph_cache;
 
+__global__ void f32_to_bf16_k(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+    for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 2; i < n; i += (size_t)gridDim.x * blockDim.x * 2) {
+        if (i + 1 < n) *reinterpret_cast<unsigned int*>(dst + i) = pack_bf16x2(src[i], src[i + 1]);
+        else dst[i] = f2bf(src[i]);
+    }
+}
+
 int enqueue_frame(const DecodeDev& dP, int H, int A, int L, int M, bool cumm, hipStream_t st) {
     const dim3 b256(256), b1024(1024);
-    hipLaunchKernelGGL(dec_lstm_k<0>, dim3(cdiv(H, 4)), b256, 0, st, dP);
+    const bool w16 = dP.att_w_hh16 != nullptr;
+    if (w16) hipLaunchKernelGGL(dec_lstm16_k<0>, dim3(H), b256, 0, st, dP);
+    else hipLaunchKernelGGL(dec_lstm_k<0>, dim3(cdiv(H, 4)), b256, 0, st, dP);
     hipLaunchKernelGGL(dec_gemv_k<0>, dim3(cdiv(A, 4)), b256, 0, st, dP);
     if (cumm) {
         hipLaunchKernelGGL(dec_cond_k, dim3(L), b256, 0, st, dP);
@@ -379,8 +469,13 @@ int enqueue_frame(const DecodeDev& dP, int H, int A, int L, int M, bool cumm, hi
     }
     hipLaunchKernelGGL(dec_score_k, dim3(cdiv(L, 4)), b256, 0, st, dP);
     hipLaunchKernelGGL(dec_ctx_k, dim3(cdiv(A, 64)), b256, sizeof(float) * (L + 4 + 256), st, dP);
-    hipLaunchKernelGGL(dec_lstm_k<1>, dim3(cdiv(H, 4)), b256, 0, st, dP);
-    hipLaunchKernelGGL(dec_lstm_k<2>, dim3(cdiv(H, 4)), b256, 0, st, dP);
+    if (w16) {
+        hipLaunchKernelGGL(dec_lstm16_k<1>, dim3(H), b256, 0, st, dP);
+        hipLaunchKernelGGL(dec_lstm16_k<2>, dim3(H), b256, 0, st, dP);
+    } else {
+        hipLaunchKernelGGL(dec_lstm_k<1>, dim3(cdiv(H, 4)), b256, 0, st, dP);
+        hipLaunchKernelGGL(dec_lstm_k<2>, dim3(cdiv(H, 4)), b256, 0, st, dP);
+    }
     hipLaunchKernelGGL(dec_gemv_k<1>, dim3(cdiv(H, 4)), b256, 0, st, dP);
     hipLaunchKernelGGL(dec_gemv_k<2>, dim3(cdiv(H, 4)), b256, 0, st, dP);
     hipLaunchKernelGGL(dec_conv_k, dim3(cdiv(2 * M, 4)), b256, 0, st, dP);
@@ -392,6 +487,22 @@ int enqueue_frame(const DecodeDev& dP, int H, int A, int L, int M, bool cumm, hi
 
 extern "C" size_t ft_decode_workspace_bytes(int L, int H, int A, int M, int E) {
     return make_layout(H, A, M, L, E).total;
+}
+
+namespace {
+// element counts of the ten matrices that get a bf16 image, in DecodeDev order
+void wimg_counts(int H, int A, int M, size_t (&n)[10]) {
+    const size_t H4 = 4 * (size_t)H;
+    n[0] = H4 * M; n[1] = H4 * H; n[2] = (size_t)A * H; n[3] = H4 * (H + A); n[4] = H4 * H; n[5] = H4 * H; n[6] = H4 * H;
+    n[7] = (size_t)H * H; n[8] = (size_t)H * H; n[9] = 2 * (size_t)M * H;
+}
+}  // namespace
+
+extern "C" size_t ft_decode_wimg_bytes(int H, int A, int M) {
+    size_t n[10], tot = 0;
+    wimg_counts(H, A, M, n);
+    for (size_t v : n) tot += (v * 2 + 255) & ~size_t(255);
+    return tot;
 }
 
 extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
@@ -432,6 +543,23 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
     }
     h.E = a->E;
     h.N = a->N; h.L = a->L; h.H = a->H; h.A = a->A; h.M = a->M;
+    if (a->wimg) {                               // bf16 weight images: rounded once per call (54 MB of writes vs N x 107 MB of reads)
+        FT_CHECK_ARG(a->wimg_bytes >= ft_decode_wimg_bytes(a->H, a->A, a->M) && reinterpret_cast<uintptr_t>(a->wimg) % 256 == 0);
+        FT_CHECK_ARG(a->H % 8 == 0 && a->A % 8 == 0 && a->M % 8 == 0);
+        size_t n[10];
+        wimg_counts(a->H, a->A, a->M, n);
+        const float* src[10] = {a->att_w_ih, a->att_w_hh, a->w_query, a->l0_w_ih, a->l0_w_hh, a->l1_w_ih, a->l1_w_hh, a->d0_w, a->d1_w, a->conv_w};
+        const bf16_t** dstp[10] = {&h.att_w_ih16, &h.att_w_hh16, &h.w_query16, &h.l0_w_ih16, &h.l0_w_hh16, &h.l1_w_ih16, &h.l1_w_hh16,
+                                   &h.d0_w16, &h.d1_w16, &h.conv_w16};
+        char* wp = reinterpret_cast<char*>(a->wimg);
+        for (int k = 0; k < 10; ++k) {
+            FT_CHECK_ARG(reinterpret_cast<uintptr_t>(src[k]) % 16 == 0);
+            bf16_t* d = reinterpret_cast<bf16_t*>(wp);
+            hipLaunchKernelGGL(f32_to_bf16_k, dim3(1024), dim3(256), 0, st, src[k], d, n[k]);
+            *dstp[k] = d;
+            wp += (n[k] * 2 + 255) & ~size_t(255);
+        }
+    }
     h.inv_temp = 1.0f / a->temperature; h.gate_threshold = a->gate_threshold;
 
     // state (h, c, prev, frame counter, stop flag) = 0; parameter block = h.  hipMemcpyAsync from

@@ -212,7 +212,13 @@ class AR_Step(nn.Module):
             g = self.gate_layer.linear_layer
             gates = ops.linear([h_att, ctx], g.weight, g.bias, mode=mode)     # Linear over [h_att ; ctx], no concat
         p = self.lstm
-        if ops.lstm2_supported(B, p.weight_hh_l0.shape[1], mode):
+        if ops.lstm_persist_groups(B, p.weight_hh_l0.shape[1], False, mode, mel.device):
+            # two persistent single-layer recurrences (csrc/lstm_persist.hip, ~2 us per step each) with layer 1's input
+            # projection as one batched GEMM between them: faster than the two-layer wavefront launch chain (~8 us per step)
+            h = ops.lstm_layer(h_att, out_lens32, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, mode=mode,
+                               xs_extra=[ctx])
+            h = ops.lstm_layer(h, out_lens32, p.weight_ih_l1, p.weight_hh_l1, p.bias_ih_l1, p.bias_hh_l1, mode=mode)
+        elif ops.lstm2_supported(B, p.weight_hh_l0.shape[1], mode):
             # both decoder layers as one software-wavefront launch chain (csrc/lstm2.hip)
             gx0 = ops.LinearFn.apply(p.weight_ih_l0, p.bias_ih_l0 + p.bias_hh_l0, L.ACT_NONE, mode, h_att, ctx)
             h = ops.LSTM2SeqFn.apply(gx0, p.weight_hh_l0, p.weight_ih_l1, p.bias_ih_l1, p.bias_hh_l1, p.weight_hh_l1, out_lens32)
@@ -317,7 +323,13 @@ class AR_Step(nn.Module):
             L.ptr(cc.location_conv_hidden.conv.weight) if cumm else None, L.ptr(cc.location_conv_hidden.conv.bias) if cumm else None,
             L.ptr(cc.location_conv_out.conv.weight) if cumm else None, L.ptr(cc.location_conv_out.conv.bias) if cumm else None,
             L.ptr(att.key.linear_layer.weight) if cumm else None, L.ptr(enc2d) if cumm else None, E,
-            L.ptr(prior_rows), L.ptr(forced_rows))
+            L.ptr(prior_rows), L.ptr(forced_rows), None, 0)
+        if L.mfma_mode() == L.FT_BF16:          # bf16 operand mode: stream bf16 images of the weights (half the bytes per frame)
+            nb = L.lib().ft_decode_wimg_bytes(H, A, M)
+            wimg = bufs.get("wimg")
+            if wimg is None or wimg.numel() < nb:
+                wimg = bufs["wimg"] = torch.empty(nb, device=dev, dtype=torch.uint8)
+            args.wimg, args.wimg_bytes = L.ptr(wimg), wimg.numel()
         L.check(L.lib().ft_decode_flow(C.byref(args), L.stream()), "ft_decode_flow")
         n = int(n_done.item()) if has_gate else N          # single host read per flow (the reference syncs every frame)
         del keep

@@ -336,32 +336,104 @@ def conv_norm_relu(x, lens, conv_w, conv_b, gamma, beta, keep=None, eps=1e-5, mo
 # --------------------------------------------------------------------------
 # length-masked LSTM sequence (packed nn.LSTM semantics, flowtron.py:689-694, :505-512)
 # --------------------------------------------------------------------------
-_PERSIST_STATUS = {}
+# --------------------------------------------------------------------------
+# persistent recurrence kernels (csrc/lstm_persist.hip): one launch per sequence, W_hh resident in registers
+# --------------------------------------------------------------------------
+# The kernels raise a device status word instead of hanging when their hand-off waits time out (grid not co-resident,
+# partitioned device).  It is checked without stalling the stream: a self-test on first use (synchronous, once per device)
+# decides whether the path is usable at all; afterwards every launch first looks at an asynchronous host copy of the word made
+# after the PREVIOUS launch, so a failure surfaces one launch late as a RuntimeError instead of as silent garbage.
+_PERSIST = {}
+
+
+class _PersistState:
+    def __init__(self, device):
+        self.status = torch.zeros(1, device=device, dtype=torch.int32)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.event = None
+        self.usable = None          # None = not tested yet
+
+
+def _persist_state(device):
+    st = _PERSIST.get(device)
+    if st is None:
+        st = _PERSIST[device] = _PersistState(device)
+    return st
 
 
 def persist_status(device):
-    """device int32 word the persistent recurrence kernels raise when a hand-off wait times out (grid not co-resident)."""
-    st = _PERSIST_STATUS.get(device)
-    if st is None:
-        st = _PERSIST_STATUS[device] = torch.zeros(1, device=device, dtype=torch.int32)
+    return _persist_state(device).status
+
+
+def _persist_watch(device):
+    """raise if an earlier persistent launch reported a failure; then queue a fresh asynchronous copy of the status word."""
+    st = _persist_state(device)
+    if st.event is not None and st.event.query():
+        if int(st.host[0]) != 0:
+            st.status.zero_()
+            st.event = None
+            st.usable = False
+            raise RuntimeError("a persistent LSTM launch did not complete (status %d): the 256-workgroup grid was not "
+                               "co-resident / XCD census failed; falling back to the launch-per-step kernels from now on"
+                               % int(st.host[0]))
     return st
+
+
+def _persist_arm(st):
+    st.host.copy_(st.status, non_blocking=True)
+    st.event = torch.cuda.Event()
+    st.event.record()
 
 
 def check_persist_status():
     """Host check (one sync) of every persistent-kernel status word; raises if a sequence did not complete."""
-    for dev, st in _PERSIST_STATUS.items():
-        if int(st.item()) != 0:
-            st.zero_()
+    for dev, st in _PERSIST.items():
+        if int(st.status.item()) != 0:
+            st.status.zero_()
+            st.usable = False
             raise RuntimeError("persistent LSTM kernel timed out on %s: the 256-workgroup grid was not co-resident "
                                "(set FLOWTRON_LSTM_PERSIST=0 to use the launch-per-step kernels)" % (dev,))
 
 
-def lstm_persist_groups(B, H, reverse, mode):
-    """batch groups of the persistent forward recurrence (0 = use the launch-per-step kernel)."""
-    ng = int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "0"))
-    if ng and not reverse and mode == L.FT_BF16 and L.lib().ft_lstm_persist_supported(B, H):
-        return ng
-    return 0
+def _persist_selftest(device, ng):
+    """tiny forward + backward through the persistent kernels, checked synchronously (once per device)."""
+    H, B, T = 1024, 8, 3
+    f = dict(device=device, dtype=torch.float32)
+    gx, w = torch.zeros(T, B, 4 * H, **f), torch.zeros(4 * H, H, **f)
+    lens = torch.full((B,), T, dtype=torch.int32, device=device)
+    y, gates, cell = torch.empty(T, B, H, **f), torch.empty(T, B, 4 * H, **f), torch.empty(T, B, H, **f)
+    dgx = torch.empty(T, B, 4 * H, **f)
+    work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=device, dtype=torch.uint8)
+    st = _persist_state(device)
+    try:
+        L.check(L.lib().ft_lstm_persist_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(work),
+                                            L.ptr(st.status), T, B, H, ng, L.stream()), "ft_lstm_persist_fwd")
+        L.check(L.lib().ft_lstm_persist_bwd(L.ptr(y), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx), L.ptr(work),
+                                            L.ptr(st.status), T, B, H, ng, L.stream()), "ft_lstm_persist_bwd")
+        ok = int(st.status.item()) == 0
+    except RuntimeError:
+        ok = False
+    st.status.zero_()
+    if not ok:
+        import warnings
+        warnings.warn("flowtron_amd: the persistent LSTM kernels are not usable on %s (grid not co-resident / XCD census failed); "
+                      "using the launch-per-step kernels" % (device,))
+    return ok
+
+
+def lstm_persist_groups(B, H, reverse, mode, device=None):
+    """transport / group code of the persistent recurrence kernels for this shape (0 = use the launch-per-step kernels).
+    FLOWTRON_LSTM_PERSIST: 0 = off, 1 (default) = 8 XCD-local groups, 8 | 4 = placement-independent fabric transport."""
+    ng = int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "1"))
+    if not ng or reverse or mode != L.FT_BF16 or not L.lib().ft_lstm_persist_supported(B, H):
+        return 0
+    if device is not None:
+        st = _persist_state(device)
+        if st.usable is None:
+            st.usable = _persist_selftest(device, ng)
+        if not st.usable:
+            return 0
+    return ng
 
 
 class LSTMSeqFn(torch.autograd.Function):
@@ -374,12 +446,13 @@ class LSTMSeqFn(torch.autograd.Function):
         y = torch.empty(T, B, H, device=gx.device, dtype=torch.float32)
         gates = torch.empty(T, B, H4, device=gx.device, dtype=torch.float32)
         cell = torch.empty(T, B, H, device=gx.device, dtype=torch.float32)
-        ng = lstm_persist_groups(B, H, reverse, mode)
+        ng = lstm_persist_groups(B, H, reverse, mode, gx.device)
         if ng:
+            st = _persist_watch(gx.device)
             work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=gx.device, dtype=torch.uint8)
             L.check(L.lib().ft_lstm_persist_fwd(L.ptr(gx), L.ptr(w_hh), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
-                                                L.ptr(work), L.ptr(persist_status(gx.device)), T, B, H, ng, L.stream()),
-                    "ft_lstm_persist_fwd")
+                                                L.ptr(work), L.ptr(st.status), T, B, H, ng, L.stream()), "ft_lstm_persist_fwd")
+            _persist_arm(st)
         else:
             work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=gx.device, dtype=torch.uint8)
             L.check(L.lib().ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w_hh), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
@@ -394,13 +467,14 @@ class LSTMSeqFn(torch.autograd.Function):
         dy = _c(dy)
         T, B, H = y.shape
         dgx = torch.empty(T, B, 4 * H, device=dy.device, dtype=torch.float32)
-        ng = lstm_persist_groups(B, H, ctx.reverse, ctx.mode)
+        ng = lstm_persist_groups(B, H, ctx.reverse, ctx.mode, dy.device)
         if ng:
-            ng = ng if ng in (1, 8, 4) else 8
+            ng = ng if ng in (1, 9, 8, 4) else 8
+            st = _persist_watch(dy.device)
             work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=dy.device, dtype=torch.uint8)
             L.check(L.lib().ft_lstm_persist_bwd(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
-                                                L.ptr(work), L.ptr(persist_status(dy.device)), T, B, H, ng, L.stream()),
-                    "ft_lstm_persist_bwd")
+                                                L.ptr(work), L.ptr(st.status), T, B, H, ng, L.stream()), "ft_lstm_persist_bwd")
+            _persist_arm(st)
         else:
             work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=dy.device, dtype=torch.uint8)
             L.check(L.lib().ft_lstm_seq_bwd(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),

@@ -261,8 +261,13 @@ typedef struct {
     /* optional [N,L] rows: attention prior (attn = softmax(log(p+1e-20)+log(prior+1e-20)), flowtron.py:544-557, :799) and
      * forced alignment (the given row replaces the computed attention, :585-588, :798); NULL = off */
     const float *prior, *forced;
+    /* optional scratch of ft_decode_wimg_bytes() bytes (256-byte aligned): when given, the ten weight matrices are rounded once
+     * per call to bf16 images and the per-frame GEMVs stream those (bf16 operand mode: half the bytes per frame; fp32
+     * activations and accumulation).  NULL = stream the fp32 weights (parity mode). */
+    void* wimg; size_t wimg_bytes;
 } ft_decode_args;
 size_t ft_decode_workspace_bytes(int L, int H, int A, int M, int E);
+size_t ft_decode_wimg_bytes(int H, int A, int M);
 int ft_decode_flow(const ft_decode_args* a, void* stream);
 
 /* ---- STFT magnitude + mel + log (audio_processing.py:117-134, 207-235) -------
@@ -270,6 +275,13 @@ int ft_decode_flow(const ft_decode_args* a, void* stream);
  * fb [n_mel, n_fft/2+1].  Radix-2 real FFT per frame in LDS (n_fft = 1024). */
 int ft_stft_mel(const float* y, const float* window, const float* fb, float* mel,
                 int B, int N, int n_fft, int hop, int n_mel, void* stream);
+/* The same front end for the reference's analysis setting n_fft = 1024, hop <= 256 (config.json:32-34) as a REAL FFT (one
+ * 512-point complex FFT + split step, one wave per frame, radix-8 passes in registers) with the triangular filterbank in
+ * sparse form: band b = weights band_w[band_ptr[b] .. band_ptr[b+1]) over the consecutive bins starting at band_bin0[b].
+ * Any of mel [B,n_mel,T], (mag, phase) [B,513,T] may be requested (NULL = skip; mag and phase together = STFT.transform,
+ * audio_processing.py:207-235).  window: hann [1024] (win_length zero-padded by the caller). */
+int ft_stft_r8(const float* y, const float* window, const int32_t* band_bin0, const int32_t* band_ptr, const float* band_w,
+               float* mel, float* mag, float* phase, int B, int N, int hop, int n_mel, void* stream);
 
 /* ---- attention-CTC loss (flowtron.py:155-182, 245-274) ------------------------------
  * lp [B,T,L] = attn_logprob in natural time order.  Per sample: classes {blank (logit blank_logprob), 1..K_b} with

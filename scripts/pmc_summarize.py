@@ -11,7 +11,7 @@ with open(path) as f:
         a = acc[name][cn]
         a[0] += float(cv); a[1] += 1
 res = {k: {c: {"avg": v[0] / v[1], "dispatches": v[1]} for c, v in d.items()} for k, d in acc.items()}
-top = dict(sorted(res.items(), key=lambda kv: -max(x["avg"] * x["dispatches"] for x in kv[1].values()))[:25])
+top = dict(sorted(res.items(), key=lambda kv: -max(x["avg"] * x["dispatches"] for x in kv[1].values()))[:48])
 json.dump(top, open(out, "w"), indent=1)
 for k, d in list(top.items())[:8]:
     print(k[:90], {c: (round(v["avg"], 2), v["dispatches"]) for c, v in d.items()})

@@ -2,6 +2,7 @@
  (a) the committed golden vectors that tests/golden/make_golden.py produced by running the REAL reference, and
  (b) the CPU oracle on fresh seeded inputs, plus size-independent properties (invertibility, padding
      invariance) at the full 2-flow config.  fp32 tolerances follow SURVEY 8c."""
+import math
 import os
 
 import numpy as np
@@ -98,6 +99,34 @@ def test_infer_vs_reference_golden(name, use_graph):
         forced = [torch.cat(a)[:, 0] for a in attns][::-1]
         mel_f, _ = m.infer(residual.cuda(), spk, txt, gate_threshold=1.0, attns=forced)
         assert mad(mel_f, mel) < 1e-5
+
+
+@pytest.mark.parametrize("use_graph", ["0", "1"])
+def test_infer_bf16_weight_images_track_fp32_full_width(use_graph):
+    """bf16 operand mode decodes from bf16 IMAGES of the weights (csrc/decode.hip: one workgroup per hidden unit, wave per gate
+    row): full-width 2-flow model, 48 frames, against the fp32-weight decode of the same kernels' parity mode (which the
+    real-reference goldens pin).  Weight rounding 2^-9 relative through ~100 recurrent steps: mel within 5e-2 (values span
+    ~[-12, 2]), attention rows within 2e-2, and the fp32-mode run itself reproduces with and without the hipGraph."""
+    from oracle import synth
+    os.environ["FLOWTRON_DECODE_GRAPH"] = use_graph
+    cfg = dict(synth.DEFAULT_MODEL_CONFIG, n_text=60)
+    rs = np.random.RandomState(5)
+    residual = torch.from_numpy(rs.standard_normal((1, 80, 48)).astype(np.float32)).cuda() * 0.5
+    txt = torch.from_numpy(rs.randint(0, 60, (1, 23))).cuda()
+    spk = torch.zeros(1, dtype=torch.long).cuda()
+    res = {}
+    try:
+        for mode in ("f32", "bf16"):
+            m, _ = build(cfg, 17, mode)
+            res[mode] = m.infer(residual, spk, txt, gate_threshold=1.0)
+    finally:
+        os.environ["FLOWTRON_MFMA"] = "f32"
+        os.environ["FLOWTRON_DECODE_GRAPH"] = "1"
+    assert res["bf16"][0].shape == res["f32"][0].shape == (1, 80, 48)
+    assert torch.isfinite(res["bf16"][0]).all()
+    assert mad(res["bf16"][0], res["f32"][0]) < 5e-2, mad(res["bf16"][0], res["f32"][0])
+    for a16, a32 in zip(res["bf16"][1], res["f32"][1]):
+        assert mad(torch.cat(a16), torch.cat(a32)) < 2e-2
 
 
 def test_cfg1_full_size_vs_reference_golden():
@@ -219,6 +248,25 @@ def test_stft_mel_vs_reference_golden():
     # full 10 s clip: shape contract N//hop + 1 (audio_processing.py:221-225)
     y10 = synth.make_audio(220500, seed=3)[None].cuda()
     assert stft.mel_spectrogram(y10).shape == (1, 80, 862)
+    # STFT.transform (audio_processing.py:207-235): magnitude column of the REAL reference's conv1d DFT (fixture mag_b0_f7), and
+    # the phase / magnitude pair against torch.stft of the same reflect-padded, hann-windowed signal (|X| abs 2e-3 of ~50, phase
+    # where the bin carries energy)
+    mag, phase = stft.stft_fn.transform(y)
+    assert mag.shape == (2, 513, g["mel"].shape[2]) and phase.shape == mag.shape
+    assert mad(mag[0, :, 7], g["mag_b0_f7"]) < 2e-3 * max(1.0, float(g["mag_b0_f7"].abs().max()))
+    ref = torch.stft(y.cpu(), 1024, hop_length=256, win_length=1024, window=torch.hann_window(1024, periodic=True), center=True,
+                     pad_mode="reflect", return_complex=True)
+    assert mad(mag, ref.abs()) < 2e-3 * float(ref.abs().max())
+    strong = ref.abs() > 0.05 * ref.abs().max()
+    dphi = torch.remainder(phase.cpu() - ref.angle() + math.pi, 2 * math.pi) - math.pi
+    assert float(dphi[strong].abs().max()) < 1e-2
+    # the general-n_fft kernel (complex radix-2 FFT + dense filterbank) still agrees with the rFFT + sparse-filterbank kernel
+    from flowtron_amd import _lib as L
+    mel_dense = torch.empty_like(mel)
+    st = stft.stft_fn
+    L.check(L.lib().ft_stft_mel(L.ptr(y), L.ptr(st.fft_window), L.ptr(stft.mel_basis), L.ptr(mel_dense), 2, y.shape[1], 1024, 256, 80,
+                                L.stream()), "ft_stft_mel")
+    assert mad(mel, mel_dense) < 2e-4
 
 
 def test_device_collate_matches_host_collate_and_prior_kernel():
