@@ -505,7 +505,7 @@ def main():
             try:
                 log("inference RTF ...")
                 model.eval()
-                n_frames = 400
+                n_frames = int(os.environ.get("BENCH_INFER_FRAMES", "400"))      # (the PMC passes of scripts/profile_r2.sh shorten it)
                 z = torch.randn(1, 80, n_frames, device="cuda") * 0.5
                 text = b["text"][:1, :69]
                 spk = b["speaker_ids"][:1]
@@ -513,14 +513,14 @@ def main():
                     model.infer(z, spk, text, gate_threshold=1.0)       # warm-up (+ hipGraph capture)
                 torch.cuda.synchronize()
                 tis = []
-                for _ in range(7):
+                for _ in range(int(os.environ.get("BENCH_INFER_CALLS", "7"))):
                     t1 = time.perf_counter()
                     mel, _ = model.infer(z, spk, text, gate_threshold=1.0)
                     torch.cuda.synchronize()
                     tis.append(time.perf_counter() - t1)
                 ti = sorted(tis)[len(tis) // 2]
                 n_fl = MODEL_CONFIG["n_flows"]
-                wbytes = 26838656 * 4                                   # fp32 weights streamed per frame per flow
+                wbytes = 26838656 * (2 if args.mfma == "bf16" else 4)   # weights streamed per frame per flow (bf16 images in bf16 mode)
                 ach = n_fl * wbytes * mel.shape[2] / ti / 1e9
                 res["infer"] = {"frames": int(mel.shape[2]), "seconds": round(ti, 5), "seconds_min": round(min(tis), 5),
                                 "seconds_max": round(max(tis), 5), "calls": len(tis), "frames_per_s": round(mel.shape[2] / ti, 1),
@@ -528,7 +528,8 @@ def main():
                                 "us_per_frame_per_flow": round(ti / mel.shape[2] / n_fl * 1e6, 2),
                                 "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
                                              "frac": round(ach / 8000.0, 4), "bytes_per_frame_per_flow": wbytes},
-                                "config": "2-flow LJS, B=1, L=69, sigma=0.5, fp32 weights, gate disabled, median of %d calls" % len(tis)}
+                                "config": "2-flow LJS, B=1, L=69, sigma=0.5, %s weights, gate disabled, median of %d calls"
+                                          % ("bf16 images of the" if args.mfma == "bf16" else "fp32", len(tis))}
             except Exception as e:
                 res["infer"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:

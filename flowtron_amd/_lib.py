@@ -46,7 +46,7 @@ class DecodeArgs(C.Structure):
         ("work_bytes", _sz), ("N", _i), ("L", _i), ("H", _i), ("A", _i), ("M", _i),
         ("temperature", _f), ("gate_threshold", _f), ("use_graph", _i)] + [
         (n, _p) for n in ("cond_w1", "cond_b1", "cond_w2", "cond_b2", "w_key", "enc")] + [("E", _i), ("prior", _p), ("forced", _p),
-                                                                                         ("wimg", _p), ("wimg_bytes", _sz)]
+                                                                                         ("wimg", _p), ("wimg_bytes", _sz), ("persist_gran", _p), ("persist_status", _p)]
 
 
 # name -> argtypes (every symbol include/flowtron_hip.h declares; checked by tests/test_abi.py)
@@ -95,6 +95,8 @@ SIGNATURES = {
     "ft_colsum": ([_p, _p, _l, _i, _l, _p], _i),
     "ft_decode_workspace_bytes": ([_i, _i, _i, _i, _i], _sz),
     "ft_decode_wimg_bytes": ([_i, _i, _i], _sz),
+    "ft_decode_persist_gran_bytes": ([], _sz),
+    "ft_decode_debug_prof": ([_p], _i),
     "ft_decode_flow": ([C.POINTER(DecodeArgs), _p], _i),
     "ft_stft_mel": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "ft_stft_r8": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),

@@ -424,6 +424,419 @@ __global__ __launch_bounds__(256) void dec_fin_k(const DecodeDev P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent decode: ONE launch per flow (bf16 weight images, no cumulative attention / prior / forced alignment).
+// The staged chain above spends most of a frame in fixed costs -- ten kernel boundaries and, in every stage, a dependent
+// chain frame counter -> pointers -> data (~4 us per stage, ~52 us per frame and flow) -- not in streaming weights.  Here 256
+// workgroups (one per CU) walk the frames themselves; every stage's output vector is handed to all workgroups as 8-byte
+// {epoch, fp32} granules (one write-through store each, tag-checked sc1 loads, no fences -- cdna_hip_programming.md G16 R2,
+// ~0.6 us per hop across XCDs) and kept in LDS, and the bf16 weight rows of a stage are REQUESTED BEFORE the wait for its
+// input, so the weight stream (L2 / Infinity Cache) hides under the hand-off.
+//   workgroup c owns hidden units 4c .. 4c+3 of the three LSTMs (wave w = unit 4c + w, its four gate rows together; the
+//   cell states never leave the wave), rows 4c .. 4c+3 of the two dense layers, query rows {c, c+256, c+512}, text
+//   position(s) c (+256 ..) of the scores, context channels {c, c+256, c+512} and row c of the 1x1 conv.
+// Hops per frame: o -> S1 (inverse coupling of the previous frame + attention LSTM), h_att -> S2 (query), q -> S3a (scores),
+// scores -> S3b (softmax + context), ctx -> S4 (gate, LSTM 0), h0 -> S5 (LSTM 1), h1 -> S6, u1 -> S7, u2 -> S8 (conv).
+struct DecP {
+    DecodeDev d;
+    unsigned long long* gran;     // granule buffers, one per stage vector (offsets below, in granules)
+    unsigned* census;             // 8 counters behind the nine granule copies (zeroed with them)
+    int* status;
+    long timeout_ticks;
+    long* prof;                   // debug: [frame][12] wall-clock stamps of workgroup 0 (ft_decode_debug_prof), or null
+};
+enum { G_O = 0, G_HATT = 256, G_Q = 256 + 1024, G_SC = G_Q + 640, G_CTX = G_SC + 1024, G_H0 = G_CTX + 640, G_H1 = G_H0 + 1024,
+       G_U1 = G_H1 + 1024, G_U2 = G_U1 + 1024, G_TOTAL = G_U2 + 1024 };
+
+typedef __attribute__((address_space(1))) unsigned long long dgu64;
+typedef __attribute__((ext_vector_type(4))) unsigned int du32x4;
+constexpr int DEC_LAUX = 2;         // aux bits of the XCD-local gather loads: 2 = nt (as lstm_persist.hip's default), 16 = sc1
+
+__device__ __forceinline__ void publish(unsigned long long* g, unsigned epoch, float v) {
+    __hip_atomic_store((dgu64*)g, ((unsigned long long)epoch << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// into this XCD's copy: stays in its L2
+__device__ __forceinline__ void publish_local(unsigned long long* g, unsigned epoch, float v) {
+    __hip_atomic_store((dgu64*)g, ((unsigned long long)epoch << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Hand-off topology.  256 workgroups each polling a whole vector across the fabric is 2 MB of sc1 reads per pass -- measured,
+// that contention (not the weight stream) is what a stage costs: ~3.5 us per hop against 0.63 us for a lone poller
+// (scripts/exp/handoff_probe.hip).  So every vector crosses the fabric ONCE PER XCD: the 32 workgroups of an XCD (run-time census,
+// as lstm_persist.hip) each relay a 1/32 slice from the global copy (sc1 polls, 16 lanes) into their XCD's own copy with
+// workgroup-scope stores that stay in that XCD's L2, and all of them gather the whole vector from the local copy (~0.25 us).
+// Tags travel with the data, so a granule is only ever forwarded / consumed when it shows the epoch: no fences anywhere.
+struct Relay {
+    unsigned long long* glob;     // p.gran: the producers' copy (write-through stores)
+    unsigned long long* loc;      // this XCD's copy
+    int q;                        // rank of this workgroup inside its XCD, 0..31
+};
+
+// all 256 threads: granules [0, n) of stage vector `off` (epoch-tagged, n <= 1024) -> dst[0, n) in LDS.  false = timed out.
+// Granules [0, relay_lo) were produced INSIDE this XCD (stages every XCD computes for itself, below); [relay_lo, n) come from
+// the chip-wide producers through the relay (relay_lo even).
+__device__ __forceinline__ bool gather(const Relay& R, int off, int n, int relay_lo, unsigned epoch, float* dst, const DecP& p, long t_start) {
+    const int npad = (n + 1) & ~1;
+    bool ok_all = true;
+    if (relay_lo < n) {   // ---- relay: slice q of [relay_lo, n) of the global copy -> local copy; lane pairs of wave 0
+        const int S = 2 * ((n - relay_lo + 63) >> 6);
+        const int j = relay_lo + R.q * S + 2 * (int)threadIdx.x;
+        if ((int)threadIdx.x * 2 < S && j < n) {
+            __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(R.glob + off, 0, npad * 8, 0x00020000);
+            for (unsigned spins = 0;; ++spins) {
+                const du32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rg, j * 8, 0, 16);        // sc1: two granules
+                if (v[1] == epoch && (j + 1 >= n || v[3] == epoch)) {
+                    __hip_atomic_store((dgu64*)(R.loc + off + j), ((unsigned long long)v[1] << 32) | v[0], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (j + 1 < n)
+                        __hip_atomic_store((dgu64*)(R.loc + off + j + 1), ((unsigned long long)v[3] << 32) | v[2], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                    break;
+                }
+                if ((spins & 63) == 63 && (wall_clock64() - t_start > p.timeout_ticks ||
+                                           __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    ok_all = false;
+                    break;
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+    // ---- gather from the XCD-local copy: a thread owns granule pairs 2 tid and 2 tid + 512, re-reads both while stale
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(R.loc + off, 0, npad * 8, 0x00020000);
+    const int j0 = threadIdx.x * 2, j1 = j0 + 512;
+    bool need0 = j0 < n, need1 = j1 < n;
+    for (unsigned spins = 0; ok_all && (need0 | need1); ++spins) {
+        du32x4 v0, v1;
+        if (need0) v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, j0 * 8, 0, DEC_LAUX);
+        if (need1) v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, j1 * 8, 0, DEC_LAUX);
+        if (need0 && v0[1] == epoch && (j0 + 1 >= n || v0[3] == epoch)) {
+            dst[j0] = __uint_as_float(v0[0]);
+            if (j0 + 1 < n) dst[j0 + 1] = __uint_as_float(v0[2]);
+            need0 = false;
+        }
+        if (need1 && v1[1] == epoch && (j1 + 1 >= n || v1[3] == epoch)) {
+            dst[j1] = __uint_as_float(v1[0]);
+            if (j1 + 1 < n) dst[j1 + 1] = __uint_as_float(v1[2]);
+            need1 = false;
+        }
+        if ((spins & 63) == 63 && (wall_clock64() - t_start > p.timeout_ticks ||
+                                   __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            ok_all = false;
+            break;
+        }
+        asm volatile("" ::: "memory");
+    }
+    if (!ok_all && (threadIdx.x & 63) == 0) atomicExch(p.status, 1);
+    return __syncthreads_and(ok_all ? 1 : 0) != 0;
+}
+
+// R weight rows (bf16, K % 8 == 0) of one wave: `issue` requests every 16-byte piece (NL per lane and row) -- called BEFORE the
+// wait for the stage's input --, `dot` multiplies them with the fp32 activation vector in LDS.
+template <int R, int NL>
+struct WRows {
+    uint4 w[R][NL];
+    __device__ __forceinline__ void issue(const bf16_t* const (&row)[R], int K, int lane) {
+        const int K8 = K >> 3;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int kk = lane + 64 * j;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                w[r][j] = (kk < K8 && row[r]) ? reinterpret_cast<const uint4*>(row[r])[kk] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    __device__ __forceinline__ void dot(const float* x, int K, int lane, float (&acc)[R]) const {
+        const int K8 = K >> 3;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int kk = lane + 64 * j;
+            if (kk < K8) {
+                const float4 xa = x4[2 * kk], xb = x4[2 * kk + 1];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    // resident weights (dec_persist_k): an opaque copy keeps the bf16 -> fp32 unpacking INSIDE the frame loop;
+                    // hoisted, the unpacked forms double the live set (480 registers) and spill to scratch
+                    uint4 t = w[r][j];
+                    asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));
+                    acc[r] += dot8(t, xa, xb);
+                }
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ void cell_update(const float (&pre)[4], float& c, float& h) {
+    float ig, fg, gg, og, cn;
+    lstm_cell<true>(pre, c, ig, fg, gg, og, cn, h);           // v_exp / v_rcp forms (common.h): bf16 operand mode
+    c = cn;
+}
+__device__ __forceinline__ float sfloat(float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); }
+__device__ __forceinline__ float fast_tanh(float x) {
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.f * 1.4426950408889634f * x) + 1.f);
+}
+
+__global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
+    const DecodeDev& P = p.d;
+    constexpr int H = 1024, A = 640, M = 80, LMAX = 1024;
+    __shared__ __attribute__((aligned(16))) float s_prev[M + 16], s_hatt[H], s_cat[H + A], s_q[A], s_pr[LMAX], s_h0[H], s_h0n[H],
+        s_h1[H], s_h1n[H], s_u1[H], s_u2[H], s_o[2 * M + 16], s_v[A], s_gw[H + A];
+    __shared__ float s_red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = blockIdx.x;
+    const int u = c * 4 + wave;                                   // this wave's hidden unit / dense row
+    const int L = P.L, N = P.N;
+    const long t_start = wall_clock64();
+    __shared__ int s_slot[2];
+    if (tid == 0) {                                               // XCD census: which L2 this workgroup shares, and its rank there
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+        s_slot[0] = (int)(xcc & 7u);
+        s_slot[1] = (int)__hip_atomic_fetch_add(p.census + (xcc & 7u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int k = tid; k < H; k += 256) { s_hatt[k] = 0.f; s_h0[k] = 0.f; s_h1[k] = 0.f; }
+    __syncthreads();
+    Relay R;
+    R.glob = p.gran;
+    R.loc = p.gran + (size_t)G_TOTAL * (1 + __builtin_amdgcn_readfirstlane(s_slot[0]));
+    R.q = __builtin_amdgcn_readfirstlane(s_slot[1]);
+    if (R.q >= 32) {                                              // not 32 workgroups per XCD: not the machine this is for
+        if (tid == 0) atomicExch(p.status, 2);
+        return;
+    }
+    float c_att = 0.f, c_0 = 0.f, c_1 = 0.f;                      // cell states of unit u (lane 0 of the wave is the keeper)
+    int i = 0, done = 0;
+    const bf16_t* rows4[4];
+    auto gate_rows = [&](const bf16_t* W, int K) {                // the four gate rows of unit u
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rows4[g] = W + ((size_t)g * H + u) * K;
+    };
+    // ---- the flow's weights live in REGISTERS for all N frames: 53.7 MB of bf16 over 256 CUs x 4 waves = 205 KB per CU =
+    // ~240 VGPRs per lane (one wave per SIMD owns the whole 512-entry file); nothing is streamed per frame but the hand-offs
+    WRows<4, 1> wa_ih;  WRows<4, 2> wa_hh;  WRows<5, 2> wq;
+    WRows<4, 4> w0_ih;  WRows<4, 2> w0_hh;  WRows<4, 2> w1_ih, w1_hh;
+    WRows<1, 2> wd0, wd1;  WRows<2, 2> wcv;
+    // The small stages (query, scores, context, 1x1 conv) are computed by EVERY XCD for itself -- 8x redundant arithmetic on
+    // resident operands -- so their hand-offs never leave the XCD's L2 (~0.5 us instead of ~2.5 us through the fabric).
+    // Wave `slot` of the XCD's 128 waves takes query rows / context channels slot + 128 k, text positions slot + 128 k and
+    // conv rows slot, slot + 128.
+    const int slot = R.q * 4 + wave;
+    gate_rows(P.att_w_ih16, M); wa_ih.issue(rows4, M, lane);
+    gate_rows(P.att_w_hh16, H); wa_hh.issue(rows4, H, lane);
+    gate_rows(P.l0_w_ih16, H + A); w0_ih.issue(rows4, H + A, lane);
+    gate_rows(P.l0_w_hh16, H); w0_hh.issue(rows4, H, lane);
+    gate_rows(P.l1_w_ih16, H); w1_ih.issue(rows4, H, lane);
+    gate_rows(P.l1_w_hh16, H); w1_hh.issue(rows4, H, lane);
+    const bf16_t* r1[1];
+    {
+        const bf16_t* r5[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) r5[k] = P.w_query16 + (size_t)(slot + 128 * k) * H;
+        wq.issue(r5, H, lane);
+        const bf16_t* r2[2] = {P.conv_w16 + (size_t)slot * H, slot + 128 < 2 * M ? P.conv_w16 + (size_t)(slot + 128) * H : nullptr};
+        wcv.issue(r2, H, lane);
+    }
+    r1[0] = P.d0_w16 + (size_t)u * H;  wd0.issue(r1, H, lane);
+    r1[0] = P.d1_w16 + (size_t)u * H;  wd1.issue(r1, H, lane);
+    float b_att[4], b_0[4], b_1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const size_t r = (size_t)g * H + u;
+        // wave-uniform: scalar registers
+        b_att[g] = sfloat(P.att_b_ih[r] + P.att_b_hh[r]); b_0[g] = sfloat(P.l0_b_ih[r] + P.l0_b_hh[r]); b_1[g] = sfloat(P.l1_b_ih[r] + P.l1_b_hh[r]);
+    }
+    const float b_d0 = sfloat(P.d0_b[u]), b_d1 = sfloat(P.d1_b[u]);
+    const float b_cv[2] = {sfloat(P.conv_b[slot]), sfloat(slot + 128 < 2 * M ? P.conv_b[slot + 128] : 0.f)};
+    // frame-invariant attention operands of this wave: key row / v (text position c + 256 wave), value column (channel qrow),
+    // the gate row (workgroup 0)
+    // resident: key rows of positions slot, slot + 128 and value columns over l < 256 (texts up to 256 symbols never touch
+    // memory for them); longer texts read the rest from the XCD's L2 each frame
+    constexpr int KRES = 2, VRES = 4;
+    float k_row[KRES][A / 64], v_col[5][VRES];
+#pragma unroll
+    for (int j = 0; j < A / 64; ++j) {
+#pragma unroll
+        for (int k = 0; k < KRES; ++k) k_row[k][j] = slot + 128 * k < L ? P.K[(size_t)(slot + 128 * k) * A + lane + 64 * j] : 0.f;
+    }
+    for (int k = tid; k < A; k += 256) s_v[k] = P.v[k];
+    for (int k = tid; k < H + A; k += 256) s_gw[k] = (c == 0 && P.gate_w) ? P.gate_w[k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int j = 0; j < VRES; ++j) v_col[k][j] = lane + 64 * j < L ? P.V[(size_t)(lane + 64 * j) * A + slot + 128 * k] : 0.f;
+    const float gate_b = (c == 0 && P.gate_w) ? P.gate_b[0] : 0.f;
+    const bool prof = p.prof != nullptr && c == 0 && tid == 0;
+    auto stamp = [&](int k) { if (prof && i < 512) p.prof[(size_t)i * 12 + k] = wall_clock64(); };
+    for (;; ++i) {
+        const unsigned e0 = (unsigned)i * 16u;                    // epochs of frame i: e0 + 1 .. e0 + 9
+        stamp(0);
+        // ================= S1: inverse coupling of frame i-1 (needs its conv output o), then the attention LSTM of frame i
+        if (i > 0) {
+            const float z = tid < M ? P.residual[(size_t)(i - 1) * M + tid] : 0.f;     // requested before the wait
+            if (!gather(R, G_O, 2 * M + 1, 2 * M, e0 - 16u + 9u, s_o, p, t_start)) return;
+            stamp(1);
+            done = s_o[2 * M] != 0.f;
+            if (tid < M) {
+                const float x = (z - s_o[M + tid]) / expf(s_o[tid]);
+                s_prev[tid] = x;
+                if (c == 0) P.mel_out[(size_t)(i - 1) * M + tid] = x;
+            }
+            if (c == 0 && tid == 0) P.n_done_dev[0] = i;
+        } else if (tid < M) s_prev[tid] = 0.f;
+        __syncthreads();
+        if (i >= N || done) break;
+        {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            wa_ih.dot(s_prev, M, lane, acc);
+            wa_hh.dot(s_hatt, H, lane, acc);
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] = wave_sum(acc[g]) + b_att[g];
+            float h;
+            cell_update(pre, c_att, h);
+            if (lane == 0) publish(p.gran + G_HATT + u, e0 + 1u, h);
+        }
+        // ================= S2: query rows c, c + 256, c + 512 (waves 0..2)
+        stamp(2);
+        if (!gather(R, G_HATT, H, 0, e0 + 1u, s_cat, p, t_start)) return;       // new h_att = first part of [h_att ; ctx]
+        stamp(3);
+        {
+            float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            wq.dot(s_cat, H, lane, acc);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const float v = wave_sum(acc[k]);
+                if (lane == 0) publish_local(R.loc + G_Q + slot + 128 * k, e0 + 2u, v);
+            }
+        }
+        // ================= S3a: scores of text positions c, c + 256, ..  (wave w takes position c + 256 w)
+        if (!gather(R, G_Q, A, A, e0 + 2u, s_q, p, t_start)) return;
+        stamp(4);
+#pragma unroll
+        for (int k = 0; k < KRES; ++k)
+            if (slot + 128 * k < L) {
+                float sc = 0.f;
+#pragma unroll
+                for (int j = 0; j < A / 64; ++j) sc += s_v[lane + 64 * j] * fast_tanh(s_q[lane + 64 * j] + k_row[k][j]);
+                sc = wave_sum(sc);
+                if (lane == 0) publish_local(R.loc + G_SC + slot + 128 * k, e0 + 3u, sc * P.inv_temp);
+            }
+        for (int l = slot + 128 * KRES; l < L; l += 128) {         // texts longer than 256 symbols
+            float sc = 0.f;
+#pragma unroll
+            for (int j = 0; j < A / 64; ++j) sc += s_v[lane + 64 * j] * fast_tanh(s_q[lane + 64 * j] + P.K[(size_t)l * A + lane + 64 * j]);
+            sc = wave_sum(sc);
+            if (lane == 0) publish_local(R.loc + G_SC + l, e0 + 3u, sc * P.inv_temp);
+        }
+        // ================= S3b: softmax over L (every workgroup), context channels c, c + 256, c + 512
+        if (!gather(R, G_SC, L, L, e0 + 3u, s_pr, p, t_start)) return;
+        stamp(5);
+        {
+            float m = -INFINITY;
+            for (int l = tid; l < L; l += 256) m = fmaxf(m, s_pr[l]);
+            m = wave_max(m);
+            if (lane == 0) s_red[wave] = m;
+            __syncthreads();
+            m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+            float sum = 0.f;
+            for (int l = tid; l < L; l += 256) { const float e = expf(s_pr[l] - m); s_pr[l] = e; sum += e; }
+            sum = wave_sum(sum);
+            if (lane == 0) s_red[4 + wave] = sum;
+            __syncthreads();
+            sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+            for (int l = tid; l < L; l += 256) {
+                const float pl = s_pr[l] / sum;
+                s_pr[l] = pl;
+                if (c == 0) P.attn_out[(size_t)i * L + l] = pl;
+            }
+            __syncthreads();
+            float pl[VRES];
+#pragma unroll
+            for (int j = 0; j < VRES; ++j) pl[j] = lane + 64 * j < L ? s_pr[lane + 64 * j] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                float cx = 0.f;
+#pragma unroll
+                for (int j = 0; j < VRES; ++j) cx += pl[j] * v_col[k][j];
+                for (int l = lane + 64 * VRES; l < L; l += 64) cx += s_pr[l] * P.V[(size_t)l * A + slot + 128 * k];
+                cx = wave_sum(cx);
+                if (lane == 0) publish_local(R.loc + G_CTX + slot + 128 * k, e0 + 4u, cx);
+            }
+        }
+        // ================= S4: LSTM layer 0 (input [h_att ; ctx], recurrent h0); workgroup 0 also evaluates the gate
+        if (!gather(R, G_CTX, A, A, e0 + 4u, s_cat + H, p, t_start)) return;
+        stamp(6);
+        float gate_done = 0.f;
+        if (c == 0 && P.gate_w) {                                  // flowtron.py:823-826 (uniform branch: all of workgroup 0)
+            float g = 0.f;
+            for (int k = tid; k < H + A; k += 256) g += s_gw[k] * s_cat[k];
+            g = wave_sum(g);
+            if (lane == 0) s_red[wave] = g;
+            __syncthreads();
+            const float gs = gate_b + s_red[0] + s_red[1] + s_red[2] + s_red[3];
+            gate_done = (1.f / (1.f + expf(-gs)) > P.gate_threshold) ? 1.f : 0.f;
+        }
+        {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            w0_ih.dot(s_cat, H + A, lane, acc);
+            w0_hh.dot(s_h0, H, lane, acc);
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] = wave_sum(acc[g]) + b_0[g];
+            float h;
+            cell_update(pre, c_0, h);
+            if (lane == 0) publish(p.gran + G_H0 + u, e0 + 5u, h);
+        }
+        // ================= S5: LSTM layer 1
+        if (!gather(R, G_H0, H, 0, e0 + 5u, s_h0n, p, t_start)) return;
+        stamp(7);
+        {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            w1_ih.dot(s_h0n, H, lane, acc);
+            w1_hh.dot(s_h1, H, lane, acc);
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] = wave_sum(acc[g]) + b_1[g];
+            float h;
+            cell_update(pre, c_1, h);
+            if (lane == 0) publish(p.gran + G_H1 + u, e0 + 6u, h);
+        }
+        // ================= S6 / S7: dense + tanh, row u
+        if (!gather(R, G_H1, H, 0, e0 + 6u, s_h1n, p, t_start)) return;
+        stamp(8);
+        {
+            float acc[1] = {0.f};
+            wd0.dot(s_h1n, H, lane, acc);
+            const float v = fast_tanh(wave_sum(acc[0]) + b_d0);
+            if (lane == 0) publish(p.gran + G_U1 + u, e0 + 7u, v);
+        }
+        if (!gather(R, G_U1, H, 0, e0 + 7u, s_u1, p, t_start)) return;
+        stamp(9);
+        {
+            float acc[1] = {0.f};
+            wd1.dot(s_u1, H, lane, acc);
+            const float v = fast_tanh(wave_sum(acc[0]) + b_d1);
+            if (lane == 0) publish(p.gran + G_U2 + u, e0 + 8u, v);
+        }
+        // ================= S8: 1x1 conv row c (wave 0 of workgroups c < 2M); workgroup 0 appends the stop flag
+        if (!gather(R, G_U2, H, 0, e0 + 8u, s_u2, p, t_start)) return;
+        stamp(10);
+        {
+            float acc[2] = {0.f, 0.f};
+            wcv.dot(s_u2, H, lane, acc);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float v = wave_sum(acc[k]) + b_cv[k];
+                if (lane == 0 && slot + 128 * k < 2 * M) publish_local(R.loc + G_O + slot + 128 * k, e0 + 9u, v);
+            }
+        }
+        if (c == 0 && tid == 0) publish(p.gran + G_O + 2 * M, e0 + 9u, gate_done);
+        // roll the recurrent inputs: new h_att / h0 / h1 become the previous ones
+        for (int k = tid; k < H; k += 256) { s_hatt[k] = s_cat[k]; s_h0[k] = s_h0n[k]; s_h1[k] = s_h1n[k]; }
+        __syncthreads();
+    }
+}
+
 struct Layout {
     size_t off_dev, off_state, n_state, off_ctl, total;
     size_t h_att, c_att, h0, c0, h1, c1, q, ctx, u1, u2, prev, cumm, prev_attn, keyin, Kdyn, escore, obuf;
@@ -498,6 +911,13 @@ void wimg_counts(int H, int A, int M, size_t (&n)[10]) {
 }
 }  // namespace
 
+// the producers' copy + one copy per XCD + the census counters
+extern "C" size_t ft_decode_persist_gran_bytes(void) { return (size_t)G_TOTAL * 8 * 9 + 64; }
+static long* g_decode_prof = nullptr;
+// debug hook: device buffer [512][12] int64 that subsequent persistent decode launches fill with per-frame stage stamps
+// (100 MHz wall clock) of workgroup 0; NULL switches it off
+extern "C" int ft_decode_debug_prof(void* dev_buf) { g_decode_prof = reinterpret_cast<long*>(dev_buf); return FT_OK; }
+
 extern "C" size_t ft_decode_wimg_bytes(int H, int A, int M) {
     size_t n[10], tot = 0;
     wimg_counts(H, A, M, n);
@@ -569,6 +989,24 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
     const DecodeDev& dP = h;       // passed to every stage kernel by value (kernarg segment)
     FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_ctx_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
+    // persistent path: bf16 images, the default model geometry, plain attention, every workgroup resident on its own CU
+    if (a->wimg && a->persist_status && !cumm && !a->prior && !a->forced && a->H == 1024 && a->A == 640 && a->M == 80 && a->L <= 1024) {
+        static int cus = -1;
+        if (cus < 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+        }
+        if (cus >= 256) {
+            FT_CHECK_ARG(a->persist_gran && reinterpret_cast<uintptr_t>(a->persist_gran) % 16 == 0);
+            FT_CHECK_HIP(hipMemsetAsync(a->persist_gran, 0, ft_decode_persist_gran_bytes(), st));   // tags = 0 (epochs start at 1)
+            unsigned long long* gr = reinterpret_cast<unsigned long long*>(a->persist_gran);
+            DecP dp{h, gr, reinterpret_cast<unsigned*>(gr + (size_t)G_TOTAL * 9), a->persist_status, 100000000L / 2, g_decode_prof};
+            hipLaunchKernelGGL(dec_persist_k, dim3(256), dim3(256), 0, st, dp);
+            FT_CHECK_LAUNCH();
+            return FT_OK;
+        }
+    }
     if (!a->use_graph) {
         for (int i = 0; i < a->N; ++i) enqueue_frame(dP, a->H, a->A, a->L, a->M, cumm, st);
         FT_CHECK_LAUNCH();

@@ -323,15 +323,25 @@ class AR_Step(nn.Module):
             L.ptr(cc.location_conv_hidden.conv.weight) if cumm else None, L.ptr(cc.location_conv_hidden.conv.bias) if cumm else None,
             L.ptr(cc.location_conv_out.conv.weight) if cumm else None, L.ptr(cc.location_conv_out.conv.bias) if cumm else None,
             L.ptr(att.key.linear_layer.weight) if cumm else None, L.ptr(enc2d) if cumm else None, E,
-            L.ptr(prior_rows), L.ptr(forced_rows), None, 0)
+            L.ptr(prior_rows), L.ptr(forced_rows), None, 0, None, None)
+        persist = None
         if L.mfma_mode() == L.FT_BF16:          # bf16 operand mode: stream bf16 images of the weights (half the bytes per frame)
             nb = L.lib().ft_decode_wimg_bytes(H, A, M)
             wimg = bufs.get("wimg")
             if wimg is None or wimg.numel() < nb:
                 wimg = bufs["wimg"] = torch.empty(nb, device=dev, dtype=torch.uint8)
             args.wimg, args.wimg_bytes = L.ptr(wimg), wimg.numel()
+            if os.environ.get("FLOWTRON_DECODE_PERSIST", "1") != "0" and ops.persist_usable(dev):
+                # one persistent launch per flow (csrc/decode.hip dec_persist_k) where its geometry applies
+                gran = bufs.get("gran")
+                if gran is None:
+                    gran = bufs["gran"] = torch.empty(L.lib().ft_decode_persist_gran_bytes(), device=dev, dtype=torch.uint8)
+                persist = ops.persist_status(dev)
+                args.persist_gran, args.persist_status = L.ptr(gran), L.ptr(persist)
         L.check(L.lib().ft_decode_flow(C.byref(args), L.stream()), "ft_decode_flow")
         n = int(n_done.item()) if has_gate else N          # single host read per flow (the reference syncs every frame)
+        if persist is not None:
+            ops.check_persist_status()
         del keep
         mel = mel_out[:n].clone().reshape(n, 1, M)          # the persistent buffers are overwritten by the next call
         attn_all = attn_out[:n].clone()

@@ -421,6 +421,16 @@ def _persist_selftest(device, ng):
     return ok
 
 
+def persist_usable(device):
+    """True if the persistent kernels passed their self-test on this device (256 co-resident workgroups, XCD census)."""
+    if not L.lib().ft_lstm_persist_supported(8, 1024):
+        return False
+    st = _persist_state(torch.device(device))
+    if st.usable is None:
+        st.usable = _persist_selftest(torch.device(device), int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "1")) or 1)
+    return bool(st.usable)
+
+
 def lstm_persist_groups(B, H, reverse, mode, device=None):
     """transport / group code of the persistent recurrence kernels for this shape (0 = use the launch-per-step kernels).
     FLOWTRON_LSTM_PERSIST: 0 = off, 1 (default) = 8 XCD-local groups, 8 | 4 = placement-independent fabric transport."""

@@ -265,9 +265,17 @@ typedef struct {
      * per call to bf16 images and the per-frame GEMVs stream those (bf16 operand mode: half the bytes per frame; fp32
      * activations and accumulation).  NULL = stream the fp32 weights (parity mode). */
     void* wimg; size_t wimg_bytes;
+    /* optional: hand-off buffer of ft_decode_persist_gran_bytes() bytes + a device status word (zeroed by the caller once).  When
+     * given together with wimg, and the flow has the default geometry (H 1024, A 640, M 80, L <= 1024, no cumulative attention /
+     * prior / forced alignment) on a 256-CU device, the WHOLE flow runs as one persistent launch (256 workgroups hand each
+     * stage's output vector to one another through tag-checked granules) instead of ten launches per frame.  *persist_status
+     * becomes non-zero if a hand-off wait times out; the caller must check it before trusting the output. */
+    void* persist_gran; int32_t* persist_status;
 } ft_decode_args;
 size_t ft_decode_workspace_bytes(int L, int H, int A, int M, int E);
 size_t ft_decode_wimg_bytes(int H, int A, int M);
+size_t ft_decode_persist_gran_bytes(void);
+int ft_decode_debug_prof(void* dev_buf);   /* debug: [512][12] int64 stage stamps of the persistent decode, NULL = off */
 int ft_decode_flow(const ft_decode_args* a, void* stream);
 
 /* ---- STFT magnitude + mel + log (audio_processing.py:117-134, 207-235) -------

@@ -17,7 +17,7 @@ grep '^{' "$OUT/bench_under_rocprof.log" | tail -1 > "$OUT/bench_line_under_rocp
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
   TAG=$(echo $C | cut -d' ' -f1)
   for WL in bench stft; do
-    if [ $WL = bench ]; then CMD="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline"; else CMD="python $REPO/scripts/prof_stft.py"; fi
+    if [ $WL = bench ]; then CMD="env BENCH_INFER_FRAMES=64 BENCH_INFER_CALLS=1 python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline"; else CMD="python $REPO/scripts/prof_stft.py"; fi
     rm -rf /tmp/pmc_run
     timeout 600 rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_run -o pmc -- $CMD > "$OUT/pmc_${TAG}_${WL}.log" 2>&1
     echo "rocprof pmc [$C] $WL exit $?" >> "$OUT/pmc_${TAG}_${WL}.log"

@@ -34,7 +34,7 @@ def make_config(root, model_overrides=None, train_overrides=None, data_overrides
     """a config.json with the reference's schema (config.json:1-67) pointing at the synthetic data set."""
     tr, va = make_dataset(root)
     cfg = {
-        "train_config": {"output_directory": os.path.join(root, "out"), "epochs": 1, "optim_algo": "RAdam", "learning_rate": 1e-3,
+        "train_config": {"output_directory": os.path.join(root, "out"), "epochs": 100, "optim_algo": "RAdam", "learning_rate": 1e-3,
                          "weight_decay": 1e-6, "grad_clip_val": 1, "sigma": 1.0, "iters_per_checkpoint": 2, "batch_size": 4,
                          "seed": 1234, "checkpoint_path": "", "ignore_layers": [], "finetune_layers": [],
                          "include_layers": ["speaker", "encoder", "embedding"], "warmstart_checkpoint_path": "",

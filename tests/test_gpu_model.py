@@ -101,14 +101,15 @@ def test_infer_vs_reference_golden(name, use_graph):
         assert mad(mel_f, mel) < 1e-5
 
 
-@pytest.mark.parametrize("use_graph", ["0", "1"])
-def test_infer_bf16_weight_images_track_fp32_full_width(use_graph):
-    """bf16 operand mode decodes from bf16 IMAGES of the weights (csrc/decode.hip: one workgroup per hidden unit, wave per gate
-    row): full-width 2-flow model, 48 frames, against the fp32-weight decode of the same kernels' parity mode (which the
-    real-reference goldens pin).  Weight rounding 2^-9 relative through ~100 recurrent steps: mel within 5e-2 (values span
-    ~[-12, 2]), attention rows within 2e-2, and the fp32-mode run itself reproduces with and without the hipGraph."""
+def test_infer_bf16_weight_images_and_persistent_decode_track_fp32_full_width():
+    """bf16 operand mode decodes from bf16 IMAGES of the weights, by default as ONE persistent launch per flow (csrc/decode.hip
+    dec_persist_k: 256 workgroups hand every stage vector to one another through tag-checked granules), else as the staged
+    launch chain (one workgroup per hidden unit, wave per gate row).  Full-width 2-flow model, 48 frames: both against the
+    fp32-weight decode of the parity mode (which the real-reference goldens pin) -- weight rounding 2^-9 relative through
+    ~100 recurrent steps: mel within 5e-2 (values span ~[-12, 2]), attention rows within 2e-2 -- and against each other
+    (same bf16 weights, different summation order: 2e-3).  The gate stop count must agree between all three."""
+    from flowtron_amd import ops
     from oracle import synth
-    os.environ["FLOWTRON_DECODE_GRAPH"] = use_graph
     cfg = dict(synth.DEFAULT_MODEL_CONFIG, n_text=60)
     rs = np.random.RandomState(5)
     residual = torch.from_numpy(rs.standard_normal((1, 80, 48)).astype(np.float32)).cuda() * 0.5
@@ -116,17 +117,23 @@ def test_infer_bf16_weight_images_track_fp32_full_width(use_graph):
     spk = torch.zeros(1, dtype=torch.long).cuda()
     res = {}
     try:
-        for mode in ("f32", "bf16"):
+        for name, mode, persist in (("f32", "f32", "0"), ("staged", "bf16", "0"), ("persist", "bf16", "1")):
+            os.environ["FLOWTRON_DECODE_PERSIST"] = persist
             m, _ = build(cfg, 17, mode)
-            res[mode] = m.infer(residual, spk, txt, gate_threshold=1.0)
+            res[name] = m.infer(residual, spk, txt, gate_threshold=1.0)
+            res[name + "_gated"] = m.infer(residual, spk, txt, gate_threshold=0.45)[0].shape[2]
+            ops.check_persist_status()
     finally:
         os.environ["FLOWTRON_MFMA"] = "f32"
-        os.environ["FLOWTRON_DECODE_GRAPH"] = "1"
-    assert res["bf16"][0].shape == res["f32"][0].shape == (1, 80, 48)
-    assert torch.isfinite(res["bf16"][0]).all()
-    assert mad(res["bf16"][0], res["f32"][0]) < 5e-2, mad(res["bf16"][0], res["f32"][0])
-    for a16, a32 in zip(res["bf16"][1], res["f32"][1]):
-        assert mad(torch.cat(a16), torch.cat(a32)) < 2e-2
+        os.environ.pop("FLOWTRON_DECODE_PERSIST", None)
+    for name in ("staged", "persist"):
+        assert res[name][0].shape == res["f32"][0].shape == (1, 80, 48)
+        assert torch.isfinite(res[name][0]).all()
+        assert mad(res[name][0], res["f32"][0]) < 5e-2, (name, mad(res[name][0], res["f32"][0]))
+        for a16, a32 in zip(res[name][1], res["f32"][1]):
+            assert mad(torch.cat(a16), torch.cat(a32)) < 2e-2
+    assert mad(res["persist"][0], res["staged"][0]) < 2e-3, mad(res["persist"][0], res["staged"][0])
+    assert res["persist_gated"] == res["staged_gated"] == res["f32_gated"]
 
 
 def test_cfg1_full_size_vs_reference_golden():
