@@ -38,13 +38,15 @@ MODEL_CONFIG = {   # reference config.json:49-66 (LJS defaults)
 HOP, SR = 256, 22050
 
 
-def synth_batch(B, seed, t_max=862, l_max=187, n_text=185):
+def synth_batch(B, seed, t_max=862, l_max=187, n_text=185, l_min=12, n_speakers=1, chars_per_frame=1 / 5.5):
     """LJSpeech-shaped synthetic batch: out_lens ~ clip(N(566,190),100,862), text length ~
-    frames/5.5, sorted by text length (data.py:200-202), log-mel-range values, beta-binomial attention prior."""
+    frames/5.5, sorted by text length (data.py:200-202), log-mel-range values, beta-binomial attention prior.
+    SURVEY 8d configs 3 / 5 (LibriTTS): n_speakers = 123 with uniform speaker ids, text lengths clipped to [5, 237]
+    (chars_per_frame raised so the batch really reaches L = 237: two 128-column score tiles, 475 CTC states)."""
     rs = np.random.RandomState(seed)
     out = np.clip(np.round(rs.normal(566, 190, B)), 100, t_max).astype(int)
     out[0] = t_max
-    inn = np.clip(np.round(out / 5.5), 12, l_max).astype(int)
+    inn = np.clip(np.round(out * chars_per_frame), l_min, l_max).astype(int)
     order = np.argsort(-inn, kind="stable")
     out, inn = out[order], inn[order]
     T, L = int(out.max()), int(inn.max())
@@ -59,7 +61,8 @@ def synth_batch(B, seed, t_max=862, l_max=187, n_text=185):
         text[b, :l] = rs.randint(0, n_text, size=l)
         gate[b, t - 1:] = 1.0
     return dict(mel=torch.from_numpy(mel), text=torch.from_numpy(text), gate=torch.from_numpy(gate),
-                speaker_ids=torch.zeros(B, dtype=torch.long), in_lens=torch.from_numpy(inn.astype(np.int64)),
+                speaker_ids=torch.from_numpy(rs.randint(0, n_speakers, size=B).astype(np.int64)) if n_speakers > 1
+                else torch.zeros(B, dtype=torch.long), in_lens=torch.from_numpy(inn.astype(np.int64)),
                 out_lens=torch.from_numpy(out.astype(np.int64)))
 
 
@@ -166,7 +169,7 @@ def lstm2_step_roofline(B, H, T):
             "bytes_per_launch": bytes_per_launch}
 
 
-def persist_roofline(B, H, T, lens_cpu):
+def persist_roofline(B, H, T, lens_cpu, mode=1):
     """Live timing of the dominant kernels of the step when the persistent recurrence path is active (csrc/lstm_persist.hip:
     ONE launch per sequence; six such launches per flow per step -- attention LSTM + the two decoder layers, forward and
     backward): HIP events on the launch stream around one sequence of the bench's own shape and lengths.  Algorithmic HBM
@@ -191,14 +194,14 @@ def persist_roofline(B, H, T, lens_cpu):
     ng = int(os.environ.get("FLOWTRON_LSTM_PERSIST", "1"))
     lib = L.lib()
     runs = {
-        "lstm_persist_fwd_k": lambda: L.check(lib.ft_lstm_persist_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
+        "lstm_persist_fwd_k": lambda: L.check(L.op16("ft_lstm_persist_fwd", mode)(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
                                                                         L.ptr(wp), L.ptr(st), T, B, H, ng, L.stream()), "persist fwd"),
-        "lstm_persist_bwd_k": lambda: L.check(lib.ft_lstm_persist_bwd(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
+        "lstm_persist_bwd_k": lambda: L.check(L.op16("ft_lstm_persist_bwd", mode)(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
                                                                         L.ptr(wp), L.ptr(st), T, B, H, ng, L.stream()), "persist bwd"),
         "lstm_fwd_step": lambda: L.check(lib.ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(ws),
-                                                              T, B, H, 0, 1, L.stream()), "step fwd"),
+                                                              T, B, H, 0, mode, L.stream()), "step fwd"),
         "lstm_bwd_step_bf16": lambda: L.check(lib.ft_lstm_seq_bwd(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
-                                                                   L.ptr(ws), T, B, H, 0, 1, L.stream()), "step bwd"),
+                                                                   L.ptr(ws), T, B, H, 0, mode, L.stream()), "step bwd"),
     }
     us = {}
     for name, fn in runs.items():
@@ -364,7 +367,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
-    ap.add_argument("--mfma", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--mfma", default=None, choices=["bf16", "f16", "f32"], help="MFMA operand type (default: the config's)")
+    ap.add_argument("--config", default="ljs", choices=["ljs", "libritts", "libritts_fp16"],
+                    help="ljs = BASELINE configs[1] (the headline line); libritts = configs[2] (123 speakers, L <= 237, bf16); "
+                         "libritts_fp16 = configs[4] (fp16 operands + GradScaler, no attention prior)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
     args = ap.parse_args()
@@ -374,7 +380,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
     assert torch.cuda.is_available(), "bench.py needs an MI355X: the product path has no CPU fallback"
+    if args.mfma is None:
+        args.mfma = "f16" if args.config == "libritts_fp16" else "bf16"
     os.environ["FLOWTRON_MFMA"] = args.mfma
+    libri = args.config != "ljs"
+    use_prior = args.config != "libritts_fp16"
+    model_config = dict(MODEL_CONFIG, n_speakers=123) if libri else dict(MODEL_CONFIG)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "6000")
     torch.cuda.set_device(local_rank)
@@ -391,7 +402,7 @@ def main():
             ftdist.init_distributed(rank, world, "nccl", None)
 
     torch.manual_seed(1234)
-    model = flowtron.Flowtron(**MODEL_CONFIG)
+    model = flowtron.Flowtron(**model_config)
     init_weights(model, 1234)
     model = model.cuda().train()
     criterion = flowtron.FlowtronLoss(sigma=1.0, gm_loss=False, gate_loss=True, use_ctc_loss=True, ctc_loss_weight=0.01,
@@ -400,25 +411,36 @@ def main():
     if world > 1:
         model = ftdist.apply_gradient_allreduce(model)
 
-    batch_cpu = synth_batch(args.batch, 1234 + 7 + rank)
+    if libri:
+        batch_cpu = synth_batch(args.batch, 1234 + 7 + rank, l_max=237, l_min=5, n_speakers=123, chars_per_frame=1 / 3.6)
+    else:
+        batch_cpu = synth_batch(args.batch, 1234 + 7 + rank)
     T, Lk = batch_cpu["mel"].shape[2], batch_cpu["text"].shape[1]
-    prior_cpu = beta_binomial_prior_batch(batch_cpu["in_lens"], batch_cpu["out_lens"], T, Lk)
     b = {k: v.cuda() for k, v in batch_cpu.items()}
-    prior = prior_cpu.cuda()
+    prior = beta_binomial_prior_batch(batch_cpu["in_lens"], batch_cpu["out_lens"], T, Lk).cuda() if use_prior else None
     frames_rank = int(batch_cpu["out_lens"].sum())
+    # fp16 operands: the reference's AMP step (train.py:292-331) -- GradScaler around backward, unscale_, clip, scaler.step
+    scaler = torch.amp.GradScaler("cuda", enabled=args.mfma == "f16")
 
     def step():
         optimizer.zero_grad()
         out = model(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], prior)
         nll, gl, ctc = criterion(out, b["gate"], b["in_lens"], b["out_lens"])
         loss = nll + gl + criterion.ctc_loss_weight * ctc
-        loss.backward()
-        optimizer.clip_grad_norm_(1.0)
-        optimizer.step()
+        if scaler.is_enabled():
+            scaler.scale(loss).backward()
+            scaler.unscale_(optimizer)
+            optimizer.clip_grad_norm_(1.0)
+            scaler.step(optimizer)
+            scaler.update()
+        else:
+            loss.backward()
+            optimizer.clip_grad_norm_(1.0)
+            optimizer.step()
         return loss
 
     hip_path = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "ljs":
         # parity of the benchmarked dtype: the HIP path on the oracle's bounded sample, with the initial weights (before any
         # update), dropout off like the oracle; the cpu_baseline worker compares (it holds the oracle's gradients)
         try:
@@ -473,20 +495,24 @@ def main():
             "metric": "mel-frames/sec training (2-flow, 80-mel)", "value": round(frames_all * args.steps / dt, 1),
             "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.mfma == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 2-flow LJS config.json model, per-GPU batch %d, T_max=%d, L_max=%d, "
-                                   "attn-prior + CTC on, fwd+loss+bwd+clip+RAdam%s" % (args.batch, T, Lk, ", 1 flat RCCL all-reduce/step" if world > 1 else ""),
+            "vs_baseline": None, "dtype": args.mfma, "data": "synthetic",
+            "config": {"workload": "%s, per-GPU batch %d, T_max=%d, L_max=%d, %s + CTC on, fwd+loss+bwd+%sclip+RAdam%s"
+                                   % ({"ljs": "BASELINE configs[1]: 2-flow LJS config.json model",
+                                       "libritts": "BASELINE configs[2]: 2-flow LibriTTS model (123 speakers)",
+                                       "libritts_fp16": "BASELINE configs[4]: 2-flow LibriTTS model (123 speakers), fp16 operands + GradScaler"}[args.config],
+                                      args.batch, T, Lk, "attn-prior" if use_prior else "no attn-prior",
+                                      "unscale+" if scaler.is_enabled() else "", ", 1 flat RCCL all-reduce/step" if world > 1 else ""),
                        "global_batch": args.batch * world, "valid_frames_per_step": int(frames_all),
                        "padded_frames_per_step": args.batch * T * world, "parallelism": "dp%d" % world,
                        "mfma_operands": args.mfma, "storage": "fp32", "final_loss": round(loss_val, 5)},
         }
-        mode = L.FT_BF16 if args.mfma == "bf16" else L.FT_F32
+        mode = {"bf16": L.FT_BF16, "f16": L.FT_F16, "f32": L.FT_F32}[args.mfma]
         log("roofline kernel timing ...")
         try:
             from flowtron_amd import ops as _ops
             if _ops.lstm_persist_groups(args.batch, MODEL_CONFIG["n_hidden"], False, mode, torch.device("cuda", torch.cuda.current_device())):
                 # dominant kernels of the step: the persistent recurrences (backward first: 6 launches per flow, ~60 % of the step)
-                res["roofline"], res["roofline_second_kernel"] = persist_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, batch_cpu["out_lens"])
+                res["roofline"], res["roofline_second_kernel"] = persist_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, batch_cpu["out_lens"], mode)
             elif _ops.lstm2_supported(args.batch, MODEL_CONFIG["n_hidden"], mode):
                 single = lstm_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, mode)
                 # dominant kernel of the step: the two-layer wavefront launch; the single-layer step kernel (attention LSTM,
@@ -501,7 +527,7 @@ def main():
         if isinstance(res.get("roofline"), dict) and "error" not in res["roofline"]:
             res["roofline"]["step_mfma_frac"] = round(res["value"] / world * 325e6 / 2.5e15, 5)
             res["roofline"]["step_mfma_tflops"] = round(res["value"] / world * 325e6 / 1e12, 2)
-        if world == 1 and not args.no_infer:
+        if world == 1 and not args.no_infer and args.config == "ljs":
             try:
                 log("inference RTF ...")
                 model.eval()
@@ -520,7 +546,7 @@ def main():
                     tis.append(time.perf_counter() - t1)
                 ti = sorted(tis)[len(tis) // 2]
                 n_fl = MODEL_CONFIG["n_flows"]
-                wbytes = 26838656 * (2 if args.mfma == "bf16" else 4)   # weights streamed per frame per flow (bf16 images in bf16 mode)
+                wbytes = 26838656 * (2 if args.mfma in ("bf16", "f16") else 4)   # weights streamed per frame per flow (bf16 images in bf16 mode)
                 ach = n_fl * wbytes * mel.shape[2] / ti / 1e9
                 res["infer"] = {"frames": int(mel.shape[2]), "seconds": round(ti, 5), "seconds_min": round(min(tis), 5),
                                 "seconds_max": round(max(tis), 5), "calls": len(tis), "frames_per_s": round(mel.shape[2] / ti, 1),
@@ -529,10 +555,10 @@ def main():
                                 "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
                                              "frac": round(ach / 8000.0, 4), "bytes_per_frame_per_flow": wbytes},
                                 "config": "2-flow LJS, B=1, L=69, sigma=0.5, %s weights, gate disabled, median of %d calls"
-                                          % ("bf16 images of the" if args.mfma == "bf16" else "fp32", len(tis))}
+                                          % ("bf16 images of the" if args.mfma in ("bf16", "f16") else "fp32", len(tis))}
             except Exception as e:
                 res["infer"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "ljs":
             try:
                 log("cpu baseline (oracle, bounded sample) ...")
                 cb = cpu_baseline(args.batch, 1234 + 7 + rank, hip_path=hip_path)

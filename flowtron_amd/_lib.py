@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libflowtron_hip.so")
 
-FT_F32, FT_BF16 = 0, 1
+FT_F32, FT_BF16, FT_F16 = 0, 1, 2
 GEMM_SPLITK = 1
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 
@@ -108,6 +108,13 @@ SIGNATURES = {
     "ft_radam_step": ([_p, _p, _p, _p, _l, _p, _d, _d, _d, _d, _d, _d, _d, _i, _p], _i),
 }
 
+# fp16-operand twins (include/flowtron_hip.h, end): same signatures, suffix _f16
+OP16_TWINS = ("ft_gemm", "ft_bf16_image", "ft_bf16_image_colsum", "ft_gemm_img", "ft_lstm_seq_fwd", "ft_lstm_seq_bwd",
+              "ft_lstm_persist_fwd", "ft_lstm_persist_bwd", "ft_lstm2_seq_fwd", "ft_lstm2_seq_bwd",
+              "ft_lstm_bidir_seq_fwd", "ft_lstm_bidir_seq_bwd")
+for _n in OP16_TWINS:
+    SIGNATURES[_n + "_f16"] = SIGNATURES[_n]
+
 _lib = None
 
 
@@ -124,7 +131,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argt
             fn.restype = rest
-        if l.ft_abi_version() != 3:
+        if l.ft_abi_version() != 4:
             raise RuntimeError("libflowtron_hip.so ABI version mismatch")
         _lib = l
     return _lib
@@ -154,10 +161,34 @@ def require_cuda(*tensors):
 
 
 def mfma_mode() -> int:
-    """Operand type fed to the matrix cores (env FLOWTRON_MFMA = f32 | bf16). Storage is fp32."""
-    m = os.environ.get("FLOWTRON_MFMA", "f32").lower()
+    """Operand type fed to the matrix cores.  Storage, accumulation and every non-matmul kernel are fp32 in all modes.
+    FLOWTRON_MFMA = f32 | bf16 | f16 pins it; unset (or "auto") follows the caller's torch.autocast region the way the
+    reference's AMP does (train.py:292 `with amp.autocast(enabled=fp16_run)`): float16 -> FT_F16, bfloat16 -> FT_BF16,
+    no autocast -> FT_F32.  Autograd nodes record the mode at forward time; backward never re-reads it."""
+    m = os.environ.get("FLOWTRON_MFMA", "auto").lower()
+    if m == "auto":
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_dtype("cuda")
+            return FT_F16 if dt == torch.float16 else FT_BF16
+        return FT_F32
     if m in ("f32", "fp32"):
         return FT_F32
     if m in ("bf16",):
         return FT_BF16
-    raise ValueError("FLOWTRON_MFMA must be f32 or bf16, got %r" % m)
+    if m in ("f16", "fp16"):
+        return FT_F16
+    raise ValueError("FLOWTRON_MFMA must be auto, f32, bf16 or f16, got %r" % m)
+
+
+def is16(mode: int) -> bool:
+    """16-bit operand modes: the image / fragment / persistent-recurrence path."""
+    return mode in (FT_BF16, FT_F16)
+
+
+def op16(name: str, mode: int):
+    """The entry point `name` of the 16-bit operand format `mode` (bf16: the plain name, fp16: its _f16 twin)."""
+    if mode == FT_F16:
+        return getattr(lib(), name + "_f16")
+    if mode == FT_BF16:
+        return getattr(lib(), name)
+    raise ValueError("%s needs a 16-bit operand mode, got %d" % (name, mode))

@@ -35,8 +35,19 @@ def _digest(paths) -> str:
     return h.hexdigest()
 
 
+# the operand-typed files are compiled twice: bf16 operands (default) and fp16 operands (-DFT_OPFMT=1, entries suffixed _f16)
+OP16_SOURCES = ("gemm.hip", "gemm_bf16.hip", "lstm.hip", "lstm2.hip", "lstm_persist.hip")
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def units():
+    """(source, extra flags, object suffix) per compilation."""
+    u = [(s, [], "") for s in sources()]
+    u += [(os.path.join(CSRC, f), ["-DFT_OPFMT=1"], "_f16") for f in OP16_SOURCES]
+    return u
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -51,13 +62,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     hd = _digest(hdrs)
 
-    def compile_one(src):
-        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+    def compile_one(unit):
+        src, extra, suffix = unit
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + suffix + ".o")
         tag = obj + ".tag"
-        d = _digest([src]) + hd
+        d = _digest([src]) + hd + " ".join(extra)
         if not force and os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == d:
             return obj
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", obj]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -67,8 +79,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             f.write(d)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(compile_one, srcs))
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(compile_one, units()))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print("[build]", " ".join(cmd), flush=True)

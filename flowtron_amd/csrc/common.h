@@ -38,14 +38,65 @@ static inline int ft_fail(int code, const char* fmt, ...) {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 
-// round-to-nearest-even fp32 -> bf16 through the gfx950 hardware converter (v_cvt_pk_bf16_f32)
+// 16-bit MFMA operand format of this translation unit.  The operand-typed files (gemm, gemm_bf16, lstm, lstm2, lstm_persist)
+// are compiled TWICE: FT_OPFMT 0 = bf16 (FT_BF16), 1 = fp16 (FT_F16: v_mfma_f32_16x16x32_f16, the reference's fp16 AMP
+// configuration).  In the fp16 objects every format-dependent extern "C" entry carries the suffix _f16 (FT_OPNAME); entries
+// with a `mode` argument dispatch to their twin themselves.  Everything else -- images, fragments, hand-off granules -- only
+// moves opaque 16-bit payloads, so the two builds share every line of code but the two functions below.
+#ifndef FT_OPFMT
+#define FT_OPFMT 0
+#endif
+#if FT_OPFMT == 1
+#define FT_OPNAME(x) x##_f16
+#define FT_OP16 FT_F16
+#else
+#define FT_OPNAME(x) x
+#define FT_OP16 FT_BF16
+#endif
+
+// round-to-nearest-even fp32 -> 16-bit operand through the hardware converters (v_cvt_pk_bf16_f32 / v_cvt_f16_f32).
+// fp16 saturates to +-inf beyond 65504: a scaled gradient that overflows is what GradScaler's inf check is for.
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_hw;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_hw;
 typedef __attribute__((ext_vector_type(2))) float f32x2_hw;
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
     const f32x2_hw v = {lo, hi};
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_hw));
 }
 __device__ __forceinline__ unsigned short f2bf(float f) { return (unsigned short)(pack_bf16x2(f, 0.f) & 0xffffu); }
+#if FT_OPFMT == 1
+// one instruction for every fp32 -> fp16 rounding in the library: hipcc lowers a vector convert to v_cvt_pk_f16_f32 and a scalar
+// one to v_cvt_f16_f32, and on gfx950 the two do NOT round ties alike (measured: the persistent and the launch-per-step
+// recurrences, which differ only in which of the two the compiler picked, diverged on ~1 value in 8192) -- v_cvt_f16_f32 is
+// the RNE one (tests/test_gpu_ops.py compares the images with torch's cast bit for bit)
+__device__ __forceinline__ unsigned int cvt_f16_bits(float f) {
+    unsigned int r;
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r & 0xffffu;
+}
+#endif
+__device__ __forceinline__ unsigned int pack_op16x2(float lo, float hi) {
+#if FT_OPFMT == 1
+    return cvt_f16_bits(lo) | (cvt_f16_bits(hi) << 16);
+#else
+    return pack_bf16x2(lo, hi);
+#endif
+}
+__device__ __forceinline__ unsigned short f2op16(float f) {
+#if FT_OPFMT == 1
+    return (unsigned short)cvt_f16_bits(f);
+#else
+    return f2bf(f);
+#endif
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {          // 16x16x32, fp32 accumulate
+#if FT_OPFMT == 1
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_hw, a), __builtin_bit_cast(f16x8_hw, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
@@ -111,6 +162,6 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // gemm_bf16.hip: 1 = handled, 0 = not applicable (use the staging kernel), < 0 = error
-int ftint_gemm_bf16(const ft_gemm_args* a, hipStream_t st);
+int FT_OPNAME(ftint_gemm_bf16)(const ft_gemm_args* a, hipStream_t st);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

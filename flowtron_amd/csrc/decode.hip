@@ -572,6 +572,20 @@ __device__ __forceinline__ void cell_update(const float (&pre)[4], float& c, flo
     lstm_cell<true>(pre, c, ig, fg, gg, og, cn, h);           // v_exp / v_rcp forms (common.h): bf16 operand mode
     c = cn;
 }
+// wave sum by DPP butterflies inside the 16-lane rows + four v_readlane (the ds_bpermute ladder of common.h's wave_sum costs
+// ~0.2 us per sum, several sums sit on every stage's critical path); the result is wave-uniform
+__device__ __forceinline__ float wsum(float v) {
+    auto step = [](float x, auto ctrl) {
+        return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v = step(v, std::integral_constant<int, 0xB1>{});     // quad_perm [1,0,3,2]
+    v = step(v, std::integral_constant<int, 0x4E>{});     // quad_perm [2,3,0,1]
+    v = step(v, std::integral_constant<int, 0x141>{});    // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{});    // row_mirror
+    const unsigned b = __float_as_uint(v);
+    return (__uint_as_float(__builtin_amdgcn_readlane(b, 0)) + __uint_as_float(__builtin_amdgcn_readlane(b, 16))) +
+           (__uint_as_float(__builtin_amdgcn_readlane(b, 32)) + __uint_as_float(__builtin_amdgcn_readlane(b, 48)));
+}
 __device__ __forceinline__ float sfloat(float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); }
 __device__ __forceinline__ float fast_tanh(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.f * 1.4426950408889634f * x) + 1.f);
@@ -580,8 +594,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
 __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
     const DecodeDev& P = p.d;
     constexpr int H = 1024, A = 640, M = 80, LMAX = 1024;
-    __shared__ __attribute__((aligned(16))) float s_prev[M + 16], s_hatt[H], s_cat[H + A], s_q[A], s_pr[LMAX], s_h0[H], s_h0n[H],
-        s_h1[H], s_h1n[H], s_u1[H], s_u2[H], s_o[2 * M + 16], s_v[A], s_gw[H + A];
+    __shared__ __attribute__((aligned(16))) float s_prev[M + 16], s_cat2[2][H + A], s_q[A], s_pr[LMAX], s_h0b[2][H],
+        s_h1b[2][H], s_u1[H], s_u2[H], s_o[2 * M + 16], s_v[A], s_gw[H + A];
     __shared__ float s_red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = blockIdx.x;
     const int u = c * 4 + wave;                                   // this wave's hidden unit / dense row
@@ -594,7 +608,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
         s_slot[0] = (int)(xcc & 7u);
         s_slot[1] = (int)__hip_atomic_fetch_add(p.census + (xcc & 7u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    for (int k = tid; k < H; k += 256) { s_hatt[k] = 0.f; s_h0[k] = 0.f; s_h1[k] = 0.f; }
+    // recurrent inputs double-buffered by frame parity: frame i reads the vectors frame i - 1 gathered (no roll copy)
+    for (int k = tid; k < H; k += 256) { s_cat2[1][k] = 0.f; s_h0b[1][k] = 0.f; s_h1b[1][k] = 0.f; }
     __syncthreads();
     Relay R;
     R.glob = p.gran;
@@ -669,6 +684,12 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
     auto stamp = [&](int k) { if (prof && i < 512) p.prof[(size_t)i * 12 + k] = wall_clock64(); };
     for (;; ++i) {
         const unsigned e0 = (unsigned)i * 16u;                    // epochs of frame i: e0 + 1 .. e0 + 9
+        float* const s_cat = s_cat2[i & 1];
+        const float* const s_hatt = s_cat2[(i & 1) ^ 1];
+        float* const s_h0n = s_h0b[i & 1];
+        const float* const s_h0 = s_h0b[(i & 1) ^ 1];
+        float* const s_h1n = s_h1b[i & 1];
+        const float* const s_h1 = s_h1b[(i & 1) ^ 1];
         stamp(0);
         // ================= S1: inverse coupling of frame i-1 (needs its conv output o), then the attention LSTM of frame i
         if (i > 0) {
@@ -691,7 +712,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
             wa_hh.dot(s_hatt, H, lane, acc);
             float pre[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pre[g] = wave_sum(acc[g]) + b_att[g];
+            for (int g = 0; g < 4; ++g) pre[g] = wsum(acc[g]) + b_att[g];
             float h;
             cell_update(pre, c_att, h);
             if (lane == 0) publish(p.gran + G_HATT + u, e0 + 1u, h);
@@ -705,7 +726,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
             wq.dot(s_cat, H, lane, acc);
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                const float v = wave_sum(acc[k]);
+                const float v = wsum(acc[k]);
                 if (lane == 0) publish_local(R.loc + G_Q + slot + 128 * k, e0 + 2u, v);
             }
         }
@@ -718,14 +739,14 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
                 float sc = 0.f;
 #pragma unroll
                 for (int j = 0; j < A / 64; ++j) sc += s_v[lane + 64 * j] * fast_tanh(s_q[lane + 64 * j] + k_row[k][j]);
-                sc = wave_sum(sc);
+                sc = wsum(sc);
                 if (lane == 0) publish_local(R.loc + G_SC + slot + 128 * k, e0 + 3u, sc * P.inv_temp);
             }
         for (int l = slot + 128 * KRES; l < L; l += 128) {         // texts longer than 256 symbols
             float sc = 0.f;
 #pragma unroll
             for (int j = 0; j < A / 64; ++j) sc += s_v[lane + 64 * j] * fast_tanh(s_q[lane + 64 * j] + P.K[(size_t)l * A + lane + 64 * j]);
-            sc = wave_sum(sc);
+            sc = wsum(sc);
             if (lane == 0) publish_local(R.loc + G_SC + l, e0 + 3u, sc * P.inv_temp);
         }
         // ================= S3b: softmax over L (every workgroup), context channels c, c + 256, c + 512
@@ -740,7 +761,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
             m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
             float sum = 0.f;
             for (int l = tid; l < L; l += 256) { const float e = expf(s_pr[l] - m); s_pr[l] = e; sum += e; }
-            sum = wave_sum(sum);
+            sum = wsum(sum);
             if (lane == 0) s_red[4 + wave] = sum;
             __syncthreads();
             sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
@@ -759,7 +780,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
 #pragma unroll
                 for (int j = 0; j < VRES; ++j) cx += pl[j] * v_col[k][j];
                 for (int l = lane + 64 * VRES; l < L; l += 64) cx += s_pr[l] * P.V[(size_t)l * A + slot + 128 * k];
-                cx = wave_sum(cx);
+                cx = wsum(cx);
                 if (lane == 0) publish_local(R.loc + G_CTX + slot + 128 * k, e0 + 4u, cx);
             }
         }
@@ -770,7 +791,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
         if (c == 0 && P.gate_w) {                                  // flowtron.py:823-826 (uniform branch: all of workgroup 0)
             float g = 0.f;
             for (int k = tid; k < H + A; k += 256) g += s_gw[k] * s_cat[k];
-            g = wave_sum(g);
+            g = wsum(g);
             if (lane == 0) s_red[wave] = g;
             __syncthreads();
             const float gs = gate_b + s_red[0] + s_red[1] + s_red[2] + s_red[3];
@@ -782,7 +803,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
             w0_hh.dot(s_h0, H, lane, acc);
             float pre[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pre[g] = wave_sum(acc[g]) + b_0[g];
+            for (int g = 0; g < 4; ++g) pre[g] = wsum(acc[g]) + b_0[g];
             float h;
             cell_update(pre, c_0, h);
             if (lane == 0) publish(p.gran + G_H0 + u, e0 + 5u, h);
@@ -796,7 +817,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
             w1_hh.dot(s_h1, H, lane, acc);
             float pre[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pre[g] = wave_sum(acc[g]) + b_1[g];
+            for (int g = 0; g < 4; ++g) pre[g] = wsum(acc[g]) + b_1[g];
             float h;
             cell_update(pre, c_1, h);
             if (lane == 0) publish(p.gran + G_H1 + u, e0 + 6u, h);
@@ -807,7 +828,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
         {
             float acc[1] = {0.f};
             wd0.dot(s_h1n, H, lane, acc);
-            const float v = fast_tanh(wave_sum(acc[0]) + b_d0);
+            const float v = fast_tanh(wsum(acc[0]) + b_d0);
             if (lane == 0) publish(p.gran + G_U1 + u, e0 + 7u, v);
         }
         if (!gather(R, G_U1, H, 0, e0 + 7u, s_u1, p, t_start)) return;
@@ -815,7 +836,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
         {
             float acc[1] = {0.f};
             wd1.dot(s_u1, H, lane, acc);
-            const float v = fast_tanh(wave_sum(acc[0]) + b_d1);
+            const float v = fast_tanh(wsum(acc[0]) + b_d1);
             if (lane == 0) publish(p.gran + G_U2 + u, e0 + 8u, v);
         }
         // ================= S8: 1x1 conv row c (wave 0 of workgroups c < 2M); workgroup 0 appends the stop flag
@@ -826,14 +847,12 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
             wcv.dot(s_u2, H, lane, acc);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const float v = wave_sum(acc[k]) + b_cv[k];
+                const float v = wsum(acc[k]) + b_cv[k];
                 if (lane == 0 && slot + 128 * k < 2 * M) publish_local(R.loc + G_O + slot + 128 * k, e0 + 9u, v);
             }
         }
         if (c == 0 && tid == 0) publish(p.gran + G_O + 2 * M, e0 + 9u, gate_done);
-        // roll the recurrent inputs: new h_att / h0 / h1 become the previous ones
-        for (int k = tid; k < H; k += 256) { s_hatt[k] = s_cat[k]; s_h0[k] = s_h0n[k]; s_h1[k] = s_h1n[k]; }
-        __syncthreads();
+
     }
 }
 

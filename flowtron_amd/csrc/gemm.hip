@@ -93,8 +93,8 @@ __device__ __forceinline__ void store_tile(void* lds, int tid, const float (&reg
             } else {
                 unsigned short* p = reinterpret_cast<unsigned short*>(lds) + row * LDH + kc;
                 uint2 w;
-                w.x = pack_bf16x2(reg[j * 4], reg[j * 4 + 1]);
-                w.y = pack_bf16x2(reg[j * 4 + 2], reg[j * 4 + 3]);
+                w.x = pack_op16x2(reg[j * 4], reg[j * 4 + 1]);
+                w.y = pack_op16x2(reg[j * 4 + 2], reg[j * 4 + 3]);
                 *reinterpret_cast<uint2*>(p) = w;
             }
         }
@@ -104,7 +104,7 @@ __device__ __forceinline__ void store_tile(void* lds, int tid, const float (&reg
             int idx = tid + NT * j;
             int row = idx >> 5, kc = idx & 31;
             if constexpr (MODE == 0) reinterpret_cast<float*>(lds)[row * LDF + kc] = reg[j];
-            else reinterpret_cast<unsigned short*>(lds)[row * LDH + kc] = f2bf(reg[j]);
+            else reinterpret_cast<unsigned short*>(lds)[row * LDH + kc] = f2op16(reg[j]);
         }
     }
 }
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
         }
     }
 
@@ -252,15 +252,21 @@ int pick_mode(const float* base, long sr, long sk, long bs, int batch) {
 
 }  // namespace
 
-extern "C" int ft_gemm(const ft_gemm_args* a, void* stream) {
+#if FT_OPFMT == 0
+extern "C" int ft_gemm_f16(const ft_gemm_args* a, void* stream);
+#endif
+extern "C" int FT_OPNAME(ft_gemm)(const ft_gemm_args* a, void* stream) {
     FT_CHECK_ARG(a != nullptr);
+#if FT_OPFMT == 0
+    if (a->mode == FT_F16) return ft_gemm_f16(a, stream);        // the fp16-operand build of this file
+#endif
     FT_CHECK_ARG(a->A && a->B && a->C);
     FT_CHECK_ARG(a->M >= 0 && a->N >= 0 && a->K >= 0 && a->batch >= 1);
-    FT_CHECK_ARG(a->mode == FT_F32 || a->mode == FT_BF16);
+    FT_CHECK_ARG(a->mode == FT_F32 || a->mode == FT_OP16);
     if (a->M == 0 || a->N == 0) return FT_OK;
     FT_CHECK_ARG(a->K > 0);
     if (a->work) {                               // bf16 operand images + DMA-staged kernel (gemm_bf16.hip)
-        const int took = ftint_gemm_bf16(a, reinterpret_cast<hipStream_t>(stream));
+        const int took = FT_OPNAME(ftint_gemm_bf16)(a, reinterpret_cast<hipStream_t>(stream));
         if (took != 0) return took < 0 ? took : FT_OK;
     }
     GemmP p;

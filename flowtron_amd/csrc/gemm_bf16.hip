@@ -30,8 +30,8 @@ inline size_t up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
     uint4 o;
-    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    o.x = pack_op16x2(v[0], v[1]); o.y = pack_op16x2(v[2], v[3]);
+    o.z = pack_op16x2(v[4], v[5]); o.w = pack_op16x2(v[6], v[7]);
     return o;
 }
 
@@ -280,8 +280,8 @@ __global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if constexpr (SPLIT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                if constexpr (SPLIT) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+                else acc[i][j] = mfma16(b[j], a[i], acc[i][j]);
             }
     }
 
@@ -386,7 +386,7 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
 }
 
 bool qualifies(const ft_gemm_args* a) {
-    return a->mode == FT_BF16 && a->batch == 1 && a->M >= 32 && a->N >= 32 && a->K >= 16 &&
+    return a->mode == FT_OP16 && a->batch == 1 && a->M >= 32 && a->N >= 32 && a->K >= 16 &&
            (double)a->M * a->N * a->K >= (double)(1 << 20);
 }
 
@@ -403,13 +403,18 @@ ImgGeo geo(long sr, long sk, int R, int K) {
 
 }  // namespace
 
-extern "C" size_t ft_gemm_workspace_bytes(const ft_gemm_args* a) {
-    if (!a || !qualifies(a)) return 0;
+#if FT_OPFMT == 0
+extern "C" size_t ft_gemm_workspace_bytes(const ft_gemm_args* a) {          // format-independent: both modes use 2-byte images
+    if (!a) return 0;
+    ft_gemm_args b = *a;
+    if (b.mode == FT_F16) b.mode = FT_BF16;
+    if (!qualifies(&b)) return 0;
     return geo(a->sAm, a->sAk, a->M, a->K).bytes + geo(a->sBn, a->sBk, a->N, a->K).bytes;
 }
+#endif
 
 // returns 1 when the call was taken by this path, 0 when the caller should use the fp32-staging kernel, < 0 on error
-int ftint_gemm_bf16(const ft_gemm_args* a, hipStream_t st) {
+int FT_OPNAME(ftint_gemm_bf16)(const ft_gemm_args* a, hipStream_t st) {
     if (!qualifies(a) || !a->work) return 0;
     const ImgGeo ga = geo(a->sAm, a->sAk, a->M, a->K), gb = geo(a->sBn, a->sBk, a->N, a->K);
     if (a->work_bytes < ga.bytes + gb.bytes) return 0;
@@ -428,12 +433,14 @@ int ftint_gemm_bf16(const ft_gemm_args* a, hipStream_t st) {
 // its forward GEMM and its weight-gradient GEMM, an output gradient to the input-gradient and the weight-gradient GEMM, a
 // weight to forward and backward -- in whichever role (k-contiguous or k-major) that GEMM needs.
 // ---------------------------------------------------------------------------------------------------------------
+#if FT_OPFMT == 0
 extern "C" size_t ft_bf16_image_bytes(int64_t rows, int64_t cols) {
     if (rows < 1 || cols < 1) return 0;
     return up(up((size_t)rows + 32, 256) * up((size_t)cols, 256) * 2, 256);
 }
+#endif
 
-extern "C" int ft_bf16_image(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, void* stream) {
+extern "C" int FT_OPNAME(ft_bf16_image)(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, void* stream) {
     FT_CHECK_ARG(src && dst && rows >= 1 && cols >= 1 && ld >= cols && rows < (1ll << 31) - 256 && cols < (1ll << 31) - 256);
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);
     make_image(src, ld, 1, (int)rows, (int)cols, reinterpret_cast<unsigned short*>(dst), (int)up((size_t)rows + 32, 256),
@@ -442,7 +449,7 @@ extern "C" int ft_bf16_image(const float* src, int64_t ld, int64_t rows, int64_t
     return FT_OK;
 }
 
-extern "C" int ft_bf16_image_colsum(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, float* colsum, void* stream) {
+extern "C" int FT_OPNAME(ft_bf16_image_colsum)(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, float* colsum, void* stream) {
     FT_CHECK_ARG(src && dst && colsum && rows >= 1 && cols >= 1 && ld >= cols && rows < (1ll << 31) - 256 && cols < (1ll << 31) - 256);
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -455,7 +462,7 @@ extern "C" int ft_bf16_image_colsum(const float* src, int64_t ld, int64_t rows, 
     return FT_OK;
 }
 
-extern "C" int ft_gemm_img(const ft_gemm_img_args* a, void* stream) {
+extern "C" int FT_OPNAME(ft_gemm_img)(const ft_gemm_img_args* a, void* stream) {
     FT_CHECK_ARG(a != nullptr);
     FT_CHECK_ARG(a->A && a->B && a->C && a->M >= 1 && a->N >= 1 && a->K >= 1);
     FT_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0 && reinterpret_cast<uintptr_t>(a->A) % 16 == 0 && reinterpret_cast<uintptr_t>(a->B) % 16 == 0);

@@ -68,7 +68,7 @@ __device__ __forceinline__ void skinny_bf16(const bf16x8* __restrict__ afrag, co
 #pragma unroll
         for (int i = 0; i < G; ++i)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w[i], acc[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) acc[m] = mfma16(a[i][m], w[i], acc[m]);
     };
     load_group(c0);
     for (int cb = c0 + cs * G; cb < nchunk; cb += cs * G) {      // (H = 1024: a single group, this loop is empty)
@@ -180,7 +180,7 @@ __device__ __forceinline__ void lstm_fwd_body(const FwdP& p) {
     lstm_cell<MODE == 1>(pre, c_old, ig, fg, gg, og, c_new, h_new);
     p.cstate[bu] = c_new;
     if constexpr (MODE == 0) p.hnext[bu] = h_new;
-    else p.hfrag_next[frag_index(eb, eu, MT)] = f2bf(h_new);
+    else p.hfrag_next[frag_index(eb, eu, MT)] = f2op16(h_new);
     p.y[row * p.ldy + eu] = h_new;
     if (p.gates) {
         float* gp = p.gates + row * 4 * H + eu;
@@ -348,7 +348,7 @@ __device__ __forceinline__ void lstm_bwd_body_bf16(const BwdP& p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         dg[(size_t)g * H] = da[g];
-        p.dafrag_next[frag_index(eb, g * H + eu, p.MT)] = f2bf(da[g]);
+        p.dafrag_next[frag_index(eb, g * H + eu, p.MT)] = f2op16(da[g]);
     }
 }
 
@@ -428,12 +428,13 @@ void launch_bwd_mm(const BwdP& p, int mt, dim3 grid, hipStream_t st) {
 
 inline size_t al256(size_t v) { return (v + 255) & ~size_t(255); }
 // fragment path: every wave gets the same number of 32-wide k-chunks (fwd: H/32 over 4 waves, bwd: 4H/32 over 16 waves)
-inline bool fast_bf16(int mode, int H) { return mode == FT_BF16 && (H % 128) == 0; }
+inline bool fast_bf16(int mode, int H) { return mode == FT_OP16 && (H % 128) == 0; }
 inline int group_of(int per_wave) { return (per_wave % 8 == 0) ? 8 : (per_wave % 4 == 0) ? 4 : (per_wave % 2 == 0) ? 2 : 1; }
 
 }  // namespace
 
 #ifndef FT_LSTM_NO_ENTRY
+#if FT_OPFMT == 0
 extern "C" size_t ft_lstm_workspace_bytes(int B, int H) {
     const size_t BH = (size_t)B * H;
     const int mt = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
@@ -443,14 +444,18 @@ extern "C" size_t ft_lstm_workspace_bytes(int B, int H) {
     const size_t bwd = al256(9 * BH * 4) + al256((size_t)4 * H * H * 4) + al256(8 * frag_act) + al256(wfrag);
     return fwd > bwd ? fwd : bwd;
 }
+#endif
 
-extern "C" int ft_lstm_seq_fwd(const float* gx, const float* w_hh, const int32_t* lens,
+extern "C" int FT_OPNAME(ft_lstm_seq_fwd)(const float* gx, const float* w_hh, const int32_t* lens,
                                float* y, int64_t ldy, float* gates, float* cell, void* work,
                                int T, int B, int H, int reverse, int mode, void* stream) {
+#if FT_OPFMT == 0
+    if (mode == FT_F16) return ft_lstm_seq_fwd_f16(gx, w_hh, lens, y, ldy, gates, cell, work, T, B, H, reverse, mode, stream);
+#endif
     FT_CHECK_ARG(gx && w_hh && lens && y && work);
     FT_CHECK_ARG(T >= 0 && B >= 1 && B <= 64 && H >= 4 && H % 4 == 0 && ldy >= H);
     FT_CHECK_ARG((gates == nullptr) == (cell == nullptr));
-    FT_CHECK_ARG(mode == FT_F32 || mode == FT_BF16);
+    FT_CHECK_ARG(mode == FT_F32 || mode == FT_OP16);
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(w_hh) % 16 == 0 && reinterpret_cast<uintptr_t>(work) % 256 == 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t BH = (size_t)B * H;
@@ -478,12 +483,15 @@ extern "C" int ft_lstm_seq_fwd(const float* gx, const float* w_hh, const int32_t
     return FT_OK;
 }
 
-extern "C" int ft_lstm_seq_bwd(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens,
+extern "C" int FT_OPNAME(ft_lstm_seq_bwd)(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens,
                                const float* gates, const float* cell, float* dgx, void* work,
                                int T, int B, int H, int reverse, int mode, void* stream) {
+#if FT_OPFMT == 0
+    if (mode == FT_F16) return ft_lstm_seq_bwd_f16(dy, ldy, w_hh, lens, gates, cell, dgx, work, T, B, H, reverse, mode, stream);
+#endif
     FT_CHECK_ARG(dy && w_hh && lens && gates && cell && dgx && work);
     FT_CHECK_ARG(T >= 0 && B >= 1 && B <= 64 && H >= 4 && H % 4 == 0 && ldy >= H);
-    FT_CHECK_ARG(mode == FT_F32 || mode == FT_BF16);
+    FT_CHECK_ARG(mode == FT_F32 || mode == FT_OP16);
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(work) % 256 == 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t BH = (size_t)B * H;
@@ -572,9 +580,11 @@ void launch_fwd_pair(const FwdP& pf, const FwdP& pr, int mt, dim3 grid, hipStrea
 }  // namespace
 
 #ifndef FT_LSTM_NO_ENTRY
+#if FT_OPFMT == 0
 extern "C" int ft_lstm_bidir_supported(int B, int H) { return (B >= 1 && B <= 64 && H >= 128 && H % 128 == 0) ? 1 : 0; }
+#endif
 
-extern "C" int ft_lstm_bidir_seq_fwd(const float* gx_f, const float* gx_r, const float* w_hh_f, const float* w_hh_r,
+extern "C" int FT_OPNAME(ft_lstm_bidir_seq_fwd)(const float* gx_f, const float* gx_r, const float* w_hh_f, const float* w_hh_r,
                                      const int32_t* lens, float* y, int64_t ldy, float* gates_f, float* gates_r,
                                      float* cell_f, float* cell_r, void* work_f, void* work_r, int T, int B, int H, void* stream) {
     FT_CHECK_ARG(gx_f && gx_r && w_hh_f && w_hh_r && lens && y && gates_f && gates_r && cell_f && cell_r && work_f && work_r);
@@ -604,7 +614,7 @@ extern "C" int ft_lstm_bidir_seq_fwd(const float* gx_f, const float* gx_r, const
     return FT_OK;
 }
 
-extern "C" int ft_lstm_bidir_seq_bwd(const float* dy, int64_t ldy, const float* w_hh_f, const float* w_hh_r, const int32_t* lens,
+extern "C" int FT_OPNAME(ft_lstm_bidir_seq_bwd)(const float* dy, int64_t ldy, const float* w_hh_f, const float* w_hh_r, const int32_t* lens,
                                      const float* gates_f, const float* gates_r, const float* cell_f, const float* cell_r,
                                      float* dgx_f, float* dgx_r, void* work_f, void* work_r, int T, int B, int H, void* stream) {
     FT_CHECK_ARG(dy && w_hh_f && w_hh_r && lens && gates_f && gates_r && cell_f && cell_r && dgx_f && dgx_r && work_f && work_r);

@@ -39,7 +39,7 @@ __device__ __forceinline__ void skinny_bf16(const bf16x8* __restrict__ afrag, co
 #pragma unroll
         for (int i = 0; i < G; ++i)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w[i], acc[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) acc[m] = mfma16(a[i][m], w[i], acc[m]);
     };
     load_group(c0);
     for (int cb = c0 + cs * G; cb < nchunk; cb += cs * G) {
@@ -76,7 +76,7 @@ __device__ __forceinline__ void skinny_bf16_dualw(const bf16x8* __restrict__ afr
 #pragma unroll
     for (int i = 0; i < G; ++i)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w0[i], acc[m], 0, 0, 0);
+        for (int m = 0; m < MT; ++m) acc[m] = mfma16(a[i][m], w0[i], acc[m]);
 #pragma unroll
     for (int i = 0; i < G; ++i)
 #pragma unroll
@@ -86,7 +86,7 @@ __device__ __forceinline__ void skinny_bf16_dualw(const bf16x8* __restrict__ afr
 #pragma unroll
     for (int i = 0; i < G; ++i)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w1[i], acc[m], 0, 0, 0);
+        for (int m = 0; m < MT; ++m) acc[m] = mfma16(a[i][m], w1[i], acc[m]);
 }
 
 __device__ __forceinline__ size_t frag_index(int b, int k, int MT) {
@@ -107,7 +107,7 @@ __global__ void make_wfrag_fwd_cat(const float* __restrict__ wa, int Ka, const f
         const int li = lane & 15, kg = lane >> 4;
         const size_t row = (size_t)(li >> 2) * H + jb * 4 + (li & 3);
         const int k = c * 32 + kg * 8 + e;
-        out[i] = f2bf(k < Ka ? wa[row * Ka + k] : wb[row * Kb + (k - Ka)]);
+        out[i] = f2op16(k < Ka ? wa[row * Ka + k] : wb[row * Kb + (k - Ka)]);
     }
 }
 // backward image of W [4H][Kc]: out[jt][c][lane][e] = W[c*32 + kg*8 + e][jt*16 + li]   (jt over Kc/16 column tiles)
@@ -120,7 +120,7 @@ __global__ void make_wfrag_bwd_t(const float* __restrict__ w, unsigned short* __
         const int c = (int)(rest % nchunk), jt = (int)(rest / nchunk);
         const int li = lane & 15, kg = lane >> 4;
         const size_t r = (size_t)c * 32 + kg * 8 + e;
-        out[i] = f2bf(w[r * Kc + jt * 16 + li]);
+        out[i] = f2op16(w[r * Kc + jt * 16 + li]);
     }
 }
 
@@ -221,7 +221,7 @@ __device__ __forceinline__ void lstm2_fwd_body(const L2FwdP& p) {
     float ig, fg, gg, og, c_new, h_new;
     lstm_cell<true>(pre, c_old, ig, fg, gg, og, c_new, h_new);
     cst[(size_t)eb * H + eu] = c_new;
-    hnext[frag_index(eb, eu, MT)] = f2bf(h_new);
+    hnext[frag_index(eb, eu, MT)] = f2op16(h_new);
     y[row * H + eu] = h_new;
     float* gp = (L1 ? p.gates1 : p.gates0) + row * 4 * H + eu;
     gp[0] = ig; gp[(size_t)H] = fg; gp[(size_t)2 * H] = gg; gp[(size_t)3 * H] = og;
@@ -302,13 +302,13 @@ __global__ __launch_bounds__(256) void lstm2_fwd_both(L2FwdP p) {
         for (int i = 0; i < G; ++i)
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                acc0[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w0[i], acc0[m], 0, 0, 0);
-                acc1[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], wi[i], acc1[m], 0, 0, 0);
+                acc0[m] = mfma16(a[i][m], w0[i], acc0[m]);
+                acc1[m] = mfma16(a[i][m], wi[i], acc1[m]);
             }
 #pragma unroll
         for (int i = 0; i < G; ++i)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc1[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i][m], w1[i], acc1[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) acc1[m] = mfma16(ah[i][m], w1[i], acc1[m]);
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void lstm2_fwd_both(L2FwdP p) {
     float ig, fg, gg, og, c_new, h_new;
     lstm_cell<true>(pre, c_old, ig, fg, gg, og, c_new, h_new);
     cst[(size_t)eb * H + eu] = c_new;
-    hnext[frag_index(eb, eu, MT)] = f2bf(h_new);
+    hnext[frag_index(eb, eu, MT)] = f2op16(h_new);
     y[row * H + eu] = h_new;
     float* gp = (L1 ? p.gates1 : p.gates0) + row * 4 * H + eu;
     gp[0] = ig; gp[(size_t)H] = fg; gp[(size_t)2 * H] = gg; gp[(size_t)3 * H] = og;
@@ -441,7 +441,7 @@ __device__ __forceinline__ void lstm2_bwd_body(const L2BwdP& p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         dg[(size_t)g * H] = da[g];
-        dan[frag_index(eb, g * H + eu, p.MT)] = f2bf(da[g]);
+        dan[frag_index(eb, g * H + eu, p.MT)] = f2op16(da[g]);
     }
 }
 
@@ -517,9 +517,9 @@ __global__ __launch_bounds__(1024) void lstm2_bwd_skew2(L2BwdP p) {
             issue_epilogue_loads();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < G; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], w0[i], acc, 0, 0, 0);
+            for (int i = 0; i < G; ++i) acc = mfma16(a[i], w0[i], acc);
 #pragma unroll
-            for (int i = 0; i < G; ++i) accp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], w1[i], accp, 0, 0, 0);
+            for (int i = 0; i < G; ++i) accp = mfma16(a[i], w1[i], accp);
         } else {
             const bf16x8* af = reinterpret_cast<const bf16x8*>(p.da0frag[(s + 1) & 1]) + (size_t)m_base * 64;   // dgates0[s+1]
             const bf16x8* wa = reinterpret_cast<const bf16x8*>(p.wT0frag) + (size_t)jt * nchunk * 64;          // W_hh0^T
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(1024) void lstm2_bwd_skew2(L2BwdP p) {
             issue_epilogue_loads();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < G; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], w0[i], acc, 0, 0, 0);
+            for (int i = 0; i < G; ++i) acc = mfma16(a[i], w0[i], acc);
         }
     }
 #pragma unroll
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(1024) void lstm2_bwd_skew2(L2BwdP p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         dg[(size_t)g * H] = da[g];
-        dan[frag_index(eb, g * H + eu, p.MT)] = f2bf(da[g]);
+        dan[frag_index(eb, g * H + eu, p.MT)] = f2op16(da[g]);
     }
 }
 
@@ -631,6 +631,7 @@ inline Bwd2Setup setup_bwd2(void* work, int B, int H) {
 }  // namespace
 
 #ifndef FT_LSTM_NO_ENTRY
+#if FT_OPFMT == 0
 extern "C" int ft_lstm2_supported(int B, int H) { return (B >= 1 && B <= 64 && H >= 128 && H % 128 == 0) ? 1 : 0; }
 
 extern "C" size_t ft_lstm2_workspace_bytes(int B, int H) {
@@ -640,8 +641,9 @@ extern "C" size_t ft_lstm2_workspace_bytes(int B, int H) {
     const size_t bwd = 2 * al256(BH * 4) + 4 * al256(4 * frag_act) + 2 * al256((size_t)mt * 16 * H * 4) + 3 * al256(wimg);
     return fwd > bwd ? fwd : bwd;
 }
+#endif
 
-extern "C" int ft_lstm2_seq_fwd(const float* gx0, const float* w_hh0, const float* w_ih1, const float* bias1, const float* w_hh1,
+extern "C" int FT_OPNAME(ft_lstm2_seq_fwd)(const float* gx0, const float* w_hh0, const float* w_ih1, const float* bias1, const float* w_hh1,
                                 const int32_t* lens, float* y0, float* gates0, float* cell0, float* y1, float* gates1, float* cell1,
                                 void* work, int T, int B, int H, void* stream) {
     FT_CHECK_ARG(gx0 && w_hh0 && w_ih1 && bias1 && w_hh1 && lens && y0 && gates0 && cell0 && y1 && gates1 && cell1 && work);
@@ -685,7 +687,7 @@ extern "C" int ft_lstm2_seq_fwd(const float* gx0, const float* w_hh0, const floa
     return FT_OK;
 }
 
-extern "C" int ft_lstm2_seq_bwd(const float* dy1, const float* w_hh0, const float* w_ih1, const float* w_hh1, const int32_t* lens,
+extern "C" int FT_OPNAME(ft_lstm2_seq_bwd)(const float* dy1, const float* w_hh0, const float* w_ih1, const float* w_hh1, const int32_t* lens,
                                 const float* gates0, const float* cell0, const float* gates1, const float* cell1,
                                 float* dgx0, float* dgx1, void* work, int T, int B, int H, void* stream) {
     FT_CHECK_ARG(dy1 && w_hh0 && w_ih1 && w_hh1 && lens && gates0 && cell0 && gates1 && cell1 && dgx0 && dgx1 && work);

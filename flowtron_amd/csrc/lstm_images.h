@@ -15,7 +15,7 @@ __global__ void make_wfrag_fwd(const float* __restrict__ w, unsigned short* __re
         const int c = (int)(rest % nchunk), jb = (int)(rest / nchunk);
         const int li = lane & 15, kg = lane >> 4;
         const size_t row = (size_t)(li >> 2) * H + jb * 4 + (li & 3);
-        out[i] = f2bf(w[row * H + c * 32 + kg * 8 + e]);
+        out[i] = f2op16(w[row * H + c * 32 + kg * 8 + e]);
     }
 }
 // W_hh [4H][H] fp32 -> backward fragment image [H/16][4H/32][64][8] bf16:
@@ -29,7 +29,7 @@ __global__ void make_wfrag_bwd(const float* __restrict__ w, unsigned short* __re
         const int c = (int)(rest % nchunk), jt = (int)(rest / nchunk);
         const int li = lane & 15, kg = lane >> 4;
         const size_t r = (size_t)c * 32 + kg * 8 + e;
-        out[i] = f2bf(w[r * H + jt * 16 + li]);
+        out[i] = f2op16(w[r * H + jt * 16 + li]);
     }
 }
 

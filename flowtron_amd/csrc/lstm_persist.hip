@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
                 }
                 const bf16x8 a = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
-                for (int j = 0; j < TPC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w[j][i], acc[j], 0, 0, 0);
+                for (int j = 0; j < TPC; ++j) acc[j] = mfma16(a, w[j][i], acc[j]);
             }
         }
         // D[m = batch row (lane>>4)*4 + r][n = li]: rows >= RPGP are padding
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
             // ---- publish h_t first: one 8-byte {epoch, bf16 pair} granule per even unit (frozen rows re-publish their state)
             const float h_nb = __shfl_down(h_state, 1, 64);
             if ((el & 1) == 0) {
-                const unsigned long long gran = ((unsigned long long)(unsigned)(t + 1) << 32) | pack_bf16x2(h_state, h_nb);
+                const unsigned long long gran = ((unsigned long long)(unsigned)(t + 1) << 32) | pack_op16x2(h_state, h_nb);
                 unsigned long long* dst = p.hgran + ((size_t)(t & 1) * NG + grp) * GRAN_PER_GROUP + gran_index<RPGP, 8>(ebl, eu);
                 // LOCAL: workgroup-scope relaxed store = ONE aligned 8-byte global_store (sc0) whose line stays in this XCD's L2;
                 // otherwise agent scope = sc1, write-through to the memory side
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
                     const bf16x8 a = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
                     for (int j = 0; j < TL; ++j)
-                        acc[j][ci & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w[j][ci], acc[j][ci & 3], 0, 0, 0);
+                        acc[j][ci & 3] = mfma16(a, w[j][ci], acc[j][ci & 3]);
                 }
             }
             if (dead) break;
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
             for (int g = 0; g < 4; ++g) {
                 const float nb = __shfl_down(da[g], 1, 64);
                 if ((el & 1) == 0) {
-                    const unsigned long long gran = ((unsigned long long)(unsigned)(n + 1) << 32) | pack_bf16x2(da[g], nb);
+                    const unsigned long long gran = ((unsigned long long)(unsigned)(n + 1) << 32) | pack_op16x2(da[g], nb);
                     unsigned long long* dst = p.dgran + ((size_t)(n & 1) * NG + grp) * GRAN_PER_GROUP + gran_index<RPGP, CPW>(ebl, g * PH + eu);
                     if constexpr (LOCAL) __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -617,9 +617,15 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
 }  // namespace
 
 static inline size_t al256p(size_t v) { return (v + 255) & ~size_t(255); }
-static long* g_persist_prof = nullptr;
+#if FT_OPFMT == 0
+long* ftint_persist_prof = nullptr;                  // shared with the fp16 build of this file
+#else
+extern long* ftint_persist_prof;
+#endif
+#define g_persist_prof ftint_persist_prof
 // debug hook (scripts/exp/lstm_persist_bench.py): device buffer of 1024 x 4 x 5 int64 that the NEXT forward launches fill
 // with per-step phase stamps of workgroup (group 0, slot 0); nullptr switches it off
+#if FT_OPFMT == 0
 extern "C" int ft_lstm_persist_debug_prof(void* dev_buf) { g_persist_prof = reinterpret_cast<long*>(dev_buf); return FT_OK; }
 
 extern "C" int ft_lstm_persist_supported(int B, int H) {
@@ -640,8 +646,9 @@ extern "C" size_t ft_lstm_persist_workspace_bytes(int B, int H) {
     // 4H backward) + census counters
     return al256p((size_t)4 * H * H * 2) + al256p((size_t)2 * 32 * (4 * H / 2) * 8) + 256;
 }
+#endif
 
-extern "C" int ft_lstm_persist_fwd(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
+extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
                                    float* gates, float* cell, void* work, int32_t* status, int T, int B, int H, int ng,
                                    void* stream) {
     FT_CHECK_ARG(gx && w_hh && lens && y && work && status);
@@ -679,7 +686,7 @@ extern "C" int ft_lstm_persist_fwd(const float* gx, const float* w_hh, const int
     return FT_OK;
 }
 
-extern "C" int ft_lstm_persist_bwd(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
+extern "C" int FT_OPNAME(ft_lstm_persist_bwd)(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
                                    const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
                                    void* stream) {
     FT_CHECK_ARG(dy && w_hh && lens && gates && cell && dgx && work && status);

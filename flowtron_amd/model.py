@@ -221,7 +221,7 @@ class AR_Step(nn.Module):
         elif ops.lstm2_supported(B, p.weight_hh_l0.shape[1], mode):
             # both decoder layers as one software-wavefront launch chain (csrc/lstm2.hip)
             gx0 = ops.LinearFn.apply(p.weight_ih_l0, p.bias_ih_l0 + p.bias_hh_l0, L.ACT_NONE, mode, h_att, ctx)
-            h = ops.LSTM2SeqFn.apply(gx0, p.weight_hh_l0, p.weight_ih_l1, p.bias_ih_l1, p.bias_hh_l1, p.weight_hh_l1, out_lens32)
+            h = ops.LSTM2SeqFn.apply(gx0, p.weight_hh_l0, p.weight_ih_l1, p.bias_ih_l1, p.bias_hh_l1, p.weight_hh_l1, out_lens32, mode)
         else:
             h = ops.lstm_layer(h_att, out_lens32, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, mode=mode,
                                xs_extra=[ctx])
@@ -325,7 +325,7 @@ class AR_Step(nn.Module):
             L.ptr(att.key.linear_layer.weight) if cumm else None, L.ptr(enc2d) if cumm else None, E,
             L.ptr(prior_rows), L.ptr(forced_rows), None, 0, None, None)
         persist = None
-        if L.mfma_mode() == L.FT_BF16:          # bf16 operand mode: stream bf16 images of the weights (half the bytes per frame)
+        if L.is16(L.mfma_mode()):               # 16-bit operand modes: bf16 images of the weights (half the bytes; fp32 activations)
             nb = L.lib().ft_decode_wimg_bytes(H, A, M)
             wimg = bufs.get("wimg")
             if wimg is None or wimg.numel() < nb:

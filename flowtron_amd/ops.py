@@ -53,23 +53,24 @@ def gemm_raw(A, B, Cm, M, N, K, sAm, sAk, sBk, sBn, ldc, bias=None, act=L.ACT_NO
 # k-contiguous or k-major as the GEMM needs (k-major fragments come from the LDS transpose-read, so nothing is transposed).
 # --------------------------------------------------------------------------
 class Bf16Image:
-    __slots__ = ("buf", "rows", "cols", "ld", "colsum")
+    __slots__ = ("buf", "rows", "cols", "ld", "colsum", "fmt")
 
-    def __init__(self, t2d, colsum=False):
+    def __init__(self, t2d, colsum=False, mode=None):
         """t2d: fp32 CUDA matrix [rows, cols], unit column stride.  colsum=True also returns the fp32 column sums of t2d
         (self.colsum) from the same pass -- the bias gradient when t2d is an output gradient."""
         assert t2d.dim() == 2 and t2d.stride(1) == 1 and t2d.dtype == torch.float32
         L.require_cuda(t2d)
         self.rows, self.cols = int(t2d.shape[0]), int(t2d.shape[1])
+        self.fmt = L.mfma_mode() if mode is None else mode      # FT_BF16 or FT_F16: 16-bit payloads of that operand format
         self.ld = (self.cols + 255) // 256 * 256
         self.buf = torch.empty(L.lib().ft_bf16_image_bytes(self.rows, self.cols), device=t2d.device, dtype=torch.uint8)
         self.colsum = None
         if colsum:
             self.colsum = torch.empty(self.cols, device=t2d.device, dtype=torch.float32)
-            L.check(L.lib().ft_bf16_image_colsum(L.ptr(t2d), int(t2d.stride(0)), self.rows, self.cols, L.ptr(self.buf), L.ptr(self.colsum),
+            L.check(L.op16("ft_bf16_image_colsum", self.fmt)(L.ptr(t2d), int(t2d.stride(0)), self.rows, self.cols, L.ptr(self.buf), L.ptr(self.colsum),
                                                  L.stream()), "ft_bf16_image_colsum")
         else:
-            L.check(L.lib().ft_bf16_image(L.ptr(t2d), int(t2d.stride(0)), self.rows, self.cols, L.ptr(self.buf), L.stream()), "ft_bf16_image")
+            L.check(L.op16("ft_bf16_image", self.fmt)(L.ptr(t2d), int(t2d.stride(0)), self.rows, self.cols, L.ptr(self.buf), L.stream()), "ft_bf16_image")
 
     def ptr(self, row_off=0, col_off=0):
         assert col_off % 8 == 0
@@ -83,15 +84,15 @@ import weakref as _weakref
 _IMG_CACHE = {}
 
 
-def shared_image(t, rows, cols):
-    """bf16 image of the fp32 tensor `t` viewed as [rows, cols]; one conversion per tensor (version)."""
+def shared_image(t, rows, cols, mode):
+    """16-bit image (operand format `mode`) of the fp32 tensor `t` viewed as [rows, cols]; one conversion per tensor (version)."""
     key = id(t)
     hit = _IMG_CACHE.get(key)
     if hit is not None:
         ref, ver, img = hit
-        if ref() is t and ver == t._version and img.rows == rows and img.cols == cols:
+        if ref() is t and ver == t._version and img.rows == rows and img.cols == cols and img.fmt == mode:
             return img
-    img = Bf16Image(t.reshape(rows, cols))
+    img = Bf16Image(t.reshape(rows, cols), mode=mode)
     if len(_IMG_CACHE) > 64:                     # dead entries (their tensors are gone) are swept lazily
         for k in [k for k, (r, _, _) in _IMG_CACHE.items() if r() is None]:
             del _IMG_CACHE[k]
@@ -104,7 +105,7 @@ def shared_image(t, rows, cols):
 
 def images_apply(mode, M, N, K):
     """same rule as ft_gemm_workspace_bytes: bf16 mode and a GEMM large enough to amortise the image passes."""
-    return _BF16_IMAGES and mode == L.FT_BF16 and M >= 32 and N >= 32 and K >= 16 and M * N * K >= (1 << 20)
+    return _BF16_IMAGES and L.is16(mode) and M >= 32 and N >= 32 and K >= 16 and M * N * K >= (1 << 20)
 
 
 def gemm_img(A, a_km, a_ptr, B, b_km, b_ptr, Cm, M, N, K, ldc, bias=None, act=L.ACT_NONE, alpha=1.0, beta=0.0, splitk=False):
@@ -112,7 +113,8 @@ def gemm_img(A, a_km, a_ptr, B, b_km, b_ptr, Cm, M, N, K, ldc, bias=None, act=L.
     L.require_cuda(Cm, bias)
     a = L.GemmImgArgs(a_ptr, b_ptr, L.ptr(Cm), L.ptr(bias), M, N, K, A.ld, B.ld, ldc, int(a_km), int(b_km),
                       alpha, beta, act, L.GEMM_SPLITK if splitk else 0)
-    L.check(L.lib().ft_gemm_img(C.byref(a), L.stream()), "ft_gemm_img")
+    assert A.fmt == B.fmt, "operand images of different formats"
+    L.check(L.op16("ft_gemm_img", A.fmt)(C.byref(a), L.stream()), "ft_gemm_img")
 
 
 # hand-off of an output-gradient image between two autograd nodes of the SAME backward pass (the LSTM backward builds the
@@ -166,8 +168,8 @@ class LinearFn(torch.autograd.Function):
         use_img = all(images_apply(mode, rows, N, x.shape[-1]) for x in xs) and all((x.shape[-1] % 8 == 0) for x in xs[:-1])
         ctx.imgs = None
         if use_img:
-            w_img = Bf16Image(W)
-            x_imgs = [shared_image(x, rows, x.shape[-1]) for x in xs]
+            w_img = Bf16Image(W, mode=mode)
+            x_imgs = [shared_image(x, rows, x.shape[-1], mode) for x in xs]
             ctx.imgs = (w_img, x_imgs)          # reused by backward (dX reads W k-major, dW reads x k-major)
         off = 0
         for i, x in enumerate(xs):
@@ -206,8 +208,10 @@ class LinearFn(torch.autograd.Function):
         if imgs is not None:
             w_img, x_imgs = imgs
             d_img = _handoff_take(dpre) if ctx.act == L.ACT_NONE else None      # e.g. the LSTM backward already made it
+            if d_img is not None and d_img.fmt != w_img.fmt:
+                d_img = None
             if d_img is None:
-                d_img = Bf16Image(dpre.reshape(rows, N), colsum=want_db)          # bias gradient rides on the conversion pass
+                d_img = Bf16Image(dpre.reshape(rows, N), colsum=want_db, mode=w_img.fmt)          # bias gradient rides on the conversion pass
             db = d_img.colsum if want_db else None
         if want_db and db is None:
             db = colsum(dpre, rows, N, N)
@@ -435,7 +439,7 @@ def lstm_persist_groups(B, H, reverse, mode, device=None):
     """transport / group code of the persistent recurrence kernels for this shape (0 = use the launch-per-step kernels).
     FLOWTRON_LSTM_PERSIST: 0 = off, 1 (default) = 8 XCD-local groups, 8 | 4 = placement-independent fabric transport."""
     ng = int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "1"))
-    if not ng or reverse or mode != L.FT_BF16 or not L.lib().ft_lstm_persist_supported(B, H):
+    if not ng or reverse or not L.is16(mode) or not L.lib().ft_lstm_persist_supported(B, H):
         return 0
     if device is not None:
         st = _persist_state(device)
@@ -460,7 +464,7 @@ class LSTMSeqFn(torch.autograd.Function):
         if ng:
             st = _persist_watch(gx.device)
             work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=gx.device, dtype=torch.uint8)
-            L.check(L.lib().ft_lstm_persist_fwd(L.ptr(gx), L.ptr(w_hh), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
+            L.check(L.op16("ft_lstm_persist_fwd", mode)(L.ptr(gx), L.ptr(w_hh), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
                                                 L.ptr(work), L.ptr(st.status), T, B, H, ng, L.stream()), "ft_lstm_persist_fwd")
             _persist_arm(st)
         else:
@@ -482,7 +486,7 @@ class LSTMSeqFn(torch.autograd.Function):
             ng = ng if ng in (1, 9, 8, 4) else 8
             st = _persist_watch(dy.device)
             work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=dy.device, dtype=torch.uint8)
-            L.check(L.lib().ft_lstm_persist_bwd(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
+            L.check(L.op16("ft_lstm_persist_bwd", ctx.mode)(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
                                                 L.ptr(work), L.ptr(st.status), T, B, H, ng, L.stream()), "ft_lstm_persist_bwd")
             _persist_arm(st)
         else:
@@ -498,7 +502,7 @@ class LSTMSeqFn(torch.autograd.Function):
             dW = torch.zeros_like(w_hh)
             if T > 1 and images_apply(ctx.mode, 4 * H, H, rows):
                 # images of dgates / outputs over all T*B rows; the one-step shift is a row offset into them
-                d_img, y_img = Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True), shared_image(y, T * B, H)
+                d_img, y_img = Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True, mode=ctx.mode), shared_image(y, T * B, H, ctx.mode)
                 fwd = not ctx.reverse
                 gemm_img(d_img, 1, d_img.ptr(B if fwd else 0), y_img, 1, y_img.ptr(0 if fwd else B), dW, 4 * H, H, rows, H, splitk=True)
                 _handoff_put(dgx, d_img)        # the input projection's backward reads the same dgates
@@ -520,7 +524,8 @@ class BiLSTMSeqFn(torch.autograd.Function):
     """[h_fwd | h_rev] of a bidirectional layer, both recurrences in one launch chain (csrc/lstm.hip lstm_*_pair)."""
 
     @staticmethod
-    def forward(ctx, gx_f, gx_r, w_f, w_r, lens):
+    def forward(ctx, gx_f, gx_r, w_f, w_r, lens, mode=L.FT_BF16):
+        ctx.mode = mode
         gx_f, gx_r, w_f, w_r = _c(gx_f), _c(gx_r), _c(w_f), _c(w_r)
         L.require_cuda(gx_f, gx_r, w_f, w_r, lens)
         T, B, H4 = gx_f.shape
@@ -531,7 +536,7 @@ class BiLSTMSeqFn(torch.autograd.Function):
         cell = [torch.empty(T, B, H, **f) for _ in range(2)]
         nb = L.lib().ft_lstm_workspace_bytes(B, H)
         work = [torch.empty(nb, device=gx_f.device, dtype=torch.uint8) for _ in range(2)]
-        L.check(L.lib().ft_lstm_bidir_seq_fwd(L.ptr(gx_f), L.ptr(gx_r), L.ptr(w_f), L.ptr(w_r), L.ptr(lens), L.ptr(y), 2 * H,
+        L.check(L.op16("ft_lstm_bidir_seq_fwd", mode)(L.ptr(gx_f), L.ptr(gx_r), L.ptr(w_f), L.ptr(w_r), L.ptr(lens), L.ptr(y), 2 * H,
                                               L.ptr(gates[0]), L.ptr(gates[1]), L.ptr(cell[0]), L.ptr(cell[1]),
                                               L.ptr(work[0]), L.ptr(work[1]), T, B, H, L.stream()), "ft_lstm_bidir_seq_fwd")
         ctx.save_for_backward(w_f, w_r, lens, y, gates[0], gates[1], cell[0], cell[1])
@@ -547,7 +552,7 @@ class BiLSTMSeqFn(torch.autograd.Function):
         dgx = [torch.empty(T, B, 4 * H, **f) for _ in range(2)]
         nb = L.lib().ft_lstm_workspace_bytes(B, H)
         work = [torch.empty(nb, device=dy.device, dtype=torch.uint8) for _ in range(2)]
-        L.check(L.lib().ft_lstm_bidir_seq_bwd(L.ptr(dy), 2 * H, L.ptr(w_f), L.ptr(w_r), L.ptr(lens), L.ptr(g0), L.ptr(g1),
+        L.check(L.op16("ft_lstm_bidir_seq_bwd", ctx.mode)(L.ptr(dy), 2 * H, L.ptr(w_f), L.ptr(w_r), L.ptr(lens), L.ptr(g0), L.ptr(g1),
                                               L.ptr(c0), L.ptr(c1), L.ptr(dgx[0]), L.ptr(dgx[1]), L.ptr(work[0]), L.ptr(work[1]),
                                               T, B, H, L.stream()), "ft_lstm_bidir_seq_bwd")
         dWs = [None, None]
@@ -559,8 +564,8 @@ class BiLSTMSeqFn(torch.autograd.Function):
                     # dW_hh[r,j] = sum da_t[b,r] h_prev(t)[b,j];  h_prev = y[t-1] (forward) / y[t+1] (reverse), y row stride 2H
                     da = dgx[d][1:] if d == 0 else dgx[d][:-1]
                     hp = y[:-1, :, :H] if d == 0 else y[1:, :, H:]
-                    gemm_raw(da, hp, dWs[d], 4 * H, H, rows, 1, 4 * H, 2 * H, 1, H, mode=L.FT_BF16, splitk=True)
-        return dgx[0], dgx[1], dWs[0], dWs[1], None
+                    gemm_raw(da, hp, dWs[d], 4 * H, H, rows, 1, 4 * H, 2 * H, 1, H, mode=ctx.mode, splitk=True)
+        return dgx[0], dgx[1], dWs[0], dWs[1], None, None
 
 
 def bilstm_layer(x, lens, wf, wr, mode=None):
@@ -569,10 +574,10 @@ def bilstm_layer(x, lens, wf, wr, mode=None):
     T, B, _ = x.shape
     H = wf[1].shape[1]
     import os
-    if mode == L.FT_BF16 and os.environ.get("FLOWTRON_BILSTM", "1") != "0" and L.lib().ft_lstm_bidir_supported(B, H):
+    if L.is16(mode) and os.environ.get("FLOWTRON_BILSTM", "1") != "0" and L.lib().ft_lstm_bidir_supported(B, H):
         gx_f = LinearFn.apply(wf[0], wf[2] + wf[3], L.ACT_NONE, mode, x)
         gx_r = LinearFn.apply(wr[0], wr[2] + wr[3], L.ACT_NONE, mode, x)
-        return BiLSTMSeqFn.apply(gx_f, gx_r, wf[1], wr[1], lens)
+        return BiLSTMSeqFn.apply(gx_f, gx_r, wf[1], wr[1], lens, mode)
     yf = lstm_layer(x, lens, *wf, reverse=False, mode=mode)
     yb = lstm_layer(x, lens, *wr, reverse=True, mode=mode)
     return torch.cat([yf, yb], 2)
@@ -866,7 +871,8 @@ class LSTM2SeqFn(torch.autograd.Function):
     """y1 = LSTM_l1(LSTM_l0(gx0)); gx0 = x W_ih0^T + b0 comes from LinearFn.  bf16 MFMA operands, forward direction."""
 
     @staticmethod
-    def forward(ctx, gx0, w_hh0, w_ih1, b_ih1, b_hh1, w_hh1, lens):
+    def forward(ctx, gx0, w_hh0, w_ih1, b_ih1, b_hh1, w_hh1, lens, mode=L.FT_BF16):
+        ctx.mode = mode
         gx0, w_hh0, w_ih1, w_hh1 = _c(gx0), _c(w_hh0), _c(w_ih1), _c(w_hh1)
         L.require_cuda(gx0, w_hh0, w_ih1, w_hh1, lens)
         T, B, H4 = gx0.shape
@@ -877,7 +883,7 @@ class LSTM2SeqFn(torch.autograd.Function):
         cell0, cell1 = torch.empty(T, B, H, **f), torch.empty(T, B, H, **f)
         bias1 = (b_ih1 + b_hh1).contiguous()
         work = torch.empty(L.lib().ft_lstm2_workspace_bytes(B, H), device=gx0.device, dtype=torch.uint8)
-        L.check(L.lib().ft_lstm2_seq_fwd(L.ptr(gx0), L.ptr(w_hh0), L.ptr(w_ih1), L.ptr(bias1), L.ptr(w_hh1), L.ptr(lens), L.ptr(y0),
+        L.check(L.op16("ft_lstm2_seq_fwd", mode)(L.ptr(gx0), L.ptr(w_hh0), L.ptr(w_ih1), L.ptr(bias1), L.ptr(w_hh1), L.ptr(lens), L.ptr(y0),
                                          L.ptr(gates0), L.ptr(cell0), L.ptr(y1), L.ptr(gates1), L.ptr(cell1), L.ptr(work), T, B, H,
                                          L.stream()), "ft_lstm2_seq_fwd")
         ctx.save_for_backward(w_hh0, w_ih1, w_hh1, lens, y0, gates0, cell0, y1, gates1, cell1)
@@ -891,10 +897,10 @@ class LSTM2SeqFn(torch.autograd.Function):
         dgx0 = torch.empty(T, B, 4 * H, device=dy1.device, dtype=torch.float32)
         dgx1 = torch.empty_like(dgx0)
         work = torch.empty(L.lib().ft_lstm2_workspace_bytes(B, H), device=dy1.device, dtype=torch.uint8)
-        L.check(L.lib().ft_lstm2_seq_bwd(L.ptr(dy1), L.ptr(w_hh0), L.ptr(w_ih1), L.ptr(w_hh1), L.ptr(lens), L.ptr(gates0), L.ptr(cell0),
+        L.check(L.op16("ft_lstm2_seq_bwd", ctx.mode)(L.ptr(dy1), L.ptr(w_hh0), L.ptr(w_ih1), L.ptr(w_hh1), L.ptr(lens), L.ptr(gates0), L.ptr(cell0),
                                          L.ptr(gates1), L.ptr(cell1), L.ptr(dgx0), L.ptr(dgx1), L.ptr(work), T, B, H, L.stream()),
                 "ft_lstm2_seq_bwd")
-        mode = L.FT_BF16
+        mode = ctx.mode
         rows = T * B
         dW_hh0 = torch.zeros_like(w_hh0)
         dW_hh1 = torch.zeros_like(w_hh1)
@@ -904,8 +910,8 @@ class LSTM2SeqFn(torch.autograd.Function):
         if T > 1 and images_apply(mode, 4 * H, H, r1):
             # four images serve the three weight-gradient GEMMs (the one-step shift is a row offset) and, through the
             # hand-off, the dX / dW GEMMs of the layer-0 input projection
-            d0, d1 = Bf16Image(dgx0.reshape(rows, 4 * H), colsum=True), Bf16Image(dgx1.reshape(rows, 4 * H), colsum=True)
-            i0, i1 = Bf16Image(y0.reshape(rows, H)), shared_image(y1, rows, H)
+            d0, d1 = Bf16Image(dgx0.reshape(rows, 4 * H), colsum=True, mode=mode), Bf16Image(dgx1.reshape(rows, 4 * H), colsum=True, mode=mode)
+            i0, i1 = Bf16Image(y0.reshape(rows, H), mode=mode), shared_image(y1, rows, H, mode)
             gemm_img(d0, 1, d0.ptr(B), i0, 1, i0.ptr(), dW_hh0, 4 * H, H, r1, H, splitk=True)
             gemm_img(d1, 1, d1.ptr(B), i1, 1, i1.ptr(), dW_hh1, 4 * H, H, r1, H, splitk=True)
             gemm_img(d1, 1, d1.ptr(), i0, 1, i0.ptr(), dW_ih1, 4 * H, H, rows, H, splitk=True)
@@ -918,9 +924,9 @@ class LSTM2SeqFn(torch.autograd.Function):
             gemm_raw(dgx1, y0, dW_ih1, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=mode, splitk=True)
         if db1 is None:
             db1 = colsum(dgx1, rows, 4 * H, 4 * H)
-        return dgx0, dW_hh0, dW_ih1, db1, db1, dW_hh1, None
+        return dgx0, dW_hh0, dW_ih1, db1, db1, dW_hh1, None, None
 
 
 def lstm2_supported(B, H, mode):
     import os
-    return (mode == L.FT_BF16 and os.environ.get("FLOWTRON_LSTM2", "1") != "0" and bool(L.lib().ft_lstm2_supported(B, H)))
+    return (L.is16(mode) and os.environ.get("FLOWTRON_LSTM2", "1") != "0" and bool(L.lib().ft_lstm2_supported(B, H)))

@@ -18,6 +18,12 @@
  *     FT_F32 = fp32 operands (v_mfma_f32_16x16x4_f32, exact fp32, parity mode),
  *     FT_BF16 = operands rounded to bf16 on the way into the matrix core
  *     (v_mfma_f32_16x16x32_bf16), fp32 accumulate.  Storage stays fp32.
+ *     FT_F16 = the same code path with fp16 operands (v_mfma_f32_16x16x32_f16):
+ *     the reference's fp16 AMP configuration (train.py:254,292).  Values beyond
+ *     65504 round to +-inf, which is what torch's GradScaler inf check expects.
+ *     Entry points with a `mode` argument accept FT_F16 directly; the ones that
+ *     consume or produce 16-bit images / fragments without a mode argument have
+ *     a twin of identical signature and the suffix _f16 (end of this header).
  *   - time-major activations: [T,B,C] row-major, like the reference's
  *     internal layout after flowtron.py:884.
  */
@@ -31,10 +37,10 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 3
+#define FT_ABI_VERSION 4
 
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
-enum { FT_F32 = 0, FT_BF16 = 1 };
+enum { FT_F32 = 0, FT_BF16 = 1, FT_F16 = 2 };
 enum { FT_ACT_NONE = 0, FT_ACT_TANH = 1, FT_ACT_RELU = 2, FT_ACT_SIGMOID = 3 };
 enum { FT_GEMM_SPLITK = 1 };
 
@@ -320,6 +326,35 @@ int ft_sumsq(const float* x, float* acc, int64_t n, void* stream);
 int ft_radam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   const float* gnorm_sq_dev, double clip, double lr, double beta1, double beta2, double eps,
                   double weight_decay, double step_size, int rectified, void* stream);
+
+/* ---- fp16-operand twins (FT_F16): same signatures, semantics and workspace queries as the entries they are named after;
+ * 16-bit images / fragments made by a twin must only be fed to twins. ---- */
+int ft_gemm_f16(const ft_gemm_args* a, void* stream);
+int ft_bf16_image_f16(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, void* stream);
+int ft_bf16_image_colsum_f16(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, float* colsum, void* stream);
+int ft_gemm_img_f16(const ft_gemm_img_args* a, void* stream);
+int ft_lstm_seq_fwd_f16(const float* gx, const float* w_hh, const int32_t* lens,
+                    float* y, int64_t ldy, float* gates, float* cell, void* work,
+                    int T, int B, int H, int reverse, int mode, void* stream);
+int ft_lstm_seq_bwd_f16(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens,
+                    const float* gates, const float* cell, float* dgx, void* work,
+                    int T, int B, int H, int reverse, int mode, void* stream);
+int ft_lstm_persist_fwd_f16(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
+                        float* gates, float* cell, void* work, int32_t* status, int T, int B, int H, int ng, void* stream);
+int ft_lstm_persist_bwd_f16(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
+                        const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng, void* stream);
+int ft_lstm2_seq_fwd_f16(const float* gx0, const float* w_hh0, const float* w_ih1, const float* bias1, const float* w_hh1,
+                     const int32_t* lens, float* y0, float* gates0, float* cell0, float* y1, float* gates1, float* cell1,
+                     void* work, int T, int B, int H, void* stream);
+int ft_lstm2_seq_bwd_f16(const float* dy1, const float* w_hh0, const float* w_ih1, const float* w_hh1, const int32_t* lens,
+                     const float* gates0, const float* cell0, const float* gates1, const float* cell1,
+                     float* dgx0, float* dgx1, void* work, int T, int B, int H, void* stream);
+int ft_lstm_bidir_seq_fwd_f16(const float* gx_f, const float* gx_r, const float* w_hh_f, const float* w_hh_r,
+                          const int32_t* lens, float* y, int64_t ldy, float* gates_f, float* gates_r,
+                          float* cell_f, float* cell_r, void* work_f, void* work_r, int T, int B, int H, void* stream);
+int ft_lstm_bidir_seq_bwd_f16(const float* dy, int64_t ldy, const float* w_hh_f, const float* w_hh_r, const int32_t* lens,
+                          const float* gates_f, const float* gates_r, const float* cell_f, const float* cell_r,
+                          float* dgx_f, float* dgx_r, void* work_f, void* work_r, int T, int B, int H, void* stream);
 
 #ifdef __cplusplus
 }

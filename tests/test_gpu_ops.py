@@ -527,25 +527,31 @@ def test_bidirectional_pair_chain_equals_two_chains(env, monkeypatch, B, T):
     assert mad(res[0][0], ref) < 3e-2
 
 
+@pytest.mark.parametrize("fmt", [1, 2])               # FT_BF16 | FT_F16 (the _f16 twins)
 @pytest.mark.parametrize("rows,cols,off", [(1000, 300, 0), (257, 4096, 0), (31, 80, 1), (2050, 136, 0)])
-def test_bf16_image_and_fused_column_sums(env, rows, cols, off):
-    """ft_bf16_image / ft_bf16_image_colsum: the image is bit-identical to torch's RNE bf16 cast, zero outside the
+def test_bf16_image_and_fused_column_sums(env, rows, cols, off, fmt):
+    """ft_bf16_image / ft_bf16_image_colsum: the image is bit-identical to torch's RNE bf16 (fp16) cast, zero outside the
     logical extent ([ceil256(rows+32)][ceil256(cols)]); the fused column sums equal the fp32 sums of the SOURCE
     (tolerance: fp32 summation order over <= 2050 rows)."""
     L, ops = env
     torch.manual_seed(rows + cols)
     wide = torch.randn(rows, cols + off + 3)
+    # exact ties of both formats, fp16 subnormals, the fp16 overflow boundary (65520 is the first value that rounds to inf)
+    special = [1 + 2.0 ** -11, 1 + 3 * 2.0 ** -11, 1 + 2.0 ** -8, 1 + 3 * 2.0 ** -8, 3e-6, -3e-6, 6.0e-8, 65519.0, 65520.0, -1e5]
+    wide[0, off:off + len(special)] = torch.tensor(special)
     src = g(wide)[:, off:off + cols]                       # strided view; off = 1 makes the rows only 4-byte aligned
     for with_sum in (False, True):
-        img = ops.Bf16Image(src, colsum=with_sum)
+        img = ops.Bf16Image(src, colsum=with_sum, mode=fmt)
         Rp, ld = (rows + 32 + 255) // 256 * 256, (cols + 255) // 256 * 256
         assert img.ld == ld and img.buf.numel() >= Rp * ld * 2
         raw = img.buf[:Rp * ld * 2].view(torch.int16).view(Rp, ld).cpu()
-        ref = wide[:, off:off + cols].to(torch.bfloat16).view(torch.int16)
+        ref = wide[:, off:off + cols].to(torch.bfloat16 if fmt == 1 else torch.float16).view(torch.int16)
         assert torch.equal(raw[:rows, :cols], ref)
         assert int(raw[rows:].abs().max()) == 0 and (cols == ld or int(raw[:, cols:].abs().max()) == 0)
         if with_sum:
-            assert mad(img.colsum, wide[:, off:off + cols].double().sum(0).float()) < 2e-4 * math.sqrt(rows)
+            view = wide[:, off:off + cols]
+            err = (img.colsum.cpu() - view.double().sum(0).float()).abs()
+            assert bool((err < 2e-4 * math.sqrt(rows) + 1e-6 * view.abs().sum(0)).all()), err.max()
 
 
 @pytest.mark.parametrize("ng", [1, 9, 8, 4, 2])   # 1 | 9 = XCD-local transport with nt | sc1 loads (8 groups = 8 XCDs)

@@ -31,7 +31,8 @@ def _run(tmp_path, monkeypatch, mode, fp16_run, model_overrides, iters=4, checkp
     return ref_loop.train(cfg, iters), cfg
 
 
-@pytest.mark.parametrize("mode,fp16_run", [("f32", False), ("bf16", False), ("bf16", True)])
+# ("auto", True): FLOWTRON_MFMA unset/auto + the loop's amp.autocast(float16) -> the fp16 operand kernels, as in the reference's AMP run
+@pytest.mark.parametrize("mode,fp16_run", [("f32", False), ("bf16", False), ("bf16", True), ("f16", True), ("auto", True)])
 def test_training_loop_checkpoint_resume_and_inference(tmp_path, monkeypatch, mode, fp16_run):
     import ref_loop
     out, cfg = _run(tmp_path, monkeypatch, mode, fp16_run, SMALL, iters=5)
