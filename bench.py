@@ -5,8 +5,8 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-One step = zero_grad + Flowtron.forward + FlowtronLoss (NLL + gate + attention-CTC) + backward (with the single
-flat-arena RCCL all-reduce when N > 1) + global-norm clip + fused RAdam update, on BASELINE.json configs[1]:
+One step = zero_grad + Flowtron.forward + FlowtronLoss (NLL + gate + attention-CTC) + backward (with the in-place RCCL
+all-reduce(AVG) of the flat gradient arena, one bucket per flow launched under the remaining backward, when N > 1) + global-norm clip + fused RAdam update, on BASELINE.json configs[1]:
 2-flow LJS config.json model, 80-bin mels, per-GPU batch 32 of LJSpeech-shaped synthetic utterances (<= 10 s),
 attention prior + CTC on, bf16 MFMA operands with fp32 accumulate/storage.  Weak scaling: every rank processes its
 own 32 utterances.  value = valid mel frames (sum of out_lens over all ranks and steps) / wall time.
@@ -501,7 +501,7 @@ def main():
                                        "libritts": "BASELINE configs[2]: 2-flow LibriTTS model (123 speakers)",
                                        "libritts_fp16": "BASELINE configs[4]: 2-flow LibriTTS model (123 speakers), fp16 operands + GradScaler"}[args.config],
                                       args.batch, T, Lk, "attn-prior" if use_prior else "no attn-prior",
-                                      "unscale+" if scaler.is_enabled() else "", ", 1 flat RCCL all-reduce/step" if world > 1 else ""),
+                                      "unscale+" if scaler.is_enabled() else "", ", per-flow bucketed RCCL all-reduce(AVG) under backward" if world > 1 else ""),
                        "global_batch": args.batch * world, "valid_frames_per_step": int(frames_all),
                        "padded_frames_per_step": args.batch * T * world, "parallelism": "dp%d" % world,
                        "mfma_operands": args.mfma, "storage": "fp32", "final_loss": round(loss_val, 5)},

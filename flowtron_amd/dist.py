@@ -6,7 +6,8 @@ reference (distributed.py:96-120)                 here
 -------------------------------------------------  ------------------------------------------------
 per step: torch.cat of 68 grads (244 MB copy),     ONE persistent flat fp32 gradient arena; every
 all_reduce, /= world, 68 copy_ back                 param.grad is a VIEW into it, so the step is a
-                                                    single in-place RCCL all-reduce(AVG) of the arena
+                                                    in-place RCCL all-reduce(AVG) of the arena, one
+                                                    bucket per flow, launched as its gradients complete
 68 parameter broadcasts at start-up                 one broadcast of a flat parameter arena
 4 scalar all-reduces + .item() per step             reduce_tensors(): one 4-float all-reduce
 
@@ -47,12 +48,28 @@ def init_distributed(rank, num_gpus, dist_backend="nccl", dist_url=None):
                                 init_method="tcp://" + master_ip + ":" + master_port)
 
 
-def _avg_all_reduce(flat: torch.Tensor):
-    ws = dist.get_world_size()
-    if ws == 1:
-        return
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)              # one in-place ring/mesh reduction of the whole arena
-    flat /= ws
+def _avg_op():
+    """RCCL divides inside the reduction kernel (ReduceOp.AVG): no separate 244 MB `flat /= world_size` pass.  gloo (the CPU
+    test backend) has no AVG: SUM, then divide."""
+    return dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM
+
+
+def _avg_all_reduce(flat: torch.Tensor, async_op: bool = False):
+    """in-place average of `flat` over the ranks; async_op=True returns a waitable (call _finish on it)."""
+    op = _avg_op()
+    work = dist.all_reduce(flat, op=op, async_op=async_op)
+    if async_op:
+        return (work, flat, op)
+    if op == dist.ReduceOp.SUM:
+        flat /= dist.get_world_size()
+    return None
+
+
+def _finish(pending):
+    work, flat, op = pending
+    work.wait()                                               # the compute stream now waits for the collective's stream
+    if op == dist.ReduceOp.SUM:
+        flat /= dist.get_world_size()
 
 
 def reduce_tensor(tensor, num_gpus):
@@ -117,13 +134,14 @@ class FlatArena:
         self.flat_grad.zero_()
         self.adopt_stray_grads(copy=False)
 
-    def adopt_stray_grads(self, copy=True):
+    def adopt_stray_grads(self, copy=True, only=None):
         """If something replaced p.grad (e.g. torch's default zero_grad(set_to_none=True) followed by backward), pull it
         back into the arena so the single-collective path stays valid.  A parameter whose grad is None got NO gradient:
         with copy=True its arena slice is zeroed (the slice still holds the previous iteration's values) and it is
         reported back as (offset, numel) so that the optimizer can skip it like radam.py:57-58; its .grad stays None."""
         skipped = []
-        for p, off in zip(self.params, self.offsets):
+        items = zip(self.params, self.offsets) if only is None else ((self.params[i], self.offsets[i]) for i in only)
+        for p, off in items:
             k = p.numel()
             g = p.grad
             if g is None:
@@ -140,29 +158,91 @@ class FlatArena:
         return skipped
 
 
+def gradient_buckets(module, arena: "FlatArena"):
+    """Contiguous arena ranges that become final together during backward: one per flow (`flows.<i>.*`) and one per run of
+    adjacent non-flow parameters (embeddings, encoder: their gradients complete last because every flow reads the encoder
+    output), named after the top-level modules it covers.  Returns [(name, lo, hi, [param indices])] in arena order."""
+    names = {id(p): n for n, p in module.named_parameters()}
+    groups = []
+    for i, p in enumerate(arena.params):
+        n = names.get(id(p), "")
+        flow = n.startswith("flows.")
+        key = ".".join(n.split(".")[:2]) if flow else n.split(".")[0]
+        if groups and (groups[-1][0] == key if flow else not groups[-1][2]):
+            groups[-1][1].append(i)
+            if not flow and key not in groups[-1][0].split("+"):
+                groups[-1][0] += "+" + key
+        else:
+            groups.append([key, [i], flow])
+    out = []
+    for key, idx, _ in groups:
+        lo = arena.offsets[idx[0]]
+        hi = arena.offsets[idx[-1] + 1] if idx[-1] + 1 < len(arena.offsets) else arena.numel
+        out.append((key, lo, hi, idx))
+    return out
+
+
 def apply_gradient_allreduce(module):
-    """distributed.py:81-133: same contract (the module keeps its class; gradients are averaged across ranks
-    once per backward), implemented as ONE in-place all-reduce of a persistent flat gradient arena."""
+    """distributed.py:81-133: same contract (the module keeps its class; gradients are averaged across ranks once per
+    backward).  The persistent flat gradient arena is reduced IN PLACE, bucket by bucket: a bucket (one flow's parameters,
+    ~120 MB) is handed to RCCL the moment the last of its gradients has been accumulated (post-accumulate-grad hooks), so
+    the all-reduce of flow F-1 runs on RCCL's stream under the backward recurrences of flows F-2 .. 0 -- launch chains that
+    leave most of the chip idle -- and only the last bucket (embeddings + encoder, 9 MB) is exposed.  Whatever was not
+    launched by then (parameters without a gradient) is reduced by the end-of-backward callback, which also waits.
+    FLOWTRON_DP_BUCKETS=1 falls back to ONE all-reduce of the whole arena at the end of backward."""
     ws = dist.get_world_size() if dist.is_initialized() else 1
     arena = FlatArena.for_params(list(module.parameters()), flatten_params=True)
     module._grad_arena = arena
-    if ws > 1:
+    if dist.is_initialized():
         dist.broadcast(arena.flat_param, 0)                      # C1: one broadcast instead of 68
         for b in module.buffers():
             dist.broadcast(b, 0)
     module.needs_reduction = True
+    bucketed = os.environ.get("FLOWTRON_DP_BUCKETS", "flow") != "1"
+    buckets = gradient_buckets(module, arena) if bucketed else [("all", 0, arena.numel, list(range(len(arena.params))))]
+    bucket_of = {}
+    for bi, (_, _, _, idx) in enumerate(buckets):
+        for i in idx:
+            bucket_of[id(arena.params[i])] = bi
+    state = {"left": [len(b[3]) for b in buckets], "launched": [False] * len(buckets), "pending": [], "queued": False}
+    module._grad_buckets = buckets
+    module._grad_bucket_log = []                                 # order in which buckets were launched in the last backward (tests)
 
-    def allreduce_params():
+    def launch(bi):
+        if state["launched"][bi] or not dist.is_initialized():
+            return
+        state["launched"][bi] = True
+        _, lo, hi, idx = buckets[bi]
+        arena.adopt_stray_grads(copy=True, only=idx)
+        module._grad_bucket_log.append(buckets[bi][0])
+        state["pending"].append(_avg_all_reduce(arena.flat_grad[lo:hi], async_op=True))
+
+    def finish_backward():
+        state["queued"] = False
         if module.needs_reduction:
             module.needs_reduction = False
-            arena.adopt_stray_grads(copy=True)
-            _avg_all_reduce(arena.flat_grad)                     # C2: the only per-step collective
+            for bi in range(len(buckets)):                       # leftovers: buckets with a gradient-less parameter
+                launch(bi)
+            for pend in state["pending"]:
+                _finish(pend)
+        state["pending"] = []
+        state["left"] = [len(b[3]) for b in buckets]
+        state["launched"] = [False] * len(buckets)
 
-    def allreduce_hook(*unused):
-        Variable._execution_engine.queue_callback(allreduce_params)
+    def on_grad(p):
+        if not module.needs_reduction:
+            return
+        if not state["queued"]:
+            state["queued"] = True
+            module._grad_bucket_log = []
+            Variable._execution_engine.queue_callback(finish_backward)
+        bi = bucket_of[id(p)]
+        state["left"][bi] -= 1
+        if bucketed and state["left"][bi] == 0:
+            launch(bi)
 
     for p in arena.params:
-        p.register_hook(allreduce_hook)
+        p.register_post_accumulate_grad_hook(on_grad)
 
     def set_needs_reduction(self, input, output):
         self.needs_reduction = True

@@ -9,6 +9,16 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
+def _plain(res):
+    """tensors cross the queue BY VALUE (numpy): torch's shared-memory handles need the sender alive at unpickling time"""
+    return {k: (v.detach().numpy().copy() if torch.is_tensor(v) else v) for k, v in res.items()}
+
+
+def _tensors(res):
+    import numpy as np
+    return {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in res.items()}
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -47,7 +57,7 @@ def _worker(rank, world, port, q):
     net(x).pow(2).mean().backward()
     res["g_stray"] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
     res["views2"] = all(arena._ptr_lo <= p.grad.data_ptr() < arena._ptr_hi for p in net.parameters())
-    q.put((rank, res))
+    q.put((rank, _plain(res)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,7 +70,7 @@ def test_two_rank_gradient_allreduce_gloo():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = dict(q.get(timeout=120) for _ in range(world))
+    out = {r: _tensors(v) for r, v in (q.get(timeout=120) for _ in range(world))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -84,3 +94,96 @@ def test_two_rank_gradient_allreduce_gloo():
     assert torch.allclose(r0["g0"], (gs[0] + gs[1]) / 2, atol=1e-6)
     assert abs(r0["rt"].item() - 1.5) < 1e-6
     assert torch.allclose(r0["rts"], torch.tensor([0.5, 2.0, 3.5, 0.5]))
+
+
+class _ToyFlows(torch.nn.Module):
+    """the parameter layout of Flowtron as the bucketing sees it: front (embedding + encoder) then flows.0, flows.1 ..;
+    forward runs flows 0 .. F-1 on the encoder output, so backward completes flows.F-1 first and the front last."""
+
+    def __init__(self, n_flows=3, with_unused=False):
+        super().__init__()
+        self.embedding = torch.nn.Embedding(11, 6)
+        self.encoder = torch.nn.Linear(6, 6)
+        self.flows = torch.nn.ModuleList([torch.nn.Sequential(torch.nn.Linear(12, 8), torch.nn.Tanh(), torch.nn.Linear(8, 6))
+                                          for _ in range(n_flows)])
+        if with_unused:
+            self.flows[1].register_parameter("unused", torch.nn.Parameter(torch.ones(5)))
+
+    def forward(self, ids, x):
+        enc = self.encoder(self.embedding(ids)).mean(1)
+        for f in self.flows:
+            x = x + f(torch.cat([x, enc], 1))
+        return x
+
+
+def _bucket_worker(rank, world, port, q, mode, with_unused):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["FLOWTRON_DP_BUCKETS"] = mode
+    import distributed as D
+    D.init_distributed(rank, world, "gloo", None)
+    torch.manual_seed(5)
+    net = D.apply_gradient_allreduce(_ToyFlows(3, with_unused))
+    torch.manual_seed(50 + rank)
+    ids, x = torch.randint(0, 11, (4, 3)), torch.randn(4, 6)
+    res = {"ids": ids, "x": x}
+    for it in range(2):
+        net.zero_grad()
+        net(ids, x).pow(2).mean().backward()
+        res["g%d" % it] = net._grad_arena.flat_grad.clone()
+        res["log%d" % it] = list(net._grad_bucket_log)
+    res["buckets"] = [(n, lo, hi) for n, lo, hi, _ in net._grad_buckets]
+    res["unused_grad_is_none"] = (not with_unused) or net.flows[1].unused.grad is None or float(net.flows[1].unused.grad.abs().sum()) == 0.0
+    q.put((rank, _plain(res)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_bucket_world(mode, with_unused):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q, mode, with_unused)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {r: _tensors(v) for r, v in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return out
+
+
+@pytest.mark.parametrize("with_unused", [False, True])
+def test_per_flow_buckets_overlap_order_and_equal_the_single_allreduce(with_unused):
+    """per-flow buckets: launched in the order backward completes them (last flow first, front last), every rank ends with
+    the same averaged arena, identical to FLOWTRON_DP_BUCKETS=1 (one all-reduce at the end) and to the mean of the local
+    gradients; a bucket holding a parameter that never gets a gradient is swept up by the end-of-backward callback."""
+    a = _run_bucket_world("flow", with_unused)
+    b = _run_bucket_world("1", with_unused)
+    names = [n for n, _, _ in a[0]["buckets"]]
+    assert names == ["embedding+encoder", "flows.0", "flows.1", "flows.2"]
+    los = [lo for _, lo, _ in a[0]["buckets"]]
+    his = [hi for _, _, hi in a[0]["buckets"]]
+    assert los[0] == 0 and los[1:] == his[:-1] and his[-1] == a[0]["g0"].numel()        # contiguous cover of the arena
+    for it in (0, 1):
+        if with_unused:     # flows.1 never completes by itself: launched by the final callback, after the front
+            assert a[0]["log%d" % it] == ["flows.2", "flows.0", "embedding+encoder", "flows.1"]
+        else:
+            assert a[0]["log%d" % it] == ["flows.2", "flows.1", "flows.0", "embedding+encoder"]
+        assert b[0]["log%d" % it] == ["all"]
+        assert torch.equal(a[0]["g%d" % it], a[1]["g%d" % it])
+        assert torch.allclose(a[0]["g%d" % it], b[0]["g%d" % it], atol=1e-7)
+    assert a[0]["unused_grad_is_none"]
+    # against the mean of the two local gradients
+    torch.manual_seed(5)
+    net = _ToyFlows(3, with_unused)
+    gs = []
+    for r in (0, 1):
+        net.zero_grad()
+        net(a[r]["ids"], a[r]["x"]).pow(2).mean().backward()
+        gs.append([p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in net.parameters()])
+    import distributed as D
+    arena = D.FlatArena(list(net.parameters()))
+    for p, off, g0, g1 in zip(arena.params, arena.offsets, gs[0], gs[1]):
+        assert torch.allclose(a[0]["g0"][off:off + p.numel()].view_as(p), (g0 + g1) / 2, atol=1e-6)

@@ -1,0 +1,144 @@
+"""Data-parallel path on the MI355X over RCCL (-m gpu): the drop-in `distributed.py` entry points on a real Flowtron module.
+  * world_size 1 (always runs on the 1-GPU box): init_process_group("nccl"), start-up broadcast, per-flow buckets handed to
+    RCCL from the post-accumulate-grad hooks with ReduceOp.AVG and async handles, stream wait at the end of backward -- the
+    gradients must equal those of the unwrapped module, the buckets must be launched last-flow-first, and an optimizer step
+    on the shared arena must work.
+  * world_size 2 (self-skips unless two GPUs are visible): two ranks, different utterances; both end with the same averaged
+    arena, equal to the mean of the two local gradients.
+Every world runs in spawned processes so the pytest process never owns a process group."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+SMALL = dict(n_text=64, n_text_dim=128, n_speaker_dim=32, n_attn_channels=64, n_hidden=128)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _local_grads(cfg, sd, batch, dev):
+    import flowtron
+    m = flowtron.Flowtron(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()               # eval() = the encoder's dropout off (gradients still flow): ranks / runs comparable
+    crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)
+    b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+    nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+    (nll + gl + 0.01 * ctc).backward()
+    return {k: p.grad.detach().float().cpu().numpy().copy() for k, p in m.named_parameters()}
+
+
+def _worker(rank, world, port, q, mode):
+    try:
+        for p_ in (ROOT, HERE):
+            if p_ not in sys.path:
+                sys.path.insert(0, p_)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FLOWTRON_MFMA=mode, LOCAL_RANK=str(rank),
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import distributed as D
+        import flowtron
+        from flowtron_amd.optim import RAdam
+        from oracle import synth
+        D.init_distributed(rank, world, "nccl", None)
+        dev = torch.device("cuda", rank)
+        cfg = dict(synth.DEFAULT_MODEL_CONFIG)
+        cfg.update(SMALL)
+        cfg["n_flows"] = 2
+        sd = synth.make_state_dict(cfg, seed=3)
+        lens = ([40, 33, 21], [12, 9, 7]) if rank == 0 else ([37, 30, 25], [11, 10, 6])
+        batch = synth.make_batch(cfg, lens[0], lens[1], seed=10 + rank, with_prior=True)
+        local = _local_grads(cfg, sd, batch, dev)
+        torch.manual_seed(1000 + rank)                                 # different init per rank: the broadcast must equalise
+        m = flowtron.Flowtron(**cfg).to(dev).eval()
+        if rank == 0:
+            m.load_state_dict(sd)
+        opt = RAdam(m.parameters(), lr=1e-3, weight_decay=1e-6)       # optimizer first, wrapper second (train.py:230,251)
+        m = D.apply_gradient_allreduce(m)
+        crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)
+        b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        res = {"local": local}
+        w_before = m._grad_arena.flat_param.detach().cpu().numpy().copy()
+        for it in range(2):
+            m.zero_grad()
+            out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+            nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+            (nll + gl + 0.01 * ctc).backward()
+            torch.cuda.synchronize()
+            res["log%d" % it] = list(m._grad_bucket_log)
+            res["g%d" % it] = {k: p.grad.detach().float().cpu().numpy().copy() for k, p in m.named_parameters()}
+        res["w_before"] = w_before
+        opt.clip_grad_norm_(1.0)
+        opt.step()
+        torch.cuda.synchronize()
+        res["w_after"] = m._grad_arena.flat_param.detach().cpu().numpy().copy()
+        res["shares_arena"] = opt.arena is m._grad_arena
+        res["backend"] = torch.distributed.get_backend()
+        res["loss"] = float(D.reduce_tensor(nll.detach(), world))
+        q.put((rank, res))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception as e:                                             # the parent must not wait for the queue timeout
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+
+
+def _run(world, mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=500) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    for r in out.values():
+        assert "error" not in r, r.get("error")
+    return out
+
+
+def _close(a, b, tol):
+    import numpy as np
+    return float(np.abs(a - b).max()) <= tol * (float(np.abs(b).max()) + 1e-12) + 1e-9
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_rccl_single_rank_bucketed_allreduce_is_the_identity(mode):
+    out = _run(1, mode)[0]
+    assert out["backend"] == "nccl" and out["shares_arena"]
+    for it in (0, 1):
+        log = out["log%d" % it]          # last flow first; the encoder and the embeddings (read by every flow) complete last
+        assert log[:2] == ["flows.1", "flows.0"] and sorted(log[2:]) == ["encoder", "speaker_embedding+embedding"], log
+        for k, g in out["g%d" % it].items():
+            # AVG over one rank; split-K atomics make run-to-run bits differ slightly in the weight gradients
+            assert _close(g, out["local"][k], 2e-5 if mode == "f32" else 2e-3), (k, it)
+    import numpy as np
+    assert np.isfinite(out["w_after"]).all() and np.abs(out["w_after"] - out["w_before"]).max() > 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_rccl_two_ranks_average_gradients():
+    out = _run(2, "f32")
+    r0, r1 = out[0], out[1]
+    import numpy as np
+    assert np.array_equal(r0["w_before"], r1["w_before"])               # start-up broadcast from rank 0
+    for k in r0["g0"]:
+        assert np.array_equal(r0["g0"][k], r1["g0"][k]), k               # every rank holds the same reduced arena
+        assert _close(r0["g0"][k], 0.5 * (r0["local"][k] + r1["local"][k]), 2e-5), k
+    assert r0["log0"][:2] == ["flows.1", "flows.0"] and len(r0["log0"]) == 4
+    assert np.array_equal(r0["w_after"], r1["w_after"]) and abs(r0["loss"] - r1["loss"]) < 1e-6
