@@ -189,7 +189,15 @@ def apply_gradient_allreduce(module):
     the all-reduce of flow F-1 runs on RCCL's stream under the backward recurrences of flows F-2 .. 0 -- launch chains that
     leave most of the chip idle -- and only the last bucket (embeddings + encoder, 9 MB) is exposed.  Whatever was not
     launched by then (parameters without a gradient) is reduced by the end-of-backward callback, which also waits.
-    FLOWTRON_DP_BUCKETS=1 falls back to ONE all-reduce of the whole arena at the end of backward."""
+    FLOWTRON_DP_BUCKETS=1 falls back to ONE all-reduce of the whole arena at the end of backward.
+
+    Co-residency rule.  The persistent recurrence kernels (csrc/lstm_persist.hip) need all 256 CUs at once, one workgroup
+    per CU owning the whole register file, and spin on each other: an RCCL kernel that is only partly resident beside a partly
+    resident persistent grid on two ranks can wait on each other across ranks (ring channel c needs channel c resident on
+    every rank) until the persistent kernel's 0.5 s timeout fires.  So when the forward pass of this step used them, the
+    buckets are NOT launched under backward: they go out back to back from the end-of-backward callback, when nothing else
+    is queued on the device (still in place, still AVG-folded, still pipelined bucket after bucket).  The overlap applies to
+    the launch-per-step kernels (FLOWTRON_LSTM_PERSIST=0, batches > 32, H != 1024).  FLOWTRON_DP_OVERLAP=1 | 0 overrides."""
     ws = dist.get_world_size() if dist.is_initialized() else 1
     arena = FlatArena.for_params(list(module.parameters()), flatten_params=True)
     module._grad_arena = arena
@@ -204,7 +212,16 @@ def apply_gradient_allreduce(module):
     for bi, (_, _, _, idx) in enumerate(buckets):
         for i in idx:
             bucket_of[id(arena.params[i])] = bi
-    state = {"left": [len(b[3]) for b in buckets], "launched": [False] * len(buckets), "pending": [], "queued": False}
+    state = {"left": [len(b[3]) for b in buckets], "launched": [False] * len(buckets), "pending": [], "queued": False,
+             "persist_before": 0, "overlap": True}
+    force = os.environ.get("FLOWTRON_DP_OVERLAP", "auto")
+
+    def persist_launches():
+        try:
+            from . import ops
+            return ops.PERSIST_LAUNCHES
+        except Exception:                                        # CPU-only host (gloo tests): no HIP library, no persistent kernels
+            return 0
     module._grad_buckets = buckets
     module._grad_bucket_log = []                                 # order in which buckets were launched in the last backward (tests)
 
@@ -238,15 +255,21 @@ def apply_gradient_allreduce(module):
             Variable._execution_engine.queue_callback(finish_backward)
         bi = bucket_of[id(p)]
         state["left"][bi] -= 1
-        if bucketed and state["left"][bi] == 0:
+        if bucketed and state["overlap"] and state["left"][bi] == 0:
             launch(bi)
 
     for p in arena.params:
         p.register_post_accumulate_grad_hook(on_grad)
 
+    def before_forward(self, input):
+        state["persist_before"] = persist_launches()
+
     def set_needs_reduction(self, input, output):
         self.needs_reduction = True
+        used_persistent = persist_launches() != state["persist_before"]
+        state["overlap"] = (force == "1") or (force != "0" and not used_persistent)
 
+    module.register_forward_pre_hook(before_forward)
     module.register_forward_hook(set_needs_reduction)
 
     def zero_grad(set_to_none: bool = False):                    # keep grads inside the arena (train.py:282)

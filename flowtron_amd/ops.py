@@ -383,7 +383,12 @@ def _persist_watch(device):
     return st
 
 
+PERSIST_LAUNCHES = 0          # persistent (whole-chip, co-resident) kernel launches so far: dist.py keeps collectives away from them
+
+
 def _persist_arm(st):
+    global PERSIST_LAUNCHES
+    PERSIST_LAUNCHES += 1
     st.host.copy_(st.status, non_blocking=True)
     st.event = torch.cuda.Event()
     st.event.record()

@@ -43,7 +43,7 @@ def _local_grads(cfg, sd, batch, dev):
     return {k: p.grad.detach().float().cpu().numpy().copy() for k, p in m.named_parameters()}
 
 
-def _worker(rank, world, port, q, mode):
+def _worker(rank, world, port, q, mode, full_width=False):
     try:
         for p_ in (ROOT, HERE):
             if p_ not in sys.path:
@@ -57,7 +57,8 @@ def _worker(rank, world, port, q, mode):
         D.init_distributed(rank, world, "nccl", None)
         dev = torch.device("cuda", rank)
         cfg = dict(synth.DEFAULT_MODEL_CONFIG)
-        cfg.update(SMALL)
+        if not full_width:
+            cfg.update(SMALL)
         cfg["n_flows"] = 2
         sd = synth.make_state_dict(cfg, seed=3)
         lens = ([40, 33, 21], [12, 9, 7]) if rank == 0 else ([37, 30, 25], [11, 10, 6])
@@ -97,11 +98,11 @@ def _worker(rank, world, port, q, mode):
         q.put((rank, {"error": traceback.format_exc()}))
 
 
-def _run(world, mode):
+def _run(world, mode, full_width=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, full_width)) for r in range(world)]
     for p in procs:
         p.start()
     out = dict(q.get(timeout=500) for _ in range(world))
@@ -129,6 +130,16 @@ def test_rccl_single_rank_bucketed_allreduce_is_the_identity(mode):
             assert _close(g, out["local"][k], 2e-5 if mode == "f32" else 2e-3), (k, it)
     import numpy as np
     assert np.isfinite(out["w_after"]).all() and np.abs(out["w_after"] - out["w_before"]).max() > 0
+
+
+def test_rccl_buckets_wait_for_the_end_of_backward_when_the_persistent_recurrences_ran():
+    """H = 1024, bf16: the step goes through lstm_persist_{fwd,bwd}_k (whole-chip co-resident grids), so no collective may be
+    in flight beside them (dist.py, co-residency rule): the buckets leave in arena order from the end-of-backward callback."""
+    out = _run(1, "bf16", full_width=True)[0]
+    for it in (0, 1):
+        assert out["log%d" % it] == ["speaker_embedding+embedding", "flows.0", "flows.1", "encoder"], out["log%d" % it]
+        for k, g in out["g%d" % it].items():
+            assert _close(g, out["local"][k], 2e-3), (k, it)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
