@@ -98,7 +98,19 @@ __device__ __forceinline__ unsigned row_shl(unsigned v) {
     else return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xf, 0xf, true);
 }
 
-constexpr int SB = 32;                   // steps per HBM burst (LDS staging of the rows the recurrence reads from HBM)
+// Staging of the HBM rows the recurrence reads.
+// Forward: gx rows arrive in synchronous bursts of SB steps (one HBM round trip per 32 steps, ~0.1 us per step).
+// Backward (saved gates, cell, dy: 6 rows per step, 97 KB per burst -- measured 20 us of whole-workgroup stall per 32 steps,
+// 0.6 us per step): a RING of LDS slots, one step per slot, filled DIST steps ahead by LDS-DMA from waves 2-3 -- six dwords per
+// lane and step, issued right after the reduce barrier together with the output stores of the previous step.  Those waves have
+// ~1 us of slack per step (they wait for the group's publish), which hides the HBM round trip that, vmcnt retiring in order,
+// sits in front of their next poll; the forward kernel's waves have no such slack (tried: 1.93 -> 2.15 us per step), and a DMA
+// issued BEFORE the barrier stalls everybody (LDS-DMA also counts in lgkmcnt, which every LDS barrier has to drain).
+// Slot reuse: the occupant of slot m % RING (step m - RING) is last read in step m - RING + 1 (cell ring); its successor is
+// requested in step m - DIST > m - RING + 1.
+constexpr int SB = 32;
+constexpr int RING = 8, DIST = 6;
+static_assert(DIST < RING - 1, "slot reuse");
 
 // XCD census (LOCAL transport): group = this workgroup's XCC id, slot = arrival order inside that XCD
 template <int CPG>
@@ -363,7 +375,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
 // state (RPGP x 4H bf16), so a wave sweeps its 32 chunks in 4 batches of 8 with the next batch's loads in flight.
 // Accumulation mimics lstm_bwd_step_bf16's 16-wave split (partial a of wave w = chunks w+4a, w+4a+16, ..; the 16 partials
 // are summed in wave order), so the result is bit-identical to the launch-per-step kernel.  Saved gates / cell / dy come
-// in, and dgx goes out, through the same SB-step LDS bursts as the forward kernel.
+// in through the same LDS ring as the forward kernel (dgx goes out from waves 2-3).
 struct PersistBwdP {
     const float* dy; long ldy; const int* lens;
     const float* gates; const float* cell; float* dgx;
@@ -390,12 +402,12 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     constexpr int NBT = NLG > 8 ? 2 : 1, LPB = NLG / NBT;   // sweep batches per step (<= 16 loads in flight each), load groups per batch
     static_assert(TL >= 1, "NG = 2 would leave half a column tile per CU");
     static_assert(NE == 128, "one epilogue element per thread of waves 0-1");
-    // LDS: 16-partial reduce (double buffered) | SB steps in [i][gates x4, dy][e] | SB+1 cells [i][e] | 2 steps out [parity][4][e]
+    // LDS: 16-partial reduce (double buffered) | RING steps in [slot][gates x4, dy][e] | RING cells [slot][e] | 2 steps out [parity][4][e]
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float (*red)[16][TL][RPGP][17] = reinterpret_cast<float (*)[16][TL][RPGP][17]>(smem);
     float* ins = smem + 2 * 16 * TL * RPGP * 17;
-    float* cells = ins + SB * 5 * NE;
-    float* outs = cells + (SB + 1) * NE;
+    float* cells = ins + RING * 5 * NE;
+    float* outs = cells + RING * NE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
@@ -430,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     }
     tg = tg < T ? tg : T;
 
-    // step counter n = 0 .. tg-1 walks time s = tg-1-n downwards; burst k stages steps n in [k SB, (k+1) SB)
+    // step counter n = 0 .. tg-1 walks time s = tg-1-n downwards
     // output role of waves 2-3 (see the forward kernel): thread tid >= 128 stores the dgx row of the previous step
     const int oe = tid - NE;
     const int ob = b0 + oe / UPC, ou = q * UPC + oe % UPC;
@@ -441,36 +453,30 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
         float* dg = p.dgx + ((size_t)(tg - 1 - n) * B + ob) * 4 * PH + ou;
         dg[0] = o[0]; dg[(size_t)PH] = o[NE]; dg[(size_t)2 * PH] = o[2 * NE]; dg[(size_t)3 * PH] = o[3 * NE];
     };
-    auto burst = [&](int n) {                                    // n % SB == 0
-        __syncthreads();
-        const int nst = (tg - n) < SB ? (tg - n) : SB;
-        // LDS-DMA (global_load_lds_dword: no VGPR staging -- the register file belongs to the W_hh^T fragments): wave w
-        // serves elements e = 64 (w & 1) + lane of the pairs k = (w >> 1), (w >> 1) + 2, ..; LDS destination = wave-uniform
-        // base + 4 lane, i.e. exactly the [pair][e] staging layout
-        const int wu = __builtin_amdgcn_readfirstlane(wave);
-        const int eh = (wave & 1) * 64 + lane;
-        const int hb = b0 + eh / UPC, hu = q * UPC + eh % UPC;
-        const bool hvalid = hb < B;
-        if (hvalid) {                                            // straight-line asm DMAs (see the forward kernel)
-            const unsigned half_off = (unsigned)(wu & 1) * 256u;
-            const unsigned ins0 = (unsigned)(size_t)(lds_void*)ins + half_off, cells0 = (unsigned)(size_t)(lds_void*)cells + half_off;
+    // ring slot n % RING: saved gates x4 + dy of step n; cell slot n % RING = cell[s(n) - 1] (c_prev of step n = c_t of step n+1),
+    // cell slot RING-1 starts out as cell[tg - 1] (c_t of step 0)
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
+    const int eh = (wave & 1) * 64 + lane;
+    const int hb = b0 + eh / UPC, hu = q * UPC + eh % UPC;
+    const bool hvalid = hb < B;
+    const unsigned ins0 = (unsigned)(size_t)(lds_void*)ins + (unsigned)(wu & 1) * 256u;
+    const unsigned cells0 = (unsigned)(size_t)(lds_void*)cells + (unsigned)(wu & 1) * 256u;
+    auto prefetch = [&](int m) {                                 // waves 2-3
+        if (wu >= 2 && m < tg && hvalid) {
+            const int sm = tg - 1 - m;
+            const size_t row = (size_t)sm * B + hb;
+            const unsigned dst = ins0 + (unsigned)((m % RING) * 5 * NE * 4);
 #pragma unroll
-            for (int kk = 0; kk < (SB * 5 + 1) / 2; ++kk) {      // gates x4, dy
-                const int k = 2 * kk + (wu >> 1), i = k / 5, f = k - i * 5, s = tg - 1 - (n + i);
-                if (k < nst * 5) {
-                    const size_t row = (size_t)s * B + hb;
-                    dma_dword(f < 4 ? p.gates + row * 4 * PH + (size_t)f * PH + hu : p.dy + row * p.ldy + hu, ins0 + (unsigned)k * NE * 4u);
-                }
-            }
-#pragma unroll
-            for (int kk = 0; kk < (SB + 2) / 2; ++kk) {          // cell[s] of the staged steps and the one below (c_prev)
-                const int i = 2 * kk + (wu >> 1), s = tg - 1 - (n + i);
-                if (i <= nst && i <= SB && s >= 0) dma_dword(p.cell + ((size_t)s * B + hb) * PH + hu, cells0 + (unsigned)i * NE * 4u);
-            }
+            for (int f = 0; f < 4; ++f) dma_dword(p.gates + row * 4 * PH + (size_t)f * PH + hu, dst + (unsigned)(f * NE * 4));
+            dma_dword(p.dy + row * p.ldy + hu, dst + (unsigned)(4 * NE * 4));
+            if (sm > 0) dma_dword(p.cell + (row - B) * PH + hu, cells0 + (unsigned)((m % RING) * NE * 4));
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the DMA writes are this wave's own VM operations
-        __syncthreads();
     };
+    if (wu >= 2 && tg > 0 && hvalid) dma_dword(p.cell + ((size_t)(tg - 1) * B + hb) * PH + hu, cells0 + (unsigned)((RING - 1) * NE * 4));
+#pragma unroll
+    for (int m = 0; m < DIST; ++m) prefetch(m);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     float dc_carry = 0.f;
     __amdgpu_buffer_rsrc_t rs[2];
@@ -483,8 +489,11 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     const long t_start = wall_clock64();
     bool dead = false;
 
+    // debug stamps: [step][wave][0..4] = loop top, polls + MFMAs done, partials written + barrier passed, published, poll passes
+    const bool prof = p.prof != nullptr && grp == 0 && q == 0 && lane == 0;
     for (int n = 0; n < tg; ++n) {                 // n-th step of the sweep: time index s = tg-1-n
-        if ((n % SB) == 0) burst(n);
+        long st0 = 0, st1 = 0, st2 = 0, st3 = 0, npass = 0;
+        if (prof) st0 = wall_clock64();
         const int s = tg - 1 - n;
         f32x4 acc[TL][4];
 #pragma unroll
@@ -519,6 +528,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
                         }
                     }
                     if (ready == (1u << LPB) - 1u) break;
+                    if (prof) ++npass;
                     if ((spins & 15) == 15) {
                         if (wall_clock64() - t_start > p.timeout_ticks ||
                             __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
@@ -559,6 +569,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
             if (dead) break;
         }
         const int rb = n & 1;
+        if (prof) st1 = wall_clock64();
         if (kg * 4 < RPGP) {
 #pragma unroll
             for (int j = 0; j < TL; ++j)
@@ -568,9 +579,11 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
                     for (int r = 0; r < 4; ++r) red[rb][wave + 4 * a][j][kg * 4 + r][li] = acc[j][a][r];
         }
         __syncthreads();
+        if (prof) st2 = wall_clock64();
         if (n > 0) store_outputs(n - 1);
+        prefetch(n + DIST);
         if (erole) {
-            const int i = n % SB;
+            const int i = n % RING;
             const bool active = s < len;
             float da[4] = {0.f, 0.f, 0.f, 0.f};
             if (active) {
@@ -579,7 +592,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
                 float dh = in[4 * NE];
 #pragma unroll
                 for (int w16 = 0; w16 < 16; ++w16) dh += red[rb][w16][j][ebl][nn];
-                const float c_t = cells[i * NE + tid], c_prev = s > 0 ? cells[(i + 1) * NE + tid] : 0.f;
+                const float c_t = cells[((n + RING - 1) % RING) * NE + tid], c_prev = s > 0 ? cells[i * NE + tid] : 0.f;
                 float carry;
                 lstm_cell_bwd<true>(dh, dc_carry, in[0], in[NE], in[2 * NE], in[3 * NE], c_t, c_prev, da, carry);
                 dc_carry = carry;
@@ -595,9 +608,14 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
                     else __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            if (prof) st3 = wall_clock64();
             float* o = outs + (n & 1) * 4 * NE + tid;
 #pragma unroll
             for (int g = 0; g < 4; ++g) o[g * NE] = da[g];
+        }
+        if (prof && n < 1024) {
+            long* o = p.prof + ((size_t)n * 4 + wave) * 5;
+            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = npass;
         }
     }
     if (dead) {
@@ -703,9 +721,9 @@ extern "C" int FT_OPNAME(ft_lstm_persist_bwd)(const float* dy, int64_t ldy, cons
     unsigned* census = reinterpret_cast<unsigned*>(base + al256p((size_t)4 * H * H * 2) + gran_bytes);
     FT_CHECK_HIP(hipMemsetAsync(dgran, 0, gran_bytes + 256, st));
     hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H);
-    PersistBwdP p{dy, (long)ldy, lens, gates, cell, dgx, wTfrag, dgran, status, census, T, B, 100000000L / 2, nullptr};
+    PersistBwdP p{dy, (long)ldy, lens, gates, cell, dgx, wTfrag, dgran, status, census, T, B, 100000000L / 2, g_persist_prof};
     // dynamic LDS: 16-partial reduce (2 x 16 x 32 unit-rows... = 2*16*TL*RPGP*17 = 2*16*8*17 floats) + staged steps
-    const size_t lds = sizeof(float) * ((size_t)2 * 16 * 8 * 17 + (size_t)SB * 5 * 128 + (size_t)(SB + 1) * 128 + (size_t)2 * 4 * 128);
+    const size_t lds = sizeof(float) * ((size_t)2 * 16 * 8 * 17 + (size_t)RING * 5 * 128 + (size_t)RING * 128 + (size_t)2 * 4 * 128);
     auto launch = [&](auto kern) -> int {
         FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(NCU), dim3(256), lds, st, p);

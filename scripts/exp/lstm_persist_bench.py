@@ -92,5 +92,18 @@ for ng in (1, 9, 8):
     res["bwd_persist%d" % ng] = r + (st, bool(torch.equal(d0, d1)), float((d0 - d1).abs().max()))
     print("backward persistent ng=%d: min %.3f median %.3f us/step  status %d  bit-identical %s  max|d| %.3e" % ((ng,) + res["bwd_persist%d" % ng]), flush=True)
     status.zero_()
+# ---- phase stamps of one workgroup (backward, XCD-local transport)
+prof.zero_()
+L.lib().ft_lstm_persist_debug_prof(L.ptr(prof))
+run_persist_bwd(1, d1, wp)
+torch.cuda.synchronize()
+L.lib().ft_lstm_persist_debug_prof(None)
+pr = prof.cpu().reshape(1024, 4, 5)[100:800].double()
+for wv in range(4):
+    top, swp, bar, pub, npass = (pr[:, wv, k] for k in range(5))
+    step = (top[1:] - top[:-1]).mean() * 10
+    print("bwd wave %d: step %.0f ns | polls+mfma %.0f | partials+barrier %.0f | epilogue->publish %.0f | publish->next top %.0f | poll passes %.2f"
+          % (wv, step, ((swp - top).mean()) * 10, ((bar - swp).mean()) * 10, ((pub - bar).mean()) * 10 if wv < 2 else 0.0,
+             ((top[1:] - (pub if wv < 2 else bar)[:-1]).mean()) * 10, npass.mean()), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/lstm_persist_bench.json", "w"))
