@@ -110,6 +110,7 @@ __device__ __forceinline__ unsigned row_shl(unsigned v) {
 // requested in step m - DIST > m - RING + 1.
 constexpr int SB = 32;
 constexpr int RING = 8, DIST = 6;
+constexpr int PFW = 2;                   // first of the two waves that request the ring rows (0: the epilogue waves, 2: the output waves)
 static_assert(DIST < RING - 1, "slot reuse");
 
 // XCD census (LOCAL transport): group = this workgroup's XCC id, slot = arrival order inside that XCD
@@ -461,8 +462,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     const bool hvalid = hb < B;
     const unsigned ins0 = (unsigned)(size_t)(lds_void*)ins + (unsigned)(wu & 1) * 256u;
     const unsigned cells0 = (unsigned)(size_t)(lds_void*)cells + (unsigned)(wu & 1) * 256u;
-    auto prefetch = [&](int m) {                                 // waves 2-3
-        if (wu >= 2 && m < tg && hvalid) {
+    auto prefetch = [&](int m) {                                 // waves PFW, PFW + 1
+        if ((wu >> 1) == PFW / 2 && m < tg && hvalid) {
             const int sm = tg - 1 - m;
             const size_t row = (size_t)sm * B + hb;
             const unsigned dst = ins0 + (unsigned)((m % RING) * 5 * NE * 4);
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
             if (sm > 0) dma_dword(p.cell + (row - B) * PH + hu, cells0 + (unsigned)((m % RING) * NE * 4));
         }
     };
-    if (wu >= 2 && tg > 0 && hvalid) dma_dword(p.cell + ((size_t)(tg - 1) * B + hb) * PH + hu, cells0 + (unsigned)((RING - 1) * NE * 4));
+    if ((wu >> 1) == PFW / 2 && tg > 0 && hvalid) dma_dword(p.cell + ((size_t)(tg - 1) * B + hb) * PH + hu, cells0 + (unsigned)((RING - 1) * NE * 4));
 #pragma unroll
     for (int m = 0; m < DIST; ++m) prefetch(m);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -581,7 +582,10 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
         __syncthreads();
         if (prof) st2 = wall_clock64();
         if (n > 0) store_outputs(n - 1);
-        prefetch(n + DIST);
+        if constexpr (PFW == 2) prefetch(n + DIST);
+        // the output waves' next poll could not be consumed before these stores / DMAs have landed anyway (vmcnt retires in
+        // order); issued now it would read the granules BEFORE the group has published and cost a second round trip
+        if (wu >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (erole) {
             const int i = n % RING;
             const bool active = s < len;
@@ -612,6 +616,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
             float* o = outs + (n & 1) * 4 * NE + tid;
 #pragma unroll
             for (int g = 0; g < 4; ++g) o[g * NE] = da[g];
+            if constexpr (PFW == 0) prefetch(n + DIST);
         }
         if (prof && n < 1024) {
             long* o = p.prof + ((size_t)n * 4 + wave) * 5;
