@@ -16,6 +16,7 @@
 // (kernarg segment: weight addresses are known at wave start, so the weight stream is in flight
 // before the frame counter has even been read), and a chunk of frames is captured ONCE into a
 // hipGraph that is replayed for every chunk of every utterance that reuses the same buffers.
+#include <deque>
 #include <mutex>
 #include <unordered_map>
 
@@ -881,6 +882,8 @@ Layout make_layout(int H, int A, int M, int L, int E) {
 constexpr int GRAPH_FRAMES = 8;
 std::mutex g_graph_mu;
 std::unordered_map<uint64_t, hipGraphExec_t> g_graph_cache;
+std::deque<uint64_t> g_graph_order;                  // insertion order: the oldest graph is evicted when the cache is full
+constexpr size_t GRAPH_CACHE_MAX = 64;
 
 __global__ void f32_to_bf16_k(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
     for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 2; i < n; i += (size_t)gridDim.x * blockDim.x * 2) {
@@ -1045,7 +1048,16 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
         auto it = g_graph_cache.find(key);
         if (it != g_graph_cache.end()) exec = it->second;
         if (!exec) {
-            if (g_graph_cache.size() > 512) return ft_fail(FT_EHIP, "ft_decode_flow: graph cache overflow (unstable buffer addresses)");
+            if (g_graph_cache.size() >= GRAPH_CACHE_MAX) {         // long-running servers with varied (N, L, threshold, buffers): evict
+                const uint64_t old = g_graph_order.front();
+                g_graph_order.pop_front();
+                auto o = g_graph_cache.find(old);
+                if (o != g_graph_cache.end()) {
+                    FT_CHECK_HIP(hipStreamSynchronize(st));           // the evicted graph may still be running on this stream
+                    hipGraphExecDestroy(o->second);
+                    g_graph_cache.erase(o);
+                }
+            }
             hipStream_t cs;
             FT_CHECK_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             hipGraph_t graph = nullptr;
@@ -1059,6 +1071,7 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
             hipStreamDestroy(cs);
             if (e != hipSuccess) return ft_fail(FT_EHIP, "ft_decode_flow: graph capture failed: %s", hipGetErrorString(e));
             g_graph_cache[key] = exec;
+            g_graph_order.push_back(key);
         }
     }
     for (int i = 0; i < a->N; i += GRAPH_FRAMES) FT_CHECK_HIP(hipGraphLaunch(exec, st));

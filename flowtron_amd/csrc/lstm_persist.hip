@@ -58,6 +58,7 @@ struct PersistP {
     int T, B;
     long timeout_ticks;                  // wall_clock64 ticks (100 MHz)
     long* prof;                          // debug: per-step phase stamps of one workgroup (ft_lstm_persist_debug_prof), or null
+    int pre_poll_sleep;                  // s_sleep units before a step's first poll (tuning knob FT_PERSIST_SLEEP; 0 = none)
 };
 
 // a 128-bit value with unspecified contents at no cost (registers of lanes that a masked load leaves untouched)
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
             // hipcc shuffle accumulators and weight fragments through v_accvgpr_mov on every chunk).
             const unsigned epoch = (unsigned)t;
             const int par = (t - 1) & 1;
+            if (wu < 2) for (int z = 0; z < p.pre_poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
             u32x4 lo[NLG], hi[NLG];
 #pragma unroll
             for (int g = 0; g < NLG; ++g) {
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
                 c_state = c_new; h_state = h_new;
             }
             // ---- publish h_t first: one 8-byte {epoch, bf16 pair} granule per even unit (frozen rows re-publish their state)
-            const float h_nb = __shfl_down(h_state, 1, 64);
+            const float h_nb = __uint_as_float(row_shl<1>(__float_as_uint(h_state)));     // lane + 1 of the row: the odd unit of the pair
             if ((el & 1) == 0) {
                 const unsigned long long gran = ((unsigned long long)(unsigned)(t + 1) << 32) | pack_op16x2(h_state, h_nb);
                 unsigned long long* dst = p.hgran + ((size_t)(t & 1) * NG + grp) * GRAN_PER_GROUP + gran_index<RPGP, 8>(ebl, eu);
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
             // ---- publish dgates_s: one granule per gate per even unit (k = gate*H + unit)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float nb = __shfl_down(da[g], 1, 64);
+                const float nb = __uint_as_float(row_shl<1>(__float_as_uint(da[g])));
                 if ((el & 1) == 0) {
                     const unsigned long long gran = ((unsigned long long)(unsigned)(n + 1) << 32) | pack_op16x2(da[g], nb);
                     unsigned long long* dst = p.dgran + ((size_t)(n & 1) * NG + grp) * GRAN_PER_GROUP + gran_index<RPGP, CPW>(ebl, g * PH + eu);
@@ -690,7 +692,8 @@ extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh
     FT_CHECK_HIP(hipMemsetAsync(hgran, 0, gran_bytes, st));           // tags = 0: no epoch matches (epochs start at 1)
     FT_CHECK_HIP(hipMemsetAsync(census, 0, 256, st));
     hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H);
-    PersistP p{gx, lens, y, (long)ldy, gates, cell, wfrag, hgran, status, census, T, B, 100000000L / 2, g_persist_prof};   // 0.5 s
+    static const int pre_sleep = getenv("FT_PERSIST_SLEEP") ? atoi(getenv("FT_PERSIST_SLEEP")) : 0;
+    PersistP p{gx, lens, y, (long)ldy, gates, cell, wfrag, hgran, status, census, T, B, 100000000L / 2, g_persist_prof, pre_sleep};   // 0.5 s
     // dynamic LDS: reduce buffers (2*4*TPC*RPGP*17 = 2*4*32*17 floats) + SB staged gx rows + 2 output rows
     const size_t lds = sizeof(float) * ((size_t)2 * 4 * 32 * 17 + (size_t)SB * 4 * 128 + (size_t)2 * 6 * 128);
     auto launch = [&](auto kern) -> int {

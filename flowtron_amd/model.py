@@ -195,6 +195,15 @@ class AR_Step(nn.Module):
             self.gate_layer = LinearNorm(n_hidden + n_attn_channels, 1, bias=True, w_init_gain="sigmoid")
         self._decode_work = None
 
+    def __getstate__(self):
+        """train.py pickles the whole module into its checkpoints (train.py:131-141): the decode scratch (buffers per utterance
+        shape, the 54 MB weight image, the hand-off granules) is runtime state, not model state."""
+        d = self.__dict__.copy()
+        for k in ("_decode_bufs", "_decode_wimg", "_decode_gran"):
+            d.pop(k, None)
+        d["_decode_work"] = None
+        return d
+
     def forward(self, mel, text, in_lens32, out_lens32, attn_prior=None):
         """Teacher-forced flow. mel [T,B,M], text = encoder outputs [L,B,E].
         Returns (z [T,B,M], log_s [T,B,M], gates [T,B,1] | None, attn [B,T,L], attn_logprob [B,T,L])."""
@@ -272,10 +281,15 @@ class AR_Step(nn.Module):
         # persistent per-(N, L) buffers: the decode hipGraph bakes every pointer, so stable addresses = one capture,
         # replayed for every later utterance of this shape
         key = (N, Lk, str(dev))
-        bufs = self._decode_bufs.get(key) if hasattr(self, "_decode_bufs") else None
-        if bufs is None:
-            if not hasattr(self, "_decode_bufs"):
-                self._decode_bufs = {}
+        if not hasattr(self, "_decode_bufs"):
+            import collections
+            self._decode_bufs = collections.OrderedDict()       # LRU over (N, L, device): a server with varied lengths stays bounded
+        bufs = self._decode_bufs.get(key)
+        if bufs is not None:
+            self._decode_bufs.move_to_end(key)
+        else:
+            while len(self._decode_bufs) >= 8:
+                self._decode_bufs.popitem(last=False)
             f32 = dict(device=dev, dtype=torch.float32)
             bufs = self._decode_bufs[key] = dict(K=torch.empty(Lk, A, **f32), V=torch.empty(Lk, A, **f32), res=torch.empty(N, M, **f32),
                                                  mel=torch.empty(N, M, **f32), attn=torch.empty(N, Lk, **f32),
@@ -327,15 +341,15 @@ class AR_Step(nn.Module):
         persist = None
         if L.is16(L.mfma_mode()):               # 16-bit operand modes: bf16 images of the weights (half the bytes; fp32 activations)
             nb = L.lib().ft_decode_wimg_bytes(H, A, M)
-            wimg = bufs.get("wimg")
-            if wimg is None or wimg.numel() < nb:
-                wimg = bufs["wimg"] = torch.empty(nb, device=dev, dtype=torch.uint8)
+            wimg = getattr(self, "_decode_wimg", None)           # one image buffer per flow, whatever the utterance shape
+            if wimg is None or wimg.numel() < nb or wimg.device != dev:
+                wimg = self._decode_wimg = torch.empty(nb, device=dev, dtype=torch.uint8)
             args.wimg, args.wimg_bytes = L.ptr(wimg), wimg.numel()
             if os.environ.get("FLOWTRON_DECODE_PERSIST", "1") != "0" and ops.persist_usable(dev):
                 # one persistent launch per flow (csrc/decode.hip dec_persist_k) where its geometry applies
-                gran = bufs.get("gran")
-                if gran is None:
-                    gran = bufs["gran"] = torch.empty(L.lib().ft_decode_persist_gran_bytes(), device=dev, dtype=torch.uint8)
+                gran = getattr(self, "_decode_gran", None)
+                if gran is None or gran.device != dev:
+                    gran = self._decode_gran = torch.empty(L.lib().ft_decode_persist_gran_bytes(), device=dev, dtype=torch.uint8)
                 persist = ops.persist_status(dev)
                 args.persist_gran, args.persist_status = L.ptr(gran), L.ptr(persist)
         L.check(L.lib().ft_decode_flow(C.byref(args), L.stream()), "ft_decode_flow")
