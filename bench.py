@@ -11,8 +11,14 @@ all-reduce(AVG) of the flat gradient arena, one bucket per flow launched under t
 attention prior + CTC on, bf16 MFMA operands with fp32 accumulate/storage.  Weak scaling: every rank processes its
 own 32 utterances.  value = valid mel frames (sum of out_lens over all ranks and steps) / wall time.
 
-Rank 0 prints ONE JSON line.  It also carries `roofline` (the recurrent LSTM step kernel, live HIP-event timing),
-`cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample) and `infer_rtf`.
+Rank 0 prints ONE JSON line.  It also carries `roofline` / `roofline_second_kernel` (the dominant kernels of the step -- the
+persistent LSTM recurrences -- timed live with HIP events on the launch stream, next to the launch-per-step kernels they
+replace), `step_mfma_frac` (the whole step against the MFMA roof), `parity` (the HIP gradients of a batch slice against the
+CPU oracle), `cpu_baseline` (the oracle timed on this box's host cores on a bounded sample) and `infer` (RTF of a 400-frame
+2-flow decode, median of 7 calls).
+
+--config libritts / libritts_fp16 run BASELINE configs[2] / configs[4] (123 speakers, texts up to 237 symbols; fp16 MFMA
+operands + torch GradScaler, no attention prior) instead; --mfma overrides the operand type (bf16 | f16 | f32).
 """
 from __future__ import annotations
 

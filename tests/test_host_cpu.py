@@ -292,3 +292,31 @@ def test_radam_load_state_dict_restores_the_flat_arenas():
         assert o2.state[q]["step"] == 4
     off = o2.arena.offsets
     assert torch.equal(o2.flat_m[off[2]:off[2] + 33], o.flat_m[o.arena.offsets[2]:o.arena.offsets[2] + 33])
+
+
+def test_gradient_buckets_cover_the_arena_flow_by_flow():
+    """dist.gradient_buckets on the default model: contiguous, exhaustive, one bucket per flow (110.7 MB each) between the
+    embeddings and the encoder -- the ranges the data-parallel wrapper hands to RCCL one by one."""
+    import flowtron
+    from flowtron_amd import dist as D
+    from oracle import synth
+    m = flowtron.Flowtron(**synth.DEFAULT_MODEL_CONFIG)
+    arena = D.FlatArena(list(m.parameters()))
+    b = D.gradient_buckets(m, arena)
+    assert [n for n, _, _, _ in b] == ["speaker_embedding+embedding", "flows.0", "flows.1", "encoder"]
+    assert b[0][1] == 0 and b[-1][2] == arena.numel and all(b[i][2] == b[i + 1][1] for i in range(3))
+    assert sum(len(idx) for _, _, _, idx in b) == len(arena.params) == 68
+    assert abs((b[1][2] - b[1][1]) * 4 / 1e6 - 110.7) < 0.1
+
+
+def test_operand_mode_follows_env_then_autocast(monkeypatch):
+    from flowtron_amd import _lib as L
+    for v, want in (("f32", L.FT_F32), ("bf16", L.FT_BF16), ("f16", L.FT_F16), ("fp16", L.FT_F16)):
+        monkeypatch.setenv("FLOWTRON_MFMA", v)
+        assert L.mfma_mode() == want
+    monkeypatch.setenv("FLOWTRON_MFMA", "int8")
+    with pytest.raises(ValueError):
+        L.mfma_mode()
+    monkeypatch.delenv("FLOWTRON_MFMA")
+    assert L.mfma_mode() == L.FT_F32                      # no autocast region: parity mode
+    assert L.is16(L.FT_BF16) and L.is16(L.FT_F16) and not L.is16(L.FT_F32)
