@@ -7,6 +7,8 @@ Fixtures:
                  with and without torch's clip_grad_norm_(1.0) before the step (train.py:323-331), two weight decays:
                  parameters after every step + final exp_avg / exp_avg_sq.  Pins ft_sumsq + ft_radam_step, the N_sma >= 5
                  switch (step 6) and the checkpoint round trip.
+  cfg_libritts.pt  BASELINE configs[2]-shaped case (tests/libri_case.py: 123 speakers, L = 237, ragged B = 4, H = 1024): the
+                 reference's fp32 losses and sampled gradients.
   cfg2_bf16.pt   BASELINE config 2 model (2-flow LJS config.json defaults, H = 1024) on a B = 4, T <= 120 batch:
                  the reference in fp32 AND under torch.autocast("cpu", bfloat16) (the dtype the benchmark is quoted in;
                  train.py:292 wraps the forward in autocast).  Per parameter: fp32 gradient norm, a seeded sample of the
@@ -99,9 +101,39 @@ def run_cfg2(R, autocast):
     return (nll.detach().float(), gl.detach().float(), ctc.detach().float()), {k: p.grad.detach().float().clone() for k, p in m.named_parameters()}
 
 
+def run_libritts(R):
+    """cfg_libritts.pt: the real reference (fp32) on tests/libri_case.py: losses + per parameter the gradient norm and a seeded
+    sample of the gradient (same sampling as cfg2_bf16.pt)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import libri_case
+    cfg, sd, b = libri_case.make()
+    m = R.Flowtron(**cfg)
+    m.load_state_dict(sd)
+    m.train()
+    crit = R.FlowtronLoss(1.0, False, True, True, 0.01, -8)
+    real = F.dropout
+    F.dropout = lambda x, p=0.5, training=True, inplace=False: x.clone()
+    try:
+        out = m(b["mel"].clone(), b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"].clone())
+        nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+        (nll + gl + 0.01 * ctc).backward()
+    finally:
+        F.dropout = real
+    res = {"losses_fp32": (nll.detach().float(), gl.detach().float(), ctc.detach().float()), "grad": {}}
+    for k, p in m.named_parameters():
+        flat = p.grad.detach().float().reshape(-1)
+        idx = sample_idx_stable(flat.numel(), k)
+        res["grad"][k] = {"norm": flat.norm().item(), "idx": idx, "sample": (flat if idx is None else flat[idx]).clone()}
+    torch.save(res, os.path.join(HERE, "cfg_libritts.pt"))
+    print("cfg_libritts.pt", os.path.getsize(os.path.join(HERE, "cfg_libritts.pt")) // 1024, "KiB; losses", [x.item() for x in res["losses_fp32"]])
+
+
 def main():
     assert refshim.available(), "needs /root/reference"
     torch.set_num_threads(8)
+    if "--libritts-only" in sys.argv:
+        run_libritts(refshim.load())
+        return
     torch.save({"shapes": RADAM_SHAPES, "cases": [run_radam(c, wd) for c in (0.0, 1.0) for wd in (1e-6, 1e-2)]},
                os.path.join(HERE, "radam_traj.pt"))
     R = refshim.load()
@@ -120,6 +152,7 @@ def main():
     torch.save(res, os.path.join(HERE, "cfg2_bf16.pt"))
     for f in ("radam_traj.pt", "cfg2_bf16.pt"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+    run_libritts(R)
 
 
 if __name__ == "__main__":
