@@ -58,7 +58,6 @@ struct PersistP {
     int T, B;
     long timeout_ticks;                  // wall_clock64 ticks (100 MHz)
     long* prof;                          // debug: per-step phase stamps of one workgroup (ft_lstm_persist_debug_prof), or null
-    int pre_poll_sleep;                  // s_sleep units before a step's first poll (tuning knob FT_PERSIST_SLEEP; 0 = none)
 };
 
 // a 128-bit value with unspecified contents at no cost (registers of lanes that a masked load leaves untouched)
@@ -111,7 +110,6 @@ __device__ __forceinline__ unsigned row_shl(unsigned v) {
 // requested in step m - DIST > m - RING + 1.
 constexpr int SB = 32;
 constexpr int RING = 8, DIST = 6;
-constexpr int PFW = 2;                   // first of the two waves that request the ring rows (0: the epilogue waves, 2: the output waves)
 static_assert(DIST < RING - 1, "slot reuse");
 
 // XCD census (LOCAL transport): group = this workgroup's XCC id, slot = arrival order inside that XCD
@@ -258,7 +256,6 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
             // hipcc shuffle accumulators and weight fragments through v_accvgpr_mov on every chunk).
             const unsigned epoch = (unsigned)t;
             const int par = (t - 1) & 1;
-            if (wu < 2) for (int z = 0; z < p.pre_poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
             u32x4 lo[NLG], hi[NLG];
 #pragma unroll
             for (int g = 0; g < NLG; ++g) {
@@ -464,8 +461,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     const bool hvalid = hb < B;
     const unsigned ins0 = (unsigned)(size_t)(lds_void*)ins + (unsigned)(wu & 1) * 256u;
     const unsigned cells0 = (unsigned)(size_t)(lds_void*)cells + (unsigned)(wu & 1) * 256u;
-    auto prefetch = [&](int m) {                                 // waves PFW, PFW + 1
-        if ((wu >> 1) == PFW / 2 && m < tg && hvalid) {
+    auto prefetch = [&](int m) {                                 // waves 2-3 (from the epilogue waves instead: 3.13 vs 3.07 us)
+        if (wu >= 2 && m < tg && hvalid) {
             const int sm = tg - 1 - m;
             const size_t row = (size_t)sm * B + hb;
             const unsigned dst = ins0 + (unsigned)((m % RING) * 5 * NE * 4);
@@ -475,7 +472,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
             if (sm > 0) dma_dword(p.cell + (row - B) * PH + hu, cells0 + (unsigned)((m % RING) * NE * 4));
         }
     };
-    if ((wu >> 1) == PFW / 2 && tg > 0 && hvalid) dma_dword(p.cell + ((size_t)(tg - 1) * B + hb) * PH + hu, cells0 + (unsigned)((RING - 1) * NE * 4));
+    if (wu >= 2 && tg > 0 && hvalid) dma_dword(p.cell + ((size_t)(tg - 1) * B + hb) * PH + hu, cells0 + (unsigned)((RING - 1) * NE * 4));
 #pragma unroll
     for (int m = 0; m < DIST; ++m) prefetch(m);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -584,7 +581,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
         __syncthreads();
         if (prof) st2 = wall_clock64();
         if (n > 0) store_outputs(n - 1);
-        if constexpr (PFW == 2) prefetch(n + DIST);
+        prefetch(n + DIST);
         // the output waves' next poll could not be consumed before these stores / DMAs have landed anyway (vmcnt retires in
         // order); issued now it would read the granules BEFORE the group has published and cost a second round trip
         if (wu >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -618,7 +615,6 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
             float* o = outs + (n & 1) * 4 * NE + tid;
 #pragma unroll
             for (int g = 0; g < 4; ++g) o[g * NE] = da[g];
-            if constexpr (PFW == 0) prefetch(n + DIST);
         }
         if (prof && n < 1024) {
             long* o = p.prof + ((size_t)n * 4 + wave) * 5;
@@ -692,8 +688,7 @@ extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh
     FT_CHECK_HIP(hipMemsetAsync(hgran, 0, gran_bytes, st));           // tags = 0: no epoch matches (epochs start at 1)
     FT_CHECK_HIP(hipMemsetAsync(census, 0, 256, st));
     hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H);
-    static const int pre_sleep = getenv("FT_PERSIST_SLEEP") ? atoi(getenv("FT_PERSIST_SLEEP")) : 0;
-    PersistP p{gx, lens, y, (long)ldy, gates, cell, wfrag, hgran, status, census, T, B, 100000000L / 2, g_persist_prof, pre_sleep};   // 0.5 s
+    PersistP p{gx, lens, y, (long)ldy, gates, cell, wfrag, hgran, status, census, T, B, 100000000L / 2, g_persist_prof};   // 0.5 s
     // dynamic LDS: reduce buffers (2*4*TPC*RPGP*17 = 2*4*32*17 floats) + SB staged gx rows + 2 output rows
     const size_t lds = sizeof(float) * ((size_t)2 * 4 * 32 * 17 + (size_t)SB * 4 * 128 + (size_t)2 * 6 * 128);
     auto launch = [&](auto kern) -> int {
