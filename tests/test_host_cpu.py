@@ -320,3 +320,24 @@ def test_operand_mode_follows_env_then_autocast(monkeypatch):
     monkeypatch.delenv("FLOWTRON_MFMA")
     assert L.mfma_mode() == L.FT_F32                      # no autocast region: parity mode
     assert L.is16(L.FT_BF16) and L.is16(L.FT_F16) and not L.is16(L.FT_F32)
+
+
+def test_product_path_never_touches_the_oracle():
+    """oracle/ is test infrastructure: the package and the root drop-ins must not import, load or execute anything from it
+    (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline / parity legs may)."""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, f) for f in ("flowtron.py", "audio_processing.py", "distributed.py", "radam.py", "data.py")]
+    pkg = os.path.join(root, "flowtron_amd")
+    files += [os.path.join(pkg, f) for f in os.listdir(pkg) if f.endswith(".py")]
+    for path in files:
+        tree = ast.parse(open(path).read(), path)
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "oracle" or n.startswith("oracle.") for n in names), (path, names)
+    for f in os.listdir(os.path.join(pkg, "csrc")):
+        assert "oracle" not in open(os.path.join(pkg, "csrc", f), errors="ignore").read().lower() or f.endswith(".md"), f
