@@ -176,6 +176,31 @@ def test_mel_filterbank_and_window_match_oracle():
     assert (torch.from_numpy(hann_window(1024, 1024)) - O.hann_periodic(1024).float()).abs().max().item() < 1e-7
 
 
+def test_mel_filterbank_pinned_to_published_librosa_equivalent(golden_dir):
+    """audio_processing.py:104-107 takes the 80 x 513 filterbank from librosa, which is not installed here.  The fixture holds
+    the output of transformers.audio_utils.mel_filter_bank(norm='slaney', mel_scale='slaney') -- Hugging Face's published
+    replacement for librosa.filters.mel (tests/golden/make_golden_fb.py) -- and pins BOTH restatements (oracle and product) to
+    it; when transformers is importable the fixture itself is regenerated and compared, so it cannot drift silently."""
+    import numpy as np
+    from flowtron_amd.audio import slaney_mel_filterbank
+    from oracle import flowtron_oracle as O
+    g = np.load(os.path.join(golden_dir, "mel_fb_hf_slaney.npz"))
+    ref = g["fb"]
+    assert ref.shape == (80, 513) and ref.dtype == np.float64
+    prod = np.asarray(slaney_mel_filterbank(22050, 1024, 80, 0.0, 8000.0), dtype=np.float64)
+    orac = O.mel_filterbank().double().numpy()
+    assert np.abs(prod - ref).max() < 5e-9 and np.abs(orac - ref).max() < 5e-9      # values up to 0.0265: < 2e-7 relative
+    # structure librosa guarantees: every filter non-empty, Slaney area normalisation, at most two filters per bin
+    assert (ref.sum(1) > 0).all() and ((ref > 0).sum(0) <= 2).all()
+    try:
+        from transformers.audio_utils import mel_filter_bank
+    except Exception:
+        return
+    again = mel_filter_bank(num_frequency_bins=513, num_mel_filters=80, min_frequency=0.0, max_frequency=8000.0,
+                            sampling_rate=22050, norm="slaney", mel_scale="slaney").T
+    assert np.abs(again - ref).max() == 0.0
+
+
 def _reference_class(path, name):
     """Extract ONE class from a reference module without importing the module (data.py pulls in librosa etc.)."""
     import ast
