@@ -361,8 +361,10 @@ def _lstm_step(x, h, c, w_ih, w_hh, b_ih, b_hh):
 
 
 def ar_step_infer(sd: SD, pfx: str, residual, enc, has_gate, temperature=1.0, gate_threshold=0.5,
-                  attn_prior=None, attns=None):
-    """residual [N,1,M], enc [L,1,E] -> (mel [N',1,M], attn [N',L]) (flowtron.py:775-828)."""
+                  attn_prior=None, attns=None, gates_out=None):
+    """residual [N,1,M], enc [L,1,E] -> (mel [N',1,M], attn [N',L]) (flowtron.py:775-828).
+    gates_out: optional list that receives (sigmoid(gate), gate input [h_att ; ctx]) of every decoded frame (the 400-frame decode
+    test builds a gate with a wide stop margin from them)."""
     N, B, M = residual.shape
     H = sd[pfx + "lstm.weight_hh_l0"].shape[1]
     ap = pfx + "attention_layer."
@@ -410,12 +412,15 @@ def ar_step_infer(sd: SD, pfx: str, residual, enc, has_gate, temperature=1.0, ga
         attn_rows.append(p[0])
         if has_gate:
             g = d @ sd[pfx + "gate_layer.linear_layer.weight"].t() + sd[pfx + "gate_layer.linear_layer.bias"]
+            if gates_out is not None:
+                gates_out.append((float(torch.sigmoid(g)), d[0].clone()))
             if float(torch.sigmoid(g)) > gate_threshold:
                 break
     return torch.stack(outs, 0), torch.stack(attn_rows, 0)
 
 
-def infer(sd: SD, cfg: dict, residual, speaker_ids, text, temperature=1.0, gate_threshold=0.5, attn_prior=None, attns=None):
+def infer(sd: SD, cfg: dict, residual, speaker_ids, text, temperature=1.0, gate_threshold=0.5, attn_prior=None, attns=None,
+          gates_out=None):
     """Flowtron.infer (flowtron.py:901-930). residual [1,M,N] -> (mel [1,M,N'], [attn per flow]).
     attn_prior [1,N,L]; attns: per flow (flows order) an [N,L] forced alignment in that flow's own time order."""
     n_flows = cfg["n_flows"]
@@ -428,10 +433,12 @@ def infer(sd: SD, cfg: dict, residual, speaker_ids, text, temperature=1.0, gate_
         fa = None if attns is None else attns[i]
         if i % 2 == 1:
             pr = None if attn_prior is None else torch.flip(attn_prior, (1,))
-            xr, a = ar_step_infer(sd, pfx, torch.flip(x, (0,)), enc, has_gate, temperature, gate_threshold, pr, fa)
+            xr, a = ar_step_infer(sd, pfx, torch.flip(x, (0,)), enc, has_gate, temperature, gate_threshold, pr, fa,
+                                  gates_out if has_gate else None)
             x = torch.flip(xr, (0,))
         else:
-            x, a = ar_step_infer(sd, pfx, x, enc, has_gate, temperature, gate_threshold, attn_prior, fa)
+            x, a = ar_step_infer(sd, pfx, x, enc, has_gate, temperature, gate_threshold, attn_prior, fa,
+                                 gates_out if has_gate else None)
         attn_out.append(a)
     return x.permute(1, 2, 0), attn_out
 

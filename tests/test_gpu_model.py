@@ -136,6 +136,76 @@ def test_infer_bf16_weight_images_and_persistent_decode_track_fp32_full_width():
     assert res["persist_gated"] == res["staged_gated"] == res["f32_gated"]
 
 
+def test_decode_400_frames_vs_oracle_all_three_decoders(capsys):
+    """BASELINE configs[3] at the shape bench.py times (2-flow LJS model, B = 1, L = 69 text symbols, 400 residual frames,
+    sigma = 0.5) against the fp32 CPU ORACLE (O.infer = restatement of flowtron.py:775-828, 901-930), for every decoder the
+    library has: the fp32-weight staged hipGraph chain (the reference's own arithmetic, inference.py:68-71), the bf16-image staged
+    chain and the one-launch persistent decode (dec_persist_k, the one behind the headline RTF).
+    Tolerances on mel (values span ~[-2, 2] here) and attention rows (probabilities) over all 400 frames x 2 flows:
+      fp32 weights : mel 2e-3, attention 2e-4 (400 sequentially dependent frames of fp32 re-association);
+      bf16 weights : mel 0.1 max / 0.01 mean, attention 3e-2 (weights rounded to 8 significand bits, 800 recurrent steps).
+    Gate: random weights give a gate that hovers at 0.50-0.53 with no usable margin, so the test DESIGNS the gate layer from the
+    oracle's own trajectory -- the minimum-norm weight with logit -1 on frames 0 .. 249 and +1 on frame 250 of the gated flow
+    (sigmoid 0.27 / 0.73 around the threshold 0.5; a 3 % perturbation of the gate input moves the logit by 0.03) -- and every
+    decoder must stop at exactly the oracle's frame."""
+    import flowtron
+    from flowtron_amd import ops
+    from oracle import flowtron_oracle as O
+    from oracle import synth
+    cfg = dict(synth.DEFAULT_MODEL_CONFIG)
+    N, Lk, f_stop = 400, 69, 250
+    rs = np.random.RandomState(404)
+    residual = torch.from_numpy(rs.standard_normal((1, 80, N)).astype(np.float32)) * 0.5
+    txt = torch.from_numpy(rs.randint(0, cfg["n_text"], (1, Lk)))
+    spk = torch.zeros(1, dtype=torch.long)
+    sd = synth.make_state_dict(cfg, seed=23)
+    torch.set_num_threads(max(1, min(64, len(os.sched_getaffinity(0)))))
+    gates = []
+    with torch.no_grad():
+        ref_mel, ref_attn = O.infer(sd, cfg, residual, spk, txt, gate_threshold=2.0, gates_out=gates)
+    assert ref_mel.shape == (1, 80, N) and len(gates) == N
+    D = torch.stack([g[1] for g in gates]).double()                       # [N, H + A] gate inputs of the gated (last) flow
+    y = -torch.ones(f_stop + 1, dtype=torch.float64)
+    y[f_stop] = 1.0
+    w = torch.linalg.pinv(D[: f_stop + 1]) @ y
+    gk = [k for k in sd if k.endswith("gate_layer.linear_layer.weight")][0]
+    sd[gk] = w.float().reshape(1, -1)
+    sd[gk.replace("weight", "bias")] = torch.zeros(1)
+    with torch.no_grad():
+        assert O.infer(sd, cfg, residual, spk, txt, gate_threshold=0.5)[0].shape[2] == f_stop + 1
+    res = {}
+    try:
+        for name, mode, persist in (("f32", "f32", "0"), ("bf16_staged", "bf16", "0"), ("bf16_persist", "bf16", "1")):
+            os.environ["FLOWTRON_DECODE_PERSIST"] = persist
+            os.environ["FLOWTRON_MFMA"] = mode
+            m = flowtron.Flowtron(**cfg)
+            m.load_state_dict(sd)
+            m = m.cuda().eval()
+            mel, attns = m.infer(residual.cuda(), spk.cuda(), txt.cuda(), gate_threshold=2.0)
+            n_gated = m.infer(residual.cuda(), spk.cuda(), txt.cuda(), gate_threshold=0.5)[0].shape[2]
+            ops.check_persist_status()
+            res[name] = (mel.cpu(), [torch.cat(a)[:, 0].cpu() for a in attns], n_gated)
+    finally:
+        os.environ["FLOWTRON_MFMA"] = "f32"
+        os.environ.pop("FLOWTRON_DECODE_PERSIST", None)
+    rows = []
+    for name, (mel, attns, n_gated) in res.items():
+        assert mel.shape == ref_mel.shape and torch.isfinite(mel).all()
+        d = (mel - ref_mel).abs()
+        da = max(mad(a, r) for a, r in zip(attns, ref_attn))
+        rows.append((name, d.max().item(), d.mean().item(), da, n_gated))
+    with capsys.disabled():
+        print("\n[decode 400 frames x 2 flows vs fp32 oracle] oracle stops at frame %d; |mel| <= %.2f" % (f_stop + 1, ref_mel.abs().max().item()))
+        for r in rows:
+            print("   %-13s mel max %.2e mean %.2e | attention max %.2e | gated frames %d" % r)
+    for name, dmax, dmean, da, n_gated in rows:
+        if name == "f32":
+            assert dmax < 2e-3 and da < 2e-4, (name, dmax, da)
+        else:
+            assert dmax < 0.1 and dmean < 0.01 and da < 3e-2, (name, dmax, dmean, da)
+        assert n_gated == f_stop + 1, (name, n_gated, f_stop + 1)
+
+
 def test_cfg1_full_size_vs_reference_golden():
     """BASELINE config 1: 1-flow, n_text=148, B=2, T=800/650, L=148/120, fp32, prior + CTC on."""
     import flowtron

@@ -554,8 +554,19 @@ def test_bf16_image_and_fused_column_sums(env, rows, cols, off, fmt):
             assert bool((err < 2e-4 * math.sqrt(rows) + 1e-6 * view.abs().sum(0)).all()), err.max()
 
 
+def _bench_lens(lens, ng):
+    """lens == "bench": the ragged out_lens of bench.py's own batch (BASELINE configs[1]: B = 32, T = 862), i.e. the exact launch
+    geometry the benchmark times; only for the default transport (ng = 1) -- the others are covered at the short shapes."""
+    if lens != "bench":
+        return lens
+    if ng != 1:
+        pytest.skip("bench shape: default transport only")
+    import bench
+    return [int(v) for v in bench.synth_batch(32, 1234 + 7)["out_lens"]]
+
+
 @pytest.mark.parametrize("ng", [1, 9, 8, 4, 2])   # 1 | 9 = XCD-local transport with nt | sc1 loads (8 groups = 8 XCDs)
-@pytest.mark.parametrize("T,B,lens", [(37, 32, None), (9, 5, [9, 9, 4, 2, 1]), (20, 17, None)])
+@pytest.mark.parametrize("T,B,lens", [(37, 32, None), (9, 5, [9, 9, 4, 2, 1]), (20, 17, None), (862, 32, "bench")])
 def test_persistent_lstm_forward_is_bit_identical_to_launch_per_step(env, ng, T, B, lens):
     """ft_lstm_persist_fwd (one launch per sequence, W_hh fragments resident in registers, ng independent batch groups,
     tag-checked granule hand-off) against ft_lstm_seq_fwd(FT_BF16): same rounding and accumulation order -> bit-identical
@@ -567,6 +578,7 @@ def test_persistent_lstm_forward_is_bit_identical_to_launch_per_step(env, ng, T,
     torch.manual_seed(T * 100 + B)
     gx = torch.randn(T, B, 4 * H, device="cuda") * 0.5
     w = torch.randn(4 * H, H, device="cuda") / H ** 0.5
+    lens = _bench_lens(lens, ng)
     if lens is None:
         lens = [max(1, T - 2 * i) for i in range(B)]
     lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda")
@@ -594,7 +606,7 @@ def test_persistent_lstm_forward_is_bit_identical_to_launch_per_step(env, ng, T,
 
 
 @pytest.mark.parametrize("ng", [1, 9, 8, 4])
-@pytest.mark.parametrize("T,B,lens", [(37, 32, None), (9, 5, [9, 9, 4, 2, 1]), (20, 17, None)])
+@pytest.mark.parametrize("T,B,lens", [(37, 32, None), (9, 5, [9, 9, 4, 2, 1]), (20, 17, None), (862, 32, "bench")])
 def test_persistent_lstm_backward_is_bit_identical_to_launch_per_step(env, ng, T, B, lens):
     """ft_lstm_persist_bwd against ft_lstm_seq_bwd(FT_BF16) on the saved tensors of a real forward: same fragment rounding,
     same 16-partial accumulation order, same pinned cell arithmetic -> bit-identical dgx, zeros on pad rows."""
@@ -606,6 +618,7 @@ def test_persistent_lstm_backward_is_bit_identical_to_launch_per_step(env, ng, T
     gx = torch.randn(T, B, 4 * H, device="cuda") * 0.5
     w = torch.randn(4 * H, H, device="cuda") / H ** 0.5
     dy = torch.randn(T, B, H, device="cuda") * 0.1
+    lens = _bench_lens(lens, ng)
     if lens is None:
         lens = [max(1, T - 2 * i) for i in range(B)]
     lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda")

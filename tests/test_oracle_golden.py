@@ -158,3 +158,24 @@ def test_libritts_full_width_oracle_vs_real_reference(golden_dir):
         if r > worst[1]:
             worst = (k, r)
     assert worst[1] < 2e-4, worst
+
+
+def test_chunked_oracle_equals_one_shot_oracle():
+    """tests/oracle_chunked.py (the oracle over a big batch, a few utterances at a time -- what the full-size GPU parity test
+    of BASELINE configs[1] uses) returns the one-shot oracle's losses and gradients: utterances are independent and every loss
+    term is a weighted sum over them."""
+    import oracle_chunked as OC
+    cfg = dict(synth.SMALL_MODEL_CONFIG)
+    out_lens, in_lens = [23, 19, 17, 12, 9, 5], [9, 8, 8, 6, 4, 3]
+    sd = synth.make_state_dict(cfg, seed=5)
+    b = synth.make_batch(cfg, out_lens, in_lens, seed=5, with_prior=True)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.forward(sdg, cfg, b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+    nll, gl, ctc = O.loss(out, b["gate_target"], b["in_lens"], b["out_lens"], 1.0, True, True, -8)
+    (nll + gl + 0.01 * ctc).sum().backward()
+    for chunk in (2, 4):
+        (n2, g2, c2), grads = OC.forward_backward(cfg, sd, b, b["attn_prior"], chunk=chunk)
+        assert abs(n2 - nll.item()) < 1e-5 * abs(nll.item()) and abs(g2 - gl.item()) < 1e-5 and abs(c2 - ctc.item()) < 1e-4
+        for k, v in sdg.items():
+            denom = max(v.grad.norm().item(), 1e-5 * v.numel() ** 0.5)
+            assert (grads[k] - v.grad).norm().item() / denom < 2e-4, (k, chunk)
