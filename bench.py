@@ -11,11 +11,11 @@ all-reduce(AVG) of the flat gradient arena, one bucket per flow launched under t
 attention prior + CTC on, bf16 MFMA operands with fp32 accumulate/storage.  Weak scaling: every rank processes its
 own 32 utterances.  value = valid mel frames (sum of out_lens over all ranks and steps) / wall time.
 
-Rank 0 prints ONE JSON line.  It also carries `roofline` / `roofline_second_kernel` (the dominant kernels of the step -- the
-persistent LSTM recurrences -- timed live with HIP events on the launch stream, next to the launch-per-step kernels they
-replace), `step_mfma_frac` (the whole step against the MFMA roof), `parity` (the HIP gradients of a batch slice against the
-CPU oracle), `cpu_baseline` (the oracle timed on this box's host cores on a bounded sample) and `infer` (RTF of a 400-frame
-2-flow decode, median of 7 calls).
+Rank 0 prints ONE JSON line.  `roofline` = the whole step against the MFMA roof; under it `dominant_kernel` / `second_kernel`
+(the persistent LSTM recurrences, timed live with HIP events on the launch stream next to the launch-per-step kernels they
+replace) carry their own bound: a per-step hand-off-latency floor, with the HBM and MFMA fractions beside it; `parity` (the HIP gradients of a batch slice against the CPU oracle), `cpu_baseline` (the oracle timed on this box's host
+cores on a bounded sample), `infer` (RTF of a 400-frame 2-flow decode with 16-bit weight images, median of 7 calls) and
+`infer_fp32` (the same decode with fp32 weights and arithmetic -- the precision of the reference's inference.py).
 
 --config libritts / libritts_fp16 run BASELINE configs[2] / configs[4] (123 speakers, texts up to 237 symbols; fp16 MFMA
 operands + torch GradScaler, no attention prior) instead; --mfma overrides the operand type (bf16 | f16 | f32).
@@ -222,26 +222,71 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
         us[name] = sorted(ts)[1]
     ops.check_persist_status()
     rows = int(lens_cpu.sum())
+    hops = handoff_hops()
     out = {}
-    for name, per_row, repl in (("lstm_persist_bwd_k", 4 * (4 * H + H + H + 4 * H), "lstm_bwd_step_bf16"),
-                                ("lstm_persist_fwd_k", 4 * (4 * H + H + 4 * H + H), "lstm_fwd_step")):
+    # What bounds a step of these kernels is the dependency chain, not HBM and not the MFMA rate.  floor_us_per_step = the part of
+    # that chain no schedule can remove, from the kernel's structure and measured primitives:
+    #   one same-XCD L2 hand-off per step (publish -> every consumer sees the tag): profiles/r02_handoff_hops.json;
+    #   the MFMAs one wave must issue back to back per step (64 x v_mfma_f32_16x16x32: ~17 cycles each from one wave per SIMD,
+    #   MI355X_MICROARCH.md cycle table, 2.4 GHz);
+    #   the granule bytes every CU pulls from its XCD's L2 per step (16 KB forward, 64 KB backward, x 256 CUs) at the measured
+    #   L2 peak of 34.5 TB/s.
+    # The LDS reduce, the barrier, the cell update and the skew between the 32 CUs of a group are what `frac` leaves.
+    mfma_us = 64 * 17 / 2.4e3
+    for name, per_row, repl, gran_kb in (("lstm_persist_bwd_k", 4 * (4 * H + H + H + 4 * H), "lstm_bwd_step_bf16", 64),
+                                         ("lstm_persist_fwd_k", 4 * (4 * H + H + 4 * H + H), "lstm_fwd_step", 16)):
         nbytes = 2 * 4 * H * H + rows * per_row
         ach = nbytes / (us[name] * 1e-6) / 1e9
-        out[name] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                     "frac": round(ach / 8000.0, 4), "traffic": pmc_traffic(name), "us_per_launch": round(us[name], 1),
-                     "bytes_per_launch": nbytes, "steps_per_launch": T, "us_per_step": round(us[name] / T, 3),
+        per_step = us[name] / T
+        l2_us = 256 * gran_kb * 1024 / 34.5e12 * 1e6
+        floor = hops["same_xcd_hop_us"] + mfma_us + l2_us
+        mb = pmc_value("MFMA_BUSY", name, "mfma_busy_frac")
+        out[name] = {"kernel": name, "bound": "handoff-latency", "us_per_step": round(per_step, 3), "floor_us_per_step": round(floor, 3),
+                     "frac": round(floor / per_step, 3),
+                     "floor_terms_us": {"l2_handoff_hop": round(hops["same_xcd_hop_us"], 3), "mfma_issue_64_per_wave": round(mfma_us, 3),
+                                        "granule_bytes_over_l2_peak": round(l2_us, 3)},
+                     "steps_per_launch": T, "us_per_launch": round(us[name], 1),
                      "replaces": {"kernel": repl, "us_per_step": round(us[repl] / T, 3)},
-                     "note": "one launch = one whole sequence (T dependent steps); latency-bound by the per-step L2 hand-off, "
-                             "W_hh stays in registers (the launch-per-step kernel re-streams 8.4 MB of it every step)"}
+                     "hbm": {"achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                             "bytes_per_launch": nbytes, "traffic": pmc_traffic(name)},
+                     "mfma_busy_frac_pmc": mb,
+                     "note": "one launch = one whole sequence of T dependent steps, W_hh resident in registers; neither the HBM nor the "
+                             "MFMA roof binds it (both fractions are reported beside the floor): the figure of merit is us_per_step "
+                             "against floor_us_per_step"}
     return out["lstm_persist_bwd_k"], out["lstm_persist_fwd_k"]
+
+
+def handoff_hops():
+    """measured hand-off hops (us) committed under profiles/ (scripts/exp/handoff_probe.hip); fixed fall-back = the same numbers"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_handoff_hops.json")))["used_by_bench"]
+        return {"same_xcd_hop_us": float(d["same_xcd_hop_us"]), "cross_xcd_hop_us": float(d["cross_xcd_hop_us"])}
+    except Exception:
+        return {"same_xcd_hop_us": 0.2985, "cross_xcd_hop_us": 0.6432}
+
+
+PMC_PREFIXES = ("r03_pmc_", "r02_pmc_", "r01_pmc_lstm_")
+
+
+def pmc_value(counter_file, kernel_substr, field):
+    """one derived field of the committed rocprofv3 --pmc summaries (profiles/rNN_pmc_<counter_file>.json), newest round first"""
+    for prefix in PMC_PREFIXES:
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", "%s%s.json" % (prefix, counter_file))))
+            for k, v in d.items():
+                if kernel_substr in k and field in v:
+                    return round(float(v[field]), 4)
+        except Exception:
+            continue
+    return None
 
 
 def pmc_traffic(kernel_substr):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE and WRITE_SIZE
-    runs, profiles/r02_pmc_*.json, else the round-1 files), with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE
+    runs, profiles/rNN_pmc_*.json, newest round first), with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE
     reads 1/2 of a wide coalesced 16 B/lane stream; counters are KiB).  bench.py cannot run rocprofv3 on itself, so this is
     the last measured value, or null when the files are absent."""
-    for prefix in ("r02_pmc_", "r01_pmc_lstm_"):
+    for prefix in PMC_PREFIXES:
         try:
             vals = {}
             for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -271,7 +316,7 @@ def usable_cores():
 ILL_CONDITIONED = ("encoder.convolutions", "embedding.weight", "attention_layer.query")   # tests/test_gpu_bench_path.py
 
 
-def sample_of(batch, n_utt=4):
+def sample_of(batch, n_utt=8):
     """The bounded sample both the CPU oracle and the HIP parity pass evaluate: the n shortest utterances of the batch,
     re-sorted by text length (data.py:200-202), trimmed to their own T / L, with their beta-binomial prior."""
     idx = torch.argsort(batch["out_lens"])[:n_utt]
@@ -298,7 +343,7 @@ def cpu_baseline_worker(batch_size, seed, hip_path=None):
     init_weights(model, 1234)
     batch = synth_batch(batch_size, seed)
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-    n_utt = 4
+    n_utt = 8
     smp = sample_of(batch, n_utt)
     out_lens, in_lens, mel, text, pr, gate = smp["out_lens"], smp["in_lens"], smp["mel"], smp["text"], smp["prior"], smp["gate"]
     idx = slice(None)
@@ -370,8 +415,8 @@ def main():
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (default 100: a ~4 s timed region)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
     ap.add_argument("--mfma", default=None, choices=["bf16", "f16", "f32"], help="MFMA operand type (default: the config's)")
     ap.add_argument("--config", default="ljs", choices=["ljs", "libritts", "libritts_fp16"],
@@ -514,56 +559,91 @@ def main():
         }
         mode = {"bf16": L.FT_BF16, "f16": L.FT_F16, "f32": L.FT_F32}[args.mfma]
         log("roofline kernel timing ...")
+        # Top level: the WHOLE STEP against the MFMA roof: valid frames/s x 325 MFLOP of algorithmic work per valid frame
+        # (2 flows, forward + backward, padding and the tanh recomputation not counted) over the dense bf16 peak.  The step is a chain
+        # of latency-bound recurrences with GEMMs in between, so the dominant KERNELS are reported under their own bound below it.
+        frames_per_gpu = res["value"] / world
+        res["roofline"] = {"bound": "mfma", "scope": "whole training step", "achieved": round(frames_per_gpu * 325e6 / 1e12, 2),
+                           "peak": 2500.0, "unit": "TFLOP/s", "frac": round(frames_per_gpu * 325e6 / 2.5e15, 5), "traffic": None,
+                           "flop_per_valid_frame": 325e6,
+                           "gemm_mfma_busy_frac_pmc": {k: pmc_value("MFMA_BUSY", k, "mfma_busy_frac") for k in
+                                                       ("gemm_bf16_k<true, true, true, 256>", "gemm_bf16_k<false, true, false, 128>",
+                                                        "gemm_bf16_k<false, false, false, 128>")}}
         try:
             from flowtron_amd import ops as _ops
             if _ops.lstm_persist_groups(args.batch, MODEL_CONFIG["n_hidden"], False, mode, torch.device("cuda", torch.cuda.current_device())):
-                # dominant kernels of the step: the persistent recurrences (backward first: 6 launches per flow, ~60 % of the step)
-                res["roofline"], res["roofline_second_kernel"] = persist_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, batch_cpu["out_lens"], mode)
+                # dominant kernels of the step: the persistent recurrences, six launches each per step (3 LSTMs x 2 flows)
+                dom, second = persist_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, batch_cpu["out_lens"], mode)
+                for blk in (dom, second):
+                    blk["share_of_step"] = round(6 * blk["us_per_launch"] * 1e-3 / res["ms_per_step"], 3)
+                res["roofline"]["dominant_kernel"], res["roofline"]["second_kernel"] = dom, second
             elif _ops.lstm2_supported(args.batch, MODEL_CONFIG["n_hidden"], mode):
-                single = lstm_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, mode)
-                # dominant kernel of the step: the two-layer wavefront launch; the single-layer step kernel (attention LSTM,
-                # second by time) is reported beside it
-                res["roofline"] = lstm2_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T)
-                res["roofline_second_kernel"] = single
+                res["roofline"]["dominant_kernel"] = lstm2_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T)
+                res["roofline"]["second_kernel"] = lstm_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, mode)
             else:
-                res["roofline"] = lstm_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, mode)
+                res["roofline"]["dominant_kernel"] = lstm_step_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, mode)
         except Exception as e:                      # never lose the headline number to the side measurement
-            res["roofline"] = {"error": repr(e)}
-        # the whole step against the MFMA roof -- valid frames/s x 325 MFLOP (2 flows, fwd + bwd) / 2.5 PFLOP/s
-        if isinstance(res.get("roofline"), dict) and "error" not in res["roofline"]:
-            res["roofline"]["step_mfma_frac"] = round(res["value"] / world * 325e6 / 2.5e15, 5)
-            res["roofline"]["step_mfma_tflops"] = round(res["value"] / world * 325e6 / 1e12, 2)
+            res["roofline"]["dominant_kernel"] = {"error": repr(e)}
         if world == 1 and not args.no_infer and args.config == "ljs":
-            try:
-                log("inference RTF ...")
-                model.eval()
-                n_frames = int(os.environ.get("BENCH_INFER_FRAMES", "400"))      # (the PMC passes of scripts/profile_r2.sh shorten it)
-                z = torch.randn(1, 80, n_frames, device="cuda") * 0.5
-                text = b["text"][:1, :69]
-                spk = b["speaker_ids"][:1]
-                for _ in range(2):
-                    model.infer(z, spk, text, gate_threshold=1.0)       # warm-up (+ hipGraph capture)
-                torch.cuda.synchronize()
-                tis = []
-                for _ in range(int(os.environ.get("BENCH_INFER_CALLS", "7"))):
-                    t1 = time.perf_counter()
-                    mel, _ = model.infer(z, spk, text, gate_threshold=1.0)
+            model.eval()
+            n_frames = int(os.environ.get("BENCH_INFER_FRAMES", "400"))      # (the PMC passes of scripts/profile_r2.sh shorten it)
+            z = torch.randn(1, 80, n_frames, device="cuda") * 0.5
+            text = b["text"][:1, :69]
+            spk = b["speaker_ids"][:1]
+            n_fl = MODEL_CONFIG["n_flows"]
+            hops = handoff_hops()
+
+            def time_infer(operands):
+                """median wall time of Flowtron.infer (400 frames, gate disabled) with the decoder of that operand mode"""
+                os.environ["FLOWTRON_MFMA"] = operands
+                try:
+                    for _ in range(2):
+                        model.infer(z, spk, text, gate_threshold=1.0)       # warm-up (+ hipGraph capture / weight images)
                     torch.cuda.synchronize()
-                    tis.append(time.perf_counter() - t1)
+                    tis = []
+                    for _ in range(int(os.environ.get("BENCH_INFER_CALLS", "7"))):
+                        t1 = time.perf_counter()
+                        mel, _ = model.infer(z, spk, text, gate_threshold=1.0)
+                        torch.cuda.synchronize()
+                        tis.append(time.perf_counter() - t1)
+                finally:
+                    os.environ["FLOWTRON_MFMA"] = args.mfma
                 ti = sorted(tis)[len(tis) // 2]
-                n_fl = MODEL_CONFIG["n_flows"]
-                wbytes = 26838656 * (2 if args.mfma in ("bf16", "f16") else 4)   # weights streamed per frame per flow (bf16 images in bf16 mode)
-                ach = n_fl * wbytes * mel.shape[2] / ti / 1e9
-                res["infer"] = {"frames": int(mel.shape[2]), "seconds": round(ti, 5), "seconds_min": round(min(tis), 5),
-                                "seconds_max": round(max(tis), 5), "calls": len(tis), "frames_per_s": round(mel.shape[2] / ti, 1),
-                                "rtf": round(ti / (mel.shape[2] * HOP / SR), 5),
-                                "us_per_frame_per_flow": round(ti / mel.shape[2] / n_fl * 1e6, 2),
-                                "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                                             "frac": round(ach / 8000.0, 4), "bytes_per_frame_per_flow": wbytes},
-                                "config": "2-flow LJS, B=1, L=69, sigma=0.5, %s weights, gate disabled, median of %d calls"
-                                          % ("bf16 images of the" if args.mfma in ("bf16", "f16") else "fp32", len(tis))}
+                nf = int(mel.shape[2])
+                return nf, ti, {"frames": nf, "seconds": round(ti, 5), "seconds_min": round(min(tis), 5), "seconds_max": round(max(tis), 5),
+                                "calls": len(tis), "frames_per_s": round(nf / ti, 1), "rtf": round(ti / (nf * HOP / SR), 5),
+                                "us_per_frame_per_flow": round(ti / nf / n_fl * 1e6, 2)}
+            try:
+                log("inference RTF (16-bit weight images, persistent decode) ...")
+                nf, ti, blk = time_infer(args.mfma)
+                # dec_persist_k streams nothing per frame (the flow's weights are register-resident), so neither HBM nor MFMA bounds
+                # it: a frame is 9 dependent stages, each ending in a hand-off of its output vector -- 5 chip-wide (h_att, h0, h1, u1,
+                # u2: one fabric hop into every XCD + one L2 hop to every CU) and 4 XCD-local (query, scores, context, conv output)
+                floor = 5 * (hops["cross_xcd_hop_us"] + hops["same_xcd_hop_us"]) + 4 * hops["same_xcd_hop_us"]
+                per = ti / nf / n_fl * 1e6
+                blk["roofline"] = {"bound": "handoff-latency", "stages_per_frame": 9, "floor_us_per_frame_per_flow": round(floor, 2),
+                                   "us_per_frame_per_flow": round(per, 2), "frac": round(floor / per, 3),
+                                   "note": "floor = 5 x (cross-XCD hop + same-XCD hop) + 4 x same-XCD hop from profiles/r02_handoff_hops.json; the "
+                                           "GEMV arithmetic of a stage (VALU, 26.8 M weights over 1024 waves) and host-side launch / "
+                                           "result copies are what frac leaves"}
+                blk["config"] = "2-flow LJS, B=1, L=69, sigma=0.5, %s images of the weights (NARROWER than the reference's fp32 inference.py; see infer_fp32), gate disabled" % args.mfma
+                res["infer"] = blk
             except Exception as e:
                 res["infer"] = {"error": repr(e)}
+            try:
+                log("inference RTF (fp32 weights: the reference's precision) ...")
+                nf, ti, blk = time_infer("f32")
+                wbytes = 26838656 * 4                                   # SURVEY 8d: weights a frame of one flow must read, fp32
+                ach = n_fl * wbytes * nf / ti / 1e9
+                blk["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                                   "bytes_per_frame_per_flow": wbytes,
+                                   "note": "fp32 weights do not fit the register file (107 MB per flow): the staged hipGraph chain streams them "
+                                           "every frame (L2 / Infinity Cache resident after the first frame)"}
+                blk["config"] = ("2-flow LJS, B=1, L=69, sigma=0.5, fp32 weights and arithmetic = the reference's inference.py:68-71 "
+                                 "(no autocast), staged hipGraph decode chain, gate disabled")
+                res["infer_fp32"] = blk
+            except Exception as e:
+                res["infer_fp32"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and args.config == "ljs":
             try:
                 log("cpu baseline (oracle, bounded sample) ...")

@@ -105,7 +105,8 @@ SIGNATURES = {
     "ft_attn_ctc_bwd": ([_p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_beta_binomial_prior": ([_p, _p, _p, _i, _i, _i, _f, _p], _i),
     "ft_sumsq": ([_p, _p, _l, _p], _i),
-    "ft_radam_step": ([_p, _p, _p, _p, _l, _p, _d, _d, _d, _d, _d, _d, _d, _i, _p], _i),
+    "ft_radam_step": ([_p, _p, _p, _p, _l, _p, _d, _d, _d, _d, _d, _d, _d, _i, _p, _p], _i),
+    "ft_poison_if_nonzero": ([_p, _p, _p], _i),
 }
 
 # fp16-operand twins (include/flowtron_hip.h, end): same signatures, suffix _f16
@@ -131,7 +132,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argt
             fn.restype = rest
-        if l.ft_abi_version() != 4:
+        if l.ft_abi_version() != 5:
             raise RuntimeError("libflowtron_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -286,13 +286,21 @@ __global__ void sumsq_k(const float* __restrict__ x, float* __restrict__ acc, lo
 //   v = b2 v + (1-b2) g'^2 ; m = b1 m + (1-b1) g'
 //   p -= wd*lr*p (if wd != 0) ; N_sma >= 5: p -= step_size * m/(sqrt(v)+eps) ; else p -= step_size*m
 //   (step_size is the host-computed radam.py:95-105 value and already contains lr)
+__global__ void poison_k(const int* __restrict__ status, float* __restrict__ dst) {
+    if (status[0] != 0) dst[0] = __builtin_nanf("");
+}
+
 __global__ void radam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                         long n, const float* __restrict__ gnorm_sq, float clip, float wd_lr, float b1, float b2, float omb1,
-                        float omb2, float eps, float step_size, int rectified) {
+                        float omb2, float eps, float step_size, int rectified, int* __restrict__ skipped) {
     float cs = 1.f;
-    if (gnorm_sq && clip > 0.f) {
-        const float nrm = sqrtf(gnorm_sq[0]);
-        cs = fminf(1.f, clip / (nrm + 1e-6f));
+    if (gnorm_sq) {
+        const float sq = gnorm_sq[0];
+        if (!(sq <= 3.0e38f)) {                     // NaN or Inf: drop the step (include/flowtron_hip.h, guard)
+            if (skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
+            return;
+        }
+        if (clip > 0.f) cs = fminf(1.f, clip / (sqrtf(sq) + 1e-6f));
     }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * cs;
@@ -446,14 +454,20 @@ extern "C" int ft_sumsq(const float* x, float* acc, int64_t n, void* stream) {
 }
 extern "C" int ft_radam_step(float* p, const float* g, float* m, float* v, int64_t n,
                              const float* gnorm_sq_dev, double clip, double lr, double beta1, double beta2, double eps,
-                             double weight_decay, double step_size, int rectified, void* stream) {
+                             double weight_decay, double step_size, int rectified, int32_t* skipped_dev, void* stream) {
     FT_CHECK_ARG(p && g && m && v && n >= 0);
     if (n == 0) return FT_OK;
     // hyper-parameters arrive in double, as the python optimizer holds them: the derived coefficients are formed in double
     // and rounded once, like the scalars radam.py hands to mul_/add_/addcmul_
     hipLaunchKernelGGL(radam_k, dim3(grid_for(n, NT, 4096)), dim3(NT), 0, ST(stream), p, g, m, v, (long)n, gnorm_sq_dev, (float)clip,
                        (float)(weight_decay * lr), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
-                       (float)step_size, rectified);
+                       (float)step_size, rectified, skipped_dev);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_poison_if_nonzero(const int32_t* status_dev, float* dst, void* stream) {
+    FT_CHECK_ARG(status_dev && dst);
+    hipLaunchKernelGGL(poison_k, dim3(1), dim3(1), 0, ST(stream), status_dev, dst);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

@@ -7,7 +7,7 @@ reference (distributed.py:96-120)                 here
 per step: torch.cat of 68 grads (244 MB copy),     ONE persistent flat fp32 gradient arena; every
 all_reduce, /= world, 68 copy_ back                 param.grad is a VIEW into it, so the step is a
                                                     in-place RCCL all-reduce(AVG) of the arena, one
-                                                    bucket per flow, launched as its gradients complete
+                                                    bucket per flow (regime agreed across ranks at wrap time)
 68 parameter broadcasts at start-up                 one broadcast of a flat parameter arena
 4 scalar all-reduces + .item() per step             reduce_tensors(): one 4-float all-reduce
 
@@ -182,23 +182,39 @@ def gradient_buckets(module, arena: "FlatArena"):
     return out
 
 
+def _agree_min(flag: int) -> int:
+    """the minimum of an integer flag over all ranks (one tiny collective at wrap time): every rank then runs the same regime"""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return int(flag)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(flag)], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
 def apply_gradient_allreduce(module):
     """distributed.py:81-133: same contract (the module keeps its class; gradients are averaged across ranks once per
-    backward).  The persistent flat gradient arena is reduced IN PLACE, bucket by bucket: a bucket (one flow's parameters,
-    ~120 MB) is handed to RCCL the moment the last of its gradients has been accumulated (post-accumulate-grad hooks), so
-    the all-reduce of flow F-1 runs on RCCL's stream under the backward recurrences of flows F-2 .. 0 -- launch chains that
-    leave most of the chip idle -- and only the last bucket (embeddings + encoder, 9 MB) is exposed.  Whatever was not
-    launched by then (parameters without a gradient) is reduced by the end-of-backward callback, which also waits.
+    backward).  The persistent flat gradient arena is reduced IN PLACE, bucket by bucket (one bucket per flow, ~111 MB, plus
+    encoder + embeddings), each bucket one async RCCL all-reduce(AVG), all waited for by the end-of-backward callback.
+
+    Two regimes, chosen ONCE at wrap time and agreed across ranks (all_reduce(MIN) of the flag), so that every rank always issues
+    the same collectives in the same order -- never from per-rank run-time state:
+      default            the buckets leave back to back from the end-of-backward callback, in arena order, when nothing else is
+                         queued on the device.  The default training path runs the persistent recurrence kernels
+                         (csrc/lstm_persist.hip: all 256 CUs, one workgroup per CU, workgroups spin on each other); an RCCL kernel
+                         holding CUs beside a partly resident persistent grid stalls it until the collective's kernel has exited,
+                         and the whole exchange is ~1.4 ms at N = 8, so nothing is gained by overlapping.
+      FLOWTRON_DP_OVERLAP=1 (on every rank)   a bucket is handed to RCCL the moment the last of its gradients has been
+                         accumulated (post-accumulate-grad hooks), under the remaining backward.  Meant for the launch-per-step
+                         kernels (FLOWTRON_LSTM_PERSIST=0, batches > 32, H != 1024), whose launch chains leave most of the chip idle.
+    Launch order inside a regime is a function of the autograd graph only (completion order of the buckets, then arena order
+    for whatever was not launched by a hook), identical on all ranks.
     FLOWTRON_DP_BUCKETS=1 falls back to ONE all-reduce of the whole arena at the end of backward.
 
-    Co-residency rule.  The persistent recurrence kernels (csrc/lstm_persist.hip) need all 256 CUs at once, one workgroup
-    per CU owning the whole register file, and spin on each other: an RCCL kernel that is only partly resident beside a partly
-    resident persistent grid on two ranks can wait on each other across ranks (ring channel c needs channel c resident on
-    every rank) until the persistent kernel's 0.5 s timeout fires.  So when the forward pass of this step used them, the
-    buckets are NOT launched under backward: they go out back to back from the end-of-backward callback, when nothing else
-    is queued on the device (still in place, still AVG-folded, still pipelined bucket after bucket).  The overlap applies to
-    the launch-per-step kernels (FLOWTRON_LSTM_PERSIST=0, batches > 32, H != 1024).  FLOWTRON_DP_OVERLAP=1 | 0 overrides."""
-    ws = dist.get_world_size() if dist.is_initialized() else 1
+    Robustness: the hook state is re-armed by the forward pre-hook, so a backward pass that raised (the engine then never runs
+    the end-of-backward callback) cannot leave stale counters behind; before a bucket leaves, `if (persistent-recurrence status)
+    grad = NaN` is enqueued on it (optim.poison_from_status), which makes a failed recurrence on ONE rank drop that optimizer
+    step on EVERY rank (ft_radam_step's non-finite-norm guard) instead of averaging garbage into the weights."""
     arena = FlatArena.for_params(list(module.parameters()), flatten_params=True)
     module._grad_arena = arena
     if dist.is_initialized():
@@ -206,24 +222,26 @@ def apply_gradient_allreduce(module):
         for b in module.buffers():
             dist.broadcast(b, 0)
     module.needs_reduction = True
-    bucketed = os.environ.get("FLOWTRON_DP_BUCKETS", "flow") != "1"
+    bucketed = bool(_agree_min(os.environ.get("FLOWTRON_DP_BUCKETS", "flow") != "1"))
+    overlap = bool(_agree_min(os.environ.get("FLOWTRON_DP_OVERLAP", "0") == "1")) and bucketed
     buckets = gradient_buckets(module, arena) if bucketed else [("all", 0, arena.numel, list(range(len(arena.params))))]
     bucket_of = {}
     for bi, (_, _, _, idx) in enumerate(buckets):
         for i in idx:
             bucket_of[id(arena.params[i])] = bi
-    state = {"left": [len(b[3]) for b in buckets], "launched": [False] * len(buckets), "pending": [], "queued": False,
-             "persist_before": 0, "overlap": True}
-    force = os.environ.get("FLOWTRON_DP_OVERLAP", "auto")
-
-    def persist_launches():
-        try:
-            from . import ops
-            return ops.PERSIST_LAUNCHES
-        except Exception:                                        # CPU-only host (gloo tests): no HIP library, no persistent kernels
-            return 0
+    state = {"left": [len(b[3]) for b in buckets], "launched": [False] * len(buckets), "pending": [], "queued": False}
     module._grad_buckets = buckets
+    module._grad_overlap = overlap
     module._grad_bucket_log = []                                 # order in which buckets were launched in the last backward (tests)
+    on_gpu = arena.flat_grad.is_cuda
+
+    def rearm():
+        for pend in state["pending"]:                            # collectives of a pass whose callback never ran: every rank issued
+            _finish(pend)                                        # them (same graph), so waiting is safe; their result is discarded
+        state["pending"] = []
+        state["left"] = [len(b[3]) for b in buckets]
+        state["launched"] = [False] * len(buckets)
+        state["queued"] = False
 
     def launch(bi):
         if state["launched"][bi] or not dist.is_initialized():
@@ -231,6 +249,9 @@ def apply_gradient_allreduce(module):
         state["launched"][bi] = True
         _, lo, hi, idx = buckets[bi]
         arena.adopt_stray_grads(copy=True, only=idx)
+        if on_gpu:
+            from .optim import poison_from_status
+            poison_from_status(arena.flat_grad[lo:hi])
         module._grad_bucket_log.append(buckets[bi][0])
         state["pending"].append(_avg_all_reduce(arena.flat_grad[lo:hi], async_op=True))
 
@@ -238,7 +259,7 @@ def apply_gradient_allreduce(module):
         state["queued"] = False
         if module.needs_reduction:
             module.needs_reduction = False
-            for bi in range(len(buckets)):                       # leftovers: buckets with a gradient-less parameter
+            for bi in range(len(buckets)):                       # everything a hook did not launch, in arena order
                 launch(bi)
             for pend in state["pending"]:
                 _finish(pend)
@@ -255,19 +276,20 @@ def apply_gradient_allreduce(module):
             Variable._execution_engine.queue_callback(finish_backward)
         bi = bucket_of[id(p)]
         state["left"][bi] -= 1
-        if bucketed and state["overlap"] and state["left"][bi] == 0:
+        if state["left"][bi] < 0:
+            raise RuntimeError("gradient hook of bucket %r fired more often than it has parameters: the hook state was not re-armed "
+                               "(two backward passes through one forward?)" % (buckets[bi][0],))
+        if overlap and state["left"][bi] == 0:
             launch(bi)
 
     for p in arena.params:
         p.register_post_accumulate_grad_hook(on_grad)
 
     def before_forward(self, input):
-        state["persist_before"] = persist_launches()
+        rearm()
 
     def set_needs_reduction(self, input, output):
         self.needs_reduction = True
-        used_persistent = persist_launches() != state["persist_before"]
-        state["overlap"] = (force == "1") or (force != "0" and not used_persistent)
 
     module.register_forward_pre_hook(before_forward)
     module.register_forward_hook(set_needs_reduction)

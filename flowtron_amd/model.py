@@ -354,8 +354,13 @@ class AR_Step(nn.Module):
                 args.persist_gran, args.persist_status = L.ptr(gran), L.ptr(persist)
         L.check(L.lib().ft_decode_flow(C.byref(args), L.stream()), "ft_decode_flow")
         n = int(n_done.item()) if has_gate else N          # single host read per flow (the reference syncs every frame)
-        if persist is not None:
-            ops.check_persist_status()
+        if persist is not None and not ops.check_persist_status(raise_on_failure=False):
+            # the one-launch decode did not complete (grid not co-resident): logged once by ops, the device is switched to the
+            # launch-per-step / staged kernels, and THIS flow is decoded again on the staged chain -- the caller never sees it
+            args.persist_gran, args.persist_status = None, None
+            attn_out.zero_()
+            L.check(L.lib().ft_decode_flow(C.byref(args), L.stream()), "ft_decode_flow")
+            n = int(n_done.item()) if has_gate else N
         del keep
         mel = mel_out[:n].clone().reshape(n, 1, M)          # the persistent buffers are overwritten by the next call
         attn_all = attn_out[:n].clone()

@@ -344,9 +344,14 @@ def conv_norm_relu(x, lens, conv_w, conv_b, gamma, beta, keep=None, eps=1e-5, mo
 # persistent recurrence kernels (csrc/lstm_persist.hip): one launch per sequence, W_hh resident in registers
 # --------------------------------------------------------------------------
 # The kernels raise a device status word instead of hanging when their hand-off waits time out (grid not co-resident,
-# partitioned device).  It is checked without stalling the stream: a self-test on first use (synchronous, once per device)
-# decides whether the path is usable at all; afterwards every launch first looks at an asynchronous host copy of the word made
-# after the PREVIOUS launch, so a failure surfaces one launch late as a RuntimeError instead of as silent garbage.
+# partitioned device, a foreign kernel holding CUs).  Nothing here stalls the stream and nothing kills a run:
+#   * a self-test on first use (synchronous, once per device) decides whether the path is usable at all;
+#   * afterwards every launch first looks at an asynchronous host copy of the word made after the PREVIOUS launch: a failure
+#     surfaces one launch late, is logged ONCE, and switches this device to the launch-per-step kernels for good;
+#   * the step that contained the failed launch never reaches the weights: the word stays set until the optimizer (or the DP
+#     wrapper, before the gradient all-reduce) has enqueued `if (status) grad[0] = NaN` (ft_poison_if_nonzero), and the fused
+#     RAdam kernel drops an update whose global gradient norm is not finite (ft_radam_step) -- on every rank, without a host
+#     synchronisation.  While the word is set, further persistent launches of that step abort at their first wait.
 _PERSIST = {}
 
 
@@ -356,6 +361,8 @@ class _PersistState:
         self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.event = None
         self.usable = None          # None = not tested yet
+        self.fail_seen = False      # the host has noticed a failure whose status word has not been consumed (poisoned) yet
+        self.failures = 0
 
 
 def _persist_state(device):
@@ -369,18 +376,35 @@ def persist_status(device):
     return _persist_state(device).status
 
 
+def _persist_failed(st, device, code, where):
+    import warnings
+    st.usable = False
+    st.fail_seen = True
+    st.failures += 1
+    st.event = None
+    warnings.warn("flowtron_amd: a persistent recurrence launch on %s did not complete (status %d, seen %s): the 256-workgroup grid was "
+                  "not co-resident / the XCD census failed.  That optimizer step is dropped (non-finite-norm guard) and this device "
+                  "uses the launch-per-step kernels from now on." % (device, code, where))
+
+
 def _persist_watch(device):
-    """raise if an earlier persistent launch reported a failure; then queue a fresh asynchronous copy of the status word."""
+    """look at the asynchronous host copy of the status word made after the previous persistent launch (no stall)"""
     st = _persist_state(device)
     if st.event is not None and st.event.query():
-        if int(st.host[0]) != 0:
-            st.status.zero_()
-            st.event = None
-            st.usable = False
-            raise RuntimeError("a persistent LSTM launch did not complete (status %d): the 256-workgroup grid was not "
-                               "co-resident / XCD census failed; falling back to the launch-per-step kernels from now on"
-                               % int(st.host[0]))
+        code = int(st.host[0])
+        st.event = None
+        if code != 0 and not st.fail_seen:
+            _persist_failed(st, device, code, "one launch late")
     return st
+
+
+def persist_consume_failure(device):
+    """Called by whoever has just enqueued the poison of this step's gradients (optim.poison_from_status): once the host has seen
+    the failure, the status word is cleared BEHIND the poison kernel on the stream, so exactly the affected steps are dropped."""
+    st = _PERSIST.get(device)
+    if st is not None and st.fail_seen:
+        st.status.zero_()
+        st.fail_seen = False
 
 
 PERSIST_LAUNCHES = 0          # persistent (whole-chip, co-resident) kernel launches so far: dist.py keeps collectives away from them
@@ -394,14 +418,24 @@ def _persist_arm(st):
     st.event.record()
 
 
-def check_persist_status():
-    """Host check (one sync) of every persistent-kernel status word; raises if a sequence did not complete."""
+def check_persist_status(raise_on_failure=True):
+    """Host check (one sync) of every persistent-kernel status word.  Tests / bench / inference call it where a garbage result
+    must not go unnoticed; returns True when everything completed.  On a failure the device is switched to the launch-per-step
+    kernels; with raise_on_failure the caller gets a RuntimeError (the result it just computed is invalid), otherwise False
+    (the caller re-runs, e.g. AR_Step.infer on the staged decode chain)."""
+    ok = True
     for dev, st in _PERSIST.items():
-        if int(st.status.item()) != 0:
+        code = int(st.status.item())
+        if code != 0:
+            ok = False
+            if not st.fail_seen:
+                _persist_failed(st, dev, code, "by a synchronous check")
             st.status.zero_()
-            st.usable = False
-            raise RuntimeError("persistent LSTM kernel timed out on %s: the 256-workgroup grid was not co-resident "
-                               "(set FLOWTRON_LSTM_PERSIST=0 to use the launch-per-step kernels)" % (dev,))
+            st.fail_seen = False
+            if raise_on_failure:
+                raise RuntimeError("persistent kernel timed out on %s (status %d): the 256-workgroup grid was not co-resident; the "
+                                   "launch-per-step kernels are used from now on (FLOWTRON_LSTM_PERSIST=0 selects them up front)" % (dev, code))
+    return ok
 
 
 def _persist_selftest(device, ng):

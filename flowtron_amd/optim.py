@@ -7,7 +7,14 @@ as views into flat moment arenas, so `optimizer.state_dict()` stays checkpoint-c
 `load_state_dict` copies a loaded checkpoint's moments back INTO the arenas (the kernels read only the arenas).
 
 Parameters whose .grad is None at step() time are skipped like radam.py:57-58 (`if p.grad is None: continue`): no moment
-update, no weight decay; they do not enter the global norm either (torch clip_grad_norm_ ignores them).
+update, no weight decay, their state['step'] does not advance; they do not enter the global norm either (torch
+clip_grad_norm_ ignores them).  Deviation: bias correction and N_sma use ONE global step count for the whole arena (radam.py
+keeps one per parameter; they only differ for a parameter that was without a gradient for some iterations).
+
+Guard: the fused kernel drops the whole update when the global gradient norm is NaN / Inf (ft_radam_step): the device-side
+equivalent of GradScaler's overflow skip (train.py:330), which also catches a step poisoned by a persistent recurrence that
+reported a time-out (`poison_from_status`) -- on every rank, because the poison travels through the gradient all-reduce.
+`skipped_steps` reads the device counter.
 """
 from __future__ import annotations
 
@@ -36,6 +43,8 @@ class RAdam(Optimizer):
         self.flat_m = torch.zeros_like(arena.flat_grad)
         self.flat_v = torch.zeros_like(arena.flat_grad)
         self.gnorm_sq = torch.zeros(1, device=arena.flat_grad.device, dtype=torch.float32)
+        self._skipped = torch.zeros(1, device=arena.flat_grad.device, dtype=torch.int32)
+        self._have_norm = False
         self._step = 0
         self._bind_state()
 
@@ -79,13 +88,24 @@ class RAdam(Optimizer):
             return ss, True
         return lr / (1 - beta1 ** step), False
 
+    @property
+    def skipped_steps(self) -> int:
+        """updates the device-side guard dropped so far (non-finite global gradient norm); one host read"""
+        return int(self._skipped.item())
+
+    def _norm_sq(self):
+        """||g||^2 of the arena on device; a persistent recurrence that reported a time-out poisons it first (NaN)."""
+        a = self.arena
+        a.adopt_stray_grads(copy=True)
+        poison_from_status(a.flat_grad)
+        self.gnorm_sq.zero_()
+        L.check(L.lib().ft_sumsq(L.ptr(a.flat_grad), L.ptr(self.gnorm_sq), a.numel, L.stream()), "ft_sumsq")
+        self._have_norm = True
+
     def clip_grad_norm_(self, max_norm: float):
         """Enqueue ||g||^2 on device and remember the clip for the next step(); returns the device scalar ||g||^2
         (no host sync -- torch.nn.utils.clip_grad_norm_ at train.py:328 does 68 norms and a sync)."""
-        a = self.arena
-        a.adopt_stray_grads(copy=True)
-        self.gnorm_sq.zero_()
-        L.check(L.lib().ft_sumsq(L.ptr(a.flat_grad), L.ptr(self.gnorm_sq), a.numel, L.stream()), "ft_sumsq")
+        self._norm_sq()
         self._clip = float(max_norm)
         return self.gnorm_sq
 
@@ -103,17 +123,32 @@ class RAdam(Optimizer):
         beta1, beta2 = g["betas"]
         ss, rect = self.step_size_for(self._step, g["lr"], beta1, beta2)
         clip = getattr(self, "_clip", 0.0)
+        if not self._have_norm:                  # no clip_grad_norm_ this iteration: the guard still needs the norm (clip stays 0)
+            self._norm_sq()
         L.check(L.lib().ft_radam_step(L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.flat_m), L.ptr(self.flat_v),
-                                      a.numel, L.ptr(self.gnorm_sq) if clip > 0 else None, clip, g["lr"], beta1, beta2,
-                                      g["eps"], g["weight_decay"], ss, int(rect), L.stream()), "ft_radam_step")
+                                      a.numel, L.ptr(self.gnorm_sq), clip, g["lr"], beta1, beta2,
+                                      g["eps"], g["weight_decay"], ss, int(rect), L.ptr(self._skipped), L.stream()), "ft_radam_step")
         self._clip = 0.0
+        self._have_norm = False
         for off, k, pv, mv, vv in keep:
             a.flat_param[off:off + k].copy_(pv)
             self.flat_m[off:off + k].copy_(mv)
             self.flat_v[off:off + k].copy_(vv)
-        for p in a.params:
-            self.state[p]["step"] = self._step
+        held = {off for off, _ in skipped}
+        for p, off in zip(a.params, a.offsets):
+            if off not in held:                  # radam.py:57-58: a parameter without a gradient keeps its step count
+                self.state[p]["step"] = self._step
         return loss
 
     def zero_grad(self, set_to_none: bool = False):
         self.arena.zero_grad()
+
+
+def poison_from_status(flat: torch.Tensor):
+    """Enqueue `if (persistent-recurrence status word != 0) flat[0] = NaN` (ft_poison_if_nonzero): no host synchronisation.
+    A no-op when no persistent kernel has run on this device."""
+    from . import ops
+    st = ops._PERSIST.get(flat.device)
+    if st is not None:
+        L.check(L.lib().ft_poison_if_nonzero(L.ptr(st.status), L.ptr(flat), L.stream()), "ft_poison_if_nonzero")
+        ops.persist_consume_failure(flat.device)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 4
+#define FT_ABI_VERSION 5
 
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1, FT_F16 = 2 };
@@ -321,11 +321,19 @@ int ft_beta_binomial_prior(const int32_t* in_lens, const int32_t* out_lens, floa
  * One pass: g *= min(1, clip / (sqrt(*gnorm_sq_dev) + 1e-6)) (torch clip_grad_norm_, train.py:328; skipped when clip == 0
  * or gnorm_sq_dev == NULL), v = beta2 v + (1-beta2) g g, m = beta1 m + (1-beta1) g, p -= weight_decay*lr*p,
  * p -= step_size * (rectified ? m / (sqrt(v) + eps) : m).  step_size is radam.py:95-105 (contains lr).  Hyper-parameters
- * are doubles like the python optimizer's; derived coefficients are rounded to fp32 once. */
+ * are doubles like the python optimizer's; derived coefficients are rounded to fp32 once.
+ * Guard (device side, no host synchronisation): when gnorm_sq_dev is given and *gnorm_sq_dev is NaN or Inf the whole update
+ * is SKIPPED -- p, m, v keep their values -- and *skipped_dev (optional) is incremented: what GradScaler.step does for an fp16
+ * overflow (train.py:330), extended to every non-finite global norm, so that one poisoned step (ft_poison_if_nonzero below)
+ * can never reach the weights or the moments. */
 int ft_sumsq(const float* x, float* acc, int64_t n, void* stream);
 int ft_radam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   const float* gnorm_sq_dev, double clip, double lr, double beta1, double beta2, double eps,
-                  double weight_decay, double step_size, int rectified, void* stream);
+                  double weight_decay, double step_size, int rectified, int32_t* skipped_dev, void* stream);
+/* if (*status_dev != 0) dst[0] = NaN.  Enqueued behind the last persistent recurrence launch of a backward pass on the first
+ * element of a gradient bucket BEFORE its all-reduce / the norm reduction: a recurrence that reported a time-out (status word of
+ * ft_lstm_persist_*) poisons the global gradient norm on EVERY rank, and the guard of ft_radam_step drops that step everywhere. */
+int ft_poison_if_nonzero(const int32_t* status_dev, float* dst, void* stream);
 
 /* ---- fp16-operand twins (FT_F16): same signatures, semantics and workspace queries as the entries they are named after;
  * 16-bit images / fragments made by a twin must only be fed to twins. ---- */

@@ -116,17 +116,39 @@ class _ToyFlows(torch.nn.Module):
         return x
 
 
-def _bucket_worker(rank, world, port, q, mode, with_unused):
+def _bucket_worker(rank, world, port, q, mode, with_unused, overlap="1", raise_in_backward=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["FLOWTRON_DP_BUCKETS"] = mode
+    os.environ["FLOWTRON_DP_OVERLAP"] = overlap[rank] if isinstance(overlap, (list, tuple)) else overlap
     import distributed as D
     D.init_distributed(rank, world, "gloo", None)
     torch.manual_seed(5)
     net = D.apply_gradient_allreduce(_ToyFlows(3, with_unused))
     torch.manual_seed(50 + rank)
     ids, x = torch.randint(0, 11, (4, 3)), torch.randn(4, 6)
-    res = {"ids": ids, "x": x}
+    res = {"ids": ids, "x": x, "overlap": bool(net._grad_overlap)}
+    if raise_in_backward:
+        # a backward pass that dies half way (OOM, a raising hook): the autograd engine never runs the end-of-backward callback, so
+        # `queued` / `left` / `pending` are stale; the forward pre-hook must re-arm them or every later step trains on unreduced
+        # gradients.  Every rank raises at the same node (same graph), so the collectives already issued match.
+        class _Boom(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, v):
+                return v.clone()
+
+            @staticmethod
+            def backward(ctx, g):
+                raise RuntimeError("boom")
+        net.zero_grad()
+        h = net.flows[0]
+        y = net(ids, x)
+        hooked = _Boom.apply(net.flows[1][0].weight)             # flows.2 has completed when this node is reached
+        try:
+            (y.pow(2).mean() + 0.0 * hooked.sum()).backward()
+            res["raised"] = False
+        except RuntimeError:
+            res["raised"] = True
     for it in range(2):
         net.zero_grad()
         net(ids, x).pow(2).mean().backward()
@@ -139,12 +161,12 @@ def _bucket_worker(rank, world, port, q, mode, with_unused):
     dist.destroy_process_group()
 
 
-def _run_bucket_world(mode, with_unused):
+def _run_bucket_world(mode, with_unused, overlap="1", raise_in_backward=False):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q, mode, with_unused)) for r in range(world)]
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q, mode, with_unused, overlap, raise_in_backward)) for r in range(world)]
     for p in procs:
         p.start()
     out = {r: _tensors(v) for r, v in (q.get(timeout=120) for _ in range(world))}
@@ -156,7 +178,7 @@ def _run_bucket_world(mode, with_unused):
 
 @pytest.mark.parametrize("with_unused", [False, True])
 def test_per_flow_buckets_overlap_order_and_equal_the_single_allreduce(with_unused):
-    """per-flow buckets: launched in the order backward completes them (last flow first, front last), every rank ends with
+    """FLOWTRON_DP_OVERLAP=1 on every rank: per-flow buckets launched in the order backward completes them (last flow first, front last), every rank ends with
     the same averaged arena, identical to FLOWTRON_DP_BUCKETS=1 (one all-reduce at the end) and to the mean of the local
     gradients; a bucket holding a parameter that never gets a gradient is swept up by the end-of-backward callback."""
     a = _run_bucket_world("flow", with_unused)
@@ -187,3 +209,35 @@ def test_per_flow_buckets_overlap_order_and_equal_the_single_allreduce(with_unus
     arena = D.FlatArena(list(net.parameters()))
     for p, off, g0, g1 in zip(arena.params, arena.offsets, gs[0], gs[1]):
         assert torch.allclose(a[0]["g0"][off:off + p.numel()].view_as(p), (g0 + g1) / 2, atol=1e-6)
+
+
+
+def test_default_regime_is_end_of_backward_in_arena_order_and_ranks_agree_on_it():
+    """Default (no FLOWTRON_DP_OVERLAP): the buckets leave from the end-of-backward callback in arena order.  A rank whose
+    environment asks for overlap while another's does not must NOT issue a different collective sequence: the regime is the
+    MINIMUM over ranks, agreed once at wrap time -- both ranks run the default regime and end with the same averaged arena."""
+    a = _run_bucket_world("flow", False, overlap="0")
+    mixed = _run_bucket_world("flow", False, overlap=["1", "0"])
+    ref = _run_bucket_world("flow", False, overlap="1")
+    order = ["embedding+encoder", "flows.0", "flows.1", "flows.2"]
+    for world in (a, mixed):
+        for r in (0, 1):
+            assert world[r]["overlap"] is False
+            assert world[r]["log0"] == order and world[r]["log1"] == order
+        assert torch.equal(world[0]["g0"], world[1]["g0"]) and torch.equal(world[0]["g1"], world[1]["g1"])
+        assert torch.allclose(world[0]["g0"], ref[0]["g0"], atol=1e-7)
+    assert ref[0]["overlap"] is True and ref[1]["overlap"] is True
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_hook_state_is_rearmed_after_a_backward_pass_that_raised(overlap):
+    """the end-of-backward callback does not run when backward raises; the next forward must re-arm the hook state
+    (and wait for collectives the dead pass had already issued) so that the following steps still reduce every bucket."""
+    a = _run_bucket_world("flow", False, overlap=overlap, raise_in_backward=True)
+    ref = _run_bucket_world("flow", False, overlap=overlap)
+    for r in (0, 1):
+        assert a[r]["raised"] is True
+        for it in (0, 1):
+            assert len(a[r]["log%d" % it]) == 4, a[r]["log%d" % it]
+            assert torch.allclose(a[r]["g%d" % it], ref[r]["g%d" % it], atol=1e-7)
+    assert torch.equal(a[0]["g1"], a[1]["g1"])

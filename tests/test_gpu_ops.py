@@ -295,7 +295,7 @@ def test_sumsq_radam_colsum(env):
     assert abs(acc.item() - (gr.double() ** 2).sum().item()) < 1e-4 * acc.item()
     clip, lr, b1, b2, eps, wd, step_size = 1.0, 1e-3, 0.9, 0.999, 1e-8, 1e-6, 2.5e-3
     L.check(L.lib().ft_radam_step(L.ptr(pd), L.ptr(gd), L.ptr(md), L.ptr(vd), n, L.ptr(acc), clip, lr, b1, b2, eps, wd,
-                                  step_size, 1, L.stream()), "radam")
+                                  step_size, 1, None, L.stream()), "radam")
     cs = min(1.0, clip / (gr.norm().item() + 1e-6))
     g2 = gr * cs
     v2 = v * b2 + (1 - b2) * g2 * g2

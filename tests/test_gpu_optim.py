@@ -129,3 +129,85 @@ def test_parameter_without_gradient_is_left_untouched():
     assert torch.equal(ps[1].detach(), before[1]) and ps[1].grad is None
     assert torch.equal(opt.state[ps[1]]["exp_avg"], m1)
     assert not torch.equal(ps[0].detach(), before[0])
+
+
+def test_non_finite_gradient_norm_drops_the_update_on_device():
+    """ft_radam_step's guard: a NaN / Inf global gradient norm leaves parameters and moments untouched and counts the skip
+    (device side, what GradScaler.step does for an fp16 overflow -- train.py:330); the following finite step is a normal one."""
+    from flowtron_amd.optim import RAdam
+    g = _golden()
+    ps = _params(g["shapes"])
+    opt = RAdam(ps, lr=1e-3, weight_decay=1e-6)
+    _set_grads(ps, 1, g["shapes"])
+    opt.clip_grad_norm_(1.0)
+    opt.step()
+    snap = (opt.arena.flat_param.clone(), opt.flat_m.clone(), opt.flat_v.clone())
+    for bad in (float("nan"), float("inf")):
+        _set_grads(ps, 2, g["shapes"])
+        ps[1].grad.view(-1)[3] = bad
+        opt.clip_grad_norm_(1.0)
+        opt.step()
+        assert torch.equal(opt.arena.flat_param, snap[0]) and torch.equal(opt.flat_m, snap[1]) and torch.equal(opt.flat_v, snap[2])
+    assert opt.skipped_steps == 2
+    _set_grads(ps, 2, g["shapes"])
+    opt.step()                                        # no clip this time: the guard computes the norm itself
+    assert not torch.equal(opt.arena.flat_param, snap[0]) and torch.isfinite(opt.arena.flat_param).all()
+    assert opt.skipped_steps == 2
+
+
+def test_failed_persistent_recurrence_drops_the_step_and_falls_back_without_killing_the_run():
+    """A persistent recurrence that reports a time-out (status word != 0; here injected between forward and backward of a
+    full-width bf16 step, which also makes the backward launches abort at their first wait) must not reach the weights and must
+    not raise: the step is poisoned (ft_poison_if_nonzero) and dropped by the optimizer's guard, the host notices one launch late,
+    warns ONCE, switches the device to the launch-per-step kernels, and training continues on them."""
+    import warnings
+    import flowtron
+    from flowtron_amd import ops
+    from flowtron_amd.optim import RAdam
+    from oracle import synth
+    os.environ["FLOWTRON_MFMA"] = "bf16"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    try:
+        cfg = dict(synth.DEFAULT_MODEL_CONFIG)
+        if not ops.lstm_persist_groups(4, cfg["n_hidden"], False, 1, dev):
+            pytest.skip("persistent recurrences not usable on this device")
+        m = flowtron.Flowtron(**cfg)
+        m.load_state_dict(synth.make_state_dict(cfg, seed=3))
+        m = m.cuda().eval()
+        opt = RAdam(m.parameters(), lr=1e-3, weight_decay=1e-6)
+        crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)
+        b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth.make_batch(cfg, [40, 33, 21, 12], [12, 9, 7, 5], seed=4, with_prior=True).items()}
+
+        def step(inject):
+            opt.zero_grad()
+            out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+            nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+            if inject:
+                ops.persist_status(dev).fill_(1)
+            (nll + gl + 0.01 * ctc).backward()
+            opt.clip_grad_norm_(1.0)
+            opt.step()
+            torch.cuda.synchronize()
+        step(False)
+        w1 = opt.arena.flat_param.clone()
+        launches = ops.PERSIST_LAUNCHES
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            step(True)                                 # poisoned: dropped
+            assert torch.equal(opt.arena.flat_param, w1)
+            step(False)                                # host has noticed by now (or notices here): fallback kernels; at most one more drop
+            step(False)
+            step(False)
+        msgs = [str(w.message) for w in caught if "persistent recurrence" in str(w.message)]
+        assert len(msgs) == 1, msgs
+        assert not ops.persist_usable(dev)
+        assert 1 <= opt.skipped_steps <= 2
+        assert torch.isfinite(opt.arena.flat_param).all() and not torch.equal(opt.arena.flat_param, w1)
+        assert int(ops.persist_status(dev).item()) == 0
+        n_after = ops.PERSIST_LAUNCHES
+        step(False)
+        assert ops.PERSIST_LAUNCHES == n_after          # launch-per-step kernels from now on
+        assert n_after > launches                       # (the injected step still launched persistent kernels)
+    finally:
+        os.environ["FLOWTRON_MFMA"] = "f32"
+        ops._PERSIST.clear()                            # later tests re-run the self-test and get the persistent path back
