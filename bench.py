@@ -415,13 +415,14 @@ def main():
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100, help="timed steps (default 100: a ~4 s timed region)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 100: a ~4 s timed region; 3 for --config ljs_cumm)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
     ap.add_argument("--mfma", default=None, choices=["bf16", "f16", "f32"], help="MFMA operand type (default: the config's)")
-    ap.add_argument("--config", default="ljs", choices=["ljs", "libritts", "libritts_fp16"],
+    ap.add_argument("--config", default="ljs", choices=["ljs", "libritts", "libritts_fp16", "ljs_cumm"],
                     help="ljs = BASELINE configs[1] (the headline line); libritts = configs[2] (123 speakers, L <= 237, bf16); "
-                         "libritts_fp16 = configs[4] (fp16 operands + GradScaler, no attention prior)")
+                         "libritts_fp16 = configs[4] (fp16 operands + GradScaler, no attention prior); ljs_cumm = configs[1] with "
+                         "use_cumm_attention (location-sensitive attention, SURVEY 8a row a17: the key projection is redone every frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
     args = ap.parse_args()
@@ -431,12 +432,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
     assert torch.cuda.is_available(), "bench.py needs an MI355X: the product path has no CPU fallback"
+    if args.steps is None:
+        args.steps = 3 if args.config == "ljs_cumm" else 100
     if args.mfma is None:
         args.mfma = "f16" if args.config == "libritts_fp16" else "bf16"
     os.environ["FLOWTRON_MFMA"] = args.mfma
-    libri = args.config != "ljs"
+    libri = args.config in ("libritts", "libritts_fp16")
     use_prior = args.config != "libritts_fp16"
-    model_config = dict(MODEL_CONFIG, n_speakers=123) if libri else dict(MODEL_CONFIG)
+    model_config = dict(MODEL_CONFIG, n_speakers=123) if libri else dict(MODEL_CONFIG, use_cumm_attention=args.config == "ljs_cumm")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "6000")
     torch.cuda.set_device(local_rank)
@@ -549,6 +552,7 @@ def main():
             "vs_baseline": None, "dtype": args.mfma, "data": "synthetic",
             "config": {"workload": "%s, per-GPU batch %d, T_max=%d, L_max=%d, %s + CTC on, fwd+loss+bwd+%sclip+RAdam%s"
                                    % ({"ljs": "BASELINE configs[1]: 2-flow LJS config.json model",
+                                       "ljs_cumm": "BASELINE configs[1] model with use_cumm_attention=True (location-sensitive attention)",
                                        "libritts": "BASELINE configs[2]: 2-flow LibriTTS model (123 speakers)",
                                        "libritts_fp16": "BASELINE configs[4]: 2-flow LibriTTS model (123 speakers), fp16 operands + GradScaler"}[args.config],
                                       args.batch, T, Lk, "attn-prior" if use_prior else "no attn-prior",

@@ -34,7 +34,8 @@ class GemmArgs(C.Structure):
 class GemmImgArgs(C.Structure):
     _fields_ = [("A", _p), ("B", _p), ("C", _p), ("bias", _p), ("M", _i), ("N", _i), ("K", _i),
                 ("lda", _l), ("ldb", _l), ("ldc", _l), ("a_kmajor", _i), ("b_kmajor", _i),
-                ("alpha", _f), ("beta", _f), ("act", _i), ("flags", _i)]
+                ("alpha", _f), ("beta", _f), ("act", _i), ("flags", _i),
+                ("rowmap", _p), ("rows_dev", _p), ("compact", _i), ("k_shift", _i)]
 
 
 class DecodeArgs(C.Structure):
@@ -59,6 +60,9 @@ SIGNATURES = {
     "ft_bf16_image": ([_p, _l, _l, _l, _p, _p], _i),
     "ft_bf16_image_colsum": ([_p, _l, _l, _l, _p, _p, _p], _i),
     "ft_gemm_img": ([C.POINTER(GemmImgArgs), _p], _i),
+    "ft_rowmap_build": ([_p, _p, _p, _i, _i, _p], _i),
+    "ft_bf16_image_rows": ([_p, _l, _l, _l, _p, _p, _p, _p, _p], _i),
+    "ft_pad_rows_fill": ([_p, _l, _i, _p, _i, _i, _i, _p], _i),
     "ft_embedding_fwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
     "ft_embedding_bwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
     "ft_im2col": ([_p, _p, _p, _i, _i, _i, _i, _p], _i),
@@ -110,7 +114,7 @@ SIGNATURES = {
 }
 
 # fp16-operand twins (include/flowtron_hip.h, end): same signatures, suffix _f16
-OP16_TWINS = ("ft_gemm", "ft_bf16_image", "ft_bf16_image_colsum", "ft_gemm_img", "ft_lstm_seq_fwd", "ft_lstm_seq_bwd",
+OP16_TWINS = ("ft_gemm", "ft_bf16_image", "ft_bf16_image_colsum", "ft_gemm_img", "ft_bf16_image_rows", "ft_lstm_seq_fwd", "ft_lstm_seq_bwd",
               "ft_lstm_persist_fwd", "ft_lstm_persist_bwd", "ft_lstm2_seq_fwd", "ft_lstm2_seq_bwd",
               "ft_lstm_bidir_seq_fwd", "ft_lstm_bidir_seq_bwd")
 for _n in OP16_TWINS:

@@ -46,6 +46,27 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ Q, c
     const int len = min(in_lens[b], L);
     const int nlt = (len + LT - 1) / LT;
 
+    // Tiles of padded frames (~30 % of a batch's rows): every query row of such a tile is the projection of the same zero LSTM
+    // output, so all TT score rows are equal.  Decided on the DATA, not on lengths (exact for any input): if the TT query rows
+    // of this tile are bit-identical, the scores are evaluated for ONE row (by the 32 threads of row group 0) and copied; the
+    // per-row softmax / prior posterior below still runs for every row (the prior may differ from frame to frame).
+    bool differs = false;
+    {
+        const float* q0 = Q + ((long)t0 * B + b) * A;
+        for (int idx = tid; idx < TT * AC && !differs; idx += 256) {            // cheap pre-filter: the first a-chunk
+            const int row = idx >> 6, col = idx & 63;
+            if (t0 + row < T && col < A) differs = Q[((long)(t0 + row) * B + b) * A + col] != q0[col];
+        }
+        if (!__syncthreads_or(differs ? 1 : 0)) {
+            for (int idx = tid; idx < TT * A; idx += 256) {
+                const int row = idx / A, col = idx % A;
+                if (t0 + row < T && Q[((long)(t0 + row) * B + b) * A + col] != q0[col]) { differs = true; break; }
+            }
+        }
+    }
+    const bool uniform_q = !__syncthreads_or(differs ? 1 : 0);
+    const bool idle = uniform_q && tg != 0;              // row groups 1..7 have nothing to compute in a uniform tile
+
     for (int lt = 0; lt < nlt; ++lt) {
         float acc[4][4];
 #pragma unroll
@@ -75,6 +96,25 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ Q, c
             }
             if (tid < AC) vs[tid] = (a0 + tid < A) ? v[a0 + tid] : 0.f;
             __syncthreads();
+            if (uniform_q) {                                   // one score row (same summation order as the general path below)
+                if (!idle) {
+#pragma unroll 2
+                    for (int a4 = 0; a4 < AC / 4; ++a4) {
+                        const float4 vv = *reinterpret_cast<const float4*>(vs + a4 * 4);
+                        vsum += (vv.x + vv.y) + (vv.z + vv.w);
+                        const float4 q0 = *reinterpret_cast<const float4*>(qs + a4 * 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (jact[j]) {
+                                const float4 kk = *reinterpret_cast<const float4*>(ks + (j * 32 + tl) * LDA + a4 * 4);
+                                acc[0][j] += vv.x * rsig(q0.x + kk.x) + vv.y * rsig(q0.y + kk.y) +
+                                             vv.z * rsig(q0.z + kk.z) + vv.w * rsig(q0.w + kk.w);
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
 #pragma unroll 2
             for (int a4 = 0; a4 < AC / 4; ++a4) {
                 const float4 vv = *reinterpret_cast<const float4*>(vs + a4 * 4);
@@ -94,6 +134,17 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ Q, c
                     }
                 }
             }
+        }
+        if (uniform_q) {
+            if (!idle) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (jact[j]) {
+                        const float e = (vsum - 2.f * acc[0][j]) * inv_temp;
+                        for (int r = 0; r < TT; ++r) es[r * LP + lt * LT + j * 32 + tl] = e;
+                    }
+            }
+            continue;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)

@@ -286,6 +286,31 @@ __global__ void sumsq_k(const float* __restrict__ x, float* __restrict__ acc, lo
 //   v = b2 v + (1-b2) g'^2 ; m = b1 m + (1-b1) g'
 //   p -= wd*lr*p (if wd != 0) ; N_sma >= 5: p -= step_size * m/(sqrt(v)+eps) ; else p -= step_size*m
 //   (step_size is the host-computed radam.py:95-105 value and already contains lr)
+// one block per utterance: offset = sum of (len + 1) of the utterances before it (B is small), then the block writes its span
+__global__ void rowmap_k(const int* __restrict__ lens, int* __restrict__ rowmap, int* __restrict__ rows_dev, int T, int B) {
+    const int b = blockIdx.x;
+    int off = 0;
+    for (int i = 0; i < b; ++i) { int l = lens[i]; l = l < 0 ? 0 : (l > T ? T : l); off += l + 1; }
+    int len = lens[b];
+    len = len < 0 ? 0 : (len > T ? T : len);
+    for (int t = threadIdx.x; t < len; t += blockDim.x) rowmap[off + t] = t * B + b;
+    if (threadIdx.x == 0) {
+        rowmap[off + len] = len < T ? len * B + b : -1;
+        if (b == B - 1) rows_dev[0] = off + len + 1;
+    }
+}
+
+// grid (T*B rows, cols/1024 chunks): padded rows t > lens[b] only
+__global__ void pad_fill_k(float* __restrict__ y, long ld, int cols, const int* __restrict__ lens, int T, int B, int mode) {
+    const int row = blockIdx.x, t = row / B, b = row % B;
+    int len = lens[b];
+    len = len < 0 ? 0 : len;
+    if (t <= len) return;
+    const float* src = y + (size_t)(len * B + b) * ld;
+    float* dst = y + (size_t)row * ld;
+    for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < cols; c += gridDim.y * blockDim.x) dst[c] = mode ? src[c] : 0.f;
+}
+
 __global__ void poison_k(const int* __restrict__ status, float* __restrict__ dst) {
     if (status[0] != 0) dst[0] = __builtin_nanf("");
 }
@@ -462,6 +487,18 @@ extern "C" int ft_radam_step(float* p, const float* g, float* m, float* v, int64
     hipLaunchKernelGGL(radam_k, dim3(grid_for(n, NT, 4096)), dim3(NT), 0, ST(stream), p, g, m, v, (long)n, gnorm_sq_dev, (float)clip,
                        (float)(weight_decay * lr), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
                        (float)step_size, rectified, skipped_dev);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_rowmap_build(const int32_t* lens, int32_t* rowmap, int32_t* rows_dev, int T, int B, void* stream) {
+    FT_CHECK_ARG(lens && rowmap && rows_dev && T >= 1 && B >= 1 && (int64_t)T * B + B < (1ll << 31));
+    hipLaunchKernelGGL(rowmap_k, dim3(B), dim3(256), 0, ST(stream), lens, rowmap, rows_dev, T, B);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_pad_rows_fill(float* y, int64_t ld, int cols, const int32_t* lens, int T, int B, int mode, void* stream) {
+    FT_CHECK_ARG(y && lens && T >= 1 && B >= 1 && cols >= 1 && ld >= cols && (mode == 0 || mode == 1));
+    hipLaunchKernelGGL(pad_fill_k, dim3(T * B, cols > 1024 ? 4 : 1), dim3(256), 0, ST(stream), y, (long)ld, cols, lens, T, B, mode);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

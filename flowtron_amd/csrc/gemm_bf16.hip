@@ -35,15 +35,30 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
     return o;
 }
 
+// Row map (compact images, ft_bf16_image_rows): image row i holds source row rowmap[i] for i < *rdev (-1 = a zero row); rows up
+// to ceil256(*rdev + 32) are written (zeros beyond *rdev: the reduction dimension of the weight-gradient GEMMs runs over image
+// rows in 32-row steps, and a one-row shift may look one step further), the rest of the worst-case sized buffer is never touched.
+__device__ __forceinline__ int mapped_rows(const int* rdev, int Rp, int& Rz) {
+    const int R = *rdev;
+    const int z = (R + 32 + 255) & ~255;
+    Rz = z < Rp ? z : Rp;
+    return R;
+}
+
 // src(r,c) = src[r*sr + c*sc]; vec: sc == 1, 16-byte aligned rows
 __global__ __launch_bounds__(256) void img_rows_k(const float* __restrict__ src, long sr, long sc, int R, int Cc,
-                                                  unsigned short* __restrict__ dst, int Rp, int Cp, int vec) {
+                                                  unsigned short* __restrict__ dst, int Rp, int Cp, int vec,
+                                                  const int* __restrict__ rowmap, const int* __restrict__ rdev) {
     const int cq = Cp >> 3;
-    const size_t total = (size_t)Rp * cq;
+    int Rz = Rp;
+    if (rdev) R = mapped_rows(rdev, Rp, Rz);
+    const size_t total = (size_t)Rz * cq;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / cq), c = (int)(i % cq) * 8;
+        const int ri = (int)(i / cq), c = (int)(i % cq) * 8;
+        int r = ri;
+        if (rowmap) r = ri < R ? rowmap[ri] : -1;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (r < R && c < Cc) {
+        if (r >= 0 && (rowmap || r < R) && c < Cc) {
             const float* p = src + (size_t)r * sr + (size_t)c * sc;
             if (vec && c + 7 < Cc) {
                 const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
@@ -53,7 +68,7 @@ __global__ __launch_bounds__(256) void img_rows_k(const float* __restrict__ src,
                 for (int e = 0; e < 8; ++e) if (c + e < Cc) v[e] = p[(size_t)e * sc];
             }
         }
-        *reinterpret_cast<uint4*>(dst + (size_t)r * Cp + c) = pack8(v);
+        *reinterpret_cast<uint4*>(dst + (size_t)ri * Cp + c) = pack8(v);
     }
 }
 
@@ -62,19 +77,25 @@ __global__ __launch_bounds__(256) void img_rows_k(const float* __restrict__ src,
 // grid (Cp/256, Rp/256); colsum [Cc] must be zero on entry, slabs combine with fp32 atomics (as ft_colsum does).
 __global__ __launch_bounds__(256) void img_rows_sum_k(const float* __restrict__ src, long sr, int R, int Cc,
                                                       unsigned short* __restrict__ dst, int Rp, int Cp, int vec,
-                                                      float* __restrict__ colsum) {
+                                                      float* __restrict__ colsum, const int* __restrict__ rowmap,
+                                                      const int* __restrict__ rdev) {
     __shared__ float red[8][32][9];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = (blockIdx.x * 32 + tx) * 8;
     const int r0 = blockIdx.y * 256;
+    int Rz = Rp;
+    if (rdev) R = mapped_rows(rdev, Rp, Rz);
+    if (r0 >= Rz) return;                                           // whole slab beyond the mapped rows (uniform)
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (c < Cp) {
 #pragma unroll 4
         for (int k = 0; k < 32; ++k) {
-            const int r = r0 + ty + 8 * k;
-            if (r >= Rp) break;
+            const int ri = r0 + ty + 8 * k;
+            if (ri >= Rz) break;
+            int r = ri;
+            if (rowmap) r = ri < R ? rowmap[ri] : -1;
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (r < R && c < Cc) {
+            if (r >= 0 && (rowmap || r < R) && c < Cc) {
                 const float* p = src + (size_t)r * sr + c;
                 if (vec && c + 7 < Cc) {
                     const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
@@ -86,7 +107,7 @@ __global__ __launch_bounds__(256) void img_rows_sum_k(const float* __restrict__ 
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += v[e];
-            *reinterpret_cast<uint4*>(dst + (size_t)r * Cp + c) = pack8(v);
+            *reinterpret_cast<uint4*>(dst + (size_t)ri * Cp + c) = pack8(v);
         }
     }
 #pragma unroll
@@ -100,11 +121,12 @@ __global__ __launch_bounds__(256) void img_rows_sum_k(const float* __restrict__ 
     if (col < Cc) atomicAdd(colsum + col, s8);
 }
 
-void make_image(const float* src, long sr, long sc, int R, int Cc, unsigned short* dst, int Rp, int Cp, hipStream_t st) {
+void make_image(const float* src, long sr, long sc, int R, int Cc, unsigned short* dst, int Rp, int Cp, hipStream_t st,
+                const int* rowmap = nullptr, const int* rdev = nullptr) {
     const bool vec = sc == 1 && reinterpret_cast<uintptr_t>(src) % 16 == 0 && sr % 4 == 0;
     const size_t chunks = (size_t)Rp * (Cp >> 3);
     const int blocks = (int)((chunks + 255) / 256 < 16384 ? (chunks + 255) / 256 : 16384);
-    hipLaunchKernelGGL(img_rows_k, dim3(blocks), dim3(256), 0, st, src, sr, sc, R, Cc, dst, Rp, Cp, vec ? 1 : 0);
+    hipLaunchKernelGGL(img_rows_k, dim3(blocks), dim3(256), 0, st, src, sr, sc, R, Cc, dst, Rp, Cp, vec ? 1 : 0, rowmap, rdev);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -117,6 +139,10 @@ struct BfP {
     float alpha, beta;
     int act, gx, gy, splits, ksteps;        // tile grid, split-K factor, k-steps per split
     int vec_c;                              // C rows are 16-byte aligned: float4 epilogue
+    // compact row space (ft_gemm_img_args.compact): 1 = the M rows are compact rows -- tiles at or beyond *rows_dev exit, C row
+    // `rowmap[m]` receives compact row m (negative / beyond *rows_dev: dropped); 2 = the reduction runs over compact rows --
+    // k-steps at or beyond *rows_dev - k_shift are not visited (the images are zero there up to the next 32-row step)
+    const int* rowmap; const int* rows_dev; int compact, k_shift;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -211,14 +237,29 @@ __global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, kg = lane >> 4;
     int tile = blockIdx.x;
+    const int t0 = blockIdx.y * p.ksteps;
+    int t1 = (t0 + p.ksteps < p.nk) ? t0 + p.ksteps : p.nk;
+    int rows_lim = p.M, gy = p.gy;
+    if (p.compact) {
+        const int R = __builtin_amdgcn_readfirstlane(*p.rows_dev);
+        if (p.compact == 1) {
+            // the grid was sized for the capacity: only the first gx * ceil(R / RTA) workgroups have a tile, and the XCD-aware
+            // order below is formed over THOSE (else the XCDs that own the tail of the capacity would sit idle)
+            rows_lim = R < p.M ? R : p.M;
+            gy = (rows_lim + RTA - 1) / RTA;
+            if (tile >= p.gx * gy) return;
+        } else {
+            const int nk_eff = (R - p.k_shift + 31) >> 5;
+            t1 = t1 < nk_eff ? t1 : nk_eff;
+            if (SPLIT && t0 >= t1) return;                          // this k-slice lies entirely in the unused tail
+        }
+    }
     {   // XCD-aware order (workgroup L runs on XCD L % 8): every XCD gets a contiguous run of tiles, x fastest
-        const int total = p.gx * p.gy, q = total >> 3, r = total & 7;
+        const int total = p.gx * gy, q = total >> 3, r = total & 7;
         const int xcd = tile & 7, idx = tile >> 3;
         tile = xcd * q + (xcd < r ? xcd : r) + idx;
     }
     const int m0 = (tile / p.gx) * RTA, n0 = (tile % p.gx) * TB;
-    const int t0 = blockIdx.y * p.ksteps;
-    const int t1 = (t0 + p.ksteps < p.nk) ? t0 + p.ksteps : p.nk;
 
     Operand<AKM, RTA> oa;
     Operand<BKM, 128> ob;
@@ -290,8 +331,9 @@ __global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * (RTA / 2) + i * 16 + kg * 4 + r;
-                if (row >= p.M) continue;
+                int row = m0 + wm * (RTA / 2) + i * 16 + kg * 4 + r;
+                if (row >= rows_lim) continue;
+                if (p.compact == 1) { row = p.rowmap[row]; if (row < 0) continue; }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int col = n0 + wn * 64 + j * 16 + li;
@@ -307,8 +349,9 @@ __global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
     const bool vec = p.vec_c != 0;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
-        const int row = m0 + wm * (RTA / 2) + i * 16 + li;
-        if (row >= p.M) continue;
+        int row = m0 + wm * (RTA / 2) + i * 16 + li;
+        if (row >= rows_lim) continue;
+        if (p.compact == 1) { row = p.rowmap[row]; if (row < 0) continue; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = n0 + wn * 64 + j * 16 + kg * 4;
@@ -348,12 +391,14 @@ void launch_s(const BfP& p, dim3 grid, bool big, hipStream_t st) {
 // images -> C.  a_km / b_km: the operand image is k-major ([k][row]) instead of k-contiguous ([row][k]).
 // Images are padded to multiples of 256 in both dimensions (ft_bf16_image), so either tile height may run off the logical M.
 int run_images(const unsigned short* A, long lda, int a_km, const unsigned short* B, long ldb, int b_km, float* C, long ldc,
-               const float* bias, int M, int N, int K, float alpha, float beta, int act, int flags, hipStream_t st) {
+               const float* bias, int M, int N, int K, float alpha, float beta, int act, int flags, hipStream_t st,
+               const int* rowmap = nullptr, const int* rows_dev = nullptr, int compact = 0, int k_shift = 0) {
     static const int force_tile = [] { const char* e = getenv("FT_GEMM_BF16_TILE"); return e ? atoi(e) : 0; }();
     BfP p;
     p.A = A; p.B = B; p.C = C; p.bias = bias;
     p.M = M; p.N = N; p.nk = cdiv(K, 32); p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.beta = beta; p.act = act;
+    p.rowmap = rowmap; p.rows_dev = rows_dev; p.compact = compact; p.k_shift = k_shift;
     const bool can_split = (flags & FT_GEMM_SPLITK) && act == FT_ACT_NONE && (beta == 0.f || beta == 1.f) && K >= 2048;
     // 256 x 128 workgroup tiles (2 per CU) when they still fill the chip, possibly with split-K; else 128 x 128 (4 per CU)
     const long tiles_big = (long)cdiv(M, 256) * cdiv(N, TB);
@@ -375,6 +420,9 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
         if (s > 64) s = 64;
         if (s < 1) s = 1;
     }
+    if (compact == 1) s = 1;                   // scattered output rows: no split-K (the zero fill would have to be scattered too)
+    // compact reduction: K is the capacity, ~30 % of the k-slices of a typical batch are empty -- over-split to keep the slots filled
+    if (compact == 2 && s > 1) { s = s * 4 / 3; if (s > K / 512) s = K / 512; if (s > 64) s = 64; if (s < 1) s = 1; }
     p.ksteps = cdiv(p.nk, s);
     p.splits = cdiv(p.nk, p.ksteps);
     if (p.splits > 1 && beta == 0.f) FT_CHECK_HIP(hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, st));
@@ -457,7 +505,7 @@ extern "C" int FT_OPNAME(ft_bf16_image_colsum)(const float* src, int64_t ld, int
     const int vec = (reinterpret_cast<uintptr_t>(src) % 16 == 0 && ld % 4 == 0) ? 1 : 0;
     FT_CHECK_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)cols, st));
     hipLaunchKernelGGL(img_rows_sum_k, dim3(cdiv(Cp, 256), cdiv(Rp, 256)), dim3(256), 0, st, src, (long)ld, (int)rows, (int)cols,
-                       reinterpret_cast<unsigned short*>(dst), Rp, Cp, vec, colsum);
+                       reinterpret_cast<unsigned short*>(dst), Rp, Cp, vec, colsum, nullptr, nullptr);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }
@@ -466,7 +514,28 @@ extern "C" int FT_OPNAME(ft_gemm_img)(const ft_gemm_img_args* a, void* stream) {
     FT_CHECK_ARG(a != nullptr);
     FT_CHECK_ARG(a->A && a->B && a->C && a->M >= 1 && a->N >= 1 && a->K >= 1);
     FT_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0 && reinterpret_cast<uintptr_t>(a->A) % 16 == 0 && reinterpret_cast<uintptr_t>(a->B) % 16 == 0);
+    FT_CHECK_ARG(a->compact >= 0 && a->compact <= 2 && (a->compact == 0 || a->rows_dev) && (a->compact != 1 || a->rowmap));
+    FT_CHECK_ARG(a->k_shift >= 0 && (a->compact == 2 || a->k_shift == 0));
     return run_images(reinterpret_cast<const unsigned short*>(a->A), a->lda, a->a_kmajor, reinterpret_cast<const unsigned short*>(a->B),
                       a->ldb, a->b_kmajor, a->C, a->ldc, a->bias, a->M, a->N, a->K, a->alpha, a->beta, a->act, a->flags,
-                      reinterpret_cast<hipStream_t>(stream));
+                      reinterpret_cast<hipStream_t>(stream), a->rowmap, a->rows_dev, a->compact, a->k_shift);
+}
+
+// compact image: image row i = source row rowmap[i] (i < *rows_dev; -1 = zero row); buffer sized for cap_rows
+extern "C" int FT_OPNAME(ft_bf16_image_rows)(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, float* colsum,
+                                             const int32_t* rowmap, const int32_t* rows_dev, void* stream) {
+    FT_CHECK_ARG(src && dst && rowmap && rows_dev && cap_rows >= 1 && cols >= 1 && ld >= cols && cap_rows < (1ll << 31) - 512 && cols < (1ll << 31) - 256);
+    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int Rp = (int)up((size_t)cap_rows + 32, 256), Cp = (int)up((size_t)cols, 256);
+    if (!colsum) {
+        make_image(src, ld, 1, (int)cap_rows, (int)cols, reinterpret_cast<unsigned short*>(dst), Rp, Cp, st, rowmap, rows_dev);
+    } else {
+        const int vec = (reinterpret_cast<uintptr_t>(src) % 16 == 0 && ld % 4 == 0) ? 1 : 0;
+        FT_CHECK_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)cols, st));
+        hipLaunchKernelGGL(img_rows_sum_k, dim3(cdiv(Cp, 256), cdiv(Rp, 256)), dim3(256), 0, st, src, (long)ld, (int)cap_rows, (int)cols,
+                           reinterpret_cast<unsigned short*>(dst), Rp, Cp, vec, colsum, rowmap, rows_dev);
+    }
+    FT_CHECK_LAUNCH();
+    return FT_OK;
 }

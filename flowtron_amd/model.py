@@ -34,8 +34,8 @@ class LinearNorm(nn.Module):
         self.linear_layer = nn.Linear(in_dim, out_dim, bias=bias)
         nn.init.xavier_uniform_(self.linear_layer.weight, gain=nn.init.calculate_gain(w_init_gain))
 
-    def forward(self, x, act=L.ACT_NONE):
-        return ops.linear(x, self.linear_layer.weight, self.linear_layer.bias, act)
+    def forward(self, x, act=L.ACT_NONE, rowmap=None, fill="y+dx"):
+        return ops.linear(x, self.linear_layer.weight, self.linear_layer.bias, act, rowmap=rowmap, fill=fill)
 
 
 class ConvNorm(nn.Module):
@@ -69,9 +69,11 @@ class DenseLayer(nn.Module):
         in_sizes = [in_dim] + sizes[:-1]
         self.layers = nn.ModuleList([LinearNorm(i, o, bias=True) for i, o in zip(in_sizes, sizes)])
 
-    def forward(self, x):
+    def forward(self, x, rowmap=None):
         for lin in self.layers:
-            x = lin(x, L.ACT_TANH)          # GEMM with bias + tanh fused in the epilogue
+            # GEMM with bias + tanh fused in the epilogue; with a row map only valid frames are multiplied, and since the only
+            # reader of a dense output is the next compact GEMM, padded rows stay unwritten (fill = "")
+            x = lin(x, L.ACT_TANH, rowmap=rowmap, fill="")
         return x
 
 
@@ -131,12 +133,14 @@ class Attention(nn.Module):
         self.v = LinearNorm(n_att_channels, 1, bias=False, w_init_gain="tanh")
         self.score_mask_value = -float("inf")
 
-    def forward(self, queries, keys, values, in_lens32, attn_prior=None):
+    def forward(self, queries, keys, values, in_lens32, attn_prior=None, rowmap=None):
         """queries [T,B,H], keys/values source [L,B,E] -> ctx [T,B,A], attn [B,T,L], attn_logprob [B,T,L]."""
         mode = L.mfma_mode()
         K = ops.linear(keys, self.key.linear_layer.weight, None, mode=mode)
         V = ops.linear(values, self.value.linear_layer.weight, None, mode=mode)
-        Q = ops.linear(queries, self.query.linear_layer.weight, None, mode=mode)
+        # the score kernel walks every frame (the reference returns the attention of padded frames too): padded query rows are
+        # filled with the utterance's first padded row (fill "y"); the query's input gradient only feeds guarded consumers
+        Q = ops.linear(queries, self.query.linear_layer.weight, None, mode=mode, rowmap=rowmap, fill="y")
         attn, logprob = ops.AttentionScoresFn.apply(Q, K, self.v.linear_layer.weight, in_lens32, attn_prior,
                                                     self.temperature)
         ctx = ops.ContextFn.apply(attn, V, mode)
@@ -204,18 +208,20 @@ class AR_Step(nn.Module):
         d["_decode_work"] = None
         return d
 
-    def forward(self, mel, text, in_lens32, out_lens32, attn_prior=None):
+    def forward(self, mel, text, in_lens32, out_lens32, attn_prior=None, rowmap=None):
         """Teacher-forced flow. mel [T,B,M], text = encoder outputs [L,B,E].
-        Returns (z [T,B,M], log_s [T,B,M], gates [T,B,1] | None, attn [B,T,L], attn_logprob [B,T,L])."""
+        Returns (z [T,B,M], log_s [T,B,M], gates [T,B,1] | None, attn [B,T,L], attn_logprob [B,T,L]).
+        rowmap (ops.RowMap over out_lens32): the batched GEMMs multiply valid frames only (pack-by-length, flowtron.py:689-694)."""
         T, B, M = mel.shape
         mode = L.mfma_mode()
+        rm = rowmap
         mel0 = torch.cat([mel.new_zeros(1, B, M), mel[:-1]], 0)              # flowtron.py:726-729
         a = self.attention_lstm
-        h_att = ops.lstm_layer(mel0, out_lens32, a.weight_ih_l0, a.weight_hh_l0, a.bias_ih_l0, a.bias_hh_l0, mode=mode)
+        h_att = ops.lstm_layer(mel0, out_lens32, a.weight_ih_l0, a.weight_hh_l0, a.bias_ih_l0, a.bias_hh_l0, mode=mode, rowmap=rm)
         if self.use_cumm_attention:
             ctx, attn, logprob = self.run_cumm_attn_sequence(h_att, text, in_lens32)   # drops the prior like flowtron.py:742-743
         else:
-            ctx, attn, logprob = self.attention_layer(h_att, text, text, in_lens32, attn_prior)
+            ctx, attn, logprob = self.attention_layer(h_att, text, text, in_lens32, attn_prior, rowmap=rm)
         gates = None
         if hasattr(self, "gate_layer"):
             g = self.gate_layer.linear_layer
@@ -224,19 +230,21 @@ class AR_Step(nn.Module):
         if ops.lstm_persist_groups(B, p.weight_hh_l0.shape[1], False, mode, mel.device):
             # two persistent single-layer recurrences (csrc/lstm_persist.hip, ~2 us per step each) with layer 1's input
             # projection as one batched GEMM between them: faster than the two-layer wavefront launch chain (~8 us per step)
+            # (the context gradient feeds the attention backward, which reduces over ALL frames: zero its padded rows)
             h = ops.lstm_layer(h_att, out_lens32, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, mode=mode,
-                               xs_extra=[ctx])
-            h = ops.lstm_layer(h, out_lens32, p.weight_ih_l1, p.weight_hh_l1, p.bias_ih_l1, p.bias_hh_l1, mode=mode)
+                               xs_extra=[ctx], rowmap=rm, fill="dx")
+            h = ops.lstm_layer(h, out_lens32, p.weight_ih_l1, p.weight_hh_l1, p.bias_ih_l1, p.bias_hh_l1, mode=mode, rowmap=rm)
         elif ops.lstm2_supported(B, p.weight_hh_l0.shape[1], mode):
             # both decoder layers as one software-wavefront launch chain (csrc/lstm2.hip)
-            gx0 = ops.LinearFn.apply(p.weight_ih_l0, p.bias_ih_l0 + p.bias_hh_l0, L.ACT_NONE, mode, h_att, ctx)
+            gx0 = ops.LinearFn.apply(p.weight_ih_l0, p.bias_ih_l0 + p.bias_hh_l0, L.ACT_NONE, mode, None, "", h_att, ctx)
             h = ops.LSTM2SeqFn.apply(gx0, p.weight_hh_l0, p.weight_ih_l1, p.bias_ih_l1, p.bias_hh_l1, p.weight_hh_l1, out_lens32, mode)
         else:
             h = ops.lstm_layer(h_att, out_lens32, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, mode=mode,
-                               xs_extra=[ctx])
-            h = ops.lstm_layer(h, out_lens32, p.weight_ih_l1, p.weight_hh_l1, p.bias_ih_l1, p.bias_hh_l1, mode=mode)
-        h = self.dense_layer(h)
-        out = ops.linear(h, self.conv.weight.reshape(self.conv.weight.shape[0], -1), self.conv.bias, mode=mode)
+                               xs_extra=[ctx], rowmap=rm, fill="dx")
+            h = ops.lstm_layer(h, out_lens32, p.weight_ih_l1, p.weight_hh_l1, p.bias_ih_l1, p.bias_hh_l1, mode=mode, rowmap=rm)
+        h = self.dense_layer(h, rowmap=rm)
+        # the coupling output is returned for every frame (z, log_s of padded frames are the reference's defined junk): fill "y"
+        out = ops.linear(h, self.conv.weight.reshape(self.conv.weight.shape[0], -1), self.conv.bias, mode=mode, rowmap=rm, fill="y")
         z = ops.AffineFn.apply(out, mel)                                      # z = exp(log_s) * mel + b
         log_s = out[..., :M]
         return z, log_s, gates, attn, logprob
@@ -376,12 +384,12 @@ class AR_Back_Step(nn.Module):
                                n_attn_channels, n_lstm_layers, add_gate, use_cumm_attention)
         self.ar_step._time_reversed = True
 
-    def forward(self, mel, text, in_lens32, out_lens32, attn_prior=None):
+    def forward(self, mel, text, in_lens32, out_lens32, attn_prior=None, rowmap=None):
         # flip + per-sample roll (flowtron.py:606-613) == the reverse-by-length involution, one gather kernel, no host syncs
         mel = ops.reverse_by_length(mel, out_lens32, True)
         if attn_prior is not None:
             attn_prior = ops.reverse_by_length(attn_prior, out_lens32, False)
-        z, log_s, gates, attn, logprob = self.ar_step(mel, text, in_lens32, out_lens32, attn_prior)
+        z, log_s, gates, attn, logprob = self.ar_step(mel, text, in_lens32, out_lens32, attn_prior, rowmap=rowmap)
         z = ops.reverse_by_length(z, out_lens32, True)
         return z, log_s, gates, attn, logprob
 
@@ -444,8 +452,10 @@ class Flowtron(nn.Module):
             attn_prior = attn_prior.float()
         log_s_list, attns_list, attns_logprob_list = [], [], []
         gate = None
+        # pack-by-length for the batched GEMMs of the 16-bit operand modes (one row map per forward, built on the device)
+        rm = ops.row_map(out32, x.shape[0], x.shape[1]) if L.is16(L.mfma_mode()) else None
         for flow in self.flows:
-            x, log_s, gate, attn, logprob = flow(x, enc, in32, out32, attn_prior)
+            x, log_s, gate, attn, logprob = flow(x, enc, in32, out32, attn_prior, rowmap=rm)
             log_s_list.append(log_s)
             attns_list.append(attn)
             attns_logprob_list.append(logprob)

@@ -52,21 +52,59 @@ def gemm_raw(A, B, Cm, M, N, K, sAm, sAk, sBk, sBn, ldc, bias=None, act=L.ACT_NO
 # image serves all its GEMMs -- x: forward + dW, dY: dX + dW, W: forward + dX, LSTM dgates: dW_hh + dW_ih (+ dX) --
 # k-contiguous or k-major as the GEMM needs (k-major fragments come from the LDS transpose-read, so nothing is transposed).
 # --------------------------------------------------------------------------
-class Bf16Image:
-    __slots__ = ("buf", "rows", "cols", "ld", "colsum", "fmt")
+class RowMap:
+    """Pack-by-length row map of the time-major decoder activations [T,B,*] (csrc: ft_rowmap_build; the reference packs with
+    pack_padded_sequence, flowtron.py:689-694): compact rows are batch-major, utterance b = its valid frames + ONE separator
+    (its first padded frame, or a zero row when it has none).  Built on the device from the int32 length vector -- no host
+    sync; `cap` = T*B + B is the capacity images and grids are sized for, `rows` the device-side row count."""
+    __slots__ = ("T", "B", "cap", "lens", "map", "rows")
 
-    def __init__(self, t2d, colsum=False, mode=None):
+    def __init__(self, lens32, T, B):
+        L.require_cuda(lens32)
+        self.T, self.B, self.cap, self.lens = int(T), int(B), int(T) * int(B) + int(B), lens32
+        self.map = torch.empty(self.cap, device=lens32.device, dtype=torch.int32)
+        self.rows = torch.empty(1, device=lens32.device, dtype=torch.int32)
+        L.check(L.lib().ft_rowmap_build(L.ptr(lens32), L.ptr(self.map), L.ptr(self.rows), self.T, self.B, L.stream()), "ft_rowmap_build")
+
+    def fill(self, y2d, ncols, copy_separator):
+        """padded frames t > len_b of the time-major matrix y2d [T*B, >= ncols]: zeros, or (copy_separator) the values of the
+        utterance's first padded frame, which a compact GEMM has just computed"""
+        L.check(L.lib().ft_pad_rows_fill(L.ptr(y2d), int(y2d.stride(0)), int(ncols), L.ptr(self.lens), self.T, self.B,
+                                         1 if copy_separator else 0, L.stream()), "ft_pad_rows_fill")
+
+
+_COMPACT = _os.environ.get("FLOWTRON_GEMM_COMPACT", "1") != "0"
+
+
+def row_map(lens32, T, B):
+    """the RowMap the 16-bit image GEMMs of a [T,B,*] stack should use, or None (FLOWTRON_GEMM_COMPACT=0: padded rows are multiplied)"""
+    return RowMap(lens32, T, B) if (_COMPACT and _BF16_IMAGES) else None
+
+
+class Bf16Image:
+    __slots__ = ("buf", "rows", "cols", "ld", "colsum", "fmt", "rowmap")
+
+    def __init__(self, t2d, colsum=False, mode=None, rowmap=None):
         """t2d: fp32 CUDA matrix [rows, cols], unit column stride.  colsum=True also returns the fp32 column sums of t2d
-        (self.colsum) from the same pass -- the bias gradient when t2d is an output gradient."""
+        (self.colsum) from the same pass -- the bias gradient when t2d is an output gradient.
+        rowmap: a RowMap over t2d's rows (t2d = a time-major [T*B, cols] activation): the image holds the VALID rows only, in
+        compact order (self.rows = the map's capacity)."""
         assert t2d.dim() == 2 and t2d.stride(1) == 1 and t2d.dtype == torch.float32
         L.require_cuda(t2d)
         self.rows, self.cols = int(t2d.shape[0]), int(t2d.shape[1])
         self.fmt = L.mfma_mode() if mode is None else mode      # FT_BF16 or FT_F16: 16-bit payloads of that operand format
         self.ld = (self.cols + 255) // 256 * 256
+        self.rowmap = rowmap
+        self.colsum = torch.empty(self.cols, device=t2d.device, dtype=torch.float32) if colsum else None
+        if rowmap is not None:
+            assert self.rows == rowmap.T * rowmap.B, "row map built for another [T, B]"
+            self.rows = rowmap.cap
+            self.buf = torch.empty(L.lib().ft_bf16_image_bytes(self.rows, self.cols), device=t2d.device, dtype=torch.uint8)
+            L.check(L.op16("ft_bf16_image_rows", self.fmt)(L.ptr(t2d), int(t2d.stride(0)), self.rows, self.cols, L.ptr(self.buf), L.ptr(self.colsum),
+                                                            L.ptr(rowmap.map), L.ptr(rowmap.rows), L.stream()), "ft_bf16_image_rows")
+            return
         self.buf = torch.empty(L.lib().ft_bf16_image_bytes(self.rows, self.cols), device=t2d.device, dtype=torch.uint8)
-        self.colsum = None
         if colsum:
-            self.colsum = torch.empty(self.cols, device=t2d.device, dtype=torch.float32)
             L.check(L.op16("ft_bf16_image_colsum", self.fmt)(L.ptr(t2d), int(t2d.stride(0)), self.rows, self.cols, L.ptr(self.buf), L.ptr(self.colsum),
                                                  L.stream()), "ft_bf16_image_colsum")
         else:
@@ -84,15 +122,17 @@ import weakref as _weakref
 _IMG_CACHE = {}
 
 
-def shared_image(t, rows, cols, mode):
-    """16-bit image (operand format `mode`) of the fp32 tensor `t` viewed as [rows, cols]; one conversion per tensor (version)."""
+def shared_image(t, rows, cols, mode, rowmap=None):
+    """16-bit image (operand format `mode`) of the fp32 tensor `t` viewed as [rows, cols]; one conversion per tensor (version)
+    and row map."""
     key = id(t)
     hit = _IMG_CACHE.get(key)
+    want_rows = rows if rowmap is None else rowmap.cap
     if hit is not None:
         ref, ver, img = hit
-        if ref() is t and ver == t._version and img.rows == rows and img.cols == cols and img.fmt == mode:
+        if ref() is t and ver == t._version and img.rows == want_rows and img.cols == cols and img.fmt == mode and img.rowmap is rowmap:
             return img
-    img = Bf16Image(t.reshape(rows, cols), mode=mode)
+    img = Bf16Image(t.reshape(rows, cols), mode=mode, rowmap=rowmap)
     if len(_IMG_CACHE) > 64:                     # dead entries (their tensors are gone) are swept lazily
         for k in [k for k, (r, _, _) in _IMG_CACHE.items() if r() is None]:
             del _IMG_CACHE[k]
@@ -108,11 +148,16 @@ def images_apply(mode, M, N, K):
     return _BF16_IMAGES and L.is16(mode) and M >= 32 and N >= 32 and K >= 16 and M * N * K >= (1 << 20)
 
 
-def gemm_img(A, a_km, a_ptr, B, b_km, b_ptr, Cm, M, N, K, ldc, bias=None, act=L.ACT_NONE, alpha=1.0, beta=0.0, splitk=False):
-    """C[M,N] = act(alpha * A.B + beta*C + bias) from images.  a_ptr / b_ptr: A.ptr(...) / B.ptr(...) (may point inside)."""
+def gemm_img(A, a_km, a_ptr, B, b_km, b_ptr, Cm, M, N, K, ldc, bias=None, act=L.ACT_NONE, alpha=1.0, beta=0.0, splitk=False,
+             rowmap=None, compact=0, k_shift=0):
+    """C[M,N] = act(alpha * A.B + beta*C + bias) from images.  a_ptr / b_ptr: A.ptr(...) / B.ptr(...) (may point inside).
+    rowmap + compact: 1 = M runs over the map's compact rows (pass M = rowmap.cap), C rows are scattered through the map;
+    2 = the reduction runs over compact rows (pass K = rowmap.cap; k_shift = a row shift already applied to a_ptr)."""
     L.require_cuda(Cm, bias)
     a = L.GemmImgArgs(a_ptr, b_ptr, L.ptr(Cm), L.ptr(bias), M, N, K, A.ld, B.ld, ldc, int(a_km), int(b_km),
-                      alpha, beta, act, L.GEMM_SPLITK if splitk else 0)
+                      alpha, beta, act, L.GEMM_SPLITK if splitk else 0,
+                      L.ptr(rowmap.map) if rowmap is not None else None, L.ptr(rowmap.rows) if rowmap is not None else None,
+                      int(compact) if rowmap is not None else 0, int(k_shift))
     assert A.fmt == B.fmt, "operand images of different formats"
     L.check(L.op16("ft_gemm_img", A.fmt)(C.byref(a), L.stream()), "ft_gemm_img")
 
@@ -157,8 +202,16 @@ def lens32(lens: torch.Tensor) -> torch.Tensor:
 # (nn.Linear / 1x1 Conv1d / LSTM input projection call sites, flowtron.py:568-571, :758, :767-768)
 # --------------------------------------------------------------------------
 class LinearFn(torch.autograd.Function):
+    """rowmap (RowMap | None): the inputs are time-major [T,B,K] activations of a padded batch; in the 16-bit image path the
+    GEMMs then run over the VALID rows only (the reference packs them, flowtron.py:689-694): compact images, output rows
+    scattered back, weight gradients reduced over compact rows.  Rows of padded frames are NOT written unless `fill` asks:
+      "y"  in fill: forward output rows of padded frames = the utterance's first padded frame (which the GEMM computes: every
+                    padded frame of an utterance has the same inputs), for consumers that walk all T frames;
+      "dx" in fill: input-gradient rows of padded frames = 0, for consumers that reduce over all T frames.
+    Call sites whose consumers only ever touch valid frames (the recurrences, the next compact GEMM) pass fill = ""."""
+
     @staticmethod
-    def forward(ctx, W, bias, act, mode, *xs):
+    def forward(ctx, W, bias, act, mode, rowmap, fill, *xs):
         xs = [_c(x) for x in xs]
         L.require_cuda(W, *xs)
         W = _c(W)
@@ -166,26 +219,31 @@ class LinearFn(torch.autograd.Function):
         rows = xs[0].numel() // xs[0].shape[-1]
         y = torch.empty(xs[0].shape[:-1] + (N,), device=W.device, dtype=torch.float32)
         use_img = all(images_apply(mode, rows, N, x.shape[-1]) for x in xs) and all((x.shape[-1] % 8 == 0) for x in xs[:-1])
+        if rowmap is not None and (not use_img or rows != rowmap.T * rowmap.B):
+            rowmap = None
         ctx.imgs = None
         if use_img:
             w_img = Bf16Image(W, mode=mode)
-            x_imgs = [shared_image(x, rows, x.shape[-1], mode) for x in xs]
+            x_imgs = [shared_image(x, rows, x.shape[-1], mode, rowmap) for x in xs]
             ctx.imgs = (w_img, x_imgs)          # reused by backward (dX reads W k-major, dW reads x k-major)
         off = 0
         for i, x in enumerate(xs):
             K = x.shape[-1]
             last = i == len(xs) - 1
             if use_img:
-                gemm_img(x_imgs[i], 0, x_imgs[i].ptr(), w_img, 0, w_img.ptr(0, off), y, rows, N, K, N,
-                         bias=bias if last else None, act=act if last else L.ACT_NONE, beta=0.0 if i == 0 else 1.0)
+                gemm_img(x_imgs[i], 0, x_imgs[i].ptr(), w_img, 0, w_img.ptr(0, off), y, rows if rowmap is None else rowmap.cap, N, K, N,
+                         bias=bias if last else None, act=act if last else L.ACT_NONE, beta=0.0 if i == 0 else 1.0,
+                         rowmap=rowmap, compact=1)
             else:
                 gemm_raw(x, W[:, off:], y, rows, N, K, K, 1, 1, Ktot, N,
                          bias=bias if last else None, act=act if last else L.ACT_NONE,
                          beta=0.0 if i == 0 else 1.0, mode=mode)
             off += K
         assert off == Ktot
+        if rowmap is not None and "y" in fill:
+            rowmap.fill(y.reshape(rows, N), N, copy_separator=True)
         ctx.save_for_backward(W, y if act != L.ACT_NONE else None, *xs)
-        ctx.act, ctx.mode, ctx.has_bias = act, mode, bias is not None
+        ctx.act, ctx.mode, ctx.has_bias, ctx.rowmap, ctx.fill = act, mode, bias is not None, rowmap, fill
         return y
 
     @staticmethod
@@ -194,6 +252,7 @@ class LinearFn(torch.autograd.Function):
         dy = _c(dy)
         N, Ktot = W.shape
         rows = dy.numel() // N
+        rowmap = ctx.rowmap
         if ctx.act != L.ACT_NONE:
             dpre = torch.empty_like(dy)
             L.check(L.lib().ft_act_bwd(L.ptr(y), L.ptr(dy), L.ptr(dpre), dy.numel(), ctx.act, L.stream()), "ft_act_bwd")
@@ -208,20 +267,23 @@ class LinearFn(torch.autograd.Function):
         if imgs is not None:
             w_img, x_imgs = imgs
             d_img = _handoff_take(dpre) if ctx.act == L.ACT_NONE else None      # e.g. the LSTM backward already made it
-            if d_img is not None and d_img.fmt != w_img.fmt:
+            if d_img is not None and (d_img.fmt != w_img.fmt or d_img.rowmap is not rowmap or (want_db and d_img.colsum is None)):
                 d_img = None
             if d_img is None:
-                d_img = Bf16Image(dpre.reshape(rows, N), colsum=want_db, mode=w_img.fmt)          # bias gradient rides on the conversion pass
+                d_img = Bf16Image(dpre.reshape(rows, N), colsum=want_db, mode=w_img.fmt, rowmap=rowmap)   # bias gradient rides on the conversion pass
             db = d_img.colsum if want_db else None
         if want_db and db is None:
             db = colsum(dpre, rows, N, N)
+        mrows = rows if rowmap is None else rowmap.cap
         for i, x in enumerate(xs):
             K = x.shape[-1]
-            if ctx.needs_input_grad[4 + i]:
+            if ctx.needs_input_grad[6 + i]:
                 dx = torch.empty_like(x)
                 # dx[r,k] = sum_n dpre[r,n] W[n, off+k]
                 if imgs is not None:
-                    gemm_img(d_img, 0, d_img.ptr(), w_img, 1, w_img.ptr(0, off), dx, rows, K, N, K)
+                    gemm_img(d_img, 0, d_img.ptr(), w_img, 1, w_img.ptr(0, off), dx, mrows, K, N, K, rowmap=rowmap, compact=1)
+                    if rowmap is not None and "dx" in ctx.fill:
+                        rowmap.fill(dx.reshape(rows, K), K, copy_separator=False)
                 else:
                     gemm_raw(dpre, W[:, off:], dx, rows, K, N, N, 1, Ktot, 1, K, mode=ctx.mode)
                 dxs.append(dx)
@@ -230,18 +292,19 @@ class LinearFn(torch.autograd.Function):
             if dW is not None:
                 # dW[n, off+k] = sum_r dpre[r,n] x[r,k]
                 if imgs is not None:
-                    gemm_img(d_img, 1, d_img.ptr(), x_imgs[i], 1, x_imgs[i].ptr(), dW[:, off:], N, K, rows, Ktot, splitk=True)
+                    gemm_img(d_img, 1, d_img.ptr(), x_imgs[i], 1, x_imgs[i].ptr(), dW[:, off:], N, K, mrows, Ktot, splitk=True,
+                             rowmap=rowmap, compact=2)
                 else:
                     gemm_raw(dpre, x, dW[:, off:], N, K, rows, 1, N, K, 1, Ktot, mode=ctx.mode, splitk=True)
             off += K
         ctx.imgs = None
-        return (dW, db, None, None, *dxs)
+        return (dW, db, None, None, None, None, *dxs)
 
 
-def linear(xs, W, bias=None, act=L.ACT_NONE, mode=None):
+def linear(xs, W, bias=None, act=L.ACT_NONE, mode=None, rowmap=None, fill="y+dx"):
     if isinstance(xs, torch.Tensor):
         xs = [xs]
-    return LinearFn.apply(W, bias, act, L.mfma_mode() if mode is None else mode, *xs)
+    return LinearFn.apply(W, bias, act, L.mfma_mode() if mode is None else mode, rowmap, fill, *xs)
 
 
 # --------------------------------------------------------------------------
@@ -491,10 +554,11 @@ def lstm_persist_groups(B, H, reverse, mode, device=None):
 
 class LSTMSeqFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, gx, w_hh, lens, reverse, mode):
+    def forward(ctx, gx, w_hh, lens, reverse, mode, rowmap=None):
         gx, w_hh = _c(gx), _c(w_hh)
         L.require_cuda(gx, w_hh, lens)
         T, B, H4 = gx.shape
+        ctx.rowmap = rowmap if (rowmap is not None and not reverse and rowmap.T == T and rowmap.B == B) else None
         H = H4 // 4
         y = torch.empty(T, B, H, device=gx.device, dtype=torch.float32)
         gates = torch.empty(T, B, H4, device=gx.device, dtype=torch.float32)
@@ -539,7 +603,14 @@ class LSTMSeqFn(torch.autograd.Function):
             da = dgx[1:] if not ctx.reverse else dgx[:-1]
             hp = y[:-1] if not ctx.reverse else y[1:]
             dW = torch.zeros_like(w_hh)
-            if T > 1 and images_apply(ctx.mode, 4 * H, H, rows):
+            rm = ctx.rowmap
+            if T > 1 and images_apply(ctx.mode, 4 * H, H, rows) and rm is not None:
+                # compact images (valid frames only, batch-major with one zero separator row per utterance): the one-step shift
+                # dgates_t <-> h_{t-1} is a shift by ONE compact row, and the utterance boundaries multiply with a separator
+                d_img, y_img = Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True, mode=ctx.mode, rowmap=rm), shared_image(y, T * B, H, ctx.mode, rm)
+                gemm_img(d_img, 1, d_img.ptr(1), y_img, 1, y_img.ptr(0), dW, 4 * H, H, rm.cap, H, splitk=True, rowmap=rm, compact=2, k_shift=1)
+                _handoff_put(dgx, d_img)        # the input projection's backward reads the same dgates
+            elif T > 1 and images_apply(ctx.mode, 4 * H, H, rows):
                 # images of dgates / outputs over all T*B rows; the one-step shift is a row offset into them
                 d_img, y_img = Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True, mode=ctx.mode), shared_image(y, T * B, H, ctx.mode)
                 fwd = not ctx.reverse
@@ -547,16 +618,20 @@ class LSTMSeqFn(torch.autograd.Function):
                 _handoff_put(dgx, d_img)        # the input projection's backward reads the same dgates
             elif T > 1:
                 gemm_raw(da, hp, dW, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=ctx.mode, splitk=True)
-        return dgx, dW, None, None, None
+        return dgx, dW, None, None, None, None
 
 
-def lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=False, mode=None, xs_extra=None):
-    """One LSTM layer over a padded sequence: input projection for all T*B rows as one MFMA GEMM,
-    then the sequential recurrence."""
+def lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=False, mode=None, xs_extra=None, rowmap=None, fill=""):
+    """One LSTM layer over a padded sequence: input projection for all T*B rows (valid rows only with a RowMap) as one MFMA
+    GEMM, then the sequential recurrence.  The recurrence kernels never use a padded frame's gx / dy row and write zeros to its
+    y / dgx row themselves, so the projection leaves padded rows unwritten (fill = ""); pass fill = "dx" when something that
+    reduces over all T frames reads the INPUT gradients (the attention context)."""
     mode = L.mfma_mode() if mode is None else mode
     xs = [x] if xs_extra is None else [x] + list(xs_extra)
-    gx = LinearFn.apply(w_ih, b_ih + b_hh, L.ACT_NONE, mode, *xs)
-    return LSTMSeqFn.apply(gx, w_hh, lens, reverse, mode)
+    if reverse:
+        rowmap = None
+    gx = LinearFn.apply(w_ih, b_ih + b_hh, L.ACT_NONE, mode, rowmap, fill, *xs)
+    return LSTMSeqFn.apply(gx, w_hh, lens, reverse, mode, rowmap)
 
 
 class BiLSTMSeqFn(torch.autograd.Function):
@@ -614,8 +689,8 @@ def bilstm_layer(x, lens, wf, wr, mode=None):
     H = wf[1].shape[1]
     import os
     if L.is16(mode) and os.environ.get("FLOWTRON_BILSTM", "1") != "0" and L.lib().ft_lstm_bidir_supported(B, H):
-        gx_f = LinearFn.apply(wf[0], wf[2] + wf[3], L.ACT_NONE, mode, x)
-        gx_r = LinearFn.apply(wr[0], wr[2] + wr[3], L.ACT_NONE, mode, x)
+        gx_f = LinearFn.apply(wf[0], wf[2] + wf[3], L.ACT_NONE, mode, None, "", x)
+        gx_r = LinearFn.apply(wr[0], wr[2] + wr[3], L.ACT_NONE, mode, None, "", x)
         return BiLSTMSeqFn.apply(gx_f, gx_r, wf[1], wr[1], lens, mode)
     yf = lstm_layer(x, lens, *wf, reverse=False, mode=mode)
     yb = lstm_layer(x, lens, *wr, reverse=True, mode=mode)

@@ -90,6 +90,13 @@ typedef struct {
     int a_kmajor, b_kmajor;
     float alpha, beta;
     int act, flags;
+    /* compact row space (pack-by-length, the reference's pack_padded_sequence at flowtron.py:689-694): the images were made by
+     * ft_bf16_image_rows from the VALID rows only.  compact = 0: plain.  1: the M rows are compact rows -- workgroup tiles at or
+     * beyond *rows_dev exit at once, and compact row m is written to C row rowmap[m] (negative: dropped); M = the capacity the
+     * grid is sized for; no split-K.  2: the reduction runs over compact rows -- K = capacity, k-steps at or beyond
+     * *rows_dev - k_shift are not visited (k_shift = the row offset already applied to A for a one-step time shift). */
+    const int32_t* rowmap; const int32_t* rows_dev;
+    int compact, k_shift;
 } ft_gemm_img_args;
 size_t ft_bf16_image_bytes(int64_t rows, int64_t cols);
 int ft_bf16_image(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, void* stream);
@@ -97,6 +104,19 @@ int ft_bf16_image(const float* src, int64_t ld, int64_t rows, int64_t cols, void
  * gradient; colsum [cols] is overwritten; row slabs combine with fp32 atomics like ft_colsum) */
 int ft_bf16_image_colsum(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, float* colsum, void* stream);
 int ft_gemm_img(const ft_gemm_img_args* a, void* stream);
+/* Pack-by-length row map of a time-major [T][B][*] activation (flowtron.py:689-694 packs, here without a host sync): compact
+ * rows are batch-major -- utterance b contributes rows (t, b), t < lens[b], then ONE separator: row (lens[b], b) when
+ * lens[b] < T (the utterance's first padded frame, which stands for all of them: every padded frame of b holds the same
+ * values), else -1 (a zero row).  rowmap needs T*B + B entries; rows_dev[0] = sum_b (lens[b] + 1).  The separator rows make the
+ * one-step shift of the recurrent weight gradient (dW_hh = sum_t dgates_t^T h_{t-1}) a one-ROW shift in compact space. */
+int ft_rowmap_build(const int32_t* lens, int32_t* rowmap, int32_t* rows_dev, int T, int B, void* stream);
+/* compact image: image row i = bf16(src row rowmap[i]) for i < *rows_dev (negative: zeros), zeros up to
+ * ceil256(*rows_dev + 32); dst holds ft_bf16_image_bytes(cap_rows, cols).  colsum (optional) as ft_bf16_image_colsum. */
+int ft_bf16_image_rows(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, float* colsum,
+                       const int32_t* rowmap, const int32_t* rows_dev, void* stream);
+/* rows (t, b) with t > lens[b] of the time-major matrix y [T*B][cols] (row stride ld): mode 0 = zero them, 1 = copy row
+ * (lens[b], b) into them (a compact GEMM wrote only valid rows and the separator; consumers that walk every frame need the rest) */
+int ft_pad_rows_fill(float* y, int64_t ld, int cols, const int32_t* lens, int T, int B, int mode, void* stream);
 
 /* ---- embedding gather (flowtron.py:873-874) ------------------------------
  * out[r][0:dim] = W[ids[r]] for r < n (out row stride ld_out).  bwd: dW[ids[r]] += dout[r]. */
@@ -341,6 +361,8 @@ int ft_gemm_f16(const ft_gemm_args* a, void* stream);
 int ft_bf16_image_f16(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, void* stream);
 int ft_bf16_image_colsum_f16(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, float* colsum, void* stream);
 int ft_gemm_img_f16(const ft_gemm_img_args* a, void* stream);
+int ft_bf16_image_rows_f16(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, float* colsum,
+                           const int32_t* rowmap, const int32_t* rows_dev, void* stream);
 int ft_lstm_seq_fwd_f16(const float* gx, const float* w_hh, const int32_t* lens,
                     float* y, int64_t ldy, float* gates, float* cell, void* work,
                     int T, int B, int H, int reverse, int mode, void* stream);

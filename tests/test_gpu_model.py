@@ -141,9 +141,10 @@ def test_decode_400_frames_vs_oracle_all_three_decoders(capsys):
     sigma = 0.5) against the fp32 CPU ORACLE (O.infer = restatement of flowtron.py:775-828, 901-930), for every decoder the
     library has: the fp32-weight staged hipGraph chain (the reference's own arithmetic, inference.py:68-71), the bf16-image staged
     chain and the one-launch persistent decode (dec_persist_k, the one behind the headline RTF).
-    Tolerances on mel (values span ~[-2, 2] here) and attention rows (probabilities) over all 400 frames x 2 flows:
-      fp32 weights : mel 2e-3, attention 2e-4 (400 sequentially dependent frames of fp32 re-association);
-      bf16 weights : mel 0.1 max / 0.01 mean, attention 3e-2 (weights rounded to 8 significand bits, 800 recurrent steps).
+    Tolerances on mel (values span ~[-2, 2] here) and attention rows (probabilities) over all 400 frames x 2 flows, ~10x what the
+    MI355X measures (run A of round 3: fp32 3.6e-7 / 1.9e-8; bf16 staged and persistent 8.6e-5 max, 1.4e-5 mean / 3.2e-5):
+      fp32 weights : mel 1e-5, attention 1e-6 (400 sequentially dependent frames of fp32 re-association);
+      bf16 weights : mel 1e-3 max / 2e-4 mean, attention 5e-4 (weights rounded to 8 significand bits, 800 recurrent steps).
     Gate: random weights give a gate that hovers at 0.50-0.53 with no usable margin, so the test DESIGNS the gate layer from the
     oracle's own trajectory -- the minimum-norm weight with logit -1 on frames 0 .. 249 and +1 on frame 250 of the gated flow
     (sigmoid 0.27 / 0.73 around the threshold 0.5; a 3 % perturbation of the gate input moves the logit by 0.03) -- and every
@@ -200,9 +201,9 @@ def test_decode_400_frames_vs_oracle_all_three_decoders(capsys):
             print("   %-13s mel max %.2e mean %.2e | attention max %.2e | gated frames %d" % r)
     for name, dmax, dmean, da, n_gated in rows:
         if name == "f32":
-            assert dmax < 2e-3 and da < 2e-4, (name, dmax, da)
+            assert dmax < 1e-5 and da < 1e-6, (name, dmax, da)
         else:
-            assert dmax < 0.1 and dmean < 0.01 and da < 3e-2, (name, dmax, dmean, da)
+            assert dmax < 1e-3 and dmean < 2e-4 and da < 5e-4, (name, dmax, dmean, da)
         assert n_gated == f_stop + 1, (name, n_gated, f_stop + 1)
 
 
@@ -239,6 +240,58 @@ def test_cfg1_full_size_vs_reference_golden():
     residual = torch.from_numpy(rs.standard_normal((1, 80, n)).astype(np.float32)) * 0.5
     mel, _ = m.infer(residual.cuda(), b["speaker_ids"][:1], b["text"][:1, : g["in_lens"][0]], gate_threshold=1.0)
     assert mad(mel, g["infer_mel"]) < 2e-4
+
+
+def test_cumulative_attention_full_width_vs_reference_golden(capsys):
+    """SURVEY 8a row a17 at FULL width: use_cumm_attention = True (location-sensitive attention: Conv1d(2->32,k5) + ReLU +
+    Conv1d(32->640,k3) + sigmoid over [cumulative ; previous] attention modulating the keys, flowtron.py:129-152, 697-723, 793-806),
+    H 1024 / A 640 / E 640, 2 flows, B = 2, T = 400 / 333 -- against golden vectors of the REAL reference
+    (tests/golden/cumm_full.pt, make_golden_r3.py --cumm): strided forward outputs, the three losses, gradient norms + samples of
+    all 76 parameter tensors, and a 48-frame inference.  fp32 MFMA mode; tolerances as test_cfg1_full_size_vs_reference_golden
+    (400 frames of a feedback loop through the attention: 5e-4 on z / log_s)."""
+    import time
+    import flowtron
+    from oracle import synth
+    g = _load("cumm_full.pt")
+    cfg = g["cfg"]
+    m, _ = build(cfg, g["seed"])
+    b = cuda_batch(synth.make_batch(cfg, g["out_lens"], g["in_lens"], seed=g["seed"], with_prior=True))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+    crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)
+    nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+    (nll + gl + 0.01 * ctc).sum().backward()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = g["stride"]
+    dz = mad(out[0][::st], g["z"])
+    dls = max(mad(out[1][i][::st], g["log_s"][i]) for i in range(2))
+    dat = max(mad(out[3][i][:, ::st], g["attn"][i]) for i in range(2))
+    with capsys.disabled():
+        print("\n[cumulative attention, full width, T 400, B 2] fwd+loss+bwd %.2f s (first call) | z %.2e log_s %.2e attn %.2e | nll %.6f / %.6f ctc %.5f / %.5f"
+              % (dt, dz, dls, dat, nll.item(), g["nll"].item(), ctc.item(), g["ctc"].item()))
+    assert dz < 5e-4 and dls < 5e-4 and dat < 5e-5, (dz, dls, dat)
+    assert mad(out[2][::st], g["gate"]) < 5e-4
+    assert abs(nll.item() - g["nll"].item()) < 2e-5 * abs(g["nll"].item())
+    assert abs(gl.item() - g["gate_loss"].item()) < 2e-5
+    assert abs(ctc.item() - g["ctc"].item()) < 2e-4 * max(1.0, abs(g["ctc"].item()))
+    bad = []
+    for k, p in m.named_parameters():
+        ref_n = g["grad_norm"][k]
+        samp = g["grad_sample"][k]
+        mine = p.grad.cpu().flatten()[:: max(1, p.numel() // 64)][:64]
+        scale = max(ref_n / p.numel() ** 0.5, 1e-7)
+        if abs(p.grad.norm().item() - ref_n) > 5e-3 * max(ref_n, 1e-5 * p.numel() ** 0.5) or (mine - samp).abs().max().item() > 5e-2 * scale + 1e-7:
+            bad.append((k, p.grad.norm().item(), ref_n, (mine - samp).abs().max().item(), scale))
+    assert not bad, bad[:5]
+    n = g["infer_mel"].shape[2]
+    rs = np.random.RandomState(g["seed"] + 11)
+    residual = torch.from_numpy(rs.standard_normal((1, 80, n)).astype(np.float32)) * 0.5
+    mel, attns = m.infer(residual.cuda(), b["speaker_ids"][:1], b["text"][:1, : g["in_lens"][0]], gate_threshold=1.0)
+    assert mad(mel, g["infer_mel"]) < 2e-4
+    for a, ra in zip(attns, g["infer_attn"]):
+        assert mad(torch.cat(a)[:, 0], ra) < 2e-5
 
 
 def test_full_config_invertibility_and_padding_invariance():

@@ -394,7 +394,7 @@ def test_lstm2_wavefront_chain_vs_oracle_and_unfused(env, T, B, H):
     def run(fused):
         d = [t.detach().cuda().requires_grad_(True) for t in cpu]
         if fused:
-            gx0 = ops.LinearFn.apply(d[1], d[3] + d[4], L.ACT_NONE, 1, d[0])
+            gx0 = ops.LinearFn.apply(d[1], d[3] + d[4], L.ACT_NONE, 1, None, "", d[0])
             y = ops.LSTM2SeqFn.apply(gx0, d[2], d[5], d[7], d[8], d[6], l32)
         else:
             y0 = ops.lstm_layer(d[0], l32, d[1], d[2], d[3], d[4], mode=1)
@@ -641,3 +641,104 @@ def test_persistent_lstm_backward_is_bit_identical_to_launch_per_step(env, ng, T
     assert torch.equal(d0, d1)
     act = torch.arange(T, device="cuda")[:, None] < lens_t[None, :]
     assert float(d1[~act].abs().max() if (~act).any() else 0.0) == 0.0
+
+
+# ---------------------------------------------------------------- pack-by-length (compact) image GEMMs
+def _valid_mask(T, B, lens):
+    return (torch.arange(T)[:, None] < torch.tensor(lens)[None, :])          # [T,B]
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+def test_rowmap_and_compact_image(env, fmt):
+    """ft_rowmap_build: batch-major compact rows, one separator per utterance (its first padded frame, or -1 when it has none),
+    device-side row count; ft_bf16_image_rows: the image holds exactly those source rows (bit-identical to torch's cast), zero
+    rows for -1 and up to ceil256(rows + 32), and its fused column sums are the sums over the mapped rows."""
+    L, ops = env
+    T, B, cols = 21, 5, 136
+    lens = [21, 17, 9, 1, 0]
+    lens32 = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    rm = ops.RowMap(lens32, T, B)
+    want = []
+    for b, l in enumerate(lens):
+        want += [t * B + b for t in range(l)] + [l * B + b if l < T else -1]
+    assert int(rm.rows.item()) == len(want) == sum(lens) + B and rm.cap == T * B + B
+    assert rm.map[: len(want)].cpu().tolist() == want
+    torch.manual_seed(3)
+    src = torch.randn(T * B, cols, device="cuda")
+    img = ops.Bf16Image(src, colsum=True, mode=fmt, rowmap=rm)
+    Rz = (len(want) + 32 + 255) // 256 * 256
+    raw = img.buf[: Rz * img.ld * 2].view(torch.int16).view(Rz, img.ld).cpu()
+    ref = src.cpu().to(torch.bfloat16 if fmt == 1 else torch.float16).view(torch.int16)
+    for i, r in enumerate(want):
+        if r >= 0:
+            assert torch.equal(raw[i, :cols], ref[r]), i
+        else:
+            assert int(raw[i].abs().max()) == 0
+    assert int(raw[len(want):].abs().max()) == 0 and int(raw[:, cols:].abs().max()) == 0
+    rows = [r for r in want if r >= 0]
+    assert (img.colsum.cpu() - src.cpu()[rows].double().sum(0).float()).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_compact_linear_equals_padded_linear_on_valid_rows(env, act):
+    """LinearFn with a RowMap (valid rows only, output rows scattered back) against the same call over all padded rows, bf16
+    operands: forward outputs and input gradients of VALID rows are bit-identical (same per-row k order), weight / bias
+    gradients agree to summation order -- provided the output gradient of padded rows is zero, as the masked losses make it;
+    fill "y" reproduces the padded rows of the padded run (they all equal the utterance's first padded row), fill "dx" zeroes
+    the input gradients of padded rows."""
+    L, ops = env
+    torch.manual_seed(21)
+    T, B, K1, K2, N = 37, 5, 64, 48, 256
+    lens = [37, 30, 12, 1, 5]
+    lens32 = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    m = _valid_mask(T, B, lens).cuda()
+    x1 = torch.randn(T, B, K1, device="cuda") * m[..., None]              # padded frames of an utterance share one value (zeros here)
+    x2 = torch.randn(T, B, K2, device="cuda") * m[..., None] + 0.25 * (~m)[..., None]
+    W = torch.randn(N, K1 + K2, device="cuda") * 0.1
+    b = torch.randn(N, device="cuda")
+    go = torch.randn(T, B, N, device="cuda") * m[..., None]
+    res = []
+    for rm in (None, ops.RowMap(lens32, T, B)):
+        d = [t.clone().requires_grad_(True) for t in (x1, x2, W, b)]
+        out = ops.linear([d[0], d[1]], d[2], d[3], act=act, mode=1, rowmap=rm, fill="y+dx")
+        out.backward(go)
+        torch.cuda.synchronize()
+        res.append([out.detach()] + [t.grad for t in d])
+    (y0, dx10, dx20, dW0, db0), (y1, dx11, dx21, dW1, db1) = res
+    assert torch.equal(y0, y1)                                               # valid rows bit-identical, padded rows reproduced
+    assert torch.equal(dx10[m], dx11[m]) and torch.equal(dx20[m], dx21[m])
+    assert float(dx11[~m].abs().max()) == 0.0 and float(dx21[~m].abs().max()) == 0.0
+    assert rel(dW1, dW0) < 2e-6 and rel(db1, db0) < 2e-6
+    # unwritten rows stay untouched without a fill: poison them through the allocator and look
+    d = [t.clone().requires_grad_(True) for t in (x1, x2, W, b)]
+    out = ops.linear([d[0], d[1]], d[2], d[3], act=act, mode=1, rowmap=ops.RowMap(lens32, T, B), fill="")
+    assert torch.equal(out[m], y0[m])
+
+
+@pytest.mark.parametrize("H", [128, 1024])
+def test_compact_lstm_layer_equals_padded(env, H):
+    """ops.lstm_layer with a RowMap (compact input projection, compact dW_ih / dW_hh with the one-step shift as a one-ROW shift
+    across the separator rows) against the padded path: y and dx bit-identical on valid frames, weight gradients to summation
+    order.  H = 1024 runs the persistent recurrences, H = 128 the launch-per-step kernels."""
+    L, ops = env
+    torch.manual_seed(5)
+    T, B, K = 37, 5, 80
+    lens = [37, 37, 20, 3, 1]
+    lens32 = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    m = _valid_mask(T, B, lens).cuda()
+    x = torch.randn(T, B, K, device="cuda") * m[..., None]
+    w_ih, w_hh = torch.randn(4 * H, K, device="cuda") * 0.1, torch.randn(4 * H, H, device="cuda") / H ** 0.5
+    b_ih, b_hh = torch.randn(4 * H, device="cuda") * 0.1, torch.randn(4 * H, device="cuda") * 0.1
+    go = torch.randn(T, B, H, device="cuda") * m[..., None]
+    res = []
+    for rm in (None, ops.RowMap(lens32, T, B)):
+        d = [t.clone().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
+        y = ops.lstm_layer(d[0], lens32, d[1], d[2], d[3], d[4], mode=1, rowmap=rm, fill="dx")
+        y.backward(go)
+        torch.cuda.synchronize()
+        res.append([y.detach()] + [t.grad for t in d])
+    ops.check_persist_status()
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1][m], res[1][1][m]) and float(res[1][1][~m].abs().max()) == 0.0
+    for a, b_, name in zip(res[1][2:], res[0][2:], ("dW_ih", "dW_hh", "db_ih", "db_hh")):
+        assert rel(a, b_) < 5e-6, (name, rel(a, b_))

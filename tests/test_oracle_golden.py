@@ -179,3 +179,33 @@ def test_chunked_oracle_equals_one_shot_oracle():
         for k, v in sdg.items():
             denom = max(v.grad.norm().item(), 1e-5 * v.numel() ** 0.5)
             assert (grads[k] - v.grad).norm().item() / denom < 2e-4, (k, chunk)
+
+
+def test_cumulative_attention_full_width_oracle_vs_real_reference(golden_dir):
+    """the oracle's location-sensitive attention branch (attn_cond / cumm_attention_sequence / the infer loop) at FULL width
+    (H 1024, A 640, T 400) against the real reference's golden (cumm_full.pt): forward outputs, losses, 48-frame inference."""
+    g = _load(golden_dir, "cumm_full.pt")
+    cfg = g["cfg"]
+    sd = synth.make_state_dict(cfg, seed=g["seed"])
+    b = synth.make_batch(cfg, g["out_lens"], g["in_lens"], seed=g["seed"], with_prior=True)
+    O.LSTM_IMPL["fn"] = O.lstm_seq_fast
+    try:
+        with torch.no_grad():
+            out = O.forward(sd, cfg, b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+            nll, gl, ctc = O.loss(out, b["gate_target"], b["in_lens"], b["out_lens"], 1.0, True, True, -8)
+    finally:
+        O.LSTM_IMPL["fn"] = O.lstm_cell_seq
+    st = g["stride"]
+    assert _maxdiff(out[0][::st], g["z"]) < 2e-4
+    for i in range(2):
+        assert _maxdiff(out[1][i][::st], g["log_s"][i]) < 2e-4
+        assert _maxdiff(out[3][i][:, ::st], g["attn"][i]) < 2e-5
+    assert abs(nll.item() - g["nll"].item()) < 1e-5 * abs(g["nll"].item())
+    assert abs(gl.item() - g["gate_loss"].item()) < 1e-5
+    assert abs(ctc.item() - g["ctc"].item()) < 1e-4 * abs(g["ctc"].item())
+    n = g["infer_mel"].shape[2]
+    rs = np.random.RandomState(g["seed"] + 11)
+    residual = torch.from_numpy(rs.standard_normal((1, 80, n)).astype(np.float32)) * 0.5
+    with torch.no_grad():
+        mel, attn = O.infer(sd, cfg, residual, b["speaker_ids"][:1], b["text"][:1, : g["in_lens"][0]], gate_threshold=1.0)
+    assert _maxdiff(mel, g["infer_mel"]) < 1e-4
