@@ -27,6 +27,42 @@ constexpr int LDA = AC + 4;  // LDS row stride (floats): 16-lane groups of ds_re
 // v_rcp_f32 per element, and sum_a v[a]*tanh = sum_a v[a] - 2 sum_a v[a]*r keeps a single FMA in the forward loop.
 constexpr float C2 = 2.8853900817779268f;
 __device__ __forceinline__ float rsig(float x) { return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x) + 1.0f); }
+// PRODUCT form of the same quantity: 2^(q'+k') = 2^q' 2^k', so with Eq = 2^q' (once per query element) and Ek = 2^k' (once per key
+// element) r = 1 / (Eq Ek + 1) costs ONE transcendental (v_rcp_f32) per (t, l, a) instead of two.  Used only while every staged
+// |q'|, |k'| <= EXP_SAFE (|q|, |k| <= 20.8: both factors and their product stay finite and normal); a tile that holds a larger
+// value -- decided on the data -- takes the sum form above, so the result never depends on a range assumption.
+constexpr float EXP_SAFE = 60.0f;
+__device__ __forceinline__ float rsig_prod(float eq, float ek) { return __builtin_amdgcn_rcpf(fmaf(eq, ek, 1.0f)); }
+template <bool PROD>
+__device__ __forceinline__ float rs(float q, float k) {
+    if constexpr (PROD) return rsig_prod(q, k);
+    else return rsig(q + k);
+}
+
+// scores of one a-chunk for a 4x4 (t, l) micro-tile (UNI: one query row only); qs / ks hold q', k' (sum form) or 2^q', 2^k' (PROD)
+template <bool PROD, bool UNI>
+__device__ __forceinline__ void score_chunk(const float* qs, const float* ks, const float* vs, int tg, int tl, const bool (&jact)[4],
+                                            float (&acc)[4][4], float& vsum, int LDAs, int ACs) {
+#pragma unroll 2
+    for (int a4 = 0; a4 < ACs / 4; ++a4) {
+        const float4 vv = *reinterpret_cast<const float4*>(vs + a4 * 4);
+        vsum += (vv.x + vv.y) + (vv.z + vv.w);
+        float4 q[4];
+#pragma unroll
+        for (int i = 0; i < (UNI ? 1 : 4); ++i) q[i] = *reinterpret_cast<const float4*>(qs + ((UNI ? 0 : tg * 4) + i) * LDAs + a4 * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (jact[j]) {
+                const float4 kk = *reinterpret_cast<const float4*>(ks + (j * 32 + tl) * LDAs + a4 * 4);
+#pragma unroll
+                for (int i = 0; i < (UNI ? 1 : 4); ++i) {
+                    acc[i][j] += vv.x * rs<PROD>(q[i].x, kk.x) + vv.y * rs<PROD>(q[i].y, kk.y) +
+                                 vv.z * rs<PROD>(q[i].z, kk.z) + vv.w * rs<PROD>(q[i].w, kk.w);
+                }
+            }
+        }
+    }
+}
 
 template <bool HAS_PRIOR>
 __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ Q, const float* __restrict__ K,
@@ -79,61 +115,47 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ Q, c
         float vsum = 0.f;
 
         for (int a0 = 0; a0 < A; a0 += AC) {
-            __syncthreads();
+            // load the chunk into registers first (no LDS touched yet), decide the form on the data, then stage
+            float qv[(TT * AC) / 256], kv[(LT * AC) / 256];
+            bool big = false;
 #pragma unroll
             for (int r = 0; r < (TT * AC) / 256; ++r) {
                 const int idx = tid + 256 * r;
                 const int row = idx >> 6, col = idx & 63;
                 const int t = t0 + row, a = a0 + col;
-                qs[row * LDA + col] = (t < T && a < A) ? C2 * Q[((long)t * B + b) * A + a] : 0.f;
+                qv[r] = (t < T && a < A) ? C2 * Q[((long)t * B + b) * A + a] : 0.f;
+                big |= !(fabsf(qv[r]) <= EXP_SAFE);
             }
-#pragma unroll 4
+#pragma unroll
             for (int r = 0; r < (LT * AC) / 256; ++r) {
                 const int idx = tid + 256 * r;
                 const int row = idx >> 6, col = idx & 63;
                 const int l = lt * LT + row, a = a0 + col;
-                ks[row * LDA + col] = (l < len && a < A) ? C2 * K[((long)l * B + b) * A + a] : 0.f;
+                kv[r] = (l < len && a < A) ? C2 * K[((long)l * B + b) * A + a] : 0.f;
+                big |= !(fabsf(kv[r]) <= EXP_SAFE);
+            }
+            const bool prod = !__syncthreads_or(big ? 1 : 0);      // (also: the previous chunk's LDS reads are done)
+#pragma unroll
+            for (int r = 0; r < (TT * AC) / 256; ++r) {
+                const int idx = tid + 256 * r;
+                qs[(idx >> 6) * LDA + (idx & 63)] = prod ? __builtin_amdgcn_exp2f(qv[r]) : qv[r];
+            }
+#pragma unroll
+            for (int r = 0; r < (LT * AC) / 256; ++r) {
+                const int idx = tid + 256 * r;
+                ks[(idx >> 6) * LDA + (idx & 63)] = prod ? __builtin_amdgcn_exp2f(kv[r]) : kv[r];
             }
             if (tid < AC) vs[tid] = (a0 + tid < A) ? v[a0 + tid] : 0.f;
             __syncthreads();
-            if (uniform_q) {                                   // one score row (same summation order as the general path below)
+            if (uniform_q) {                                   // one score row (same summation order as the general path)
                 if (!idle) {
-#pragma unroll 2
-                    for (int a4 = 0; a4 < AC / 4; ++a4) {
-                        const float4 vv = *reinterpret_cast<const float4*>(vs + a4 * 4);
-                        vsum += (vv.x + vv.y) + (vv.z + vv.w);
-                        const float4 q0 = *reinterpret_cast<const float4*>(qs + a4 * 4);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (jact[j]) {
-                                const float4 kk = *reinterpret_cast<const float4*>(ks + (j * 32 + tl) * LDA + a4 * 4);
-                                acc[0][j] += vv.x * rsig(q0.x + kk.x) + vv.y * rsig(q0.y + kk.y) +
-                                             vv.z * rsig(q0.z + kk.z) + vv.w * rsig(q0.w + kk.w);
-                            }
-                        }
-                    }
+                    if (prod) score_chunk<true, true>(qs, ks, vs, tg, tl, jact, acc, vsum, LDA, AC);
+                    else score_chunk<false, true>(qs, ks, vs, tg, tl, jact, acc, vsum, LDA, AC);
                 }
                 continue;
             }
-#pragma unroll 2
-            for (int a4 = 0; a4 < AC / 4; ++a4) {
-                const float4 vv = *reinterpret_cast<const float4*>(vs + a4 * 4);
-                vsum += (vv.x + vv.y) + (vv.z + vv.w);
-                float4 q[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const float4*>(qs + (tg * 4 + i) * LDA + a4 * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (jact[j]) {
-                        const float4 kk = *reinterpret_cast<const float4*>(ks + (j * 32 + tl) * LDA + a4 * 4);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            acc[i][j] += vv.x * rsig(q[i].x + kk.x) + vv.y * rsig(q[i].y + kk.y) +
-                                         vv.z * rsig(q[i].z + kk.z) + vv.w * rsig(q[i].w + kk.w);
-                        }
-                    }
-                }
-            }
+            if (prod) score_chunk<true, false>(qs, ks, vs, tg, tl, jact, acc, vsum, LDA, AC);
+            else score_chunk<false, false>(qs, ks, vs, tg, tl, jact, acc, vsum, LDA, AC);
         }
         if (uniform_q) {
             if (!idle) {
@@ -281,11 +303,14 @@ __global__ __launch_bounds__(256) void attn_dqdk_k(const float* __restrict__ Q, 
     const int a = aw + lane;
     const bool av = a < A;
     const int ac = av ? a : A - 1;      // clamp: keeps the loads unconditional, results of idle lanes are dropped
-    float q[32], dq[32];
+    float q[32], eq[32], dq[32];
+    bool qbig = false;
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
         const int t = min(t0 + i, T - 1);
         q[i] = C2 * Q[((long)t * B + b) * A + ac];
+        qbig |= !(fabsf(q[i]) <= EXP_SAFE);
+        eq[i] = __builtin_amdgcn_exp2f(q[i]);
         dq[i] = 0.f;
     }
     float dva = 0.f;
@@ -297,18 +322,37 @@ __global__ __launch_bounds__(256) void attn_dqdk_k(const float* __restrict__ Q, 
         const float kv = kv_next;
         if (l + 1 < len) kv_next = C2 * kp[(long)(l + 1) * ks];
         float dkp = 0.f;
+        // product form (one v_rcp per element) unless this wave holds an out-of-range value for this key (wave-uniform choice)
+        if (!__any(qbig || !(fabsf(kv) <= EXP_SAFE))) {
+            const float ek = __builtin_amdgcn_exp2f(kv);
 #pragma unroll
-        for (int i4 = 0; i4 < 8; ++i4) {
-            const float4 d4 = *reinterpret_cast<const float4*>(de_s + l * 32 + i4 * 4);     // same address in every lane: broadcast
-            const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+            for (int i4 = 0; i4 < 8; ++i4) {
+                const float4 d4 = *reinterpret_cast<const float4*>(de_s + l * 32 + i4 * 4);     // same address in every lane: broadcast
+                const float d[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = i4 * 4 + j;
-                const float r = rsig(q[i] + kv);
-                const float u = fmaf(-r, r, r);              // r (1 - r) = (1 - tanh^2) / 4
-                dq[i] = fmaf(d[j], u, dq[i]);
-                dkp = fmaf(d[j], u, dkp);
-                dva = fmaf(d[j], fmaf(-2.f, r, 1.f), dva);
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i4 * 4 + j;
+                    const float r = rsig_prod(eq[i], ek);
+                    const float u = fmaf(-r, r, r);              // r (1 - r) = (1 - tanh^2) / 4
+                    dq[i] = fmaf(d[j], u, dq[i]);
+                    dkp = fmaf(d[j], u, dkp);
+                    dva = fmaf(d[j], fmaf(-2.f, r, 1.f), dva);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i4 = 0; i4 < 8; ++i4) {
+                const float4 d4 = *reinterpret_cast<const float4*>(de_s + l * 32 + i4 * 4);
+                const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i4 * 4 + j;
+                    const float r = rsig(q[i] + kv);
+                    const float u = fmaf(-r, r, r);
+                    dq[i] = fmaf(d[j], u, dq[i]);
+                    dkp = fmaf(d[j], u, dkp);
+                    dva = fmaf(d[j], fmaf(-2.f, r, 1.f), dva);
+                }
             }
         }
         if (av) atomicAdd(dK + ((long)l * B + b) * A + a, dkp * va4);
