@@ -380,14 +380,17 @@ extern "C" int ft_attention_fwd(const float* Q, const float* K, const float* v, 
     FT_CHECK_ARG(B <= 65535);
     const int LP = cdiv(L, LT) * LT;
     const size_t lds = sizeof(float) * ((size_t)TT * LDA + (size_t)LT * LDA + AC + (size_t)TT * LP);
-    if (lds > (size_t)MAX_LDS) return ft_fail(FT_EUNSUPPORTED, "ft_attention_fwd: L=%d needs %zu B of LDS (max %d)", L, lds, MAX_LDS);
+    if (lds > (size_t)MAX_LDS - 1024) return ft_fail(FT_EUNSUPPORTED, "ft_attention_fwd: L=%d needs %zu B of LDS (max %d)", L, lds, MAX_LDS - 1024);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(cdiv(T, TT), B);
+    // (the kernel also has a few static LDS bytes -- __syncthreads_or -- so ask for what this launch needs, not for all 160 KiB)
     if (prior) {
-        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+        if (lds > 48 * 1024)
+            FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(attn_fwd_k<true>, grid, dim3(256), lds, st, Q, K, v, in_lens, prior, attn, logprob, p_save, T, B, L, A, LP, 1.0f / temperature);
     } else {
-        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+        if (lds > 48 * 1024)
+            FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(attn_fwd_k<false>, grid, dim3(256), lds, st, Q, K, v, in_lens, prior, attn, logprob, p_save, T, B, L, A, LP, 1.0f / temperature);
     }
     FT_CHECK_LAUNCH();

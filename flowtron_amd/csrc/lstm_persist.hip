@@ -40,6 +40,7 @@
 namespace {
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
 typedef __attribute__((address_space(1))) void gl_void;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -98,6 +99,50 @@ __device__ __forceinline__ unsigned row_shl(unsigned v) {
     else return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xf, 0xf, true);
 }
 
+// BARE hand-off (template BARE = true): the same packed layout WITHOUT tags -- a 16-byte load carries eight k-values, half the
+// bytes per step (measured: a wave reading freshly written granules is latency-bound at ~50-75 GB/s per CU, so the 64 KB a CU
+// pulls per backward step are most of its 2 us sweep).  "Not yet written" is a SENTINEL instead of an epoch tag: three rotating
+// buffers; during step n a producer resets its own slots of buffer (n+1) % 3 to 0xFFFFFFFF (that buffer holds step n-2, which
+// every consumer of the group has finished reading: they all published step n-1, and this CU has gathered all of it), waits for
+// those stores (s_waitcnt vmcnt(0)) and only then publishes step n into buffer n % 3.  A consumer that polls buffer (n+1) % 3
+// for step n+1 has already gathered step n from every producer, hence stands behind every producer's reset: it can only see
+// the sentinel or the new value, never the value of step n-2.  A dword is two 16-bit operands; a pair of NaNs with all-ones
+// payloads (the converters produce the canonical 0x7FC0 / 0xFFC0 / 0x7E00) would read as "not yet" and end in the bounded
+// time-out like any other failure.  Buffer layout [group][3][w][lg][64 lanes][4 dwords].
+constexpr unsigned SENT = 0xFFFFFFFFu;
+template <int RPGP, int NCW>
+__device__ __forceinline__ int bare_index(int b, int k) {       // dword index of the operand pair (k, k+1), k even
+    constexpr int CPL = 16 / RPGP, NLG = NCW / CPL;
+    const int c = k >> 5, w = c & 3, ci = c >> 2, kg = (k >> 3) & 3, e = k & 7;
+    const int lg = ci / CPL, j = ci % CPL, lane = kg * 16 + j * RPGP + b;
+    return (((w * NLG + lg) * 64 + lane) << 2) + (e >> 1);
+}
+// the eight operands of one lane from the load(s) of a load group: tagged = two loads {v, tag, v, tag}, bare = one load
+template <bool BARE>
+__device__ __forceinline__ u32x4 payload(const u32x4* l) {
+    if constexpr (BARE) return l[0];
+    else return (u32x4){l[0][0], l[0][2], l[1][0], l[1][2]};
+}
+template <bool BARE>
+__device__ __forceinline__ bool fresh(const u32x4* l, unsigned epoch) {
+    if constexpr (BARE) return (l[0][0] != SENT) & (l[0][1] != SENT) & (l[0][2] != SENT) & (l[0][3] != SENT);
+    else return (l[0][1] == epoch) & (l[0][3] == epoch) & (l[1][1] == epoch) & (l[1][3] == epoch);
+}
+template <int S>
+__device__ __forceinline__ u32x4 shl4(u32x4 v) {
+    return (u32x4){row_shl<S>(v[0]), row_shl<S>(v[1]), row_shl<S>(v[2]), row_shl<S>(v[3])};
+}
+// member j (0 .. CPL-1) of a load group moved into the MFMA row positions: a row shift by j RPGP lanes
+template <int RPGP>
+__device__ __forceinline__ u32x4 member(u32x4 v, int j) {
+    switch (j) {
+        case 0: return v;
+        case 1: return shl4<RPGP & 15>(v);
+        case 2: return shl4<(2 * RPGP) & 15>(v);
+        default: return shl4<(3 * RPGP) & 15>(v);
+    }
+}
+
 // Staging of the HBM rows the recurrence reads.
 // Forward: gx rows arrive in synchronous bursts of SB steps (one HBM round trip per 32 steps, ~0.1 us per step).
 // Backward (saved gates, cell, dy: 6 rows per step, 97 KB per burst -- measured 20 us of whole-workgroup stall per 32 steps,
@@ -132,7 +177,7 @@ __device__ __forceinline__ bool join_group_local(unsigned* census, int* status, 
     return true;
 }
 
-template <int NG, bool LOCAL, int LAUX>
+template <int NG, bool LOCAL, int LAUX, bool BARE>
 __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
     static_assert(!LOCAL || NG == 8, "the L2-local transport needs group == XCD");
     constexpr int CPG = NCU / NG;                  // CUs (workgroups) per group
@@ -228,14 +273,21 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
     };
 
     float c_state = 0.f, h_state = 0.f;
+    // hand-off buffers of this group.  Tagged: two parity buffers of 8-byte granules.  BARE: three rotating buffers of bare
+    // operand pairs behind ONE resource, the buffer of a step selected by a scalar byte offset.
+    constexpr int LPG = BARE ? 1 : 2;                            // 16-byte loads per load group
+    constexpr int DW_PER_GROUP = NCHUNK * 32 * RPGP / 2;         // BARE: dwords per buffer and group
     __amdgpu_buffer_rsrc_t rs[2];
 #pragma unroll
     for (int par = 0; par < 2; ++par)
         rs[par] = __builtin_amdgcn_make_buffer_rsrc(p.hgran + ((size_t)par * NG + grp) * GRAN_PER_GROUP, 0,
                                                     GRAN_PER_GROUP * 8, 0x00020000);
-    // load (lg, half) of this wave = 1 KiB at ((wave NLG + lg) 2 + half) KiB: lane offset in the VGPR, the rest scalar
+    unsigned* const bare0 = reinterpret_cast<unsigned*>(p.hgran) + (size_t)grp * 3 * DW_PER_GROUP;
+    const __amdgpu_buffer_rsrc_t rbare = __builtin_amdgcn_make_buffer_rsrc(bare0, 0, 3 * DW_PER_GROUP * 4, 0x00020000);
+    int m3 = 0;                                                  // t % 3
+    // load h of load group lg of this wave = 1 KiB at ((wave NLG + lg) LPG + h) KiB: lane offset in the VGPR, the rest scalar
     const int voff = lane * 16;
-    const int soff_w = __builtin_amdgcn_readfirstlane(wave) * (NLG * 2048);
+    const int soff_w = __builtin_amdgcn_readfirstlane(wave) * (NLG * LPG * 1024);
     const long t_start = wall_clock64();
     bool dead = false;
     // debug stamps (100 MHz wall clock): [step][wave][0..4] = loop top, sweep+MFMA done, reduce barrier passed, published,
@@ -256,19 +308,21 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
             // hipcc shuffle accumulators and weight fragments through v_accvgpr_mov on every chunk).
             const unsigned epoch = (unsigned)t;
             const int par = (t - 1) & 1;
-            u32x4 lo[NLG], hi[NLG];
+            const int boff = BARE ? (m3 == 0 ? 2 : m3 - 1) * (DW_PER_GROUP * 4) : 0;     // BARE: buffer (t - 1) % 3
+            u32x4 ld[NLG][LPG];
+            auto issue = [&](int g) {
 #pragma unroll
-            for (int g = 0; g < NLG; ++g) {
-                lo[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, soff_w + g * 2048, LAUX);   // LAUX: 16 = sc1, 2 = nt
-                hi[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, soff_w + g * 2048 + 1024, LAUX);
-            }
-            unsigned ready = 0;                    // wave-uniform bit per load group: tags matched
+                for (int h = 0; h < LPG; ++h)                                              // LAUX: 16 = sc1, 2 = nt
+                    ld[g][h] = __builtin_amdgcn_raw_buffer_load_b128(BARE ? rbare : rs[par], voff, soff_w + (g * LPG + h) * 1024 + boff, LAUX);
+            };
+#pragma unroll
+            for (int g = 0; g < NLG; ++g) issue(g);
+            unsigned ready = 0;                    // wave-uniform bit per load group: every lane holds the data of this step
             for (unsigned spins = 0;; ++spins) {
 #pragma unroll
                 for (int g = 0; g < NLG; ++g) {
                     if (!((ready >> g) & 1u)) {
-                        const bool ok = (lo[g][1] == epoch) & (lo[g][3] == epoch) & (hi[g][1] == epoch) & (hi[g][3] == epoch);
-                        if (__all(ok)) ready |= 1u << g;
+                        if (__all(fresh<BARE>(ld[g], epoch))) ready |= 1u << g;
                     }
                 }
                 npass = spins + 1;
@@ -283,27 +337,13 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
                 asm volatile("" ::: "memory");     // the builtin loads are not atomics: keep the re-reads inside the loop
 #pragma unroll
                 for (int g = 0; g < NLG; ++g) {
-                    if (!((ready >> g) & 1u)) {
-                        lo[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, soff_w + g * 2048, LAUX);
-                        hi[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, soff_w + g * 2048 + 1024, LAUX);
-                    }
+                    if (!((ready >> g) & 1u)) issue(g);
                 }
             }
             if (dead) break;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {          // chunk i of this wave = load group i / CPL, member i % CPL
-                constexpr int SH = RPGP;           // (shift below is (i % CPL) * RPGP lanes)
-                const int g = i / CPL;
-                u32x4 v;
-                switch (i % CPL) {
-                    case 0: v = (u32x4){lo[g][0], lo[g][2], hi[g][0], hi[g][2]}; break;
-                    case 1: v = (u32x4){row_shl<SH>(lo[g][0]), row_shl<SH>(lo[g][2]), row_shl<SH>(hi[g][0]), row_shl<SH>(hi[g][2])}; break;
-                    case 2: v = (u32x4){row_shl<(2 * SH) & 15>(lo[g][0]), row_shl<(2 * SH) & 15>(lo[g][2]), row_shl<(2 * SH) & 15>(hi[g][0]),
-                                        row_shl<(2 * SH) & 15>(hi[g][2])}; break;
-                    default: v = (u32x4){row_shl<(3 * SH) & 15>(lo[g][0]), row_shl<(3 * SH) & 15>(lo[g][2]), row_shl<(3 * SH) & 15>(hi[g][0]),
-                                         row_shl<(3 * SH) & 15>(hi[g][2])}; break;
-                }
-                const bf16x8 a = __builtin_bit_cast(bf16x8, v);
+                const bf16x8 a = __builtin_bit_cast(bf16x8, member<RPGP>(payload<BARE>(ld[i / CPL]), i % CPL));
 #pragma unroll
                 for (int j = 0; j < TPC; ++j) acc[j] = mfma16(a, w[j][i], acc[j]);
             }
@@ -323,6 +363,15 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
         if (erole) {
             const bool active = t < len;
             const int j = el >> 2, ul = el & 3;
+            if constexpr (BARE) {
+                // reset this thread's slot of buffer (t + 1) % 3 (it holds step t - 2, which everybody has consumed) first: the
+                // acknowledgement returns under the cell update below, and the publish waits for it
+                if ((el & 1) == 0) {
+                    unsigned* dst = bare0 + (m3 == 2 ? 0 : m3 + 1) * DW_PER_GROUP + bare_index<RPGP, 8>(ebl, eu);
+                    if constexpr (LOCAL) __hip_atomic_store((gu32*)dst, SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_store((gu32*)dst, SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             const float* gxr = gxs + (t % SB) * 4 * NE + tid;
             float pre[4];
 #pragma unroll
@@ -338,7 +387,15 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
             }
             // ---- publish h_t first: one 8-byte {epoch, bf16 pair} granule per even unit (frozen rows re-publish their state)
             const float h_nb = __uint_as_float(row_shl<1>(__float_as_uint(h_state)));     // lane + 1 of the row: the odd unit of the pair
-            if ((el & 1) == 0) {
+            if constexpr (BARE) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the reset above is in the L2 before the publish leaves
+                if ((el & 1) == 0) {
+                    unsigned* dst = bare0 + m3 * DW_PER_GROUP + bare_index<RPGP, 8>(ebl, eu);
+                    const unsigned val = pack_op16x2(h_state, h_nb);
+                    if constexpr (LOCAL) __hip_atomic_store((gu32*)dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_store((gu32*)dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else if ((el & 1) == 0) {
                 const unsigned long long gran = ((unsigned long long)(unsigned)(t + 1) << 32) | pack_op16x2(h_state, h_nb);
                 unsigned long long* dst = p.hgran + ((size_t)(t & 1) * NG + grp) * GRAN_PER_GROUP + gran_index<RPGP, 8>(ebl, eu);
                 // LOCAL: workgroup-scope relaxed store = ONE aligned 8-byte global_store (sc0) whose line stays in this XCD's L2;
@@ -355,6 +412,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
             long* o = p.prof + ((size_t)t * 4 + wave) * 5;
             o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = npass;
         }
+        m3 = m3 == 2 ? 0 : m3 + 1;
     }
     if (dead) {
         if (lane == 0) atomicExch(p.status, 1);
@@ -387,7 +445,7 @@ struct PersistBwdP {
     long* prof;
 };
 
-template <int NG, bool LOCAL, int LAUX>
+template <int NG, bool LOCAL, int LAUX, bool BARE>
 __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     static_assert(!LOCAL || NG == 8, "the L2-local transport needs group == XCD");
     constexpr int CPG = NCU / NG;                  // workgroups per group
@@ -479,13 +537,18 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     __syncthreads();
 
     float dc_carry = 0.f;
+    constexpr int LPG = BARE ? 1 : 2;                            // 16-byte loads per load group (see the forward kernel)
+    constexpr int DW_PER_GROUP = KCH * 32 * RPGP / 2;            // BARE: dwords per buffer and group
     __amdgpu_buffer_rsrc_t rs[2];
 #pragma unroll
     for (int par = 0; par < 2; ++par)
         rs[par] = __builtin_amdgcn_make_buffer_rsrc(p.dgran + ((size_t)par * NG + grp) * GRAN_PER_GROUP, 0,
                                                     GRAN_PER_GROUP * 8, 0x00020000);
+    unsigned* const bare0 = reinterpret_cast<unsigned*>(p.dgran) + (size_t)grp * 3 * DW_PER_GROUP;
+    const __amdgpu_buffer_rsrc_t rbare = __builtin_amdgcn_make_buffer_rsrc(bare0, 0, 3 * DW_PER_GROUP * 4, 0x00020000);
+    int m3 = 0;                                                  // n % 3
     const int voff = lane * 16;
-    const int soff_w = __builtin_amdgcn_readfirstlane(wave) * (NLG * 2048);
+    const int soff_w = __builtin_amdgcn_readfirstlane(wave) * (NLG * LPG * 1024);
     const long t_start = wall_clock64();
     bool dead = false;
 
@@ -503,28 +566,28 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
         if (n > 0) {
             const unsigned epoch = (unsigned)n;
             const int par = (n - 1) & 1;
-            u32x4 lo[2][LPB], hi[2][LPB];
-            auto issue = [&](int bt, u32x4 (&l_)[LPB], u32x4 (&h_)[LPB]) {
+            const int boff = BARE ? (m3 == 0 ? 2 : m3 - 1) * (DW_PER_GROUP * 4) : 0;     // BARE: buffer (n - 1) % 3
+            u32x4 ld[2][LPB][LPG];
+            auto issue1 = [&](int bt, int g, u32x4 (&l_)[LPG]) {
 #pragma unroll
-                for (int g = 0; g < LPB; ++g) {
-                    const int so = soff_w + (bt * LPB + g) * 2048;
-                    l_[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, so, LAUX);
-                    h_[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, so + 1024, LAUX);
-                }
+                for (int h = 0; h < LPG; ++h)
+                    l_[h] = __builtin_amdgcn_raw_buffer_load_b128(BARE ? rbare : rs[par], voff, soff_w + ((bt * LPB + g) * LPG + h) * 1024 + boff, LAUX);
             };
-            issue(0, lo[0], hi[0]);
+            auto issue = [&](int bt, u32x4 (&l_)[LPB][LPG]) {
+#pragma unroll
+                for (int g = 0; g < LPB; ++g) issue1(bt, g, l_[g]);
+            };
+            issue(0, ld[0]);
 #pragma unroll
             for (int bt = 0; bt < NBT; ++bt) {
-                if (bt < NBT - 1) issue(bt + 1, lo[(bt + 1) & 1], hi[(bt + 1) & 1]);
-                u32x4 (&L_)[LPB] = lo[bt & 1];
-                u32x4 (&H_)[LPB] = hi[bt & 1];
+                if (bt < NBT - 1) issue(bt + 1, ld[(bt + 1) & 1]);
+                u32x4 (&L_)[LPB][LPG] = ld[bt & 1];
                 unsigned ready = 0;
                 for (unsigned spins = 0;; ++spins) {             // loads and tag compares only (see the forward kernel)
 #pragma unroll
                     for (int g = 0; g < LPB; ++g) {
                         if (!((ready >> g) & 1u)) {
-                            const bool ok = (L_[g][1] == epoch) & (L_[g][3] == epoch) & (H_[g][1] == epoch) & (H_[g][3] == epoch);
-                            if (__all(ok)) ready |= 1u << g;
+                            if (__all(fresh<BARE>(L_[g], epoch))) ready |= 1u << g;
                         }
                     }
                     if (ready == (1u << LPB) - 1u) break;
@@ -539,28 +602,14 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int g = 0; g < LPB; ++g) {
-                        if (!((ready >> g) & 1u)) {
-                            const int so = soff_w + (bt * LPB + g) * 2048;
-                            L_[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, so, LAUX);
-                            H_[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, so + 1024, LAUX);
-                        }
+                        if (!((ready >> g) & 1u)) issue1(bt, g, L_[g]);
                     }
                 }
                 if (dead) break;
 #pragma unroll
                 for (int i = 0; i < LPB * CPL; ++i) {                // chunk ci of this wave = load group ci / CPL, member ci % CPL
-                    constexpr int SH = RPGP;
-                    const int ci = bt * LPB * CPL + i, g = i / CPL;
-                    u32x4 v;
-                    switch (i % CPL) {
-                        case 0: v = (u32x4){L_[g][0], L_[g][2], H_[g][0], H_[g][2]}; break;
-                        case 1: v = (u32x4){row_shl<SH>(L_[g][0]), row_shl<SH>(L_[g][2]), row_shl<SH>(H_[g][0]), row_shl<SH>(H_[g][2])}; break;
-                        case 2: v = (u32x4){row_shl<(2 * SH) & 15>(L_[g][0]), row_shl<(2 * SH) & 15>(L_[g][2]), row_shl<(2 * SH) & 15>(H_[g][0]),
-                                            row_shl<(2 * SH) & 15>(H_[g][2])}; break;
-                        default: v = (u32x4){row_shl<(3 * SH) & 15>(L_[g][0]), row_shl<(3 * SH) & 15>(L_[g][2]), row_shl<(3 * SH) & 15>(H_[g][0]),
-                                             row_shl<(3 * SH) & 15>(H_[g][2])}; break;
-                    }
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, v);
+                    const int ci = bt * LPB * CPL + i;
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, member<RPGP>(payload<BARE>(L_[i / CPL]), i % CPL));
 #pragma unroll
                     for (int j = 0; j < TL; ++j)
                         acc[j][ci & 3] = mfma16(a, w[j][ci], acc[j][ci & 3]);
@@ -589,6 +638,19 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
             const int i = n % RING;
             const bool active = s < len;
             float da[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (BARE) {
+                // reset this thread's four slots of buffer (n + 1) % 3 (step n - 2: consumed by everybody); acknowledged under the
+                // cell backward below (waves 0-1 have nothing else outstanding: the ring DMAs and dgx stores belong to waves 2-3)
+                if ((el & 1) == 0) {
+                    unsigned* base = bare0 + (m3 == 2 ? 0 : m3 + 1) * DW_PER_GROUP;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        unsigned* dst = base + bare_index<RPGP, CPW>(ebl, g * PH + eu);
+                        if constexpr (LOCAL) __hip_atomic_store((gu32*)dst, SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else __hip_atomic_store((gu32*)dst, SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
             if (active) {
                 const int j = el >> 4, nn = el & 15;
                 const float* in = ins + i * 5 * NE + tid;
@@ -601,14 +663,22 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
                 dc_carry = carry;
             }
             // ---- publish dgates_s: one granule per gate per even unit (k = gate*H + unit)
+            if constexpr (BARE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the resets above have reached the L2
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float nb = __uint_as_float(row_shl<1>(__float_as_uint(da[g])));
                 if ((el & 1) == 0) {
-                    const unsigned long long gran = ((unsigned long long)(unsigned)(n + 1) << 32) | pack_op16x2(da[g], nb);
-                    unsigned long long* dst = p.dgran + ((size_t)(n & 1) * NG + grp) * GRAN_PER_GROUP + gran_index<RPGP, CPW>(ebl, g * PH + eu);
-                    if constexpr (LOCAL) __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (BARE) {
+                        unsigned* dst = bare0 + m3 * DW_PER_GROUP + bare_index<RPGP, CPW>(ebl, g * PH + eu);
+                        const unsigned val = pack_op16x2(da[g], nb);
+                        if constexpr (LOCAL) __hip_atomic_store((gu32*)dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else __hip_atomic_store((gu32*)dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        const unsigned long long gran = ((unsigned long long)(unsigned)(n + 1) << 32) | pack_op16x2(da[g], nb);
+                        unsigned long long* dst = p.dgran + ((size_t)(n & 1) * NG + grp) * GRAN_PER_GROUP + gran_index<RPGP, CPW>(ebl, g * PH + eu);
+                        if constexpr (LOCAL) __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
             if (prof) st3 = wall_clock64();
@@ -620,6 +690,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
             long* o = p.prof + ((size_t)n * 4 + wave) * 5;
             o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = npass;
         }
+        m3 = m3 == 2 ? 0 : m3 + 1;
     }
     if (dead) {
         if (lane == 0) atomicExch(p.status, 1);
@@ -675,7 +746,11 @@ extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh
     FT_CHECK_ARG(gx && w_hh && lens && y && work && status);
     FT_CHECK_ARG((gates == nullptr) == (cell == nullptr));
     FT_CHECK_ARG(T >= 0 && ldy >= H && reinterpret_cast<uintptr_t>(work) % 256 == 0);
-    FT_CHECK_ARG(ng == 1 || ng == 9 || ng == 8 || ng == 4 || ng == 2);   // 1 / 9 = XCD-local transport (nt / sc1 loads)
+    // ng: 1 / 9 = XCD-local transport (nt / sc1 loads), 8 | 4 | 2 = placement-independent fabric transport, all with tagged
+    // granules; + 10 (11, 19, 18, 14, 12) = the same transports with BARE operand pairs and the sentinel protocol
+    const bool bare = ng > 10;
+    const int ngb = bare ? ng - 10 : ng;
+    FT_CHECK_ARG(ngb == 1 || ngb == 9 || ngb == 8 || ngb == 4 || ngb == 2);
     if (!ft_lstm_persist_supported(B, H))
         return ft_fail(FT_EUNSUPPORTED, "ft_lstm_persist_fwd: needs H == 1024, B <= 32 and a 256-CU device (H=%d B=%d)", H, B);
     if (T == 0) return FT_OK;
@@ -683,9 +758,10 @@ extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh
     char* base = reinterpret_cast<char*>(work);
     unsigned short* wfrag = reinterpret_cast<unsigned short*>(base);
     unsigned long long* hgran = reinterpret_cast<unsigned long long*>(base + al256p((size_t)4 * H * H * 2));
+    // tagged: 2 parities x 32 rows x H/2 granules x 8 B; bare: 3 buffers x 32 rows x H/2 dwords (smaller)
     const size_t gran_bytes = al256p((size_t)2 * 32 * (H / 2) * 8);
     unsigned* census = reinterpret_cast<unsigned*>(base + al256p((size_t)4 * H * H * 2) + al256p((size_t)2 * 32 * (4 * H / 2) * 8));
-    FT_CHECK_HIP(hipMemsetAsync(hgran, 0, gran_bytes, st));           // tags = 0: no epoch matches (epochs start at 1)
+    FT_CHECK_HIP(hipMemsetAsync(hgran, bare ? 0xFF : 0, gran_bytes, st));   // tags = 0: no epoch matches (epochs start at 1); bare: sentinels
     FT_CHECK_HIP(hipMemsetAsync(census, 0, 256, st));
     hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H);
     PersistP p{gx, lens, y, (long)ldy, gates, cell, wfrag, hgran, status, census, T, B, 100000000L / 2, g_persist_prof};   // 0.5 s
@@ -697,11 +773,19 @@ extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh
         return FT_OK;
     };
     int rc;
-    if (ng == 1) rc = launch(lstm_persist_fwd_k<8, true, 2>);
-    else if (ng == 9) rc = launch(lstm_persist_fwd_k<8, true, 16>);
-    else if (ng == 8) rc = launch(lstm_persist_fwd_k<8, false, 16>);
-    else if (ng == 4) rc = launch(lstm_persist_fwd_k<4, false, 16>);
-    else rc = launch(lstm_persist_fwd_k<2, false, 16>);
+    if (!bare) {
+        if (ngb == 1) rc = launch(lstm_persist_fwd_k<8, true, 2, false>);
+        else if (ngb == 9) rc = launch(lstm_persist_fwd_k<8, true, 16, false>);
+        else if (ngb == 8) rc = launch(lstm_persist_fwd_k<8, false, 16, false>);
+        else if (ngb == 4) rc = launch(lstm_persist_fwd_k<4, false, 16, false>);
+        else rc = launch(lstm_persist_fwd_k<2, false, 16, false>);
+    } else {
+        if (ngb == 1) rc = launch(lstm_persist_fwd_k<8, true, 2, true>);
+        else if (ngb == 9) rc = launch(lstm_persist_fwd_k<8, true, 16, true>);
+        else if (ngb == 8) rc = launch(lstm_persist_fwd_k<8, false, 16, true>);
+        else if (ngb == 4) rc = launch(lstm_persist_fwd_k<4, false, 16, true>);
+        else rc = launch(lstm_persist_fwd_k<2, false, 16, true>);
+    }
     if (rc != FT_OK) return rc;
     FT_CHECK_LAUNCH();
     return FT_OK;
@@ -712,7 +796,9 @@ extern "C" int FT_OPNAME(ft_lstm_persist_bwd)(const float* dy, int64_t ldy, cons
                                    void* stream) {
     FT_CHECK_ARG(dy && w_hh && lens && gates && cell && dgx && work && status);
     FT_CHECK_ARG(T >= 0 && ldy >= H && reinterpret_cast<uintptr_t>(work) % 256 == 0);
-    FT_CHECK_ARG(ng == 1 || ng == 9 || ng == 8 || ng == 4);
+    const bool bare = ng > 10;
+    const int ngb = bare ? ng - 10 : ng;
+    FT_CHECK_ARG(ngb == 1 || ngb == 9 || ngb == 8 || ngb == 4);
     if (!ft_lstm_persist_supported(B, H))
         return ft_fail(FT_EUNSUPPORTED, "ft_lstm_persist_bwd: needs H == 1024, B <= 32 and a 256-CU device (H=%d B=%d)", H, B);
     if (T == 0) return FT_OK;
@@ -722,7 +808,8 @@ extern "C" int FT_OPNAME(ft_lstm_persist_bwd)(const float* dy, int64_t ldy, cons
     unsigned long long* dgran = reinterpret_cast<unsigned long long*>(base + al256p((size_t)4 * H * H * 2));
     const size_t gran_bytes = al256p((size_t)2 * 32 * (4 * H / 2) * 8);
     unsigned* census = reinterpret_cast<unsigned*>(base + al256p((size_t)4 * H * H * 2) + gran_bytes);
-    FT_CHECK_HIP(hipMemsetAsync(dgran, 0, gran_bytes + 256, st));
+    FT_CHECK_HIP(hipMemsetAsync(dgran, bare ? 0xFF : 0, gran_bytes, st));
+    FT_CHECK_HIP(hipMemsetAsync(census, 0, 256, st));
     hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H);
     PersistBwdP p{dy, (long)ldy, lens, gates, cell, dgx, wTfrag, dgran, status, census, T, B, 100000000L / 2, g_persist_prof};
     // dynamic LDS: 16-partial reduce (2 x 16 x 32 unit-rows... = 2*16*TL*RPGP*17 = 2*16*8*17 floats) + staged steps
@@ -733,10 +820,17 @@ extern "C" int FT_OPNAME(ft_lstm_persist_bwd)(const float* dy, int64_t ldy, cons
         return FT_OK;
     };
     int rc;
-    if (ng == 1) rc = launch(lstm_persist_bwd_k<8, true, 2>);
-    else if (ng == 9) rc = launch(lstm_persist_bwd_k<8, true, 16>);
-    else if (ng == 8) rc = launch(lstm_persist_bwd_k<8, false, 16>);
-    else rc = launch(lstm_persist_bwd_k<4, false, 16>);
+    if (!bare) {
+        if (ngb == 1) rc = launch(lstm_persist_bwd_k<8, true, 2, false>);
+        else if (ngb == 9) rc = launch(lstm_persist_bwd_k<8, true, 16, false>);
+        else if (ngb == 8) rc = launch(lstm_persist_bwd_k<8, false, 16, false>);
+        else rc = launch(lstm_persist_bwd_k<4, false, 16, false>);
+    } else {
+        if (ngb == 1) rc = launch(lstm_persist_bwd_k<8, true, 2, true>);
+        else if (ngb == 9) rc = launch(lstm_persist_bwd_k<8, true, 16, true>);
+        else if (ngb == 8) rc = launch(lstm_persist_bwd_k<8, false, 16, true>);
+        else rc = launch(lstm_persist_bwd_k<4, false, 16, true>);
+    }
     if (rc != FT_OK) return rc;
     FT_CHECK_LAUNCH();
     return FT_OK;

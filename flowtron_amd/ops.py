@@ -539,7 +539,9 @@ def persist_usable(device):
 
 def lstm_persist_groups(B, H, reverse, mode, device=None):
     """transport / group code of the persistent recurrence kernels for this shape (0 = use the launch-per-step kernels).
-    FLOWTRON_LSTM_PERSIST: 0 = off, 1 (default) = 8 XCD-local groups, 8 | 4 = placement-independent fabric transport."""
+    FLOWTRON_LSTM_PERSIST: 0 = off, 1 (default) = 8 XCD-local groups, 9 = the same with sc1 polls, 8 | 4 | 2 = placement-independent
+    fabric transport; + 10 (11, 19, 18, 14, 12) = the same transport with BARE operand pairs (sentinel protocol, half the hand-off
+    bytes; csrc/lstm_persist.hip)."""
     ng = int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "1"))
     if not ng or reverse or not L.is16(mode) or not L.lib().ft_lstm_persist_supported(B, H):
         return 0
@@ -586,7 +588,7 @@ class LSTMSeqFn(torch.autograd.Function):
         dgx = torch.empty(T, B, 4 * H, device=dy.device, dtype=torch.float32)
         ng = lstm_persist_groups(B, H, ctx.reverse, ctx.mode, dy.device)
         if ng:
-            ng = ng if ng in (1, 9, 8, 4) else 8
+            ng = ng if ng in (1, 9, 8, 4, 11, 19, 18, 14) else (18 if ng > 10 else 8)      # (no 2-group backward kernel)
             st = _persist_watch(dy.device)
             work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=dy.device, dtype=torch.uint8)
             L.check(L.op16("ft_lstm_persist_bwd", ctx.mode)(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),

@@ -44,7 +44,7 @@ w0 = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=dev, dtype=torch.
 res["step"] = timeit(lambda: run_step(y0, g0, c0, w0))
 print("launch-per-step: min %.3f median %.3f us/step" % res["step"], flush=True)
 wp = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=dev, dtype=torch.uint8)
-for ng in (1, 9, 8, 4):
+for ng in (1, 11, 19, 9, 8, 18):
     y1, g1, c1 = bufs()
     y1.fill_(7.0)
     r = timeit(lambda: run_persist(ng, y1, g1, c1, wp))
@@ -58,10 +58,11 @@ for ng in (1, 9, 8, 4):
 prof = torch.zeros(1024 * 4 * 5, dtype=torch.int64, device=dev)
 L.lib().ft_lstm_persist_debug_prof(L.ptr(prof))
 yp, gp_, cp = bufs()
-run_persist(1, yp, gp_, cp, wp)
+run_persist(int(os.environ.get("PROF_NG", "11")), yp, gp_, cp, wp)
 torch.cuda.synchronize()
 L.lib().ft_lstm_persist_debug_prof(None)
 pr = prof.cpu().reshape(1024, 4, 5)[100:800].double()
+print("stamps of transport", os.environ.get("PROF_NG", "11"))
 for wv in range(4):
     top, swp, bar, pub, npass = (pr[:, wv, k] for k in range(5))
     step = (top[1:] - top[:-1]).mean() * 10
@@ -85,7 +86,7 @@ def run_persist_bwd(ng, dgx, work):
 
 res["bwd_step"] = timeit(lambda: run_step_bwd(d0, w0))
 print("backward launch-per-step: min %.3f median %.3f us/step" % res["bwd_step"], flush=True)
-for ng in (1, 9, 8):
+for ng in (1, 11, 19, 9, 8, 18):
     d1 = torch.full((T, B, 4 * H), 7.0, device=dev)
     r = timeit(lambda: run_persist_bwd(ng, d1, wp))
     st = int(status.item())
@@ -95,7 +96,7 @@ for ng in (1, 9, 8):
 # ---- phase stamps of one workgroup (backward, XCD-local transport)
 prof.zero_()
 L.lib().ft_lstm_persist_debug_prof(L.ptr(prof))
-run_persist_bwd(1, d1, wp)
+run_persist_bwd(int(os.environ.get("PROF_NG", "11")), d1, wp)
 torch.cuda.synchronize()
 L.lib().ft_lstm_persist_debug_prof(None)
 pr = prof.cpu().reshape(1024, 4, 5)[100:800].double()
