@@ -198,12 +198,13 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
     ws = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=dev, dtype=torch.uint8)
     st = ops.persist_status(torch.device("cuda", torch.cuda.current_device()))
     ng = int(os.environ.get("FLOWTRON_LSTM_PERSIST", "1"))
+    ng_bwd = 11 if (ng == 1 and os.environ.get("FLOWTRON_LSTM_PERSIST_BWD", "bare") != "tagged") else ng      # as ops.LSTMSeqFn.backward
     lib = L.lib()
     runs = {
         "lstm_persist_fwd_k": lambda: L.check(L.op16("ft_lstm_persist_fwd", mode)(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
                                                                         L.ptr(wp), L.ptr(st), T, B, H, ng, L.stream()), "persist fwd"),
         "lstm_persist_bwd_k": lambda: L.check(L.op16("ft_lstm_persist_bwd", mode)(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
-                                                                        L.ptr(wp), L.ptr(st), T, B, H, ng, L.stream()), "persist bwd"),
+                                                                        L.ptr(wp), L.ptr(st), T, B, H, ng_bwd, L.stream()), "persist bwd"),
         "lstm_fwd_step": lambda: L.check(lib.ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(ws),
                                                               T, B, H, 0, mode, L.stream()), "step fwd"),
         "lstm_bwd_step_bf16": lambda: L.check(lib.ft_lstm_seq_bwd(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
@@ -229,12 +230,12 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
     #   one same-XCD L2 hand-off per step (publish -> every consumer sees the tag): profiles/r02_handoff_hops.json;
     #   the MFMAs one wave must issue back to back per step (64 x v_mfma_f32_16x16x32: ~17 cycles each from one wave per SIMD,
     #   MI355X_MICROARCH.md cycle table, 2.4 GHz);
-    #   the granule bytes every CU pulls from its XCD's L2 per step (16 KB forward, 64 KB backward, x 256 CUs) at the measured
-    #   L2 peak of 34.5 TB/s.
+    #   the hand-off bytes every CU pulls from its XCD's L2 per step (forward: 16 KB of tagged granules; backward: 32 KB of bare
+    #   operand pairs, 64 KB with tagged granules; x 256 CUs) at the measured L2 peak of 34.5 TB/s.
     # The LDS reduce, the barrier, the cell update and the skew between the 32 CUs of a group are what `frac` leaves.
     mfma_us = 64 * 17 / 2.4e3
-    for name, per_row, repl, gran_kb in (("lstm_persist_bwd_k", 4 * (4 * H + H + H + 4 * H), "lstm_bwd_step_bf16", 64),
-                                         ("lstm_persist_fwd_k", 4 * (4 * H + H + 4 * H + H), "lstm_fwd_step", 16)):
+    for name, per_row, repl, gran_kb in (("lstm_persist_bwd_k", 4 * (4 * H + H + H + 4 * H), "lstm_bwd_step_bf16", 32 if ng_bwd > 10 else 64),
+                                         ("lstm_persist_fwd_k", 4 * (4 * H + H + 4 * H + H), "lstm_fwd_step", 8 if ng > 10 else 16)):
         nbytes = 2 * 4 * H * H + rows * per_row
         ach = nbytes / (us[name] * 1e-6) / 1e9
         per_step = us[name] / T
