@@ -38,6 +38,12 @@ class GemmImgArgs(C.Structure):
                 ("rowmap", _p), ("rows_dev", _p), ("compact", _i), ("k_shift", _i)]
 
 
+class CummAttnArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("text", "Q", "V", "w_key", "v", "w1", "b1", "w2", "b2", "in_lens", "ctx", "attn", "logprob",
+                                  "cumm_all", "kproj_all", "work")] + [("work_bytes", _sz)] + [
+        (n, _i) for n in ("T", "B", "L", "E", "A", "NF", "K1", "K2")] + [("temperature", _f), ("mode", _i)]
+
+
 class DecodeArgs(C.Structure):
     _fields_ = [(n, _p) for n in (
         "att_w_ih", "att_w_hh", "att_b_ih", "att_b_hh", "w_query", "v", "K", "V",
@@ -84,6 +90,9 @@ SIGNATURES = {
     "ft_lstm_bidir_supported": ([_i, _i], _i),
     "ft_lstm_bidir_seq_fwd": ([_p] * 6 + [_l] + [_p] * 6 + [_i, _i, _i, _p], _i),
     "ft_lstm_bidir_seq_bwd": ([_p, _l] + [_p] * 11 + [_i, _i, _i, _p], _i),
+    "ft_cumm_attn_workspace_bytes": ([_i] * 8, _sz),
+    "ft_cumm_attn_fwd": ([C.POINTER(CummAttnArgs), _p], _i),
+    "ft_cumm_attn_bwd": ([C.POINTER(CummAttnArgs)] + [_p] * 13, _i),
     "ft_attention_fwd": ([_p] * 8 + [_i, _i, _i, _i, _f, _p], _i),
     "ft_attention_bwd": ([_p] * 13 + [_i, _i, _i, _i, _f, _p], _i),
     "ft_affine_fwd": ([_p, _p, _p, _l, _i, _p], _i),

@@ -250,15 +250,23 @@ class AR_Step(nn.Module):
         return z, log_s, gates, attn, logprob
 
     def run_cumm_attn_sequence(self, h_att, text, in_lens32):
-        """flowtron.py:697-723: the location features of frame i depend on the attention of frames < i, so the reference
-        (and this mirror) walks the frames; every operation inside is a HIP kernel (im2col+GEMM convs, key modulation,
-        per-frame key projection, fused score/softmax kernel with T = 1, context GEMM)."""
-        T, B, _ = h_att.shape
-        Lk = text.shape[0]
+        """flowtron.py:697-723: the location features of frame i depend on the attention of frames < i, so the frames are walked
+        in order -- by the LIBRARY (ops.CummAttnSeqFn -> csrc/cumm_attn.hip: one C-ABI call per flow forward, one backward), not by
+        Python: location convolutions as im2col + GEMM, key modulation, the per-frame key projection, a fused score / softmax /
+        context / running-sum kernel.  FLOWTRON_CUMM_LOOP=python keeps the per-frame autograd walk (every operation a HIP kernel
+        too; ~250 us of host time per frame) as the yardstick the tests compare the fused path with."""
         mode = L.mfma_mode()
         att = self.attention_layer
         V = ops.linear(text, att.value.linear_layer.weight, None, mode=mode)
         Q = ops.linear(h_att, att.query.linear_layer.weight, None, mode=mode)
+        if os.environ.get("FLOWTRON_CUMM_LOOP", "fused") != "python":
+            c = self.attn_cond_layer
+            return ops.CummAttnSeqFn.apply(Q, V, text, att.key.linear_layer.weight, att.v.linear_layer.weight,
+                                           c.location_conv_hidden.conv.weight, c.location_conv_hidden.conv.bias,
+                                           c.location_conv_out.conv.weight, c.location_conv_out.conv.bias,
+                                           in_lens32, float(att.temperature), mode)
+        T, B, _ = h_att.shape
+        Lk = text.shape[0]
         full = torch.full((B,), Lk, dtype=torch.int32, device=text.device)
         cumm = text.new_zeros(Lk, B)
         prev = text.new_zeros(Lk, B)

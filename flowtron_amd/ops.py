@@ -776,6 +776,63 @@ class ContextFn(torch.autograd.Function):
         return dattn, dV, None
 
 
+class CummAttnSeqFn(torch.autograd.Function):
+    """run_cumm_attn_sequence (flowtron.py:697-723) as ONE pair of C-ABI calls per flow: the library walks the T dependent frames
+    (csrc/cumm_attn.hip: location convolutions, key modulation, per-frame key projection, scores + softmax + context + running
+    sum; 8 launches per frame forward, 22 backward, no Python / allocator / autograd work per frame).
+    Q [T,B,A] and V [L,B,A] are the projected queries / values, text [L,B,E] the encoder outputs the keys are made from."""
+
+    @staticmethod
+    def forward(ctx, Q, V, text, w_key, v, w1, b1, w2, b2, in_lens, temperature, mode):
+        Q, V, text, w_key, v, w1, b1, w2, b2 = (_c(t) for t in (Q, V, text, w_key, v.reshape(-1), w1, b1, w2, b2))
+        L.require_cuda(Q, V, text, w_key, v, w1, b1, w2, b2, in_lens)
+        T, B, A = Q.shape
+        Lk, _, E = text.shape
+        NF, _, K1 = w1.shape
+        K2 = w2.shape[2]
+        f = dict(device=Q.device, dtype=torch.float32)
+        out_ctx, attn, logprob = torch.empty(T, B, A, **f), torch.empty(B, T, Lk, **f), torch.empty(B, T, Lk, **f)
+        cumm_all, kproj_all = torch.empty(T, B, Lk, **f), torch.empty(T, Lk * B, A, **f)
+        work = torch.empty(L.lib().ft_cumm_attn_workspace_bytes(Lk, B, E, A, NF, K1, K2, 0) + 256, device=Q.device, dtype=torch.uint8)
+        args = CummAttnSeqFn._args(Q, V, text, w_key, v, w1, b1, w2, b2, in_lens, out_ctx, attn, logprob, cumm_all, kproj_all, work,
+                                   temperature, mode)
+        L.check(L.lib().ft_cumm_attn_fwd(C.byref(args), L.stream()), "ft_cumm_attn_fwd")
+        ctx.save_for_backward(Q, V, text, w_key, v, w1, b1, w2, b2, in_lens, attn, cumm_all, kproj_all)
+        ctx.temperature, ctx.mode = float(temperature), mode
+        return out_ctx, attn, logprob
+
+    @staticmethod
+    def _args(Q, V, text, w_key, v, w1, b1, w2, b2, in_lens, out_ctx, attn, logprob, cumm_all, kproj_all, work, temperature, mode):
+        T, B, A = Q.shape
+        Lk, _, E = text.shape
+        base = (work.data_ptr() + 255) // 256 * 256
+        return L.CummAttnArgs(L.ptr(text), L.ptr(Q), L.ptr(V), L.ptr(w_key), L.ptr(v), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2),
+                              L.ptr(in_lens), L.ptr(out_ctx), L.ptr(attn), L.ptr(logprob), L.ptr(cumm_all), L.ptr(kproj_all),
+                              base, work.numel() - (base - work.data_ptr()), T, B, Lk, E, A, w1.shape[0], w1.shape[2], w2.shape[2],
+                              float(temperature), int(mode))
+
+    @staticmethod
+    def backward(ctx, dctx, dattn, dlogprob):
+        Q, V, text, w_key, v, w1, b1, w2, b2, in_lens, attn, cumm_all, kproj_all = ctx.saved_tensors
+        T, B, A = Q.shape
+        Lk, _, E = text.shape
+        NF, _, K1 = w1.shape
+        K2 = w2.shape[2]
+        f = dict(device=Q.device, dtype=torch.float32)
+        dctx = _c(dctx) if dctx is not None else torch.zeros(T, B, A, **f)
+        dattn = _c(dattn) if dattn is not None else None
+        dlogprob = _c(dlogprob) if dlogprob is not None else None
+        dQ, dV, dtext = torch.empty_like(Q), torch.empty_like(V), torch.empty_like(text)
+        dwk, dv, dw1, db1, dw2, db2 = (torch.empty_like(t) for t in (w_key, v, w1, b1, w2, b2))
+        work = torch.empty(L.lib().ft_cumm_attn_workspace_bytes(Lk, B, E, A, NF, K1, K2, 1) + 256, device=Q.device, dtype=torch.uint8)
+        scratch = torch.empty(1, **f)                 # forward-only outputs are not written by the backward call
+        args = CummAttnSeqFn._args(Q, V, text, w_key, v, w1, b1, w2, b2, in_lens, scratch, attn, scratch, cumm_all, kproj_all, work,
+                                   ctx.temperature, ctx.mode)
+        L.check(L.lib().ft_cumm_attn_bwd(C.byref(args), L.ptr(dctx), L.ptr(dattn), L.ptr(dlogprob), L.ptr(dQ), L.ptr(dV), L.ptr(dtext),
+                                         L.ptr(dwk), L.ptr(dv), L.ptr(dw1), L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.stream()), "ft_cumm_attn_bwd")
+        return dQ, dV, dtext, dwk, dv.reshape(1, -1), dw1, db1, dw2, db2, None, None, None
+
+
 # --------------------------------------------------------------------------
 # affine coupling, reverse-by-length
 # --------------------------------------------------------------------------

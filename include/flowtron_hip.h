@@ -331,6 +331,32 @@ int ft_attn_ctc_fwd(const float* lp, const int32_t* in_lens, const int32_t* out_
 int ft_attn_ctc_bwd(const float* lp, const int32_t* in_lens, const int32_t* out_lens, float blank_logprob,
                     float* work, const float* gout_dev, float* dlp, int B, int T, int L, int beta_ready, void* stream);
 
+/* ---- cumulative ("location-sensitive") attention of a teacher-forced flow, one call per sequence ----------
+ * flowtron.py:697-723 (run_cumm_attn_sequence), :129-152 (AttentionConditioningLayer), :544-592 (Attention.forward).  Per frame
+ * i: cond = sigmoid(conv_K2(relu(conv_K1([cumm_i ; prev_i])))) over the text axis (2 -> NF -> E channels, zero padding at the ends),
+ * keys = (text . cond) w_key^T, scores v . tanh(Q_i + keys) / temperature, softmax over l < in_lens[b], logprob = log(attn + 1e-8),
+ * ctx_i = attn_i V, cumm_{i+1} = cumm_i + attn_i, prev_{i+1} = attn_i.  The LIBRARY walks the T dependent frames (8 launches per
+ * frame forward, 22 backward, enqueued back to back on `stream`; no host synchronisation).
+ * Layouts: text [L][B][E] (encoder outputs), Q [T][B][A] and V [L][B][A] (already projected), w_key [A][E], v [A], w1 [NF][2][K1],
+ * w2 [E][NF][K2]; outputs ctx [T][B][A], attn / logprob [B][T][L].  Saved for backward (caller-owned, filled by fwd):
+ * cumm_all [T][B][L] and kproj_all [T][L*B][A].  work: ft_cumm_attn_workspace_bytes() bytes, 256-byte aligned.
+ * bwd: dctx [T][B][A]; dattn / dlogprob [B][T][L] or NULL; every gradient output is overwritten (accumulated over the frames
+ * inside): dQ [T][B][A], dV [L][B][A], dtext [L][B][E], dw_key, dv, dw1, db1, dw2, db2. */
+typedef struct {
+    const float *text, *Q, *V, *w_key, *v, *w1, *b1, *w2, *b2;
+    const int32_t* in_lens;
+    float *ctx, *attn, *logprob, *cumm_all, *kproj_all;
+    void* work; size_t work_bytes;
+    int T, B, L, E, A, NF, K1, K2;
+    float temperature;
+    int mode;
+} ft_cumm_attn_args;
+size_t ft_cumm_attn_workspace_bytes(int L, int B, int E, int A, int NF, int K1, int K2, int backward);
+int ft_cumm_attn_fwd(const ft_cumm_attn_args* a, void* stream);
+int ft_cumm_attn_bwd(const ft_cumm_attn_args* a, const float* dctx, const float* dattn, const float* dlogprob,
+                     float* dQ, float* dV, float* dtext, float* dw_key, float* dv, float* dw1, float* db1, float* dw2, float* db2,
+                     void* stream);
+
 /* ---- beta-binomial attention prior (data.py:31-41, 111-141) --------
  * prior[b,t,k] = BetaBinom.pmf(k; n = in_lens[b]-1, a = scaling*(t+1), b = scaling*(out_lens[b]-t)) for
  * t < out_lens[b], k < in_lens[b]; 0 in the padding.  [B,T,L] fp32, float64 lgamma inside. */

@@ -294,6 +294,49 @@ def test_cumulative_attention_full_width_vs_reference_golden(capsys):
         assert mad(torch.cat(a)[:, 0], ra) < 2e-5
 
 
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 3e-2)])
+def test_cumulative_attention_library_walk_equals_python_walk(mode, tol):
+    """csrc/cumm_attn.hip (the library walks the frames: ops.CummAttnSeqFn) against the per-frame autograd walk it replaces
+    (FLOWTRON_CUMM_LOOP=python: the same im2col / GEMM / activation kernels, the unfused score + context kernels), full width,
+    ragged B = 3, T = 37: forward outputs, losses and every parameter gradient.  fp32: re-association only; bf16: the two walks
+    round different intermediates (the python walk builds images of the key GEMM's operands, the library hands the same fp32
+    operands to ft_gemm), so the comparison is at operand-rounding level."""
+    import flowtron
+    from oracle import synth
+    cfg = dict(synth.DEFAULT_MODEL_CONFIG, use_cumm_attention=True)
+    res = {}
+    try:
+        for walk in ("python", "fused"):
+            os.environ["FLOWTRON_CUMM_LOOP"] = walk
+            m, _ = build(cfg, 13, mode)
+            b = cuda_batch(synth.make_batch(cfg, [37, 30, 11], [14, 9, 5], seed=13, with_prior=True))
+            out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+            crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)
+            nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+            (nll + gl + 0.01 * ctc).sum().backward()
+            torch.cuda.synchronize()
+            res[walk] = (out[0].detach().cpu(), [a.detach().cpu() for a in out[3]], (nll.item(), gl.item(), ctc.item()),
+                         {k: p.grad.detach().cpu() for k, p in m.named_parameters()})
+    finally:
+        os.environ.pop("FLOWTRON_CUMM_LOOP", None)
+        os.environ["FLOWTRON_MFMA"] = "f32"
+    zp, ap, lp, gp = res["python"]
+    zf, af, lf, gf = res["fused"]
+    assert mad(zf, zp) < (1e-5 if mode == "f32" else 2e-2)
+    for a, b_ in zip(af, ap):
+        assert mad(a, b_) < (1e-6 if mode == "f32" else 5e-3)
+    for x, y in zip(lf, lp):
+        assert abs(x - y) < tol * max(1.0, abs(y))
+    worst = ("", 0.0)
+    for k, g in gp.items():
+        if k.startswith("encoder.convolutions") and k.endswith("conv.bias"):
+            continue
+        r = (gf[k] - g).norm().item() / max(g.norm().item(), 1e-5 * g.numel() ** 0.5)
+        if r > worst[1]:
+            worst = (k, r)
+    assert worst[1] < (2e-4 if mode == "f32" else 0.1), worst
+
+
 def test_full_config_invertibility_and_padding_invariance():
     """2-flow default config (config.json): forward(infer(z)) == z (the reference's own, broken,
     test_invertibility bound is 1e-5 'or less', flowtron.py:932-954), and a sample's valid outputs do not
