@@ -11,7 +11,7 @@
 // GEMM (4.1 GFLOP at B 32, L 157: the whole decoder of the default model costs less per frame), so the loop itself is what
 // has to stay cheap.  The drop-in module used to walk the frames in Python (ten autograd nodes, ten allocations and ~250 us of
 // host time per frame: 1.78 s per training step at BASELINE configs[1]'s shape); here the library walks them: every buffer is
-// carved once from a caller-provided workspace, a frame is 8 (forward) / 22 (backward) kernel launches enqueued back to back
+// carved once from a caller-provided workspace, a frame is 9 (forward) / 23 (backward) kernel launches enqueued back to back
 // on the caller's stream -- the existing im2col / GEMM / activation kernels plus the fused score kernels below -- and
 // backward re-derives cond_i from the saved cumm_i instead of keeping T x [L,B,E] tensors.
 //
@@ -25,7 +25,7 @@ constexpr float C2 = 2.8853900817779268f;      // 2 log2(e): tanh(x) = 1 - 2 / (
 __device__ __forceinline__ float rsig(float x) { return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x) + 1.0f); }
 
 struct Buf {            // carved from the workspace (floats)
-    float *s2, *col1, *h1, *col2, *cond, *km;                                   // forward chain of one frame
+    float *s2, *col1, *h1, *col2, *cond, *km, *esc;                             // forward chain of one frame (esc: scores / dp [B][L])
     float *dkp, *dkm, *dcond, *dcol2, *dh1, *dcol1, *ds2, *g_prev, *g_cumm;      // backward only
     int* full_lens;                                                             // [B] = L (Conv1d pads at the ends only)
     void* gemm_work; size_t gemm_work_bytes;
@@ -39,7 +39,7 @@ Buf carve(void* base, int L, int B, int E, int A, int NF, int K1, int K2, bool b
     size_t off = 0;
     const size_t R = (size_t)L * B;
     auto take = [&](size_t n) { float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr; off += up64(n * 4); return p; };
-    b.s2 = take(R * 2); b.col1 = take(R * 2 * K1); b.h1 = take(R * NF); b.col2 = take(R * NF * K2); b.cond = take(R * E); b.km = take(R * E);
+    b.s2 = take(R * 2); b.col1 = take(R * 2 * K1); b.h1 = take(R * NF); b.col2 = take(R * NF * K2); b.cond = take(R * E); b.km = take(R * E); b.esc = take(R);
     if (bwd) {
         b.dkp = take(R * A); b.dkm = take(R * E); b.dcond = take(R * E); b.dcol2 = take(R * NF * K2); b.dh1 = take(R * NF);
         b.dcol1 = take(R * 2 * K1); b.ds2 = take(R * 2); b.g_prev = take((size_t)B * L); b.g_cumm = take((size_t)B * L);
@@ -78,129 +78,170 @@ __global__ void unstack_acc_k(const float* __restrict__ ds2, float* __restrict__
 __global__ void fma_acc_k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = fmaf(a[i], b[i], out[i]);
 }
-// out[n] += sum_r x[r][n]  (one block per 64 columns, 4 row lanes)
+// out[n] += sum_r x[r][n]: grid (ceil(N / 64), ceil(rows / 256)), a block sums a 256-row slab of 64 columns and adds it with one
+// fp32 atomic per column (the output accumulates over the frames anyway)
 __global__ __launch_bounds__(256) void colsum_acc_k(const float* __restrict__ x, long rows, int N, float* __restrict__ out) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), ry = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.y * 256, r1 = r0 + 256 < rows ? r0 + 256 : rows;
     float s = 0.f;
-    if (c < N)
-        for (long r = ry; r < rows; r += 4) s += x[r * N + c];
+    if (c < N) {
+#pragma unroll 8
+        for (long r = r0 + ry; r < r1; r += 4) s += x[r * N + c];
+    }
     red[ry][threadIdx.x & 63] = s;
     __syncthreads();
-    if (ry == 0 && c < N) out[c] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (ry == 0 && c < N) atomicAdd(out + c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
-// ---- fused score / softmax / context / running sum of ONE frame: one workgroup per utterance ----------------------------
-// q = Q[i][b][:], kp = K_i [L][B][A], V [L][B][A]; writes attn[b][i][:], logprob[b][i][:], ctx[i][b][:] and, when cumm_next is
-// given, cumm_next[b][:] = cumm[b][:] + attn
-__global__ __launch_bounds__(256) void cumm_score_fwd_k(const float* __restrict__ Q, const float* __restrict__ kp, const float* __restrict__ v,
-                                                        const float* __restrict__ V, const int* __restrict__ in_lens,
-                                                        const float* __restrict__ cumm, float* __restrict__ cumm_next,
-                                                        float* __restrict__ attn, float* __restrict__ logprob, float* __restrict__ ctx,
-                                                        int i, int T, int B, int L, int A, float inv_temp) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* qs = sm;            // [A]   C2 * q
-    float* vs = qs + A;        // [A]
-    float* es = vs + A;        // [L]
-    __shared__ float red[8];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// ---- scores / softmax / context / running sum of ONE frame, spread over the chip ------------------------------------------
+// A frame has only B x L scores of A terms each (3.2 M tanh at B 32, L 157): small, but on the critical path 862 times per
+// flow, so it is cut for PARALLELISM, not for launch count: scores in (b, 16-key) workgroups, softmax + context in
+// (b, 64-channel) workgroups that each redo the 157-element softmax of their utterance (cheaper than another hand-off).
+
+// e[b][l] = v . tanh(Q[i][b] + K_i[l][b]) / temperature, l < in_len: grid (ceil(L / 16), B), a wave takes 4 keys
+__global__ __launch_bounds__(256) void cumm_scores_k(const float* __restrict__ Q, const float* __restrict__ kp, const float* __restrict__ v,
+                                                     const int* __restrict__ in_lens, float* __restrict__ e,
+                                                     int i, int B, int L, int A, float inv_temp) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int len = min(in_lens[b], L);
-    for (int a = tid; a < A; a += 256) { qs[a] = C2 * Q[((size_t)i * B + b) * A + a]; vs[a] = v[a]; }
-    __syncthreads();
-    for (int l = wave; l < len; l += 4) {
+    const float* q = Q + ((size_t)i * B + b) * A;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int l = blockIdx.x * 16 + wave * 4 + j;
+        if (l >= len) break;                                    // wave-uniform
         const float* k = kp + ((size_t)l * B + b) * A;
         float acc = 0.f, vsum = 0.f;
-        for (int a = lane; a < A; a += 64) { acc = fmaf(vs[a], rsig(qs[a] + C2 * k[a]), acc); vsum += vs[a]; }
+        for (int a = lane; a < A; a += 64) { const float va = v[a]; acc = fmaf(va, rsig(C2 * (q[a] + k[a])), acc); vsum += va; }
         acc = wave_sum(acc); vsum = wave_sum(vsum);
-        if (lane == 0) es[l] = (vsum - 2.f * acc) * inv_temp;
+        if (lane == 0) e[(size_t)b * L + l] = (vsum - 2.f * acc) * inv_temp;
     }
-    __syncthreads();
+}
+
+// softmax of e[b][:] into LDS (every workgroup of utterance b does it for itself): ps[l] = p_l for l < len; returns nothing
+__device__ __forceinline__ void softmax_row(const float* __restrict__ e, float* ps, float* red, int len, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
     float m = -INFINITY;
-    for (int l = tid; l < len; l += 256) m = fmaxf(m, es[l]);
+    for (int l = tid; l < len; l += 256) { const float x = e[l]; ps[l] = x; m = fmaxf(m, x); }
     m = wave_max(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float s = 0.f;
-    for (int l = tid; l < len; l += 256) { const float e = expf(es[l] - m); es[l] = e; s += e; }
+    for (int l = tid; l < len; l += 256) { const float x = expf(ps[l] - m); ps[l] = x; s += x; }
     s = wave_sum(s);
     if (lane == 0) red[4 + wave] = s;
     __syncthreads();
     s = (red[4] + red[5]) + (red[6] + red[7]);
-    const size_t row = ((size_t)b * T + i) * L;
-    for (int l = tid; l < L; l += 256) {
-        const float p = l < len ? es[l] / s : 0.f;
-        if (l < len) es[l] = p;
-        attn[row + l] = p;
-        logprob[row + l] = logf(p + 1e-8f);
-        if (cumm_next) cumm_next[(size_t)b * L + l] = cumm[(size_t)b * L + l] + p;
-    }
+    for (int l = tid; l < len; l += 256) ps[l] = ps[l] / s;
     __syncthreads();
-    for (int a = tid; a < A; a += 256) {
-        float c = 0.f;
-        for (int l = 0; l < len; ++l) c = fmaf(es[l], V[((size_t)l * B + b) * A + a], c);
-        ctx[((size_t)i * B + b) * A + a] = c;
+}
+
+// grid (ceil(A / 64), B): ctx[i][b][a0 .. a0+63] = sum_l p_l V[l][b][a]; workgroup x == 0 also writes attn, logprob, cumm_next
+__global__ __launch_bounds__(256) void cumm_ctx_k(const float* __restrict__ e, const float* __restrict__ V, const int* __restrict__ in_lens,
+                                                  const float* __restrict__ cumm, float* __restrict__ cumm_next,
+                                                  float* __restrict__ attn, float* __restrict__ logprob, float* __restrict__ ctx,
+                                                  int i, int T, int B, int L, int A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* ps = sm;                    // [L]
+    float* part = ps + ((L + 3) & ~3); // [4][64]
+    __shared__ float red[8];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int len = min(in_lens[b], L);
+    softmax_row(e + (size_t)b * L, ps, red, len, tid);
+    if (blockIdx.x == 0) {
+        const size_t row = ((size_t)b * T + i) * L;
+        for (int l = tid; l < L; l += 256) {
+            const float p = l < len ? ps[l] : 0.f;
+            attn[row + l] = p;
+            logprob[row + l] = logf(p + 1e-8f);
+            if (cumm_next) cumm_next[(size_t)b * L + l] = cumm[(size_t)b * L + l] + p;
+        }
+    }
+    const int a = blockIdx.x * 64 + lane;
+    float c = 0.f;
+    if (a < A) {
+#pragma unroll 8
+        for (int l = wave; l < len; l += 4) c = fmaf(ps[l], V[((size_t)l * B + b) * A + a], c);
+    }
+    part[wave * 64 + lane] = c;
+    __syncthreads();
+    if (wave == 0 && a < A) ctx[((size_t)i * B + b) * A + a] = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+}
+
+// backward, part 1: dp[b][l] = external + carried + dctx[i][b] . V[l][b]   (grid (ceil(L / 16), B), a wave takes 4 keys)
+__global__ __launch_bounds__(256) void cumm_dp_k(const float* __restrict__ V, const int* __restrict__ in_lens, const float* __restrict__ attn,
+                                                 const float* __restrict__ dctx, const float* __restrict__ dattn,
+                                                 const float* __restrict__ dlogprob, const float* __restrict__ g_prev,
+                                                 const float* __restrict__ g_cumm, float* __restrict__ dp,
+                                                 int i, int T, int B, int L, int A) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int len = min(in_lens[b], L);
+    const float* dc = dctx + ((size_t)i * B + b) * A;
+    const size_t row = ((size_t)b * T + i) * L;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int l = blockIdx.x * 16 + wave * 4 + j;
+        if (l >= len) break;
+        const float* vl = V + ((size_t)l * B + b) * A;
+        float acc = 0.f;
+        for (int a = lane; a < A; a += 64) acc = fmaf(dc[a], vl[a], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            float d = acc + g_prev[(size_t)b * L + l] + g_cumm[(size_t)b * L + l];
+            if (dattn) d += dattn[row + l];
+            if (dlogprob) d += dlogprob[row + l] / (attn[row + l] + 1e-8f);
+            dp[(size_t)b * L + l] = d;
+        }
     }
 }
 
-// backward of the same frame: dctx [T][B][A], dattn / dlogprob [B][T][L] (nullable), g_prev / g_cumm [B][L] (gradients that reach
-// attn_i through prev_{i+1} and through every later cumm); writes dQ[i][b][:], dkp [L][B][A] (0 beyond in_len), accumulates dV, dv
+// backward, part 2: grid (ceil(A / 64), B).  s_l = p_l (dp_l - sum_m p_m dp_m) / temperature (redone per workgroup), then for the
+// workgroup's 64 channels: dK_i[l][b][a] = s_l v_a (1 - tanh^2), dQ[i][b][a] = sum_l of it, dv_a += sum_l s_l tanh,
+// dV[l][b][a] += p_l dctx[i][b][a]; rows l >= in_len of dK_i are zeroed
 __global__ __launch_bounds__(256) void cumm_score_bwd_k(const float* __restrict__ Q, const float* __restrict__ kp, const float* __restrict__ v,
-                                                        const float* __restrict__ V, const int* __restrict__ in_lens,
-                                                        const float* __restrict__ attn, const float* __restrict__ dctx,
-                                                        const float* __restrict__ dattn, const float* __restrict__ dlogprob,
-                                                        const float* __restrict__ g_prev, const float* __restrict__ g_cumm,
+                                                        const int* __restrict__ in_lens, const float* __restrict__ attn,
+                                                        const float* __restrict__ dctx, const float* __restrict__ dp,
                                                         float* __restrict__ dQ, float* __restrict__ dkp, float* __restrict__ dV,
                                                         float* __restrict__ dv, int i, int T, int B, int L, int A, float inv_temp) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* qs = sm;            // [A]  C2 * q
-    float* dcs = qs + A;       // [A]  dctx
-    float* ps = dcs + A;       // [L]  attention
-    float* ss = ps + L;        // [L]  dp, then de * inv_temp
+    float* ps = sm;                        // [L] attention
+    float* ss = ps + ((L + 3) & ~3);       // [L] s_l
+    float* part = ss + ((L + 3) & ~3);     // [2][4][64]
     __shared__ float red[4];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int len = min(in_lens[b], L);
     const size_t row = ((size_t)b * T + i) * L;
-    for (int a = tid; a < A; a += 256) { qs[a] = C2 * Q[((size_t)i * B + b) * A + a]; dcs[a] = dctx[((size_t)i * B + b) * A + a]; }
-    for (int l = tid; l < len; l += 256) ps[l] = attn[row + l];
-    __syncthreads();
-    for (int l = wave; l < len; l += 4) {                       // dp_l = external + carried + dctx . V_l
-        const float* vl = V + ((size_t)l * B + b) * A;
-        float acc = 0.f;
-        for (int a = lane; a < A; a += 64) acc = fmaf(dcs[a], vl[a], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            float dp = acc + g_prev[(size_t)b * L + l] + g_cumm[(size_t)b * L + l];
-            if (dattn) dp += dattn[row + l];
-            if (dlogprob) dp += dlogprob[row + l] / (ps[l] + 1e-8f);
-            ss[l] = dp;
-        }
-    }
-    __syncthreads();
     float s = 0.f;
-    for (int l = tid; l < len; l += 256) s = fmaf(ps[l], ss[l], s);
+    for (int l = tid; l < len; l += 256) { const float p = attn[row + l], d = dp[(size_t)b * L + l]; ps[l] = p; ss[l] = d; s = fmaf(p, d, s); }
     s = wave_sum(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
     s = (red[0] + red[1]) + (red[2] + red[3]);
-    __syncthreads();
     for (int l = tid; l < len; l += 256) ss[l] = ps[l] * (ss[l] - s) * inv_temp;
     __syncthreads();
-    for (int a = tid; a < A; a += 256) {
-        const float va = v[a], q = qs[a], dc = dcs[a];
-        float dq = 0.f, dva = 0.f;
-        for (int l = 0; l < len; ++l) {
+    const int a = blockIdx.x * 64 + lane;
+    float dq = 0.f, dva = 0.f;
+    if (a < A) {
+        const float va = v[a], q = Q[((size_t)i * B + b) * A + a], dc = dctx[((size_t)i * B + b) * A + a];
+#pragma unroll 4
+        for (int l = wave; l < len; l += 4) {
             const size_t o = ((size_t)l * B + b) * A + a;
-            const float r = rsig(q + C2 * kp[o]);
+            const float r = rsig(C2 * (q + kp[o]));
             const float g = ss[l] * va * (4.f * fmaf(-r, r, r));           // 1 - tanh^2 = 4 r (1 - r)
             dq += g;
             dkp[o] = g;
             dva = fmaf(ss[l], fmaf(-2.f, r, 1.f), dva);
             dV[o] = fmaf(ps[l], dc, dV[o]);
         }
-        for (int l = len; l < L; ++l) dkp[((size_t)l * B + b) * A + a] = 0.f;
-        dQ[((size_t)i * B + b) * A + a] = dq;
-        atomicAdd(dv + a, dva);
+        for (int l = len + wave; l < L; l += 4) dkp[((size_t)l * B + b) * A + a] = 0.f;
+    }
+    part[wave * 64 + lane] = dq;
+    part[256 + wave * 64 + lane] = dva;
+    __syncthreads();
+    if (wave == 0 && a < A) {
+        dQ[((size_t)i * B + b) * A + a] = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+        atomicAdd(dv + a, (part[256 + lane] + part[320 + lane]) + (part[384 + lane] + part[448 + lane]));
     }
 }
 
@@ -233,7 +274,7 @@ int check(const ft_cumm_attn_args* a) {
     FT_CHECK_ARG(a->ctx && a->attn && a->logprob && a->cumm_all && a->kproj_all && a->work);
     FT_CHECK_ARG(a->T >= 1 && a->B >= 1 && a->L >= 1 && a->E >= 1 && a->A >= 1 && a->NF >= 1 && (a->K1 & 1) && (a->K2 & 1) && a->temperature > 0.f);
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(a->work) % 256 == 0);
-    FT_CHECK_ARG((size_t)(2 * a->A + 2 * a->L) * 4 <= 60 * 1024);
+    FT_CHECK_ARG((size_t)(2 * a->L + 1024) * 4 <= 60 * 1024 && a->B <= 65535);
     return FT_OK;
 }
 
@@ -251,15 +292,16 @@ extern "C" int ft_cumm_attn_fwd(const ft_cumm_attn_args* a, void* stream) {
     FT_CHECK_ARG(a->work_bytes >= b.total);
     hipLaunchKernelGGL(fill_int_k, dim3(cdiv(B, 256)), dim3(256), 0, st, b.full_lens, B, L);
     FT_CHECK_HIP(hipMemsetAsync(a->cumm_all, 0, sizeof(float) * (size_t)B * L, st));          // cumm_0 = 0
-    const size_t lds = sizeof(float) * ((size_t)2 * A + L);
+    const size_t lds = sizeof(float) * ((size_t)((L + 3) & ~3) + 256);
     for (int i = 0; i < T; ++i) {
         float* cumm_i = a->cumm_all + (size_t)i * B * L;
         const float* prev_i = i > 0 ? a->attn + (size_t)(i - 1) * L : nullptr;                  // attn[b][i-1][:], row stride T*L
         CK(cond_chain(a, b, cumm_i, prev_i, st));
         float* kp = a->kproj_all + (size_t)i * R * A;
         CK(gemm(b.km, a->w_key, kp, nullptr, R, A, E, E, 1, 1, E, A, 0.f, FT_ACT_NONE, a->mode, 0, b, st));
-        hipLaunchKernelGGL(cumm_score_fwd_k, dim3(B), dim3(256), lds, st, a->Q, kp, a->v, a->V, a->in_lens, cumm_i,
-                           i + 1 < T ? cumm_i + (size_t)B * L : nullptr, a->attn, a->logprob, a->ctx, i, T, B, L, A, 1.0f / a->temperature);
+        hipLaunchKernelGGL(cumm_scores_k, dim3(cdiv(L, 16), B), dim3(256), 0, st, a->Q, kp, a->v, a->in_lens, b.esc, i, B, L, A, 1.0f / a->temperature);
+        hipLaunchKernelGGL(cumm_ctx_k, dim3(cdiv(A, 64), B), dim3(256), lds, st, b.esc, a->V, a->in_lens, cumm_i,
+                           i + 1 < T ? cumm_i + (size_t)B * L : nullptr, a->attn, a->logprob, a->ctx, i, T, B, L, A);
     }
     FT_CHECK_LAUNCH();
     return FT_OK;
@@ -286,15 +328,17 @@ extern "C" int ft_cumm_attn_bwd(const ft_cumm_attn_args* a, const float* dctx, c
     FT_CHECK_HIP(hipMemsetAsync(db2, 0, sizeof(float) * (size_t)E, st));
     FT_CHECK_HIP(hipMemsetAsync(b.g_prev, 0, sizeof(float) * (size_t)B * L, st));
     FT_CHECK_HIP(hipMemsetAsync(b.g_cumm, 0, sizeof(float) * (size_t)B * L, st));
-    const size_t lds = sizeof(float) * ((size_t)2 * A + 2 * L);
+    const size_t lds = sizeof(float) * ((size_t)2 * ((L + 3) & ~3) + 512);
     const float inv_temp = 1.0f / a->temperature;
     for (int i = T - 1; i >= 0; --i) {
         const float* cumm_i = a->cumm_all + (size_t)i * B * L;
         const float* prev_i = i > 0 ? a->attn + (size_t)(i - 1) * L : nullptr;
         const float* kp = a->kproj_all + (size_t)i * R * A;
         // 1. scores / softmax / context backward: dQ_i, dK_i, dV, dv
-        hipLaunchKernelGGL(cumm_score_bwd_k, dim3(B), dim3(256), lds, st, a->Q, kp, a->v, a->V, a->in_lens, a->attn, dctx, dattn, dlogprob,
-                           b.g_prev, b.g_cumm, dQ, b.dkp, dV, dv, i, T, B, L, A, inv_temp);
+        hipLaunchKernelGGL(cumm_dp_k, dim3(cdiv(L, 16), B), dim3(256), 0, st, a->V, a->in_lens, a->attn, dctx, dattn, dlogprob,
+                           b.g_prev, b.g_cumm, b.esc, i, T, B, L, A);
+        hipLaunchKernelGGL(cumm_score_bwd_k, dim3(cdiv(A, 64), B), dim3(256), lds, st, a->Q, kp, a->v, a->in_lens, a->attn, dctx, b.esc,
+                           dQ, b.dkp, dV, dv, i, T, B, L, A, inv_temp);
         // 2. the frame's location features again (cond_i, km_i, h1, col1, col2)
         CK(cond_chain(a, b, cumm_i, prev_i, st));
         // 3. key projection backward: dW_key += dK^T km ; dkm = dK W_key
@@ -306,14 +350,14 @@ extern "C" int ft_cumm_attn_bwd(const ft_cumm_attn_args* a, const float* dctx, c
         CK(ft_act_bwd(b.cond, b.dcond, b.dkm, (int64_t)R * E, FT_ACT_SIGMOID, st));                     // dpre2 -> b.dkm
         // 5. second convolution backward
         CK(gemm(b.dkm, b.col2, dw2, nullptr, E, C2n, R, 1, E, C2n, 1, C2n, 1.f, FT_ACT_NONE, a->mode, FT_GEMM_SPLITK, b, st));
-        hipLaunchKernelGGL(colsum_acc_k, dim3(cdiv(E, 64)), dim3(256), 0, st, b.dkm, (long)R, E, db2);
+        hipLaunchKernelGGL(colsum_acc_k, dim3(cdiv(E, 64), cdiv(R, 256)), dim3(256), 0, st, b.dkm, (long)R, E, db2);
         CK(gemm(b.dkm, a->w2, b.dcol2, nullptr, R, C2n, E, E, 1, C2n, 1, C2n, 0.f, FT_ACT_NONE, a->mode, 0, b, st));
         CK(ft_col2im(b.dcol2, b.dh1, b.full_lens, L, B, NF, a->K2, st));
         float* dpre1 = b.dcond;                                                                          // (free again: [R, NF] fits)
         CK(ft_act_bwd(b.h1, b.dh1, dpre1, (int64_t)R * NF, FT_ACT_RELU, st));
         // 6. first convolution backward
         CK(gemm(dpre1, b.col1, dw1, nullptr, NF, C1, R, 1, NF, C1, 1, C1, 1.f, FT_ACT_NONE, a->mode, FT_GEMM_SPLITK, b, st));
-        hipLaunchKernelGGL(colsum_acc_k, dim3(cdiv(NF, 64)), dim3(256), 0, st, dpre1, (long)R, NF, db1);
+        hipLaunchKernelGGL(colsum_acc_k, dim3(cdiv(NF, 64), cdiv(R, 256)), dim3(256), 0, st, dpre1, (long)R, NF, db1);
         CK(gemm(dpre1, a->w1, b.dcol1, nullptr, R, C1, NF, NF, 1, C1, 1, C1, 0.f, FT_ACT_NONE, a->mode, 0, b, st));
         CK(ft_col2im(b.dcol1, b.ds2, b.full_lens, L, B, 2, a->K1, st));
         // 7. gradients of this frame's (cumm, prev) inputs: prev feeds attn_{i-1} only, cumm feeds every earlier attention

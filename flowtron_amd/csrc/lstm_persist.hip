@@ -722,14 +722,16 @@ extern "C" int ft_lstm_persist_debug_prof(void* dev_buf) { g_persist_prof = rein
 
 extern "C" int ft_lstm_persist_supported(int B, int H) {
     if (H != PH || B < 1 || B > 32) return 0;
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        cus = prop.multiProcessorCount;
+    // CU count of the CURRENT device, cached per device ordinal (a process may drive several GPUs)
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+    int n = dev < 64 ? __atomic_load_n(&cus[dev], __ATOMIC_RELAXED) : 0;
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (dev < 64) __atomic_store_n(&cus[dev], n, __ATOMIC_RELAXED);
     }
-    return cus >= NCU ? 1 : 0;
+    return n >= NCU ? 1 : 0;
 }
 
 extern "C" size_t ft_lstm_persist_workspace_bytes(int B, int H) {

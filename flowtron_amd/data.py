@@ -32,8 +32,10 @@ class DeferredMel:
     (train.py:286) -- the one call the reference makes on it.  Result: [B, n_mel, T_max] fp32 on the device, zero beyond
     each utterance's frames, exactly what DataCollate's zero padding produces (data.py:215-229)."""
 
-    def __init__(self, audio, n_samples, stft_args):
-        self.audio, self.n_samples, self.stft_args = audio, n_samples, dict(stft_args)
+    def __init__(self, audio, n_samples, stft_args, max_t=None):
+        # max_t: the padded frame count DataCollate uses for every slot of the batch (rounded up to a multiple of
+        # n_frames_per_step, data.py:213-216); None = the longest utterance's own frame count
+        self.audio, self.n_samples, self.stft_args, self.max_t = audio, n_samples, dict(stft_args), max_t
 
     def __len__(self):
         return self.audio.shape[0]
@@ -52,7 +54,8 @@ class DeferredMel:
         audio = _pinned_stage(self.audio).to(dev, non_blocking=False)
         hop = stft.stft_fn.hop_length
         frames = [int(n) // hop + 1 for n in self.n_samples.tolist()]
-        mel = torch.zeros(len(frames), stft.n_mel_channels, max(frames), device=dev, dtype=torch.float32)
+        max_t = max(frames) if self.max_t is None else max(int(self.max_t), max(frames))
+        mel = torch.zeros(len(frames), stft.n_mel_channels, max_t, device=dev, dtype=torch.float32)
         for i, (n, t) in enumerate(zip(self.n_samples.tolist(), frames)):       # reflect padding depends on each utterance's end
             mel[i, :, :t] = stft.mel_spectrogram(audio[i:i + 1, :int(n)])[0]
         return mel
@@ -280,7 +283,7 @@ class DataCollate:
             gate_padded[i, it.n_frames - 1:] = 1
             output_lengths[i] = it.n_frames
             speaker_ids[i] = int(spk)
-        mel = DeferredMel(audio, n_samples, batch[0][0].stft_args)
+        mel = DeferredMel(audio, n_samples, batch[0][0].stft_args, max_t=max_t)
         scaling, thr = batch[0][0].prior_args or (self.betab_scaling_factor, self.attn_prior_threshold)
         prior = DeferredPrior(input_lengths, output_lengths, max_t, max_in, scaling, thr) if self.use_attn_prior else None
         return (mel, speaker_ids, text_padded, input_lengths, output_lengths, gate_padded, prior)
