@@ -143,6 +143,7 @@ struct BfP {
     // `rowmap[m]` receives compact row m (negative / beyond *rows_dev: dropped); 2 = the reduction runs over compact rows --
     // k-steps at or beyond *rows_dev - k_shift are not visited (the images are zero there up to the next 32-row step)
     const int* rowmap; const int* rows_dev; int compact, k_shift;
+    int chunk_w;                            // > 0: L2-aware tile order with column chunks of this many tiles (no split-K)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -247,19 +248,42 @@ __global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
             // order below is formed over THOSE (else the XCDs that own the tail of the capacity would sit idle)
             rows_lim = R < p.M ? R : p.M;
             gy = (rows_lim + RTA - 1) / RTA;
-            if (tile >= p.gx * gy) return;
+            if (gy == 0) return;
         } else {
             const int nk_eff = (R - p.k_shift + 31) >> 5;
             t1 = t1 < nk_eff ? t1 : nk_eff;
             if (SPLIT && t0 >= t1) return;                          // this k-slice lies entirely in the unused tail
         }
     }
-    {   // XCD-aware order (workgroup L runs on XCD L % 8): every XCD gets a contiguous run of tiles, x fastest
+    int mt, nt;
+    if (p.chunk_w > 0 && gy >= 16) {
+        // L2-aware order (workgroup L runs on XCD L % 8, in launch order).  An XCD owns a contiguous range of tile ROWS and walks it
+        // in column chunks of chunk_w tiles, row-major inside a chunk: the B panels of the chunk (<= ~2 MB, chosen by the host
+        // from K) stay in that XCD's 4 MiB L2 while every A panel of the range is streamed past them once, and the chunk_w
+        // workgroups that share an A panel run back to back.  The plain order below keeps 32 B panels (the whole 13.6 MB weight
+        // image of an LSTM input projection) live per XCD: every tile then re-reads its B panel from beyond the L2.
+        const int xcd = tile & 7, idx = tile >> 3;
+        const int qm = gy >> 3, rm = gy & 7;
+        const int mh = qm + (xcd < rm ? 1 : 0);
+        const int m_lo = xcd * qm + (xcd < rm ? xcd : rm);
+        if (idx >= mh * p.gx) return;
+        const int per_chunk = mh * p.chunk_w;
+        const int ch = idx / per_chunk, within = idx - ch * per_chunk;
+        const int left = p.gx - ch * p.chunk_w;
+        const int cw = left < p.chunk_w ? left : p.chunk_w;
+        const int mi = within / cw;
+        mt = m_lo + mi;
+        nt = ch * p.chunk_w + (within - mi * cw);
+    } else {
+        // XCD-aware order: every XCD gets a contiguous run of tiles, x fastest
         const int total = p.gx * gy, q = total >> 3, r = total & 7;
         const int xcd = tile & 7, idx = tile >> 3;
+        if (tile >= total) return;
         tile = xcd * q + (xcd < r ? xcd : r) + idx;
+        mt = tile / p.gx;
+        nt = tile % p.gx;
     }
-    const int m0 = (tile / p.gx) * RTA, n0 = (tile % p.gx) * TB;
+    const int m0 = mt * RTA, n0 = nt * TB;
 
     Operand<AKM, RTA> oa;
     Operand<BKM, 128> ob;
@@ -426,7 +450,16 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
     p.ksteps = cdiv(p.nk, s);
     p.splits = cdiv(p.nk, p.ksteps);
     if (p.splits > 1 && beta == 0.f) FT_CHECK_HIP(hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, st));
-    const dim3 grid(p.gx * p.gy, p.splits);
+    // L2-aware tile order for the un-split kernels: column chunks whose B panels (chunk_w x TB rows x K) fit ~2 MB of an XCD's L2
+    static const int order_on = [] { const char* e = getenv("FT_GEMM_BF16_ORDER"); return e ? atoi(e) : 1; }();
+    p.chunk_w = 0;
+    int gridx = p.gx * p.gy;
+    if (order_on && p.splits == 1 && p.gy >= 16) {
+        long cw = (2l << 20) / ((long)TB * (long)p.nk * 32 * 2);
+        p.chunk_w = (int)(cw < 1 ? 1 : (cw > p.gx ? p.gx : cw));
+        gridx = 8 * ((p.gy + 7) / 8) * p.gx;          // every XCD is handed the blocks of the largest row range
+    }
+    const dim3 grid(gridx, p.splits);
     if (a_km) { if (b_km) launch_s<true, true>(p, grid, big, st); else launch_s<true, false>(p, grid, big, st); }
     else      { if (b_km) launch_s<false, true>(p, grid, big, st); else launch_s<false, false>(p, grid, big, st); }
     FT_CHECK_LAUNCH();
