@@ -401,6 +401,231 @@ __global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 kernel for the large k-contiguous x k-contiguous GEMMs (forward projections, input gradients against a
+// transposed weight image): 8 waves = two GROUPS of four (group g owns tile rows 128 g .. 128 g + 127, wave wc of a group the
+// columns 64 wc .. 64 wc + 63: a 128 x 64 wave tile = 8 x 4 MFMA tiles, 128 accumulator registers), one workgroup per CU,
+// 128 KiB of LDS = two K-tile buffers of [A 256 rows | B 256 rows] x 64 k.
+//   * One SIMD hosts one wave of each group, and the groups run HALF A PHASE APART (group 1 passes one extra barrier at
+//     entry, group 0 one at exit): while one wave of a SIMD issues the 16 MFMAs of a C quadrant (M segment), its partner
+//     fetches fragments from LDS and issues the DMAs of a later K-tile (L segment); every segment ends in a workgroup barrier.
+//   * A K-tile is four phases = the four 64 x 32 quadrants of the wave tile in the order (0,0) (0,1) (1,1) (1,0), so the
+//     fragment reads are minimal: L0 reads A(qm0) + B(qn0), L1 B(qn1), L2 A(qm1), L3 nothing (24 ds_read_b128 per K-tile).
+//   * Staging (global_load_lds, 16 B per lane, no VGPRs): a group stages its OWN A half and one B half of the NEXT K-tile, a
+//     quarter per L segment in the order A(qm0 rows), B(qn0 rows), B(qn1 rows), A(qm1 rows) -- two DMAs per lane and segment.
+//     Each segment ends with `s_waitcnt vmcnt(4)`: everything but the DMAs of the last two segments has landed, which is
+//     exactly what the NEXT L segment of either group reads (a part is issued >= 2 phases before its first reader); the
+//     barrier behind the wait publishes it.  WAR: a part's LDS rows were last read >= 2 phases before they are overwritten, and
+//     every L segment drains its own ds_reads (lgkmcnt(0)) before its barrier.
+//   * LDS image: 128-byte rows (64 k), the 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7): the four 16-lane
+//     service groups of ds_read_b128 then hit 16 distinct slots.  The DMA writes lane-linear, so the swizzle is applied to the
+//     SOURCE address (same 128-byte global line: coalescing is unaffected).
+// Same epilogue contract as gemm_bf16_k (alpha, beta, bias, activation, compact row map); no split-K.
+__device__ __forceinline__ void ds_read16(bf16x8& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); }
+template <int OFF>
+__device__ __forceinline__ void ds_read16o(bf16x8& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF)); }
+__device__ __forceinline__ void frag_wait(bf16x8 (&a)[8], bf16x8 (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                 "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+__device__ __forceinline__ void frag_wait(bf16x8 (&a)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+}
+__device__ __forceinline__ void frag_wait(bf16x8 (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_big_k(BfP p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];          // 2 x (32 KiB A + 32 KiB B)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), wc = __builtin_amdgcn_readfirstlane(wave & 3);
+    const int li = lane & 15, kg = lane >> 4;
+    int tile = blockIdx.x;
+    int rows_lim = p.M, gy = p.gy;
+    if (p.compact == 1) {
+        const int R = __builtin_amdgcn_readfirstlane(*p.rows_dev);
+        rows_lim = R < p.M ? R : p.M;
+        gy = (rows_lim + 255) >> 8;
+        if (gy == 0) return;
+    }
+    int mt, nt;
+    if (p.chunk_w > 0 && gy >= 16) {                      // L2-aware order, as gemm_bf16_k
+        const int xcd = tile & 7, idx = tile >> 3;
+        const int qm = gy >> 3, rm = gy & 7;
+        const int mh = qm + (xcd < rm ? 1 : 0);
+        const int m_lo = xcd * qm + (xcd < rm ? xcd : rm);
+        if (idx >= mh * p.gx) return;
+        const int per_chunk = mh * p.chunk_w;
+        const int ch = idx / per_chunk, within = idx - ch * per_chunk;
+        const int left = p.gx - ch * p.chunk_w;
+        const int cw = left < p.chunk_w ? left : p.chunk_w;
+        const int mi = within / cw;
+        mt = m_lo + mi;
+        nt = ch * p.chunk_w + (within - mi * cw);
+    } else {
+        const int total = p.gx * gy, q = total >> 3, r = total & 7;
+        const int xcd = tile & 7, idx = tile >> 3;
+        if (tile >= total) return;
+        tile = xcd * q + (xcd < r ? xcd : r) + idx;
+        mt = tile / p.gx;
+        nt = tile % p.gx;
+    }
+    const int m0 = mt * 256, n0 = nt * 256;
+    const int nkt = (p.nk + 1) >> 1;                      // K-tiles of 64 (p.nk counts 32-wide steps; images are zero-padded to 256)
+
+    // ---- staging: this lane's source pointers (K-tile 0) and LDS piece offsets of the four parts a group stages per K-tile.
+    // A piece = 8 LDS rows x 128 B = one wave-wide DMA; wave w of the group takes pieces 2w, 2w+1 of a part (8 pieces = 64 rows).
+    const int wg = wave & 3;                               // wave inside its group
+    const int prow = lane >> 3, pch = lane & 7;            // row inside a piece, physical 16-byte chunk
+    const unsigned short* src[4][2];
+    int dst[4][2];
+#pragma unroll
+    for (int part = 0; part < 4; ++part)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pc = wg * 2 + h;                     // piece 0..7 of this part
+            int lrow;                                      // LDS row (0..255) of the piece's first row, inside the A or the B tile
+            bool isA;
+            if (part == 0) { isA = true; lrow = grp * 128 + pc * 8; }                    // A, qm0 rows of the own half
+            else if (part == 3) { isA = true; lrow = grp * 128 + 64 + pc * 8; }          // A, qm1 rows
+            else {                                                                      // B half `grp`: columns of waves 2 grp, 2 grp + 1
+                isA = false;
+                const int w2 = pc >> 2, blk = pc & 3;                                   // which wave's 32-row block, 8-row block inside
+                lrow = (grp * 2 + w2) * 64 + (part == 1 ? 0 : 32) + blk * 8;
+            }
+            const int r = lrow + prow;
+            const int c = pch ^ ((r >> 1) & 7);                                         // logical chunk stored at physical chunk pch
+            const unsigned short* img = isA ? p.A + (size_t)(m0 + r) * p.lda : p.B + (size_t)(n0 + r) * p.ldb;
+            src[part][h] = img + c * 8;
+            dst[part][h] = (isA ? 0 : 32768) + lrow * 128;
+        }
+    auto stage = [&](int part, int kt) {                   // part of K-tile kt into buffer kt & 1
+        unsigned char* base = smem + (kt & 1) * 65536;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            __builtin_amdgcn_global_load_lds((glb_void*)(src[part][h] + (size_t)kt * 64), (lds_void*)(base + dst[part][h]), 16, 0, 0);
+    };
+
+    // ---- fragment read addresses: row-dependent swizzle s = (li >> 1), chunk (ks * 4 + kg) ^ s -> byte offsets off0 (ks 0), off0 ^ 64 (ks 1)
+    const unsigned sw0 = (unsigned)((kg ^ (li >> 1)) << 4), sw1 = sw0 ^ 64u;
+    const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;
+    const unsigned a_row = lds0 + (unsigned)((grp * 128 + li) * 128);                    // + qm * 8192 + i * 2048
+    const unsigned b_row = lds0 + 32768u + (unsigned)((wc * 64 + li) * 128);             // + qn * 4096 + j * 2048
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 a[8], b0[4], b1[4];                             // a[ks * 4 + i]; b*[ks * 2 + j]
+
+    auto read_a = [&](int kt, int qm) {
+        const unsigned base0 = a_row + (unsigned)((kt & 1) * 65536 + qm * 8192) + sw0;
+        const unsigned b1a = a_row + (unsigned)((kt & 1) * 65536 + qm * 8192) + sw1;
+        ds_read16o<0>(a[0], base0); ds_read16o<2048>(a[1], base0); ds_read16o<4096>(a[2], base0); ds_read16o<6144>(a[3], base0);
+        ds_read16o<0>(a[4], b1a); ds_read16o<2048>(a[5], b1a); ds_read16o<4096>(a[6], b1a); ds_read16o<6144>(a[7], b1a);
+    };
+    auto read_b = [&](int kt, int qn, bf16x8 (&b)[4]) {
+        const unsigned base0 = b_row + (unsigned)((kt & 1) * 65536 + qn * 4096) + sw0;
+        const unsigned base1 = b_row + (unsigned)((kt & 1) * 65536 + qn * 4096) + sw1;
+        ds_read16o<0>(b[0], base0); ds_read16o<2048>(b[1], base0);
+        ds_read16o<0>(b[2], base1); ds_read16o<2048>(b[3], base1);
+    };
+    auto quad = [&](int qm, int qn, const bf16x8 (&b)[4]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[qm * 4 + i][qn * 2 + j] = mfma16(b[ks * 2 + j], a[ks * 4 + i], acc[qm * 4 + i][qn * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // end of an L segment: staged data older than the last two segments has landed, own fragment reads are complete, barrier
+    auto end_l = [&](int keep) {
+        if (keep >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (keep == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto end_m = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: K-tile 0 entirely
+#pragma unroll
+    for (int part = 0; part < 4; ++part) stage(part, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();            // group 1 runs half a phase behind group 0
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        // phase 0
+        read_a(kt, 0); read_b(kt, 0, b0);
+        frag_wait(a, b0);
+        if (more) stage(0, kt + 1);
+        end_l(more ? 4 : 2);            // (last K-tile: the only younger DMAs are those of the previous segment)
+        quad(0, 0, b0);
+        end_m();
+        // phase 1
+        read_b(kt, 1, b1);
+        frag_wait(b1);
+        if (more) stage(1, kt + 1);
+        end_l(more ? 4 : 0);
+        quad(0, 1, b1);
+        end_m();
+        // phase 2
+        read_a(kt, 1);
+        frag_wait(a);
+        if (more) stage(2, kt + 1);
+        end_l(more ? 4 : 0);
+        quad(1, 1, b1);
+        end_m();
+        // phase 3
+        if (more) stage(3, kt + 1);
+        end_l(more ? 4 : 0);
+        quad(1, 0, b0);
+        end_m();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();            // match group 1's extra barrier
+
+    // ---- epilogue: lane (li, kg), register r  <->  C[m = i*16 + li][n = j*16 + kg*4 + r]
+    const bool vec = p.vec_c != 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int row = m0 + grp * 128 + i * 16 + li;
+        if (row >= rows_lim) continue;
+        if (p.compact == 1) { row = p.rowmap[row]; if (row < 0) continue; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wc * 64 + j * 16 + kg * 4;
+            if (col >= p.N) continue;
+            float* cp = p.C + (long)row * p.ldc + col;
+            float v[4] = {p.alpha * acc[i][j][0], p.alpha * acc[i][j][1], p.alpha * acc[i][j][2], p.alpha * acc[i][j][3]};
+            const int nv = (p.N - col < 4) ? p.N - col : 4;
+            const bool full = vec && nv == 4;
+            if (p.beta != 0.f) {
+                if (full) { const float4 c = *reinterpret_cast<const float4*>(cp); v[0] += p.beta * c.x; v[1] += p.beta * c.y; v[2] += p.beta * c.z; v[3] += p.beta * c.w; }
+                else for (int r = 0; r < nv; ++r) v[r] += p.beta * cp[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < nv && p.bias) v[r] += p.bias[col + r];
+                if (p.act == FT_ACT_TANH) v[r] = tanhf_(v[r]);
+                else if (p.act == FT_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+                else if (p.act == FT_ACT_SIGMOID) v[r] = sigmoidf_(v[r]);
+            }
+            if (full) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+            else for (int r = 0; r < nv; ++r) cp[r] = v[r];
+        }
+    }
+}
+
 template <bool AKM, bool BKM>
 void launch_s(const BfP& p, dim3 grid, bool big, hipStream_t st) {
     if (big) {
@@ -458,6 +683,23 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
         long cw = (2l << 20) / ((long)TB * (long)p.nk * 32 * 2);
         p.chunk_w = (int)(cw < 1 ? 1 : (cw > p.gx ? p.gx : cw));
         gridx = 8 * ((p.gy + 7) / 8) * p.gx;          // every XCD is handed the blocks of the largest row range
+    }
+    // the 256 x 256 x 64 two-group kernel: both operands k-contiguous, no split-K, enough tiles to fill the chip
+    const char* big_env = getenv("FT_GEMM_BF16_BIG");
+    const bool big256 = (!big_env || atoi(big_env) != 0) && !a_km && !b_km && p.splits == 1 && M >= 4096 && N >= 512 && K >= 256;
+    if (big256) {
+        p.gx = cdiv(N, 256); p.gy = cdiv(M, 256);
+        p.chunk_w = 0;
+        int gx256 = p.gx * p.gy;
+        if (order_on && p.gy >= 16) {
+            long cw = (2l << 20) / (256l * (long)p.nk * 32 * 2);
+            p.chunk_w = (int)(cw < 1 ? 1 : (cw > p.gx ? p.gx : cw));
+            gx256 = 8 * ((p.gy + 7) / 8) * p.gx;
+        }
+        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_k), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        hipLaunchKernelGGL(gemm_bf16_big_k, dim3(gx256), dim3(512), 131072, st, p);
+        FT_CHECK_LAUNCH();
+        return FT_OK;
     }
     const dim3 grid(gridx, p.splits);
     if (a_km) { if (b_km) launch_s<true, true>(p, grid, big, st); else launch_s<true, false>(p, grid, big, st); }

@@ -742,3 +742,32 @@ def test_compact_lstm_layer_equals_padded(env, H):
     assert torch.equal(res[0][1][m], res[1][1][m]) and float(res[1][1][~m].abs().max()) == 0.0
     for a, b_, name in zip(res[1][2:], res[0][2:], ("dW_ih", "dW_hh", "db_ih", "db_hh")):
         assert rel(a, b_) < 5e-6, (name, rel(a, b_))
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_big_tile_image_gemm_is_bit_identical_to_the_128_tile_kernel(env, act, monkeypatch):
+    """gemm_bf16_big_k (256 x 256 x 64, two wave groups half a phase apart, counted DMA waits) against gemm_bf16_k on shapes that
+    select it (M >= 4096, N >= 512, K >= 256, both operands k-contiguous): the accumulation order per output element is the same
+    (32-wide k steps in order), so the outputs must be BIT-identical -- any staging / swizzle / barrier slip shows as a mismatch.
+    Covers ragged M / N / K against the tile, bias + activation, the accumulate-into-C (beta = 1, two-input) path and the compact
+    row map."""
+    L, ops = env
+    torch.manual_seed(77)
+    T, B, K1, K2, N = 150, 32, 320, 264, 640                     # rows 4800; K 320 -> 5 K-tiles, 264 -> 5 (ragged last)
+    lens = [150 - 3 * i for i in range(B)]
+    lens32 = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    x1, x2 = torch.randn(T, B, K1, device="cuda"), torch.randn(T, B, K2, device="cuda")
+    W = torch.randn(N, K1 + K2, device="cuda") * 0.05
+    b = torch.randn(N, device="cuda")
+    res = {}
+    for big in ("0", "1"):
+        monkeypatch.setenv("FT_GEMM_BF16_BIG", big)
+        outs = []
+        for rm in (None, ops.RowMap(lens32, T, B)):
+            outs.append(ops.linear([x1, x2], W, b, act=act, mode=1, rowmap=rm, fill="y").detach().clone())
+        res[big] = outs
+    for a_, b_ in zip(res["0"], res["1"]):
+        assert torch.equal(a_, b_), (a_ - b_).abs().max().item()
+    ref = torch.cat([x1, x2], 2).bfloat16().float() @ W.bfloat16().float().t() + b
+    ref = torch.tanh(ref) if act else ref
+    assert mad(res["1"][0], ref) < 2e-3
