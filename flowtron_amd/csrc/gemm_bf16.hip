@@ -686,7 +686,13 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
     }
     // the 256 x 256 x 64 two-group kernel: both operands k-contiguous, no split-K, enough tiles to fill the chip
     const char* big_env = getenv("FT_GEMM_BF16_BIG");
-    const bool big256 = (!big_env || atoi(big_env) != 0) && !a_km && !b_km && p.splits == 1 && M >= 4096 && N >= 512 && K >= 256;
+    // Measured on MI355X (scripts/exp/gemm_img_bench.py, M = 19 200 compact rows, bit-identical outputs): it wins where a tile
+    // has a long reduction and the grid many rounds -- x[R,1664] W[4096,1664]^T 781 vs 615 TFLOP/s -- and loses where one
+    // workgroup per CU cannot hide its own prologue / epilogue behind a neighbour (K = 1024: 603 vs 640; N = 1024: 456 vs 603;
+    // 300 tiles are 1.2 rounds of 256 CUs).  FT_GEMM_BF16_BIG = 0 | 1 | 2: off | where it wins (default) | wherever it applies.
+    const int big_mode = big_env ? atoi(big_env) : 1;
+    const bool big256 = big_mode != 0 && !a_km && !b_km && p.splits == 1 && M >= 4096 && N >= 512 && K >= 256 &&
+                        (big_mode == 2 || (N >= 2048 && K >= 1536));
     if (big256) {
         p.gx = cdiv(N, 256); p.gy = cdiv(M, 256);
         p.chunk_w = 0;

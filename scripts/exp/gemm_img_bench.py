@@ -9,12 +9,12 @@ shapes = [("gx0 fwd  x[R,1664] W[4096,1664]^T", R, 4096, 1664), ("gx1 fwd  x[R,1
           ("dense    x[R,1024] W[1024,1024]^T", R, 1024, 1024), ("query    x[R,1024] W[640,1024]^T", R, 640, 1024),
           ("gx0 dX   d[R,4096] Wt[1664,4096]^T", R, 1664, 4096), ("dense dX d[R,1024] Wt[1024,1024]^T", R, 1024, 1024)]
 torch.manual_seed(0)
-for name, M, N, K in shapes:
+for name, M, N, K in shapes[: int(os.environ.get("GEMM_BENCH_SHAPES", "99"))]:
     x = torch.randn(M, K, device="cuda")
     w = torch.randn(N, K, device="cuda") / K ** 0.5
     xi, wi = ops.Bf16Image(x, mode=1), ops.Bf16Image(w, mode=1)
     outs, res = [], []
-    for big in ("0", "1"):
+    for big in ("0", "2"):
         os.environ["FT_GEMM_BF16_BIG"] = big
         y = torch.empty(M, N, device="cuda")
         for _ in range(3):
