@@ -317,7 +317,10 @@ def usable_cores():
 ILL_CONDITIONED = ("encoder.convolutions", "embedding.weight", "attention_layer.query")   # tests/test_gpu_bench_path.py
 
 
-def sample_of(batch, n_utt=8):
+CPU_SAMPLE_UTTS = 16          # utterances of the bounded CPU-oracle sample (cpu_baseline and parity legs)
+
+
+def sample_of(batch, n_utt=CPU_SAMPLE_UTTS):
     """The bounded sample both the CPU oracle and the HIP parity pass evaluate: the n shortest utterances of the batch,
     re-sorted by text length (data.py:200-202), trimmed to their own T / L, with their beta-binomial prior."""
     idx = torch.argsort(batch["out_lens"])[:n_utt]
@@ -331,8 +334,9 @@ def sample_of(batch, n_utt=8):
 
 def cpu_baseline_worker(batch_size, seed, hip_path=None):
     """The CPU oracle (oracle/flowtron_oracle.py = restatement of the reference, pinned to golden vectors made
-    with the real reference) on a BOUNDED sample: the 4 shortest utterances of rank 0's batch (~10 s of CPU work), full
-    forward + loss + backward, fp32, all usable host cores.  Runs in its own process (no GPU context).  When the main
+    with the real reference) on a BOUNDED sample: the CPU_SAMPLE_UTTS shortest utterances of rank 0's batch (~10 s of CPU work
+    on the GPU box's 16 usable cores), full forward + loss + backward, fp32, all usable host cores, torch's CPU LSTM over the padded
+    batch (O.lstm_seq_padded: ~10x faster than the packed CPU path the reference itself would take).  Runs in its own process (no GPU context).  When the main
     process saved the HIP path's losses and gradients for the same sample and the same weights (hip_path), the worker also
     returns the parity figures of the benchmarked dtype against the oracle."""
     from oracle import flowtron_oracle as O
@@ -344,14 +348,14 @@ def cpu_baseline_worker(batch_size, seed, hip_path=None):
     init_weights(model, 1234)
     batch = synth_batch(batch_size, seed)
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-    n_utt = 8
+    n_utt = CPU_SAMPLE_UTTS
     smp = sample_of(batch, n_utt)
     out_lens, in_lens, mel, text, pr, gate = smp["out_lens"], smp["in_lens"], smp["mel"], smp["text"], smp["prior"], smp["gate"]
     idx = slice(None)
     batch = dict(batch, speaker_ids=smp["speaker_ids"])
     T, Lk = mel.shape[2], text.shape[1]
-    O.LSTM_IMPL["fn"] = O.lstm_seq_fast
-    best = None
+    O.LSTM_IMPL["fn"] = O.lstm_seq_padded    # torch's CPU LSTM over the padded batch: several times faster than the packed path the
+    best = None                               # reference takes on CPU (its autograd zero-fills [sum(lens), 4H] once per step)
     for it in range(2):
         for v in sd.values():
             v.grad = None

@@ -56,7 +56,9 @@ class DecodeArgs(C.Structure):
                                                                                          ("wimg", _p), ("wimg_bytes", _sz), ("persist_gran", _p), ("persist_status", _p)]
 
 
-# name -> argtypes (every symbol include/flowtron_hip.h declares; checked by tests/test_abi.py)
+SUMSQ_PARTIALS = 1024      # FT_SUMSQ_PARTIALS: floats of scratch ft_sumsq needs
+
+# name -> argtypes (every symbol include/flowtron_hip.h declares; checked by tests/test_host_cpu.py)
 SIGNATURES = {
     "ft_abi_version": ([], _i),
     "ft_last_error": ([], C.c_char_p),
@@ -117,7 +119,7 @@ SIGNATURES = {
     "ft_attn_ctc_fwd": ([_p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_attn_ctc_bwd": ([_p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_beta_binomial_prior": ([_p, _p, _p, _i, _i, _i, _f, _p], _i),
-    "ft_sumsq": ([_p, _p, _l, _p], _i),
+    "ft_sumsq": ([_p, _p, _l, _p, _p], _i),
     "ft_radam_step": ([_p, _p, _p, _p, _l, _p, _d, _d, _d, _d, _d, _d, _d, _i, _p, _p], _i),
     "ft_poison_if_nonzero": ([_p, _p, _p], _i),
 }
@@ -145,7 +147,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argt
             fn.restype = rest
-        if l.ft_abi_version() != 5:
+        if l.ft_abi_version() != 6:
             raise RuntimeError("libflowtron_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -268,8 +268,8 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_k(const float* __restric
     }
 }
 
-// dQ, dK and dv from ONE evaluation of the tanh tensor.  grid = (ceil(T/32), B, ceil(A/256)); lane <-> a (one 64-wide
-// a-chunk per wave), every thread keeps 32 query rows in registers and walks the keys:
+// dQ, dK and dv from ONE evaluation of the tanh tensor.  grid = (ceil(T/32), B, a-chunk groups); lane <-> a (one 64-wide
+// a-chunk per wave, 1-5 waves per workgroup chosen by the launcher), every thread keeps 32 query rows in registers and walks the keys:
 //   g[t,l,a] = de[b,t,l] * r(1-r),  dQ[t,a] = 4 v[a] sum_l g   (owned by one thread: plain store),
 //   dK[l,a] += 4 v[a] sum_{t in tile} g   (one fp32 atomic per (l, a) per 32-row tile; dK must be zeroed),
 //   dv[a]  += sum_{t,l} de * tanh.
@@ -283,13 +283,13 @@ __global__ __launch_bounds__(256) void attn_dqdk_k(const float* __restrict__ Q, 
     const int b = blockIdx.y, t0 = blockIdx.x * 32;
     const int len = min(in_lens[b], L);
     int nz = 0;
-    for (int idx = tid; idx < len * 32; idx += 256) {
+    for (int idx = tid; idx < len * 32; idx += (int)blockDim.x) {
         const int r = idx & 31, l = idx >> 5;
         const float v = (t0 + r < T) ? de[((long)b * T + t0 + r) * L + l] : 0.f;
         de_s[idx] = v;
         nz |= (v != 0.f);
     }
-    const int aw = blockIdx.z * 256 + w * 64;
+    const int aw = blockIdx.z * (int)blockDim.x + w * 64;
     if (!__syncthreads_or(nz)) {
         // the whole 32-row tile carries no gradient (padded frames of a short utterance: ~30 % of the rows of a batch):
         // dQ = 0, no contribution to dK / dv -- skip the tanh recomputation.  Exact: decided on the data, not on lengths.
@@ -416,10 +416,16 @@ extern "C" int ft_attention_bwd(const float* Q, const float* K, const float* v, 
     else
         hipLaunchKernelGGL(attn_softmax_bwd_k<false>, dim3(rows_grid), dim3(256), 0, st, attn, p_save, dattn, dlogprob, in_lens, de_work, T, B, L, inv_temp);
     // one tanh pass for dQ, dK and dv (separate dQ / dK kernels, each recomputing tanh: 73.8 vs 71.5 ms per training step)
+    FT_CHECK_HIP(hipMemsetAsync(dK, 0, sizeof(float) * (size_t)L * B * A, st));
+    // four waves per workgroup = four 64-wide a-chunks.  Measured alternatives (profiles/r03_attn_dqdk_variants.log): five waves
+    // (A = 640 = 2 x 5 chunks, no idle wave): 772 vs 603 us -- 134 VGPRs leave three waves per SIMD, i.e. three 4-wave
+    // workgroups per CU but only two 5-wave ones; the dK sums of four tiles combined in LDS before leaving the CU (a quarter of
+    // the atomics, 115 KB of LDS = one workgroup per CU): 1 045 us.  The pass is VALU-bound, not atomics-bound.
+    const int nchunk = cdiv(A, 64);
+    const int nw = nchunk < 4 ? nchunk : 4;
     if (lds_q > 48 * 1024)      // (the kernel also has a few static LDS bytes: ask for what this launch needs, not for all 160 KiB)
         FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dqdk_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
-    FT_CHECK_HIP(hipMemsetAsync(dK, 0, sizeof(float) * (size_t)L * B * A, st));
-    hipLaunchKernelGGL(attn_dqdk_k, dim3(cdiv(T, 32), B, cdiv(A, 256)), dim3(256), lds_q, st, Q, K, v, in_lens, de_work, dQ, dK, dv,
+    hipLaunchKernelGGL(attn_dqdk_k, dim3(cdiv(T, 32), B, cdiv(nchunk, nw)), dim3(64 * nw), lds_q, st, Q, K, v, in_lens, de_work, dQ, dK, dv,
                        T, B, L, A);
     FT_CHECK_LAUNCH();
     return FT_OK;

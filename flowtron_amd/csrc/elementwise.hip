@@ -266,7 +266,11 @@ __global__ void zero_k(float* __restrict__ p, long n) {
 }
 
 // ---------------- optimizer (flat arena) ----------------
-__global__ void sumsq_k(const float* __restrict__ x, float* __restrict__ acc, long n) {
+// Two launches and NO float atomics: the square norm feeds the clip factor of every rank's optimizer step, and data-parallel
+// replicas only stay bit-identical if every rank computes bit-identical norms from its bit-identical reduced gradients (an
+// atomicAdd per block sums in arrival order: two ranks on one MI355X ended a step with weights one ulp apart).  Block b writes
+// its partial sum to part[b]; one workgroup then adds the partials in index order.
+__global__ void sumsq_part_k(const float* __restrict__ x, float* __restrict__ part, long n) {
     __shared__ float red[NT / 64];
     float s = 0.f;
     const long n4 = n >> 2;
@@ -278,7 +282,14 @@ __global__ void sumsq_k(const float* __restrict__ x, float* __restrict__ acc, lo
     for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         s += x[i] * x[i];
     s = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(acc, s);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void sumsq_fin_k(const float* __restrict__ part, int nb, float* __restrict__ acc) {
+    __shared__ float red[NT / 64];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) acc[0] += s;
 }
 
 // radam.py:44-122 restated per element (fp32 state):
@@ -469,11 +480,13 @@ extern "C" int ft_eltwise(const float* a, const float* b, float* out, int64_t n,
     FT_CHECK_LAUNCH();
     return FT_OK;
 }
-extern "C" int ft_sumsq(const float* x, float* acc, int64_t n, void* stream) {
-    FT_CHECK_ARG(x && acc && n >= 0);
+extern "C" int ft_sumsq(const float* x, float* acc, int64_t n, float* partials, void* stream) {
+    FT_CHECK_ARG(x && acc && partials && n >= 0);
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(x) % 16 == 0);
     if (n == 0) return FT_OK;
-    hipLaunchKernelGGL(sumsq_k, dim3(grid_for(n / 4 + 1, NT, 2048)), dim3(NT), 0, ST(stream), x, acc, (long)n);
+    const int nb = grid_for(n / 4 + 1, NT, FT_SUMSQ_PARTIALS);       // a function of n alone: the same order on every rank
+    hipLaunchKernelGGL(sumsq_part_k, dim3(nb), dim3(NT), 0, ST(stream), x, partials, (long)n);
+    hipLaunchKernelGGL(sumsq_fin_k, dim3(1), dim3(NT), 0, ST(stream), partials, nb, acc);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

@@ -164,7 +164,7 @@ def gemm_img(A, a_km, a_ptr, B, b_km, b_ptr, Cm, M, N, K, ldc, bias=None, act=L.
 
 # hand-off of an output-gradient image between two autograd nodes of the SAME backward pass (the LSTM backward builds the
 # image of dgates for its own dW_hh GEMM; the input projection's LinearFn.backward receives that very tensor as dy).
-# Keyed by (data_ptr, shape); cleared by an engine callback at the end of the pass, so an address can never match stale data.
+# Keyed by (device, data_ptr, shape); cleared by an engine callback at the end of the pass, so an address can never match stale data.
 _HANDOFF = {"imgs": {}, "armed": False}
 
 
@@ -180,11 +180,11 @@ def _handoff_put(t, img):
         except RuntimeError:            # not inside a backward pass: no consumer can follow
             return
         _HANDOFF["armed"] = True
-    _HANDOFF["imgs"][(t.data_ptr(), tuple(t.shape))] = img
+    _HANDOFF["imgs"][(t.device.index, t.data_ptr(), tuple(t.shape))] = img
 
 
 def _handoff_take(t):
-    return _HANDOFF["imgs"].pop((t.data_ptr(), tuple(t.shape)), None)
+    return _HANDOFF["imgs"].pop((t.device.index, t.data_ptr(), tuple(t.shape)), None)
 
 
 def colsum(x2d: torch.Tensor, rows: int, N: int, ld: int) -> torch.Tensor:

@@ -43,6 +43,7 @@ class RAdam(Optimizer):
         self.flat_m = torch.zeros_like(arena.flat_grad)
         self.flat_v = torch.zeros_like(arena.flat_grad)
         self.gnorm_sq = torch.zeros(1, device=arena.flat_grad.device, dtype=torch.float32)
+        self._partials = torch.empty(L.SUMSQ_PARTIALS, device=arena.flat_grad.device, dtype=torch.float32)
         self._skipped = torch.zeros(1, device=arena.flat_grad.device, dtype=torch.int32)
         self._have_norm = False
         self._step = 0
@@ -99,7 +100,7 @@ class RAdam(Optimizer):
         a.adopt_stray_grads(copy=True)
         poison_from_status(a.flat_grad)
         self.gnorm_sq.zero_()
-        L.check(L.lib().ft_sumsq(L.ptr(a.flat_grad), L.ptr(self.gnorm_sq), a.numel, L.stream()), "ft_sumsq")
+        L.check(L.lib().ft_sumsq(L.ptr(a.flat_grad), L.ptr(self.gnorm_sq), a.numel, L.ptr(self._partials), L.stream()), "ft_sumsq")
         self._have_norm = True
 
     def clip_grad_norm_(self, max_norm: float):

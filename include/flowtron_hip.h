@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 5
+#define FT_ABI_VERSION 6
 
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1, FT_F16 = 2 };
@@ -371,8 +371,12 @@ int ft_beta_binomial_prior(const int32_t* in_lens, const int32_t* out_lens, floa
  * Guard (device side, no host synchronisation): when gnorm_sq_dev is given and *gnorm_sq_dev is NaN or Inf the whole update
  * is SKIPPED -- p, m, v keep their values -- and *skipped_dev (optional) is incremented: what GradScaler.step does for an fp16
  * overflow (train.py:330), extended to every non-finite global norm, so that one poisoned step (ft_poison_if_nonzero below)
- * can never reach the weights or the moments. */
-int ft_sumsq(const float* x, float* acc, int64_t n, void* stream);
+ * can never reach the weights or the moments.
+ * ft_sumsq: acc[0] += sum x^2, DETERMINISTIC (no float atomics: per-workgroup partial sums into `partials`, FT_SUMSQ_PARTIALS
+ * floats of caller scratch, added in index order by one workgroup) -- data-parallel replicas stay bit-identical only if every
+ * rank derives the same clip factor from the same reduced gradients. */
+#define FT_SUMSQ_PARTIALS 1024
+int ft_sumsq(const float* x, float* acc, int64_t n, float* partials, void* stream);
 int ft_radam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   const float* gnorm_sq_dev, double clip, double lr, double beta1, double beta2, double eps,
                   double weight_decay, double step_size, int rectified, int32_t* skipped_dev, void* stream);

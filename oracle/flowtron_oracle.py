@@ -116,6 +116,24 @@ def lstm_seq_fast(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=False):
     return y[:, inv]
 
 
+def lstm_seq_padded(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=False):
+    """Same function once more, for LONG sequences: torch's CPU LSTM over the PADDED batch, outputs of pad frames zeroed
+    afterwards.  A forward-direction LSTM's output at t < len does not depend on later frames, so the valid outputs (and,
+    through the mask, every gradient) equal those of the packed run of flowtron.py:689-694; the reversed direction runs on
+    the per-sample reversed input like lstm_seq_fast.  Why it exists: autograd through the PACKED CPU LSTM narrows the
+    [sum(lens), 4H] projection once per step, and every narrow's backward zero-fills a tensor of that full size -- O(T^2):
+    at T = 862 that was 88 s of fill_ per four utterances.  Pinned to lstm_cell_seq in tests/test_oracle_golden.py."""
+    T, B, _ = x.shape
+    if lens is None:
+        lens = torch.full((B,), T, dtype=torch.long)
+    lens = lens.cpu().long()
+    xs = reverse_valid(x, lens) if reverse else x
+    h0 = x.new_zeros(1, B, w_hh.shape[1])
+    y = torch._VF.lstm(xs, (h0, h0), [w_ih, w_hh, b_ih, b_hh], True, 1, 0.0, True, False, False)[0]
+    y = y * (torch.arange(T)[:, None] < lens[None, :]).unsqueeze(-1).to(y.dtype)
+    return reverse_valid(y, lens) if reverse else y
+
+
 def reverse_valid(x, lens):
     """Reverse each sample's valid span [0,len) in time (dim 0), pads untouched."""
     T, B = x.shape[:2]

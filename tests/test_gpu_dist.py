@@ -43,19 +43,19 @@ def _local_grads(cfg, sd, batch, dev):
     return {k: p.grad.detach().float().cpu().numpy().copy() for k, p in m.named_parameters()}
 
 
-def _worker(rank, world, port, q, mode, full_width=False, overlap="0"):
+def _worker(rank, world, port, q, mode, full_width=False, overlap="0", backend="nccl", shared_gpu=False):
     try:
         for p_ in (ROOT, HERE):
             if p_ not in sys.path:
                 sys.path.insert(0, p_)
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FLOWTRON_MFMA=mode, LOCAL_RANK=str(rank),
-                          HSA_ENABLE_IPC_MODE_LEGACY="0", FLOWTRON_DP_OVERLAP=overlap)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FLOWTRON_MFMA=mode,
+                          LOCAL_RANK="0" if shared_gpu else str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0", FLOWTRON_DP_OVERLAP=overlap)
         import distributed as D
         import flowtron
         from flowtron_amd.optim import RAdam
         from oracle import synth
-        D.init_distributed(rank, world, "nccl", None)
-        dev = torch.device("cuda", rank)
+        D.init_distributed(rank, world, backend, None)
+        dev = torch.device("cuda", 0 if shared_gpu else rank)
         cfg = dict(synth.DEFAULT_MODEL_CONFIG)
         if not full_width:
             cfg.update(SMALL)
@@ -88,6 +88,11 @@ def _worker(rank, world, port, q, mode, full_width=False, overlap="0"):
         torch.cuda.synchronize()
         res["w_after"] = m._grad_arena.flat_param.detach().cpu().numpy().copy()
         res["shares_arena"] = opt.arena is m._grad_arena
+        res["skipped"] = int(opt.skipped_steps)
+        from flowtron_amd import ops as _ops
+        res["persist_launches"] = int(_ops.PERSIST_LAUNCHES)
+        st = _ops._PERSIST.get(dev)
+        res["persist_failures"] = int(st.failures) if st is not None else 0
         res["backend"] = torch.distributed.get_backend()
         res["loss"] = float(D.reduce_tensor(nll.detach(), world))
         q.put((rank, res))
@@ -98,11 +103,11 @@ def _worker(rank, world, port, q, mode, full_width=False, overlap="0"):
         q.put((rank, {"error": traceback.format_exc()}))
 
 
-def _run(world, mode, full_width=False, overlap="0"):
+def _run(world, mode, full_width=False, overlap="0", backend="nccl", shared_gpu=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, full_width, overlap)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, full_width, overlap, backend, shared_gpu)) for r in range(world)]
     for p in procs:
         p.start()
     out = dict(q.get(timeout=500) for _ in range(world))
@@ -155,3 +160,33 @@ def test_rccl_two_ranks_average_gradients():
         assert _close(r0["g0"][k], 0.5 * (r0["local"][k] + r1["local"][k]), 2e-5), k
     assert len(r0["log0"]) == 4 and r0["log0"] == r1["log0"]
     assert np.array_equal(r0["w_after"], r1["w_after"]) and abs(r0["loss"] - r1["loss"]) < 1e-6
+
+
+@pytest.mark.skipif(os.environ.get("FLOWTRON_TEST_SHARED_GPU", "1") != "1", reason="FLOWTRON_TEST_SHARED_GPU=0")
+def test_two_ranks_on_one_gpu_over_gloo_with_the_persistent_kernels():
+    """RCCL refuses two ranks on one device, so the N > 1 code path on real HIP streams runs over gloo: two processes on cuda:0,
+    full width (H 1024, bf16: every step launches the whole-chip persistent recurrences), default regime (buckets leave at
+    the end of backward, each behind ft_poison_if_nonzero), different utterances per rank.  Two processes' persistent grids
+    may meet on the chip; then their bounded spins time out, the status word poisons that step on BOTH ranks (the NaN
+    travels through the all-reduce) and the fused RAdam drops it.  Either way: no hang, every rank holds the same reduced
+    arena and the same weights afterwards; when no launch failed, the arena is the mean of the two local gradients."""
+    out = _run(2, "bf16", full_width=True, backend="gloo", shared_gpu=True)
+    r0, r1 = out[0], out[1]
+    import numpy as np
+    assert r0["backend"] == "gloo" and np.array_equal(r0["w_before"], r1["w_before"])
+    assert r0["log0"] == r1["log0"] == ["speaker_embedding+embedding", "flows.0", "flows.1", "encoder"]
+    clean = True
+    for k in r0["g1"]:
+        a, b = r0["g1"][k], r1["g1"][k]
+        assert np.array_equal(a, b, equal_nan=True), k                  # every rank holds the same reduced arena
+        clean &= bool(np.isfinite(a).all())
+    if clean:
+        for k in r0["g1"]:
+            assert _close(r0["g1"][k], 0.5 * (r0["local"][k] + r1["local"][k]), 4e-3), k
+        assert r0["skipped"] == r1["skipped"] == 0
+    else:
+        assert r0["skipped"] == r1["skipped"] == 1                       # the poisoned step was dropped on both ranks
+    assert np.array_equal(r0["w_after"], r1["w_after"]) and np.isfinite(r0["w_after"]).all()
+    print("\n[two ranks, one GPU, gloo] clean=%s skipped=%s persistent launches %s / %s" %
+          (clean, r0["skipped"], r0["persist_launches"], r1["persist_launches"])
+          + "  failures %s / %s" % (r0["persist_failures"], r1["persist_failures"]))

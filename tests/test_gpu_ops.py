@@ -240,7 +240,8 @@ def test_lstm_seq_bf16_fragment_path(env, T, B, H, reverse):
 # ---------------------------------------------------------------- attention
 @pytest.mark.parametrize("T,B,Lk,A,E,prior,with_dlp", [(19, 3, 11, 48, 40, True, True), (40, 2, 37, 640, 64, False, True),
                                                         (33, 4, 150, 64, 32, True, False), (5, 1, 3, 20, 8, False, False),
-                                                        (300, 2, 20, 64, 16, True, True)])      # long T: time-sliced dK kernel
+                                                        (300, 2, 20, 64, 16, True, True),       # long T: four 32-row tiles per workgroup, dK combined in LDS
+                                                        (70, 3, 23, 100, 16, True, True), (130, 2, 9, 48, 8, False, True)])   # partial a-chunk, idle tile waves
 def test_attention(env, T, B, Lk, A, E, prior, with_dlp):
     L, ops = env
     torch.manual_seed(T * 3 + Lk)
@@ -291,8 +292,16 @@ def test_sumsq_radam_colsum(env):
     p, gr, m, v = torch.randn(n), torch.randn(n) * 3, torch.randn(n) * 0.1, torch.rand(n) * 0.01
     pd, gd, md, vd = g(p), g(gr), g(m), g(v)
     acc = torch.zeros(1, device="cuda")
-    L.check(L.lib().ft_sumsq(L.ptr(gd), L.ptr(acc), n, L.stream()), "sumsq")
+    part = torch.empty(L.SUMSQ_PARTIALS, device="cuda")
+    L.check(L.lib().ft_sumsq(L.ptr(gd), L.ptr(acc), n, L.ptr(part), L.stream()), "sumsq")
     assert abs(acc.item() - (gr.double() ** 2).sum().item()) < 1e-4 * acc.item()
+    big = torch.randn(60_977_601, device="cuda") * 1e-3                 # the arena's size (+1: the scalar tail): many workgroups
+    seen = set()
+    for _ in range(5):                                                  # no float atomics: the same bits every time
+        a2 = torch.zeros(1, device="cuda")
+        L.check(L.lib().ft_sumsq(L.ptr(big), L.ptr(a2), big.numel(), L.ptr(part), L.stream()), "sumsq")
+        seen.add(a2.item())
+    assert len(seen) == 1 and abs(seen.pop() - float((big.double() ** 2).sum())) < 1e-4 * float((big.double() ** 2).sum())
     clip, lr, b1, b2, eps, wd, step_size = 1.0, 1e-3, 0.9, 0.999, 1e-8, 1e-6, 2.5e-3
     L.check(L.lib().ft_radam_step(L.ptr(pd), L.ptr(gd), L.ptr(md), L.ptr(vd), n, L.ptr(acc), clip, lr, b1, b2, eps, wd,
                                   step_size, 1, None, L.stream()), "radam")

@@ -181,6 +181,54 @@ def test_chunked_oracle_equals_one_shot_oracle():
             assert (grads[k] - v.grad).norm().item() / denom < 2e-4, (k, chunk)
 
 
+@pytest.mark.parametrize("T,B,I,H,reverse", [(13, 5, 24, 16, False), (13, 5, 24, 16, True), (40, 3, 8, 32, False), (7, 1, 8, 8, True)])
+def test_lstm_variants_equal_the_explicit_recurrence(T, B, I, H, reverse):
+    """The oracle's three statements of the length-masked LSTM (flowtron.py:689-694) agree on ragged batches, outputs and every
+    gradient: the explicit recurrence (the definition, pinned by the goldens), torch's packed CPU LSTM (what the reference
+    executes) and torch's CPU LSTM over the padded batch with pad frames zeroed (what the T = 862 GPU parity test and bench.py's
+    cpu_baseline use: the packed path's autograd is O(T^2))."""
+    torch.manual_seed(T + H)
+    lens = torch.tensor(sorted([T] + [int(v) for v in torch.randint(1, T + 1, (B - 1,))], reverse=True))
+    x = torch.randn(T, B, I)
+    ws = [torch.randn(4 * H, I) * 0.3, torch.randn(4 * H, H) * 0.3, torch.randn(4 * H) * 0.1, torch.randn(4 * H) * 0.1]
+    g = torch.randn(T, B, H)
+    res = []
+    for fn in (O.lstm_cell_seq, O.lstm_seq_fast, O.lstm_seq_padded):
+        xx = x.clone().requires_grad_(True)
+        w = [v.clone().requires_grad_(True) for v in ws]
+        y = fn(xx, lens, *w, reverse=reverse)
+        (y * g).sum().backward()
+        res.append([y.detach(), xx.grad] + [v.grad for v in w])
+    for other in res[1:]:
+        for a, b_ in zip(res[0], other):
+            assert _maxdiff(a, b_) < 1e-5
+    pad = ~(torch.arange(T)[:, None] < lens[None, :])
+    assert float(res[2][0][pad].abs().max() if pad.any() else 0.0) == 0.0      # pad frames: exactly zero, like pad_packed_sequence
+
+
+def test_chunked_oracle_on_the_padded_lstm_equals_one_shot_oracle():
+    """the combination the full-size GPU parity test uses: oracle_chunked + O.lstm_seq_padded == the one-shot oracle on the
+    explicit recurrence"""
+    import oracle_chunked as OC
+    cfg = dict(synth.SMALL_MODEL_CONFIG)
+    out_lens, in_lens = [23, 19, 17, 12, 9, 5], [9, 8, 8, 6, 4, 3]
+    sd = synth.make_state_dict(cfg, seed=6)
+    b = synth.make_batch(cfg, out_lens, in_lens, seed=6, with_prior=True)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.forward(sdg, cfg, b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+    nll, gl, ctc = O.loss(out, b["gate_target"], b["in_lens"], b["out_lens"], 1.0, True, True, -8)
+    (nll + gl + 0.01 * ctc).sum().backward()
+    O.LSTM_IMPL["fn"] = O.lstm_seq_padded
+    try:
+        (n2, g2, c2), grads = OC.forward_backward(cfg, sd, b, b["attn_prior"], chunk=4)
+    finally:
+        O.LSTM_IMPL["fn"] = O.lstm_cell_seq
+    assert abs(n2 - nll.item()) < 1e-5 * abs(nll.item()) and abs(g2 - gl.item()) < 1e-5 and abs(c2 - ctc.item()) < 1e-4
+    for k, v in sdg.items():
+        denom = max(v.grad.norm().item(), 1e-5 * v.numel() ** 0.5)
+        assert (grads[k] - v.grad).norm().item() / denom < 2e-4, k
+
+
 def test_cumulative_attention_full_width_oracle_vs_real_reference(golden_dir):
     """the oracle's location-sensitive attention branch (attn_cond / cumm_attention_sequence / the infer loop) at FULL width
     (H 1024, A 640, T 400) against the real reference's golden (cumm_full.pt): forward outputs, losses, 48-frame inference."""
