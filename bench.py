@@ -561,7 +561,7 @@ def main():
                                        "libritts": "BASELINE configs[2]: 2-flow LibriTTS model (123 speakers)",
                                        "libritts_fp16": "BASELINE configs[4]: 2-flow LibriTTS model (123 speakers), fp16 operands + GradScaler"}[args.config],
                                       args.batch, T, Lk, "attn-prior" if use_prior else "no attn-prior",
-                                      "unscale+" if scaler.is_enabled() else "", ", per-flow bucketed RCCL all-reduce(AVG) under backward" if world > 1 else ""),
+                                      "unscale+" if scaler.is_enabled() else "", (", per-flow bucketed RCCL all-reduce(AVG) " + ("under backward" if getattr(model, "_grad_overlap", False) else "at the end of backward")) if world > 1 else ""),
                        "global_batch": args.batch * world, "valid_frames_per_step": int(frames_all),
                        "padded_frames_per_step": args.batch * T * world, "parallelism": "dp%d" % world,
                        "mfma_operands": args.mfma, "storage": "fp32", "final_loss": round(loss_val, 5)},
@@ -667,6 +667,7 @@ def main():
                     os.remove(hip_path)
         print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()                       # rank 0 is still timing its roofline kernels: everybody leaves together
         dist.destroy_process_group()
 
 
