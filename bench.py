@@ -447,6 +447,11 @@ def main():
     model_config = dict(MODEL_CONFIG, n_speakers=123) if libri else dict(MODEL_CONFIG, use_cumm_attention=args.config == "ljs_cumm")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "6000")
+    # test hook (tests/test_gpu_dist.py): the N > 1 control flow of this script on a ONE-GPU box -- every rank on cuda:0 and gloo
+    # instead of RCCL (which refuses two ranks on one device).  Never set by the driver; the line then says so in `config`.
+    shared_gpu = os.environ.get("BENCH_SHARED_GPU", "0") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     import flowtron
@@ -458,7 +463,8 @@ def main():
     if world > 1:
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):          # the reference-style "> initializing distributed" chatter
-            ftdist.init_distributed(rank, world, "nccl", None)
+            os.environ["LOCAL_RANK"] = str(local_rank)
+            ftdist.init_distributed(rank, world, "gloo" if shared_gpu else "nccl", None)
 
     torch.manual_seed(1234)
     model = flowtron.Flowtron(**model_config)
@@ -564,7 +570,8 @@ def main():
                                       "unscale+" if scaler.is_enabled() else "", (", per-flow bucketed RCCL all-reduce(AVG) " + ("under backward" if getattr(model, "_grad_overlap", False) else "at the end of backward")) if world > 1 else ""),
                        "global_batch": args.batch * world, "valid_frames_per_step": int(frames_all),
                        "padded_frames_per_step": args.batch * T * world, "parallelism": "dp%d" % world,
-                       "mfma_operands": args.mfma, "storage": "fp32", "final_loss": round(loss_val, 5)},
+                       "mfma_operands": args.mfma, "storage": "fp32", "final_loss": round(loss_val, 5),
+                       **({"test_hook": "BENCH_SHARED_GPU: all ranks on ONE GPU over gloo -- not a scaling measurement"} if shared_gpu else {})},
         }
         mode = {"bf16": L.FT_BF16, "f16": L.FT_F16, "f32": L.FT_F32}[args.mfma]
         log("roofline kernel timing ...")

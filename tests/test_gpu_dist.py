@@ -190,3 +190,24 @@ def test_two_ranks_on_one_gpu_over_gloo_with_the_persistent_kernels():
     print("\n[two ranks, one GPU, gloo] clean=%s skipped=%s persistent launches %s / %s" %
           (clean, r0["skipped"], r0["persist_launches"], r1["persist_launches"])
           + "  failures %s / %s" % (r0["persist_failures"], r1["persist_failures"]))
+
+
+def test_bench_script_with_two_ranks_as_the_driver_launches_it():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2` -- the driver's own command for the
+    scaling runs -- on this one-GPU box through bench.py's test hook (both ranks on cuda:0, gloo instead of RCCL): the barriers,
+    the MAX-over-ranks time, the SUM of frames, one JSON line from rank 0, a clean exit of both ranks."""
+    import json
+    import subprocess
+    env = dict(os.environ, BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--no-infer", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["global_batch"] == 64 and d["config"]["valid_frames_per_step"] > 18932        # both ranks' frames
+    assert abs(d["value"] - d["config"]["valid_frames_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
+    assert "at the end of backward" in d["config"]["workload"] and "dominant_kernel" in d["roofline"]
