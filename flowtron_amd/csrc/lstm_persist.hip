@@ -443,6 +443,11 @@ struct PersistBwdP {
     int T, B;
     long timeout_ticks;
     long* prof;
+    // optional (dimg != nullptr): the 16-bit operand image of dgates in pack-by-length row order -- what ft_bf16_image_rows would
+    // make of dgx afterwards (batch-major compact rows, utterance b = its len_b frames + one zero separator row, zero rows up to
+    // ceil256(R + 32)) -- written by the output waves beside the fp32 rows, and the column sums of dgates (the bias gradient)
+    // added to dbias[4H]: the weight-gradient / input-gradient GEMMs then start without a conversion pass over dgx.
+    unsigned short* dimg; long dimg_ld; int dimg_rows; float* dbias;
 };
 
 template <int NG, bool LOCAL, int LAUX, bool BARE>
@@ -505,11 +510,27 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     const int oe = tid - NE;
     const int ob = b0 + oe / UPC, ou = q * UPC + oe % UPC;
     const bool ovalid = tid >= NE && ob < B;
+    int olen = 0, ooff = 0;                                      // image: this row's length and its first compact row
+    if (p.dimg && ovalid) {
+        olen = p.lens[ob];
+        for (int bb = 0; bb < ob; ++bb) ooff += p.lens[bb] + 1;
+    }
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     auto store_outputs = [&](int n) {                            // dgx row of step counter n from outs[n & 1]
         if (!ovalid) return;
         const float* o = outs + (n & 1) * 4 * NE + oe;
-        float* dg = p.dgx + ((size_t)(tg - 1 - n) * B + ob) * 4 * PH + ou;
-        dg[0] = o[0]; dg[(size_t)PH] = o[NE]; dg[(size_t)2 * PH] = o[2 * NE]; dg[(size_t)3 * PH] = o[3 * NE];
+        const int so = tg - 1 - n;
+        const float v0 = o[0], v1 = o[NE], v2 = o[2 * NE], v3 = o[3 * NE];
+        if (p.dgx) {
+            float* dg = p.dgx + ((size_t)so * B + ob) * 4 * PH + ou;
+            dg[0] = v0; dg[(size_t)PH] = v1; dg[(size_t)2 * PH] = v2; dg[(size_t)3 * PH] = v3;
+        }
+        if (p.dimg && so < olen) {
+            unsigned short* ip = p.dimg + (size_t)(ooff + so) * p.dimg_ld + ou;
+            ip[0] = (unsigned short)pack_op16x2(v0, 0.f); ip[PH] = (unsigned short)pack_op16x2(v1, 0.f);
+            ip[2 * PH] = (unsigned short)pack_op16x2(v2, 0.f); ip[3 * PH] = (unsigned short)pack_op16x2(v3, 0.f);
+            bsum[0] += v0; bsum[1] += v1; bsum[2] += v2; bsum[3] += v3;
+        }
     };
     // ring slot n % RING: saved gates x4 + dy of step n; cell slot n % RING = cell[s(n) - 1] (c_prev of step n = c_t of step n+1),
     // cell slot RING-1 starts out as cell[tg - 1] (c_t of step 0)
@@ -698,12 +719,31 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     }
     __syncthreads();
     if (tg > 0) store_outputs(tg - 1);
-    if (ev)                                                             // pad rows beyond the group's longest sequence
+    if (ev && p.dgx)                                                    // pad rows beyond the group's longest sequence
         for (int t = tg; t < T; ++t) {
             float* dg = p.dgx + ((size_t)t * B + eb) * 4 * PH + eu;
 #pragma unroll
             for (int g = 0; g < 4; ++g) dg[(size_t)g * PH] = 0.f;
         }
+    if (p.dimg) {
+        if (ovalid) {                                                   // bias gradient; the utterance's zero separator row
+            unsigned short* ip = p.dimg + (size_t)(ooff + olen) * p.dimg_ld + ou;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                atomicAdd(p.dbias + g * PH + ou, bsum[g]);
+                ip[g * PH] = 0;
+            }
+        }
+        // zero rows behind the last utterance up to ceil256(R + 32) (gemm_bf16.hip mapped_rows): workgroup w takes rows R + w, R + w + 256
+        int R = 0;
+        for (int bb = 0; bb < B; ++bb) R += p.lens[bb] + 1;
+        int Rz = (R + 32 + 255) & ~255;
+        Rz = Rz < p.dimg_rows ? Rz : p.dimg_rows;
+        for (int r = R + grp * CPG + q; r < Rz; r += NCU) {
+            uint4* row = reinterpret_cast<uint4*>(p.dimg + (size_t)r * p.dimg_ld);
+            for (int c = tid; c < 4 * PH / 8; c += 256) row[c] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
 }
 
 }  // namespace
@@ -793,10 +833,22 @@ extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh
     return FT_OK;
 }
 
+extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
+                                   const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
+                                   void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream);
+
 extern "C" int FT_OPNAME(ft_lstm_persist_bwd)(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
                                    const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
                                    void* stream) {
-    FT_CHECK_ARG(dy && w_hh && lens && gates && cell && dgx && work && status);
+    return FT_OPNAME(ft_lstm_persist_bwd_img)(dy, ldy, w_hh, lens, gates, cell, dgx, work, status, T, B, H, ng, nullptr, 0, 0, nullptr, stream);
+}
+
+extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
+                                   const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
+                                   void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream) {
+    FT_CHECK_ARG(dy && w_hh && lens && gates && cell && (dgx || dimg) && work && status);
+    FT_CHECK_ARG(dimg == nullptr || (dbias && dimg_ld >= 4 * (int64_t)H && dimg_ld % 8 == 0 && dimg_rows >= (int64_t)T * B + B &&
+                                     reinterpret_cast<uintptr_t>(dimg) % 16 == 0));
     FT_CHECK_ARG(T >= 0 && ldy >= H && reinterpret_cast<uintptr_t>(work) % 256 == 0);
     const bool bare = ng > 10;
     const int ngb = bare ? ng - 10 : ng;
@@ -813,7 +865,8 @@ extern "C" int FT_OPNAME(ft_lstm_persist_bwd)(const float* dy, int64_t ldy, cons
     FT_CHECK_HIP(hipMemsetAsync(dgran, bare ? 0xFF : 0, gran_bytes, st));
     FT_CHECK_HIP(hipMemsetAsync(census, 0, 256, st));
     hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H);
-    PersistBwdP p{dy, (long)ldy, lens, gates, cell, dgx, wTfrag, dgran, status, census, T, B, 100000000L / 2, g_persist_prof};
+    PersistBwdP p{dy, (long)ldy, lens, gates, cell, dgx, wTfrag, dgran, status, census, T, B, 100000000L / 2, g_persist_prof,
+                  reinterpret_cast<unsigned short*>(dimg), (long)dimg_ld, (int)dimg_rows, dbias};
     // dynamic LDS: 16-partial reduce (2 x 16 x 32 unit-rows... = 2*16*TL*RPGP*17 = 2*16*8*17 floats) + staged steps
     const size_t lds = sizeof(float) * ((size_t)2 * 16 * 8 * 17 + (size_t)RING * 5 * 128 + (size_t)RING * 128 + (size_t)2 * 4 * 128);
     auto launch = [&](auto kern) -> int {

@@ -74,6 +74,7 @@ class RowMap:
 
 
 _COMPACT = _os.environ.get("FLOWTRON_GEMM_COMPACT", "1") != "0"
+_PERSIST_IMG = _os.environ.get("FLOWTRON_LSTM_PERSIST_IMG", "1")      # 1: the persistent backward emits the dgates image INSTEAD of fp32 dgx where its only consumer is the projection's backward; both; 0
 
 
 def row_map(lens32, T, B):
@@ -113,6 +114,17 @@ class Bf16Image:
     def ptr(self, row_off=0, col_off=0):
         assert col_off % 8 == 0
         return self.buf.data_ptr() + 2 * (row_off * self.ld + col_off)
+
+    @classmethod
+    def empty_rows(cls, cols, rowmap, mode, device):
+        """an UNWRITTEN compact image over `rowmap` ([cap, cols] 16-bit payloads of format `mode`) with zeroed column sums, for a
+        kernel that produces the image itself (ft_lstm_persist_bwd_img)"""
+        self = cls.__new__(cls)
+        self.rows, self.cols, self.fmt, self.rowmap = rowmap.cap, int(cols), mode, rowmap
+        self.ld = (self.cols + 255) // 256 * 256
+        self.buf = torch.empty(L.lib().ft_bf16_image_bytes(self.rows, self.cols), device=device, dtype=torch.uint8)
+        self.colsum = torch.zeros(self.cols, device=device, dtype=torch.float32)
+        return self
 
 
 # images of activations are shared between every consumer of the SAME tensor (h_att feeds the query projection, the gate and
@@ -165,11 +177,12 @@ def gemm_img(A, a_km, a_ptr, B, b_km, b_ptr, Cm, M, N, K, ldc, bias=None, act=L.
 # hand-off of an output-gradient image between two autograd nodes of the SAME backward pass (the LSTM backward builds the
 # image of dgates for its own dW_hh GEMM; the input projection's LinearFn.backward receives that very tensor as dy).
 # Keyed by (device, data_ptr, shape); cleared by an engine callback at the end of the pass, so an address can never match stale data.
-_HANDOFF = {"imgs": {}, "armed": False}
+_HANDOFF = {"imgs": {}, "armed": False, "unwritten": set()}
 
 
 def _handoff_clear():
     _HANDOFF["imgs"].clear()
+    _HANDOFF["unwritten"].clear()
     _HANDOFF["armed"] = False
 
 
@@ -187,6 +200,21 @@ def _handoff_take(t):
     return _HANDOFF["imgs"].pop((t.device.index, t.data_ptr(), tuple(t.shape)), None)
 
 
+def _handoff_put_image_only(t, img):
+    """as _handoff_put, for a gradient tensor whose fp32 storage was NOT written (only its image exists): a consumer that would
+    read the fp32 values fails loudly (_require_written)"""
+    _handoff_put(t, img)
+    if not _HANDOFF["armed"]:
+        raise RuntimeError("flowtron_amd: an image-only gradient outside a backward pass")
+    _HANDOFF["unwritten"].add((t.device.index, t.data_ptr(), tuple(t.shape)))
+
+
+def _require_written(t):
+    if (t.device.index, t.data_ptr(), tuple(t.shape)) in _HANDOFF["unwritten"]:
+        raise RuntimeError("flowtron_amd: this gradient exists only as a 16-bit operand image (ft_lstm_persist_bwd_img); its consumer "
+                           "must take the image (set FLOWTRON_LSTM_PERSIST_IMG=both to keep the fp32 copy)")
+
+
 def colsum(x2d: torch.Tensor, rows: int, N: int, ld: int) -> torch.Tensor:
     out = torch.empty(N, device=x2d.device, dtype=torch.float32)
     L.check(L.lib().ft_colsum(L.ptr(x2d), L.ptr(out), rows, N, ld, L.stream()), "ft_colsum")
@@ -201,6 +229,11 @@ def lens32(lens: torch.Tensor) -> torch.Tensor:
 # Linear over one or two row-blocks of the weight:  y = act(sum_i x_i W[:, off_i:off_i+K_i]^T + b)
 # (nn.Linear / 1x1 Conv1d / LSTM input projection call sites, flowtron.py:568-571, :758, :767-768)
 # --------------------------------------------------------------------------
+def linear_uses_images(mode, rows, N, xs):
+    """whether LinearFn runs (and differentiates) this projection through shared 16-bit operand images"""
+    return all(images_apply(mode, rows, N, x.shape[-1]) for x in xs) and all((x.shape[-1] % 8 == 0) for x in xs[:-1])
+
+
 class LinearFn(torch.autograd.Function):
     """rowmap (RowMap | None): the inputs are time-major [T,B,K] activations of a padded batch; in the 16-bit image path the
     GEMMs then run over the VALID rows only (the reference packs them, flowtron.py:689-694): compact images, output rows
@@ -218,7 +251,7 @@ class LinearFn(torch.autograd.Function):
         N, Ktot = W.shape
         rows = xs[0].numel() // xs[0].shape[-1]
         y = torch.empty(xs[0].shape[:-1] + (N,), device=W.device, dtype=torch.float32)
-        use_img = all(images_apply(mode, rows, N, x.shape[-1]) for x in xs) and all((x.shape[-1] % 8 == 0) for x in xs[:-1])
+        use_img = linear_uses_images(mode, rows, N, xs)
         if rowmap is not None and (not use_img or rows != rowmap.T * rowmap.B):
             rowmap = None
         ctx.imgs = None
@@ -270,8 +303,11 @@ class LinearFn(torch.autograd.Function):
             if d_img is not None and (d_img.fmt != w_img.fmt or d_img.rowmap is not rowmap or (want_db and d_img.colsum is None)):
                 d_img = None
             if d_img is None:
+                _require_written(dpre)
                 d_img = Bf16Image(dpre.reshape(rows, N), colsum=want_db, mode=w_img.fmt, rowmap=rowmap)   # bias gradient rides on the conversion pass
             db = d_img.colsum if want_db else None
+        if imgs is None:
+            _require_written(dpre)
         if want_db and db is None:
             db = colsum(dpre, rows, N, N)
         mrows = rows if rowmap is None else rowmap.cap
@@ -556,7 +592,10 @@ def lstm_persist_groups(B, H, reverse, mode, device=None):
 
 class LSTMSeqFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, gx, w_hh, lens, reverse, mode, rowmap=None):
+    def forward(ctx, gx, w_hh, lens, reverse, mode, rowmap=None, gx_private=False):
+        """gx_private: gx comes straight from a LinearFn over the same rowmap that differentiates through images (lstm_layer), so
+        its gradient may be handed over as the 16-bit image alone"""
+        ctx.gx_private = bool(gx_private)
         gx, w_hh = _c(gx), _c(w_hh)
         L.require_cuda(gx, w_hh, lens)
         T, B, H4 = gx.shape
@@ -587,6 +626,7 @@ class LSTMSeqFn(torch.autograd.Function):
         T, B, H = y.shape
         dgx = torch.empty(T, B, 4 * H, device=dy.device, dtype=torch.float32)
         ng = lstm_persist_groups(B, H, ctx.reverse, ctx.mode, dy.device)
+        d_img_k, img_only = None, False
         if ng:
             # default (1): the forward recurrence keeps the tagged granules (1.94 vs 2.06 us per step: its publish sits on the
             # critical path and the sentinel protocol adds a store + wait there), the backward one takes the BARE operand pairs
@@ -596,8 +636,21 @@ class LSTMSeqFn(torch.autograd.Function):
             ng = ng if ng in (1, 9, 8, 4, 11, 19, 18, 14) else (18 if ng > 10 else 8)      # (no 2-group backward kernel)
             st = _persist_watch(dy.device)
             work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=dy.device, dtype=torch.uint8)
-            L.check(L.op16("ft_lstm_persist_bwd", ctx.mode)(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
-                                                L.ptr(work), L.ptr(st.status), T, B, H, ng, L.stream()), "ft_lstm_persist_bwd")
+            rm = ctx.rowmap
+            if (_PERSIST_IMG != "0" and rm is not None and ctx.needs_input_grad[1] and T > 1 and images_apply(ctx.mode, 4 * H, H, (T - 1) * B)
+                    and (ctx.gx_private or _PERSIST_IMG == "both")):
+                # the output waves leave the compact 16-bit image of dgates and its column sums INSTEAD of the fp32 rows (beside
+                # them with FLOWTRON_LSTM_PERSIST_IMG=both: 3.07 vs 2.91 us per step): no 450 MB dgx, no conversion pass over it
+                d_img_k = Bf16Image.empty_rows(4 * H, rm, ctx.mode, dy.device)
+                img_only = _PERSIST_IMG != "both"
+                L.check(L.op16("ft_lstm_persist_bwd_img", ctx.mode)(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(gates), L.ptr(cell),
+                                                    None if img_only else L.ptr(dgx),
+                                                    L.ptr(work), L.ptr(st.status), T, B, H, ng, L.ptr(d_img_k.buf), d_img_k.ld,
+                                                    d_img_k.buf.numel() // (2 * d_img_k.ld), L.ptr(d_img_k.colsum), L.stream()),
+                        "ft_lstm_persist_bwd_img")
+            else:
+                L.check(L.op16("ft_lstm_persist_bwd", ctx.mode)(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
+                                                    L.ptr(work), L.ptr(st.status), T, B, H, ng, L.stream()), "ft_lstm_persist_bwd")
             _persist_arm(st)
         else:
             work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=dy.device, dtype=torch.uint8)
@@ -614,9 +667,13 @@ class LSTMSeqFn(torch.autograd.Function):
             if T > 1 and images_apply(ctx.mode, 4 * H, H, rows) and rm is not None:
                 # compact images (valid frames only, batch-major with one zero separator row per utterance): the one-step shift
                 # dgates_t <-> h_{t-1} is a shift by ONE compact row, and the utterance boundaries multiply with a separator
-                d_img, y_img = Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True, mode=ctx.mode, rowmap=rm), shared_image(y, T * B, H, ctx.mode, rm)
+                d_img = d_img_k if d_img_k is not None else Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True, mode=ctx.mode, rowmap=rm)
+                y_img = shared_image(y, T * B, H, ctx.mode, rm)
                 gemm_img(d_img, 1, d_img.ptr(1), y_img, 1, y_img.ptr(0), dW, 4 * H, H, rm.cap, H, splitk=True, rowmap=rm, compact=2, k_shift=1)
-                _handoff_put(dgx, d_img)        # the input projection's backward reads the same dgates
+                if img_only:
+                    _handoff_put_image_only(dgx, d_img)     # ... and ONLY the image exists
+                else:
+                    _handoff_put(dgx, d_img)    # the input projection's backward reads the same dgates
             elif T > 1 and images_apply(ctx.mode, 4 * H, H, rows):
                 # images of dgates / outputs over all T*B rows; the one-step shift is a row offset into them
                 d_img, y_img = Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True, mode=ctx.mode), shared_image(y, T * B, H, ctx.mode)
@@ -625,7 +682,7 @@ class LSTMSeqFn(torch.autograd.Function):
                 _handoff_put(dgx, d_img)        # the input projection's backward reads the same dgates
             elif T > 1:
                 gemm_raw(da, hp, dW, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=ctx.mode, splitk=True)
-        return dgx, dW, None, None, None, None
+        return dgx, dW, None, None, None, None, None
 
 
 def lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=False, mode=None, xs_extra=None, rowmap=None, fill=""):
@@ -638,7 +695,9 @@ def lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=False, mode=None, xs_ext
     if reverse:
         rowmap = None
     gx = LinearFn.apply(w_ih, b_ih + b_hh, L.ACT_NONE, mode, rowmap, fill, *xs)
-    return LSTMSeqFn.apply(gx, w_hh, lens, reverse, mode, rowmap)
+    T, B = x.shape[0], x.shape[1]
+    private = rowmap is not None and rowmap.T == T and rowmap.B == B and linear_uses_images(mode, T * B, w_ih.shape[0], xs)
+    return LSTMSeqFn.apply(gx, w_hh, lens, reverse, mode, rowmap, private)
 
 
 class BiLSTMSeqFn(torch.autograd.Function):

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 6
+#define FT_ABI_VERSION 7
 
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1, FT_F16 = 2 };
@@ -176,6 +176,15 @@ int ft_lstm_persist_debug_prof(void* dev_buf);
  * W_hh; bit-identical to ft_lstm_seq_bwd(FT_BF16).  Same workspace query. */
 int ft_lstm_persist_bwd(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
                         const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng, void* stream);
+/* The same launch, additionally leaving the 16-bit operand image of dgates in pack-by-length row order in `dimg` -- exactly what
+ * ft_bf16_image_rows(dgx, ..., rowmap of `lens`) would produce afterwards (utterance b = its len_b frames + one zero separator
+ * row, batch-major; zero rows up to ceil256(R + 32); dimg: ft_bf16_image_bytes(T*B + B, 4H), row stride dimg_ld elements,
+ * dimg_rows rows allocated) -- and ADDING the column sums of dgates (the bias gradient of the layer) to dbias[4H] (zeroed by the
+ * caller; fp32 atomics, one per workgroup row and column).  The weight- and input-gradient GEMMs (flowtron.py:689-694's
+ * autograd transposes) then start without a conversion pass over the 450 MB dgx.  dimg == NULL: identical to ft_lstm_persist_bwd. */
+int ft_lstm_persist_bwd_img(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
+                            const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
+                            void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream);
 
 /* Two stacked layers (the decoder nn.LSTM(.., num_layers=2), flowtron.py:654, :760-765) as ONE launch chain: layer 1 at
  * time t-1 and layer 0 at time t are two workgroup groups of the same launch, and layer 1's input projection
@@ -403,6 +412,9 @@ int ft_lstm_persist_fwd_f16(const float* gx, const float* w_hh, const int32_t* l
                         float* gates, float* cell, void* work, int32_t* status, int T, int B, int H, int ng, void* stream);
 int ft_lstm_persist_bwd_f16(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
                         const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng, void* stream);
+int ft_lstm_persist_bwd_img_f16(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
+                            const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
+                            void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream);
 int ft_lstm2_seq_fwd_f16(const float* gx0, const float* w_hh0, const float* w_ih1, const float* bias1, const float* w_hh1,
                      const int32_t* lens, float* y0, float* gates0, float* cell0, float* y1, float* gates1, float* cell1,
                      void* work, int T, int B, int H, void* stream);

@@ -652,6 +652,77 @@ def test_persistent_lstm_backward_is_bit_identical_to_launch_per_step(env, ng, T
     assert float(d1[~act].abs().max() if (~act).any() else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("ng", [1, 11])
+@pytest.mark.parametrize("T,B,lens", [(37, 32, None), (9, 5, [9, 9, 4, 2, 1]), (40, 32, "ragged0"), (862, 32, "bench")])
+def test_persistent_backward_emits_the_compact_dgates_image(env, fmt, ng, T, B, lens):
+    """ft_lstm_persist_bwd_img: the same dgx as ft_lstm_persist_bwd, plus the compact 16-bit image of dgates -- bit-identical to
+    ft_bf16_image_rows over that dgx (valid rows, zero separators, zero rows up to ceil256(R + 32)) -- and its column sums."""
+    L, ops = env
+    H = 1024
+    if not L.lib().ft_lstm_persist_supported(B, H):
+        pytest.skip("needs a 256-CU device")
+    torch.manual_seed(T * 10 + B + fmt)
+    gx = torch.randn(T, B, 4 * H, device="cuda") * 0.5
+    w = torch.randn(4 * H, H, device="cuda") / H ** 0.5
+    dy = torch.randn(T, B, H, device="cuda") * 0.1
+    if lens == "ragged0":
+        lens = [T] + [max(1, (T * (B - i)) // B - (i % 3)) for i in range(1, B)]
+    else:
+        lens = _bench_lens(lens, ng)
+    if lens is None:
+        lens = [max(1, T - 2 * i) for i in range(B)]
+    lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    y, gates, cell = torch.empty(T, B, H, device="cuda"), torch.zeros(T, B, 4 * H, device="cuda"), torch.zeros(T, B, H, device="cuda")
+    work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device="cuda", dtype=torch.uint8)
+    L.check(L.lib().ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens_t), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(work),
+                                    T, B, H, 0, fmt, L.stream()), "ft_lstm_seq_fwd")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    wp = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device="cuda", dtype=torch.uint8)
+    d0 = torch.full((T, B, 4 * H), 7.0, device="cuda")
+    d1 = torch.full((T, B, 4 * H), 7.0, device="cuda")
+    L.check(L.op16("ft_lstm_persist_bwd", fmt)(L.ptr(dy), H, L.ptr(w), L.ptr(lens_t), L.ptr(gates), L.ptr(cell), L.ptr(d0), L.ptr(wp),
+                                               L.ptr(status), T, B, H, ng, L.stream()), "ft_lstm_persist_bwd")
+    rm = ops.RowMap(lens_t, T, B)
+    img = ops.Bf16Image.empty_rows(4 * H, rm, fmt, torch.device("cuda"))
+    img.buf.fill_(0x5A)                                                 # whatever the allocator left behind
+    rows_alloc = img.buf.numel() // (2 * img.ld)
+    L.check(L.op16("ft_lstm_persist_bwd_img", fmt)(L.ptr(dy), H, L.ptr(w), L.ptr(lens_t), L.ptr(gates), L.ptr(cell), L.ptr(d1), L.ptr(wp),
+                                                   L.ptr(status), T, B, H, ng, L.ptr(img.buf), img.ld, rows_alloc, L.ptr(img.colsum),
+                                                   L.stream()), "ft_lstm_persist_bwd_img")
+    img2 = ops.Bf16Image.empty_rows(4 * H, rm, fmt, torch.device("cuda"))          # image ONLY: no fp32 dgx at all
+    img2.buf.fill_(0x33)
+    L.check(L.op16("ft_lstm_persist_bwd_img", fmt)(L.ptr(dy), H, L.ptr(w), L.ptr(lens_t), L.ptr(gates), L.ptr(cell), None, L.ptr(wp),
+                                                   L.ptr(status), T, B, H, ng, L.ptr(img2.buf), img2.ld, rows_alloc, L.ptr(img2.colsum),
+                                                   L.stream()), "ft_lstm_persist_bwd_img (image only)")
+    ref = ops.Bf16Image(d0.reshape(T * B, 4 * H), colsum=True, mode=fmt, rowmap=rm)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0 and torch.equal(d0, d1)
+    R = sum(lens) + B
+    Rz = min((R + 32 + 255) // 256 * 256, rows_alloc)
+    a = img.buf[: Rz * img.ld * 2].view(torch.int16).view(Rz, img.ld)[:, : 4 * H]
+    b = ref.buf[: Rz * ref.ld * 2].view(torch.int16).view(Rz, ref.ld)[:, : 4 * H]
+    assert torch.equal(a, b)
+    assert float((img.colsum - ref.colsum).abs().max()) <= 1e-4 * float(ref.colsum.abs().max()) + 1e-6
+    a2 = img2.buf[: Rz * img2.ld * 2].view(torch.int16).view(Rz, img2.ld)[:, : 4 * H]
+    assert torch.equal(a2, b)
+    assert float((img2.colsum - ref.colsum).abs().max()) <= 1e-4 * float(ref.colsum.abs().max()) + 1e-6
+
+
+def test_image_only_gradient_fails_loudly_when_read_as_fp32(env):
+    """ops._require_written: a gradient that exists only as its 16-bit image must never be read as fp32 by a consumer that missed
+    the hand-off"""
+    L, ops = env
+    t = torch.empty(4, 8, device="cuda")
+    ops._HANDOFF["unwritten"].add((t.device.index, t.data_ptr(), tuple(t.shape)))
+    try:
+        with pytest.raises(RuntimeError, match="only as a 16-bit operand image"):
+            ops._require_written(t)
+        ops._require_written(torch.empty(4, 8, device="cuda"))             # any other tensor: fine
+    finally:
+        ops._handoff_clear()
+
+
 # ---------------------------------------------------------------- pack-by-length (compact) image GEMMs
 def _valid_mask(T, B, lens):
     return (torch.arange(T)[:, None] < torch.tensor(lens)[None, :])          # [T,B]
