@@ -85,6 +85,10 @@ SIGNATURES = {
     "ft_lstm_persist_fwd": ([_p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_lstm_persist_debug_prof": ([_p], _i),
     "ft_lstm_persist_bwd": ([_p, _l, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "ft_bilstm_persist_supported": ([_i, _i], _i),
+    "ft_bilstm_persist_workspace_bytes": ([_i, _i], C.c_size_t),
+    "ft_bilstm_persist_fwd": ([_p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "ft_bilstm_persist_bwd": ([_p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "ft_lstm_persist_bwd_img": ([_p, _l, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _l, _l, _p, _p], _i),
     "ft_lstm2_supported": ([_i, _i], _i),
     "ft_lstm2_workspace_bytes": ([_i, _i], _sz),
@@ -128,7 +132,7 @@ SIGNATURES = {
 # fp16-operand twins (include/flowtron_hip.h, end): same signatures, suffix _f16
 OP16_TWINS = ("ft_gemm", "ft_bf16_image", "ft_bf16_image_colsum", "ft_gemm_img", "ft_bf16_image_rows", "ft_lstm_seq_fwd", "ft_lstm_seq_bwd",
               "ft_lstm_persist_fwd", "ft_lstm_persist_bwd", "ft_lstm_persist_bwd_img", "ft_lstm2_seq_fwd", "ft_lstm2_seq_bwd",
-              "ft_lstm_bidir_seq_fwd", "ft_lstm_bidir_seq_bwd")
+              "ft_lstm_bidir_seq_fwd", "ft_lstm_bidir_seq_bwd", "ft_bilstm_persist_fwd", "ft_bilstm_persist_bwd")
 for _n in OP16_TWINS:
     SIGNATURES[_n + "_f16"] = SIGNATURES[_n]
 
@@ -148,7 +152,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argt
             fn.restype = rest
-        if l.ft_abi_version() != 7:
+        if l.ft_abi_version() != 8:
             raise RuntimeError("libflowtron_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -509,9 +509,15 @@ def persist_consume_failure(device):
 PERSIST_LAUNCHES = 0          # persistent (whole-chip, co-resident) kernel launches so far: dist.py keeps collectives away from them
 
 
-def _persist_arm(st):
-    global PERSIST_LAUNCHES
-    PERSIST_LAUNCHES += 1
+BILSTM_PERSIST_LAUNCHES = 0   # launches of the encoder's persistent bidirectional kernels (csrc/bilstm_persist.hip)
+
+
+def _persist_arm(st, bilstm=False):
+    global PERSIST_LAUNCHES, BILSTM_PERSIST_LAUNCHES
+    if bilstm:
+        BILSTM_PERSIST_LAUNCHES += 1
+    else:
+        PERSIST_LAUNCHES += 1
     st.host.copy_(st.status, non_blocking=True)
     st.event = torch.cuda.Event()
     st.event.record()
@@ -588,6 +594,19 @@ def lstm_persist_groups(B, H, reverse, mode, device=None):
         if not st.usable:
             return 0
     return ng
+
+
+def bilstm_persist_ok(B, H, mode, device):
+    """the encoder-shaped persistent bidirectional kernels (H 256, B <= 32, 16-bit operands) on a device whose persistent grids
+    passed the self-test; FLOWTRON_BILSTM_PERSIST=0 or FLOWTRON_LSTM_PERSIST=0 keep the launch-per-step pair chain"""
+    if _os.environ.get("FLOWTRON_BILSTM_PERSIST", "1") == "0" or int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "1")) == 0:
+        return False
+    if not L.is16(mode) or not L.lib().ft_bilstm_persist_supported(B, H):
+        return False
+    st = _persist_state(device)
+    if st.usable is None:
+        st.usable = _persist_selftest(device, int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "1")))
+    return bool(st.usable)
 
 
 class LSTMSeqFn(torch.autograd.Function):
@@ -714,11 +733,19 @@ class BiLSTMSeqFn(torch.autograd.Function):
         y = torch.empty(T, B, 2 * H, **f)
         gates = [torch.empty(T, B, H4, **f) for _ in range(2)]
         cell = [torch.empty(T, B, H, **f) for _ in range(2)]
-        nb = L.lib().ft_lstm_workspace_bytes(B, H)
-        work = [torch.empty(nb, device=gx_f.device, dtype=torch.uint8) for _ in range(2)]
-        L.check(L.op16("ft_lstm_bidir_seq_fwd", mode)(L.ptr(gx_f), L.ptr(gx_r), L.ptr(w_f), L.ptr(w_r), L.ptr(lens), L.ptr(y), 2 * H,
-                                              L.ptr(gates[0]), L.ptr(gates[1]), L.ptr(cell[0]), L.ptr(cell[1]),
-                                              L.ptr(work[0]), L.ptr(work[1]), T, B, H, L.stream()), "ft_lstm_bidir_seq_fwd")
+        if bilstm_persist_ok(B, H, mode, gx_f.device):
+            st = _persist_watch(gx_f.device)
+            work = torch.empty(L.lib().ft_bilstm_persist_workspace_bytes(B, H), device=gx_f.device, dtype=torch.uint8)
+            L.check(L.op16("ft_bilstm_persist_fwd", mode)(L.ptr(gx_f), L.ptr(gx_r), L.ptr(w_f), L.ptr(w_r), L.ptr(lens), L.ptr(y), 2 * H,
+                                                  L.ptr(gates[0]), L.ptr(gates[1]), L.ptr(cell[0]), L.ptr(cell[1]),
+                                                  L.ptr(work), L.ptr(st.status), T, B, H, L.stream()), "ft_bilstm_persist_fwd")
+            _persist_arm(st, bilstm=True)
+        else:
+            nb = L.lib().ft_lstm_workspace_bytes(B, H)
+            work = [torch.empty(nb, device=gx_f.device, dtype=torch.uint8) for _ in range(2)]
+            L.check(L.op16("ft_lstm_bidir_seq_fwd", mode)(L.ptr(gx_f), L.ptr(gx_r), L.ptr(w_f), L.ptr(w_r), L.ptr(lens), L.ptr(y), 2 * H,
+                                                  L.ptr(gates[0]), L.ptr(gates[1]), L.ptr(cell[0]), L.ptr(cell[1]),
+                                                  L.ptr(work[0]), L.ptr(work[1]), T, B, H, L.stream()), "ft_lstm_bidir_seq_fwd")
         ctx.save_for_backward(w_f, w_r, lens, y, gates[0], gates[1], cell[0], cell[1])
         return y
 
@@ -730,11 +757,19 @@ class BiLSTMSeqFn(torch.autograd.Function):
         H = H2 // 2
         f = dict(device=dy.device, dtype=torch.float32)
         dgx = [torch.empty(T, B, 4 * H, **f) for _ in range(2)]
-        nb = L.lib().ft_lstm_workspace_bytes(B, H)
-        work = [torch.empty(nb, device=dy.device, dtype=torch.uint8) for _ in range(2)]
-        L.check(L.op16("ft_lstm_bidir_seq_bwd", ctx.mode)(L.ptr(dy), 2 * H, L.ptr(w_f), L.ptr(w_r), L.ptr(lens), L.ptr(g0), L.ptr(g1),
-                                              L.ptr(c0), L.ptr(c1), L.ptr(dgx[0]), L.ptr(dgx[1]), L.ptr(work[0]), L.ptr(work[1]),
-                                              T, B, H, L.stream()), "ft_lstm_bidir_seq_bwd")
+        if bilstm_persist_ok(B, H, ctx.mode, dy.device):
+            st = _persist_watch(dy.device)
+            work = torch.empty(L.lib().ft_bilstm_persist_workspace_bytes(B, H), device=dy.device, dtype=torch.uint8)
+            L.check(L.op16("ft_bilstm_persist_bwd", ctx.mode)(L.ptr(dy), 2 * H, L.ptr(w_f), L.ptr(w_r), L.ptr(lens), L.ptr(g0), L.ptr(g1),
+                                                  L.ptr(c0), L.ptr(c1), L.ptr(dgx[0]), L.ptr(dgx[1]), L.ptr(work), L.ptr(st.status),
+                                                  T, B, H, L.stream()), "ft_bilstm_persist_bwd")
+            _persist_arm(st, bilstm=True)
+        else:
+            nb = L.lib().ft_lstm_workspace_bytes(B, H)
+            work = [torch.empty(nb, device=dy.device, dtype=torch.uint8) for _ in range(2)]
+            L.check(L.op16("ft_lstm_bidir_seq_bwd", ctx.mode)(L.ptr(dy), 2 * H, L.ptr(w_f), L.ptr(w_r), L.ptr(lens), L.ptr(g0), L.ptr(g1),
+                                                  L.ptr(c0), L.ptr(c1), L.ptr(dgx[0]), L.ptr(dgx[1]), L.ptr(work[0]), L.ptr(work[1]),
+                                                  T, B, H, L.stream()), "ft_lstm_bidir_seq_bwd")
         dWs = [None, None]
         rows = (T - 1) * B
         for d in range(2):

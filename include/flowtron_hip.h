@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 7
+#define FT_ABI_VERSION 8
 
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1, FT_F16 = 2 };
@@ -214,6 +214,20 @@ int ft_lstm_bidir_seq_fwd(const float* gx_f, const float* gx_r, const float* w_h
 int ft_lstm_bidir_seq_bwd(const float* dy, int64_t ldy, const float* w_hh_f, const float* w_hh_r, const int32_t* lens,
                           const float* gates_f, const float* gates_r, const float* cell_f, const float* cell_r,
                           float* dgx_f, float* dgx_r, void* work_f, void* work_r, int T, int B, int H, void* stream);
+
+/* Persistent form of ft_lstm_bidir_seq_* for the text encoder's shape (H == 256, B <= 32, 256-CU device, 16-bit operands): ONE launch
+ * per pass for both directions and all time steps (csrc/bilstm_persist.hip: every wave an independent agent, no workgroup-level
+ * step, XCD-local hand-off).  Same tensors as ft_lstm_bidir_seq_*; one workspace (ft_bilstm_persist_workspace_bytes, 256-byte
+ * aligned); `status` as for ft_lstm_persist_*.  Same operand rounding as the launch-per-step chain, different fp32 summation order
+ * (K is not split over waves): results agree to rounding, not bit for bit. */
+int ft_bilstm_persist_supported(int B, int H);
+size_t ft_bilstm_persist_workspace_bytes(int B, int H);
+int ft_bilstm_persist_fwd(const float* gx_f, const float* gx_r, const float* w_hh_f, const float* w_hh_r, const int32_t* lens,
+                          float* y, int64_t ldy, float* gates_f, float* gates_r, float* cell_f, float* cell_r,
+                          void* work, int32_t* status, int T, int B, int H, void* stream);
+int ft_bilstm_persist_bwd(const float* dy, int64_t ldy, const float* w_hh_f, const float* w_hh_r, const int32_t* lens,
+                          const float* gates_f, const float* gates_r, const float* cell_f, const float* cell_r,
+                          float* dgx_f, float* dgx_r, void* work, int32_t* status, int T, int B, int H, void* stream);
 
 /* ---- additive attention scores + softmax + prior posterior (flowtron.py:544-583)
  * Q [T,B,A] (time-major), K [L,B,A], v [A], in_lens [B], prior [B,T,L] or NULL.
@@ -427,6 +441,12 @@ int ft_lstm_bidir_seq_fwd_f16(const float* gx_f, const float* gx_r, const float*
 int ft_lstm_bidir_seq_bwd_f16(const float* dy, int64_t ldy, const float* w_hh_f, const float* w_hh_r, const int32_t* lens,
                           const float* gates_f, const float* gates_r, const float* cell_f, const float* cell_r,
                           float* dgx_f, float* dgx_r, void* work_f, void* work_r, int T, int B, int H, void* stream);
+int ft_bilstm_persist_fwd_f16(const float* gx_f, const float* gx_r, const float* w_hh_f, const float* w_hh_r, const int32_t* lens,
+                          float* y, int64_t ldy, float* gates_f, float* gates_r, float* cell_f, float* cell_r,
+                          void* work, int32_t* status, int T, int B, int H, void* stream);
+int ft_bilstm_persist_bwd_f16(const float* dy, int64_t ldy, const float* w_hh_f, const float* w_hh_r, const int32_t* lens,
+                          const float* gates_f, const float* gates_r, const float* cell_f, const float* cell_r,
+                          float* dgx_f, float* dgx_r, void* work, int32_t* status, int T, int B, int H, void* stream);
 
 #ifdef __cplusplus
 }

@@ -723,6 +723,78 @@ def test_image_only_gradient_fails_loudly_when_read_as_fp32(env):
         ops._handoff_clear()
 
 
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("T,B,lens", [(157, 32, "ragged"), (9, 5, [9, 9, 4, 2, 1]), (40, 17, None), (33, 32, "full")])
+def test_persistent_bilstm_matches_the_launch_per_step_pair_chain(env, fmt, T, B, lens):
+    """csrc/bilstm_persist.hip (the text encoder's BiLSTM, H 256, one launch per pass for both directions) against the pair chain
+    ft_lstm_bidir_seq_*: same 16-bit operand rounding, different fp32 summation order (K is not split over waves) -> y, saved gates /
+    cell and dgx agree to rounding; y and dgx are exactly zero on padded frames."""
+    L, ops = env
+    H = 256
+    if not L.lib().ft_bilstm_persist_supported(B, H):
+        pytest.skip("needs a 256-CU device")
+    torch.manual_seed(T + B + fmt)
+    if lens == "ragged":
+        lens = [T] + [max(1, T - 4 * i - (i % 3)) for i in range(1, B)]
+    elif lens == "full":
+        lens = [T] * B
+    elif lens is None:
+        lens = [max(1, T - 2 * i) for i in range(B)]
+    lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    gx = [torch.randn(T, B, 4 * H, device="cuda") * 0.7 for _ in range(2)]
+    w = [torch.randn(4 * H, H, device="cuda") / H ** 0.5 for _ in range(2)]
+    dy = torch.randn(T, B, 2 * H, device="cuda") * 0.1
+    f = dict(device="cuda", dtype=torch.float32)
+    res = []
+    for persistent in (False, True):
+        y = torch.full((T, B, 2 * H), 7.0, **f)
+        gates = [torch.zeros(T, B, 4 * H, **f) for _ in range(2)]
+        cell = [torch.zeros(T, B, H, **f) for _ in range(2)]
+        dgx = [torch.full((T, B, 4 * H), 7.0, **f) for _ in range(2)]
+        if persistent:
+            status = torch.zeros(1, dtype=torch.int32, device="cuda")
+            wk = torch.empty(L.lib().ft_bilstm_persist_workspace_bytes(B, H), device="cuda", dtype=torch.uint8)
+            L.check(L.op16("ft_bilstm_persist_fwd", fmt)(L.ptr(gx[0]), L.ptr(gx[1]), L.ptr(w[0]), L.ptr(w[1]), L.ptr(lens_t), L.ptr(y), 2 * H,
+                                                         L.ptr(gates[0]), L.ptr(gates[1]), L.ptr(cell[0]), L.ptr(cell[1]), L.ptr(wk),
+                                                         L.ptr(status), T, B, H, L.stream()), "ft_bilstm_persist_fwd")
+            L.check(L.op16("ft_bilstm_persist_bwd", fmt)(L.ptr(dy), 2 * H, L.ptr(w[0]), L.ptr(w[1]), L.ptr(lens_t), L.ptr(gates[0]),
+                                                         L.ptr(gates[1]), L.ptr(cell[0]), L.ptr(cell[1]), L.ptr(dgx[0]), L.ptr(dgx[1]),
+                                                         L.ptr(wk), L.ptr(status), T, B, H, L.stream()), "ft_bilstm_persist_bwd")
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0
+        else:
+            wk = [torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device="cuda", dtype=torch.uint8) for _ in range(2)]
+            L.check(L.op16("ft_lstm_bidir_seq_fwd", fmt)(L.ptr(gx[0]), L.ptr(gx[1]), L.ptr(w[0]), L.ptr(w[1]), L.ptr(lens_t), L.ptr(y), 2 * H,
+                                                         L.ptr(gates[0]), L.ptr(gates[1]), L.ptr(cell[0]), L.ptr(cell[1]), L.ptr(wk[0]),
+                                                         L.ptr(wk[1]), T, B, H, L.stream()), "ft_lstm_bidir_seq_fwd")
+            L.check(L.op16("ft_lstm_bidir_seq_bwd", fmt)(L.ptr(dy), 2 * H, L.ptr(w[0]), L.ptr(w[1]), L.ptr(lens_t), L.ptr(gates[0]),
+                                                         L.ptr(gates[1]), L.ptr(cell[0]), L.ptr(cell[1]), L.ptr(dgx[0]), L.ptr(dgx[1]),
+                                                         L.ptr(wk[0]), L.ptr(wk[1]), T, B, H, L.stream()), "ft_lstm_bidir_seq_bwd")
+            torch.cuda.synchronize()
+        res.append((y, gates, cell, dgx))
+    act = torch.arange(T, device="cuda")[:, None] < lens_t[None, :]
+    (y0, g0, c0, d0), (y1, g1, c1, d1) = res
+    assert float(y1[~act].abs().max() if (~act).any() else 0.0) == 0.0
+    # a 1e-7 difference in a pre-activation can flip the 16-bit rounding of h_t (1 ulp = 4e-3 relative), and 157 steps carry it
+    # on: the two implementations sit 3-9e-4 apart and EQUALLY far (1.06e-3) from the fp32 oracle (scripts/exp/bilstm_persist_check.py)
+    tol = 3e-3 if fmt == 1 else 6e-4
+    assert float((y0 - y1).abs().max()) < tol
+    for d in range(2):
+        assert float((g0[d][act] - g1[d][act]).abs().max()) < tol and float((c0[d][act] - c1[d][act]).abs().max()) < 2 * tol
+        assert float(d1[d][~act].abs().max() if (~act).any() else 0.0) == 0.0
+        scale = float(d0[d].abs().max())
+        assert float((d0[d] - d1[d]).abs().max()) < tol * scale + 1e-7, (d, float((d0[d] - d1[d]).abs().max()), scale)
+    # against the definition (fp32 CPU oracle, explicit recurrence): the bf16 / fp16 operand tolerance of the other LSTM tests
+    from oracle import flowtron_oracle as O
+    lens_c = torch.tensor(lens)
+    for d in range(2):
+        g = gx[d].cpu().requires_grad_(True)
+        yy = O.lstm_cell_seq(g, lens_c, torch.eye(4 * H), w[d].cpu(), torch.zeros(4 * H), torch.zeros(4 * H), reverse=bool(d))
+        (yy * dy.cpu()[:, :, d * H:(d + 1) * H]).sum().backward()
+        assert float((y1[:, :, d * H:(d + 1) * H].cpu() - yy.detach()).abs().max()) < (6e-3 if fmt == 1 else 1.5e-3)
+        assert float((d1[d].cpu() - g.grad).norm() / g.grad.norm()) < (5e-3 if fmt == 1 else 1.5e-3)
+
+
 # ---------------------------------------------------------------- pack-by-length (compact) image GEMMs
 def _valid_mask(T, B, lens):
     return (torch.arange(T)[:, None] < torch.tensor(lens)[None, :])          # [T,B]
