@@ -145,22 +145,22 @@ __global__ __launch_bounds__(256) void bilstm_persist_fwd_k(BiFwdP p) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) w[c] = wf[((size_t)jb * 8 + c) * 64 + lane];
     }
-    // lanes 0..15 (kg == 0) hold the real rows: lane li <-> gate li / 4, unit jb*4 + li % 4; acc register r <-> row r
-    const int gcol = (li >> 2) * BH + jb * 4 + (li & 3);                 // column of gx / gates of this lane
+    // The MFMA leaves row r of the tile in register r of lanes 0..15 (lane li <-> gate li / 4, unit li % 4).  One shuffle per row
+    // hands row r to the 16-lane group kg = r, so that every lane group finishes ONE row: one gx load, one cell update and one
+    // store of each kind per lane and step instead of four (the vector-memory instruction count is what a step costs here).
+    const int mylen = kg == 0 ? len[0] : kg == 1 ? len[1] : kg == 2 ? len[2] : len[3];
+    const int gcol = (li >> 2) * BH + jb * 4 + (li & 3);                 // column of gx of this lane: gate li / 4, unit li % 4
     const float* gxp = p.gx[dir];
-    auto load_gx = [&](int t, float (&v)[4]) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (kg == 0 && t >= 0 && t < len[r]) ? gxp[((size_t)t * B + b0 + r) * 4 * BH + gcol] : 0.f;
-    };
+    auto load_gx = [&](int t) { return (t >= 0 && t < mylen) ? gxp[((size_t)t * B + b0 + kg) * 4 * BH + gcol] : 0.f; };
     unsigned long long* gbase = p.gran + ((size_t)xcd * 2 + dir) * GRAN_F;          // + parity * 16 * GRAN_F
     __amdgpu_buffer_rsrc_t rs[2];
 #pragma unroll
     for (int par = 0; par < 2; ++par) rs[par] = __builtin_amdgcn_make_buffer_rsrc(gbase + (size_t)par * 16 * GRAN_F, 0, GRAN_F * 8, 0x00020000);
     const int voff = lane * 16;
     const long t_start = wall_clock64();
-    float c_state[4] = {0.f, 0.f, 0.f, 0.f}, h_state[4] = {0.f, 0.f, 0.f, 0.f};
-    float gxv[4], gxn[4];
-    load_gx(dir ? tg - 1 : 0, gxv);
+    float c_state = 0.f, h_state = 0.f;
+    float gxv = load_gx(dir ? tg - 1 : 0), gxn;
+    const int u = jb * 4 + (li & 3);                     // (lanes li < 4 of every group own unit li)
     bool dead = false;
     for (int s = 0; s < tg; ++s) {
         const int t = dir ? tg - 1 - s : s;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void bilstm_persist_fwd_k(BiFwdP p) {
         if (s > 0) {
             if (!poll<2>(ld, rs[(s - 1) & 1], voff, (unsigned)s, t_start, p.timeout_ticks, p.status)) { dead = true; break; }
         }
-        load_gx(dir ? t - 1 : t + 1, gxn);               // next step's rows: a whole step ahead of the poll that queues behind them
+        gxn = load_gx(dir ? t - 1 : t + 1);              // next step's row: a whole step ahead of the poll that queues behind it
         if (s > 0) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -177,42 +177,30 @@ __global__ __launch_bounds__(256) void bilstm_persist_fwd_k(BiFwdP p) {
                 acc = mfma16(__builtin_bit_cast(bf16x8, member(pay, c & 3)), w[c], acc);
             }
         }
-        // pre-activations of (row r, gate li/4, unit li%4) in lanes 0..15; the gates of a unit gathered into lane li < 4
-        float hn[4];
-        float og_[4][4];                                  // [row][i,f,g,o] for the saved tensors
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float pre_i = acc[r] + gxv[r];
-            float pre[4] = {pre_i, row_shl_f<4>(pre_i), row_shl_f<8>(pre_i), row_shl_f<12>(pre_i)};
-            float c_new, h_new;
-            lstm_cell<true>(pre, c_state[r], og_[r][0], og_[r][1], og_[r][2], og_[r][3], c_new, h_new);
-            if (t < len[r]) { c_state[r] = c_new; h_state[r] = h_new; }
-            hn[r] = row_shl_f<1>(h_state[r]);             // the odd unit of the pair
-        }
-        if (kg == 0 && li < 4 && (li & 1) == 0) {
-            // publish h_t: one {epoch, pair} granule per row (rows that do not take part publish their frozen / zero state)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const unsigned long long gran = ((unsigned long long)(unsigned)(s + 1) << 32) | pack_op16x2(h_state[r], hn[r]);
-                unsigned long long* dst = gbase + (size_t)(s & 1) * 16 * GRAN_F + gran_index(r, jb * 4 + li);
+        const float x1 = __shfl(acc[1], li, 64), x2 = __shfl(acc[2], li, 64), x3 = __shfl(acc[3], li, 64);
+        const float pre_i = (kg == 0 ? acc[0] : kg == 1 ? x1 : kg == 2 ? x2 : x3) + gxv;     // (row kg, gate li / 4, unit li % 4)
+        float pre[4] = {pre_i, row_shl_f<4>(pre_i), row_shl_f<8>(pre_i), row_shl_f<12>(pre_i)};   // lanes li < 4: the four gates of unit li
+        float ig, fg, gg, og, c_new, h_new;
+        lstm_cell<true>(pre, c_state, ig, fg, gg, og, c_new, h_new);
+        const bool active = t < mylen;
+        if (active) { c_state = c_new; h_state = h_new; }
+        const float hn = row_shl_f<1>(h_state);          // the odd unit of the pair
+        if (li < 4) {
+            if ((li & 1) == 0) {
+                // publish h_t: one {epoch, pair} granule (a row that does not take part publishes its frozen / zero state)
+                const unsigned long long gran = ((unsigned long long)(unsigned)(s + 1) << 32) | pack_op16x2(h_state, hn);
+                unsigned long long* dst = gbase + (size_t)(s & 1) * 16 * GRAN_F + gran_index(kg, u);
                 __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-        }
-        if (kg == 0 && li < 4) {
-            const int u = jb * 4 + li;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (t < len[r]) {
-                    const size_t row = (size_t)t * B + b0 + r;
-                    p.y[row * p.ldy + dir * BH + u] = h_state[r];
-                    float* gp = p.gates[dir] + row * 4 * BH + u;
-                    gp[0] = og_[r][0]; gp[BH] = og_[r][1]; gp[2 * BH] = og_[r][2]; gp[3 * BH] = og_[r][3];
-                    p.cell[dir][row * BH + u] = c_state[r];
-                }
+            if (active) {
+                const size_t row = (size_t)t * B + b0 + kg;
+                p.y[row * p.ldy + dir * BH + u] = h_state;
+                float* gp = p.gates[dir] + row * 4 * BH + u;
+                gp[0] = ig; gp[BH] = fg; gp[2 * BH] = gg; gp[3 * BH] = og;
+                p.cell[dir][row * BH + u] = c_state;
             }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gxv[r] = gxn[r];
+        gxv = gxn;
     }
     if (dead && lane == 0) atomicExch(p.status, 1);
 }
@@ -246,32 +234,28 @@ __global__ __launch_bounds__(256) void bilstm_persist_bwd_k(BiBwdP p) {
     for (int par = 0; par < 2; ++par) rs[par] = __builtin_amdgcn_make_buffer_rsrc(gbase + (size_t)par * 16 * GRAN_B, 0, GRAN_B * 8, 0x00020000);
     const int voff = lane * 16;
     const long t_start = wall_clock64();
-    // saved rows of a step (lanes 0..15: unit u, rows r): gates i f g o, dy, and the cell of the recurrence's previous step
+    // As in the forward kernel, one shuffle per row hands row r of the MFMA result (register r of lanes 0..15, lane <-> unit) to
+    // the lane group kg = r: every lane finishes ONE (row, unit) element -- six row loads, one cell backward, four granule and
+    // four dgx stores per lane and step instead of four times as many.
+    const int mylen = kg == 0 ? len[0] : kg == 1 ? len[1] : kg == 2 ? len[2] : len[3];
     const float* gp = p.gates[dir];
     const float* cp = p.cell[dir];
-    struct Rows { float g[4][4]; float dy[4]; float cprev[4]; };
-    auto load_rows = [&](int t, Rows& v) {
+    struct Rows { float g[4]; float dy; float cprev; };
+    auto load_rows = [&](int t, Rows& v) {               // saved gates i f g o, dy, and the cell of the recurrence's previous step
         const int tp = dir ? t + 1 : t - 1;              // the recurrence's previous step in time
+        const bool on = t >= 0 && t < mylen;
+        const size_t row = (size_t)t * B + b0 + kg;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool on = kg == 0 && t >= 0 && t < len[r];
-            const size_t row = (size_t)t * B + b0 + r;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) v.g[r][g] = on ? gp[row * 4 * BH + g * BH + u] : 0.f;
-            v.dy[r] = on ? p.dy[row * p.ldy + dir * BH + u] : 0.f;
-            // (also for a row that only joins at the walk's NEXT step: this value becomes its c_t there)
-            v.cprev[r] = (kg == 0 && tp >= 0 && tp < len[r]) ? cp[((size_t)tp * B + b0 + r) * BH + u] : 0.f;
-        }
+        for (int g = 0; g < 4; ++g) v.g[g] = on ? gp[row * 4 * BH + g * BH + u] : 0.f;
+        v.dy = on ? p.dy[row * p.ldy + dir * BH + u] : 0.f;
+        // (also for a row that only joins at the walk's NEXT step: this value becomes its c_t there)
+        v.cprev = (tp >= 0 && tp < mylen) ? cp[((size_t)tp * B + b0 + kg) * BH + u] : 0.f;
     };
     // backward walks the recurrence the other way round: forward direction t = tg-1 .. 0, reverse direction t = 0 .. tg-1
     Rows cur, nxt;
-    load_rows(dir ? 0 : tg - 1, cur);
-    float c_t[4], dc_carry[4] = {0.f, 0.f, 0.f, 0.f};
-    {
-        const int t0 = dir ? 0 : tg - 1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) c_t[r] = (kg == 0 && t0 >= 0 && t0 < len[r]) ? cp[((size_t)t0 * B + b0 + r) * BH + u] : 0.f;
-    }
+    const int t0 = dir ? 0 : tg - 1;
+    load_rows(t0, cur);
+    float c_t = (t0 >= 0 && t0 < mylen) ? cp[((size_t)t0 * B + b0 + kg) * BH + u] : 0.f, dc_carry = 0.f;
     bool dead = false;
     for (int s = 0; s < tg; ++s) {
         const int t = dir ? s : tg - 1 - s;
@@ -287,42 +271,32 @@ __global__ __launch_bounds__(256) void bilstm_persist_bwd_k(BiBwdP p) {
             }
         }
         if (s + 1 < tg) load_rows(dir ? t + 1 : t - 1, nxt);
-        float da[4][4];
+        const float x1 = __shfl(acc[1], li, 64), x2 = __shfl(acc[2], li, 64), x3 = __shfl(acc[3], li, 64);
+        const float dh_rec = kg == 0 ? acc[0] : kg == 1 ? x1 : kg == 2 ? x2 : x3;                // (row kg, unit u)
+        float da[4], carry;
+        lstm_cell_bwd<true>(dh_rec + cur.dy, dc_carry, cur.g[0], cur.g[1], cur.g[2], cur.g[3], c_t, cur.cprev, da, carry);
+        const bool active = t < mylen;
+        if (active) {
+            dc_carry = carry;
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float carry;
-            lstm_cell_bwd<true>(acc[r] + cur.dy[r], dc_carry[r], cur.g[r][0], cur.g[r][1], cur.g[r][2], cur.g[r][3], c_t[r], cur.cprev[r],
-                                da[r], carry);
-            if (t < len[r]) {
-                dc_carry[r] = carry;
-            } else {
+            for (int g = 0; g < 4; ++g) da[g] = 0.f;
+        }
+        // publish dgates_s: k = gate * H + unit, one granule per unit pair (even lanes)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) da[r][g] = 0.f;
+        for (int g = 0; g < 4; ++g) {
+            const float nb = row_shl_f<1>(da[g]);
+            if ((li & 1) == 0) {
+                const unsigned long long gran = ((unsigned long long)(unsigned)(s + 1) << 32) | pack_op16x2(da[g], nb);
+                unsigned long long* dst = gbase + (size_t)(s & 1) * 16 * GRAN_B + gran_index(kg, g * BH + u);
+                __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        // publish dgates_s: k = gate * H + unit, one granule per unit pair (even lanes of kg == 0), 16 per lane
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float nb = row_shl_f<1>(da[r][g]);
-                if (kg == 0 && (li & 1) == 0) {
-                    const unsigned long long gran = ((unsigned long long)(unsigned)(s + 1) << 32) | pack_op16x2(da[r][g], nb);
-                    unsigned long long* dst = gbase + (size_t)(s & 1) * 16 * GRAN_B + gran_index(r, g * BH + u);
-                    __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-        if (kg == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (t < len[r]) {
-                    float* dg = p.dgx[dir] + ((size_t)t * B + b0 + r) * 4 * BH + u;
-                    dg[0] = da[r][0]; dg[BH] = da[r][1]; dg[2 * BH] = da[r][2]; dg[3 * BH] = da[r][3];
-                }
-            }
+        if (active) {
+            float* dg = p.dgx[dir] + ((size_t)t * B + b0 + kg) * 4 * BH + u;
+            dg[0] = da[0]; dg[BH] = da[1]; dg[2 * BH] = da[2]; dg[3 * BH] = da[3];
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) c_t[r] = cur.cprev[r];        // the cell of the step the walk visits next
+        c_t = cur.cprev;                                 // the cell of the step the walk visits next
         cur = nxt;
     }
     if (dead && lane == 0) atomicExch(p.status, 1);
