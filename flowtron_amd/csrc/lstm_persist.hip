@@ -450,8 +450,11 @@ struct PersistBwdP {
     unsigned short* dimg; long dimg_ld; int dimg_rows; float* dbias;
 };
 
-template <int NG, bool LOCAL, int LAUX, bool BARE>
+// OUT: 0 = fp32 dgx rows only, 1 = dgx and the compact 16-bit image, 2 = the image only (compile-time: the plain path carries none
+// of the image code, the image-only path none of the fp32 stores)
+template <int NG, bool LOCAL, int LAUX, bool BARE, int OUT = 0>
 __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
+    constexpr bool WF32 = OUT != 2, WIMG = OUT != 0;
     static_assert(!LOCAL || NG == 8, "the L2-local transport needs group == XCD");
     constexpr int CPG = NCU / NG;                  // workgroups per group
     constexpr int UPC = PH / CPG;                  // hidden units per CU: 32 (NG 8), 16 (NG 4)
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     const int ob = b0 + oe / UPC, ou = q * UPC + oe % UPC;
     const bool ovalid = tid >= NE && ob < B;
     int olen = 0, ooff = 0;                                      // image: this row's length and its first compact row
-    if (p.dimg && ovalid) {
+    if (WIMG && ovalid) {
         olen = p.lens[ob];
         for (int bb = 0; bb < ob; ++bb) ooff += p.lens[bb] + 1;
     }
@@ -521,11 +524,11 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
         const float* o = outs + (n & 1) * 4 * NE + oe;
         const int so = tg - 1 - n;
         const float v0 = o[0], v1 = o[NE], v2 = o[2 * NE], v3 = o[3 * NE];
-        if (p.dgx) {
+        if constexpr (WF32) {
             float* dg = p.dgx + ((size_t)so * B + ob) * 4 * PH + ou;
             dg[0] = v0; dg[(size_t)PH] = v1; dg[(size_t)2 * PH] = v2; dg[(size_t)3 * PH] = v3;
         }
-        if (p.dimg && so < olen) {
+        if (WIMG && so < olen) {
             unsigned short* ip = p.dimg + (size_t)(ooff + so) * p.dimg_ld + ou;
             ip[0] = (unsigned short)pack_op16x2(v0, 0.f); ip[PH] = (unsigned short)pack_op16x2(v1, 0.f);
             ip[2 * PH] = (unsigned short)pack_op16x2(v2, 0.f); ip[3 * PH] = (unsigned short)pack_op16x2(v3, 0.f);
@@ -719,13 +722,13 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     }
     __syncthreads();
     if (tg > 0) store_outputs(tg - 1);
-    if (ev && p.dgx)                                                    // pad rows beyond the group's longest sequence
+    if (WF32 && ev)                                                     // pad rows beyond the group's longest sequence
         for (int t = tg; t < T; ++t) {
             float* dg = p.dgx + ((size_t)t * B + eb) * 4 * PH + eu;
 #pragma unroll
             for (int g = 0; g < 4; ++g) dg[(size_t)g * PH] = 0.f;
         }
-    if (p.dimg) {
+    if constexpr (WIMG) {
         if (ovalid) {                                                   // bias gradient; the utterance's zero separator row
             unsigned short* ip = p.dimg + (size_t)(ooff + olen) * p.dimg_ld + ou;
 #pragma unroll
@@ -875,17 +878,22 @@ extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, 
         return FT_OK;
     };
     int rc;
+    const int out = dimg == nullptr ? 0 : (dgx ? 1 : 2);
+#define FT_PBWD(NG_, LOCAL_, LAUX_, BARE_) \
+    (out == 0 ? launch(lstm_persist_bwd_k<NG_, LOCAL_, LAUX_, BARE_, 0>) : out == 1 ? launch(lstm_persist_bwd_k<NG_, LOCAL_, LAUX_, BARE_, 1>) \
+                                                                                  : launch(lstm_persist_bwd_k<NG_, LOCAL_, LAUX_, BARE_, 2>))
     if (!bare) {
-        if (ngb == 1) rc = launch(lstm_persist_bwd_k<8, true, 2, false>);
-        else if (ngb == 9) rc = launch(lstm_persist_bwd_k<8, true, 16, false>);
-        else if (ngb == 8) rc = launch(lstm_persist_bwd_k<8, false, 16, false>);
-        else rc = launch(lstm_persist_bwd_k<4, false, 16, false>);
+        if (ngb == 1) rc = FT_PBWD(8, true, 2, false);
+        else if (ngb == 9) rc = FT_PBWD(8, true, 16, false);
+        else if (ngb == 8) rc = FT_PBWD(8, false, 16, false);
+        else rc = FT_PBWD(4, false, 16, false);
     } else {
-        if (ngb == 1) rc = launch(lstm_persist_bwd_k<8, true, 2, true>);
-        else if (ngb == 9) rc = launch(lstm_persist_bwd_k<8, true, 16, true>);
-        else if (ngb == 8) rc = launch(lstm_persist_bwd_k<8, false, 16, true>);
-        else rc = launch(lstm_persist_bwd_k<4, false, 16, true>);
+        if (ngb == 1) rc = FT_PBWD(8, true, 2, true);
+        else if (ngb == 9) rc = FT_PBWD(8, true, 16, true);
+        else if (ngb == 8) rc = FT_PBWD(8, false, 16, true);
+        else rc = FT_PBWD(4, false, 16, true);
     }
+#undef FT_PBWD
     if (rc != FT_OK) return rc;
     FT_CHECK_LAUNCH();
     return FT_OK;
