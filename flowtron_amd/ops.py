@@ -599,7 +599,9 @@ def lstm_persist_groups(B, H, reverse, mode, device=None):
 def bilstm_persist_ok(B, H, mode, device):
     """the encoder-shaped persistent bidirectional kernels (H 256, B <= 32, 16-bit operands) on a device whose persistent grids
     passed the self-test; FLOWTRON_BILSTM_PERSIST=0 or FLOWTRON_LSTM_PERSIST=0 keep the launch-per-step pair chain"""
-    if _os.environ.get("FLOWTRON_BILSTM_PERSIST", "1") == "0" or int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "1")) == 0:
+    # (the kernels form their groups from the XCD census like transports 1 / 9: not for the placement-independent fabric
+    # transports 8 / 4 / 2, which are what one selects on a device where the census cannot come out)
+    if _os.environ.get("FLOWTRON_BILSTM_PERSIST", "1") == "0" or int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "1")) not in (1, 9, 11, 19):
         return False
     if not L.is16(mode) or not L.lib().ft_bilstm_persist_supported(B, H):
         return False
