@@ -199,22 +199,31 @@ def apply_gradient_allreduce(module):
 
     Two regimes, chosen ONCE at wrap time and agreed across ranks (all_reduce(MIN) of the flag), so that every rank always issues
     the same collectives in the same order -- never from per-rank run-time state:
-      default            the buckets leave back to back from the end-of-backward callback, in arena order, when nothing else is
-                         queued on the device.  The default training path runs the persistent recurrence kernels
-                         (csrc/lstm_persist.hip: all 256 CUs, one workgroup per CU, workgroups spin on each other); an RCCL kernel
-                         holding CUs beside a partly resident persistent grid stalls it until the collective's kernel has exited,
-                         and the whole exchange is ~1.4 ms at N = 8, so nothing is gained by overlapping.
-      FLOWTRON_DP_OVERLAP=1 (on every rank)   a bucket is handed to RCCL the moment the last of its gradients has been
-                         accumulated (post-accumulate-grad hooks), under the remaining backward.  Meant for the launch-per-step
-                         kernels (FLOWTRON_LSTM_PERSIST=0, batches > 32, H != 1024), whose launch chains leave most of the chip idle.
+      default            ONE in-place all-reduce(AVG) of the whole arena from the end-of-backward callback (north_star: "a single
+                         RCCL all-reduce per step"; distributed.py:96-120 also issues one).  The default training path runs the
+                         persistent recurrence kernels (csrc/lstm_persist.hip: all 256 CUs, one workgroup per CU, workgroups spin
+                         on each other), which leave no CU for a collective's kernel to run beside them, so nothing is gained by
+                         starting earlier -- and four back-to-back bucket collectives would only pay four latencies.
+      FLOWTRON_DP_OVERLAP=1 (on every rank)   one bucket per flow (~111 MB) plus encoder + embeddings; a bucket is handed to RCCL
+                         the moment the last of its gradients has been accumulated (post-accumulate-grad hooks), under the
+                         remaining backward.  Meant for the launch-per-step kernels (FLOWTRON_LSTM_PERSIST=0, batches > 32,
+                         H != 1024), whose launch chains leave most of the chip idle.
     Launch order inside a regime is a function of the autograd graph only (completion order of the buckets, then arena order
     for whatever was not launched by a hook), identical on all ranks.
-    FLOWTRON_DP_BUCKETS=1 falls back to ONE all-reduce of the whole arena at the end of backward.
+    FLOWTRON_DP_BUCKETS=flow forces the per-flow buckets without overlap (back to back at the end of backward: the round-3
+    default, kept for A/B measurements), FLOWTRON_DP_BUCKETS=1 forces the single all-reduce in either regime.
 
-    Robustness: the hook state is re-armed by the forward pre-hook, so a backward pass that raised (the engine then never runs
-    the end-of-backward callback) cannot leave stale counters behind; before a bucket leaves, `if (persistent-recurrence status)
-    grad = NaN` is enqueued on it (optim.poison_from_status), which makes a failed recurrence on ONE rank drop that optimizer
-    step on EVERY rank (ft_radam_step's non-finite-norm guard) instead of averaging garbage into the weights."""
+    Robustness: the hook state is re-armed by the forward pre-hook AND by the first gradient hook that fires a second time within
+    what the state believes to be one pass (a backward that raised -- the engine then never runs the end-of-backward callback --
+    followed by another backward without a forward in between: the hooks fire in graph order, so the very first hook of the new
+    pass is recognised), so stale counters can neither survive nor release a bucket early; before a bucket leaves, `if
+    (persistent-recurrence status) grad = NaN` is enqueued on it (optim.poison_from_status), which makes a failed recurrence on
+    ONE rank drop that optimizer step on EVERY rank (ft_radam_step's non-finite-norm guard) instead of averaging garbage into
+    the weights.  Like distributed.py:111-126, one reduction per FORWARD: a second backward through the same forward
+    (retain_graph) accumulates locally and is not reduced again.
+
+    `module._comm_timing = True` (bench.py) brackets the end-of-backward exchange with HIP events on the compute stream:
+    `module._comm_events` then holds one (start, end) pair per step = the communication time the step could not hide."""
     arena = FlatArena.for_params(list(module.parameters()), flatten_params=True)
     module._grad_arena = arena
     if dist.is_initialized():
@@ -222,16 +231,19 @@ def apply_gradient_allreduce(module):
         for b in module.buffers():
             dist.broadcast(b, 0)
     module.needs_reduction = True
-    bucketed = bool(_agree_min(os.environ.get("FLOWTRON_DP_BUCKETS", "flow") != "1"))
-    overlap = bool(_agree_min(os.environ.get("FLOWTRON_DP_OVERLAP", "0") == "1")) and bucketed
+    overlap = bool(_agree_min(os.environ.get("FLOWTRON_DP_OVERLAP", "0") == "1"))
+    bucketed = bool(_agree_min(os.environ.get("FLOWTRON_DP_BUCKETS", "flow" if overlap else "1") != "1"))
+    overlap = overlap and bucketed
     buckets = gradient_buckets(module, arena) if bucketed else [("all", 0, arena.numel, list(range(len(arena.params))))]
     bucket_of = {}
     for bi, (_, _, _, idx) in enumerate(buckets):
         for i in idx:
             bucket_of[id(arena.params[i])] = bi
-    state = {"left": [len(b[3]) for b in buckets], "launched": [False] * len(buckets), "pending": [], "queued": False}
+    state = {"left": [len(b[3]) for b in buckets], "launched": [False] * len(buckets), "pending": [], "queued": False, "seen": set()}
     module._grad_buckets = buckets
     module._grad_overlap = overlap
+    module._comm_timing = False
+    module._comm_events = []
     module._grad_bucket_log = []                                 # order in which buckets were launched in the last backward (tests)
     on_gpu = arena.flat_grad.is_cuda
 
@@ -242,6 +254,7 @@ def apply_gradient_allreduce(module):
         state["left"] = [len(b[3]) for b in buckets]
         state["launched"] = [False] * len(buckets)
         state["queued"] = False
+        state["seen"] = set()
 
     def launch(bi):
         if state["launched"][bi] or not dist.is_initialized():
@@ -259,26 +272,36 @@ def apply_gradient_allreduce(module):
         state["queued"] = False
         if module.needs_reduction:
             module.needs_reduction = False
+            timed = module._comm_timing and on_gpu and dist.is_initialized()
+            if timed:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             for bi in range(len(buckets)):                       # everything a hook did not launch, in arena order
                 launch(bi)
             for pend in state["pending"]:
                 _finish(pend)
+            if timed:
+                ev[1].record()
+                module._comm_events.append(ev)
         state["pending"] = []
         state["left"] = [len(b[3]) for b in buckets]
         state["launched"] = [False] * len(buckets)
+        state["seen"] = set()
 
     def on_grad(p):
         if not module.needs_reduction:
             return
+        if id(p) in state["seen"]:
+            # this parameter's hook already fired in what the state takes for the current pass: that pass never reached its
+            # end-of-backward callback (it raised) and a NEW backward has begun without a forward in between -- start over
+            rearm()
+        state["seen"].add(id(p))
         if not state["queued"]:
             state["queued"] = True
             module._grad_bucket_log = []
             Variable._execution_engine.queue_callback(finish_backward)
         bi = bucket_of[id(p)]
         state["left"][bi] -= 1
-        if state["left"][bi] < 0:
-            raise RuntimeError("gradient hook of bucket %r fired more often than it has parameters: the hook state was not re-armed "
-                               "(two backward passes through one forward?)" % (buckets[bi][0],))
         if overlap and state["left"][bi] == 0:
             launch(bi)
 

@@ -217,7 +217,10 @@ class AR_Step(nn.Module):
         rm = rowmap
         mel0 = torch.cat([mel.new_zeros(1, B, M), mel[:-1]], 0)              # flowtron.py:726-729
         a = self.attention_lstm
-        h_att = ops.lstm_layer(mel0, out_lens32, a.weight_ih_l0, a.weight_hh_l0, a.bias_ih_l0, a.bias_hh_l0, mode=mode, rowmap=rm)
+        # fill "dx": d(mel0) flows into the PREVIOUS flow's z gradient, whose separator rows (first padded frame of an utterance)
+        # the compact weight-gradient GEMMs of that flow do read -- padded rows must be zeros, not unwritten memory (T*B*80 floats)
+        h_att = ops.lstm_layer(mel0, out_lens32, a.weight_ih_l0, a.weight_hh_l0, a.bias_ih_l0, a.bias_hh_l0, mode=mode, rowmap=rm,
+                               fill="dx")
         if self.use_cumm_attention:
             ctx, attn, logprob = self.run_cumm_attn_sequence(h_att, text, in_lens32)   # drops the prior like flowtron.py:742-743
         else:
@@ -467,6 +470,11 @@ class Flowtron(nn.Module):
             log_s_list.append(log_s)
             attns_list.append(attn)
             attns_logprob_list.append(logprob)
+        if not torch.is_grad_enabled() and ops.PERSIST_LAUNCHES:
+            # forward-only pass (validation, train.py:143-202): no optimizer step will look at the persistent kernels' status word,
+            # so a launch that timed out would hand back garbage silently and poison the NEXT training step -- check (one host
+            # read; the validation loop reads its losses with .item() anyway) and raise here
+            ops.check_persist_status(raise_on_failure=True)
         return x, log_s_list, gate, attns_list, attns_logprob_list, None, None, None
 
     def infer(self, residual, speaker_ids, text, temperature=1.0, gate_threshold=0.5, attns=None, attn_prior=None):

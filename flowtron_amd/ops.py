@@ -177,13 +177,29 @@ def gemm_img(A, a_km, a_ptr, B, b_km, b_ptr, Cm, M, N, K, ldc, bias=None, act=L.
 # hand-off of an output-gradient image between two autograd nodes of the SAME backward pass (the LSTM backward builds the
 # image of dgates for its own dW_hh GEMM; the input projection's LinearFn.backward receives that very tensor as dy).
 # Keyed by (device, data_ptr, shape); cleared by an engine callback at the end of the pass, so an address can never match stale data.
-_HANDOFF = {"imgs": {}, "armed": False, "unwritten": set()}
+_HANDOFF = {"imgs": {}, "armed": False, "unwritten": set(), "nan_next": 0}
+_NAN_POOL = {}          # device -> 64 fp32 NaNs: one slot per image-only gradient alive in a backward pass
 
 
 def _handoff_clear():
     _HANDOFF["imgs"].clear()
     _HANDOFF["unwritten"].clear()
     _HANDOFF["armed"] = False
+    _HANDOFF["nan_next"] = 0
+
+
+def image_only_gradient(shape, device):
+    """The fp32 face of a gradient that exists ONLY as a 16-bit operand image (ft_lstm_persist_bwd_img): every element reads NaN.
+    No storage of the gradient's size is allocated -- ONE NaN float, expanded with zero strides; each such gradient of a backward
+    pass takes its own slot of a small pool, so (device, data_ptr, shape) still identifies it for the image hand-off.  A foreign
+    reader (a node hook, anomaly mode's output check, an unexpected second consumer) therefore sees NaN -- never stale memory."""
+    pool = _NAN_POOL.get(device)
+    if pool is None:
+        pool = _NAN_POOL[device] = torch.full((64,), float("nan"), device=device, dtype=torch.float32)
+    i = _HANDOFF["nan_next"]
+    _HANDOFF["nan_next"] = i + 1
+    slot = pool[i:i + 1] if i < 64 else torch.full((1,), float("nan"), device=device, dtype=torch.float32)
+    return slot.expand(*shape) if len(shape) else slot.reshape(())
 
 
 def _handoff_put(t, img):
@@ -210,7 +226,7 @@ def _handoff_put_image_only(t, img):
 
 
 def _require_written(t):
-    if (t.device.index, t.data_ptr(), tuple(t.shape)) in _HANDOFF["unwritten"]:
+    if _HANDOFF["unwritten"] and (t.device.index, t.data_ptr(), tuple(t.shape)) in _HANDOFF["unwritten"]:
         raise RuntimeError("flowtron_amd: this gradient exists only as a 16-bit operand image (ft_lstm_persist_bwd_img); its consumer "
                            "must take the image (set FLOWTRON_LSTM_PERSIST_IMG=both to keep the fp32 copy)")
 
@@ -282,10 +298,18 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         W, y, *xs = ctx.saved_tensors
-        dy = _c(dy)
         N, Ktot = W.shape
         rows = dy.numel() // N
         rowmap = ctx.rowmap
+        # an image handed over by the producer of dy (the LSTM backward) is looked up on dy AS IT ARRIVES: an image-only gradient is
+        # a zero-stride NaN tensor (image_only_gradient) that must not be materialised
+        d_img_in = _handoff_take(dy) if (ctx.act == L.ACT_NONE and ctx.imgs is not None) else None
+        if d_img_in is not None and (d_img_in.fmt != ctx.imgs[0].fmt or d_img_in.rowmap is not rowmap
+                                     or (ctx.has_bias and ctx.needs_input_grad[1] and d_img_in.colsum is None)):
+            d_img_in = None
+        if d_img_in is None:
+            _require_written(dy)
+            dy = _c(dy)
         if ctx.act != L.ACT_NONE:
             dpre = torch.empty_like(dy)
             L.check(L.lib().ft_act_bwd(L.ptr(y), L.ptr(dy), L.ptr(dpre), dy.numel(), ctx.act, L.stream()), "ft_act_bwd")
@@ -299,15 +323,10 @@ class LinearFn(torch.autograd.Function):
         imgs = ctx.imgs
         if imgs is not None:
             w_img, x_imgs = imgs
-            d_img = _handoff_take(dpre) if ctx.act == L.ACT_NONE else None      # e.g. the LSTM backward already made it
-            if d_img is not None and (d_img.fmt != w_img.fmt or d_img.rowmap is not rowmap or (want_db and d_img.colsum is None)):
-                d_img = None
+            d_img = d_img_in                                                   # e.g. the LSTM backward already made it
             if d_img is None:
-                _require_written(dpre)
                 d_img = Bf16Image(dpre.reshape(rows, N), colsum=want_db, mode=w_img.fmt, rowmap=rowmap)   # bias gradient rides on the conversion pass
             db = d_img.colsum if want_db else None
-        if imgs is None:
-            _require_written(dpre)
         if want_db and db is None:
             db = colsum(dpre, rows, N, N)
         mrows = rows if rowmap is None else rowmap.cap
@@ -645,7 +664,7 @@ class LSTMSeqFn(torch.autograd.Function):
         w_hh, lens, y, gates, cell = ctx.saved_tensors
         dy = _c(dy)
         T, B, H = y.shape
-        dgx = torch.empty(T, B, 4 * H, device=dy.device, dtype=torch.float32)
+        dgx = None                                   # allocated below unless the gradient leaves as an image only
         ng = lstm_persist_groups(B, H, ctx.reverse, ctx.mode, dy.device)
         d_img_k, img_only = None, False
         if ng:
@@ -661,28 +680,34 @@ class LSTMSeqFn(torch.autograd.Function):
             if (_PERSIST_IMG != "0" and rm is not None and ctx.needs_input_grad[1] and T > 1 and images_apply(ctx.mode, 4 * H, H, (T - 1) * B)
                     and (ctx.gx_private or _PERSIST_IMG == "both")):
                 # the output waves leave the compact 16-bit image of dgates and its column sums INSTEAD of the fp32 rows (beside
-                # them with FLOWTRON_LSTM_PERSIST_IMG=both: 3.07 vs 2.91 us per step): no 450 MB dgx, no conversion pass over it
+                # them with FLOWTRON_LSTM_PERSIST_IMG=both: 3.07 vs 2.91 us per step): no 450 MB dgx, no conversion pass over it.
+                # Anomaly mode inspects every gradient a node returns: it gets real values (both), not the NaN face of an image.
                 d_img_k = Bf16Image.empty_rows(4 * H, rm, ctx.mode, dy.device)
-                img_only = _PERSIST_IMG != "both"
+                img_only = _PERSIST_IMG != "both" and not torch.is_anomaly_enabled()
+                if not img_only:
+                    dgx = torch.empty(T, B, 4 * H, device=dy.device, dtype=torch.float32)
                 L.check(L.op16("ft_lstm_persist_bwd_img", ctx.mode)(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(gates), L.ptr(cell),
                                                     None if img_only else L.ptr(dgx),
                                                     L.ptr(work), L.ptr(st.status), T, B, H, ng, L.ptr(d_img_k.buf), d_img_k.ld,
                                                     d_img_k.buf.numel() // (2 * d_img_k.ld), L.ptr(d_img_k.colsum), L.stream()),
                         "ft_lstm_persist_bwd_img")
             else:
+                dgx = torch.empty(T, B, 4 * H, device=dy.device, dtype=torch.float32)
                 L.check(L.op16("ft_lstm_persist_bwd", ctx.mode)(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
                                                     L.ptr(work), L.ptr(st.status), T, B, H, ng, L.stream()), "ft_lstm_persist_bwd")
             _persist_arm(st)
         else:
+            dgx = torch.empty(T, B, 4 * H, device=dy.device, dtype=torch.float32)
             work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=dy.device, dtype=torch.uint8)
             L.check(L.lib().ft_lstm_seq_bwd(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
                                             L.ptr(work), T, B, H, int(ctx.reverse), ctx.mode, L.stream()), "ft_lstm_seq_bwd")
+        if img_only:
+            # the gradient autograd carries is the NaN face of the image: a foreign reader sees NaN, never unwritten memory
+            dgx = image_only_gradient((T, B, 4 * H), dy.device)
         dW = None
         if ctx.needs_input_grad[1]:
             # dW_hh[r,j] = sum_{t,b} da_t[b,r] * h_prev(t)[b,j];  h_prev = y[t-1] (fwd) / y[t+1] (reverse)
             rows = (T - 1) * B
-            da = dgx[1:] if not ctx.reverse else dgx[:-1]
-            hp = y[:-1] if not ctx.reverse else y[1:]
             dW = torch.zeros_like(w_hh)
             rm = ctx.rowmap
             if T > 1 and images_apply(ctx.mode, 4 * H, H, rows) and rm is not None:
@@ -702,6 +727,8 @@ class LSTMSeqFn(torch.autograd.Function):
                 gemm_img(d_img, 1, d_img.ptr(B if fwd else 0), y_img, 1, y_img.ptr(0 if fwd else B), dW, 4 * H, H, rows, H, splitk=True)
                 _handoff_put(dgx, d_img)        # the input projection's backward reads the same dgates
             elif T > 1:
+                da = dgx[1:] if not ctx.reverse else dgx[:-1]
+                hp = y[:-1] if not ctx.reverse else y[1:]
                 gemm_raw(da, hp, dW, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=ctx.mode, splitk=True)
         return dgx, dW, None, None, None, None, None
 

@@ -14,7 +14,10 @@ keeps one per parameter; they only differ for a parameter that was without a gra
 Guard: the fused kernel drops the whole update when the global gradient norm is NaN / Inf (ft_radam_step): the device-side
 equivalent of GradScaler's overflow skip (train.py:330), which also catches a step poisoned by a persistent recurrence that
 reported a time-out (`poison_from_status`) -- on every rank, because the poison travels through the gradient all-reduce.
-`skipped_steps` reads the device counter.
+`skipped_steps` reads the device counter.  A dropped update leaves weights and moments untouched, but the host-side step count
+(bias correction, N_sma) still advances -- unlike a GradScaler skip; with a handful of dropped steps per run the drift of the
+step size is < 1 % after the first few hundred iterations, and a run that drops steps systematically shows up in
+`skipped_steps` (bench.py prints it; a training loop should log it at its logging cadence).
 """
 from __future__ import annotations
 
@@ -102,6 +105,7 @@ class RAdam(Optimizer):
         self.gnorm_sq.zero_()
         L.check(L.lib().ft_sumsq(L.ptr(a.flat_grad), L.ptr(self.gnorm_sq), a.numel, L.ptr(self._partials), L.stream()), "ft_sumsq")
         self._have_norm = True
+        self._norm_version = a.flat_grad._version      # autograd's in-place accumulation into the arena views bumps it
 
     def clip_grad_norm_(self, max_norm: float):
         """Enqueue ||g||^2 on device and remember the clip for the next step(); returns the device scalar ||g||^2
@@ -124,7 +128,9 @@ class RAdam(Optimizer):
         beta1, beta2 = g["betas"]
         ss, rect = self.step_size_for(self._step, g["lr"], beta1, beta2)
         clip = getattr(self, "_clip", 0.0)
-        if not self._have_norm:                  # no clip_grad_norm_ this iteration: the guard still needs the norm (clip stays 0)
+        # no clip_grad_norm_ this iteration: the guard still needs the norm (clip stays 0); gradients that changed since the norm
+        # was taken (another backward between clip_grad_norm_ and step): the norm is taken again
+        if not self._have_norm or a.flat_grad._version != getattr(self, "_norm_version", -1):
             self._norm_sq()
         L.check(L.lib().ft_radam_step(L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.flat_m), L.ptr(self.flat_v),
                                       a.numel, L.ptr(self.gnorm_sq), clip, g["lr"], beta1, beta2,

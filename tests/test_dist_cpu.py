@@ -119,7 +119,10 @@ class _ToyFlows(torch.nn.Module):
 def _bucket_worker(rank, world, port, q, mode, with_unused, overlap="1", raise_in_backward=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["FLOWTRON_DP_BUCKETS"] = mode
+    if mode is None:
+        os.environ.pop("FLOWTRON_DP_BUCKETS", None)              # the default: one all-reduce, per-flow buckets only with overlap
+    else:
+        os.environ["FLOWTRON_DP_BUCKETS"] = mode
     os.environ["FLOWTRON_DP_OVERLAP"] = overlap[rank] if isinstance(overlap, (list, tuple)) else overlap
     import distributed as D
     D.init_distributed(rank, world, "gloo", None)
@@ -145,10 +148,17 @@ def _bucket_worker(rank, world, port, q, mode, with_unused, overlap="1", raise_i
         y = net(ids, x)
         hooked = _Boom.apply(net.flows[1][0].weight)             # flows.2 has completed when this node is reached
         try:
-            (y.pow(2).mean() + 0.0 * hooked.sum()).backward()
+            (y.pow(2).mean() + 0.0 * hooked.sum()).backward(retain_graph=raise_in_backward == "retry")
             res["raised"] = False
         except RuntimeError:
             res["raised"] = True
+        if raise_in_backward == "retry":
+            # ... and the caller retries the backward pass WITHOUT a new forward (no pre-hook re-arms anything): the first gradient
+            # hook that fires a second time must be taken for the start of a new pass
+            net._grad_arena.flat_grad.zero_()
+            y.pow(2).mean().backward()
+            res["g_retry"] = net._grad_arena.flat_grad.clone()
+            res["log_retry"] = list(net._grad_bucket_log)
     for it in range(2):
         net.zero_grad()
         net(ids, x).pow(2).mean().backward()
@@ -241,3 +251,32 @@ def test_hook_state_is_rearmed_after_a_backward_pass_that_raised(overlap):
             assert len(a[r]["log%d" % it]) == 4, a[r]["log%d" % it]
             assert torch.allclose(a[r]["g%d" % it], ref[r]["g%d" % it], atol=1e-7)
     assert torch.equal(a[0]["g1"], a[1]["g1"])
+
+
+def test_default_is_one_allreduce_of_the_arena_and_overlap_selects_the_per_flow_buckets():
+    """VERDICT r3 #7 / north_star "a single RCCL all-reduce per step": with no FLOWTRON_DP_BUCKETS in the environment the
+    end-of-backward exchange is ONE collective over the whole arena; FLOWTRON_DP_OVERLAP=1 (on every rank) switches to the per-flow
+    buckets launched under the remaining backward.  Same averaged gradients either way."""
+    one = _run_bucket_world(None, False, overlap="0")
+    ovl = _run_bucket_world(None, False, overlap="1")
+    for r in (0, 1):
+        assert one[r]["overlap"] is False and ovl[r]["overlap"] is True
+        for it in (0, 1):
+            assert one[r]["log%d" % it] == ["all"]
+            assert ovl[r]["log%d" % it] == ["flows.2", "flows.1", "flows.0", "embedding+encoder"]
+    assert [n for n, _, _ in one[0]["buckets"]] == ["all"]
+    assert torch.equal(one[0]["g1"], one[1]["g1"]) and torch.allclose(one[0]["g1"], ovl[0]["g1"], atol=1e-7)
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_a_backward_retried_without_a_new_forward_reduces_every_bucket_once(overlap):
+    """a backward pass that raised leaves partly counted buckets behind; when the caller retries the backward through the
+    retained graph (no forward, so no pre-hook), the hook state starts over at the first hook that fires twice -- no bucket leaves
+    early with half of its gradients, none is left out, and nothing raises."""
+    a = _run_bucket_world("flow", False, overlap=overlap, raise_in_backward="retry")
+    ref = _run_bucket_world("flow", False, overlap=overlap)
+    for r in (0, 1):
+        assert a[r]["raised"] is True
+        assert sorted(a[r]["log_retry"]) == ["embedding+encoder", "flows.0", "flows.1", "flows.2"]
+        assert torch.allclose(a[r]["g_retry"], ref[r]["g0"], atol=1e-7)
+    assert torch.equal(a[0]["g_retry"], a[1]["g_retry"])

@@ -666,3 +666,47 @@ def test_bf16_full_width_edge_shapes_match_plain_paths(out_lens, in_lens):
         if e > worst[1]:
             worst = (k, e)
     assert worst[1] < 3e-2, worst
+
+
+def test_three_flows_ragged_bf16_compact_gemms_ignore_stale_memory_in_padded_rows():
+    """with n_flows >= 3 the input gradient of the attention LSTM's mel projection reaches the separator rows
+    (first padded frame of an utterance) of the EARLIER flows' coupling-output gradients, which their compact weight-gradient GEMMs
+    and bias column sums read.  Those rows must be zeros, not whatever the allocator held: 3-flow full-width model, ragged batch,
+    the caching allocator's pool poisoned with NaN and with large finite values before every pass; pack-by-length (default)
+    against FLOWTRON_GEMM_COMPACT=0 (padded rows multiplied, every padded row written)."""
+    import flowtron
+    from flowtron_amd import ops
+    from oracle import synth
+    cfg = dict(synth.DEFAULT_MODEL_CONFIG, n_text=40, n_flows=3)
+    b = cuda_batch(synth.make_batch(cfg, [37, 30, 22, 37, 9, 3], [11, 10, 9, 8, 4, 2], seed=11, with_prior=True))
+    res = {}
+    saved = ops._COMPACT
+    try:
+        for name, compact, poison in (("padded", False, 3.0e4), ("compact_nan", True, float("nan")), ("compact_big", True, 3.0e4)):
+            ops._COMPACT = compact
+            m, _ = build(cfg, 11, "bf16")
+            crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)
+            junk = [torch.full((n,), poison, device="cuda") for n in (1 << 24, 1 << 22, 1 << 20, 1 << 18, 1 << 16)]
+            del junk                                                       # back into the allocator's pool, contents intact
+            out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+            nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+            junk = [torch.full((n,), poison, device="cuda") for n in (1 << 24, 1 << 22, 1 << 20, 1 << 18, 1 << 16)]
+            del junk
+            (nll + gl + 0.01 * ctc).sum().backward()
+            torch.cuda.synchronize()
+            ops.check_persist_status()
+            res[name] = (nll.item(), {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()})
+    finally:
+        ops._COMPACT = saved
+        os.environ.update(FLOWTRON_MFMA="f32")
+    ref = res["padded"]
+    for name in ("compact_nan", "compact_big"):
+        assert abs(res[name][0] - ref[0]) <= 2e-3 * max(1.0, abs(ref[0]))
+        worst = ("", 0.0)
+        for k, r in ref[1].items():
+            g = res[name][1][k]
+            assert torch.isfinite(g).all(), (name, k)
+            e = (g - r).norm().item() / max(r.norm().item(), 1e-4 * r.numel() ** 0.5)
+            if e > worst[1]:
+                worst = (k, e)
+        assert worst[1] < 3e-2, (name, worst)

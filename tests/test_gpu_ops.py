@@ -723,6 +723,54 @@ def test_image_only_gradient_fails_loudly_when_read_as_fp32(env):
         ops._handoff_clear()
 
 
+def test_image_only_gradient_reads_nan_for_a_foreign_consumer_and_anomaly_mode_gets_values(env, monkeypatch):
+    """VERDICT r3 #6 / SURVEY 8(b) "gradients remain ordinary": between the persistent backward recurrence and the input projection's
+    backward the default path carries the dgates gradient as its 16-bit image only.  A foreign reader between the two nodes (a
+    node pre-hook here) must see NaN in every element -- never stale allocator memory --, the repo's own consumer still produces the
+    gradients of the `both` path bit for bit, no gradient-sized fp32 buffer is allocated, and anomaly mode (which inspects every
+    returned gradient) is served real values."""
+    L, ops = env
+    H, T, B, K = 1024, 12, 32, 64
+    if not ops.lstm_persist_groups(B, H, False, L.FT_BF16, torch.device("cuda", torch.cuda.current_device())):
+        pytest.skip("persistent recurrences not usable on this device")
+    torch.manual_seed(5)
+    lens = torch.tensor([T] * 4 + [max(2, T - i) for i in range(B - 4)], dtype=torch.int32, device="cuda")
+    x0 = torch.randn(T, B, K, device="cuda")
+    w_ih0, w_hh0 = torch.randn(4 * H, K, device="cuda") * 0.1, torch.randn(4 * H, H, device="cuda") / H ** 0.5
+    b = torch.zeros(4 * H, device="cuda")
+    dy = torch.randn(T, B, H, device="cuda") * 0.1
+
+    def run(img_mode, hook, anomaly=False):
+        monkeypatch.setattr(ops, "_PERSIST_IMG", img_mode)
+        torch.empty(64 << 20, device="cuda").fill_(7.0)                  # leave recognisable garbage in the allocator's pool
+        x, w_ih, w_hh = x0.clone().requires_grad_(True), w_ih0.clone().requires_grad_(True), w_hh0.clone().requires_grad_(True)
+        rm = ops.RowMap(lens, T, B)
+        seen = []
+        import contextlib
+        with (torch.autograd.detect_anomaly(check_nan=True) if anomaly else contextlib.nullcontext()):
+            h = ops.lstm_layer(x, lens, w_ih, w_hh, b, b, mode=L.FT_BF16, rowmap=rm, fill="dx")
+            lin_node = h.grad_fn.next_functions[0][0]
+            assert "LinearFn" in type(lin_node).__name__
+            if hook:
+                lin_node.register_prehook(lambda grads: seen.append(grads[0]))
+            h.backward(dy)
+        torch.cuda.synchronize()
+        ops.check_persist_status()
+        return x.grad, w_ih.grad, w_hh.grad, seen
+
+    gx_b, gwi_b, gwh_b, _ = run("both", False)
+    gx_1, gwi_1, gwh_1, seen = run("1", True)
+    assert len(seen) == 1
+    g = seen[0]
+    assert g.shape == (T, B, 4 * H) and bool(torch.isnan(g).all()), "a foreign reader must see NaN, not unwritten memory"
+    assert g.untyped_storage().nbytes() <= 1024, "no gradient-sized fp32 buffer behind an image-only gradient"
+    for a_, b_ in ((gx_1, gx_b), (gwi_1, gwi_b), (gwh_1, gwh_b)):
+        assert torch.isfinite(a_).all() and torch.equal(a_, b_)
+    gx_a, gwi_a, gwh_a, _ = run("1", False, anomaly=True)               # anomaly mode: real values, no "returned nan" error
+    for a_, b_ in ((gx_a, gx_b), (gwi_a, gwi_b), (gwh_a, gwh_b)):
+        assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("fmt", [1, 2])
 @pytest.mark.parametrize("T,B,lens", [(157, 32, "ragged"), (9, 5, [9, 9, 4, 2, 1]), (40, 17, None), (33, 32, "full")])
 def test_persistent_bilstm_matches_the_launch_per_step_pair_chain(env, fmt, T, B, lens):
