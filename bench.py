@@ -5,8 +5,8 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-One step = zero_grad + Flowtron.forward + FlowtronLoss (NLL + gate + attention-CTC) + backward (with the in-place RCCL
-all-reduce(AVG) of the flat gradient arena, one bucket per flow launched under the remaining backward, when N > 1) + global-norm clip + fused RAdam update, on BASELINE.json configs[1]:
+One step = zero_grad + Flowtron.forward + FlowtronLoss (NLL + gate + attention-CTC) + backward (with ONE in-place RCCL
+all-reduce(AVG) of the flat gradient arena at the end of backward when N > 1; per-flow buckets under backward with FLOWTRON_DP_OVERLAP=1) + global-norm clip + fused RAdam update, on BASELINE.json configs[1]:
 2-flow LJS config.json model, 80-bin mels, per-GPU batch 32 of LJSpeech-shaped synthetic utterances (<= 10 s),
 attention prior + CTC on, bf16 MFMA operands with fp32 accumulate/storage.  Weak scaling: every rank processes its
 own 32 utterances.  value = valid mel frames (sum of out_lens over all ranks and steps) / wall time.
@@ -200,11 +200,20 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
     ng = int(os.environ.get("FLOWTRON_LSTM_PERSIST", "1"))
     ng_bwd = 11 if (ng == 1 and os.environ.get("FLOWTRON_LSTM_PERSIST_BWD", "bare") != "tagged") else ng      # as ops.LSTMSeqFn.backward
     lib = L.lib()
+    # the backward recurrence as the training step launches it (ops.LSTMSeqFn.backward, FLOWTRON_LSTM_PERSIST_IMG=1): the output
+    # waves leave the compact 16-bit image of dgates + the bias column sums, no fp32 dgx
+    rm = ops.RowMap(lens, T, B)
+    dimg = ops.Bf16Image.empty_rows(4 * H, rm, mode, torch.device("cuda", torch.cuda.current_device()))
+    img_only = os.environ.get("FLOWTRON_LSTM_PERSIST_IMG", "1") == "1"
     runs = {
         "lstm_persist_fwd_k": lambda: L.check(L.op16("ft_lstm_persist_fwd", mode)(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
                                                                         L.ptr(wp), L.ptr(st), T, B, H, ng, L.stream()), "persist fwd"),
-        "lstm_persist_bwd_k": lambda: L.check(L.op16("ft_lstm_persist_bwd", mode)(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
-                                                                        L.ptr(wp), L.ptr(st), T, B, H, ng_bwd, L.stream()), "persist bwd"),
+        "lstm_persist_bwd_k": (lambda: L.check(L.op16("ft_lstm_persist_bwd_img", mode)(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), None,
+                                                                        L.ptr(wp), L.ptr(st), T, B, H, ng_bwd, L.ptr(dimg.buf), dimg.ld,
+                                                                        dimg.buf.numel() // (2 * dimg.ld), L.ptr(dimg.colsum), L.stream()), "persist bwd img"))
+        if img_only else
+        (lambda: L.check(L.op16("ft_lstm_persist_bwd", mode)(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
+                                                                        L.ptr(wp), L.ptr(st), T, B, H, ng_bwd, L.stream()), "persist bwd")),
         "lstm_fwd_step": lambda: L.check(lib.ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(ws),
                                                               T, B, H, 0, mode, L.stream()), "step fwd"),
         "lstm_bwd_step_bf16": lambda: L.check(lib.ft_lstm_seq_bwd(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
@@ -234,14 +243,17 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
     #   operand pairs, 64 KB with tagged granules; x 256 CUs) at the measured L2 peak of 34.5 TB/s.
     # The LDS reduce, the barrier, the cell update and the skew between the 32 CUs of a group are what `frac` leaves.
     mfma_us = 64 * 17 / 2.4e3
-    for name, per_row, repl, gran_kb in (("lstm_persist_bwd_k", 4 * (4 * H + H + H + 4 * H), "lstm_bwd_step_bf16", 32 if ng_bwd > 10 else 64),
+    # algorithmic HBM bytes per valid row: backward reads saved gates, cell, dy (fp32) and writes dgates -- as the 16-bit compact
+    # image (2 B per element) in the step's default mode, as fp32 rows otherwise
+    bwd_out = 2 * 4 * H if img_only else 4 * 4 * H
+    for name, per_row, repl, gran_kb in (("lstm_persist_bwd_k", 4 * (4 * H + H + H) + bwd_out, "lstm_bwd_step_bf16", 32 if ng_bwd > 10 else 64),
                                          ("lstm_persist_fwd_k", 4 * (4 * H + H + 4 * H + H), "lstm_fwd_step", 8 if ng > 10 else 16)):
         nbytes = 2 * 4 * H * H + rows * per_row
         ach = nbytes / (us[name] * 1e-6) / 1e9
         per_step = us[name] / T
         l2_us = 256 * gran_kb * 1024 / 34.5e12 * 1e6
         floor = hops["same_xcd_hop_us"] + mfma_us + l2_us
-        mb = pmc_value("MFMA_BUSY", name, "mfma_busy_frac")
+        mb, mb_src = pmc_value("MFMA_BUSY", name, "mfma_busy_frac", with_source=True)
         out[name] = {"kernel": name, "bound": "handoff-latency", "us_per_step": round(per_step, 3), "floor_us_per_step": round(floor, 3),
                      "frac": round(floor / per_step, 3),
                      "floor_terms_us": {"l2_handoff_hop": round(hops["same_xcd_hop_us"], 3), "mfma_issue_64_per_wave": round(mfma_us, 3),
@@ -250,7 +262,8 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
                      "replaces": {"kernel": repl, "us_per_step": round(us[repl] / T, 3)},
                      "hbm": {"achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                              "bytes_per_launch": nbytes, "traffic": pmc_traffic(name)},
-                     "mfma_busy_frac_pmc": mb,
+                     "mfma_busy_frac_pmc": mb, "pmc_round": mb_src,
+                     "entry_point": "ft_lstm_persist_bwd_img (image only)" if (name.endswith("bwd_k") and img_only) else None,
                      "note": "one launch = one whole sequence of T dependent steps, W_hh resident in registers; neither the HBM nor the "
                              "MFMA roof binds it (both fractions are reported beside the floor): the figure of merit is us_per_step "
                              "against floor_us_per_step"}
@@ -266,38 +279,51 @@ def handoff_hops():
         return {"same_xcd_hop_us": 0.2985, "cross_xcd_hop_us": 0.6432}
 
 
-PMC_PREFIXES = ("r03_pmc_", "r02_pmc_", "r01_pmc_lstm_")
+PMC_PREFIXES = ("r04_pmc_", "r03_pmc_", "r02_pmc_", "r01_pmc_lstm_")
 
 
-def pmc_value(counter_file, kernel_substr, field):
-    """one derived field of the committed rocprofv3 --pmc summaries (profiles/rNN_pmc_<counter_file>.json), newest round first"""
+def _pmc_file(prefix, counter_file):
+    path = os.path.join(ROOT, "profiles", "%s%s.json" % (prefix, counter_file))
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
+def _pmc_scalar(v):
+    """a field of scripts/pmc_summarize.py's output: either a number or {"avg": number, "dispatches": n}"""
+    return float(v["avg"]) if isinstance(v, dict) else float(v)
+
+
+def pmc_value(counter_file, kernel_substr, field, with_source=False):
+    """one derived field of the committed rocprofv3 --pmc summaries (profiles/rNN_pmc_<counter_file>.json), newest round first.
+    A file that exists but cannot be read as expected RAISES (a swallowed TypeError made the line quote round-2
+    counters for round-3 kernels); a kernel that a newer round's file does not list falls through to the older file, and the
+    round the value comes from travels with it (`with_source`)."""
     for prefix in PMC_PREFIXES:
-        try:
-            d = json.load(open(os.path.join(ROOT, "profiles", "%s%s.json" % (prefix, counter_file))))
-            for k, v in d.items():
-                if kernel_substr in k and field in v:
-                    return round(float(v[field]), 4)
-        except Exception:
+        d = _pmc_file(prefix, counter_file)
+        if d is None:
             continue
-    return None
+        for k, v in d.items():
+            if kernel_substr in k and field in v:
+                val = round(_pmc_scalar(v[field]), 4)
+                return (val, prefix[:3]) if with_source else val
+    return (None, None) if with_source else None
 
 
 def pmc_traffic(kernel_substr):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE and WRITE_SIZE
     runs, profiles/rNN_pmc_*.json, newest round first), with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE
     reads 1/2 of a wide coalesced 16 B/lane stream; counters are KiB).  bench.py cannot run rocprofv3 on itself, so this is
-    the last measured value, or null when the files are absent."""
+    the last measured value, or null when no round lists the kernel."""
     for prefix in PMC_PREFIXES:
-        try:
-            vals = {}
-            for c in ("FETCH_SIZE", "WRITE_SIZE"):
-                d = json.load(open(os.path.join(ROOT, "profiles", "%s%s.json" % (prefix, c))))
-                for k, v in d.items():
-                    if kernel_substr in k:
-                        vals[c] = v[c]["avg"]
+        vals = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = _pmc_file(prefix, c)
+            if d is None:
+                continue
+            for k, v in d.items():
+                if kernel_substr in k and c in v:
+                    vals[c] = _pmc_scalar(v[c])
+        if len(vals) == 2:
             return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
-        except Exception:
-            continue
     return None
 
 
@@ -414,6 +440,83 @@ def log(msg):
     print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
 
 
+class _SyntheticAudioSet(torch.utils.data.Dataset):
+    """The bench batch as a DATASET the drop-in loader path consumes: item i = (AudioItem of synthetic audio whose frame count is
+    utterance i's out_len, speaker id, text ids, None) -- what flowtron_amd.data.Data.__getitem__ yields (reference data.py:173-186),
+    minus the file read and the text front end."""
+
+    def __init__(self, batch_cpu, steps):
+        from flowtron_amd.data import AudioItem
+        self.b, self.steps, self.AudioItem = batch_cpu, steps, AudioItem
+        self.stft_args = dict(filter_length=1024, hop_length=HOP, win_length=1024, n_mel_channels=80, sampling_rate=SR, mel_fmin=0.0,
+                              mel_fmax=8000.0)
+        rs = np.random.RandomState(7)
+        self.audio = [torch.from_numpy((0.1 * rs.standard_normal((int(t) - 1) * HOP + 17)).astype(np.float32)) for t in batch_cpu["out_lens"]]
+
+    def __len__(self):
+        return len(self.audio) * self.steps
+
+    def __getitem__(self, i):
+        j = i % len(self.audio)
+        a = self.audio[j]
+        return (self.AudioItem(a, a.numel() // HOP + 1, self.stft_args, (1.0, 0.0)), self.b["speaker_ids"][j:j + 1],
+                self.b["text"][j, :int(self.b["in_lens"][j])], None)
+
+
+def trainpy_step_block(model, criterion, optimizer, batch_cpu, steps, warmup, use_prior):
+    """The step as the reference's UNMODIFIED train.py:282-331 executes it on the drop-in modules, timed beside
+    the headline: batches from a torch DataLoader (train.py:74-80: one worker, batch_size, drop_last) through
+    flowtron_amd.data.DataCollate, the seven `.cuda()` calls (the mel and prior slots are DeferredMel / DeferredPrior: rFFT + mel
+    filterbank and the beta-binomial prior run on the device there), model.zero_grad(), autocast(enabled=False), the four
+    loss `.item()` host reads, backward, torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0), optimizer.step().
+    Same model, optimizer, batch shape and lengths as the headline; the mel VALUES come from synthetic audio."""
+    from flowtron_amd.data import DataCollate
+    ds = _SyntheticAudioSet(batch_cpu, steps + warmup)
+    B = len(ds.audio)
+    loader = torch.utils.data.DataLoader(ds, num_workers=1, shuffle=False, sampler=None, batch_size=B, pin_memory=False, drop_last=True,
+                                         collate_fn=DataCollate(1, use_prior))
+    ctc_w = criterion.ctc_loss_weight
+    t_data, t_step, frames = [], [], 0
+    it = iter(loader)
+    model.train()
+    for i in range(steps + warmup):
+        batch = next(it)                                  # the worker prefetches: host-side collate overlaps the previous step
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.zero_grad()
+        (mel, spk_ids, txt, in_lens, out_lens, gate_target, attn_prior) = batch
+        mel, spk_ids, txt = mel.cuda(), spk_ids.cuda(), txt.cuda()
+        in_lens, out_lens = in_lens.cuda(), out_lens.cuda()
+        gate_target = gate_target.cuda()
+        attn_prior = attn_prior.cuda() if attn_prior is not None else None
+        torch.cuda.synchronize()                          # (measurement only: splits data time from step time)
+        t1 = time.perf_counter()
+        with torch.amp.autocast("cuda", enabled=False):
+            out = model(mel, spk_ids, txt, in_lens, out_lens, attn_prior)
+            loss_nll, loss_gate, loss_ctc = criterion(out, gate_target, in_lens, out_lens, is_validation=False)
+            loss = loss_nll + loss_gate
+            loss += loss_ctc * ctc_w
+        reduced = (loss.item(), loss_gate.item(), loss_nll.item(), loss_ctc.item())
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        optimizer.step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if i >= warmup:
+            t_data.append(t1 - t0)
+            t_step.append(t2 - t1)
+            frames += int(out_lens.sum().item())
+    del it
+    ms = sum(t_step) / len(t_step) * 1e3
+    dms = sum(t_data) / len(t_data) * 1e3
+    return {"what": "train.py:282-331 call for call on the drop-in modules: DataLoader(num_workers=1) -> DataCollate -> 7x .cuda() "
+                    "(DeferredMel: ft_stft_r8 + mel on device; DeferredPrior: ft_beta_binomial_prior) -> model.zero_grad() -> forward + loss -> "
+                    "4x .item() -> backward -> torch.nn.utils.clip_grad_norm_ -> optimizer.step()",
+            "steps": len(t_step), "ms_per_step": round(ms, 2), "data_ms_per_batch": round(dms, 2),
+            "ms_per_step_incl_data": round(ms + dms, 2), "mel_frames_per_s_incl_data": round(frames / (sum(t_step) + sum(t_data)), 1),
+            "final_loss": round(reduced[0], 5), "T_max": int(mel.shape[2]), "L_max": int(txt.shape[1])}
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
         print(json.dumps(cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)), flush=True)
@@ -430,6 +533,7 @@ def main():
                          "use_cumm_attention (location-sensitive attention, SURVEY 8a row a17: the key projection is redone every frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
+    ap.add_argument("--no-trainpy", action="store_true", help="skip the train.py-call-sequence block (trainpy_step)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -475,6 +579,7 @@ def main():
     optimizer = RAdam(model.parameters(), lr=1e-3, weight_decay=1e-6)
     if world > 1:
         model = ftdist.apply_gradient_allreduce(model)
+        model._comm_timing = True                                 # HIP events around the end-of-backward exchange (dist.py)
 
     if libri:
         batch_cpu = synth_batch(args.batch, 1234 + 7 + rank, l_max=237, l_min=5, n_speakers=123, chars_per_frame=1 / 3.6)
@@ -542,18 +647,29 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     log("timed region done: %.1f ms/step" % (dt / max(args.steps, 1) * 1e3))
+    comm_ms = None
+    if world > 1 and getattr(model, "_comm_events", None):
+        evs = model._comm_events[-args.steps:]
+        comm_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+        model._comm_timing = False
     from flowtron_amd import ops as _ops_chk
     _ops_chk.check_persist_status()                              # a persistent recurrence that timed out would have produced garbage
     loss_val = float(loss.item())
     stats = torch.tensor([dt, float(frames_rank)], dtype=torch.float64, device="cuda")
+    comm_all = None
     if world > 1:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         fsum = stats[1:].clone()
         dist.all_reduce(fsum, op=dist.ReduceOp.SUM)
         dt, frames_all = float(tmax.item()), float(fsum.item())
+        cm = torch.zeros(world, dtype=torch.float64, device="cuda")
+        cm[rank] = comm_ms if comm_ms is not None else -1.0
+        dist.all_reduce(cm, op=dist.ReduceOp.SUM)
+        comm_all = [round(float(v), 3) for v in cm.tolist()]
     else:
         frames_all = float(frames_rank)
+    skipped = int(optimizer.skipped_steps)
 
     if rank == 0:
         res = {
@@ -567,13 +683,47 @@ def main():
                                        "libritts": "BASELINE configs[2]: 2-flow LibriTTS model (123 speakers)",
                                        "libritts_fp16": "BASELINE configs[4]: 2-flow LibriTTS model (123 speakers), fp16 operands + GradScaler"}[args.config],
                                       args.batch, T, Lk, "attn-prior" if use_prior else "no attn-prior",
-                                      "unscale+" if scaler.is_enabled() else "", (", per-flow bucketed RCCL all-reduce(AVG) " + ("under backward" if getattr(model, "_grad_overlap", False) else "at the end of backward")) if world > 1 else ""),
+                                      "unscale+" if scaler.is_enabled() else "", (", %s RCCL all-reduce(AVG) of the gradient arena %s" % (("per-flow bucketed", "under backward") if getattr(model, "_grad_overlap", False) else ("ONE in-place", "at the end of backward"))) if world > 1 else ""),
                        "global_batch": args.batch * world, "valid_frames_per_step": int(frames_all),
                        "padded_frames_per_step": args.batch * T * world, "parallelism": "dp%d" % world,
                        "mfma_operands": args.mfma, "storage": "fp32", "final_loss": round(loss_val, 5),
                        **({"test_hook": "BENCH_SHARED_GPU: all ranks on ONE GPU over gloo -- not a scaling measurement"} if shared_gpu else {})},
         }
+        res["config"]["skipped_steps"] = skipped             # updates dropped by the device-side non-finite-norm guard (0 = none)
+        n1_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "flowtron_bench_n1_%s.json" % args.config)
+        if world == 1:
+            try:
+                json.dump({"value": res["value"], "ms_per_step": res["ms_per_step"], "steps": args.steps}, open(n1_path, "w"))
+            except OSError:
+                pass
+        else:
+            # self-diagnosing N > 1 line: what the collective cost on every rank, on which backend, beside the N = 1
+            # run of the same box when the driver ran it first (SCALE runs N = 1, 2, 4, 8 back to back)
+            n1 = None
+            try:
+                n1 = json.load(open(n1_path))
+            except (OSError, ValueError):
+                pass
+            arena_mb = model._grad_arena.numel * 4 / 1e6
+            res["dp"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                         "collectives_per_step": len(model._grad_buckets), "regime": "overlap" if model._grad_overlap else "end-of-backward",
+                         "arena_mb": round(arena_mb, 1), "allreduce_ms_per_rank": comm_all,
+                         "exposed_comm_ms": None if not comm_all else round(max(comm_all), 3),
+                         "allreduce_busbw_gb_s": None if not comm_all or max(comm_all) <= 0 else
+                         round(2 * (world - 1) / world * arena_mb / 1e3 / (max(comm_all) * 1e-3), 1),
+                         "n1_same_box": n1,
+                         "weak_scaling_efficiency_vs_n1": None if not n1 else round(res["value"] / (world * n1["value"]), 4),
+                         "design_prediction": {"2": 0.92, "4": 0.95, "8": 0.96}.get(str(world)),
+                         "note": "allreduce_ms = HIP events on the compute stream around the end-of-backward exchange (poison check + "
+                                 "collective(s) + stream wait); with the end-of-backward regime all of it is exposed"}
         mode = {"bf16": L.FT_BF16, "f16": L.FT_F16, "f32": L.FT_F32}[args.mfma]
+        if world == 1 and not args.no_trainpy and args.config in ("ljs", "libritts"):
+            try:
+                log("train.py call sequence (DataLoader -> .cuda() -> zero_grad -> fwd -> 4x item -> bwd -> torch clip -> step) ...")
+                res["trainpy_step"] = trainpy_step_block(model, criterion, optimizer, batch_cpu, min(args.steps, 20), 3, use_prior)
+                res["trainpy_step"]["gap_to_headline_ms"] = round(res["trainpy_step"]["ms_per_step"] - res["ms_per_step"], 2)
+            except Exception as e:
+                res["trainpy_step"] = {"error": repr(e)}
         log("roofline kernel timing ...")
         # Top level: the WHOLE STEP against the MFMA roof: valid frames/s x 325 MFLOP of algorithmic work per valid frame
         # (2 flows, forward + backward, padding and the tanh recomputation not counted) over the dense bf16 peak.  The step is a chain
@@ -582,9 +732,9 @@ def main():
         res["roofline"] = {"bound": "mfma", "scope": "whole training step", "achieved": round(frames_per_gpu * 325e6 / 1e12, 2),
                            "peak": 2500.0, "unit": "TFLOP/s", "frac": round(frames_per_gpu * 325e6 / 2.5e15, 5), "traffic": None,
                            "flop_per_valid_frame": 325e6,
-                           "gemm_mfma_busy_frac_pmc": {k: pmc_value("MFMA_BUSY", k, "mfma_busy_frac") for k in
-                                                       ("gemm_bf16_k<true, true, true, 256>", "gemm_bf16_k<false, true, false, 128>",
-                                                        "gemm_bf16_k<false, false, false, 128>")}}
+                           "gemm_mfma_busy_frac_pmc": {k: dict(zip(("frac", "pmc_round"), pmc_value("MFMA_BUSY", k, "mfma_busy_frac", with_source=True)))
+                                                       for k in ("gemm_bf16_k<true, true, true, 256>", "gemm_bf16_k<false, true, false, 128>",
+                                                                 "gemm_bf16_k<false, false, false, 128>", "gemm_bf16_big_k")}}
         try:
             from flowtron_amd import ops as _ops
             if _ops.lstm_persist_groups(args.batch, MODEL_CONFIG["n_hidden"], False, mode, torch.device("cuda", torch.cuda.current_device())):

@@ -543,3 +543,44 @@ def beta_binomial_prior(P: int, M: int, scaling: float = 1.0) -> torch.Tensor:
     logc = lg(torch.tensor(n + 1, dtype=torch.float64)) - lg(k + 1) - lg(n - k + 1)
     logp = logc + lg(k + a) + lg(n - k + b) - lg(n + a + b) - (lg(a) + lg(b) - lg(a + b))
     return torch.exp(logp)
+
+
+# --------------------------------------------------------------------------
+# optimizer step of the caller row: RAdam as radam.py:44-120 states it, plus the global-norm clip of
+# train.py:325-329 -- a functional restatement over a dict of tensors.  TEST INFRASTRUCTURE like the rest of this file.
+# --------------------------------------------------------------------------
+def clip_grad_norm(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (train.py:327-329): total L2 norm over all gradients; scale by max_norm / (norm + 1e-6)
+    when that is < 1.  Returns (total_norm, clipped gradients)."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return total, {k: g * coef for k, g in grads.items()}
+
+
+def radam_step(params, grads, state, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """One radam.py step (radam.py:52-120) on every tensor of `params` (in place); `state` = {"step": int, "m": {k: tensor},
+    "v": {k: tensor}} (exp_avg / exp_avg_sq, radam.py:63-66), created empty by the caller."""
+    import math
+    beta1, beta2 = betas
+    state["step"] = state.get("step", 0) + 1
+    t = state["step"]
+    beta2_t = beta2 ** t
+    n_sma_max = 2 / (1 - beta2) - 1                                             # radam.py:86
+    n_sma = n_sma_max - 2 * t * beta2_t / (1 - beta2_t)                         # radam.py:87-89
+    if n_sma >= 5:                                                              # radam.py:93-101
+        step_size = lr * math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_sma_max - 4) * (n_sma - 2) / n_sma * n_sma_max / (n_sma_max - 2)) \
+            / (1 - beta1 ** t)
+    else:                                                                       # radam.py:102-103
+        step_size = lr / (1 - beta1 ** t)
+    for k, p in params.items():
+        g = grads[k]
+        m = state.setdefault("m", {}).setdefault(k, torch.zeros_like(p))
+        v = state.setdefault("v", {}).setdefault(k, torch.zeros_like(p))
+        v.mul_(beta2).addcmul_(g, g, value=1 - beta2)                           # radam.py:78
+        m.mul_(beta1).add_(g, alpha=1 - beta1)                                  # radam.py:79
+        if weight_decay != 0:
+            p.add_(p, alpha=-weight_decay * lr)                                 # radam.py:106-109
+        if n_sma >= 5:
+            p.addcdiv_(m, v.sqrt().add_(eps), value=-step_size)                 # radam.py:112-114
+        else:
+            p.add_(m, alpha=-step_size)                                         # radam.py:116

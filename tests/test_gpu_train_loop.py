@@ -66,3 +66,46 @@ def test_full_width_loop_runs_the_persistent_recurrences(tmp_path, monkeypatch):
     out, _ = _run(tmp_path, monkeypatch, "bf16", True, {}, iters=3)
     ops.check_persist_status()
     assert all(torch.isfinite(torch.tensor(v)) for v in out["losses"].values())
+
+
+def test_five_iteration_trajectory_matches_the_real_reference_loop(monkeypatch):
+    """SURVEY 8a row a25 / VERDICT r3 missing #2: the composed loop of train.py:282-331 -- model.zero_grad(), forward, FlowtronLoss,
+    backward, torch.nn.utils.clip_grad_norm_, RAdam.step, five iterations on two alternating ragged batches -- on the drop-in
+    modules (fp32 MFMA mode) against `tests/golden/train_traj.pt`, which tests/golden/make_golden_r4.py produced by running the
+    SAME function (`run_reference_loop`) over the REAL reference's Flowtron / FlowtronLoss / radam.RAdam on CPU with dropout
+    neutralised: the four losses and the pre-clip gradient norm of every iteration, every parameter after the last one."""
+    import importlib.util
+    import flowtron
+    import radam
+    monkeypatch.setenv("FLOWTRON_MFMA", "f32")
+    spec_ = importlib.util.spec_from_file_location("_make_golden_r4", os.path.join(HERE, "golden", "make_golden_r4.py"))
+    mg = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mg)
+    g = torch.load(os.path.join(HERE, "golden", "train_traj.pt"), weights_only=False)
+    assert g["spec"] == mg.TRAJ, "the committed fixture was made from another specification"
+
+    def ones_masks(model, b):                    # the drop-in encoder draws keep-masks itself (no F.dropout to patch): all kept, unscaled
+        Lk, B = b["text"].shape[1], b["text"].shape[0]
+        C = model.embedding.weight.shape[1]
+        model.encoder.dropout_masks = [torch.ones(Lk, B, C, device="cuda") for _ in range(3)]
+
+    res = mg.run_reference_loop(flowtron.Flowtron, flowtron.FlowtronLoss, radam.RAdam, device="cuda", neutralise_dropout=False,
+                                prepare=ones_masks)
+    torch.cuda.synchronize()
+    for it in range(g["spec"]["iters"]):
+        for j, name in enumerate(("loss", "gate", "nll", "ctc")):
+            r, m = float(g["losses"][it, j]), float(res["losses"][it, j])
+            assert abs(m - r) < 1e-4 * max(1.0, abs(r)), (it, name, m, r)
+        rn, mn = float(g["grad_norms"][it]), float(res["grad_norms"][it])
+        assert abs(mn - rn) < 5e-4 * rn, (it, mn, rn)
+    from oracle import synth
+    init = synth.make_state_dict(g["spec"]["cfg"], seed=g["spec"]["seed"])
+    worst = ("", 0.0)
+    for k, ref in g["params"].items():
+        moved = (ref - init[k]).abs().max().item()
+        err = (res["params"][k] - ref).abs().max().item()
+        if err > worst[1]:
+            worst = (k, err)
+        assert err < 2e-6 + 1e-2 * moved, (k, err, moved)
+    assert res["optimizer"]._step == g["spec"]["iters"] and res["optimizer"].skipped_steps == 0
+    print("trajectory: worst parameter deviation %.2e (%s)" % (worst[1], worst[0]))

@@ -257,3 +257,34 @@ def test_cumulative_attention_full_width_oracle_vs_real_reference(golden_dir):
     with torch.no_grad():
         mel, attn = O.infer(sd, cfg, residual, b["speaker_ids"][:1], b["text"][:1, : g["in_lens"][0]], gate_threshold=1.0)
     assert _maxdiff(mel, g["infer_mel"]) < 1e-4
+
+
+def test_training_trajectory_oracle_vs_real_reference(golden_dir):
+    """five iterations of train.py:282-331 (zero_grad, forward, loss, backward, clip_grad_norm_, RAdam step) by the
+    REAL reference modules on CPU (tests/golden/make_golden_r4.py -> train_traj.pt) against the oracle's forward / loss with
+    autograd, O.clip_grad_norm and O.radam_step: losses and pre-clip gradient norms of every iteration, every parameter at the end."""
+    g = _load(golden_dir, "train_traj.pt")
+    spec = g["spec"]
+    cfg = spec["cfg"]
+    params = {k: v.clone() for k, v in synth.make_state_dict(cfg, seed=spec["seed"]).items()}
+    batches = [synth.make_batch(cfg, b["out_lens"], b["in_lens"], seed=b["seed"], with_prior=True) for b in spec["batches"]]
+    state = {}
+    for it in range(spec["iters"]):
+        b = batches[it % len(batches)]
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+        out = O.forward(sd, cfg, b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+        nll, gl, ctc = O.loss(out, b["gate_target"], b["in_lens"], b["out_lens"], spec["sigma"], True, True, spec["blank_logprob"])
+        loss = nll + gl + spec["ctc_loss_weight"] * ctc
+        ref = g["losses"][it]
+        for mine, r in zip((loss, gl, nll, ctc), ref.tolist()):
+            assert abs(float(mine) - r) < 2e-5 * max(1.0, abs(r)), (it, float(mine), r)
+        loss.sum().backward()
+        total, grads = O.clip_grad_norm({k: v.grad for k, v in sd.items()}, spec["grad_clip_val"])
+        assert abs(float(total) - float(g["grad_norms"][it])) < 1e-4 * float(g["grad_norms"][it]), (it, float(total))
+        with torch.no_grad():
+            O.radam_step(params, grads, state, lr=spec["lr"], weight_decay=spec["weight_decay"])
+    assert g["optimizer_steps"] == [spec["iters"]]
+    init = synth.make_state_dict(cfg, seed=spec["seed"])
+    for k, ref in g["params"].items():
+        moved = (ref - init[k]).abs().max().item()
+        assert _maxdiff(params[k], ref) < 2e-6 + 2e-3 * moved, (k, _maxdiff(params[k], ref), moved)
