@@ -120,6 +120,7 @@ SIGNATURES = {
     "ft_decode_flow": ([C.POINTER(DecodeArgs), _p], _i),
     "ft_stft_mel": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "ft_stft_r8": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "ft_stft_r8_ragged": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "ft_attn_ctc_workspace_floats": ([_i, _i, _i], _sz),
     "ft_attn_ctc_fwd": ([_p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_attn_ctc_bwd": ([_p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _i, _p], _i),

@@ -142,6 +142,25 @@ class TacotronSTFT(torch.nn.Module):
     def spectral_de_normalize(self, magnitudes):
         return dynamic_range_decompression(magnitudes)
 
+    def mel_spectrogram_ragged(self, y, n_samples, max_t=None):
+        """The collated batch of the data path in one launch (ft_stft_r8_ragged): y [B,N] zero-padded audio on the device,
+        n_samples [B] (int32, device) -> [B, n_mel_channels, max_t]; utterance b's frames t < n_samples[b] // hop + 1 equal
+        mel_spectrogram(y[b:b+1, :n_samples[b]]), later frames are zero (DataCollate's padding, data.py:215-229)."""
+        L.require_cuda(y, n_samples)
+        y = y.contiguous().float()
+        if self.mel_basis.device != y.device:
+            self.to(y.device)
+        B, N = y.shape
+        st = self.stft_fn
+        T_out = N // st.hop_length + 1 if max_t is None else int(max_t)
+        if not (st.fast_path() and self.n_mel_channels <= 128 and N > st.filter_length // 2):
+            raise NotImplementedError("the ragged front end is built for n_fft = 1024, hop <= 256 (config.json:32-34)")
+        mel = torch.empty(B, self.n_mel_channels, T_out, device=y.device, dtype=torch.float32)
+        L.check(L.lib().ft_stft_r8_ragged(L.ptr(y), L.ptr(n_samples.to(torch.int32)), L.ptr(st.fft_window), L.ptr(self.fb_bin0),
+                                          L.ptr(self.fb_ptr), L.ptr(self.fb_w), L.ptr(mel), B, N, st.hop_length, self.n_mel_channels,
+                                          T_out, L.stream()), "ft_stft_r8_ragged")
+        return mel
+
     def mel_spectrogram(self, y):
         """y [B,N] float32 in [-1,1] (device tensor) -> [B, n_mel_channels, N // hop + 1]."""
         L.require_cuda(y)

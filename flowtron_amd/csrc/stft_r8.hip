@@ -46,6 +46,8 @@ struct StftP {
     const int* band_bin0; const int* band_ptr; const float* band_w;      // CSR of the filterbank: band b covers bins
     float* mel; float* mag; float* phase;                                // [bin0[b], bin0[b] + ptr[b+1] - ptr[b])
     int N, hop, n_mel, n_frames;
+    const int* n_samples;            // ragged batch (ft_stft_r8_ragged): utterance b holds n_samples[b] <= N samples and
+    int ldt;                         // n_samples[b] / hop + 1 frames; frames beyond that are written as zeros; ldt = output row stride
 };
 
 __global__ __launch_bounds__(256) void stft_r8_k(StftP p) {
@@ -56,12 +58,14 @@ __global__ __launch_bounds__(256) void stft_r8_k(StftP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, f0 = blockIdx.x * FPG;
     const float* yb = p.y + (size_t)b * p.N;
+    const int Nb = p.n_samples ? min(max(p.n_samples[b], 1), p.N) : p.N;   // this utterance's own length: the reflection is about ITS end
+    const int nfb = p.n_samples ? Nb / p.hop + 1 : p.n_frames;
     const int span = (FPG - 1) * p.hop + NFFT;
     for (int j = tid; j < span; j += 256) {
         int n = f0 * p.hop + j - NH;                                      // reflect padding (audio_processing.py:210-214)
         if (n < 0) n = -n;
-        if (n >= p.N) n = 2 * (p.N - 1) - n;
-        xs[j] = (n >= 0 && n < p.N) ? yb[n] : 0.f;
+        if (n >= Nb) n = 2 * (Nb - 1) - n;
+        xs[j] = (n >= 0 && n < Nb) ? yb[n] : 0.f;
     }
     // per-lane constants for all frames: twiddles W512^{l k1} (l = lane), W64^{b2 k2} (b2 = lane & 7), the split twiddles
     // W1024^{k} of this lane's bins k = lane + 64 r, and the window taps of its 8 complex input points
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256) void stft_r8_k(StftP p) {
     float* M = mg[wave];
     for (int fi = 0; fi < FPW; ++fi) {
         const int t = f0 + wave * FPW + fi;
-        if (t >= p.n_frames) break;                                       // wave-uniform
+        if (t >= nfb) break;                                              // wave-uniform
         const float* xf = xs + (wave * FPW + fi) * p.hop;
         // ---- pass 1: lane l holds z[l + 64 j]; DFT over j; twiddle W512^{l k1}
         cpx v[8];
@@ -145,8 +149,8 @@ __global__ __launch_bounds__(256) void stft_r8_k(StftP p) {
                 const float m = sqrtf(re * re + im * im);
                 M[k] = m;
                 if (p.mag) {
-                    p.mag[((size_t)b * NB + k) * p.n_frames + t] = m;
-                    p.phase[((size_t)b * NB + k) * p.n_frames + t] = atan2f(im, re);
+                    p.mag[((size_t)b * NB + k) * p.ldt + t] = m;
+                    p.phase[((size_t)b * NB + k) * p.ldt + t] = atan2f(im, re);
                 }
             }
         }
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256) void stft_r8_k(StftP p) {
         const int nf = min(FPG, p.n_frames - f0);
         for (int idx = tid; idx < p.n_mel * FPG; idx += 256) {
             const int mb = idx / FPG, f = idx - mb * FPG;
-            if (f < nf) p.mel[((size_t)b * p.n_mel + mb) * p.n_frames + f0 + f] = mo[mb][f];
+            if (f < nf) p.mel[((size_t)b * p.n_mel + mb) * p.ldt + f0 + f] = (f0 + f < nfb) ? mo[mb][f] : 0.f;   // zero padding of DataCollate
         }
     }
 }
@@ -184,8 +188,23 @@ extern "C" int ft_stft_r8(const float* y, const float* window, const int32_t* ba
     FT_CHECK_ARG(!mel || (band_bin0 && band_ptr && band_w && n_mel >= 1 && n_mel <= 128));
     FT_CHECK_ARG(B >= 1 && B <= 65535 && hop >= 1 && hop <= 256 && N > NH);
     const int n_frames = N / hop + 1;
-    StftP p{y, window, band_bin0, band_ptr, band_w, mel, mag, phase, N, hop, n_mel, n_frames};
+    StftP p{y, window, band_bin0, band_ptr, band_w, mel, mag, phase, N, hop, n_mel, n_frames, nullptr, n_frames};
     hipLaunchKernelGGL(stft_r8_k, dim3(cdiv(n_frames, FPG), B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+
+// The collated batch of the data path (data.py:207-229 pads every mel with zeros to the longest one): y [B,N] zero-padded audio,
+// utterance b holds n_samples[b] samples (device int32) -> mel [B,n_mel,T_out]: frames < n_samples[b] / hop + 1 as ft_stft_r8
+// computes them for that utterance alone (reflection about ITS last sample), zeros beyond.  ONE launch for the batch instead of
+// one per utterance (each ~35 us of latency for <= 862 frames).  T_out >= max_b (n_samples[b] / hop + 1).
+extern "C" int ft_stft_r8_ragged(const float* y, const int32_t* n_samples, const float* window, const int32_t* band_bin0,
+                                 const int32_t* band_ptr, const float* band_w, float* mel, int B, int N, int hop, int n_mel,
+                                 int T_out, void* stream) {
+    FT_CHECK_ARG(y && n_samples && window && mel && band_bin0 && band_ptr && band_w && n_mel >= 1 && n_mel <= 128);
+    FT_CHECK_ARG(B >= 1 && B <= 65535 && hop >= 1 && hop <= 256 && N > NH && T_out >= 1);
+    StftP p{y, window, band_bin0, band_ptr, band_w, mel, nullptr, nullptr, N, hop, n_mel, T_out, n_samples, T_out};
+    hipLaunchKernelGGL(stft_r8_k, dim3(cdiv(T_out, FPG), B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

@@ -339,6 +339,13 @@ int ft_stft_mel(const float* y, const float* window, const float* fb, float* mel
  * audio_processing.py:207-235).  window: hann [1024] (win_length zero-padded by the caller). */
 int ft_stft_r8(const float* y, const float* window, const int32_t* band_bin0, const int32_t* band_ptr, const float* band_w,
                float* mel, float* mag, float* phase, int B, int N, int hop, int n_mel, void* stream);
+/* The collated batch of the data path (data.py:149-155 per item, :207-229 zero padding) in ONE launch:
+ * y [B,N] zero-padded audio, utterance b holds n_samples[b] samples (device int32) -> mel [B,n_mel,T_out]: the frames
+ * t < n_samples[b] / hop + 1 exactly as ft_stft_r8 computes them for that utterance alone (reflect padding about ITS last
+ * sample), zeros beyond -- the tensor DataCollate builds on the host.  T_out >= max_b (n_samples[b] / hop + 1). */
+int ft_stft_r8_ragged(const float* y, const int32_t* n_samples, const float* window, const int32_t* band_bin0,
+                      const int32_t* band_ptr, const float* band_w, float* mel, int B, int N, int hop, int n_mel, int T_out,
+                      void* stream);
 
 /* ---- attention-CTC loss (flowtron.py:155-182, 245-274) ------------------------------
  * lp [B,T,L] = attn_logprob in natural time order.  Per sample: classes {blank (logit blank_logprob), 1..K_b} with

@@ -36,6 +36,13 @@ print("idle by gap size (us):", {k: round(v, 1) for k, v in gaps.items()})
 print("--- by kernel (this step)")
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
     print("%9.1f us %5d x  %s" % (t, c, n))
+print("--- gaps >= 20 us (offset us, gap us, kernel before -> kernel after)")
+prev, pn = t0, "radam_k (previous step)"
+for s_, e_, n_, g_ in step:
+    if (s_ - prev) / 1e3 >= 20.0:
+        print("%9.1f %8.1f  %s -> %s" % ((s_ - t0) / 1e3, (s_ - prev) / 1e3, pn, n_))
+    if e_ > prev:
+        prev, pn = e_, n_
 print("--- timeline (offset us, gap us, dur us, kernel, grid)")
 prev = t0
 for s, e, n, g in step:

@@ -43,13 +43,17 @@ def _local_grads(cfg, sd, batch, dev):
     return {k: p.grad.detach().float().cpu().numpy().copy() for k, p in m.named_parameters()}
 
 
-def _worker(rank, world, port, q, mode, full_width=False, overlap="0", backend="nccl", shared_gpu=False):
+def _worker(rank, world, port, q, mode, full_width=False, overlap="0", backend="nccl", shared_gpu=False, buckets=None):
     try:
         for p_ in (ROOT, HERE):
             if p_ not in sys.path:
                 sys.path.insert(0, p_)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FLOWTRON_MFMA=mode,
                           LOCAL_RANK="0" if shared_gpu else str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0", FLOWTRON_DP_OVERLAP=overlap)
+        if buckets is None:
+            os.environ.pop("FLOWTRON_DP_BUCKETS", None)
+        else:
+            os.environ["FLOWTRON_DP_BUCKETS"] = buckets
         import distributed as D
         import flowtron
         from flowtron_amd.optim import RAdam
@@ -103,11 +107,11 @@ def _worker(rank, world, port, q, mode, full_width=False, overlap="0", backend="
         q.put((rank, {"error": traceback.format_exc()}))
 
 
-def _run(world, mode, full_width=False, overlap="0", backend="nccl", shared_gpu=False):
+def _run(world, mode, full_width=False, overlap="0", backend="nccl", shared_gpu=False, buckets=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, full_width, overlap, backend, shared_gpu)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, full_width, overlap, backend, shared_gpu, buckets)) for r in range(world)]
     for p in procs:
         p.start()
     out = dict(q.get(timeout=500) for _ in range(world))
@@ -138,13 +142,15 @@ def test_rccl_single_rank_bucketed_allreduce_is_the_identity(mode):
     assert np.isfinite(out["w_after"]).all() and np.abs(out["w_after"] - out["w_before"]).max() > 0
 
 
-def test_rccl_default_regime_buckets_leave_at_the_end_of_backward_full_width():
+@pytest.mark.parametrize("buckets,expect", [(None, ["all"]), ("flow", ["speaker_embedding+embedding", "flows.0", "flows.1", "encoder"])])
+def test_rccl_default_regime_is_one_allreduce_at_the_end_of_backward_full_width(buckets, expect):
     """Default regime at H = 1024, bf16 (the step goes through lstm_persist_{fwd,bwd}_k, whole-chip co-resident grids): no
-    collective is in flight beside them -- the buckets leave in arena order from the end-of-backward callback, each behind the
-    poison check of the persistent status word (ft_poison_if_nonzero), and the gradients equal the unwrapped module's."""
-    out = _run(1, "bf16", full_width=True)[0]
+    collective is in flight beside them -- ONE all-reduce of the whole arena leaves from the end-of-backward callback behind the
+    poison check of the persistent status word (ft_poison_if_nonzero), and the gradients equal the unwrapped module's.
+    FLOWTRON_DP_BUCKETS=flow keeps the round-3 behaviour (the per-flow buckets back to back in arena order) for A/B runs."""
+    out = _run(1, "bf16", full_width=True, buckets=buckets)[0]
     for it in (0, 1):
-        assert out["log%d" % it] == ["speaker_embedding+embedding", "flows.0", "flows.1", "encoder"], out["log%d" % it]
+        assert out["log%d" % it] == expect, out["log%d" % it]
         for k, g in out["g%d" % it].items():
             assert _close(g, out["local"][k], 2e-3), (k, it)
 
@@ -158,15 +164,15 @@ def test_rccl_two_ranks_average_gradients():
     for k in r0["g0"]:
         assert np.array_equal(r0["g0"][k], r1["g0"][k]), k               # every rank holds the same reduced arena
         assert _close(r0["g0"][k], 0.5 * (r0["local"][k] + r1["local"][k]), 2e-5), k
-    assert len(r0["log0"]) == 4 and r0["log0"] == r1["log0"]
+    assert r0["log0"] == ["all"] and r0["log0"] == r1["log0"]
     assert np.array_equal(r0["w_after"], r1["w_after"]) and abs(r0["loss"] - r1["loss"]) < 1e-6
 
 
 @pytest.mark.skipif(os.environ.get("FLOWTRON_TEST_SHARED_GPU", "1") != "1", reason="FLOWTRON_TEST_SHARED_GPU=0")
 def test_two_ranks_on_one_gpu_over_gloo_with_the_persistent_kernels():
     """RCCL refuses two ranks on one device, so the N > 1 code path on real HIP streams runs over gloo: two processes on cuda:0,
-    full width (H 1024, bf16: every step launches the whole-chip persistent recurrences), default regime (buckets leave at
-    the end of backward, each behind ft_poison_if_nonzero), different utterances per rank.  Two processes' persistent grids
+    full width (H 1024, bf16: every step launches the whole-chip persistent recurrences), default regime (one all-reduce of the
+    arena at the end of backward, behind ft_poison_if_nonzero), different utterances per rank.  Two processes' persistent grids
     may meet on the chip; then their bounded spins time out, the status word poisons that step on BOTH ranks (the NaN
     travels through the all-reduce) and the fused RAdam drops it.  Either way: no hang, every rank holds the same reduced
     arena and the same weights afterwards; when no launch failed, the arena is the mean of the two local gradients."""
@@ -174,7 +180,7 @@ def test_two_ranks_on_one_gpu_over_gloo_with_the_persistent_kernels():
     r0, r1 = out[0], out[1]
     import numpy as np
     assert r0["backend"] == "gloo" and np.array_equal(r0["w_before"], r1["w_before"])
-    assert r0["log0"] == r1["log0"] == ["speaker_embedding+embedding", "flows.0", "flows.1", "encoder"]
+    assert r0["log0"] == r1["log0"] == ["all"]
     clean = True
     for k in r0["g1"]:
         a, b = r0["g1"][k], r1["g1"][k]
@@ -210,4 +216,10 @@ def test_bench_script_with_two_ranks_as_the_driver_launches_it():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
     assert d["config"]["global_batch"] == 64 and d["config"]["valid_frames_per_step"] > 18932        # both ranks' frames
     assert abs(d["value"] - d["config"]["valid_frames_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
-    assert "at the end of backward" in d["config"]["workload"] and "dominant_kernel" in d["roofline"]
+    assert "ONE in-place RCCL all-reduce" in d["config"]["workload"] and "at the end of backward" in d["config"]["workload"]
+    assert "dominant_kernel" in d["roofline"]
+    # the self-diagnosing N > 1 block: ranks, backend, one collective per step, its time on every rank
+    dp = d["dp"]
+    assert dp["rccl_ranks"] == 2 and dp["backend"] == "gloo" and dp["collectives_per_step"] == 1 and dp["regime"] == "end-of-backward"
+    assert len(dp["allreduce_ms_per_rank"]) == 2 and all(v > 0 for v in dp["allreduce_ms_per_rank"])
+    assert dp["exposed_comm_ms"] == max(dp["allreduce_ms_per_rank"]) and dp["arena_mb"] > 200

@@ -710,3 +710,32 @@ def test_three_flows_ragged_bf16_compact_gemms_ignore_stale_memory_in_padded_row
             if e > worst[1]:
                 worst = (k, e)
         assert worst[1] < 3e-2, (name, worst)
+
+
+def test_ragged_batch_mel_equals_per_utterance_mel_and_zero_padding():
+    """ft_stft_r8_ragged (the data path's collated batch in ONE launch): every utterance's frames are bit-identical
+    to TacotronSTFT.mel_spectrogram of that utterance alone (reflect padding about ITS last sample), frames behind an utterance's
+    last one are exactly zero (DataCollate's padding, data.py:215-229), including a T_out beyond the longest utterance."""
+    from flowtron_amd.audio import TacotronSTFT
+    from flowtron_amd.data import DeferredMel
+    torch.manual_seed(12)
+    stft_args = dict(filter_length=1024, hop_length=256, win_length=1024, n_mel_channels=80, sampling_rate=22050, mel_fmin=0.0,
+                     mel_fmax=8000.0)
+    stft = TacotronSTFT(**stft_args).cuda()
+    ns = [22050, 9000, 256 * 40 + 255, 256 * 40, 700, 513]
+    N = max(ns)
+    audio = torch.zeros(len(ns), N)
+    for i, n in enumerate(ns):
+        audio[i, :n] = (torch.rand(n) * 2 - 1) * 0.8
+    n_dev = torch.tensor(ns, dtype=torch.int32, device="cuda")
+    T_out = N // 256 + 1 + 3
+    mel = stft.mel_spectrogram_ragged(audio.cuda(), n_dev, T_out)
+    assert mel.shape == (len(ns), 80, T_out)
+    for i, n in enumerate(ns):
+        t = n // 256 + 1
+        ref = stft.mel_spectrogram(audio[i:i + 1, :n].cuda())[0]
+        assert ref.shape[1] == t and torch.equal(mel[i, :, :t], ref), i
+        assert float(mel[i, :, t:].abs().max()) == 0.0
+    # the loader's deferred slot goes through it
+    d = DeferredMel(audio, torch.tensor(ns), stft_args, max_t=T_out).cuda()
+    assert torch.equal(d, mel)
