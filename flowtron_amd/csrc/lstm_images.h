@@ -33,4 +33,20 @@ __global__ void make_wfrag_bwd(const float* __restrict__ w, unsigned short* __re
     }
 }
 
+// W_hh [4H][H] fp32 -> reduce-scatter backward fragment image (lstm_persist_bwd_rs_k) [H/32][H/16][4][64][8] bf16:
+//   CU slot q (units q*32 .. q*32+31), column tile jt, chunk g (= gate), lane (kg,li), e  <-  W_hh[g*H + q*32 + kg*8 + e][jt*16 + li]
+// i.e. the B operand of  partial[row][j] = sum_c dgates[row][c] W_hh[grow(c)][j]  over the CU's OWN 128 gate rows c = g*32 + unit.
+__global__ void make_wfrag_rs(const float* __restrict__ w, unsigned short* __restrict__ out, int H) {
+    const size_t total = (size_t)4 * H * H;
+    const int ntile = H >> 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const size_t rest = i >> 9;
+        const int g = (int)(rest & 3), jt = (int)((rest >> 2) % ntile), q = (int)((rest >> 2) / ntile);
+        const int li = lane & 15, kg = lane >> 4;
+        const size_t r = (size_t)g * H + q * 32 + kg * 8 + e;
+        out[i] = f2op16(w[r * H + jt * 16 + li]);
+    }
+}
+
 }  // namespace

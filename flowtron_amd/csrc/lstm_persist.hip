@@ -92,6 +92,11 @@ __device__ __forceinline__ void dma_dword(const float* src, unsigned lds_addr) {
                  : "=&s"(keep) : "v"(src), "s"(lds_addr) : "memory");
 }
 
+// the same with the LDS address made scalar by force (lstm_persist_bwd_rs_k: its loop shape leaves the address in a VGPR otherwise)
+__device__ __forceinline__ void dma_dword_u(const float* src, unsigned lds_addr) {
+    dma_dword(src, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr));
+}
+
 // lane l <- lane l + n of the same 16-lane row (DPP row_shl:n), n = 0 .. 15
 template <int N>
 __device__ __forceinline__ unsigned row_shl(unsigned v) {
@@ -749,6 +754,327 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward recurrence, REDUCE-SCATTER form (round 4).  The all-gather form above hands the group's dgates vector (RPGP x 4H
+// 16-bit operands = 32 KB per CU and step) to every CU, which then multiplies it with ITS 32 columns of W_hh^T: measured, ~0.6 us
+// of its 2.8 us step are the 1 MB per XCD and step the 32 CUs pull out of their L2, 0.2 us the sentinel resets.  Here the product
+// is split the other way:
+//   CU q keeps the W_hh rows of ITS OWN 128 gate rows (c = gate*32 + unit; the forward kernel's slice, [128 x H] as B fragments:
+//        wave w holds column tiles 16 w .. 16 w + 15 for the four k-chunks = gates) and multiplies its own, LOCAL dgates
+//        (RPGP x 128, staged through 1 KB of LDS -- no all-gather at all) into a partial dh_rec [RPGP x H] in fp32;
+//   the partials are REDUCE-SCATTERED through the XCD's L2: CU q publishes, for every consumer q', its [32 units x RPGP rows] slab
+//        (512 B, one 16-byte store per lane and tile), and gathers the 32 slabs addressed to it (16 KB per CU and step: half the
+//        bytes of the bare all-gather, a quarter of the tagged one), summing them in a fixed order: 4 loads per wave in registers,
+//        then 8 per-wave-half sums through LDS.
+// Hand-off: every fp32 dword carries its own tag in the mantissa LSB (tag = bit 1 of the step counter; two parity buffers, so a
+// slot alternates tag per reuse; initial fill 0xFF = tag 1 != tag of steps 0 / 1): no sentinel resets, no epoch words, no extra
+// bytes -- the payload loses one mantissa bit (relative 2^-23, four orders below the 16-bit operand rounding of dgates).
+// The sum over the 32 partials is NOT the launch-per-step kernel's summation order: results agree with lstm_bwd_step_bf16 to fp32
+// rounding (tests: tolerance, not bit-identity).  Roles: all four waves poll, multiply and publish; between the two barriers of
+// a step waves 0-1 run the cell backward while waves 2-3 store the previous step's dgates rows / image and issue the ring DMAs.
+template <int OUT, bool PROF = false>
+__global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
+    constexpr bool WF32 = OUT != 2, WIMG = OUT != 0;
+    constexpr int NG = 8, CPG = NCU / NG, UPC = PH / CPG, RPGP = 32 / NG, NE = RPGP * UPC;      // 32 CUs, 32 units, 4 rows, 128 elements
+    constexpr int NT = PH / 16 / 4;                // column tiles per wave: 16
+    static_assert(UPC == 32 && RPGP == 4 && NE == 128, "built for group == XCD: 32 CUs x 32 units, 4 batch rows");
+    // LDS: gather sums [8 = wave x half][32 units][4 rows] | dgates operands [4 gates][16 A-tile rows][32 units] 16-bit (rows >= RPGP
+    // zero for good: every lane reads its fragment without a branch) | RING steps in [slot][gates x4, dy][e] | RING cells [slot][e] |
+    // 2 steps out [parity][4][e]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* gsum = smem;                                             // 8 * 128 floats
+    unsigned* daop = reinterpret_cast<unsigned*>(smem + 8 * NE);    // 4 * 16 * 16 dwords (pairs of 16-bit operands)
+    float* ins = smem + 8 * NE + 1024;
+    float* cells = ins + RING * 5 * NE;
+    float* outs = cells + RING * NE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    int grp, q;
+    if (!join_group_local<CPG>(p.census, p.status, tid, grp, q)) return;
+    const int B = p.B, T = p.T;
+    const int b0 = grp * RPGP;
+    for (int i2 = tid; i2 < 1024; i2 += 256) daop[i2] = 0u;          // (made visible by the barrier behind the first ring fill)
+
+    // ---- resident weights: tile 16 wave + j, chunk (= gate) g
+    bf16x8 w[NT][4];
+    {
+        const bf16x8* wf = reinterpret_cast<const bf16x8*>(p.wTfrag);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) w[j][g] = wf[((size_t)((q * (PH / 16) + wave * NT + j) * 4 + g)) * 64 + lane];
+    }
+
+    const bool erole = tid < NE;
+    const int el = tid % UPC, ebl = tid / UPC;
+    const int eb = b0 + ebl, eu = q * UPC + el;
+    const bool ev = erole && eb < B;
+    const int len = ev ? p.lens[eb] : 0;
+    int tg = 0;
+#pragma unroll
+    for (int r = 0; r < RPGP; ++r) {
+        const int bb = b0 + r;
+        if (bb < B) { const int l = p.lens[bb]; tg = l > tg ? l : tg; }
+    }
+    tg = tg < T ? tg : T;
+
+    // output role of waves 2-3 (as in lstm_persist_bwd_k)
+    const int oe = tid - NE;
+    const int ob = b0 + oe / UPC, ou = q * UPC + oe % UPC;
+    const bool ovalid = tid >= NE && ob < B;
+    int olen = 0, ooff = 0;
+    if (WIMG && ovalid) {
+        olen = p.lens[ob];
+        for (int bb = 0; bb < ob; ++bb) ooff += p.lens[bb] + 1;
+    }
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    auto store_outputs = [&](int n) {
+        if (!ovalid) return;
+        const float* o = outs + (n & 1) * 4 * NE + oe;
+        const int so = tg - 1 - n;
+        const float v0 = o[0], v1 = o[NE], v2 = o[2 * NE], v3 = o[3 * NE];
+        if constexpr (WF32) {
+            float* dg = p.dgx + ((size_t)so * B + ob) * 4 * PH + ou;
+            dg[0] = v0; dg[(size_t)PH] = v1; dg[(size_t)2 * PH] = v2; dg[(size_t)3 * PH] = v3;
+        }
+        if (WIMG && so < olen) {
+            unsigned short* ip = p.dimg + (size_t)(ooff + so) * p.dimg_ld + ou;
+            ip[0] = (unsigned short)pack_op16x2(v0, 0.f); ip[PH] = (unsigned short)pack_op16x2(v1, 0.f);
+            ip[2 * PH] = (unsigned short)pack_op16x2(v2, 0.f); ip[3 * PH] = (unsigned short)pack_op16x2(v3, 0.f);
+            bsum[0] += v0; bsum[1] += v1; bsum[2] += v2; bsum[3] += v3;
+        }
+    };
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
+    const int eh = (wave & 1) * 64 + lane;
+    const int hb = b0 + eh / UPC, hu = q * UPC + eh % UPC;
+    const bool hvalid = hb < B;
+    const unsigned ins0 = (unsigned)(size_t)(lds_void*)ins + (unsigned)(wu & 1) * 256u;
+    const unsigned cells0 = (unsigned)(size_t)(lds_void*)cells + (unsigned)(wu & 1) * 256u;
+    auto prefetch = [&](int m) {
+        if (wu >= 2 && m < tg && hvalid) {
+            const int sm = tg - 1 - m;
+            const size_t row = (size_t)sm * B + hb;
+            const unsigned dst = ins0 + (unsigned)((m % RING) * 5 * NE * 4);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) dma_dword_u(p.gates + row * 4 * PH + (size_t)f * PH + hu, dst + (unsigned)(f * NE * 4));
+            dma_dword_u(p.dy + row * p.ldy + hu, dst + (unsigned)(4 * NE * 4));
+            if (sm > 0) dma_dword_u(p.cell + (row - B) * PH + hu, cells0 + (unsigned)((m % RING) * NE * 4));
+        }
+    };
+    if (wu >= 2 && tg > 0 && hvalid) dma_dword_u(p.cell + ((size_t)(tg - 1) * B + hb) * PH + hu, cells0 + (unsigned)((RING - 1) * NE * 4));
+#pragma unroll
+    for (int m = 0; m < DIST; ++m) prefetch(m);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... and the compiler is TOLD so (the builtin is visible to its wait-count pass, the asm is not): otherwise the first use of every
+    // register loaded above -- the weight fragments at the first MFMA, the lengths in the output path -- sits inside the loop behind a
+    // vmcnt(0) that, executed every step, waits for whatever is in flight then: the ring DMAs and the output stores of waves 2-3
+    __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0), expcnt / lgkmcnt untouched
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" :: "v"(w[j][g]));   // a (free) first use of every fragment BEFORE the loop
+    asm volatile("" :: "v"(olen), "v"(ooff), "v"(len));
+    __syncthreads();
+
+    float dc_carry = 0.f;
+    // partial buffers: [2 parity][NG][consumer 32][producer 32][32 units][4 rows] fp32.  This CU reads its consumer block (16 KB,
+    // wave w the producers 8 w .. 8 w + 7 = 4 loads of 1 KB) and writes slab [consumer][q] of every consumer block.
+    constexpr size_t PB_GROUP = (size_t)CPG * CPG * UPC * RPGP;      // floats per group and parity (131 072 = 512 KB)
+    float* const pbase = reinterpret_cast<float*>(p.dgran);
+    __amdgpu_buffer_rsrc_t rs[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+        rs[par] = __builtin_amdgcn_make_buffer_rsrc(pbase + ((size_t)par * NG + grp) * PB_GROUP + (size_t)q * CPG * UPC * RPGP, 0,
+                                                    CPG * UPC * RPGP * 4, 0x00020000);
+    const int voff = lane * 16;
+    const int soff_w = __builtin_amdgcn_readfirstlane(wave) * 4096;
+    // write side: the whole parity buffer of the group; lane offset = this producer's slab + its unit, scalar offset = consumer block
+    __amdgpu_buffer_rsrc_t wrs[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+        wrs[par] = __builtin_amdgcn_make_buffer_rsrc(pbase + ((size_t)par * NG + grp) * PB_GROUP, 0, (int)(PB_GROUP * 4), 0x00020000);
+    const int wvoff = kg == 0 ? (q * UPC * RPGP + li * RPGP) * 4 : (int)0x7ffffff0;      // (beyond num_records: dropped)
+    const int wsoff_w = __builtin_amdgcn_readfirstlane(wave) * 8 * (CPG * UPC * RPGP * 4);
+    const long t_start = wall_clock64();
+    bool dead = false;
+    // phase stamps only in the PROF instantiation (ft_lstm_persist_debug_prof): their per-step stores make the compiler wait for
+    // ALL outstanding memory operations -- ring DMAs included -- where it reuses the stamp registers
+    const bool prof = PROF && p.prof != nullptr && grp == 0 && q == 0 && lane == 0;
+
+    for (int n = 0; n < tg; ++n) {
+        long st0 = 0, st1 = 0, st2 = 0, st3 = 0, npass = 0;
+        if (prof) st0 = wall_clock64();
+        const int s = tg - 1 - n;
+        if (n > 0) {
+            // ---- gather: the partials of step n - 1 addressed to this CU (buffer (n-1) & 1, tag = bit 1 of n - 1)
+            const unsigned tag = (unsigned)((n - 1) >> 1) & 1u;
+            const int par = (n - 1) & 1;
+            u32x4 ld[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ld[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, soff_w + g * 1024, 2);
+            unsigned ready = 0;
+            for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (!((ready >> g) & 1u)) {
+                        const bool ok = (((ld[g][0] ^ tag) | (ld[g][1] ^ tag) | (ld[g][2] ^ tag) | (ld[g][3] ^ tag)) & 1u) == 0u;
+                        if (__all(ok)) ready |= 1u << g;
+                    }
+                }
+                if (ready == 15u) break;
+                if (prof) ++npass;
+                if ((spins & 15) == 15) {
+                    // (wave-uniform by construction -- and by readfirstlane for the compiler: a lane-divergent `dead` leaves a static
+                    // path from the poll loads into the step body that skips the explicit wait below)
+                    const int st_now = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (wall_clock64() - t_start > p.timeout_ticks || st_now != 0) {
+                        dead = true;
+                        break;
+                    }
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (!((ready >> g) & 1u)) ld[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, soff_w + g * 1024, 2);
+                }
+            }
+            if (dead) break;
+            // lane (half = lane >> 5, unit = lane & 31) holds rows 0 .. 3 of producers 8 w + 2 g + half: sum over g in registers
+            f32x4 sacc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                sacc[r] = ((__uint_as_float(ld[0][r] & ~1u) + __uint_as_float(ld[1][r] & ~1u)) + __uint_as_float(ld[2][r] & ~1u)) +
+                          __uint_as_float(ld[3][r] & ~1u);
+            *reinterpret_cast<f32x4*>(gsum + ((wave * 2 + (lane >> 5)) * UPC + (lane & 31)) * 4) = sacc;
+        }
+        if (prof) st1 = wall_clock64();
+        // every poll load has returned (its data was just compared) and, vmcnt retiring in order, so has everything issued before it;
+        // say so in a form the compiler's wait-count pass sees ON EVERY PATH into the step body, or it protects the re-issued loads'
+        // destination registers with a vmcnt(0) at their next reuse -- in the MFMA block, where it would wait for the ring DMAs and
+        // output stores waves 2-3 have issued in between
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();                                             // (1) gather sums visible; dgates operands of the last step consumed
+        if (n > 0) store_outputs(n - 1);
+        prefetch(n + DIST);
+        if (erole) {
+            const int i = n % RING;
+            const bool active = s < len;
+            float da[4] = {0.f, 0.f, 0.f, 0.f};
+            if (active) {
+                const float* in = ins + i * 5 * NE + tid;
+                float dh = in[4 * NE];
+                if (n > 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) dh += gsum[(k * UPC + el) * 4 + ebl];
+                }
+                const float c_t = cells[((n + RING - 1) % RING) * NE + tid], c_prev = s > 0 ? cells[i * NE + tid] : 0.f;
+                float carry;
+                lstm_cell_bwd<true>(dh, dc_carry, in[0], in[NE], in[2 * NE], in[3 * NE], c_t, c_prev, da, carry);
+                dc_carry = carry;
+            }
+            // dgates as MFMA A operands: daop[gate][row][unit pair] (16-bit pairs; the odd unit comes from lane + 1 of the DPP row)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float nb = __uint_as_float(row_shl<1>(__float_as_uint(da[g])));
+                if ((el & 1) == 0) daop[(g * 16 + ebl) * (UPC / 2) + (el >> 1)] = pack_op16x2(da[g], nb);
+            }
+            float* o = outs + (n & 1) * 4 * NE + tid;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) o[g * NE] = da[g];
+        }
+        __syncthreads();                                             // (2) the group's rows of dgates_s are in LDS
+        if (prof) st2 = wall_clock64();
+        if (n + 1 < tg) {
+            // ---- partial dh_rec of the NEXT step: this CU's dgates x its 128 rows of W_hh; rows >= RPGP of the A tile are zero
+            bf16x8 a[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                a[g] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(daop + (g * 16 + li) * (UPC / 2) + kg * 4));
+            // tiles in groups of four (16 MFMAs: each accumulator's chain is four instructions apart); a group's results are tagged and
+            // stored while the NEXT group's MFMAs occupy the matrix pipe.  D rows 0 .. 3 sit in lanes kg == 0; tile j of wave w =
+            // columns (16 w + j) 16 + li = consumer 8 w + (j >> 1), unit (j & 1) 16 + li: one tagged 16-byte store [unit][4 rows] per
+            // tile, lane offset in the VGPR, consumer / half offsets scalar (raw buffer store: the compiler owns its data hazards)
+            const unsigned tagw = (unsigned)(n >> 1) & 1u;
+            const __amdgpu_buffer_rsrc_t wr = wrs[n & 1];
+            auto group = [&](int tq, f32x4 (&acc)[4]) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc[jj] = mfma16(a[g], w[tq * 4 + jj][g], acc[jj]);
+            };
+            auto publish = [&](int tq, const f32x4 (&acc)[4]) {
+                // no branch around the stores (MFMAs and stores stay in ONE scheduling region): lanes kg != 0 hold the padding rows of
+                // the D tile and carry an offset beyond the descriptor's range -- the hardware drops their stores
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = tq * 4 + jj;
+                    u32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (__float_as_uint(acc[jj][r]) & ~1u) | tagw;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, wr, wvoff, wsoff_w + (j >> 1) * (CPG * UPC * RPGP * 4) + (j & 1) * (16 * RPGP * 4), 0);
+                }
+            };
+            // software pipeline: the MFMAs of group tq + 1 are issued BEFORE the stores of group tq
+            f32x4 accA[4], accB[4];
+            group(0, accA);
+            group(1, accB);
+            publish(0, accA);
+            group(2, accA);
+            publish(1, accB);
+            group(3, accB);
+            publish(2, accA);
+            publish(3, accB);
+            // issue order asked of the scheduler: one MFMA, then the VALU work that fits under it (fragment moves, tags), a store
+            // after every fourth -- the matrix pipe is busy ~16 cycles per MFMA, a VALU instruction issues in ~4
+#pragma unroll
+            for (int i3 = 0; i3 < 64; ++i3) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                if ((i3 & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+            }
+        }
+        if (prof) st3 = wall_clock64();
+        if (prof && n < 1024) {
+            long* o = p.prof + ((size_t)n * 4 + wave) * 5;
+            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = npass;
+        }
+    }
+    if (dead) {
+        if (lane == 0) atomicExch(p.status, 1);
+        return;
+    }
+    __syncthreads();
+    if (tg > 0) store_outputs(tg - 1);
+    if (WF32 && ev)
+        for (int t = tg; t < T; ++t) {
+            float* dg = p.dgx + ((size_t)t * B + eb) * 4 * PH + eu;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dg[(size_t)g * PH] = 0.f;
+        }
+    if constexpr (WIMG) {
+        if (ovalid) {
+            unsigned short* ip = p.dimg + (size_t)(ooff + olen) * p.dimg_ld + ou;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                atomicAdd(p.dbias + g * PH + ou, bsum[g]);
+                ip[g * PH] = 0;
+            }
+        }
+        int R = 0;
+        for (int bb = 0; bb < B; ++bb) R += p.lens[bb] + 1;
+        int Rz = (R + 32 + 255) & ~255;
+        Rz = Rz < p.dimg_rows ? Rz : p.dimg_rows;
+        for (int r = R + grp * CPG + q; r < Rz; r += NCU) {
+            uint4* row = reinterpret_cast<uint4*>(p.dimg + (size_t)r * p.dimg_ld);
+            for (int c = tid; c < 4 * PH / 8; c += 256) row[c] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+}
+
 }  // namespace
 
 static inline size_t al256p(size_t v) { return (v + 255) & ~size_t(255); }
@@ -781,7 +1107,9 @@ extern "C" size_t ft_lstm_persist_workspace_bytes(int B, int H) {
     (void)B;
     // W_hh fragment image + granule buffers (2 parities x 32 rows x K/2 granules x 8 B, independent of NG; K = H forward,
     // 4H backward) + census counters
-    return al256p((size_t)4 * H * H * 2) + al256p((size_t)2 * 32 * (4 * H / 2) * 8) + 256;
+    // (the reduce-scatter backward, transport 21, takes 2 parities x 8 groups x [32 x 32 x 32 x 4] fp32 partials = 8 MB instead)
+    const size_t gran = (size_t)2 * 32 * (4 * H / 2) * 8, rs = (size_t)2 * 8 * 32 * 32 * 32 * 4 * sizeof(float);
+    return al256p((size_t)4 * H * H * 2) + al256p(gran > rs ? gran : rs) + 256;
 }
 #endif
 
@@ -853,8 +1181,10 @@ extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, 
     FT_CHECK_ARG(dimg == nullptr || (dbias && dimg_ld >= 4 * (int64_t)H && dimg_ld % 8 == 0 && dimg_rows >= (int64_t)T * B + B &&
                                      reinterpret_cast<uintptr_t>(dimg) % 16 == 0));
     FT_CHECK_ARG(T >= 0 && ldy >= H && reinterpret_cast<uintptr_t>(work) % 256 == 0);
-    const bool bare = ng > 10;
-    const int ngb = bare ? ng - 10 : ng;
+    // ng = 21: the reduce-scatter form (lstm_persist_bwd_rs_k: XCD-local, fp32 partials tagged in the mantissa LSB)
+    const bool rsform = ng == 21;
+    const bool bare = ng > 10 && !rsform;
+    const int ngb = rsform ? 1 : (bare ? ng - 10 : ng);
     FT_CHECK_ARG(ngb == 1 || ngb == 9 || ngb == 8 || ngb == 4);
     if (!ft_lstm_persist_supported(B, H))
         return ft_fail(FT_EUNSUPPORTED, "ft_lstm_persist_bwd: needs H == 1024, B <= 32 and a 256-CU device (H=%d B=%d)", H, B);
@@ -863,11 +1193,13 @@ extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, 
     char* base = reinterpret_cast<char*>(work);
     unsigned short* wTfrag = reinterpret_cast<unsigned short*>(base);
     unsigned long long* dgran = reinterpret_cast<unsigned long long*>(base + al256p((size_t)4 * H * H * 2));
-    const size_t gran_bytes = al256p((size_t)2 * 32 * (4 * H / 2) * 8);
-    unsigned* census = reinterpret_cast<unsigned*>(base + al256p((size_t)4 * H * H * 2) + gran_bytes);
-    FT_CHECK_HIP(hipMemsetAsync(dgran, bare ? 0xFF : 0, gran_bytes, st));
+    const size_t rs_bytes = (size_t)2 * 8 * 32 * 32 * 32 * 4 * sizeof(float);
+    const size_t gran_bytes = al256p(rsform ? rs_bytes : (size_t)2 * 32 * (4 * H / 2) * 8);
+    unsigned* census = reinterpret_cast<unsigned*>(base + ft_lstm_persist_workspace_bytes(B, H) - 256);
+    FT_CHECK_HIP(hipMemsetAsync(dgran, (bare || rsform) ? 0xFF : 0, gran_bytes, st));
     FT_CHECK_HIP(hipMemsetAsync(census, 0, 256, st));
-    hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H);
+    if (rsform) hipLaunchKernelGGL(make_wfrag_rs, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H);
+    else hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H);
     PersistBwdP p{dy, (long)ldy, lens, gates, cell, dgx, wTfrag, dgran, status, census, T, B, 100000000L / 2, g_persist_prof,
                   reinterpret_cast<unsigned short*>(dimg), (long)dimg_ld, (int)dimg_rows, dbias};
     // dynamic LDS: 16-partial reduce (2 x 16 x 32 unit-rows... = 2*16*TL*RPGP*17 = 2*16*8*17 floats) + staged steps
@@ -879,6 +1211,20 @@ extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, 
     };
     int rc;
     const int out = dimg == nullptr ? 0 : (dgx ? 1 : 2);
+    if (rsform) {
+        // LDS: 8 x 128 gather sums + 1024 dwords of dgates operands (16-row A tiles) + the ring (5 + 1 rows per slot) + 2 output rows
+        const size_t lds_rs = sizeof(float) * ((size_t)8 * 128 + 1024 + (size_t)RING * 5 * 128 + (size_t)RING * 128 + (size_t)2 * 4 * 128);
+        auto launch_rs = [&](auto kern) -> int {
+            FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs));
+            hipLaunchKernelGGL(kern, dim3(NCU), dim3(256), lds_rs, st, p);
+            return FT_OK;
+        };
+        if (g_persist_prof) rc = launch_rs(lstm_persist_bwd_rs_k<0, true>);      // debug stamps: fp32 rows, whatever was asked for
+        else rc = out == 0 ? launch_rs(lstm_persist_bwd_rs_k<0>) : out == 1 ? launch_rs(lstm_persist_bwd_rs_k<1>) : launch_rs(lstm_persist_bwd_rs_k<2>);
+        if (rc != FT_OK) return rc;
+        FT_CHECK_LAUNCH();
+        return FT_OK;
+    }
 #define FT_PBWD(NG_, LOCAL_, LAUX_, BARE_) \
     (out == 0 ? launch(lstm_persist_bwd_k<NG_, LOCAL_, LAUX_, BARE_, 0>) : out == 1 ? launch(lstm_persist_bwd_k<NG_, LOCAL_, LAUX_, BARE_, 1>) \
                                                                                   : launch(lstm_persist_bwd_k<NG_, LOCAL_, LAUX_, BARE_, 2>))

@@ -671,9 +671,12 @@ class LSTMSeqFn(torch.autograd.Function):
             # default (1): the forward recurrence keeps the tagged granules (1.94 vs 2.06 us per step: its publish sits on the
             # critical path and the sentinel protocol adds a store + wait there), the backward one takes the BARE operand pairs
             # (2.83 vs 3.09 us per step: half of 64 KB per CU and step) -- MI355X, round 3 run B, both bit-identical
-            if ng == 1 and _os.environ.get("FLOWTRON_LSTM_PERSIST_BWD", "bare") != "tagged":
+            bwd_form = _os.environ.get("FLOWTRON_LSTM_PERSIST_BWD", "bare")
+            if ng == 1 and bwd_form == "rs":
+                ng = 21                            # reduce-scatter form (lstm_persist_bwd_rs_k): fp32 partials, XCD-local
+            elif ng == 1 and bwd_form != "tagged":
                 ng = 11
-            ng = ng if ng in (1, 9, 8, 4, 11, 19, 18, 14) else (18 if ng > 10 else 8)      # (no 2-group backward kernel)
+            ng = ng if ng in (1, 9, 8, 4, 11, 19, 18, 14, 21) else (18 if ng > 10 else 8)      # (no 2-group backward kernel)
             st = _persist_watch(dy.device)
             work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=dy.device, dtype=torch.uint8)
             rm = ctx.rowmap

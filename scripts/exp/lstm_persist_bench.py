@@ -44,7 +44,7 @@ w0 = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=dev, dtype=torch.
 res["step"] = timeit(lambda: run_step(y0, g0, c0, w0))
 print("launch-per-step: min %.3f median %.3f us/step" % res["step"], flush=True)
 wp = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=dev, dtype=torch.uint8)
-for ng in (1, 11, 19, 9, 8, 18):
+for ng in [int(v) for v in os.environ.get("FWD_NGS", "1").split(",")]:
     y1, g1, c1 = bufs()
     y1.fill_(7.0)
     r = timeit(lambda: run_persist(ng, y1, g1, c1, wp))
@@ -86,25 +86,26 @@ def run_persist_bwd(ng, dgx, work):
 
 res["bwd_step"] = timeit(lambda: run_step_bwd(d0, w0))
 print("backward launch-per-step: min %.3f median %.3f us/step" % res["bwd_step"], flush=True)
-for ng in (1, 11, 19, 9, 8, 18):
+for ng in [int(v) for v in os.environ.get("BWD_NGS", "1,11,21").split(",")]:
     d1 = torch.full((T, B, 4 * H), 7.0, device=dev)
     r = timeit(lambda: run_persist_bwd(ng, d1, wp))
     st = int(status.item())
-    res["bwd_persist%d" % ng] = r + (st, bool(torch.equal(d0, d1)), float((d0 - d1).abs().max()))
-    print("backward persistent ng=%d: min %.3f median %.3f us/step  status %d  bit-identical %s  max|d| %.3e" % ((ng,) + res["bwd_persist%d" % ng]), flush=True)
+    rel = float((d0 - d1).norm() / d0.norm())
+    res["bwd_persist%d" % ng] = r + (st, bool(torch.equal(d0, d1)), float((d0 - d1).abs().max()), rel)
+    print("backward persistent ng=%d: min %.3f median %.3f us/step  status %d  bit-identical %s  max|d| %.3e  rel-L2 %.3e" % ((ng,) + res["bwd_persist%d" % ng]), flush=True)
     status.zero_()
 # ---- phase stamps of one workgroup (backward, XCD-local transport)
 prof.zero_()
 L.lib().ft_lstm_persist_debug_prof(L.ptr(prof))
-run_persist_bwd(int(os.environ.get("PROF_NG", "11")), d1, wp)
+run_persist_bwd(int(os.environ.get("PROF_NG_BWD", "21")), d1, wp)
 torch.cuda.synchronize()
 L.lib().ft_lstm_persist_debug_prof(None)
 pr = prof.cpu().reshape(1024, 4, 5)[100:800].double()
 for wv in range(4):
     top, swp, bar, pub, npass = (pr[:, wv, k] for k in range(5))
     step = (top[1:] - top[:-1]).mean() * 10
-    print("bwd wave %d: step %.0f ns | polls+mfma %.0f | partials+barrier %.0f | epilogue->publish %.0f | publish->next top %.0f | poll passes %.2f"
-          % (wv, step, ((swp - top).mean()) * 10, ((bar - swp).mean()) * 10, ((pub - bar).mean()) * 10 if wv < 2 else 0.0,
-             ((top[1:] - (pub if wv < 2 else bar)[:-1]).mean()) * 10, npass.mean()), flush=True)
+    print("bwd wave %d (ng 21: top->gathered | gathered->barrier 2 passed | barrier 2->published | published->next top): step %.0f ns | %.0f | %.0f | %.0f | %.0f | poll passes %.2f"
+          % (wv, step, ((swp - top).mean()) * 10, ((bar - swp).mean()) * 10, ((pub - bar).mean()) * 10,
+             ((top[1:] - pub[:-1]).mean()) * 10, npass.mean()), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/lstm_persist_bench.json", "w"))
