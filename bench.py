@@ -198,7 +198,8 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
     ws = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=dev, dtype=torch.uint8)
     st = ops.persist_status(torch.device("cuda", torch.cuda.current_device()))
     ng = int(os.environ.get("FLOWTRON_LSTM_PERSIST", "1"))
-    ng_bwd = 11 if (ng == 1 and os.environ.get("FLOWTRON_LSTM_PERSIST_BWD", "bare") != "tagged") else ng      # as ops.LSTMSeqFn.backward
+    bwd_form = os.environ.get("FLOWTRON_LSTM_PERSIST_BWD", "rs")                                              # as ops.LSTMSeqFn.backward
+    ng_bwd = ng if ng != 1 else (21 if bwd_form == "rs" else 11 if bwd_form != "tagged" else 1)
     lib = L.lib()
     # the backward recurrence as the training step launches it (ops.LSTMSeqFn.backward, FLOWTRON_LSTM_PERSIST_IMG=1): the output
     # waves leave the compact 16-bit image of dgates + the bias column sums, no fp32 dgx
@@ -242,10 +243,13 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
     #   the hand-off bytes every CU pulls from its XCD's L2 per step (forward: 16 KB of tagged granules; backward: 32 KB of bare
     #   operand pairs, 64 KB with tagged granules; x 256 CUs) at the measured L2 peak of 34.5 TB/s.
     # The LDS reduce, the barrier, the cell update and the skew between the 32 CUs of a group are what `frac` leaves.
-    mfma_us = 64 * 17 / 2.4e3
+    mfma_us = 0.47        # 64 back-to-back v_mfma_f32_16x16x32 of one wave per SIMD: 7.3 ns each, measured (scripts/exp/mfma_rate_probe.hip)
     # algorithmic HBM bytes per valid row: backward reads saved gates, cell, dy (fp32) and writes dgates -- as the 16-bit compact
     # image (2 B per element) in the step's default mode, as fp32 rows otherwise
     bwd_out = 2 * 4 * H if img_only else 4 * 4 * H
+    # hand-off bytes through the XCD's L2 per CU and step: forward = the all-gather of h (16 KB of tagged granules); backward = the
+    # reduce-scatter of fp32 partials (transport 21: 16 KB gathered + 16 KB published) or the all-gather of dgates (32 / 64 KB)
+    rs_form = ng_bwd == 21
     for name, per_row, repl, gran_kb in (("lstm_persist_bwd_k", 4 * (4 * H + H + H) + bwd_out, "lstm_bwd_step_bf16", 32 if ng_bwd > 10 else 64),
                                          ("lstm_persist_fwd_k", 4 * (4 * H + H + 4 * H + H), "lstm_fwd_step", 8 if ng > 10 else 16)):
         nbytes = 2 * 4 * H * H + rows * per_row
@@ -253,15 +257,16 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
         per_step = us[name] / T
         l2_us = 256 * gran_kb * 1024 / 34.5e12 * 1e6
         floor = hops["same_xcd_hop_us"] + mfma_us + l2_us
-        mb, mb_src = pmc_value("MFMA_BUSY", name, "mfma_busy_frac", with_source=True)
-        out[name] = {"kernel": name, "bound": "handoff-latency", "us_per_step": round(per_step, 3), "floor_us_per_step": round(floor, 3),
+        kname = "lstm_persist_bwd_rs_k" if (rs_form and name.endswith("bwd_k")) else name
+        mb, mb_src = pmc_value("MFMA_BUSY", kname, "mfma_busy_frac", with_source=True)
+        out[name] = {"kernel": kname, "bound": "handoff-latency", "us_per_step": round(per_step, 3), "floor_us_per_step": round(floor, 3),
                      "frac": round(floor / per_step, 3),
                      "floor_terms_us": {"l2_handoff_hop": round(hops["same_xcd_hop_us"], 3), "mfma_issue_64_per_wave": round(mfma_us, 3),
                                         "granule_bytes_over_l2_peak": round(l2_us, 3)},
                      "steps_per_launch": T, "us_per_launch": round(us[name], 1),
                      "replaces": {"kernel": repl, "us_per_step": round(us[repl] / T, 3)},
                      "hbm": {"achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                             "bytes_per_launch": nbytes, "traffic": pmc_traffic(name)},
+                             "bytes_per_launch": nbytes, "traffic": pmc_traffic(kname)},
                      "mfma_busy_frac_pmc": mb, "pmc_round": mb_src,
                      "entry_point": "ft_lstm_persist_bwd_img (image only)" if (name.endswith("bwd_k") and img_only) else None,
                      "note": "one launch = one whole sequence of T dependent steps, W_hh resident in registers; neither the HBM nor the "

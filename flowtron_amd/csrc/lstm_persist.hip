@@ -773,6 +773,26 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
 // The sum over the 32 partials is NOT the launch-per-step kernel's summation order: results agree with lstm_bwd_step_bf16 to fp32
 // rounding (tests: tolerance, not bit-identity).  Roles: all four waves poll, multiply and publish; between the two barriers of
 // a step waves 0-1 run the cell backward while waves 2-3 store the previous step's dgates rows / image and issue the ring DMAs.
+// 16x16x32 MFMA with the B operand in ACCUMULATION registers and the accumulator in architectural ones (inline asm: the builtin
+// only takes B from VGPRs, so fragments parked in AGPRs cost four v_accvgpr_read each per use).  lstm_persist_bwd_rs_k keeps all 64
+// weight fragments of a wave (256 registers) in AGPRs for the whole launch and everything else in VGPRs: no register-file moves in
+// the step.  The compiler does not see an MFMA here: the CALLER keeps dependent uses of `acc` far enough apart (>= 3 other MFMAs
+// between two accumulations into the same registers, >= 18 wait states before a VALU read; CDNA3 ISA 4.5 / 7.x hazard tables).
+__device__ __forceinline__ void mfma16_bagpr_first(f32x4& acc, const u32x4& a, const u32x4& b) {      // acc = a x b (C = 0)
+#if FT_OPFMT == 1
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+#else
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+#endif
+}
+__device__ __forceinline__ void mfma16_bagpr(f32x4& acc, const u32x4& a, const u32x4& b) {
+#if FT_OPFMT == 1
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+#else
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+#endif
+}
+
 template <int OUT, bool PROF = false>
 __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
     constexpr bool WF32 = OUT != 2, WIMG = OUT != 0;
@@ -798,9 +818,9 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
     for (int i2 = tid; i2 < 1024; i2 += 256) daop[i2] = 0u;          // (made visible by the barrier behind the first ring fill)
 
     // ---- resident weights: tile 16 wave + j, chunk (= gate) g
-    bf16x8 w[NT][4];
+    u32x4 w[NT][4];
     {
-        const bf16x8* wf = reinterpret_cast<const bf16x8*>(p.wTfrag);
+        const u32x4* wf = reinterpret_cast<const u32x4*>(p.wTfrag);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -874,7 +894,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) asm volatile("" :: "v"(w[j][g]));   // a (free) first use of every fragment BEFORE the loop
+        for (int g = 0; g < 4; ++g) asm volatile("" : "+a"(w[j][g]));   // every fragment lives in accumulation registers from here on
     asm volatile("" :: "v"(olen), "v"(ooff), "v"(len));
     __syncthreads();
 
@@ -907,6 +927,29 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
         long st0 = 0, st1 = 0, st2 = 0, st3 = 0, npass = 0;
         if (prof) st0 = wall_clock64();
         const int s = tg - 1 - n;
+        // everything of the cell backward that does not need dh_rec -- the ring reads, tanh(c_t), the five gate-derivative factors --
+        // is evaluated by the epilogue waves while the gather loads are in flight:
+        //   dc = dh fA + dc_carry ; carry' = dc f ; da_i = dc fI ; da_f = dc fF ; da_g = dc fG ; da_o = dh fO
+        //   fA = o (1 - tanh^2 c_t), fO = tanh(c_t) o (1 - o), fI = g i (1 - i), fF = c_prev f (1 - f), fG = i (1 - g^2)
+        // (lstm_cell_bwd's products re-associated: equal to fp32 rounding, like the partial sums themselves)
+        float fA = 0.f, fO = 0.f, fI = 0.f, fF = 0.f, fG = 0.f, fgate = 0.f, dy_s = 0.f;
+        const bool active = erole && s < len;
+        auto precompute = [&]() {
+            if (active) {
+                const int i = n % RING;
+                const float* in = ins + i * 5 * NE + tid;
+                const float ig = in[0], fg = in[NE], gg = in[2 * NE], og = in[3 * NE];
+                dy_s = in[4 * NE];
+                const float c_t = cells[((n + RING - 1) % RING) * NE + tid], c_prev = s > 0 ? cells[i * NE + tid] : 0.f;
+                const float tc = 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.f * 1.4426950408889634f * c_t) + 1.f);
+                fA = og * __fmaf_rn(-tc, tc, 1.f);
+                fO = tc * og * (1.f - og);
+                fI = gg * ig * (1.f - ig);
+                fF = c_prev * fg * (1.f - fg);
+                fG = ig * __fmaf_rn(-gg, gg, 1.f);
+                fgate = fg;
+            }
+        };
         if (n > 0) {
             // ---- gather: the partials of step n - 1 addressed to this CU (buffer (n-1) & 1, tag = bit 1 of n - 1)
             const unsigned tag = (unsigned)((n - 1) >> 1) & 1u;
@@ -914,6 +957,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
             u32x4 ld[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) ld[g] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, soff_w + g * 1024, 2);
+            precompute();
             unsigned ready = 0;
             for (unsigned spins = 0;; ++spins) {
 #pragma unroll
@@ -949,6 +993,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
                           __uint_as_float(ld[3][r] & ~1u);
             *reinterpret_cast<f32x4*>(gsum + ((wave * 2 + (lane >> 5)) * UPC + (lane & 31)) * 4) = sacc;
         }
+        if (n == 0) precompute();
         if (prof) st1 = wall_clock64();
         // every poll load has returned (its data was just compared) and, vmcnt retiring in order, so has everything issued before it;
         // say so in a form the compiler's wait-count pass sees ON EVERY PATH into the step body, or it protects the re-issued loads'
@@ -959,20 +1004,16 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
         if (n > 0) store_outputs(n - 1);
         prefetch(n + DIST);
         if (erole) {
-            const int i = n % RING;
-            const bool active = s < len;
             float da[4] = {0.f, 0.f, 0.f, 0.f};
             if (active) {
-                const float* in = ins + i * 5 * NE + tid;
-                float dh = in[4 * NE];
+                float dh = dy_s;
                 if (n > 0) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) dh += gsum[(k * UPC + el) * 4 + ebl];
+                    const float* gs = gsum + el * 4 + ebl;
+                    dh += ((gs[0] + gs[UPC * 4]) + (gs[2 * UPC * 4] + gs[3 * UPC * 4])) + ((gs[4 * UPC * 4] + gs[5 * UPC * 4]) + (gs[6 * UPC * 4] + gs[7 * UPC * 4]));
                 }
-                const float c_t = cells[((n + RING - 1) % RING) * NE + tid], c_prev = s > 0 ? cells[i * NE + tid] : 0.f;
-                float carry;
-                lstm_cell_bwd<true>(dh, dc_carry, in[0], in[NE], in[2 * NE], in[3 * NE], c_t, c_prev, da, carry);
-                dc_carry = carry;
+                const float dc = __fmaf_rn(dh, fA, dc_carry);
+                dc_carry = dc * fgate;
+                da[0] = dc * fI; da[1] = dc * fF; da[2] = dc * fG; da[3] = dh * fO;
             }
             // dgates as MFMA A operands: daop[gate][row][unit pair] (16-bit pairs; the odd unit comes from lane + 1 of the DPP row)
 #pragma unroll
@@ -988,10 +1029,9 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
         if (prof) st2 = wall_clock64();
         if (n + 1 < tg) {
             // ---- partial dh_rec of the NEXT step: this CU's dgates x its 128 rows of W_hh; rows >= RPGP of the A tile are zero
-            bf16x8 a[4];
+            u32x4 a[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                a[g] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(daop + (g * 16 + li) * (UPC / 2) + kg * 4));
+            for (int g = 0; g < 4; ++g) a[g] = *reinterpret_cast<const u32x4*>(daop + (g * 16 + li) * (UPC / 2) + kg * 4);
             // tiles in groups of four (16 MFMAs: each accumulator's chain is four instructions apart); a group's results are tagged and
             // stored while the NEXT group's MFMAs occupy the matrix pipe.  D rows 0 .. 3 sit in lanes kg == 0; tile j of wave w =
             // columns (16 w + j) 16 + li = consumer 8 w + (j >> 1), unit (j & 1) 16 + li: one tagged 16-byte store [unit][4 rows] per
@@ -1000,11 +1040,11 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
             const __amdgpu_buffer_rsrc_t wr = wrs[n & 1];
             auto group = [&](int tq, f32x4 (&acc)[4]) {
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int jj = 0; jj < 4; ++jj) mfma16_bagpr_first(acc[jj], a[0], w[tq * 4 + jj][0]);
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                for (int g = 1; g < 4; ++g)
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) acc[jj] = mfma16(a[g], w[tq * 4 + jj][g], acc[jj]);
+                    for (int jj = 0; jj < 4; ++jj) mfma16_bagpr(acc[jj], a[g], w[tq * 4 + jj][g]);
             };
             auto publish = [&](int tq, const f32x4 (&acc)[4]) {
                 // no branch around the stores (MFMAs and stores stay in ONE scheduling region): lanes kg != 0 hold the padding rows of
@@ -1027,15 +1067,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
             publish(1, accB);
             group(3, accB);
             publish(2, accA);
+            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");           // (the last group's results: MFMA -> VALU read wait states)
             publish(3, accB);
-            // issue order asked of the scheduler: one MFMA, then the VALU work that fits under it (fragment moves, tags), a store
-            // after every fourth -- the matrix pipe is busy ~16 cycles per MFMA, a VALU instruction issues in ~4
-#pragma unroll
-            for (int i3 = 0; i3 < 64; ++i3) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                if ((i3 & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
-            }
         }
         if (prof) st3 = wall_clock64();
         if (prof && n < 1024) {

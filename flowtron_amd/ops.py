@@ -668,12 +668,13 @@ class LSTMSeqFn(torch.autograd.Function):
         ng = lstm_persist_groups(B, H, ctx.reverse, ctx.mode, dy.device)
         d_img_k, img_only = None, False
         if ng:
-            # default (1): the forward recurrence keeps the tagged granules (1.94 vs 2.06 us per step: its publish sits on the
-            # critical path and the sentinel protocol adds a store + wait there), the backward one takes the BARE operand pairs
-            # (2.83 vs 3.09 us per step: half of 64 KB per CU and step) -- MI355X, round 3 run B, both bit-identical
-            bwd_form = _os.environ.get("FLOWTRON_LSTM_PERSIST_BWD", "bare")
+            # default (1): the forward recurrence keeps the all-gather of h as tagged granules; the backward one runs in REDUCE-SCATTER
+            # form (transport 21, round 4: 1.92 us per step against 2.84 for the bare all-gather of dgates -- every CU multiplies its
+            # own dgates, fp32 partials cross the L2; equal to fp32 rounding).  FLOWTRON_LSTM_PERSIST_BWD=bare | tagged select the
+            # all-gather kernels, which ARE bit-identical to the launch-per-step kernel.
+            bwd_form = _os.environ.get("FLOWTRON_LSTM_PERSIST_BWD", "rs")
             if ng == 1 and bwd_form == "rs":
-                ng = 21                            # reduce-scatter form (lstm_persist_bwd_rs_k): fp32 partials, XCD-local
+                ng = 21
             elif ng == 1 and bwd_form != "tagged":
                 ng = 11
             ng = ng if ng in (1, 9, 8, 4, 11, 19, 18, 14, 21) else (18 if ng > 10 else 8)      # (no 2-group backward kernel)

@@ -709,6 +709,78 @@ def test_persistent_backward_emits_the_compact_dgates_image(env, fmt, ng, T, B, 
     assert float((img2.colsum - ref.colsum).abs().max()) <= 1e-4 * float(ref.colsum.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("T,B,lens", [(37, 32, None), (9, 5, [9, 9, 4, 2, 1]), (40, 32, "ragged0"), (1, 32, None), (862, 32, "bench")])
+def test_reduce_scatter_backward_recurrence_matches_the_launch_per_step_kernel(env, fmt, T, B, lens):
+    """Transport 21 (lstm_persist_bwd_rs_k, the step's default backward recurrence since round 4): every CU multiplies its OWN dgates
+    with its 128 rows of W_hh and the fp32 partials are reduce-scattered through the XCD's L2, so the sum over the recurrent product
+    runs in another order than lstm_bwd_step_bf16's -- equal to fp32 rounding, not bit for bit.  Held against the launch-per-step
+    kernel (same 16-bit operand rounding of dgates): a different fp32 rounding occasionally flips the 16-bit rounding of a dgates
+    element (one part in 2^9 / 2^12 of that element), which the contracting recurrence carries along: rel-L2 <= 1e-3 (bf16; observed
+    2.5e-4 at T 862) / 2e-4 (fp16), and the first step (no recurrent term) bit-identical.  The three output modes agree bit for bit
+    among themselves: fp32 rows, rows + compact 16-bit image, image only (= ft_bf16_image_rows of the rows, and the column sums)."""
+    L, ops = env
+    H = 1024
+    if not L.lib().ft_lstm_persist_supported(B, H):
+        pytest.skip("needs a 256-CU device")
+    torch.manual_seed(T * 7 + B + fmt)
+    gx = torch.randn(T, B, 4 * H, device="cuda") * 0.5
+    w = torch.randn(4 * H, H, device="cuda") / H ** 0.5
+    dy = torch.randn(T, B, H, device="cuda") * 0.1
+    if lens == "ragged0":
+        lens = [T] + [max(1, (T * (B - i)) // B - (i % 3)) for i in range(1, B)]
+    else:
+        lens = _bench_lens(lens, 1)
+    if lens is None:
+        lens = [max(1, T - 2 * i) for i in range(B)]
+    lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    y, gates, cell = torch.empty(T, B, H, device="cuda"), torch.zeros(T, B, 4 * H, device="cuda"), torch.zeros(T, B, H, device="cuda")
+    work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device="cuda", dtype=torch.uint8)
+    L.check(L.lib().ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens_t), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(work),
+                                    T, B, H, 0, fmt, L.stream()), "ft_lstm_seq_fwd")
+    d0 = torch.full((T, B, 4 * H), 7.0, device="cuda")
+    L.check(L.lib().ft_lstm_seq_bwd(L.ptr(dy), H, L.ptr(w), L.ptr(lens_t), L.ptr(gates), L.ptr(cell), L.ptr(d0), L.ptr(work),
+                                    T, B, H, 0, fmt, L.stream()), "ft_lstm_seq_bwd")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    wp = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device="cuda", dtype=torch.uint8)
+    d1 = torch.full((T, B, 4 * H), 7.0, device="cuda")
+    L.check(L.op16("ft_lstm_persist_bwd", fmt)(L.ptr(dy), H, L.ptr(w), L.ptr(lens_t), L.ptr(gates), L.ptr(cell), L.ptr(d1), L.ptr(wp),
+                                               L.ptr(status), T, B, H, 21, L.stream()), "ft_lstm_persist_bwd (21)")
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    act = torch.arange(T, device="cuda")[:, None] < lens_t[None, :]
+    assert float(d1[~act].abs().max() if (~act).any() else 0.0) == 0.0            # padded frames: exact zeros
+    rel = float((d0 - d1).norm() / d0.norm())
+    assert rel <= (1e-3 if fmt == 1 else 2e-4), rel
+    for b in range(B):                                                            # each utterance's LAST frame has no recurrent term
+        assert torch.equal(d0[lens[b] - 1, b], d1[lens[b] - 1, b]), b
+    # output modes: rows + image, image only
+    rm = ops.RowMap(lens_t, T, B)
+    imgs = []
+    for with_rows in (True, False):
+        img = ops.Bf16Image.empty_rows(4 * H, rm, fmt, torch.device("cuda"))
+        img.buf.fill_(0x5A)
+        rows_alloc = img.buf.numel() // (2 * img.ld)
+        d2 = torch.full((T, B, 4 * H), 7.0, device="cuda")
+        L.check(L.op16("ft_lstm_persist_bwd_img", fmt)(L.ptr(dy), H, L.ptr(w), L.ptr(lens_t), L.ptr(gates), L.ptr(cell),
+                                                       L.ptr(d2) if with_rows else None, L.ptr(wp), L.ptr(status), T, B, H, 21,
+                                                       L.ptr(img.buf), img.ld, rows_alloc, L.ptr(img.colsum), L.stream()), "ft_lstm_persist_bwd_img (21)")
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        if with_rows:
+            assert torch.equal(d1, d2)
+        imgs.append(img)
+    ref = ops.Bf16Image(d1.reshape(T * B, 4 * H), colsum=True, mode=fmt, rowmap=rm)
+    torch.cuda.synchronize()
+    R = sum(lens) + B
+    Rz = min((R + 32 + 255) // 256 * 256, rows_alloc)
+    rb = ref.buf[: Rz * ref.ld * 2].view(torch.int16).view(Rz, ref.ld)[:, : 4 * H]
+    for img in imgs:
+        a = img.buf[: Rz * img.ld * 2].view(torch.int16).view(Rz, img.ld)[:, : 4 * H]
+        assert torch.equal(a, rb)
+        assert float((img.colsum - ref.colsum).abs().max()) <= 1e-4 * float(ref.colsum.abs().max()) + 1e-6
+
+
 def test_image_only_gradient_fails_loudly_when_read_as_fp32(env):
     """ops._require_written: a gradient that exists only as its 16-bit image must never be read as fp32 by a consumer that missed
     the hand-off"""
