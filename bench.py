@@ -481,7 +481,7 @@ def trainpy_step_block(model, criterion, optimizer, batch_cpu, steps, warmup, us
     loader = torch.utils.data.DataLoader(ds, num_workers=1, shuffle=False, sampler=None, batch_size=B, pin_memory=False, drop_last=True,
                                          collate_fn=DataCollate(1, use_prior))
     ctc_w = criterion.ctc_loss_weight
-    t_data, t_step, frames = [], [], 0
+    t_data, t_step, frames, host = [], [], 0, {}
     it = iter(loader)
     model.train()
     for i in range(steps + warmup):
@@ -501,15 +501,23 @@ def trainpy_step_block(model, criterion, optimizer, batch_cpu, steps, warmup, us
             loss_nll, loss_gate, loss_ctc = criterion(out, gate_target, in_lens, out_lens, is_validation=False)
             loss = loss_nll + loss_gate
             loss += loss_ctc * ctc_w
+        ta = time.perf_counter()                          # forward + loss enqueued (host time only)
         reduced = (loss.item(), loss_gate.item(), loss_nll.item(), loss_ctc.item())
+        tb = time.perf_counter()                          # ... and executed: the four host reads of train.py:307-321
         loss.backward()
+        tc = time.perf_counter()                          # backward enqueued
         torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        td = time.perf_counter()
         optimizer.step()
+        te = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         if i >= warmup:
             t_data.append(t1 - t0)
             t_step.append(t2 - t1)
+            for key, val in (("fwd_enqueue", ta - t1), ("items_wait", tb - ta), ("bwd_enqueue", tc - tb), ("torch_clip_enqueue", td - tc),
+                             ("optimizer_step_enqueue", te - td), ("final_sync", t2 - te)):
+                host[key] = host.get(key, 0.0) + val
             frames += int(out_lens.sum().item())
     del it
     ms = sum(t_step) / len(t_step) * 1e3
@@ -519,6 +527,7 @@ def trainpy_step_block(model, criterion, optimizer, batch_cpu, steps, warmup, us
                     "4x .item() -> backward -> torch.nn.utils.clip_grad_norm_ -> optimizer.step()",
             "steps": len(t_step), "ms_per_step": round(ms, 2), "data_ms_per_batch": round(dms, 2),
             "ms_per_step_incl_data": round(ms + dms, 2), "mel_frames_per_s_incl_data": round(frames / (sum(t_step) + sum(t_data)), 1),
+            "host_ms": {k: round(v / len(t_step) * 1e3, 2) for k, v in host.items()},
             "final_loss": round(reduced[0], 5), "T_max": int(mel.shape[2]), "L_max": int(txt.shape[1])}
 
 

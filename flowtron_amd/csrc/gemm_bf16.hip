@@ -48,7 +48,7 @@ __device__ __forceinline__ int mapped_rows(const int* rdev, int Rp, int& Rz) {
 // src(r,c) = src[r*sr + c*sc]; vec: sc == 1, 16-byte aligned rows
 __global__ __launch_bounds__(256) void img_rows_k(const float* __restrict__ src, long sr, long sc, int R, int Cc,
                                                   unsigned short* __restrict__ dst, int Rp, int Cp, int vec,
-                                                  const int* __restrict__ rowmap, const int* __restrict__ rdev) {
+                                                  const int* __restrict__ rowmap, const int* __restrict__ rdev, long dld) {
     const int cq = Cp >> 3;
     int Rz = Rp;
     if (rdev) R = mapped_rows(rdev, Rp, Rz);
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void img_rows_k(const float* __restrict__ src,
                 for (int e = 0; e < 8; ++e) if (c + e < Cc) v[e] = p[(size_t)e * sc];
             }
         }
-        *reinterpret_cast<uint4*>(dst + (size_t)ri * Cp + c) = pack8(v);
+        *reinterpret_cast<uint4*>(dst + (size_t)ri * dld + c) = pack8(v);
     }
 }
 
@@ -121,12 +121,14 @@ __global__ __launch_bounds__(256) void img_rows_sum_k(const float* __restrict__ 
     if (col < Cc) atomicAdd(colsum + col, s8);
 }
 
+// dld: row stride of the destination (default Cp); a piece of a wider image = dst pointing at its first column, dld the image's stride
 void make_image(const float* src, long sr, long sc, int R, int Cc, unsigned short* dst, int Rp, int Cp, hipStream_t st,
-                const int* rowmap = nullptr, const int* rdev = nullptr) {
+                const int* rowmap = nullptr, const int* rdev = nullptr, long dld = 0) {
     const bool vec = sc == 1 && reinterpret_cast<uintptr_t>(src) % 16 == 0 && sr % 4 == 0;
     const size_t chunks = (size_t)Rp * (Cp >> 3);
     const int blocks = (int)((chunks + 255) / 256 < 16384 ? (chunks + 255) / 256 : 16384);
-    hipLaunchKernelGGL(img_rows_k, dim3(blocks), dim3(256), 0, st, src, sr, sc, R, Cc, dst, Rp, Cp, vec ? 1 : 0, rowmap, rdev);
+    hipLaunchKernelGGL(img_rows_k, dim3(blocks), dim3(256), 0, st, src, sr, sc, R, Cc, dst, Rp, Cp, vec ? 1 : 0, rowmap, rdev,
+                       dld ? dld : (long)Cp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -803,6 +805,23 @@ extern "C" int FT_OPNAME(ft_gemm_img)(const ft_gemm_img_args* a, void* stream) {
 }
 
 // compact image: image row i = source row rowmap[i] (i < *rows_dev; -1 = zero row); buffer sized for cap_rows
+// One COLUMN BLOCK of a compact image (LinearFn over two inputs: [h_att ; ctx] -> one image, one K loop): the piece src [*, cols]
+// goes to columns [col_off, col_off + cols) of the image dst (row stride dst_ld elements, sized by ft_bf16_image_bytes for the
+// TOTAL width); columns up to col_off + fill_cols (>= cols, multiple of 8: pass the image's remaining width for the last piece)
+// are zeroed.  Rows as ft_bf16_image_rows.
+extern "C" int FT_OPNAME(ft_bf16_image_rows_into)(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, int64_t dst_ld,
+                                                  int64_t col_off, int64_t fill_cols, const int32_t* rowmap, const int32_t* rows_dev,
+                                                  void* stream) {
+    FT_CHECK_ARG(src && dst && rowmap && rows_dev && cap_rows >= 1 && cols >= 1 && ld >= cols && cap_rows < (1ll << 31) - 512);
+    FT_CHECK_ARG(col_off >= 0 && col_off % 8 == 0 && fill_cols >= cols && fill_cols % 8 == 0 && col_off + fill_cols <= dst_ld && dst_ld % 8 == 0);
+    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);
+    const int Rp = (int)up((size_t)cap_rows + 32, 256);
+    make_image(src, ld, 1, (int)cap_rows, (int)cols, reinterpret_cast<unsigned short*>(dst) + col_off, Rp, (int)fill_cols,
+               reinterpret_cast<hipStream_t>(stream), rowmap, rows_dev, (long)dst_ld);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+
 extern "C" int FT_OPNAME(ft_bf16_image_rows)(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, float* colsum,
                                              const int32_t* rowmap, const int32_t* rows_dev, void* stream) {
     FT_CHECK_ARG(src && dst && rowmap && rows_dev && cap_rows >= 1 && cols >= 1 && ld >= cols && cap_rows < (1ll << 31) - 512 && cols < (1ll << 31) - 256);

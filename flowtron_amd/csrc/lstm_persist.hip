@@ -182,6 +182,36 @@ __device__ __forceinline__ bool join_group_local(unsigned* census, int* status, 
     return true;
 }
 
+// 16x16x32 MFMA with the B operand in ACCUMULATION registers and the accumulator in architectural ones (inline asm: the builtin
+// only takes B from VGPRs, so fragments parked in AGPRs cost four v_accvgpr_read each per use).  lstm_persist_bwd_rs_k keeps all 64
+// weight fragments of a wave (256 registers) in AGPRs for the whole launch and everything else in VGPRs: no register-file moves in
+// the step.  The compiler does not see an MFMA here: the CALLER keeps dependent uses of `acc` far enough apart (>= 3 other MFMAs
+// between two accumulations into the same registers, >= 18 wait states before a VALU read; CDNA3 ISA 4.5 / 7.x hazard tables).
+__device__ __forceinline__ void mfma16_bagpr_first(f32x4& acc, const u32x4& a, const u32x4& b) {      // acc = a x b (C = 0)
+#if FT_OPFMT == 1
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+#else
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+#endif
+}
+__device__ __forceinline__ void mfma16_bagpr(f32x4& acc, const u32x4& a, const u32x4& b) {
+#if FT_OPFMT == 1
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+#else
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+#endif
+}
+
+// ... the same behind two wait states: for an A operand that VALU instructions (the DPP row shifts of member<>) have just written -- the
+// compiler pads a builtin MFMA itself (s_nop 0 / 1 in its output), an asm statement gets no such care
+__device__ __forceinline__ void mfma16_bagpr_nop(f32x4& acc, const u32x4& a, const u32x4& b) {
+#if FT_OPFMT == 1
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+#else
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+#endif
+}
+
 template <int NG, bool LOCAL, int LAUX, bool BARE>
 __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
     static_assert(!LOCAL || NG == 8, "the L2-local transport needs group == XCD");
@@ -210,7 +240,11 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
     const int B = p.B, T = p.T;
     const int b0 = grp * RPGP;
 
-    // ---- resident weights: tile j, k-chunk (wave + 4 i)
+    // ---- resident weights: tile j, k-chunk (wave + 4 i).  NG == 8 (64 fragments = 256 registers per lane): parked in ACCUMULATION
+    // registers for the whole launch and fed to the MFMAs from there (mfma16_bagpr: round 4 -- the builtin takes B from VGPRs only, so
+    // the ~17 fragments the allocator had to keep in AGPRs cost four v_accvgpr_read each on every use, issue slots the step's MFMA
+    // block does not hide); accumulators in VGPRs.  Same MFMA order per accumulator: bit-identical to the launch-per-step kernel.
+    constexpr bool WAGPR = NG == 8;
     bf16x8 w[TPC][8];
     {
         const bf16x8* wf = reinterpret_cast<const bf16x8*>(p.wfrag);
@@ -218,6 +252,12 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
         for (int j = 0; j < TPC; ++j)
 #pragma unroll
             for (int i = 0; i < 8; ++i) w[j][i] = wf[((size_t)(q * TPC + j) * NCHUNK + (wave + 4 * i)) * 64 + lane];
+        if constexpr (WAGPR) {
+#pragma unroll
+            for (int j = 0; j < TPC; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("" : "+a"(w[j][i]));
+        }
     }
 
     // ---- epilogue role: thread e < 128 owns (batch row eb, unit eu) of this CU for the whole sequence
@@ -348,10 +388,20 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
             if (dead) break;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {          // chunk i of this wave = load group i / CPL, member i % CPL
-                const bf16x8 a = __builtin_bit_cast(bf16x8, member<RPGP>(payload<BARE>(ld[i / CPL]), i % CPL));
+                const u32x4 au = member<RPGP>(payload<BARE>(ld[i / CPL]), i % CPL);
+                if constexpr (WAGPR) {
+                    const u32x4 bu0 = __builtin_bit_cast(u32x4, w[0][i]);
+                    mfma16_bagpr_nop(acc[0], au, bu0);                             // (two wait states behind the DPP shifts that wrote `au`)
 #pragma unroll
-                for (int j = 0; j < TPC; ++j) acc[j] = mfma16(a, w[j][i], acc[j]);
+                    for (int j = 1; j < TPC; ++j) mfma16_bagpr(acc[j], au, __builtin_bit_cast(u32x4, w[j][i]));
+                } else {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, au);
+#pragma unroll
+                    for (int j = 0; j < TPC; ++j) acc[j] = mfma16(a, w[j][i], acc[j]);
+                }
             }
+            // (asm MFMAs: the compiler does not know their result latency -- 12 wait states before anything reads the last one's)
+            if constexpr (WAGPR) asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
         }
         // D[m = batch row (lane>>4)*4 + r][n = li]: rows >= RPGP are padding
         const int rb = t & 1;
@@ -773,26 +823,6 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
 // The sum over the 32 partials is NOT the launch-per-step kernel's summation order: results agree with lstm_bwd_step_bf16 to fp32
 // rounding (tests: tolerance, not bit-identity).  Roles: all four waves poll, multiply and publish; between the two barriers of
 // a step waves 0-1 run the cell backward while waves 2-3 store the previous step's dgates rows / image and issue the ring DMAs.
-// 16x16x32 MFMA with the B operand in ACCUMULATION registers and the accumulator in architectural ones (inline asm: the builtin
-// only takes B from VGPRs, so fragments parked in AGPRs cost four v_accvgpr_read each per use).  lstm_persist_bwd_rs_k keeps all 64
-// weight fragments of a wave (256 registers) in AGPRs for the whole launch and everything else in VGPRs: no register-file moves in
-// the step.  The compiler does not see an MFMA here: the CALLER keeps dependent uses of `acc` far enough apart (>= 3 other MFMAs
-// between two accumulations into the same registers, >= 18 wait states before a VALU read; CDNA3 ISA 4.5 / 7.x hazard tables).
-__device__ __forceinline__ void mfma16_bagpr_first(f32x4& acc, const u32x4& a, const u32x4& b) {      // acc = a x b (C = 0)
-#if FT_OPFMT == 1
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
-#else
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
-#endif
-}
-__device__ __forceinline__ void mfma16_bagpr(f32x4& acc, const u32x4& a, const u32x4& b) {
-#if FT_OPFMT == 1
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
-#else
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
-#endif
-}
-
 template <int OUT, bool PROF = false>
 __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
     constexpr bool WF32 = OUT != 2, WIMG = OUT != 0;

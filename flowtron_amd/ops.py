@@ -74,6 +74,7 @@ class RowMap:
 
 
 _COMPACT = _os.environ.get("FLOWTRON_GEMM_COMPACT", "1") != "0"
+_CAT_IMAGES = _os.environ.get("FLOWTRON_GEMM_CAT", "1") != "0"      # a Linear over two inputs as ONE GEMM over a concatenated image
 _PERSIST_IMG = _os.environ.get("FLOWTRON_LSTM_PERSIST_IMG", "1")      # 1: the persistent backward emits the dgates image INSTEAD of fp32 dgx where its only consumer is the projection's backward; both; 0
 
 
@@ -114,6 +115,27 @@ class Bf16Image:
     def ptr(self, row_off=0, col_off=0):
         assert col_off % 8 == 0
         return self.buf.data_ptr() + 2 * (row_off * self.ld + col_off)
+
+    @classmethod
+    def cat_rows(cls, xs2d, mode, rowmap):
+        """ONE compact image of the column-wise concatenation [x_0 | x_1 | ..] of time-major activations (each [T*B, K_i] fp32,
+        K_i % 8 == 0 except the last): a Linear over several inputs then runs as one GEMM with one K loop (flowtron.py:758-765
+        concatenates [h_att ; ctx] before the decoder LSTM), and its weight gradient as one split-K GEMM."""
+        self = cls.__new__(cls)
+        self.rows, self.cols, self.fmt, self.rowmap, self.colsum = rowmap.cap, int(sum(x.shape[1] for x in xs2d)), mode, rowmap, None
+        self.ld = (self.cols + 255) // 256 * 256
+        self.buf = torch.empty(L.lib().ft_bf16_image_bytes(self.rows, self.cols), device=xs2d[0].device, dtype=torch.uint8)
+        off = 0
+        for i, x in enumerate(xs2d):
+            assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and x.shape[0] == rowmap.T * rowmap.B
+            K = int(x.shape[1])
+            last = i == len(xs2d) - 1
+            assert last or K % 8 == 0
+            L.check(L.op16("ft_bf16_image_rows_into", mode)(L.ptr(x), int(x.stride(0)), self.rows, K, L.ptr(self.buf), self.ld, off,
+                                                            (self.ld - off) if last else K, L.ptr(rowmap.map), L.ptr(rowmap.rows), L.stream()),
+                    "ft_bf16_image_rows_into")
+            off += K
+        return self
 
     @classmethod
     def empty_rows(cls, cols, rowmap, mode, device):
@@ -271,12 +293,24 @@ class LinearFn(torch.autograd.Function):
         if rowmap is not None and (not use_img or rows != rowmap.T * rowmap.B):
             rowmap = None
         ctx.imgs = None
+        ctx.cat = False
         if use_img:
             w_img = Bf16Image(W, mode=mode)
-            x_imgs = [shared_image(x, rows, x.shape[-1], mode, rowmap) for x in xs]
-            ctx.imgs = (w_img, x_imgs)          # reused by backward (dX reads W k-major, dW reads x k-major)
+            if len(xs) > 1 and rowmap is not None and _CAT_IMAGES:
+                # [x_0 | x_1] as ONE compact image: one K loop over K_0 + K_1 (the 256 x 256 x 64 kernel applies at K >= 1536), one
+                # weight-gradient GEMM -- instead of two K pieces accumulating through C (measured 259 + 316 us for the decoder
+                # LSTM's input projection against ~330 for the single loop)
+                x_cat = Bf16Image.cat_rows([x.reshape(rows, x.shape[-1]) for x in xs], mode, rowmap)
+                ctx.imgs, ctx.cat = (w_img, [x_cat]), True
+                gemm_img(x_cat, 0, x_cat.ptr(), w_img, 0, w_img.ptr(), y, rowmap.cap, N, Ktot, N, bias=bias, act=act, rowmap=rowmap, compact=1)
+            else:
+                x_imgs = [shared_image(x, rows, x.shape[-1], mode, rowmap) for x in xs]
+                ctx.imgs = (w_img, x_imgs)          # reused by backward (dX reads W k-major, dW reads x k-major)
         off = 0
         for i, x in enumerate(xs):
+            if ctx.cat:
+                off = Ktot
+                break
             K = x.shape[-1]
             last = i == len(xs) - 1
             if use_img:
@@ -344,7 +378,10 @@ class LinearFn(torch.autograd.Function):
                 dxs.append(dx)
             else:
                 dxs.append(None)
-            if dW is not None:
+            if dW is not None and ctx.cat:
+                if i == 0:      # one split-K GEMM over the concatenated image: dW[n, :] = sum_r dpre[r,n] [x_0 | x_1][r, :]
+                    gemm_img(d_img, 1, d_img.ptr(), x_imgs[0], 1, x_imgs[0].ptr(), dW, N, Ktot, mrows, Ktot, splitk=True, rowmap=rowmap, compact=2)
+            elif dW is not None:
                 # dW[n, off+k] = sum_r dpre[r,n] x[r,k]
                 if imgs is not None:
                     gemm_img(d_img, 1, d_img.ptr(), x_imgs[i], 1, x_imgs[i].ptr(), dW[:, off:], N, K, mrows, Ktot, splitk=True,

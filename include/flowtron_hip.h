@@ -114,6 +114,13 @@ int ft_rowmap_build(const int32_t* lens, int32_t* rowmap, int32_t* rows_dev, int
  * ceil256(*rows_dev + 32); dst holds ft_bf16_image_bytes(cap_rows, cols).  colsum (optional) as ft_bf16_image_colsum. */
 int ft_bf16_image_rows(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, float* colsum,
                        const int32_t* rowmap, const int32_t* rows_dev, void* stream);
+/* One column block of a compact image: src [*, cols] -> columns [col_off, col_off + cols) of dst (row stride dst_ld elements; the
+ * image is sized by ft_bf16_image_bytes for its TOTAL width), columns up to col_off + fill_cols zeroed.  A Linear over two
+ * inputs ([h_att ; ctx] W^T, flowtron.py:758-765) then runs as ONE GEMM over one image instead of two K pieces. */
+int ft_bf16_image_rows_into(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, int64_t dst_ld, int64_t col_off,
+                            int64_t fill_cols, const int32_t* rowmap, const int32_t* rows_dev, void* stream);
+int ft_bf16_image_rows_into_f16(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, int64_t dst_ld, int64_t col_off,
+                                int64_t fill_cols, const int32_t* rowmap, const int32_t* rows_dev, void* stream);
 /* rows (t, b) with t > lens[b] of the time-major matrix y [T*B][cols] (row stride ld): mode 0 = zero them, 1 = copy row
  * (lens[b], b) into them (a compact GEMM wrote only valid rows and the separator; consumers that walk every frame need the rest) */
 int ft_pad_rows_fill(float* y, int64_t ld, int cols, const int32_t* lens, int T, int B, int mode, void* stream);
