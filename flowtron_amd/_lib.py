@@ -71,6 +71,7 @@ SIGNATURES = {
     "ft_rowmap_build": ([_p, _p, _p, _i, _i, _p], _i),
     "ft_bf16_image_rows": ([_p, _l, _l, _l, _p, _p, _p, _p, _p], _i),
     "ft_bf16_image_rows_into": ([_p, _l, _l, _l, _p, _l, _l, _l, _p, _p, _p], _i),
+    "ft_bf16_image_rows_act_bwd": ([_p, _l, _p, _l, _i, _l, _l, _p, _p, _p, _p, _p], _i),
     "ft_pad_rows_fill": ([_p, _l, _i, _p, _i, _i, _i, _p], _i),
     "ft_embedding_fwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
     "ft_embedding_bwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
@@ -132,7 +133,7 @@ SIGNATURES = {
 }
 
 # fp16-operand twins (include/flowtron_hip.h, end): same signatures, suffix _f16
-OP16_TWINS = ("ft_gemm", "ft_bf16_image", "ft_bf16_image_colsum", "ft_gemm_img", "ft_bf16_image_rows", "ft_bf16_image_rows_into", "ft_lstm_seq_fwd", "ft_lstm_seq_bwd",
+OP16_TWINS = ("ft_gemm", "ft_bf16_image", "ft_bf16_image_colsum", "ft_gemm_img", "ft_bf16_image_rows", "ft_bf16_image_rows_into", "ft_bf16_image_rows_act_bwd", "ft_lstm_seq_fwd", "ft_lstm_seq_bwd",
               "ft_lstm_persist_fwd", "ft_lstm_persist_bwd", "ft_lstm_persist_bwd_img", "ft_lstm2_seq_fwd", "ft_lstm2_seq_bwd",
               "ft_lstm_bidir_seq_fwd", "ft_lstm_bidir_seq_bwd", "ft_bilstm_persist_fwd", "ft_bilstm_persist_bwd")
 for _n in OP16_TWINS:

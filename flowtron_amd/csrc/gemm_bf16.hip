@@ -75,10 +75,14 @@ __global__ __launch_bounds__(256) void img_rows_k(const float* __restrict__ src,
 // same image, plus the fp32 column sums of the SOURCE (bias gradients: the conversion pass reads the output gradient
 // anyway, so ft_colsum's second sweep over it disappears).  Block = 32 column groups x 8 row lanes over a 256-row slab;
 // grid (Cp/256, Rp/256); colsum [Cc] must be zero on entry, slabs combine with fp32 atomics (as ft_colsum does).
+// ysrc != nullptr: src is an OUTPUT GRADIENT dy and ysrc the saved output y = act(pre) of the same rows: the pass images (and sums)
+// dpre = dy act'(pre) (ft_act_bwd's formulas) -- the activation backward of a dense layer rides on the conversion pass, no fp32
+// dpre tensor is written or read back.
 __global__ __launch_bounds__(256) void img_rows_sum_k(const float* __restrict__ src, long sr, int R, int Cc,
                                                       unsigned short* __restrict__ dst, int Rp, int Cp, int vec,
                                                       float* __restrict__ colsum, const int* __restrict__ rowmap,
-                                                      const int* __restrict__ rdev) {
+                                                      const int* __restrict__ rdev, const float* __restrict__ ysrc = nullptr,
+                                                      long ysr = 0, int act = 0) {
     __shared__ float red[8][32][9];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = (blockIdx.x * 32 + tx) * 8;
@@ -103,6 +107,23 @@ __global__ __launch_bounds__(256) void img_rows_sum_k(const float* __restrict__ 
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) if (c + e < Cc) v[e] = p[e];
+                }
+                if (ysrc) {
+                    const float* py = ysrc + (size_t)r * ysr + c;
+                    float yv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (vec && c + 7 < Cc) {
+                        const float4 a = *reinterpret_cast<const float4*>(py), b = *reinterpret_cast<const float4*>(py + 4);
+                        yv[0] = a.x; yv[1] = a.y; yv[2] = a.z; yv[3] = a.w; yv[4] = b.x; yv[5] = b.y; yv[6] = b.z; yv[7] = b.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) if (c + e < Cc) yv[e] = py[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (act == FT_ACT_TANH) v[e] = v[e] * (1.f - yv[e] * yv[e]);
+                        else if (act == FT_ACT_RELU) v[e] = yv[e] > 0.f ? v[e] : 0.f;
+                        else if (act == FT_ACT_SIGMOID) v[e] = v[e] * yv[e] * (1.f - yv[e]);
+                    }
                 }
             }
 #pragma unroll
@@ -805,6 +826,25 @@ extern "C" int FT_OPNAME(ft_gemm_img)(const ft_gemm_img_args* a, void* stream) {
 }
 
 // compact image: image row i = source row rowmap[i] (i < *rows_dev; -1 = zero row); buffer sized for cap_rows
+// The output gradient of an ACTIVATED dense layer straight into its operand image: dst = image(dy * act'(pre)) over the compact
+// rows of `rowmap`, with act' expressed through the saved output y (ft_act_bwd's formulas), colsum [cols] = the bias gradient.
+// Replaces ft_act_bwd + ft_bf16_image_rows (one fp32 [rows, cols] tensor written and read back per dense layer).
+extern "C" int FT_OPNAME(ft_bf16_image_rows_act_bwd)(const float* dy, int64_t ld, const float* y, int64_t ldy, int act, int64_t cap_rows,
+                                                     int64_t cols, void* dst, float* colsum, const int32_t* rowmap,
+                                                     const int32_t* rows_dev, void* stream) {
+    FT_CHECK_ARG(dy && y && dst && colsum && rowmap && rows_dev && cap_rows >= 1 && cols >= 1 && ld >= cols && ldy >= cols);
+    FT_CHECK_ARG(act >= FT_ACT_NONE && act <= FT_ACT_SIGMOID && cap_rows < (1ll << 31) - 512 && cols < (1ll << 31) - 256);
+    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int Rp = (int)up((size_t)cap_rows + 32, 256), Cp = (int)up((size_t)cols, 256);
+    const int vec = (reinterpret_cast<uintptr_t>(dy) % 16 == 0 && ld % 4 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 && ldy % 4 == 0) ? 1 : 0;
+    FT_CHECK_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)cols, st));
+    hipLaunchKernelGGL(img_rows_sum_k, dim3(cdiv(Cp, 256), cdiv(Rp, 256)), dim3(256), 0, st, dy, (long)ld, (int)cap_rows, (int)cols,
+                       reinterpret_cast<unsigned short*>(dst), Rp, Cp, vec, colsum, rowmap, rows_dev, y, (long)ldy, act);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+
 // One COLUMN BLOCK of a compact image (LinearFn over two inputs: [h_att ; ctx] -> one image, one K loop): the piece src [*, cols]
 // goes to columns [col_off, col_off + cols) of the image dst (row stride dst_ld elements, sized by ft_bf16_image_bytes for the
 // TOTAL width); columns up to col_off + fill_cols (>= cols, multiple of 8: pass the image's remaining width for the last piece)

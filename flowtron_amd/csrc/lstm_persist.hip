@@ -823,8 +823,18 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
 // The sum over the 32 partials is NOT the launch-per-step kernel's summation order: results agree with lstm_bwd_step_bf16 to fp32
 // rounding (tests: tolerance, not bit-identity).  Roles: all four waves poll, multiply and publish; between the two barriers of
 // a step waves 0-1 run the cell backward while waves 2-3 store the previous step's dgates rows / image and issue the ring DMAs.
+#ifndef FT_RS_TAGS
+#define FT_RS_TAGS 2
+#endif
 template <int OUT, bool PROF = false>
 __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
+    // Tags per 16-byte slab piece (one lane's store = the four rows of one unit): 4 = every dword carries its own (nothing assumed about
+    // how a 16-byte store becomes visible), 2 = the FIRST and the LAST dword (default: a store observed torn at any single split
+    // point fails the check; measured 0.1 us per step cheaper than 4 -- a tag costs a VALU instruction per dword on the publish side,
+    // issue slots the MFMA block does not hide), 1 = the first dword only (relies on an aligned 16-byte store never being observed
+    // torn by an aligned 16-byte load: what cdna_hip_programming.md G16 reports for gfx950 without calling it a guarantee; 1.73 us).
+    constexpr int NTAG = FT_RS_TAGS;
+    auto tagged = [](int r) { return NTAG == 4 || r == 0 || (NTAG == 2 && r == 3); };
     constexpr bool WF32 = OUT != 2, WIMG = OUT != 0;
     constexpr int NG = 8, CPG = NCU / NG, UPC = PH / CPG, RPGP = 32 / NG, NE = RPGP * UPC;      // 32 CUs, 32 units, 4 rows, 128 elements
     constexpr int NT = PH / 16 / 4;                // column tiles per wave: 16
@@ -993,7 +1003,9 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     if (!((ready >> g) & 1u)) {
-                        const bool ok = (((ld[g][0] ^ tag) | (ld[g][1] ^ tag) | (ld[g][2] ^ tag) | (ld[g][3] ^ tag)) & 1u) == 0u;
+                        const bool ok = NTAG == 1 ? (((ld[g][0] ^ tag) & 1u) == 0u)
+                                        : NTAG == 2 ? ((((ld[g][0] ^ tag) | (ld[g][3] ^ tag)) & 1u) == 0u)
+                                                    : ((((ld[g][0] ^ tag) | (ld[g][1] ^ tag) | (ld[g][2] ^ tag) | (ld[g][3] ^ tag)) & 1u) == 0u);
                         if (__all(ok)) ready |= 1u << g;
                     }
                 }
@@ -1019,8 +1031,9 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
             f32x4 sacc;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                sacc[r] = ((__uint_as_float(ld[0][r] & ~1u) + __uint_as_float(ld[1][r] & ~1u)) + __uint_as_float(ld[2][r] & ~1u)) +
-                          __uint_as_float(ld[3][r] & ~1u);
+                sacc[r] = !tagged(r) ? ((__uint_as_float(ld[0][r]) + __uint_as_float(ld[1][r])) + __uint_as_float(ld[2][r])) + __uint_as_float(ld[3][r])
+                                     : ((__uint_as_float(ld[0][r] & ~1u) + __uint_as_float(ld[1][r] & ~1u)) + __uint_as_float(ld[2][r] & ~1u)) +
+                                           __uint_as_float(ld[3][r] & ~1u);
             *reinterpret_cast<f32x4*>(gsum + ((wave * 2 + (lane >> 5)) * UPC + (lane & 31)) * 4) = sacc;
         }
         if (n == 0) precompute();
@@ -1084,7 +1097,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
                     const int j = tq * 4 + jj;
                     u32x4 v;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (__float_as_uint(acc[jj][r]) & ~1u) | tagw;
+                    for (int r = 0; r < 4; ++r) v[r] = tagged(r) ? ((__float_as_uint(acc[jj][r]) & ~1u) | tagw) : __float_as_uint(acc[jj][r]);
                     __builtin_amdgcn_raw_buffer_store_b128(v, wr, wvoff, wsoff_w + (j >> 1) * (CPG * UPC * RPGP * 4) + (j & 1) * (16 * RPGP * 4), 0);
                 }
             };

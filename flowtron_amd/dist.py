@@ -130,31 +130,55 @@ class FlatArena:
             return a
         return cls(plist, flatten_params)
 
-    def zero_grad(self):
+    def zero_grad(self, lazy: bool = True):
+        """lazy (default, round 4): p.grad = None on every parameter -- what torch's own zero_grad(set_to_none=True) does (train.py:282
+        `model.zero_grad()`).  The next backward then HANDS its gradient tensors over (autograd steals them: no `grad += dW` kernel
+        per parameter, 68 of them per step, and no 244 MB memset), and whoever needs the flat arena next -- the optimizer, the
+        all-reduce -- pulls them in with ONE multi-tensor copy (adopt_stray_grads).  lazy=False: zero the arena and keep every
+        .grad a view into it (gradients accumulate in place; the round-1..3 behaviour)."""
+        if lazy:
+            for p in self.params:
+                p.grad = None
+            return
         self.flat_grad.zero_()
         self.adopt_stray_grads(copy=False)
 
+    def _views(self):
+        v = getattr(self, "_grad_views", None)
+        if v is None:
+            v = self._grad_views = [self.flat_grad[off:off + p.numel()].view_as(p.data) for p, off in zip(self.params, self.offsets)]
+        return v
+
     def adopt_stray_grads(self, copy=True, only=None):
-        """If something replaced p.grad (e.g. torch's default zero_grad(set_to_none=True) followed by backward), pull it
-        back into the arena so the single-collective path stays valid.  A parameter whose grad is None got NO gradient:
-        with copy=True its arena slice is zeroed (the slice still holds the previous iteration's values) and it is
-        reported back as (offset, numel) so that the optimizer can skip it like radam.py:57-58; its .grad stays None."""
-        skipped = []
-        items = zip(self.params, self.offsets) if only is None else ((self.params[i], self.offsets[i]) for i in only)
-        for p, off in items:
+        """If something replaced p.grad (zero_grad(set_to_none=True) followed by backward: the usual case since round 4), pull it
+        back into the arena so the single-collective / fused-optimizer path stays valid: one multi-tensor copy for all of them.
+        A parameter whose grad is None got NO gradient: with copy=True its arena slice is zeroed (the slice still holds the previous
+        iteration's values) and it is reported back as (offset, numel) so that the optimizer can skip it like radam.py:57-58; its
+        .grad stays None."""
+        skipped, dst, src = [], [], []
+        views = self._views()
+        idx = range(len(self.params)) if only is None else only
+        for i in idx:
+            p, off = self.params[i], self.offsets[i]
             k = p.numel()
             g = p.grad
             if g is None:
                 if copy:
-                    self.flat_grad[off:off + k].zero_()
+                    views[i].zero_()
                     skipped.append((off, k))
                 else:
-                    p.grad = self.flat_grad[off:off + k].view_as(p.data)
+                    p.grad = views[i]
             elif not (self._ptr_lo <= g.data_ptr() < self._ptr_hi):
-                view = self.flat_grad[off:off + k].view_as(p.data)
                 if copy:
-                    view.copy_(g)
-                p.grad = view
+                    if g.dtype == views[i].dtype and g.shape == views[i].shape:
+                        dst.append(views[i]); src.append(g)
+                    else:
+                        views[i].copy_(g)
+                p.grad = views[i]
+        if len(dst) == 1:
+            dst[0].copy_(src[0])
+        elif dst:
+            torch._foreach_copy_(dst, src)
         return skipped
 
 

@@ -74,6 +74,7 @@ class RowMap:
 
 
 _COMPACT = _os.environ.get("FLOWTRON_GEMM_COMPACT", "1") != "0"
+_FUSE_ACT_BWD = _os.environ.get("FLOWTRON_FUSE_ACT_BWD", "1") != "0"    # activation backward inside the gradient's image pass
 _CAT_IMAGES = _os.environ.get("FLOWTRON_GEMM_CAT", "1") != "0"      # a Linear over two inputs as ONE GEMM over a concatenated image
 _PERSIST_IMG = _os.environ.get("FLOWTRON_LSTM_PERSIST_IMG", "1")      # 1: the persistent backward emits the dgates image INSTEAD of fp32 dgx where its only consumer is the projection's backward; both; 0
 
@@ -344,7 +345,10 @@ class LinearFn(torch.autograd.Function):
         if d_img_in is None:
             _require_written(dy)
             dy = _c(dy)
-        if ctx.act != L.ACT_NONE:
+        # an activated layer over a row map on the image path: dpre = dy act'(pre) is formed INSIDE the conversion pass (image + bias
+        # column sums, ft_bf16_image_rows_act_bwd) -- no fp32 dpre tensor
+        fuse_act = ctx.act != L.ACT_NONE and ctx.imgs is not None and rowmap is not None and _FUSE_ACT_BWD
+        if ctx.act != L.ACT_NONE and not fuse_act:
             dpre = torch.empty_like(dy)
             L.check(L.lib().ft_act_bwd(L.ptr(y), L.ptr(dy), L.ptr(dpre), dy.numel(), ctx.act, L.stream()), "ft_act_bwd")
         else:
@@ -358,7 +362,12 @@ class LinearFn(torch.autograd.Function):
         if imgs is not None:
             w_img, x_imgs = imgs
             d_img = d_img_in                                                   # e.g. the LSTM backward already made it
-            if d_img is None:
+            if d_img is None and fuse_act:
+                d_img = Bf16Image.empty_rows(N, rowmap, w_img.fmt, dy.device)
+                L.check(L.op16("ft_bf16_image_rows_act_bwd", w_img.fmt)(L.ptr(dy), N, L.ptr(y), N, ctx.act, d_img.rows, N, L.ptr(d_img.buf),
+                                                                         L.ptr(d_img.colsum), L.ptr(rowmap.map), L.ptr(rowmap.rows), L.stream()),
+                        "ft_bf16_image_rows_act_bwd")
+            elif d_img is None:
                 d_img = Bf16Image(dpre.reshape(rows, N), colsum=want_db, mode=w_img.fmt, rowmap=rowmap)   # bias gradient rides on the conversion pass
             db = d_img.colsum if want_db else None
         if want_db and db is None:

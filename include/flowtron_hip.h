@@ -114,6 +114,13 @@ int ft_rowmap_build(const int32_t* lens, int32_t* rowmap, int32_t* rows_dev, int
  * ceil256(*rows_dev + 32); dst holds ft_bf16_image_bytes(cap_rows, cols).  colsum (optional) as ft_bf16_image_colsum. */
 int ft_bf16_image_rows(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, float* colsum,
                        const int32_t* rowmap, const int32_t* rows_dev, void* stream);
+/* The output gradient of an ACTIVATED dense layer (tanh / relu / sigmoid fused in ft_gemm_img's epilogue, flowtron.py:453-464)
+ * straight into its operand image: dst = image(dy * act'(pre)) over the compact rows of `rowmap`, act' through the saved output
+ * y = act(pre) like ft_act_bwd; colsum [cols] = the bias gradient.  Replaces ft_act_bwd + ft_bf16_image_rows. */
+int ft_bf16_image_rows_act_bwd(const float* dy, int64_t ld, const float* y, int64_t ldy, int act, int64_t cap_rows, int64_t cols,
+                               void* dst, float* colsum, const int32_t* rowmap, const int32_t* rows_dev, void* stream);
+int ft_bf16_image_rows_act_bwd_f16(const float* dy, int64_t ld, const float* y, int64_t ldy, int act, int64_t cap_rows, int64_t cols,
+                                   void* dst, float* colsum, const int32_t* rowmap, const int32_t* rows_dev, void* stream);
 /* One column block of a compact image: src [*, cols] -> columns [col_off, col_off + cols) of dst (row stride dst_ld elements; the
  * image is sized by ft_bf16_image_bytes for its TOTAL width), columns up to col_off + fill_cols zeroed.  A Linear over two
  * inputs ([h_att ; ctx] W^T, flowtron.py:758-765) then runs as ONE GEMM over one image instead of two K pieces. */

@@ -142,6 +142,40 @@ def test_linear_over_two_inputs_as_one_gemm_over_a_concatenated_image(env, monke
             assert torch.equal(ya[ln + 1:, bi], ya[ln:ln + 1, bi].expand(T - ln - 1, -1))
 
 
+@pytest.mark.parametrize("act_name", ["tanh", "relu", "sigmoid"])
+def test_activation_backward_inside_the_image_pass_is_bit_identical_to_the_two_pass_path(env, monkeypatch, act_name):
+    """ft_bf16_image_rows_act_bwd (dense layers of the decoder tail, flowtron.py:453-464): dpre = dy act'(pre) formed inside the
+    conversion pass (compact image + bias column sums) against ft_act_bwd followed by ft_bf16_image_rows -- the same fp32 products
+    rounded once, so the input / weight / bias gradients are bit-identical."""
+    L, ops = env
+    act = {"tanh": L.ACT_TANH, "relu": L.ACT_RELU, "sigmoid": L.ACT_SIGMOID}[act_name]
+    T, B, K, N = 29, 6, 256, 512
+    torch.manual_seed(3)
+    lens = torch.tensor([29, 29, 20, 11, 3, 1], dtype=torch.int32, device="cuda")
+    x, W, b = torch.randn(T, B, K, device="cuda"), torch.randn(N, K, device="cuda") * 0.05, torch.randn(N, device="cuda") * 0.1
+    valid = (torch.arange(T, device="cuda")[:, None] < lens[None, :])[..., None]
+    go = torch.randn(T, B, N, device="cuda") * valid
+    res = []
+    for fuse in (True, False):
+        monkeypatch.setattr(ops, "_FUSE_ACT_BWD", fuse)
+        d = [t.clone().requires_grad_(True) for t in (x, W, b)]
+        rm = ops.RowMap(lens, T, B)
+        y = ops.LinearFn.apply(d[1], d[2], act, L.FT_BF16, rm, "dx", d[0])
+        y.backward(go)
+        torch.cuda.synchronize()
+        res.append([t.grad.clone() for t in d])
+    for a_, b_, name in zip(res[0], res[1], "x W b".split()):
+        assert torch.isfinite(a_).all() and torch.equal(a_, b_), name
+    # and against fp64 on the valid rows
+    xr, Wr = x.to(torch.bfloat16).double(), W.to(torch.bfloat16).double()
+    pre = xr @ Wr.t() + b.double()
+    yv = {"tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid}[act_name](pre)
+    dact = {"tanh": 1 - yv * yv, "relu": (yv > 0).double(), "sigmoid": yv * (1 - yv)}[act_name]
+    dpre = (go.double() * dact * valid).to(torch.bfloat16).double()
+    dWr = torch.einsum("tbn,tbk->nk", dpre, xr)
+    assert float((res[0][1].double() - dWr).norm()) <= 3e-3 * float(dWr.norm())
+
+
 # ---------------------------------------------------------------- elementwise family
 def test_embedding(env):
     L, ops = env
