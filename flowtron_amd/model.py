@@ -180,9 +180,10 @@ class AR_Step(nn.Module):
     def __init__(self, n_mel_channels, n_speaker_dim, n_text_channels, n_in_channels, n_hidden, n_attn_channels,
                  n_lstm_layers, add_gate, use_cumm_attention):
         super().__init__()
-        if n_lstm_layers != 2:
-            raise NotImplementedError("the HIP decoder path is built for n_lstm_layers == 2 (config.json:58)")
-        self.use_cumm_attention = use_cumm_attention
+        if n_lstm_layers < 1:
+            raise ValueError("n_lstm_layers must be >= 1")
+        self.n_lstm_layers = int(n_lstm_layers)       # training: any depth (one recurrence + one batched projection per layer);
+        self.use_cumm_attention = use_cumm_attention  # the decode kernels (infer) are built for the config.json depth of 2
         self.conv = nn.Conv1d(n_hidden, 2 * n_mel_channels, 1)
         self.conv.weight.data = 0.0 * self.conv.weight.data
         self.conv.bias.data = 0.0 * self.conv.bias.data
@@ -230,7 +231,15 @@ class AR_Step(nn.Module):
             g = self.gate_layer.linear_layer
             gates = ops.linear([h_att, ctx], g.weight, g.bias, mode=mode)     # Linear over [h_att ; ctx], no concat
         p = self.lstm
-        if ops.lstm_persist_groups(B, p.weight_hh_l0.shape[1], False, mode, mel.device):
+        if self.n_lstm_layers != 2:
+            # any other depth (the config schema splats n_lstm_layers into nn.LSTM, flowtron.py:655): the same per-layer pair --
+            # batched input projection + one recurrence (persistent where its geometry applies) -- layer after layer
+            h = ops.lstm_layer(h_att, out_lens32, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, mode=mode,
+                               xs_extra=[ctx], rowmap=rm, fill="dx")
+            for l in range(1, self.n_lstm_layers):
+                h = ops.lstm_layer(h, out_lens32, getattr(p, "weight_ih_l%d" % l), getattr(p, "weight_hh_l%d" % l),
+                                   getattr(p, "bias_ih_l%d" % l), getattr(p, "bias_hh_l%d" % l), mode=mode, rowmap=rm)
+        elif ops.lstm_persist_groups(B, p.weight_hh_l0.shape[1], False, mode, mel.device):
             # two persistent single-layer recurrences (csrc/lstm_persist.hip, ~2 us per step each) with layer 1's input
             # projection as one batched GEMM between them: faster than the two-layer wavefront launch chain (~8 us per step)
             # (the context gradient feeds the attention backward, which reduces over ALL frames: zero its padded rows)
@@ -291,6 +300,9 @@ class AR_Step(nn.Module):
         N, B, M = residual.shape
         if B != 1:
             raise ValueError("Flowtron.infer is batch-1 (flowtron.py:901-930)")
+        if self.n_lstm_layers != 2:
+            raise NotImplementedError("the decode kernels (csrc/decode.hip) are built for n_lstm_layers == 2 (config.json:58); "
+                                      "training supports any depth")
         L.require_cuda(residual, text)
         Lk = text.shape[0]
         att = self.attention_layer

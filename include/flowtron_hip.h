@@ -26,6 +26,35 @@
  *     a twin of identical signature and the suffix _f16 (end of this header).
  *   - time-major activations: [T,B,C] row-major, like the reference's
  *     internal layout after flowtron.py:884.
+ *
+ * Where this header departs from the conventions SURVEY.md 8(b) sketched (the
+ * reference itself has no FFI to be compatible with; these are choices):
+ *   - no `ft_ctx` handle with create / destroy entry points: the library keeps NO
+ *     per-device state.  Every entry point works on the device of the stream it
+ *     is handed (the caller -- torch -- has made it current); scratch, status
+ *     words and weight images are caller-owned buffers passed per call, so the
+ *     library is re-entrant across devices and processes by construction.
+ *   - positional arguments instead of one args struct per op, except where an op
+ *     has more than ~12 operands (ft_gemm, ft_gemm_img, ft_decode_flow,
+ *     ft_cumm_attn_*: structs).
+ *   - no `ft_allreduce_flat`: the gradient exchange is torch.distributed's RCCL
+ *     all-reduce of the flat arena (north_star: "a single RCCL all-reduce over
+ *     xGMI per step"; flowtron_amd/dist.py); the library only supplies the
+ *     device-side poison / non-finite-norm guard around it.
+ *   - `ft_dense_conv_affine` (dense -> dense -> 1x1 conv -> coupling as ONE
+ *     kernel) is not built: a 1024-wide layer pair per row tile needs both weight
+ *     matrices (4 MB of 16-bit operands) per tile from the L2 -- 2.6 GB per
+ *     call at 32-row tiles, the largest that keep two activation tiles in LDS --
+ *     which is slower than the three image GEMMs it would replace.  What IS fused:
+ *     bias + tanh in the GEMM epilogue, the activation backward + bias gradient
+ *     in the gradient's image pass (ft_bf16_image_rows_act_bwd), the coupling
+ *     with its own backward (ft_affine_*), the masked NLL sums (ft_masked_sum).
+ *   - `ft_decode_init` / `ft_decode_steps` became ft_decode_flow (one call per
+ *     flow: a persistent launch, or a hipGraph of staged frames).
+ *   - `ft_lstm_seq` "multi-layer": one call per layer (ft_lstm_persist_* /
+ *     ft_lstm_seq_*), with the inter-layer projection as a batched GEMM between
+ *     them (faster than the fused two-layer wavefront, which is kept as
+ *     ft_lstm2_seq_* for shapes the persistent kernels do not take).
  */
 #ifndef FLOWTRON_HIP_H
 #define FLOWTRON_HIP_H
@@ -37,7 +66,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 8
+#define FT_ABI_VERSION 9
 
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1, FT_F16 = 2 };

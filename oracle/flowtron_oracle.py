@@ -273,8 +273,11 @@ def ar_step_forward(sd: SD, pfx: str, mel, enc, pad_mask, out_lens, attn_prior, 
     gate = None
     if has_gate:
         gate = dec_in @ sd[pfx + "gate_layer.linear_layer.weight"].t() + sd[pfx + "gate_layer.linear_layer.bias"]
-    h = _lstm(dec_in, out_lens, sd, pfx + "lstm.", 0)
-    h = _lstm(h, out_lens, sd, pfx + "lstm.", 1)
+    h = dec_in                                           # nn.LSTM(n_hidden + n_attn, n_hidden, n_lstm_layers), flowtron.py:655, :760-765
+    layer = 0
+    while (pfx + "lstm.weight_ih_l%d" % layer) in sd:
+        h = _lstm(h, out_lens, sd, pfx + "lstm.", layer)
+        layer += 1
     for i in range(2):
         h = torch.tanh(h @ sd[pfx + "dense_layer.layers.%d.linear_layer.weight" % i].t()
                        + sd[pfx + "dense_layer.layers.%d.linear_layer.bias" % i])

@@ -32,7 +32,7 @@ def state_dict_spec(cfg: dict):
     for i in range(cfg["n_flows"]):
         p = "flows.%d." % i if i % 2 == 0 else "flows.%d.ar_step." % i
         spec += [(p + "conv.weight", (2 * M, H, 1)), (p + "conv.bias", (2 * M,))]
-        for l, inp in ((0, H + A), (1, H)):
+        for l, inp in [(0, H + A)] + [(l_, H) for l_ in range(1, int(cfg.get("n_lstm_layers", 2)))]:
             spec += [(p + "lstm.weight_ih_l%d" % l, (4 * H, inp)), (p + "lstm.weight_hh_l%d" % l, (4 * H, H)),
                      (p + "lstm.bias_ih_l%d" % l, (4 * H,)), (p + "lstm.bias_hh_l%d" % l, (4 * H,))]
         spec += [(p + "attention_lstm.weight_ih_l0", (4 * H, M)), (p + "attention_lstm.weight_hh_l0", (4 * H, H)),

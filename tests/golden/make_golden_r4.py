@@ -10,6 +10,8 @@ train_traj.pt   the REAL /root/reference modules (flowtron.Flowtron, flowtron.Fl
                 (F.dropout -> identity, as in make_golden.py: the only stochastic op of the path).
                 Stored: the four losses and the pre-clip gradient norm of every iteration, every parameter after the last
                 iteration, and the optimizer's step count.  Inputs and initial weights are rebuilt from seeds by oracle/synth.py.
+lstm_depth.pt   the decoder LSTM at the depths the config schema allows besides config.json's 2 (flowtron.py:655 passes n_lstm_layers to
+                nn.LSTM): the real reference at n_lstm_layers = 1 and 3 (small model, ragged batch): z, the three losses, every gradient.
 """
 import importlib.util
 import os
@@ -71,9 +73,36 @@ def run_reference_loop(Flowtron, FlowtronLoss, RAdam, device="cpu", neutralise_d
                 params={k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}, model=model, optimizer=optimizer)
 
 
+DEPTH_CASES = [dict(n_lstm_layers=1, seed=31, out_lens=[19, 14, 19], in_lens=[8, 6, 5]),
+               dict(n_lstm_layers=3, seed=33, out_lens=[21, 9, 16, 21], in_lens=[9, 7, 7, 3])]
+
+
+def run_depth_case(R, case):
+    cfg = dict(synth.SMALL_MODEL_CONFIG, n_lstm_layers=case["n_lstm_layers"])
+    sd = synth.make_state_dict(cfg, seed=case["seed"])
+    b = synth.make_batch(cfg, case["out_lens"], case["in_lens"], seed=case["seed"], with_prior=True)
+    m = R.Flowtron(**cfg)
+    m.load_state_dict(sd)                              # strict: the spec of oracle/synth.py matches the reference's registration
+    crit = R.FlowtronLoss(1.0, False, True, True, 0.01, -8)
+    real_dropout = F.dropout
+    F.dropout = lambda x, p=0.5, training=True, inplace=False: x.clone()
+    try:
+        m.train()
+        out = m(b["mel"].clone(), b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"].clone())
+        z = out[0].detach().clone()
+        nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+        (nll + gl + 0.01 * ctc).backward()
+    finally:
+        F.dropout = real_dropout
+    return dict(case=case, cfg=cfg, z=z, nll=nll.detach(), gate_loss=gl.detach(), ctc=ctc.detach(),
+                grads={k: p.grad.detach().clone() for k, p in m.named_parameters()})
+
+
 def main():
     assert refshim.available(), "needs /root/reference"
     R = refshim.load()
+    torch.save({"cases": [run_depth_case(R, c) for c in DEPTH_CASES]}, os.path.join(HERE, "lstm_depth.pt"))
+    print("wrote lstm_depth.pt")
     spec = importlib.util.spec_from_file_location("_ref_radam", os.path.join(refshim.REF_DIR, "radam.py"))
     radam = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(radam)

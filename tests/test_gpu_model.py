@@ -65,7 +65,7 @@ def test_forward_loss_grads_vs_reference_golden(name):
         r = (p.grad.cpu() - ref).norm().item() / denom
         if r > worst[1]:
             worst = (k, r)
-    assert worst[1] < 1e-3, worst
+    assert worst[1] < 1e-4, worst          # SURVEY 8c's fp32 gradient tolerance (observed ~2e-5)
 
 
 @pytest.mark.parametrize("name", ["small_f2.pt", "small_f3.pt", "small_cumm.pt"])
@@ -488,7 +488,7 @@ def test_batch_of_one_training_matches_oracle():
     assert abs(ctc.item() - rc.item()) < 1e-4 * max(1.0, abs(rc.item()))
     for k, p in m.named_parameters():
         r = sdg[k].grad
-        assert (p.grad.cpu() - r).norm().item() / max(r.norm().item(), 1e-5 * r.numel() ** 0.5) < 1e-3, k
+        assert (p.grad.cpu() - r).norm().item() / max(r.norm().item(), 1e-5 * r.numel() ** 0.5) < 1e-4, k
 
 
 def test_long_text_many_speakers_ragged_matches_oracle():
@@ -739,3 +739,41 @@ def test_ragged_batch_mel_equals_per_utterance_mel_and_zero_padding():
     # the loader's deferred slot goes through it
     d = DeferredMel(audio, torch.tensor(ns), stft_args, max_t=T_out).cuda()
     assert torch.equal(d, mel)
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-4), ("bf16", 6e-2)])
+def test_decoder_lstm_depths_one_and_three_vs_real_reference_golden(mode, tol):
+    """VERDICT r3 missing #6: `n_lstm_layers` other than config.json's 2 (flowtron.py:655 passes it to nn.LSTM) -- training runs layer
+    after layer through the same projection + recurrence pair; against the REAL reference's z, losses and gradients at depth 1 and 3
+    (tests/golden/lstm_depth.pt).  The decode kernels stay built for depth 2: infer raises NotImplementedError."""
+    import flowtron
+    from oracle import synth
+    g = _load("lstm_depth.pt")
+    try:
+        for c in g["cases"]:
+            case, cfg = c["case"], c["cfg"]
+            m, _ = build(cfg, case["seed"], mode)
+            assert len([k for k in m.state_dict() if k.startswith("flows.0.lstm.weight_ih_l")]) == case["n_lstm_layers"]
+            b = cuda_batch(synth.make_batch(cfg, case["out_lens"], case["in_lens"], seed=case["seed"], with_prior=True))
+            out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+            nll, gl, ctc = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)(out, b["gate_target"], b["in_lens"], b["out_lens"])
+            (nll + gl + 0.01 * ctc).backward()
+            torch.cuda.synchronize()
+            if mode == "f32":
+                assert mad(out[0], c["z"]) < 1e-4
+                assert abs(nll.item() - c["nll"].item()) < 1e-5 * abs(c["nll"].item())
+            else:
+                assert abs(nll.item() - c["nll"].item()) < 2e-3 * abs(c["nll"].item())
+            worst = ("", 0.0)
+            for k, p in m.named_parameters():
+                ref = c["grads"][k]
+                if mode != "f32" and (k.startswith("encoder.convolutions") or k.startswith("embedding.") or "query" in k):
+                    continue                   # ill-conditioned under 16-bit operands for the real reference too (cfg2_bf16.pt)
+                r = (p.grad.cpu() - ref).norm().item() / max(ref.norm().item(), 1e-5 * ref.numel() ** 0.5)
+                if r > worst[1]:
+                    worst = (k, r)
+            assert worst[1] < tol, (case["n_lstm_layers"], worst)
+            with pytest.raises(NotImplementedError, match="n_lstm_layers == 2"):
+                m.infer(torch.randn(1, 80, 4, device="cuda"), b["speaker_ids"][:1], b["text"][:1, :5])
+    finally:
+        os.environ["FLOWTRON_MFMA"] = "f32"

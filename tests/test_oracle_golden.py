@@ -288,3 +288,24 @@ def test_training_trajectory_oracle_vs_real_reference(golden_dir):
     for k, ref in g["params"].items():
         moved = (ref - init[k]).abs().max().item()
         assert _maxdiff(params[k], ref) < 2e-6 + 2e-3 * moved, (k, _maxdiff(params[k], ref), moved)
+
+
+def test_decoder_lstm_depths_one_and_three_vs_real_reference(golden_dir):
+    """n_lstm_layers is a config.json key that flowtron.py:655 hands to nn.LSTM: the oracle at depth 1 and 3 against the real reference
+    (tests/golden/make_golden_r4.py -> lstm_depth.pt): z, the three losses, every gradient."""
+    g = _load(golden_dir, "lstm_depth.pt")
+    for c in g["cases"]:
+        case, cfg = c["case"], c["cfg"]
+        sd = {k: v.clone().requires_grad_(True) for k, v in synth.make_state_dict(cfg, seed=case["seed"]).items()}
+        assert ("flows.0.lstm.weight_ih_l%d" % (case["n_lstm_layers"] - 1)) in sd and ("flows.0.lstm.weight_ih_l%d" % case["n_lstm_layers"]) not in sd
+        b = synth.make_batch(cfg, case["out_lens"], case["in_lens"], seed=case["seed"], with_prior=True)
+        out = O.forward(sd, cfg, b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+        assert _maxdiff(out[0], c["z"]) < TOL
+        nll, gl, ctc = O.loss(out, b["gate_target"], b["in_lens"], b["out_lens"], 1.0, True, True, -8)
+        assert abs(nll.item() - c["nll"].item()) < 1e-5 * abs(c["nll"].item()) and abs(gl.item() - c["gate_loss"].item()) < 1e-5
+        assert abs(ctc.item() - c["ctc"].item()) < 1e-4
+        (nll + gl + 0.01 * ctc).sum().backward()
+        assert set(c["grads"]) == set(sd)
+        for k, ref in c["grads"].items():
+            denom = max(ref.norm().item(), 1e-5 * ref.numel() ** 0.5)
+            assert (sd[k].grad - ref).norm().item() / denom < 2e-4, (case["n_lstm_layers"], k)
