@@ -769,6 +769,8 @@ def test_decoder_lstm_depths_one_and_three_vs_real_reference_golden(mode, tol):
                 ref = c["grads"][k]
                 if mode != "f32" and (k.startswith("encoder.convolutions") or k.startswith("embedding.") or "query" in k):
                     continue                   # ill-conditioned under 16-bit operands for the real reference too (cfg2_bf16.pt)
+                if k.startswith("encoder.convolutions") and k.endswith("conv.bias"):
+                    continue                   # analytically zero (the instance norm removes the bias): fp32 round-off on both sides
                 r = (p.grad.cpu() - ref).norm().item() / max(ref.norm().item(), 1e-5 * ref.numel() ** 0.5)
                 if r > worst[1]:
                     worst = (k, r)
