@@ -292,6 +292,12 @@ def _pmc_file(prefix, counter_file):
     return json.load(open(path)) if os.path.exists(path) else None
 
 
+def _pmc_key_matches(key, kernel):
+    """the summary's kernel name, stripped of `void ` and namespaces, BEGINS with `kernel` (a bare substring test lets
+    `lstm_persist_fwd_k` pick up `bilstm_persist_fwd_k`)"""
+    return key.replace("void ", "").replace("(anonymous namespace)::", "").startswith(kernel)
+
+
 def _pmc_scalar(v):
     """a field of scripts/pmc_summarize.py's output: either a number or {"avg": number, "dispatches": n}"""
     return float(v["avg"]) if isinstance(v, dict) else float(v)
@@ -307,7 +313,7 @@ def pmc_value(counter_file, kernel_substr, field, with_source=False):
         if d is None:
             continue
         for k, v in d.items():
-            if kernel_substr in k and field in v:
+            if _pmc_key_matches(k, kernel_substr) and field in v:
                 val = round(_pmc_scalar(v[field]), 4)
                 return (val, prefix[:3]) if with_source else val
     return (None, None) if with_source else None
@@ -325,7 +331,7 @@ def pmc_traffic(kernel_substr):
             if d is None:
                 continue
             for k, v in d.items():
-                if kernel_substr in k and c in v:
+                if _pmc_key_matches(k, kernel_substr) and c in v:
                     vals[c] = _pmc_scalar(v[c])
         if len(vals) == 2:
             return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
@@ -815,12 +821,26 @@ def main():
                 nf, ti, blk = time_infer("f32")
                 wbytes = 26838656 * 4                                   # weights a frame of one flow must read, fp32
                 ach = n_fl * wbytes * nf / ti / 1e9
+                persist32 = os.environ.get("FLOWTRON_DECODE_PERSIST", "1") != "0"
                 blk["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                                    "bytes_per_frame_per_flow": wbytes,
-                                   "note": "fp32 weights do not fit the register file (107 MB per flow): the staged hipGraph chain streams them "
-                                           "every frame (L2 / Infinity Cache resident after the first frame)"}
+                                   "note": ("algorithmic weight bytes per frame over the frame time.  dec_persist_k<true>: one launch per flow; the "
+                                            "recurrent / large LSTM matrices (16.8 M of the 26.8 M weights) never move -- they are register-resident "
+                                            "for the whole utterance --, the other 40 MB per frame and flow (query rows and the 1x1 conv once per XCD) "
+                                            "are re-read from the L2 / Infinity Cache under the stage hand-offs")
+                                   if persist32 else
+                                   "fp32 weights streamed every frame by the staged hipGraph chain (L2 / Infinity Cache resident after the first frame)"}
                 blk["config"] = ("2-flow LJS, B=1, L=69, sigma=0.5, fp32 weights and arithmetic = the reference's inference.py:68-71 "
-                                 "(no autocast), staged hipGraph decode chain, gate disabled")
+                                 "(no autocast), %s, gate disabled" % ("one persistent launch per flow (dec_persist_k<true>)" if persist32
+                                                                        else "staged hipGraph decode chain"))
+                if persist32:                                           # the staged chain it replaces, timed beside it
+                    os.environ["FLOWTRON_DECODE_PERSIST"] = "0"
+                    try:
+                        _, ti_s, blk_s = time_infer("f32")
+                        blk["replaces"] = {"decoder": "staged hipGraph chain (8 launches per frame)", "rtf": blk_s["rtf"],
+                                           "us_per_frame_per_flow": blk_s["us_per_frame_per_flow"]}
+                    finally:
+                        os.environ["FLOWTRON_DECODE_PERSIST"] = "1"
                 res["infer_fp32"] = blk
             except Exception as e:
                 res["infer_fp32"] = {"error": repr(e)}

@@ -21,6 +21,7 @@
 #include <unordered_map>
 
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -568,9 +569,49 @@ struct WRows {
     }
 };
 
+// The same for fp32 weight rows (dec_persist_k<true>: the reference's own inference precision, inference.py:68-71).  A chunk of 8
+// weights is two float4; `issue` requests them, `dot` multiplies.  RESIDENT rows are issued once before the frame loop and live in
+// registers (AGPRs take what the 256 architectural registers cannot hold: the compiler parks them there and reads them back per
+// use); STREAMED rows are re-issued every frame right before the wait for the stage's input and come from the L2 / Infinity Cache.
+template <int R, int NL>
+struct WRowsF {
+    float4 w[R][NL][2];
+    __device__ __forceinline__ void issue(const float* const (&row)[R], int K, int lane) {
+        const int K8 = K >> 3;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int kk = lane + 64 * j;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool ok = kk < K8 && row[r];
+                const float4* src = reinterpret_cast<const float4*>(row[r]) + 2 * kk;
+                w[r][j][0] = ok ? src[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+                w[r][j][1] = ok ? src[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __device__ __forceinline__ void dot(const float* x, int K, int lane, float (&acc)[R]) const {
+        const int K8 = K >> 3;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int kk = lane + 64 * j;
+            if (kk < K8) {
+                const float4 xa = x4[2 * kk], xb = x4[2 * kk + 1];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float4 a = w[r][j][0], b = w[r][j][1];
+                    acc[r] += (a.x * xa.x + a.y * xa.y + a.z * xa.z + a.w * xa.w) + (b.x * xb.x + b.y * xb.y + b.z * xb.z + b.w * xb.w);
+                }
+            }
+        }
+    }
+};
+
+template <bool PRECISE = false>
 __device__ __forceinline__ void cell_update(const float (&pre)[4], float& c, float& h) {
     float ig, fg, gg, og, cn;
-    lstm_cell<true>(pre, c, ig, fg, gg, og, cn, h);           // v_exp / v_rcp forms (common.h): bf16 operand mode
+    lstm_cell<!PRECISE>(pre, c, ig, fg, gg, og, cn, h);       // fast: v_exp / v_rcp forms (common.h, 16-bit operand modes); precise: libm
     c = cn;
 }
 // wave sum by DPP butterflies inside the 16-lane rows + four v_readlane (the ds_bpermute ladder of common.h's wave_sum costs
@@ -592,6 +633,16 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.f * 1.4426950408889634f * x) + 1.f);
 }
 
+template <int R, int NL, bool F32> using template_rows = typename std::conditional<F32, WRowsF<R, NL>, WRows<R, NL>>::type;
+
+// F32 = false: 16-bit weight images, all of them register-resident (the round-2 kernel).
+// F32 = true (round 4): fp32 weights and libm activations -- the precision of the reference's inference.py:68-71.  107 MB per flow do
+//   not fit the register file (419 KB per CU against 512 KB of registers less the working set): the five recurrent / large input
+//   matrices of the LSTMs (attention W_hh, layer-0 W_ih[:, :H] and W_hh, layer-1 W_hh: 256 registers per lane = the accumulation
+//   half of the register file, where the compiler parks them) stay RESIDENT, the rest -- attention W_ih, the query rows, layer-0
+//   W_ih[:, H:], layer-1 W_ih, the two dense layers, the 1x1 conv: 52 KB per wave and frame -- is STREAMED from the L2 / Infinity
+//   Cache, requested right before the wait for the stage's input (the loads return under the hand-off).
+template <bool F32>
 __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
     const DecodeDev& P = p.d;
     constexpr int H = 1024, A = 640, M = 80, LMAX = 1024;
@@ -622,38 +673,54 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
     }
     float c_att = 0.f, c_0 = 0.f, c_1 = 0.f;                      // cell states of unit u (lane 0 of the wave is the keeper)
     int i = 0, done = 0;
-    const bf16_t* rows4[4];
-    auto gate_rows = [&](const bf16_t* W, int K) {                // the four gate rows of unit u
+    typedef typename std::conditional<F32, float, bf16_t>::type wt_t;
+    const wt_t* rows4[4];
+    auto gate_rows = [&](const wt_t* W, int K, int col0 = 0) {    // the four gate rows of unit u (from column col0 on)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) rows4[g] = W + ((size_t)g * H + u) * K;
+        for (int g = 0; g < 4; ++g) rows4[g] = W + ((size_t)g * H + u) * K + col0;
     };
-    // ---- the flow's weights live in REGISTERS for all N frames: 53.7 MB of bf16 over 256 CUs x 4 waves = 205 KB per CU =
-    // ~240 VGPRs per lane (one wave per SIMD owns the whole 512-entry file); nothing is streamed per frame but the hand-offs
-    WRows<4, 1> wa_ih;  WRows<4, 2> wa_hh;  WRows<5, 2> wq;
-    WRows<4, 4> w0_ih;  WRows<4, 2> w0_hh;  WRows<4, 2> w1_ih, w1_hh;
-    WRows<1, 2> wd0, wd1;  WRows<2, 2> wcv;
+    auto wsel = [](const bf16_t* w16, const float* w32) -> const wt_t* {
+        if constexpr (F32) return w32; else return w16;
+    };
+    // ---- 16-bit mode: the flow's weights live in REGISTERS for all N frames: 53.7 MB of bf16 over 256 CUs x 4 waves = 205 KB per CU
+    // = ~240 VGPRs per lane (one wave per SIMD owns the whole 512-entry file); nothing is streamed per frame but the hand-offs.
+    // fp32 mode: see the kernel's head comment (resident: wa_hh, w0_ih over h_att, w0_hh, w1_hh; the rest streamed).
+    template_rows<4, 1, F32> wa_ih;  template_rows<4, 2, F32> wa_hh;  template_rows<5, 2, F32> wq;
+    template_rows<4, F32 ? 2 : 4, F32> w0_ih;  template_rows<4, 2, F32> w0_ihc;   // (w0_ihc: fp32 mode only, columns H .. H + A)
+    template_rows<4, 2, F32> w0_hh;  template_rows<4, 2, F32> w1_ih, w1_hh;
+    template_rows<1, 2, F32> wd0, wd1;  template_rows<2, 2, F32> wcv;
     // The small stages (query, scores, context, 1x1 conv) are computed by EVERY XCD for itself -- 8x redundant arithmetic on
     // resident operands -- so their hand-offs never leave the XCD's L2 (~0.5 us instead of ~2.5 us through the fabric).
     // Wave `slot` of the XCD's 128 waves takes query rows / context channels slot + 128 k, text positions slot + 128 k and
     // conv rows slot, slot + 128.
     const int slot = R.q * 4 + wave;
-    gate_rows(P.att_w_ih16, M); wa_ih.issue(rows4, M, lane);
-    gate_rows(P.att_w_hh16, H); wa_hh.issue(rows4, H, lane);
-    gate_rows(P.l0_w_ih16, H + A); w0_ih.issue(rows4, H + A, lane);
-    gate_rows(P.l0_w_hh16, H); w0_hh.issue(rows4, H, lane);
-    gate_rows(P.l1_w_ih16, H); w1_ih.issue(rows4, H, lane);
-    gate_rows(P.l1_w_hh16, H); w1_hh.issue(rows4, H, lane);
-    const bf16_t* r1[1];
-    {
-        const bf16_t* r5[5];
+    const wt_t* r5[5];
+    const wt_t* r2[2];
+    const wt_t* r1a[1];
+    const wt_t* r1b[1];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) r5[k] = P.w_query16 + (size_t)(slot + 128 * k) * H;
+    for (int k = 0; k < 5; ++k) r5[k] = wsel(P.w_query16, P.w_query) + (size_t)(slot + 128 * k) * H;
+    r2[0] = wsel(P.conv_w16, P.conv_w) + (size_t)slot * H;
+    r2[1] = slot + 128 < 2 * M ? wsel(P.conv_w16, P.conv_w) + (size_t)(slot + 128) * H : nullptr;
+    r1a[0] = wsel(P.d0_w16, P.d0_w) + (size_t)u * H;
+    r1b[0] = wsel(P.d1_w16, P.d1_w) + (size_t)u * H;
+    // streamed (fp32 mode) weight requests, each placed right before the wait for its stage's input
+    auto issue_att_ih = [&]() { gate_rows(wsel(P.att_w_ih16, P.att_w_ih), M); wa_ih.issue(rows4, M, lane); };
+    auto issue_l0_ctx = [&]() { gate_rows(wsel(P.l0_w_ih16, P.l0_w_ih), H + A, H); w0_ihc.issue(rows4, A, lane); };
+    gate_rows(wsel(P.att_w_hh16, P.att_w_hh), H); wa_hh.issue(rows4, H, lane);
+    if constexpr (F32) { gate_rows(P.l0_w_ih, H + A); w0_ih.issue(rows4, H, lane); }
+    else { gate_rows(wsel(P.l0_w_ih16, P.l0_w_ih), H + A); w0_ih.issue(rows4, H + A, lane); }
+    gate_rows(wsel(P.l0_w_hh16, P.l0_w_hh), H); w0_hh.issue(rows4, H, lane);
+    auto issue_l1_ih = [&]() { gate_rows(wsel(P.l1_w_ih16, P.l1_w_ih), H); w1_ih.issue(rows4, H, lane); };
+    gate_rows(wsel(P.l1_w_hh16, P.l1_w_hh), H); w1_hh.issue(rows4, H, lane);
+    if constexpr (!F32) {                                         // 16-bit mode: everything resident
+        issue_l1_ih();
+        issue_att_ih();
         wq.issue(r5, H, lane);
-        const bf16_t* r2[2] = {P.conv_w16 + (size_t)slot * H, slot + 128 < 2 * M ? P.conv_w16 + (size_t)(slot + 128) * H : nullptr};
         wcv.issue(r2, H, lane);
+        wd0.issue(r1a, H, lane);
+        wd1.issue(r1b, H, lane);
     }
-    r1[0] = P.d0_w16 + (size_t)u * H;  wd0.issue(r1, H, lane);
-    r1[0] = P.d1_w16 + (size_t)u * H;  wd1.issue(r1, H, lane);
     float b_att[4], b_0[4], b_1[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -667,8 +734,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
     // the gate row (workgroup 0)
     // resident: key rows of positions slot, slot + 128 and value columns over l < 256 (texts up to 256 symbols never touch
     // memory for them); longer texts read the rest from the XCD's L2 each frame
-    constexpr int KRES = 2, VRES = 4;
-    float k_row[KRES][A / 64], v_col[5][VRES];
+    // (fp32 mode: not resident -- its registers go to the resident LSTM matrices; K and V are 177 KB each at L = 69 and sit in the L2)
+    constexpr int KRES = F32 ? 0 : 2, VRES = F32 ? 0 : 4;
+    float k_row[KRES ? KRES : 1][A / 64], v_col[5][VRES ? VRES : 1];
 #pragma unroll
     for (int j = 0; j < A / 64; ++j) {
 #pragma unroll
@@ -681,6 +749,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
 #pragma unroll
         for (int j = 0; j < VRES; ++j) v_col[k][j] = lane + 64 * j < L ? P.V[(size_t)(lane + 64 * j) * A + slot + 128 * k] : 0.f;
     const float gate_b = (c == 0 && P.gate_w) ? P.gate_b[0] : 0.f;
+    auto act_tanh = [](float x) { if constexpr (F32) return tanhf(x); else return fast_tanh(x); };
     const bool prof = p.prof != nullptr && c == 0 && tid == 0;
     auto stamp = [&](int k) { if (prof && i < 512) p.prof[(size_t)i * 12 + k] = wall_clock64(); };
     for (;; ++i) {
@@ -693,6 +762,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
         const float* const s_h1 = s_h1b[(i & 1) ^ 1];
         stamp(0);
         // ================= S1: inverse coupling of frame i-1 (needs its conv output o), then the attention LSTM of frame i
+        if constexpr (F32) issue_att_ih();
         if (i > 0) {
             const float z = tid < M ? P.residual[(size_t)(i - 1) * M + tid] : 0.f;     // requested before the wait
             if (!gather(R, G_O, 2 * M + 1, 2 * M, e0 - 16u + 9u, s_o, p, t_start)) return;
@@ -715,11 +785,12 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) pre[g] = wsum(acc[g]) + b_att[g];
             float h;
-            cell_update(pre, c_att, h);
+            cell_update<F32>(pre, c_att, h);
             if (lane == 0) publish(p.gran + G_HATT + u, e0 + 1u, h);
         }
         // ================= S2: query rows c, c + 256, c + 512 (waves 0..2)
         stamp(2);
+        if constexpr (F32) wq.issue(r5, H, lane);
         if (!gather(R, G_HATT, H, 0, e0 + 1u, s_cat, p, t_start)) return;       // new h_att = first part of [h_att ; ctx]
         stamp(3);
         {
@@ -739,14 +810,14 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
             if (slot + 128 * k < L) {
                 float sc = 0.f;
 #pragma unroll
-                for (int j = 0; j < A / 64; ++j) sc += s_v[lane + 64 * j] * fast_tanh(s_q[lane + 64 * j] + k_row[k][j]);
+                for (int j = 0; j < A / 64; ++j) sc += s_v[lane + 64 * j] * act_tanh(s_q[lane + 64 * j] + k_row[k][j]);
                 sc = wsum(sc);
                 if (lane == 0) publish_local(R.loc + G_SC + slot + 128 * k, e0 + 3u, sc * P.inv_temp);
             }
         for (int l = slot + 128 * KRES; l < L; l += 128) {         // texts longer than 256 symbols
             float sc = 0.f;
 #pragma unroll
-            for (int j = 0; j < A / 64; ++j) sc += s_v[lane + 64 * j] * fast_tanh(s_q[lane + 64 * j] + P.K[(size_t)l * A + lane + 64 * j]);
+            for (int j = 0; j < A / 64; ++j) sc += s_v[lane + 64 * j] * act_tanh(s_q[lane + 64 * j] + P.K[(size_t)l * A + lane + 64 * j]);
             sc = wsum(sc);
             if (lane == 0) publish_local(R.loc + G_SC + l, e0 + 3u, sc * P.inv_temp);
         }
@@ -772,7 +843,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
                 if (c == 0) P.attn_out[(size_t)i * L + l] = pl;
             }
             __syncthreads();
-            float pl[VRES];
+            float pl[VRES ? VRES : 1];
 #pragma unroll
             for (int j = 0; j < VRES; ++j) pl[j] = lane + 64 * j < L ? s_pr[lane + 64 * j] : 0.f;
 #pragma unroll
@@ -786,6 +857,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
             }
         }
         // ================= S4: LSTM layer 0 (input [h_att ; ctx], recurrent h0); workgroup 0 also evaluates the gate
+        if constexpr (F32) issue_l0_ctx();
         if (!gather(R, G_CTX, A, A, e0 + 4u, s_cat + H, p, t_start)) return;
         stamp(6);
         float gate_done = 0.f;
@@ -800,16 +872,18 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
         }
         {
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            w0_ih.dot(s_cat, H + A, lane, acc);
+            if constexpr (F32) { w0_ih.dot(s_cat, H, lane, acc); w0_ihc.dot(s_cat + H, A, lane, acc); }
+            else w0_ih.dot(s_cat, H + A, lane, acc);
             w0_hh.dot(s_h0, H, lane, acc);
             float pre[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) pre[g] = wsum(acc[g]) + b_0[g];
             float h;
-            cell_update(pre, c_0, h);
+            cell_update<F32>(pre, c_0, h);
             if (lane == 0) publish(p.gran + G_H0 + u, e0 + 5u, h);
         }
         // ================= S5: LSTM layer 1
+        if constexpr (F32) issue_l1_ih();
         if (!gather(R, G_H0, H, 0, e0 + 5u, s_h0n, p, t_start)) return;
         stamp(7);
         {
@@ -820,27 +894,30 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) pre[g] = wsum(acc[g]) + b_1[g];
             float h;
-            cell_update(pre, c_1, h);
+            cell_update<F32>(pre, c_1, h);
             if (lane == 0) publish(p.gran + G_H1 + u, e0 + 6u, h);
         }
         // ================= S6 / S7: dense + tanh, row u
+        if constexpr (F32) wd0.issue(r1a, H, lane);
         if (!gather(R, G_H1, H, 0, e0 + 6u, s_h1n, p, t_start)) return;
         stamp(8);
         {
             float acc[1] = {0.f};
             wd0.dot(s_h1n, H, lane, acc);
-            const float v = fast_tanh(wsum(acc[0]) + b_d0);
+            const float v = act_tanh(wsum(acc[0]) + b_d0);
             if (lane == 0) publish(p.gran + G_U1 + u, e0 + 7u, v);
         }
+        if constexpr (F32) wd1.issue(r1b, H, lane);
         if (!gather(R, G_U1, H, 0, e0 + 7u, s_u1, p, t_start)) return;
         stamp(9);
         {
             float acc[1] = {0.f};
             wd1.dot(s_u1, H, lane, acc);
-            const float v = fast_tanh(wsum(acc[0]) + b_d1);
+            const float v = act_tanh(wsum(acc[0]) + b_d1);
             if (lane == 0) publish(p.gran + G_U2 + u, e0 + 8u, v);
         }
         // ================= S8: 1x1 conv row c (wave 0 of workgroups c < 2M); workgroup 0 appends the stop flag
+        if constexpr (F32) wcv.issue(r2, H, lane);
         if (!gather(R, G_U2, H, 0, e0 + 8u, s_u2, p, t_start)) return;
         stamp(10);
         {
@@ -1011,8 +1088,9 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
     const DecodeDev& dP = h;       // passed to every stage kernel by value (kernarg segment)
     FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_ctx_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
-    // persistent path: bf16 images, the default model geometry, plain attention, every workgroup resident on its own CU
-    if (a->wimg && a->persist_status && !cumm && !a->prior && !a->forced && a->H == 1024 && a->A == 640 && a->M == 80 && a->L <= 1024) {
+    // persistent path: 16-bit images or (round 4) the fp32 originals, the default model geometry, plain attention, every workgroup
+    // resident on its own CU
+    if (a->persist_status && !cumm && !a->prior && !a->forced && a->H == 1024 && a->A == 640 && a->M == 80 && a->L <= 1024) {
         static int cus = -1;
         if (cus < 0) {
             int dev = 0;
@@ -1024,7 +1102,8 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
             FT_CHECK_HIP(hipMemsetAsync(a->persist_gran, 0, ft_decode_persist_gran_bytes(), st));   // tags = 0 (epochs start at 1)
             unsigned long long* gr = reinterpret_cast<unsigned long long*>(a->persist_gran);
             DecP dp{h, gr, reinterpret_cast<unsigned*>(gr + (size_t)G_TOTAL * 9), a->persist_status, 100000000L / 2, g_decode_prof};
-            hipLaunchKernelGGL(dec_persist_k, dim3(256), dim3(256), 0, st, dp);
+            if (a->wimg) hipLaunchKernelGGL(dec_persist_k<false>, dim3(256), dim3(256), 0, st, dp);
+            else hipLaunchKernelGGL(dec_persist_k<true>, dim3(256), dim3(256), 0, st, dp);
             FT_CHECK_LAUNCH();
             return FT_OK;
         }

@@ -376,13 +376,15 @@ class AR_Step(nn.Module):
             if wimg is None or wimg.numel() < nb or wimg.device != dev:
                 wimg = self._decode_wimg = torch.empty(nb, device=dev, dtype=torch.uint8)
             args.wimg, args.wimg_bytes = L.ptr(wimg), wimg.numel()
-            if os.environ.get("FLOWTRON_DECODE_PERSIST", "1") != "0" and ops.persist_usable(dev):
-                # one persistent launch per flow (csrc/decode.hip dec_persist_k) where its geometry applies
-                gran = getattr(self, "_decode_gran", None)
-                if gran is None or gran.device != dev:
-                    gran = self._decode_gran = torch.empty(L.lib().ft_decode_persist_gran_bytes(), device=dev, dtype=torch.uint8)
-                persist = ops.persist_status(dev)
-                args.persist_gran, args.persist_status = L.ptr(gran), L.ptr(persist)
+        if os.environ.get("FLOWTRON_DECODE_PERSIST", "1") != "0" and ops.persist_usable(dev):
+            # one persistent launch per flow (csrc/decode.hip dec_persist_k) where its geometry applies: 16-bit weight images fully
+            # register-resident, or (fp32 mode = the reference's inference precision, round 4) the fp32 originals with the recurrent
+            # matrices resident and the rest streamed from the L2 / Infinity Cache
+            gran = getattr(self, "_decode_gran", None)
+            if gran is None or gran.device != dev:
+                gran = self._decode_gran = torch.empty(L.lib().ft_decode_persist_gran_bytes(), device=dev, dtype=torch.uint8)
+            persist = ops.persist_status(dev)
+            args.persist_gran, args.persist_status = L.ptr(gran), L.ptr(persist)
         L.check(L.lib().ft_decode_flow(C.byref(args), L.stream()), "ft_decode_flow")
         n = int(n_done.item()) if has_gate else N          # single host read per flow (the reference syncs every frame)
         if persist is not None and not ops.check_persist_status(raise_on_failure=False):
