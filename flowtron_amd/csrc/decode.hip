@@ -633,15 +633,18 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.f * 1.4426950408889634f * x) + 1.f);
 }
 
+#ifndef FT_DECODE_LIBM
+#define FT_DECODE_LIBM 0
+#endif
 template <int R, int NL, bool F32> using template_rows = typename std::conditional<F32, WRowsF<R, NL>, WRows<R, NL>>::type;
 
 // F32 = false: 16-bit weight images, all of them register-resident (the round-2 kernel).
 // F32 = true (round 4): fp32 weights and libm activations -- the precision of the reference's inference.py:68-71.  107 MB per flow do
 //   not fit the register file (419 KB per CU against 512 KB of registers less the working set): the five recurrent / large input
-//   matrices of the LSTMs (attention W_hh, layer-0 W_ih[:, :H] and W_hh, layer-1 W_hh: 256 registers per lane = the accumulation
-//   half of the register file, where the compiler parks them) stay RESIDENT, the rest -- attention W_ih, the query rows, layer-0
-//   W_ih[:, H:], layer-1 W_ih, the two dense layers, the 1x1 conv: 52 KB per wave and frame -- is STREAMED from the L2 / Infinity
-//   Cache, requested right before the wait for the stage's input (the loads return under the hand-off).
+//   matrices of the LSTMs stay RESIDENT -- attention W_hh, layer-0 W_ih[:, :H] and W_hh, layer-1 W_hh in registers (256 per lane =
+//   the accumulation half of the register file, where the compiler parks them), layer-1 W_ih and layer-0 W_ih[:, H:] in 104 KB of
+//   LDS --, the rest -- attention W_ih, the query rows, the two dense layers, the 1x1 conv: 37 KB per wave and frame, most of it
+//   replicated per XCD and L2-resident -- is STREAMED, requested right before the wait for the stage's input.
 template <bool F32>
 __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
     const DecodeDev& P = p.d;
@@ -649,8 +652,35 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
     __shared__ __attribute__((aligned(16))) float s_prev[M + 16], s_cat2[2][H + A], s_q[A], s_pr[LMAX], s_h0b[2][H],
         s_h1b[2][H], s_u1[H], s_u2[H], s_o[2 * M + 16], s_v[A], s_gw[H + A];
     __shared__ float s_red[8];
+    // fp32 mode: layer-1 W_ih and layer-0 W_ih[:, H:] of this workgroup's four units live in LDS for the whole utterance
+    // ([wave][gate][H] then [wave][gate][A] floats: 104 KB of dynamic LDS) -- as streamed operands they were 27 MB per frame and flow
+    // out of the Infinity Cache on the two LSTM stages' critical paths (measured 4.4 / 5.0 us for those stages against 2.4 / 3.2)
+    extern __shared__ __attribute__((aligned(16))) float s_wlds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = blockIdx.x;
     const int u = c * 4 + wave;                                   // this wave's hidden unit / dense row
+    float* const s_w1 = s_wlds + (size_t)wave * 4 * H;            // [gate][H]
+    float* const s_w0c = s_wlds + (size_t)4 * 4 * H + (size_t)wave * 4 * A;   // [gate][A]
+    if constexpr (F32) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4* src1 = reinterpret_cast<const float4*>(P.l1_w_ih + ((size_t)g * H + u) * H);
+            for (int k4 = lane; k4 < H / 4; k4 += 64) reinterpret_cast<float4*>(s_w1 + g * H)[k4] = src1[k4];
+            const float4* src0 = reinterpret_cast<const float4*>(P.l0_w_ih + ((size_t)g * H + u) * (H + A) + H);
+            for (int k4 = lane; k4 < A / 4; k4 += 64) reinterpret_cast<float4*>(s_w0c + g * A)[k4] = src0[k4];
+        }
+    }
+    // four rows of K floats in LDS times the activation vector x (same chunking as WRowsF::dot)
+    auto dot_lds = [&](const float* wl, const float* x, int K, float (&acc)[4]) {
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        for (int kk = lane; kk < (K >> 3); kk += 64) {
+            const float4 xa = x4[2 * kk], xb = x4[2 * kk + 1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 a = reinterpret_cast<const float4*>(wl + (size_t)r * K)[2 * kk], b = reinterpret_cast<const float4*>(wl + (size_t)r * K)[2 * kk + 1];
+                acc[r] += (a.x * xa.x + a.y * xa.y + a.z * xa.z + a.w * xa.w) + (b.x * xb.x + b.y * xb.y + b.z * xb.z + b.w * xb.w);
+            }
+        }
+    };
     const int L = P.L, N = P.N;
     const long t_start = wall_clock64();
     __shared__ int s_slot[2];
@@ -686,8 +716,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
     // = ~240 VGPRs per lane (one wave per SIMD owns the whole 512-entry file); nothing is streamed per frame but the hand-offs.
     // fp32 mode: see the kernel's head comment (resident: wa_hh, w0_ih over h_att, w0_hh, w1_hh; the rest streamed).
     template_rows<4, 1, F32> wa_ih;  template_rows<4, 2, F32> wa_hh;  template_rows<5, 2, F32> wq;
-    template_rows<4, F32 ? 2 : 4, F32> w0_ih;  template_rows<4, 2, F32> w0_ihc;   // (w0_ihc: fp32 mode only, columns H .. H + A)
-    template_rows<4, 2, F32> w0_hh;  template_rows<4, 2, F32> w1_ih, w1_hh;
+    template_rows<4, F32 ? 2 : 4, F32> w0_ih;                     // (fp32 mode: the h_att columns; the ctx columns sit in LDS)
+    template_rows<4, 2, F32> w0_hh;  template_rows<4, 2, false> w1_ih;  template_rows<4, 2, F32> w1_hh;   // (w1_ih: 16-bit mode only)
     template_rows<1, 2, F32> wd0, wd1;  template_rows<2, 2, F32> wcv;
     // The small stages (query, scores, context, 1x1 conv) are computed by EVERY XCD for itself -- 8x redundant arithmetic on
     // resident operands -- so their hand-offs never leave the XCD's L2 (~0.5 us instead of ~2.5 us through the fabric).
@@ -706,15 +736,13 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
     r1b[0] = wsel(P.d1_w16, P.d1_w) + (size_t)u * H;
     // streamed (fp32 mode) weight requests, each placed right before the wait for its stage's input
     auto issue_att_ih = [&]() { gate_rows(wsel(P.att_w_ih16, P.att_w_ih), M); wa_ih.issue(rows4, M, lane); };
-    auto issue_l0_ctx = [&]() { gate_rows(wsel(P.l0_w_ih16, P.l0_w_ih), H + A, H); w0_ihc.issue(rows4, A, lane); };
     gate_rows(wsel(P.att_w_hh16, P.att_w_hh), H); wa_hh.issue(rows4, H, lane);
     if constexpr (F32) { gate_rows(P.l0_w_ih, H + A); w0_ih.issue(rows4, H, lane); }
     else { gate_rows(wsel(P.l0_w_ih16, P.l0_w_ih), H + A); w0_ih.issue(rows4, H + A, lane); }
     gate_rows(wsel(P.l0_w_hh16, P.l0_w_hh), H); w0_hh.issue(rows4, H, lane);
-    auto issue_l1_ih = [&]() { gate_rows(wsel(P.l1_w_ih16, P.l1_w_ih), H); w1_ih.issue(rows4, H, lane); };
     gate_rows(wsel(P.l1_w_hh16, P.l1_w_hh), H); w1_hh.issue(rows4, H, lane);
     if constexpr (!F32) {                                         // 16-bit mode: everything resident
-        issue_l1_ih();
+        gate_rows(P.l1_w_ih16, H); w1_ih.issue(rows4, H, lane);
         issue_att_ih();
         wq.issue(r5, H, lane);
         wcv.issue(r2, H, lane);
@@ -734,8 +762,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
     // the gate row (workgroup 0)
     // resident: key rows of positions slot, slot + 128 and value columns over l < 256 (texts up to 256 symbols never touch
     // memory for them); longer texts read the rest from the XCD's L2 each frame
-    // (fp32 mode: not resident -- its registers go to the resident LSTM matrices; K and V are 177 KB each at L = 69 and sit in the L2)
-    constexpr int KRES = F32 ? 0 : 2, VRES = F32 ? 0 : 4;
+    // (fp32 mode keeps half as many: its registers go to the resident LSTM matrices)
+    constexpr int KRES = F32 ? 1 : 2, VRES = F32 ? 2 : 4;         // (fp32: texts up to 128 symbols; the rest comes from the L2)
     float k_row[KRES ? KRES : 1][A / 64], v_col[5][VRES ? VRES : 1];
 #pragma unroll
     for (int j = 0; j < A / 64; ++j) {
@@ -749,7 +777,11 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
 #pragma unroll
         for (int j = 0; j < VRES; ++j) v_col[k][j] = lane + 64 * j < L ? P.V[(size_t)(lane + 64 * j) * A + slot + 128 * k] : 0.f;
     const float gate_b = (c == 0 && P.gate_w) ? P.gate_b[0] : 0.f;
-    auto act_tanh = [](float x) { if constexpr (F32) return tanhf(x); else return fast_tanh(x); };
+    // activations: the v_exp_f32 / v_rcp_f32 forms in BOTH modes (abs error ~1e-7 = fp32 rounding level; libm's expf / tanhf cost
+    // ~100 instructions each on the stage's critical path: 6 per LSTM cell, 10 per score lane -- measured 6 us per frame and flow);
+    // -DFT_DECODE_LIBM=1 selects libm in fp32 mode
+    constexpr bool LIBM = F32 && FT_DECODE_LIBM;
+    auto act_tanh = [](float x) { if constexpr (LIBM) return tanhf(x); else return fast_tanh(x); };
     const bool prof = p.prof != nullptr && c == 0 && tid == 0;
     auto stamp = [&](int k) { if (prof && i < 512) p.prof[(size_t)i * 12 + k] = wall_clock64(); };
     for (;; ++i) {
@@ -785,7 +817,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) pre[g] = wsum(acc[g]) + b_att[g];
             float h;
-            cell_update<F32>(pre, c_att, h);
+            cell_update<LIBM>(pre, c_att, h);
             if (lane == 0) publish(p.gran + G_HATT + u, e0 + 1u, h);
         }
         // ================= S2: query rows c, c + 256, c + 512 (waves 0..2)
@@ -857,7 +889,6 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
             }
         }
         // ================= S4: LSTM layer 0 (input [h_att ; ctx], recurrent h0); workgroup 0 also evaluates the gate
-        if constexpr (F32) issue_l0_ctx();
         if (!gather(R, G_CTX, A, A, e0 + 4u, s_cat + H, p, t_start)) return;
         stamp(6);
         float gate_done = 0.f;
@@ -872,29 +903,29 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
         }
         {
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (F32) { w0_ih.dot(s_cat, H, lane, acc); w0_ihc.dot(s_cat + H, A, lane, acc); }
+            if constexpr (F32) { w0_ih.dot(s_cat, H, lane, acc); dot_lds(s_w0c, s_cat + H, A, acc); }
             else w0_ih.dot(s_cat, H + A, lane, acc);
             w0_hh.dot(s_h0, H, lane, acc);
             float pre[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) pre[g] = wsum(acc[g]) + b_0[g];
             float h;
-            cell_update<F32>(pre, c_0, h);
+            cell_update<LIBM>(pre, c_0, h);
             if (lane == 0) publish(p.gran + G_H0 + u, e0 + 5u, h);
         }
         // ================= S5: LSTM layer 1
-        if constexpr (F32) issue_l1_ih();
         if (!gather(R, G_H0, H, 0, e0 + 5u, s_h0n, p, t_start)) return;
         stamp(7);
         {
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            w1_ih.dot(s_h0n, H, lane, acc);
+            if constexpr (F32) dot_lds(s_w1, s_h0n, H, acc);
+            else w1_ih.dot(s_h0n, H, lane, acc);
             w1_hh.dot(s_h1, H, lane, acc);
             float pre[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) pre[g] = wsum(acc[g]) + b_1[g];
             float h;
-            cell_update<F32>(pre, c_1, h);
+            cell_update<LIBM>(pre, c_1, h);
             if (lane == 0) publish(p.gran + G_H1 + u, e0 + 6u, h);
         }
         // ================= S6 / S7: dense + tanh, row u
@@ -1103,7 +1134,11 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
             unsigned long long* gr = reinterpret_cast<unsigned long long*>(a->persist_gran);
             DecP dp{h, gr, reinterpret_cast<unsigned*>(gr + (size_t)G_TOTAL * 9), a->persist_status, 100000000L / 2, g_decode_prof};
             if (a->wimg) hipLaunchKernelGGL(dec_persist_k<false>, dim3(256), dim3(256), 0, st, dp);
-            else hipLaunchKernelGGL(dec_persist_k<true>, dim3(256), dim3(256), 0, st, dp);
+            else {
+                const int lds32 = (int)(sizeof(float) * 4 * 4 * (1024 + 640));           // layer-1 W_ih + layer-0 W_ih[:, H:] rows
+                FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds32));
+                hipLaunchKernelGGL(dec_persist_k<true>, dim3(256), dim3(256), lds32, st, dp);
+            }
             FT_CHECK_LAUNCH();
             return FT_OK;
         }

@@ -1,7 +1,7 @@
 """Stage stamps of the persistent decode (workgroup 0): where a frame's time goes.  GPU box: python scripts/exp/decode_prof.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-os.environ["FLOWTRON_MFMA"] = "bf16"
+os.environ["FLOWTRON_MFMA"] = os.environ.get("DEC_MODE", "bf16")
 import torch
 import flowtron, bench
 from flowtron_amd import _lib as L
