@@ -35,7 +35,7 @@ class GemmImgArgs(C.Structure):
     _fields_ = [("A", _p), ("B", _p), ("C", _p), ("bias", _p), ("M", _i), ("N", _i), ("K", _i),
                 ("lda", _l), ("ldb", _l), ("ldc", _l), ("a_kmajor", _i), ("b_kmajor", _i),
                 ("alpha", _f), ("beta", _f), ("act", _i), ("flags", _i),
-                ("rowmap", _p), ("rows_dev", _p), ("compact", _i), ("k_shift", _i)]
+                ("rowmap", _p), ("rows_dev", _p), ("compact", _i), ("k_shift", _i), ("r1_row", _p), ("r1_col", _p)]
 
 
 class CummAttnArgs(C.Structure):
@@ -71,6 +71,8 @@ SIGNATURES = {
     "ft_rowmap_build": ([_p, _p, _p, _i, _i, _p], _i),
     "ft_bf16_image_rows": ([_p, _l, _l, _l, _p, _p, _p, _p, _p], _i),
     "ft_bf16_image_rows_into": ([_p, _l, _l, _l, _p, _l, _l, _l, _p, _p, _p], _i),
+    "ft_img_gemv_rows": ([_p, _l, _i, _p, _p, _p, _l, _p, _p, _p, _i, _i, _p], _i),
+    "ft_img_gemv_rows_bwd": ([_p, _l, _i, _p, _l, _p, _p, _p, _p, _l, _p], _i),
     "ft_bf16_image_rows_act_bwd": ([_p, _l, _p, _l, _i, _l, _l, _p, _p, _p, _p, _p], _i),
     "ft_pad_rows_fill": ([_p, _l, _i, _p, _i, _i, _i, _p], _i),
     "ft_embedding_fwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
@@ -133,7 +135,7 @@ SIGNATURES = {
 }
 
 # fp16-operand twins (include/flowtron_hip.h, end): same signatures, suffix _f16
-OP16_TWINS = ("ft_gemm", "ft_bf16_image", "ft_bf16_image_colsum", "ft_gemm_img", "ft_bf16_image_rows", "ft_bf16_image_rows_into", "ft_bf16_image_rows_act_bwd", "ft_lstm_seq_fwd", "ft_lstm_seq_bwd",
+OP16_TWINS = ("ft_gemm", "ft_bf16_image", "ft_bf16_image_colsum", "ft_gemm_img", "ft_bf16_image_rows", "ft_bf16_image_rows_into", "ft_bf16_image_rows_act_bwd", "ft_img_gemv_rows", "ft_img_gemv_rows_bwd", "ft_lstm_seq_fwd", "ft_lstm_seq_bwd",
               "ft_lstm_persist_fwd", "ft_lstm_persist_bwd", "ft_lstm_persist_bwd_img", "ft_lstm2_seq_fwd", "ft_lstm2_seq_bwd",
               "ft_lstm_bidir_seq_fwd", "ft_lstm_bidir_seq_bwd", "ft_bilstm_persist_fwd", "ft_bilstm_persist_bwd")
 for _n in OP16_TWINS:
@@ -155,7 +157,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argt
             fn.restype = rest
-        if l.ft_abi_version() != 9:
+        if l.ft_abi_version() != 10:
             raise RuntimeError("libflowtron_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -337,11 +337,12 @@ extern "C" int FT_OPNAME(ft_bilstm_persist_fwd)(const float* gx_f, const float* 
     unsigned short* wf[2] = {reinterpret_cast<unsigned short*>(base), reinterpret_cast<unsigned short*>(base + al256b(BI_WFRAG))};
     unsigned long long* gran = reinterpret_cast<unsigned long long*>(base + 2 * al256b(BI_WFRAG));
     unsigned* census = reinterpret_cast<unsigned*>(base + 2 * al256b(BI_WFRAG) + al256b(BI_GRAN));
-    FT_CHECK_HIP(hipMemsetAsync(gran, 0, (size_t)2 * 16 * GRAN_F * 8, st));          // tags 0: no epoch matches (epochs start at 1)
-    FT_CHECK_HIP(hipMemsetAsync(census, 0, 256, st));
     FT_CHECK_HIP(hipMemset2DAsync(y, (size_t)ldy * 4, 0, (size_t)2 * H * 4, (size_t)T * B, st));   // padded frames: zeros
-    hipLaunchKernelGGL(make_wfrag_fwd, dim3(256), dim3(256), 0, st, w_hh_f, wf[0], H);
-    hipLaunchKernelGGL(make_wfrag_fwd, dim3(256), dim3(256), 0, st, w_hh_r, wf[1], H);
+    // tags 0: no epoch matches (epochs start at 1); preset, with the census counters, by the first fragment kernel (WfragAux)
+    static_assert(((size_t)2 * 16 * GRAN_F * 8) % 16 == 0, "granule buffer in 16-byte pieces");
+    const WfragAux aux{reinterpret_cast<uint4*>(gran), (unsigned long)((size_t)2 * 16 * GRAN_F * 8 / 16), 0u, census};
+    hipLaunchKernelGGL(make_wfrag_fwd, dim3(256), dim3(256), 0, st, w_hh_f, wf[0], H, aux);
+    hipLaunchKernelGGL(make_wfrag_fwd, dim3(256), dim3(256), 0, st, w_hh_r, wf[1], H, WfragAux{});
     BiFwdP p{{gx_f, gx_r}, lens, y, (long)ldy, {gates_f, gates_r}, {cell_f, cell_r}, {wf[0], wf[1]}, gran, status, census, T, B,
              100000000L / 2};
     FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_persist_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BI_LDS));
@@ -364,12 +365,12 @@ extern "C" int FT_OPNAME(ft_bilstm_persist_bwd)(const float* dy, int64_t ldy, co
     unsigned short* wf[2] = {reinterpret_cast<unsigned short*>(base), reinterpret_cast<unsigned short*>(base + al256b(BI_WFRAG))};
     unsigned long long* gran = reinterpret_cast<unsigned long long*>(base + 2 * al256b(BI_WFRAG));
     unsigned* census = reinterpret_cast<unsigned*>(base + 2 * al256b(BI_WFRAG) + al256b(BI_GRAN));
-    FT_CHECK_HIP(hipMemsetAsync(gran, 0, BI_GRAN, st));
-    FT_CHECK_HIP(hipMemsetAsync(census, 0, 256, st));
     FT_CHECK_HIP(hipMemsetAsync(dgx_f, 0, (size_t)T * B * 4 * H * 4, st));
     FT_CHECK_HIP(hipMemsetAsync(dgx_r, 0, (size_t)T * B * 4 * H * 4, st));
-    hipLaunchKernelGGL(make_wfrag_bwd, dim3(256), dim3(256), 0, st, w_hh_f, wf[0], H);
-    hipLaunchKernelGGL(make_wfrag_bwd, dim3(256), dim3(256), 0, st, w_hh_r, wf[1], H);
+    static_assert(BI_GRAN % 16 == 0, "granule buffer in 16-byte pieces");
+    const WfragAux aux{reinterpret_cast<uint4*>(gran), (unsigned long)(BI_GRAN / 16), 0u, census};
+    hipLaunchKernelGGL(make_wfrag_bwd, dim3(256), dim3(256), 0, st, w_hh_f, wf[0], H, aux);
+    hipLaunchKernelGGL(make_wfrag_bwd, dim3(256), dim3(256), 0, st, w_hh_r, wf[1], H, WfragAux{});
     BiBwdP p{dy, (long)ldy, lens, {gates_f, gates_r}, {cell_f, cell_r}, {dgx_f, dgx_r}, {wf[0], wf[1]}, gran, status, census, T, B,
              100000000L / 2};
     FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_persist_bwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BI_LDS));

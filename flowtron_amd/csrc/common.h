@@ -90,6 +90,13 @@ __device__ __forceinline__ unsigned short f2op16(float f) {
     return f2bf(f);
 #endif
 }
+__device__ __forceinline__ float op16_to_f(unsigned int bits16) {                 // exact widening of one 16-bit operand
+#if FT_OPFMT == 1
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)bits16);
+#else
+    return __builtin_bit_cast(float, bits16 << 16);
+#endif
+}
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {          // 16x16x32, fp32 accumulate
 #if FT_OPFMT == 1
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_hw, a), __builtin_bit_cast(f16x8_hw, b), c, 0, 0, 0);

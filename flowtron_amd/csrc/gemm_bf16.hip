@@ -167,6 +167,8 @@ struct BfP {
     // k-steps at or beyond *rows_dev - k_shift are not visited (the images are zero there up to the next 32-row step)
     const int* rowmap; const int* rows_dev; int compact, k_shift;
     int chunk_w;                            // > 0: L2-aware tile order with column chunks of this many tiles (no split-K)
+    // rank-1 epilogue term (ft_gemm_img_args.r1_row / r1_col): C[row][col] += r1row[row] * r1col[col], row = the OUTPUT row
+    const float* r1row; const float* r1col;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -411,9 +413,11 @@ __global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
                 if (full) { const float4 c = *reinterpret_cast<const float4*>(cp); v[0] += p.beta * c.x; v[1] += p.beta * c.y; v[2] += p.beta * c.z; v[3] += p.beta * c.w; }
                 else for (int r = 0; r < nv; ++r) v[r] += p.beta * cp[r];
             }
+            const float r1 = p.r1row ? p.r1row[row] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (r < nv && p.bias) v[r] += p.bias[col + r];
+                if (r < nv && p.r1row) v[r] = fmaf(r1, p.r1col[col + r], v[r]);
                 if (p.act == FT_ACT_TANH) v[r] = tanhf_(v[r]);
                 else if (p.act == FT_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
                 else if (p.act == FT_ACT_SIGMOID) v[r] = sigmoidf_(v[r]);
@@ -636,9 +640,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_k(BfP p) {
                 if (full) { const float4 c = *reinterpret_cast<const float4*>(cp); v[0] += p.beta * c.x; v[1] += p.beta * c.y; v[2] += p.beta * c.z; v[3] += p.beta * c.w; }
                 else for (int r = 0; r < nv; ++r) v[r] += p.beta * cp[r];
             }
+            const float r1 = p.r1row ? p.r1row[row] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (r < nv && p.bias) v[r] += p.bias[col + r];
+                if (r < nv && p.r1row) v[r] = fmaf(r1, p.r1col[col + r], v[r]);
                 if (p.act == FT_ACT_TANH) v[r] = tanhf_(v[r]);
                 else if (p.act == FT_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
                 else if (p.act == FT_ACT_SIGMOID) v[r] = sigmoidf_(v[r]);
@@ -664,14 +670,16 @@ void launch_s(const BfP& p, dim3 grid, bool big, hipStream_t st) {
 // Images are padded to multiples of 256 in both dimensions (ft_bf16_image), so either tile height may run off the logical M.
 int run_images(const unsigned short* A, long lda, int a_km, const unsigned short* B, long ldb, int b_km, float* C, long ldc,
                const float* bias, int M, int N, int K, float alpha, float beta, int act, int flags, hipStream_t st,
-               const int* rowmap = nullptr, const int* rows_dev = nullptr, int compact = 0, int k_shift = 0) {
+               const int* rowmap = nullptr, const int* rows_dev = nullptr, int compact = 0, int k_shift = 0,
+               const float* r1row = nullptr, const float* r1col = nullptr) {
     static const int force_tile = [] { const char* e = getenv("FT_GEMM_BF16_TILE"); return e ? atoi(e) : 0; }();
     BfP p;
     p.A = A; p.B = B; p.C = C; p.bias = bias;
     p.M = M; p.N = N; p.nk = cdiv(K, 32); p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.beta = beta; p.act = act;
     p.rowmap = rowmap; p.rows_dev = rows_dev; p.compact = compact; p.k_shift = k_shift;
-    const bool can_split = (flags & FT_GEMM_SPLITK) && act == FT_ACT_NONE && (beta == 0.f || beta == 1.f) && K >= 2048;
+    p.r1row = r1row; p.r1col = r1col;
+    const bool can_split = (flags & FT_GEMM_SPLITK) && act == FT_ACT_NONE && (beta == 0.f || beta == 1.f) && K >= 2048 && !r1row;
     // 256 x 128 workgroup tiles (2 per CU) when they still fill the chip, possibly with split-K; else 128 x 128 (4 per CU)
     const long tiles_big = (long)cdiv(M, 256) * cdiv(N, TB);
     // measured (scripts/exp/gemm_bench.py): the tall tile pays for the long-K weight-gradient shapes (+9 %), is neutral to
@@ -753,6 +761,102 @@ ImgGeo geo(long sr, long sk, int R, int K) {
     return g;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// N = 1 projections over a compact image (the gate layer, flowtron.py:760-761, reads the SAME [h_att ; ctx] rows as the decoder
+// LSTM's input projection): a GEMV over the image the GEMM has just used instead of two fp32 GEMMs with one output column, and
+// its weight gradient as a GEMV^T.  Operand rounding as in every 16-bit GEMM of the library (x from the image, w rounded here),
+// fp32 accumulation.
+// ---------------------------------------------------------------------------------------------------------------
+// one wave per compact row; the separator row of utterance b (its first padded frame, t == lens[b]) also writes its value to
+// every later frame of b (all padded frames of an utterance hold the same inputs: ft_pad_rows_fill's copy_separator)
+__global__ __launch_bounds__(256) void img_gemv_rows_k(const unsigned short* __restrict__ img, long ld, int K, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y, long ldy,
+                                                       const int* __restrict__ rowmap, const int* __restrict__ rows_dev,
+                                                       const int* __restrict__ lens, int T, int B) {
+    extern __shared__ float s_w[];                       // ceil8(K) rounded weights
+    const int K8 = (K + 7) & ~7;
+    for (int k = threadIdx.x; k < K8; k += 256) s_w[k] = k < K ? op16_to_f(f2op16(w[k])) : 0.f;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nrows = rows_dev[0];
+    const float b0 = bias ? bias[0] : 0.f;
+    for (int c = blockIdx.x * 4 + wave; c < nrows; c += gridDim.x * 4) {
+        const int dest = rowmap[c];
+        if (dest < 0) continue;
+        const unsigned short* row = img + (size_t)c * ld;
+        float acc = 0.f;
+        for (int k = lane * 8; k < K8; k += 512) {
+            const uint4 v = *reinterpret_cast<const uint4*>(row + k);
+            const float4 wa = *reinterpret_cast<const float4*>(s_w + k), wb = *reinterpret_cast<const float4*>(s_w + k + 4);
+            acc = fmaf(op16_to_f(v.x & 0xffffu), wa.x, acc); acc = fmaf(op16_to_f(v.x >> 16), wa.y, acc);
+            acc = fmaf(op16_to_f(v.y & 0xffffu), wa.z, acc); acc = fmaf(op16_to_f(v.y >> 16), wa.w, acc);
+            acc = fmaf(op16_to_f(v.z & 0xffffu), wb.x, acc); acc = fmaf(op16_to_f(v.z >> 16), wb.y, acc);
+            acc = fmaf(op16_to_f(v.w & 0xffffu), wb.z, acc); acc = fmaf(op16_to_f(v.w >> 16), wb.w, acc);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+        acc += b0;
+        const int t = dest / B, b = dest - t * B;
+        int len = lens[b];
+        len = len < 0 ? 0 : len;
+        if (lane == 0) y[(size_t)dest * ldy] = acc;
+        if (t == len)                                                       // separator: stands for every padded frame of b
+            for (int tt = t + 1 + lane; tt < T; tt += 64) y[((size_t)tt * B + b) * ldy] = acc;
+    }
+}
+
+// dw[k] += sum_c dy[rowmap[c]] * img[c][k],  db += sum_c dy[rowmap[c]]  (dw, db zeroed by the caller); a block owns RPB compact rows,
+// a thread 8 columns
+template <int RPB>
+__global__ __launch_bounds__(256) void img_gemv_rows_bwd_k(const unsigned short* __restrict__ img, long ld, int K, const float* __restrict__ dy,
+                                                           long lddy, float* __restrict__ dw, float* __restrict__ db,
+                                                           const int* __restrict__ rowmap, const int* __restrict__ rows_dev) {
+    __shared__ float s_d[RPB];
+    const int nrows = rows_dev[0];
+    const int c0 = blockIdx.x * RPB;
+    if (c0 >= nrows) return;
+    const int nr = nrows - c0 < RPB ? nrows - c0 : RPB;
+    for (int i = threadIdx.x; i < RPB; i += 256) {
+        float d = 0.f;
+        if (i < nr) { const int dest = rowmap[c0 + i]; if (dest >= 0) d = dy[(size_t)dest * lddy]; }
+        s_d[i] = d;
+    }
+    __syncthreads();
+    const int K8 = (K + 7) & ~7;
+    for (int k = threadIdx.x * 8; k < K8; k += 2048) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const unsigned short* col = img + (size_t)c0 * ld + k;
+        // eight rows in flight (rows at or beyond nr re-read the last valid row with a zero factor: the image is only defined up to
+        // the zero rows that follow *rows_dev)
+        for (int i0 = 0; i0 < nr; i0 += 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u < nr ? i0 + u : nr - 1;
+                v[u] = *reinterpret_cast<const uint4*>(col + (size_t)i * ld);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float d = i0 + u < nr ? s_d[i0 + u] : 0.f;
+                acc[0] = fmaf(d, op16_to_f(v[u].x & 0xffffu), acc[0]); acc[1] = fmaf(d, op16_to_f(v[u].x >> 16), acc[1]);
+                acc[2] = fmaf(d, op16_to_f(v[u].y & 0xffffu), acc[2]); acc[3] = fmaf(d, op16_to_f(v[u].y >> 16), acc[3]);
+                acc[4] = fmaf(d, op16_to_f(v[u].z & 0xffffu), acc[4]); acc[5] = fmaf(d, op16_to_f(v[u].z >> 16), acc[5]);
+                acc[6] = fmaf(d, op16_to_f(v[u].w & 0xffffu), acc[6]); acc[7] = fmaf(d, op16_to_f(v[u].w >> 16), acc[7]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (k + e < K) atomicAdd(dw + k + e, acc[e]);
+    }
+    if (db && threadIdx.x < 64) {
+        float sacc = 0.f;
+        for (int i = threadIdx.x; i < nr; i += 64) sacc += s_d[i];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sacc += __shfl_xor(sacc, o);
+        if (threadIdx.x == 0) atomicAdd(db, sacc);
+    }
+}
+
 }  // namespace
 
 #if FT_OPFMT == 0
@@ -820,9 +924,10 @@ extern "C" int FT_OPNAME(ft_gemm_img)(const ft_gemm_img_args* a, void* stream) {
     FT_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0 && reinterpret_cast<uintptr_t>(a->A) % 16 == 0 && reinterpret_cast<uintptr_t>(a->B) % 16 == 0);
     FT_CHECK_ARG(a->compact >= 0 && a->compact <= 2 && (a->compact == 0 || a->rows_dev) && (a->compact != 1 || a->rowmap));
     FT_CHECK_ARG(a->k_shift >= 0 && (a->compact == 2 || a->k_shift == 0));
+    FT_CHECK_ARG((a->r1_row == nullptr) == (a->r1_col == nullptr));
     return run_images(reinterpret_cast<const unsigned short*>(a->A), a->lda, a->a_kmajor, reinterpret_cast<const unsigned short*>(a->B),
                       a->ldb, a->b_kmajor, a->C, a->ldc, a->bias, a->M, a->N, a->K, a->alpha, a->beta, a->act, a->flags,
-                      reinterpret_cast<hipStream_t>(stream), a->rowmap, a->rows_dev, a->compact, a->k_shift);
+                      reinterpret_cast<hipStream_t>(stream), a->rowmap, a->rows_dev, a->compact, a->k_shift, a->r1_row, a->r1_col);
 }
 
 // compact image: image row i = source row rowmap[i] (i < *rows_dev; -1 = zero row); buffer sized for cap_rows
@@ -876,6 +981,33 @@ extern "C" int FT_OPNAME(ft_bf16_image_rows)(const float* src, int64_t ld, int64
         hipLaunchKernelGGL(img_rows_sum_k, dim3(cdiv(Cp, 256), cdiv(Rp, 256)), dim3(256), 0, st, src, (long)ld, (int)cap_rows, (int)cols,
                            reinterpret_cast<unsigned short*>(dst), Rp, Cp, vec, colsum, rowmap, rows_dev);
     }
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+
+// y[rowmap[c]] = sum_k img[c][k] w[k] + bias[0] over the compact rows of an image (img_gemv_rows_k above); y [T*B] rows of stride ldy,
+// padded frames receive their utterance's separator value.  The image must be zero beyond K up to the next multiple of 8 columns
+// (ft_bf16_image_rows / _into pad with zeros).
+extern "C" int FT_OPNAME(ft_img_gemv_rows)(const void* img, int64_t ld, int K, const float* w, const float* bias, float* y, int64_t ldy,
+                                           const int32_t* rowmap, const int32_t* rows_dev, const int32_t* lens, int T, int B, void* stream) {
+    FT_CHECK_ARG(img && w && y && rowmap && rows_dev && lens && K >= 1 && ld >= ((K + 7) & ~7) && ld % 8 == 0 && ldy >= 1 && T >= 1 && B >= 1);
+    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(img) % 16 == 0 && K <= 16384);
+    const int blocks = cdiv(T * B + B, 4) < 2048 ? cdiv(T * B + B, 4) : 2048;
+    hipLaunchKernelGGL(img_gemv_rows_k, dim3(blocks), dim3(256), sizeof(float) * ((K + 7) & ~7), reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const unsigned short*>(img), (long)ld, K, w, bias, y, (long)ldy, rowmap, rows_dev, lens, T, B);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+
+// dw[k] += sum_c dy[rowmap[c]] img[c][k] (k < K), db[0] += sum_c dy[rowmap[c]] over the compact rows (separator rows included: a
+// separator carries the gradient of its own frame, like the weight-gradient GEMMs over compact rows); dw / db accumulate -- the
+// caller zeroes them; db may be NULL
+extern "C" int FT_OPNAME(ft_img_gemv_rows_bwd)(const void* img, int64_t ld, int K, const float* dy, int64_t lddy, float* dw, float* db,
+                                               const int32_t* rowmap, const int32_t* rows_dev, int64_t cap_rows, void* stream) {
+    FT_CHECK_ARG(img && dy && dw && rowmap && rows_dev && K >= 1 && ld >= ((K + 7) & ~7) && ld % 8 == 0 && lddy >= 1 && cap_rows >= 1);
+    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(img) % 16 == 0 && cap_rows < (1ll << 31) - 512);
+    hipLaunchKernelGGL((img_gemv_rows_bwd_k<256>), dim3(cdiv((int)cap_rows, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const unsigned short*>(img), (long)ld, K, dy, (long)lddy, dw, db, rowmap, rows_dev);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

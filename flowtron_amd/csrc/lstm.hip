@@ -472,7 +472,7 @@ extern "C" int FT_OPNAME(ft_lstm_seq_fwd)(const float* gx, const float* w_hh, co
     unsigned short* wfrag = reinterpret_cast<unsigned short*>(base + al256(3 * BH * 4) + al256(2 * frag_act));
     // zero the state, build the fragment image of W_hh
     FT_CHECK_HIP(hipMemsetAsync(base, 0, al256(3 * BH * 4) + al256(2 * frag_act), st));
-    if (fast) hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H);
+    if (fast) hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H, WfragAux{});
     dim3 grid(cdiv(H, 4));
     for (int s = 0; s < T; ++s) {
         FwdP p{gx, w_hh, lens, hbuf[s & 1], hbuf[(s + 1) & 1], cstate, y, (long)ldy, gates, cell,
@@ -512,7 +512,7 @@ extern "C" int FT_OPNAME(ft_lstm_seq_bwd)(const float* dy, int64_t ldy, const fl
     FT_CHECK_HIP(hipMemsetAsync(base, 0, al256(9 * BH * 4), st));
     if (fast) {
         FT_CHECK_HIP(hipMemsetAsync(fr, 0, al256(8 * frag_act), st));
-        hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H);
+        hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H, WfragAux{});
     } else {
         hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(H, 32), cdiv(4 * H, 32)), dim3(32, 8), 0, st, w_hh, wT, 4 * H, H);
     }
@@ -597,8 +597,8 @@ extern "C" int FT_OPNAME(ft_lstm_bidir_seq_fwd)(const float* gx_f, const float* 
     FwdCarve cf = carve_fwd(work_f, B, H, mt), cr = carve_fwd(work_r, B, H, mt);
     FT_CHECK_HIP(hipMemsetAsync(work_f, 0, cf.state_bytes, st));
     FT_CHECK_HIP(hipMemsetAsync(work_r, 0, cr.state_bytes, st));
-    hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh_f, cf.wfrag, H);
-    hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh_r, cr.wfrag, H);
+    hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh_f, cf.wfrag, H, WfragAux{});
+    hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh_r, cr.wfrag, H, WfragAux{});
     dim3 grid(H / 4, 1, 2);
     for (int s = 0; s < T; ++s) {
         FwdP pf{gx_f, w_hh_f, lens, cf.hbuf[s & 1], cf.hbuf[(s + 1) & 1], cf.cstate, y, (long)ldy, gates_f, cell_f,
@@ -629,8 +629,8 @@ extern "C" int FT_OPNAME(ft_lstm_bidir_seq_bwd)(const float* dy, int64_t ldy, co
     FT_CHECK_HIP(hipMemsetAsync(work_r, 0, cr.carry_bytes, st));
     FT_CHECK_HIP(hipMemsetAsync(cf.fr, 0, cf.frag_bytes, st));
     FT_CHECK_HIP(hipMemsetAsync(cr.fr, 0, cr.frag_bytes, st));
-    hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh_f, cf.wTfrag, H);
-    hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh_r, cr.wTfrag, H);
+    hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh_f, cf.wTfrag, H, WfragAux{});
+    hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh_r, cr.wTfrag, H, WfragAux{});
     dim3 grid(H / 16, mt, 2);
     for (int s = T - 1; s >= 0; --s) {
         BwdP pf{dy, (long)ldy, lens, gates_f, cell_f, cf.part, cf.dc_carry, cf.da_cur, dgx_f, cf.wT, cf.part,

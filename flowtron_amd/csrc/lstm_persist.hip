@@ -1210,9 +1210,9 @@ extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh
     // tagged: 2 parities x 32 rows x H/2 granules x 8 B; bare: 3 buffers x 32 rows x H/2 dwords (smaller)
     const size_t gran_bytes = al256p((size_t)2 * 32 * (H / 2) * 8);
     unsigned* census = reinterpret_cast<unsigned*>(base + al256p((size_t)4 * H * H * 2) + al256p((size_t)2 * 32 * (4 * H / 2) * 8));
-    FT_CHECK_HIP(hipMemsetAsync(hgran, bare ? 0xFF : 0, gran_bytes, st));   // tags = 0: no epoch matches (epochs start at 1); bare: sentinels
-    FT_CHECK_HIP(hipMemsetAsync(census, 0, 256, st));
-    hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H);
+    // tags = 0: no epoch matches (epochs start at 1); bare: sentinels.  Preset by the fragment kernel (lstm_images.h: WfragAux)
+    const WfragAux aux{reinterpret_cast<uint4*>(hgran), (unsigned long)(gran_bytes / 16), bare ? 0xFFFFFFFFu : 0u, census};
+    hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H, aux);
     PersistP p{gx, lens, y, (long)ldy, gates, cell, wfrag, hgran, status, census, T, B, 100000000L / 2, g_persist_prof};   // 0.5 s
     // dynamic LDS: reduce buffers (2*4*TPC*RPGP*17 = 2*4*32*17 floats) + SB staged gx rows + 2 output rows
     const size_t lds = sizeof(float) * ((size_t)2 * 4 * 32 * 17 + (size_t)SB * 4 * 128 + (size_t)2 * 6 * 128);
@@ -1272,10 +1272,9 @@ extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, 
     const size_t rs_bytes = (size_t)2 * 8 * 32 * 32 * 32 * 4 * sizeof(float);
     const size_t gran_bytes = al256p(rsform ? rs_bytes : (size_t)2 * 32 * (4 * H / 2) * 8);
     unsigned* census = reinterpret_cast<unsigned*>(base + ft_lstm_persist_workspace_bytes(B, H) - 256);
-    FT_CHECK_HIP(hipMemsetAsync(dgran, (bare || rsform) ? 0xFF : 0, gran_bytes, st));
-    FT_CHECK_HIP(hipMemsetAsync(census, 0, 256, st));
-    if (rsform) hipLaunchKernelGGL(make_wfrag_rs, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H);
-    else hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H);
+    const WfragAux aux{reinterpret_cast<uint4*>(dgran), (unsigned long)(gran_bytes / 16), (bare || rsform) ? 0xFFFFFFFFu : 0u, census};
+    if (rsform) hipLaunchKernelGGL(make_wfrag_rs, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H, aux);
+    else hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H, aux);
     PersistBwdP p{dy, (long)ldy, lens, gates, cell, dgx, wTfrag, dgran, status, census, T, B, 100000000L / 2, g_persist_prof,
                   reinterpret_cast<unsigned short*>(dimg), (long)dimg_ld, (int)dimg_rows, dbias};
     // dynamic LDS: 16-partial reduce (2 x 16 x 32 unit-rows... = 2*16*TL*RPGP*17 = 2*16*8*17 floats) + staged steps

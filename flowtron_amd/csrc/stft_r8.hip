@@ -19,6 +19,7 @@ namespace {
 constexpr int NFFT = 1024, NH = 512, NB = 513;
 constexpr int FPW = 4, FPG = 4 * FPW;                  // frames per wave / per workgroup
 constexpr int SPAN = (FPG - 1) * 256 + NFFT;           // hop is a runtime argument <= 256 in the reference; sized for 256
+constexpr int BWMAX = 2048;                            // CSR values staged in LDS when they fit (Slaney, 80 bands: ~1 000)
 
 struct cpx { float re, im; };
 __device__ __forceinline__ cpx cmul(cpx a, cpx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
@@ -55,36 +56,68 @@ __global__ __launch_bounds__(256) void stft_r8_k(StftP p) {
     __shared__ __attribute__((aligned(16))) cpx tr[4][NH];               // per-wave transpose buffer
     __shared__ float mg[4][NB + 3];                                      // per-wave magnitudes
     __shared__ float mo[128][FPG + 1];                                   // mel tile of the workgroup's frames [band][frame]
+    __shared__ float bw[BWMAX];                                          // the filterbank's non-zero weights (CSR values)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, f0 = blockIdx.x * FPG;
     const float* yb = p.y + (size_t)b * p.N;
     const int Nb = p.n_samples ? min(max(p.n_samples[b], 1), p.N) : p.N;   // this utterance's own length: the reflection is about ITS end
     const int nfb = p.n_samples ? Nb / p.hop + 1 : p.n_frames;
     const int span = (FPG - 1) * p.hop + NFFT;
-    for (int j = tid; j < span; j += 256) {
-        int n = f0 * p.hop + j - NH;                                      // reflect padding (audio_processing.py:210-214)
-        if (n < 0) n = -n;
-        if (n >= Nb) n = 2 * (Nb - 1) - n;
-        xs[j] = (n >= 0 && n < Nb) ? yb[n] : 0.f;
+    {                                                                     // all of a thread's loads in flight before the first LDS write
+        constexpr int NL = (SPAN + 255) / 256;
+        float xv[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int j = tid + 256 * u;
+            int n = f0 * p.hop + j - NH;                                  // reflect padding (audio_processing.py:210-214)
+            if (n < 0) n = -n;
+            if (n >= Nb) n = 2 * (Nb - 1) - n;
+            xv[u] = (j < span && n >= 0 && n < Nb) ? yb[n] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NL; ++u) if (tid + 256 * u < span) xs[tid + 256 * u] = xv[u];
+    }
+    // filterbank: this lane's bands (lane, lane + 64) and, when they fit, the CSR values in LDS -- the band loop below then reads
+    // weight and magnitude from LDS eight bins at a time (one global load per bin, un-unrolled, was ~60 dependent L1 round trips
+    // on the lanes that hold the widest bands: most of a frame's time)
+    int bk0[2] = {0, 0}, bw0[2] = {0, 0}, bn[2] = {0, 0};
+    bool w_lds = false;
+    if (p.mel) {
+        const int nnz = p.band_ptr[p.n_mel];
+        w_lds = nnz <= BWMAX;
+        if (w_lds) for (int j = tid; j < nnz; j += 256) bw[j] = p.band_w[j];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int mb = lane + 64 * h;
+            if (mb < p.n_mel) { bk0[h] = p.band_bin0[mb]; bw0[h] = p.band_ptr[mb]; bn[h] = p.band_ptr[mb + 1] - bw0[h]; }
+        }
     }
     // per-lane constants for all frames: twiddles W512^{l k1} (l = lane), W64^{b2 k2} (b2 = lane & 7), the split twiddles
     // W1024^{k} of this lane's bins k = lane + 64 r, and the window taps of its 8 complex input points
+    // The three twiddle tables depend on (lane, k) only: the workgroup evaluates each entry ONCE into LDS (1 089 sincospif over 256
+    // threads instead of 25 per lane of every wave) and a lane then picks its 25 constants up; the table aliases the per-wave
+    // transpose buffers, which are not in use yet.
     cpx w1[8], w2[8], w3[9];
     float2 win[8];
+    {
+        cpx* tw = &tr[0][0];                                              // [0, 512): W512^{l k}; [512, 576): W64^{b k}; [576, 1152): W1024^{k}
+        for (int i = tid; i < 512 + 64 + 576; i += 256) {
+            float s, c, a;
+            if (i < 512) a = (float)((i >> 3) * (i & 7)) / 512.0f;
+            else if (i < 576) a = (float)(((i - 512) >> 3) * ((i - 512) & 7)) / 64.0f;
+            else a = (float)(i - 576) / 1024.0f;
+            sincospif(-2.0f * a, &s, &c);
+            tw[i] = (cpx){c, s};
+        }
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        float s, c;
-        sincospif(-2.0f * (float)(lane * k) / 512.0f, &s, &c);
-        w1[k] = (cpx){c, s};
-        sincospif(-2.0f * (float)((lane & 7) * k) / 64.0f, &s, &c);
-        w2[k] = (cpx){c, s};
-        win[k] = *reinterpret_cast<const float2*>(p.window + 2 * (lane + 64 * k));
-    }
+        for (int k = 0; k < 8; ++k) {
+            w1[k] = tw[lane * 8 + k];
+            w2[k] = tw[512 + (lane & 7) * 8 + k];
+            win[k] = *reinterpret_cast<const float2*>(p.window + 2 * (lane + 64 * k));
+        }
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        float s, c;
-        sincospif(-2.0f * (float)(lane + 64 * r) / 1024.0f, &s, &c);
-        w3[r] = (cpx){c, s};
+        for (int r = 0; r < 9; ++r) w3[r] = tw[576 + lane + 64 * r];
     }
     __syncthreads();
     cpx* T = tr[wave];
@@ -157,10 +190,27 @@ __global__ __launch_bounds__(256) void stft_r8_k(StftP p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // ---- sparse triangular filterbank + log compression (audio_processing.py:132-133, :81-82)
         if (p.mel) {
-            for (int mb = lane; mb < p.n_mel; mb += 64) {
-                const int k0 = p.band_bin0[mb], w0 = p.band_ptr[mb], n = p.band_ptr[mb + 1] - w0;
-                float s = 0.f;
-                for (int i = 0; i < n; ++i) s += p.band_w[w0 + i] * M[k0 + i];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int mb = lane + 64 * h;
+                if (mb >= p.n_mel) continue;
+                const int k0 = bk0[h], w0 = bw0[h], n = bn[h];
+                float s = 0.f;                                             // one accumulator, bins in ascending order (as before)
+                if (w_lds) {
+                    for (int i = 0; i < n; i += 8) {
+                        float wv[8], mv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int j = i + u < n ? i + u : n - 1;
+                            wv[u] = bw[w0 + j];
+                            mv[u] = M[k0 + j];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (i + u < n) s += wv[u] * mv[u];
+                    }
+                } else {
+                    for (int i = 0; i < n; ++i) s += p.band_w[w0 + i] * M[k0 + i];
+                }
                 mo[mb][wave * FPW + fi] = logf(fmaxf(s, 1e-5f));
             }
         }

@@ -227,32 +227,38 @@ class AR_Step(nn.Module):
         else:
             ctx, attn, logprob = self.attention_layer(h_att, text, text, in_lens32, attn_prior, rowmap=rm)
         gates = None
-        if hasattr(self, "gate_layer"):
-            g = self.gate_layer.linear_layer
-            gates = ops.linear([h_att, ctx], g.weight, g.bias, mode=mode)     # Linear over [h_att ; ctx], no concat
         p = self.lstm
+        # the gate layer reads [h_att ; ctx] like the decoder LSTM's input projection: where that projection runs over a
+        # concatenated operand image, the N = 1 gate projection is taken from the same image (ops.LinearGateFn)
+        g = self.gate_layer.linear_layer if hasattr(self, "gate_layer") else None
+        persist = ops.lstm_persist_groups(B, p.weight_hh_l0.shape[1], False, mode, mel.device)
+        fuse_gate = g is not None and (self.n_lstm_layers != 2 or persist or not ops.lstm2_supported(B, p.weight_hh_l0.shape[1], mode))
+        if g is not None and not fuse_gate:
+            gates = ops.linear([h_att, ctx], g.weight, g.bias, mode=mode)     # Linear over [h_att ; ctx], no concat
+
+        def first_layer():
+            r = ops.lstm_layer(h_att, out_lens32, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, mode=mode,
+                               xs_extra=[ctx], rowmap=rm, fill="dx", gate=(g.weight, g.bias) if fuse_gate else None)
+            return r if fuse_gate else (r, gates)
         if self.n_lstm_layers != 2:
             # any other depth (the config schema splats n_lstm_layers into nn.LSTM, flowtron.py:655): the same per-layer pair --
             # batched input projection + one recurrence (persistent where its geometry applies) -- layer after layer
-            h = ops.lstm_layer(h_att, out_lens32, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, mode=mode,
-                               xs_extra=[ctx], rowmap=rm, fill="dx")
+            h, gates = first_layer()
             for l in range(1, self.n_lstm_layers):
                 h = ops.lstm_layer(h, out_lens32, getattr(p, "weight_ih_l%d" % l), getattr(p, "weight_hh_l%d" % l),
                                    getattr(p, "bias_ih_l%d" % l), getattr(p, "bias_hh_l%d" % l), mode=mode, rowmap=rm)
-        elif ops.lstm_persist_groups(B, p.weight_hh_l0.shape[1], False, mode, mel.device):
+        elif persist:
             # two persistent single-layer recurrences (csrc/lstm_persist.hip, ~2 us per step each) with layer 1's input
             # projection as one batched GEMM between them: faster than the two-layer wavefront launch chain (~8 us per step)
             # (the context gradient feeds the attention backward, which reduces over ALL frames: zero its padded rows)
-            h = ops.lstm_layer(h_att, out_lens32, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, mode=mode,
-                               xs_extra=[ctx], rowmap=rm, fill="dx")
+            h, gates = first_layer()
             h = ops.lstm_layer(h, out_lens32, p.weight_ih_l1, p.weight_hh_l1, p.bias_ih_l1, p.bias_hh_l1, mode=mode, rowmap=rm)
         elif ops.lstm2_supported(B, p.weight_hh_l0.shape[1], mode):
             # both decoder layers as one software-wavefront launch chain (csrc/lstm2.hip)
             gx0 = ops.LinearFn.apply(p.weight_ih_l0, p.bias_ih_l0 + p.bias_hh_l0, L.ACT_NONE, mode, None, "", h_att, ctx)
             h = ops.LSTM2SeqFn.apply(gx0, p.weight_hh_l0, p.weight_ih_l1, p.bias_ih_l1, p.bias_hh_l1, p.weight_hh_l1, out_lens32, mode)
         else:
-            h = ops.lstm_layer(h_att, out_lens32, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, mode=mode,
-                               xs_extra=[ctx], rowmap=rm, fill="dx")
+            h, gates = first_layer()
             h = ops.lstm_layer(h, out_lens32, p.weight_ih_l1, p.weight_hh_l1, p.bias_ih_l1, p.bias_hh_l1, mode=mode, rowmap=rm)
         h = self.dense_layer(h, rowmap=rm)
         # the coupling output is returned for every frame (z, log_s of padded frames are the reference's defined junk): fill "y"

@@ -184,15 +184,17 @@ def images_apply(mode, M, N, K):
 
 
 def gemm_img(A, a_km, a_ptr, B, b_km, b_ptr, Cm, M, N, K, ldc, bias=None, act=L.ACT_NONE, alpha=1.0, beta=0.0, splitk=False,
-             rowmap=None, compact=0, k_shift=0):
+             rowmap=None, compact=0, k_shift=0, rank1=None):
     """C[M,N] = act(alpha * A.B + beta*C + bias) from images.  a_ptr / b_ptr: A.ptr(...) / B.ptr(...) (may point inside).
     rowmap + compact: 1 = M runs over the map's compact rows (pass M = rowmap.cap), C rows are scattered through the map;
-    2 = the reduction runs over compact rows (pass K = rowmap.cap; k_shift = a row shift already applied to a_ptr)."""
+    2 = the reduction runs over compact rows (pass K = rowmap.cap; k_shift = a row shift already applied to a_ptr).
+    rank1 = (r [C rows] fp32, c_ptr -> N floats): C[row][col] += r[row] * c[col] in the epilogue (row = the output row)."""
     L.require_cuda(Cm, bias)
     a = L.GemmImgArgs(a_ptr, b_ptr, L.ptr(Cm), L.ptr(bias), M, N, K, A.ld, B.ld, ldc, int(a_km), int(b_km),
                       alpha, beta, act, L.GEMM_SPLITK if splitk else 0,
                       L.ptr(rowmap.map) if rowmap is not None else None, L.ptr(rowmap.rows) if rowmap is not None else None,
-                      int(compact) if rowmap is not None else 0, int(k_shift))
+                      int(compact) if rowmap is not None else 0, int(k_shift),
+                      L.ptr(rank1[0]) if rank1 is not None else None, rank1[1] if rank1 is not None else None)
     assert A.fmt == B.fmt, "operand images of different formats"
     L.check(L.op16("ft_gemm_img", A.fmt)(C.byref(a), L.stream()), "ft_gemm_img")
 
@@ -402,6 +404,97 @@ class LinearFn(torch.autograd.Function):
         return (dW, db, None, None, None, None, *dxs)
 
 
+_GATE_ON_CAT = _os.environ.get("FLOWTRON_GATE_ON_CAT", "1") != "0"   # the gate layer on the decoder input projection's concatenated image
+
+
+def linear_gate_fusable(mode, rowmap, xs, N):
+    """whether LinearGateFn applies: two inputs over a row map on the concatenated-image path (LinearFn's own conditions)"""
+    if not (_GATE_ON_CAT and _CAT_IMAGES and rowmap is not None and len(xs) == 2):
+        return False
+    rows = xs[0].numel() // xs[0].shape[-1]
+    return rows == rowmap.T * rowmap.B and linear_uses_images(mode, rows, N, xs)
+
+
+class LinearGateFn(torch.autograd.Function):
+    """y = [x0 | x1] W^T + b  AND  gate = [x0 | x1] wg^T + bg  from ONE concatenated compact image (flowtron.py:758-761: the decoder
+    LSTM's input and the gate layer both read [h_att ; ctx]).  The N = 1 gate projection is a GEMV over the image the GEMM has just
+    used (ft_img_gemv_rows) instead of two fp32 GEMMs with one output column; in backward its input gradient dgate (x) wg rides on
+    the projection's dX GEMMs as a rank-1 epilogue term (no [T,B,1664] fp32 tensor, no accumulation pass) and its weight gradient
+    is a GEMV^T over the same image.  Rows of padded frames: y as LinearFn (`fill`), gate = the utterance's separator value."""
+
+    @staticmethod
+    def forward(ctx, W, bias, Wg, bg, mode, rowmap, fill, x0, x1):
+        xs = [_c(x0), _c(x1)]
+        L.require_cuda(W, Wg, *xs)
+        W, Wg = _c(W), _c(Wg)
+        N, Ktot = W.shape
+        assert Wg.shape == (1, Ktot) and xs[0].shape[-1] + xs[1].shape[-1] == Ktot
+        rows = rowmap.T * rowmap.B
+        y = torch.empty(xs[0].shape[:-1] + (N,), device=W.device, dtype=torch.float32)
+        gate = torch.empty(xs[0].shape[:-1] + (1,), device=W.device, dtype=torch.float32)
+        w_img = Bf16Image(W, mode=mode)
+        x_cat = Bf16Image.cat_rows([x.reshape(rows, x.shape[-1]) for x in xs], mode, rowmap)
+        gemm_img(x_cat, 0, x_cat.ptr(), w_img, 0, w_img.ptr(), y, rowmap.cap, N, Ktot, N, bias=bias, rowmap=rowmap, compact=1)
+        L.check(L.op16("ft_img_gemv_rows", mode)(L.ptr(x_cat.buf), x_cat.ld, Ktot, L.ptr(Wg), L.ptr(bg), L.ptr(gate), 1, L.ptr(rowmap.map),
+                                                 L.ptr(rowmap.rows), L.ptr(rowmap.lens), rowmap.T, rowmap.B, L.stream()), "ft_img_gemv_rows")
+        if "y" in fill:
+            rowmap.fill(y.reshape(rows, N), N, copy_separator=True)
+        ctx.save_for_backward(W, Wg, *xs)
+        ctx.imgs = (w_img, x_cat)
+        ctx.mode, ctx.has_bias, ctx.has_gbias, ctx.rowmap, ctx.fill = mode, bias is not None, bg is not None, rowmap, fill
+        return y, gate
+
+    @staticmethod
+    def backward(ctx, dy, dgate):
+        W, Wg, *xs = ctx.saved_tensors
+        N, Ktot = W.shape
+        rowmap = ctx.rowmap
+        rows = rowmap.T * rowmap.B
+        w_img, x_cat = ctx.imgs
+        want_db = ctx.has_bias and ctx.needs_input_grad[1]
+        d_img = _handoff_take(dy)                      # the LSTM backward's dgates image (possibly the ONLY form dy exists in)
+        if d_img is not None and (d_img.fmt != w_img.fmt or d_img.rowmap is not rowmap or (want_db and d_img.colsum is None)):
+            d_img = None
+        if d_img is None:
+            _require_written(dy)
+            d_img = Bf16Image(_c(dy).reshape(rows, N), colsum=want_db, mode=w_img.fmt, rowmap=rowmap)
+        db = d_img.colsum if want_db else None
+        rank1 = None
+        if dgate is not None:
+            dgate = _c(dgate)
+            _require_written(dgate)
+        dxs, off = [], 0
+        for i, x in enumerate(xs):
+            K = x.shape[-1]
+            if ctx.needs_input_grad[7 + i]:
+                dx = torch.empty_like(x)
+                if dgate is not None:
+                    rank1 = (dgate, Wg.data_ptr() + 4 * off)
+                gemm_img(d_img, 0, d_img.ptr(), w_img, 1, w_img.ptr(0, off), dx, rowmap.cap, K, N, K, rowmap=rowmap, compact=1, rank1=rank1)
+                if "dx" in ctx.fill:
+                    rowmap.fill(dx.reshape(rows, K), K, copy_separator=False)
+                dxs.append(dx)
+            else:
+                dxs.append(None)
+            off += K
+        dW = None
+        if ctx.needs_input_grad[0]:
+            dW = torch.empty_like(W)
+            gemm_img(d_img, 1, d_img.ptr(), x_cat, 1, x_cat.ptr(), dW, N, Ktot, rowmap.cap, Ktot, splitk=True, rowmap=rowmap, compact=2)
+        dWg = dbg = None
+        if dgate is not None and (ctx.needs_input_grad[2] or (ctx.has_gbias and ctx.needs_input_grad[3])):
+            acc = torch.zeros(Ktot + 1, device=W.device, dtype=torch.float32)
+            L.check(L.op16("ft_img_gemv_rows_bwd", w_img.fmt)(L.ptr(x_cat.buf), x_cat.ld, Ktot, L.ptr(dgate), 1, L.ptr(acc), acc.data_ptr() + 4 * Ktot,
+                                                              L.ptr(rowmap.map), L.ptr(rowmap.rows), rowmap.cap, L.stream()), "ft_img_gemv_rows_bwd")
+            dWg = acc[:Ktot].reshape(1, Ktot) if ctx.needs_input_grad[2] else None
+            dbg = acc[Ktot:] if (ctx.has_gbias and ctx.needs_input_grad[3]) else None
+        elif dgate is None:
+            dWg = torch.zeros_like(Wg) if ctx.needs_input_grad[2] else None
+            dbg = torch.zeros(1, device=W.device, dtype=torch.float32) if (ctx.has_gbias and ctx.needs_input_grad[3]) else None
+        ctx.imgs = None
+        return (dW, db, dWg, dbg, None, None, None, *dxs)
+
+
 def linear(xs, W, bias=None, act=L.ACT_NONE, mode=None, rowmap=None, fill="y+dx"):
     if isinstance(xs, torch.Tensor):
         xs = [xs]
@@ -583,6 +676,11 @@ def _persist_arm(st, bilstm=False):
         BILSTM_PERSIST_LAUNCHES += 1
     else:
         PERSIST_LAUNCHES += 1
+    if st.event is not None:
+        # the previous asynchronous copy has not been looked at yet (the host runs about a step ahead of the device): one copy in
+        # flight is enough -- the word stays set until it is consumed, so the next copy sees a failure of any launch before it --
+        # and a D2H copy per launch costs the stream ~10 us each (copy dispatch + the gap behind it; profiles/r04_v1_step_timeline.txt)
+        return
     st.host.copy_(st.status, non_blocking=True)
     st.event = torch.cuda.Event()
     st.event.record()
@@ -783,19 +881,29 @@ class LSTMSeqFn(torch.autograd.Function):
         return dgx, dW, None, None, None, None, None
 
 
-def lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=False, mode=None, xs_extra=None, rowmap=None, fill=""):
+def lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=False, mode=None, xs_extra=None, rowmap=None, fill="", gate=None):
     """One LSTM layer over a padded sequence: input projection for all T*B rows (valid rows only with a RowMap) as one MFMA
     GEMM, then the sequential recurrence.  The recurrence kernels never use a padded frame's gx / dy row and write zeros to its
     y / dgx row themselves, so the projection leaves padded rows unwritten (fill = ""); pass fill = "dx" when something that
-    reduces over all T frames reads the INPUT gradients (the attention context)."""
+    reduces over all T frames reads the INPUT gradients (the attention context).
+    gate = (weight [1, K], bias | None): also returns the N = 1 projection of the SAME inputs (the gate layer, flowtron.py:760-761)
+    as (h, gates) -- computed from this projection's operand image where that exists."""
     mode = L.mfma_mode() if mode is None else mode
     xs = [x] if xs_extra is None else [x] + list(xs_extra)
     if reverse:
         rowmap = None
-    gx = LinearFn.apply(w_ih, b_ih + b_hh, L.ACT_NONE, mode, rowmap, fill, *xs)
     T, B = x.shape[0], x.shape[1]
+    gates = None
+    if gate is not None and linear_gate_fusable(mode, rowmap, xs, w_ih.shape[0]):
+        # gate = (weight [1, K], bias): the N = 1 projection over the same inputs rides on this projection's image (LinearGateFn)
+        gx, gates = LinearGateFn.apply(w_ih, b_ih + b_hh, gate[0], gate[1], mode, rowmap, fill, *xs)
+    else:
+        gx = LinearFn.apply(w_ih, b_ih + b_hh, L.ACT_NONE, mode, rowmap, fill, *xs)
+        if gate is not None:
+            gates = linear(xs, gate[0], gate[1], mode=mode)
     private = rowmap is not None and rowmap.T == T and rowmap.B == B and linear_uses_images(mode, T * B, w_ih.shape[0], xs)
-    return LSTMSeqFn.apply(gx, w_hh, lens, reverse, mode, rowmap, private)
+    h = LSTMSeqFn.apply(gx, w_hh, lens, reverse, mode, rowmap, private)
+    return h if gate is None else (h, gates)
 
 
 class BiLSTMSeqFn(torch.autograd.Function):

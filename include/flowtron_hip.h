@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 9
+#define FT_ABI_VERSION 10
 
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1, FT_F16 = 2 };
@@ -126,6 +126,10 @@ typedef struct {
      * *rows_dev - k_shift are not visited (k_shift = the row offset already applied to A for a one-step time shift). */
     const int32_t* rowmap; const int32_t* rows_dev;
     int compact, k_shift;
+    /* optional rank-1 epilogue term (ABI 10): C[row][col] += r1_row[row] * r1_col[col] in fp32, row = the OUTPUT row (after the
+     * row map), before the activation; both NULL = none; not with split-K.  The gate layer's input gradient dgate (x) w_gate rides
+     * on the decoder input projection's dX GEMM this way (flowtron.py:758-761: both read [h_att ; ctx]). */
+    const float* r1_row; const float* r1_col;
 } ft_gemm_img_args;
 size_t ft_bf16_image_bytes(int64_t rows, int64_t cols);
 int ft_bf16_image(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, void* stream);
@@ -157,6 +161,19 @@ int ft_bf16_image_rows_into(const float* src, int64_t ld, int64_t cap_rows, int6
                             int64_t fill_cols, const int32_t* rowmap, const int32_t* rows_dev, void* stream);
 int ft_bf16_image_rows_into_f16(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, int64_t dst_ld, int64_t col_off,
                                 int64_t fill_cols, const int32_t* rowmap, const int32_t* rows_dev, void* stream);
+/* N = 1 projection over a compact image (the gate layer LinearNorm(n_hidden + n_attn, 1), flowtron.py:668-669 / :760-761, reads the
+ * rows the decoder LSTM's input projection has just multiplied): y[rowmap[c]] = sum_k img[c][k] * op16(w[k]) + bias[0] for the compact
+ * rows c < *rows_dev; y = [T*B] rows of stride ldy; every padded frame of an utterance receives its separator's value.  The image
+ * must be zero from column K up to the next multiple of 8 (ft_bf16_image_rows / _into pad with zeros).
+ * _bwd: dw[k] += sum_c dy[rowmap[c]] img[c][k], db[0] += sum_c dy[rowmap[c]] (db may be NULL); dw / db ACCUMULATE: the caller zeroes. */
+int ft_img_gemv_rows(const void* img, int64_t ld, int K, const float* w, const float* bias, float* y, int64_t ldy,
+                     const int32_t* rowmap, const int32_t* rows_dev, const int32_t* lens, int T, int B, void* stream);
+int ft_img_gemv_rows_f16(const void* img, int64_t ld, int K, const float* w, const float* bias, float* y, int64_t ldy,
+                         const int32_t* rowmap, const int32_t* rows_dev, const int32_t* lens, int T, int B, void* stream);
+int ft_img_gemv_rows_bwd(const void* img, int64_t ld, int K, const float* dy, int64_t lddy, float* dw, float* db,
+                         const int32_t* rowmap, const int32_t* rows_dev, int64_t cap_rows, void* stream);
+int ft_img_gemv_rows_bwd_f16(const void* img, int64_t ld, int K, const float* dy, int64_t lddy, float* dw, float* db,
+                             const int32_t* rowmap, const int32_t* rows_dev, int64_t cap_rows, void* stream);
 /* rows (t, b) with t > lens[b] of the time-major matrix y [T*B][cols] (row stride ld): mode 0 = zero them, 1 = copy row
  * (lens[b], b) into them (a compact GEMM wrote only valid rows and the separator; consumers that walk every frame need the rest) */
 int ft_pad_rows_fill(float* y, int64_t ld, int cols, const int32_t* lens, int T, int B, int mode, void* stream);

@@ -142,6 +142,57 @@ def test_linear_over_two_inputs_as_one_gemm_over_a_concatenated_image(env, monke
             assert torch.equal(ya[ln + 1:, bi], ya[ln:ln + 1, bi].expand(T - ln - 1, -1))
 
 
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("K0,K1,N", [(1024, 640, 4096), (64, 44, 256)])
+def test_gate_layer_on_the_concatenated_image_of_the_decoder_input_projection(env, fmt, K0, K1, N):
+    """LinearGateFn (flowtron.py:758-761: the decoder LSTM's input projection and the gate layer both read [h_att ; ctx]): the
+    projection as LinearFn's concatenated-image GEMM, the N = 1 gate projection as a GEMV over the SAME image (ft_img_gemv_rows),
+    its input gradient as a rank-1 epilogue term of the projection's dX GEMMs, its weight gradient as a GEMV^T -- against
+    LinearFn + a separate two-input linear (the path it replaces) and against fp64 with the same operand rounding."""
+    L, ops = env
+    T, B = 23, 7
+    torch.manual_seed(K0 + 7 * fmt)
+    lens_l = [23, 23, 17, 9, 4, 2, 1]
+    lens = torch.tensor(lens_l, dtype=torch.int32, device="cuda")
+    x0, x1 = torch.randn(T, B, K0, device="cuda"), torch.randn(T, B, K1, device="cuda")
+    act = torch.arange(T, device="cuda")[:, None] < lens[None, :]
+    x0 = x0 * act[..., None]                           # h_att of a padded frame is zero; ctx of all padded frames of b is the same row
+    for bi, ln in enumerate(lens_l):
+        if ln < T:
+            x1[ln:, bi] = x1[ln, bi]
+    W, b = torch.randn(N, K0 + K1, device="cuda") * 0.05, torch.randn(N, device="cuda")
+    Wg, bg = torch.randn(1, K0 + K1, device="cuda") * 0.1, torch.randn(1, device="cuda")
+    go = torch.randn(T, B, N, device="cuda") * act[..., None]
+    gg = torch.randn(T, B, 1, device="cuda") * act[..., None]
+    rm = ops.RowMap(lens, T, B)
+    assert ops.linear_gate_fusable(fmt, rm, [x0, x1], N)
+    d = [t.clone().requires_grad_(True) for t in (x0, x1, W, b, Wg, bg)]
+    y, gate = ops.LinearGateFn.apply(d[2], d[3], d[4], d[5], fmt, rm, "y+dx", d[0], d[1])
+    torch.autograd.backward([y, gate], [go, gg])
+    e = [t.clone().requires_grad_(True) for t in (x0, x1, W, b, Wg, bg)]
+    y2 = ops.LinearFn.apply(e[2], e[3], L.ACT_NONE, fmt, rm, "y+dx", e[0], e[1])
+    gate2 = ops.linear([e[0], e[1]], e[4], e[5], mode=fmt)
+    torch.autograd.backward([y2, gate2], [go, gg])
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)                          # the same GEMM over the same image
+    assert float((gate.detach() - gate2.detach()).abs().max()) <= 2e-5 * float(gate2.detach().abs().max())
+    for a_, b_, name in zip(d, e, "x0 x1 W b Wg bg".split()):
+        # (the separate linear rounds dgate -- and wg for the input gradients -- to 16-bit GEMM operands; the GEMV^T and the rank-1
+        # epilogue term keep them in fp32: the fp64 comparisons below are the yardstick)
+        tol = (8e-3 if fmt == 1 else 1e-3) if name == "Wg" else (2e-3 if fmt == 1 else 3e-4) if name in ("x0", "x1") else 1e-4
+        assert float((a_.grad - b_.grad).norm()) <= tol * float(b_.grad.norm()) + 1e-12, name
+    dt = torch.bfloat16 if fmt == 1 else torch.float16
+    xr = torch.cat([x0, x1], 2).to(dt).double()
+    ref = xr @ Wg.to(dt).double().t() + bg.double()
+    assert float((gate.detach().double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())      # every frame: padded ones repeat the separator
+    dWg = torch.einsum("tbo,tbk->ok", gg.double(), xr)
+    assert float((d[4].grad.double() - dWg).norm()) <= 1e-5 * float(dWg.norm())
+    assert abs(float(d[5].grad) - float(gg.double().sum())) <= 1e-5 * float(gg.abs().sum())
+    dxr = ((go.to(dt).double() @ W.to(dt).double()) + gg.double() * Wg.double()) * act[..., None]
+    assert float((torch.cat([d[0].grad, d[1].grad], 2).double() - dxr).norm()) <= 2e-4 * float(dxr.norm())
+    assert float(d[0].grad[~act].abs().max()) == 0.0 and float(d[1].grad[~act].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("act_name", ["tanh", "relu", "sigmoid"])
 def test_activation_backward_inside_the_image_pass_is_bit_identical_to_the_two_pass_path(env, monkeypatch, act_name):
     """ft_bf16_image_rows_act_bwd (dense layers of the decoder tail, flowtron.py:453-464): dpre = dy act'(pre) formed inside the
