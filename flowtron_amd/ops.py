@@ -404,6 +404,7 @@ class LinearFn(torch.autograd.Function):
         return (dW, db, None, None, None, None, *dxs)
 
 
+_PERSIST_FWD_DEFAULT = "ksplit"
 _GATE_ON_CAT = _os.environ.get("FLOWTRON_GATE_ON_CAT", "1") != "0"   # the gate layer on the decoder input projection's concatenated image
 
 
@@ -790,6 +791,10 @@ class LSTMSeqFn(torch.autograd.Function):
         cell = torch.empty(T, B, H, device=gx.device, dtype=torch.float32)
         ng = lstm_persist_groups(B, H, reverse, mode, gx.device)
         if ng:
+            # default (1): FLOWTRON_LSTM_PERSIST_FWD = ms -> transport 31, the M-split kernel (every wave a full-K slice of the gate rows,
+            # cell update in registers on all four waves; the same sums in the same order), ksplit -> transport 1 (round 2-3 kernel)
+            if ng == 1 and _os.environ.get("FLOWTRON_LSTM_PERSIST_FWD", _PERSIST_FWD_DEFAULT) == "ms":
+                ng = 31
             st = _persist_watch(gx.device)
             work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=gx.device, dtype=torch.uint8)
             L.check(L.op16("ft_lstm_persist_fwd", mode)(L.ptr(gx), L.ptr(w_hh), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),

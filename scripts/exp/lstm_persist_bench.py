@@ -66,6 +66,10 @@ print("stamps of transport", os.environ.get("PROF_NG", "11"))
 for wv in range(4):
     top, swp, bar, pub, npass = (pr[:, wv, k] for k in range(5))
     step = (top[1:] - top[:-1]).mean() * 10
+    if os.environ.get("PROF_NG", "11") == "31":      # M-split kernel: top -> gathered + LDS written | barrier + LDS reads + MFMAs | cell update -> published | -> next top
+        print("wave %d (ng 31): step %.0f ns | top->gathered %.0f | stores + barrier %.0f | LDS reads + mfma %.0f | epilogue->publish %.0f | publish->next top %.0f"
+              % (wv, step, (swp - top).mean() * 10, (npass - swp).mean() * 10, (bar - npass).mean() * 10, (pub - bar).mean() * 10, (top[1:] - pub[:-1]).mean() * 10), flush=True)
+        continue
     print("wave %d: step %.0f ns | sweep+mfma %.0f | reduce+barrier %.0f | epilogue->publish %.0f | publish->next top %.0f | poll passes %.2f"
           % (wv, step, ((swp - top).mean()) * 10, ((bar - swp).mean()) * 10, ((pub - bar).mean()) * 10 if wv < 2 else 0.0,
              ((top[1:] - (pub if wv < 2 else bar)[:-1]).mean()) * 10, npass.mean()), flush=True)
