@@ -97,12 +97,17 @@ class Encoder(nn.Module):
 
     def _run(self, x, lens):
         """x [L,B,C] time-major, lens int32 [B] -> [L,B,C]."""
+        drawn = None
+        if self.dropout_masks is None and self.training:
+            # F.dropout(p=0.5) keep-masks (flowtron.py:502) of ALL conv layers in one draw: two kernels per step instead of four per layer
+            # (every layer keeps the [L,B,C] shape: the convolutions are C -> C)
+            drawn = torch.empty((len(self.convolutions),) + tuple(x.shape), device=x.device, dtype=x.dtype).bernoulli_(0.5).mul_(2.0)
         for i, (conv, norm) in enumerate(self.convolutions):
             keep = None
             if self.dropout_masks is not None:
                 keep = self.dropout_masks[i]
-            elif self.training:
-                keep = (torch.rand_like(x) >= 0.5).to(x.dtype) * 2.0      # F.dropout(p=0.5) keep-mask, flowtron.py:502
+            elif drawn is not None:
+                keep = drawn[i]
             x = ops.conv_norm_relu(x, lens, conv.conv.weight, conv.conv.bias, norm.weight, norm.bias, keep, norm.eps)
         p = self.lstm
         # both directions in one launch chain when the fragment path applies (ops.bilstm_layer)
