@@ -1086,7 +1086,7 @@ def test_rowmap_and_compact_image(env, fmt):
 
 
 @pytest.mark.parametrize("act", [0, 1])
-def test_compact_linear_equals_padded_linear_on_valid_rows(env, act):
+def test_compact_linear_equals_padded_linear_on_valid_rows(env, monkeypatch, act):
     """LinearFn with a RowMap (valid rows only, output rows scattered back) against the same call over all padded rows, bf16
     operands: forward outputs and input gradients of VALID rows are bit-identical (same per-row k order), weight / bias
     gradients agree to summation order -- provided the output gradient of padded rows is zero, as the masked losses make it;
@@ -1104,21 +1104,29 @@ def test_compact_linear_equals_padded_linear_on_valid_rows(env, act):
     b = torch.randn(N, device="cuda")
     go = torch.randn(T, B, N, device="cuda") * m[..., None]
     res = []
-    for rm in (None, ops.RowMap(lens32, T, B)):
+    # the compact path with the two K pieces (FLOWTRON_GEMM_CAT=0) keeps the padded path's per-row k order: bit-identical; with the
+    # concatenated image (the default since round 4: ONE K loop over K1 + K2) the same products meet in another order
+    for rm, cat in ((None, True), (ops.RowMap(lens32, T, B), False), (ops.RowMap(lens32, T, B), True)):
+        monkeypatch.setattr(ops, "_CAT_IMAGES", cat)
         d = [t.clone().requires_grad_(True) for t in (x1, x2, W, b)]
         out = ops.linear([d[0], d[1]], d[2], d[3], act=act, mode=1, rowmap=rm, fill="y+dx")
         out.backward(go)
         torch.cuda.synchronize()
         res.append([out.detach()] + [t.grad for t in d])
-    (y0, dx10, dx20, dW0, db0), (y1, dx11, dx21, dW1, db1) = res
+    (y0, dx10, dx20, dW0, db0), (y1, dx11, dx21, dW1, db1), (y2, dx12, dx22, dW2, db2) = res
     assert torch.equal(y0, y1)                                               # valid rows bit-identical, padded rows reproduced
     assert torch.equal(dx10[m], dx11[m]) and torch.equal(dx20[m], dx21[m])
     assert float(dx11[~m].abs().max()) == 0.0 and float(dx21[~m].abs().max()) == 0.0
     assert rel(dW1, dW0) < 2e-6 and rel(db1, db0) < 2e-6
+    assert float((y2 - y0).abs().max()) <= 4e-6 * float(y0.abs().max())     # concatenated image: equal to fp32 summation order
+    assert torch.equal(dx12[m], dx10[m]) and torch.equal(dx22[m], dx20[m])   # (dX never sums over the pieces)
+    assert float(dx12[~m].abs().max()) == 0.0 and float(dx22[~m].abs().max()) == 0.0
+    assert rel(dW2, dW0) < 2e-6 and rel(db2, db0) < 2e-6
+    monkeypatch.setattr(ops, "_CAT_IMAGES", True)
     # unwritten rows stay untouched without a fill: poison them through the allocator and look
     d = [t.clone().requires_grad_(True) for t in (x1, x2, W, b)]
     out = ops.linear([d[0], d[1]], d[2], d[3], act=act, mode=1, rowmap=ops.RowMap(lens32, T, B), fill="")
-    assert torch.equal(out[m], y0[m])
+    assert torch.equal(out[m], y2[m])                                        # (the concatenated-image path again)
 
 
 @pytest.mark.parametrize("H", [128, 1024])
