@@ -31,6 +31,22 @@ __global__ void make_wfrag_fwd(const float* __restrict__ w, unsigned short* __re
         out[i] = f2op16(w[row * H + c * 32 + kg * 8 + e]);
     }
 }
+// the same with the four GATES of a unit adjacent in the tile (column n = li: unit li >> 2, gate li & 3) -- lstm_persist_fwd_k: the
+// epilogue then fetches the four gate partials of its element with ONE 16-byte LDS read per wave partial instead of four reads
+//   block jb, chunk c, lane (kg,li), e  <-  W_hh[(li&3)*H + jb*4 + (li>>2)][c*32 + kg*8 + e]
+__global__ void make_wfrag_fwd_ug(const float* __restrict__ w, unsigned short* __restrict__ out, int H, WfragAux aux) {
+    wfrag_aux(aux);
+    const size_t total = (size_t)4 * H * H;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const size_t rest = i >> 9;
+        const int nchunk = H >> 5;
+        const int c = (int)(rest % nchunk), jb = (int)(rest / nchunk);
+        const int li = lane & 15, kg = lane >> 4;
+        const size_t row = (size_t)(li & 3) * H + jb * 4 + (li >> 2);
+        out[i] = f2op16(w[row * H + c * 32 + kg * 8 + e]);
+    }
+}
 // W_hh [4H][H] fp32 -> backward fragment image [H/16][4H/32][64][8] bf16:
 //   tile jt, chunk c (over r = 0..4H), lane (kg,li), e  <-  W_hh[c*32 + kg*8 + e][jt*16 + li]
 __global__ void make_wfrag_bwd(const float* __restrict__ w, unsigned short* __restrict__ out, int H, WfragAux aux) {

@@ -225,8 +225,9 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
     static_assert(NE == 128, "one epilogue element per thread of waves 0-1");
     // LDS: 4-wave reduce (double buffered) | SB steps of gx rows [s][gate][e] | 2 steps of outputs [parity][y,i,f,g,o,c][e]
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float (*red)[4][TPC][RPGP][17] = reinterpret_cast<float (*)[4][TPC][RPGP][17]>(smem);
-    float* gxs = smem + 2 * 4 * TPC * RPGP * 17;
+    // (rows of 16 gate columns at a 20-float pitch: 16-byte aligned for the epilogue's f32x4 reads, column n = unit * 4 + gate)
+    float (*red)[4][TPC][RPGP][20] = reinterpret_cast<float (*)[4][TPC][RPGP][20]>(smem);
+    float* gxs = smem + 2 * 4 * TPC * RPGP * 20;
     float* outs = gxs + SB * 4 * NE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -429,10 +430,13 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
             }
             const float* gxr = gxs + (t % SB) * 4 * NE + tid;
             float pre[4];
+            {
+                // the four gates of (unit ul, row ebl) are adjacent (make_wfrag_fwd_ug): one 16-byte read per wave partial; the sum
+                // keeps its order (wave 0 + 1 + 2 + 3, then gx)
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(&red[rb][0][j][ebl][ul * 4]), p1 = *reinterpret_cast<const f32x4*>(&red[rb][1][j][ebl][ul * 4]);
+                const f32x4 p2 = *reinterpret_cast<const f32x4*>(&red[rb][2][j][ebl][ul * 4]), p3 = *reinterpret_cast<const f32x4*>(&red[rb][3][j][ebl][ul * 4]);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = g * 4 + ul;
-                pre[g] = red[rb][0][j][ebl][n] + red[rb][1][j][ebl][n] + red[rb][2][j][ebl][n] + red[rb][3][j][ebl][n] + gxr[g * NE];
+                for (int g = 0; g < 4; ++g) pre[g] = p0[g] + p1[g] + p2[g] + p3[g] + gxr[g * NE];
             }
             float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f;
             if (active) {
@@ -1508,7 +1512,7 @@ extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh
     // tags = 0: no epoch matches (epochs start at 1); bare: sentinels.  Preset by the fragment kernel (lstm_images.h: WfragAux)
     const WfragAux aux{reinterpret_cast<uint4*>(hgran), (unsigned long)(gran_bytes / 16), bare ? 0xFFFFFFFFu : 0u, census};
     if (msform) hipLaunchKernelGGL(make_wfrag_ms, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H, aux);
-    else hipLaunchKernelGGL(make_wfrag_fwd, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H, aux);
+    else hipLaunchKernelGGL(make_wfrag_fwd_ug, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H, aux);
     PersistP p{gx, lens, y, (long)ldy, gates, cell, wfrag, hgran, status, census, T, B, 100000000L / 2, g_persist_prof};   // 0.5 s
     if (msform) {
         // LDS: 2 parities x 4 rows x (2 H + 16) bytes of state + SB steps of gx rows + 2 parities of saved tensors
@@ -1523,8 +1527,8 @@ extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh
         FT_CHECK_LAUNCH();
         return FT_OK;
     }
-    // dynamic LDS: reduce buffers (2*4*TPC*RPGP*17 = 2*4*32*17 floats) + SB staged gx rows + 2 output rows
-    const size_t lds = sizeof(float) * ((size_t)2 * 4 * 32 * 17 + (size_t)SB * 4 * 128 + (size_t)2 * 6 * 128);
+    // dynamic LDS: reduce buffers (2*4*TPC*RPGP*20 = 2*4*32*20 floats) + SB staged gx rows + 2 output rows
+    const size_t lds = sizeof(float) * ((size_t)2 * 4 * 32 * 20 + (size_t)SB * 4 * 128 + (size_t)2 * 6 * 128);
     auto launch = [&](auto kern) -> int {
         FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(NCU), dim3(256), lds, st, p);
