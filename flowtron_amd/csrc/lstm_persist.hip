@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
     float* gxs = smem + 2 * 4 * TPC * RPGP * 20;
     float* outs = gxs + SB * 4 * NE;
 
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
     int grp, q;
@@ -347,6 +348,12 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
         f32x4 acc[TPC];
 #pragma unroll
         for (int j = 0; j < TPC; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (WAGPR) {
+            // zeroed HERE, in front of the gather: the compiler otherwise sinks each zeroing move to right in front of the inline-asm MFMA
+            // that first reads the register -- a VALU write -> MFMA SrcC hazard it does not pad for an asm statement
+#pragma unroll
+            for (int j = 0; j < TPC; ++j) asm volatile("" : "+v"(acc[j]));
+        }
         if (t > 0) {
             // ---- sweep: this wave's 8 chunks of h_{t-1} (epoch t) straight into A fragments.  Every pass re-reads ALL chunks
             // that have not shown the epoch yet (one L2 round trip for the lot).  The poll loop holds loads and tag compares
@@ -387,16 +394,46 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
                 }
             }
             if (dead) break;
+            if constexpr (WAGPR) {
+                // chunk i of this wave = load group i / CPL, member i % CPL.  The four moves that assemble a chunk's A operand (payload
+                // dwords of two loads, shifted into the MFMA row positions by DPP) are issued one per MFMA gap of the PREVIOUS chunk,
+                // into the other of two operand buffers: in a block of their own they cost the one-wave-per-SIMD kernel their whole
+                // issue time (4 moves + wait states per chunk, ~0.1 us per step)
+                auto operand_word = [&](int i, int c) -> unsigned {
+                    const u32x4 pl = payload<BARE>(ld[i / CPL]);
+                    switch (i % CPL) {
+                        case 0: {       // (an explicit move IN this slot: a plain copy is materialised by the compiler right in front of the
+                            unsigned r; //  consuming asm MFMA -- VALU write -> MFMA source read without the two wait states: wrong operands)
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(pl[c]));
+                            return r;
+                        }
+                        case 1: return row_shl<RPGP & 15>(pl[c]);
+                        case 2: return row_shl<(2 * RPGP) & 15>(pl[c]);
+                        default: return row_shl<(3 * RPGP) & 15>(pl[c]);
+                    }
+                };
+                u32x4 au[3];                                                      // three buffers: the one being assembled was last read a whole
+#pragma unroll                                                                    // chunk (8 MFMAs) ago
+                for (int c = 0; c < 4; ++c) au[0][c] = operand_word(0, c);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {          // chunk i of this wave = load group i / CPL, member i % CPL
-                const u32x4 au = member<RPGP>(payload<BARE>(ld[i / CPL]), i % CPL);
-                if constexpr (WAGPR) {
-                    const u32x4 bu0 = __builtin_bit_cast(u32x4, w[0][i]);
-                    mfma16_bagpr_nop(acc[0], au, bu0);                             // (two wait states behind the DPP shifts that wrote `au`)
+                for (int i = 0; i < 8; ++i) {
 #pragma unroll
-                    for (int j = 1; j < TPC; ++j) mfma16_bagpr(acc[j], au, __builtin_bit_cast(u32x4, w[j][i]));
-                } else {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, au);
+                    for (int j = 0; j < TPC; ++j) {
+                        if (i == 0 && j == 0) mfma16_bagpr_nop(acc[0], au[0], __builtin_bit_cast(u32x4, w[0][0]));   // (two wait states behind the moves above)
+                        else mfma16_bagpr(acc[j], au[i % 3], __builtin_bit_cast(u32x4, w[j][i]));
+                        if (i + 1 < 8 && j < 4) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            au[(i + 1) % 3][j] = operand_word(i + 1, j);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, member<RPGP>(payload<BARE>(ld[i / CPL]), i % CPL));
 #pragma unroll
                     for (int j = 0; j < TPC; ++j) acc[j] = mfma16(a, w[j][i], acc[j]);
                 }
@@ -1378,37 +1415,47 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
             // tile, lane offset in the VGPR, consumer / half offsets scalar (raw buffer store: the compiler owns its data hazards)
             const unsigned tagw = (unsigned)(n >> 1) & 1u;
             const __amdgpu_buffer_rsrc_t wr = wrs[n & 1];
-            auto group = [&](int tq, f32x4 (&acc)[4]) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) mfma16_bagpr_first(acc[jj], a[0], w[tq * 4 + jj][0]);
-#pragma unroll
-                for (int g = 1; g < 4; ++g)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) mfma16_bagpr(acc[jj], a[g], w[tq * 4 + jj][g]);
+            // One MFMA and then ONE filler: the tag operations and the store of the PREVIOUS group's tiles are handed out one per MFMA gap
+            // (a 16x16x32 MFMA occupies the pipe for ~17 cycles, about four issue slots: a single VALU / VMEM instruction in the gap is
+            // free, a dozen of them in a row behind a group stall the pipe of a one-wave-per-SIMD kernel for their whole issue time).
+            // Filler m = 4 f + s of a group: tile f of the previous group -- s = 0: tag word 0, s = 1: tag word 3 (v_and_or_b32 in
+            // place: the accumulator is dead), s = 2: nothing, s = 3: the 16-byte store.  Tile f's last MFMA lies 4 + 3 f MFMAs back.
+            auto tag_word = [&](f32x4& v, int r) {
+                float x = v[r];
+                asm volatile("v_and_or_b32 %0, %0, -2, %1" : "+v"(x) : "v"(tagw));
+                v[r] = x;
             };
-            auto publish = [&](int tq, const f32x4 (&acc)[4]) {
-                // no branch around the stores (MFMAs and stores stay in ONE scheduling region): lanes kg != 0 hold the padding rows of
-                // the D tile and carry an offset beyond the descriptor's range -- the hardware drops their stores
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int j = tq * 4 + jj;
-                    u32x4 v;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = tagged(r) ? ((__float_as_uint(acc[jj][r]) & ~1u) | tagw) : __float_as_uint(acc[jj][r]);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, wr, wvoff, wsoff_w + (j >> 1) * (CPG * UPC * RPGP * 4) + (j & 1) * (16 * RPGP * 4), 0);
-                }
+            auto store_tile = [&](int j, const f32x4& acc) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), wr, wvoff,
+                                                       wsoff_w + (j >> 1) * (CPG * UPC * RPGP * 4) + (j & 1) * (16 * RPGP * 4), 0);
+                __builtin_amdgcn_sched_barrier(0);
             };
-            // software pipeline: the MFMAs of group tq + 1 are issued BEFORE the stores of group tq
+            auto filler = [&](int m, int ptq, f32x4 (&pacc)[4]) {
+                const int f = m >> 2, sl = m & 3;
+                if (sl == 0) { if (tagged(0)) tag_word(pacc[f], 0); if (NTAG == 4) tag_word(pacc[f], 1); }
+                else if (sl == 1) { if (tagged(3)) tag_word(pacc[f], 3); if (NTAG == 4) tag_word(pacc[f], 2); }
+                else if (sl == 3) store_tile(ptq * 4 + f, pacc[f]);     // (slot 3: behind the group's four first-MFMAs -- in slot 2 the allocator
+                                                                         // handed the stored tile's registers to the very next MFMA's result)
+            };
+            auto group = [&](int tq, f32x4 (&acc)[4], int ptq, f32x4 (&pacc)[4]) {          // ptq < 0: no previous group to publish
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        if (g == 0) mfma16_bagpr_first(acc[jj], a[0], w[tq * 4 + jj][0]);
+                        else mfma16_bagpr(acc[jj], a[g], w[tq * 4 + jj][g]);
+                        if (ptq >= 0) filler(g * 4 + jj, ptq, pacc);
+                    }
+            };
             f32x4 accA[4], accB[4];
-            group(0, accA);
-            group(1, accB);
-            publish(0, accA);
-            group(2, accA);
-            publish(1, accB);
-            group(3, accB);
-            publish(2, accA);
+            group(0, accA, -1, accB);
+            group(1, accB, 0, accA);
+            group(2, accA, 1, accB);
+            group(3, accB, 2, accA);
             asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");           // (the last group's results: MFMA -> VALU read wait states)
-            publish(3, accB);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) filler(m, 3, accB);
         }
         if (prof) st3 = wall_clock64();
         if (prof && n < 1024) {
