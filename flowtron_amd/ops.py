@@ -793,8 +793,11 @@ class LSTMSeqFn(torch.autograd.Function):
         if ng:
             # default (1): FLOWTRON_LSTM_PERSIST_FWD = ms -> transport 31, the M-split kernel (every wave a full-K slice of the gate rows,
             # cell update in registers on all four waves; the same sums in the same order), ksplit -> transport 1 (round 2-3 kernel)
-            if ng == 1 and _os.environ.get("FLOWTRON_LSTM_PERSIST_FWD", _PERSIST_FWD_DEFAULT) == "ms":
+            fwd_form = _os.environ.get("FLOWTRON_LSTM_PERSIST_FWD", _PERSIST_FWD_DEFAULT)
+            if ng == 1 and fwd_form == "ms":
                 ng = 31
+            elif ng == 1 and fwd_form == "bare":
+                ng = 11                              # the K-split kernel with bare operand pairs (sentinel protocol, half the gather bytes)
             st = _persist_watch(gx.device)
             work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=gx.device, dtype=torch.uint8)
             L.check(L.op16("ft_lstm_persist_fwd", mode)(L.ptr(gx), L.ptr(w_hh), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
