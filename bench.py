@@ -200,6 +200,8 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
     ng = int(os.environ.get("FLOWTRON_LSTM_PERSIST", "1"))
     bwd_form = os.environ.get("FLOWTRON_LSTM_PERSIST_BWD", "rs")                                              # as ops.LSTMSeqFn.backward
     ng_bwd = ng if ng != 1 else (21 if bwd_form == "rs" else 11 if bwd_form != "tagged" else 1)
+    fwd_form = os.environ.get("FLOWTRON_LSTM_PERSIST_FWD", ops._PERSIST_FWD_DEFAULT)                          # as ops.LSTMSeqFn.forward
+    ng_fwd = ng if ng != 1 else (31 if fwd_form == "ms" else 11 if fwd_form == "bare" else 1)
     lib = L.lib()
     # the backward recurrence as the training step launches it (ops.LSTMSeqFn.backward, FLOWTRON_LSTM_PERSIST_IMG=1): the output
     # waves leave the compact 16-bit image of dgates + the bias column sums, no fp32 dgx
@@ -208,7 +210,7 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
     img_only = os.environ.get("FLOWTRON_LSTM_PERSIST_IMG", "1") == "1"
     runs = {
         "lstm_persist_fwd_k": lambda: L.check(L.op16("ft_lstm_persist_fwd", mode)(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
-                                                                        L.ptr(wp), L.ptr(st), T, B, H, ng, L.stream()), "persist fwd"),
+                                                                        L.ptr(wp), L.ptr(st), T, B, H, ng_fwd, L.stream()), "persist fwd"),
         "lstm_persist_bwd_k": (lambda: L.check(L.op16("ft_lstm_persist_bwd_img", mode)(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), None,
                                                                         L.ptr(wp), L.ptr(st), T, B, H, ng_bwd, L.ptr(dimg.buf), dimg.ld,
                                                                         dimg.buf.numel() // (2 * dimg.ld), L.ptr(dimg.colsum), L.stream()), "persist bwd img"))
@@ -240,8 +242,9 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
     #   one same-XCD L2 hand-off per step (publish -> every consumer sees the tag): profiles/r02_handoff_hops.json;
     #   the MFMAs one wave must issue back to back per step (64 x v_mfma_f32_16x16x32: ~17 cycles each from one wave per SIMD,
     #   MI355X_MICROARCH.md cycle table, 2.4 GHz);
-    #   the hand-off bytes every CU pulls from its XCD's L2 per step (forward: 16 KB of tagged granules; backward: 32 KB of bare
-    #   operand pairs, 64 KB with tagged granules; x 256 CUs) at the measured L2 peak of 34.5 TB/s.
+    #   the hand-off bytes every CU pulls from its XCD's L2 per step (forward: 8 KB of bare operand pairs, 16 KB with tagged granules;
+    #   backward: 16 + 16 KB of fp32 partials in reduce-scatter form, 32 / 64 KB for the all-gather kernels; x 256 CUs) at the measured
+    #   L2 peak of 34.5 TB/s.
     # The LDS reduce, the barrier, the cell update and the skew between the 32 CUs of a group are what `frac` leaves.
     mfma_us = 0.47        # 64 back-to-back v_mfma_f32_16x16x32 of one wave per SIMD: 7.3 ns each, measured (scripts/exp/mfma_rate_probe.hip)
     # algorithmic HBM bytes per valid row: backward reads saved gates, cell, dy (fp32) and writes dgates -- as the 16-bit compact
@@ -251,7 +254,7 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
     # reduce-scatter of fp32 partials (transport 21: 16 KB gathered + 16 KB published) or the all-gather of dgates (32 / 64 KB)
     rs_form = ng_bwd == 21
     for name, per_row, repl, gran_kb in (("lstm_persist_bwd_k", 4 * (4 * H + H + H) + bwd_out, "lstm_bwd_step_bf16", 32 if ng_bwd > 10 else 64),
-                                         ("lstm_persist_fwd_k", 4 * (4 * H + H + 4 * H + H), "lstm_fwd_step", 8 if ng > 10 else 16)):
+                                         ("lstm_persist_fwd_k", 4 * (4 * H + H + 4 * H + H), "lstm_fwd_step", 8 if ng_fwd in (11, 19, 18, 14, 12) else 16)):
         nbytes = 2 * 4 * H * H + rows * per_row
         ach = nbytes / (us[name] * 1e-6) / 1e9
         per_step = us[name] / T
@@ -268,6 +271,7 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
                      "hbm": {"achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                              "bytes_per_launch": nbytes, "traffic": pmc_traffic(kname)},
                      "mfma_busy_frac_pmc": mb, "pmc_round": mb_src,
+                     "transport": ng_bwd if name.endswith("bwd_k") else ng_fwd,
                      "entry_point": "ft_lstm_persist_bwd_img (image only)" if (name.endswith("bwd_k") and img_only) else None,
                      "note": "one launch = one whole sequence of T dependent steps, W_hh resident in registers; neither the HBM nor the "
                              "MFMA roof binds it (both fractions are reported beside the floor): the figure of merit is us_per_step "

@@ -404,7 +404,7 @@ class LinearFn(torch.autograd.Function):
         return (dW, db, None, None, None, None, *dxs)
 
 
-_PERSIST_FWD_DEFAULT = "ksplit"
+_PERSIST_FWD_DEFAULT = "bare"
 _GATE_ON_CAT = _os.environ.get("FLOWTRON_GATE_ON_CAT", "1") != "0"   # the gate layer on the decoder input projection's concatenated image
 
 
@@ -791,8 +791,9 @@ class LSTMSeqFn(torch.autograd.Function):
         cell = torch.empty(T, B, H, device=gx.device, dtype=torch.float32)
         ng = lstm_persist_groups(B, H, reverse, mode, gx.device)
         if ng:
-            # default (1): FLOWTRON_LSTM_PERSIST_FWD = ms -> transport 31, the M-split kernel (every wave a full-K slice of the gate rows,
-            # cell update in registers on all four waves; the same sums in the same order), ksplit -> transport 1 (round 2-3 kernel)
+            # FLOWTRON_LSTM_PERSIST = 1 (XCD-local): FLOWTRON_LSTM_PERSIST_FWD = bare (default since the end of round 4) -> transport 11, the
+            # K-split kernel with bare operand pairs (half the gather bytes; 1.84 against 1.87 us per step once the operand moves sit in
+            # the MFMA gaps), ksplit -> transport 1 (tagged granules), ms -> transport 31 (the M-split kernel).  All bit-identical.
             fwd_form = _os.environ.get("FLOWTRON_LSTM_PERSIST_FWD", _PERSIST_FWD_DEFAULT)
             if ng == 1 and fwd_form == "ms":
                 ng = 31
