@@ -287,10 +287,30 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
     const int eh = (wave & 1) * 64 + lane;                       // burst: wave w serves elements 64 (w & 1) + lane
     const int hb = b0 + eh / UPC, hu = q * UPC + eh % UPC;
     const bool hvalid = hb < B;
+    // (RPGP == 4: 1 KiB pieces -- global_load_lds_dwordx4, 16 bytes per lane, eight lanes per 128-byte row piece: one piece = two gates of
+    //  one step for the group's four rows; 16 pieces per wave and burst instead of 64 dword pieces: a piece costs 60-185 cycles of issue
+    //  time whatever its size.  Piece c = 4 kk + wave: step c >> 1, gates 2 (c & 1) + (lane >> 5); lane -> row (lane & 31) >> 3, units 4 (lane & 7))
+    const int pr = lane >> 5, pb = (lane & 31) >> 3, pu = 4 * (lane & 7);
+    const bool pvalid = b0 + pb < B;
     auto burst = [&](int t) {                                    // t % SB == 0: gx rows of steps [t, t + SB)
         __syncthreads();
         const int nst = (tg - t) < SB ? (tg - t) : SB;
-        if (hvalid) {
+        if constexpr (RPGP == 4) {
+            if (pvalid) {
+                const float* src0 = p.gx + ((size_t)t * B + b0 + pb) * 4 * PH + (size_t)pr * PH + q * UPC + pu;
+                const unsigned dst0 = (unsigned)(size_t)(lds_void*)gxs;
+#pragma unroll
+                for (int kk = 0; kk < SB / 2; ++kk) {
+                    const int c = 4 * kk + wu, st = c >> 1, h = c & 1;
+                    if (st < nst) {
+                        unsigned keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "v"(src0 + (size_t)st * B * 4 * PH + (size_t)(2 * h) * PH),
+                                       "s"(dst0 + (unsigned)((st * 4 + 2 * h) * NE * 4)) : "memory");
+                    }
+                }
+            }
+        } else if (hvalid) {
             const float* src0 = p.gx + ((size_t)t * B + hb) * 4 * PH + hu;
             const unsigned dst0 = (unsigned)(size_t)(lds_void*)gxs + (unsigned)(wu & 1) * 256u;
 #pragma unroll
@@ -1174,14 +1194,13 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
     constexpr int NT = PH / 16 / 4;                // column tiles per wave: 16
     static_assert(UPC == 32 && RPGP == 4 && NE == 128, "built for group == XCD: 32 CUs x 32 units, 4 batch rows");
     // LDS: gather sums [8 = wave x half][32 units][4 rows] | dgates operands [4 gates][16 A-tile rows][32 units] 16-bit (rows >= RPGP
-    // zero for good: every lane reads its fragment without a branch) | RING steps in [slot][gates x4, dy][e] | RING cells [slot][e] |
+    // zero for good: every lane reads its fragment without a branch) | RING steps in [slot][gates x4, dy, previous cell][e] |
     // 2 steps out [parity][4][e]
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* gsum = smem;                                             // 8 * 128 floats
     unsigned* daop = reinterpret_cast<unsigned*>(smem + 8 * NE);    // 4 * 16 * 16 dwords (pairs of 16-bit operands)
-    float* ins = smem + 8 * NE + 1024;
-    float* cells = ins + RING * 5 * NE;
-    float* outs = cells + RING * NE;
+    float* ins = smem + 8 * NE + 1024;                              // ring: [slot][gates x4, dy, cell of the step before][e]
+    float* outs = ins + RING * 6 * NE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
@@ -1244,20 +1263,38 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
     const int eh = (wave & 1) * 64 + lane;
     const int hb = b0 + eh / UPC, hu = q * UPC + eh % UPC;
     const bool hvalid = hb < B;
-    const unsigned ins0 = (unsigned)(size_t)(lds_void*)ins + (unsigned)(wu & 1) * 256u;
-    const unsigned cells0 = (unsigned)(size_t)(lds_void*)cells + (unsigned)(wu & 1) * 256u;
+    // Ring fill: a slot is 6 rows x 128 floats = three 1 KiB LDS-DMA pieces (global_load_lds_dwordx4: 16 bytes per lane, eight lanes per
+    // 128-byte row piece of one batch row) instead of twelve 256-byte ones -- a piece costs 60-185 cycles of issue time whatever its
+    // size, and the two output waves that issue them gate the step's second barrier.  Wave 2 moves the gate rows (pieces 0, 1), wave 3
+    // the dy row and the previous step's cell row (piece 2).  Piece k = rows 2k, 2k + 1; lane -> row 2k + (lane >> 5), batch row
+    // (lane & 31) >> 3, units 4 (lane & 7) .. + 3.  (16-byte alignment of dy rows is checked by the launcher: else the dword path.)
+    const int pr = lane >> 5, pb = (lane & 31) >> 3, pu = 4 * (lane & 7);
+    const bool pvalid = b0 + pb < B;
+    const unsigned ring0 = (unsigned)(size_t)(lds_void*)ins;
+    auto dma16 = [&](const float* src, unsigned lds_addr) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"((unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr)) : "memory");
+    };
     auto prefetch = [&](int m) {
-        if (wu >= 2 && m < tg && hvalid) {
-            const int sm = tg - 1 - m;
-            const size_t row = (size_t)sm * B + hb;
-            const unsigned dst = ins0 + (unsigned)((m % RING) * 5 * NE * 4);
-#pragma unroll
-            for (int f = 0; f < 4; ++f) dma_dword_u(p.gates + row * 4 * PH + (size_t)f * PH + hu, dst + (unsigned)(f * NE * 4));
-            dma_dword_u(p.dy + row * p.ldy + hu, dst + (unsigned)(4 * NE * 4));
-            if (sm > 0) dma_dword_u(p.cell + (row - B) * PH + hu, cells0 + (unsigned)((m % RING) * NE * 4));
+        if (wu < 2 || m >= tg) return;
+        const int sm = tg - 1 - m;
+        const size_t row = (size_t)sm * B + b0 + pb;
+        const unsigned dst = ring0 + (unsigned)((m % RING) * 6 * NE * 4);
+        if (wu == 2) {
+            if (pvalid) {
+                dma16(p.gates + row * 4 * PH + (size_t)pr * PH + q * UPC + pu, dst);                       // gates i, f
+                dma16(p.gates + row * 4 * PH + (size_t)(2 + pr) * PH + q * UPC + pu, dst + 2 * NE * 4);      // gates g, o
+            }
+        } else {
+            // piece 2: row 4 = dy of step sm, row 5 = cell of step sm - 1 (absent for sm == 0: those lanes stay out)
+            const float* src = pr == 0 ? p.dy + row * p.ldy + q * UPC + pu : p.cell + (row - B) * PH + q * UPC + pu;
+            if (pvalid && (pr == 0 || sm > 0)) dma16(src, dst + 4 * NE * 4);
         }
     };
-    if (wu >= 2 && tg > 0 && hvalid) dma_dword_u(p.cell + ((size_t)(tg - 1) * B + hb) * PH + hu, cells0 + (unsigned)((RING - 1) * NE * 4));
+    // the cell of the LAST step (c_t of n = 0) goes to row 5 of slot RING - 1: upper half of a piece-2 DMA by wave 3
+    if (wu == 3 && tg > 0 && pvalid && pr == 1)
+        dma16(p.cell + ((size_t)(tg - 1) * B + b0 + pb) * PH + q * UPC + pu, ring0 + (unsigned)(((RING - 1) * 6 + 4) * NE * 4));
 #pragma unroll
     for (int m = 0; m < DIST; ++m) prefetch(m);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1311,10 +1348,10 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
         auto precompute = [&]() {
             if (active) {
                 const int i = n % RING;
-                const float* in = ins + i * 5 * NE + tid;
+                const float* in = ins + i * 6 * NE + tid;
                 const float ig = in[0], fg = in[NE], gg = in[2 * NE], og = in[3 * NE];
                 dy_s = in[4 * NE];
-                const float c_t = cells[((n + RING - 1) % RING) * NE + tid], c_prev = s > 0 ? cells[i * NE + tid] : 0.f;
+                const float c_t = ins[(((n + RING - 1) % RING) * 6 + 5) * NE + tid], c_prev = s > 0 ? in[5 * NE] : 0.f;
                 const float tc = 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.f * 1.4426950408889634f * c_t) + 1.f);
                 fA = og * __fmaf_rn(-tc, tc, 1.f);
                 fO = tc * og * (1.f - og);
@@ -1538,7 +1575,7 @@ extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh
                                    void* stream) {
     FT_CHECK_ARG(gx && w_hh && lens && y && work && status);
     FT_CHECK_ARG((gates == nullptr) == (cell == nullptr));
-    FT_CHECK_ARG(T >= 0 && ldy >= H && reinterpret_cast<uintptr_t>(work) % 256 == 0);
+    FT_CHECK_ARG(T >= 0 && ldy >= H && reinterpret_cast<uintptr_t>(work) % 256 == 0 && reinterpret_cast<uintptr_t>(gx) % 16 == 0);
     // ng: 1 / 9 = XCD-local transport (nt / sc1 loads), 8 | 4 | 2 = placement-independent fabric transport, all with tagged
     // granules; + 10 (11, 19, 18, 14, 12) = the same transports with BARE operand pairs and the sentinel protocol
     // ng = 31: the M-split form (lstm_persist_fwd_ms_k: XCD-local, tagged granules, every wave a full-K slice of the gate rows)
@@ -1647,6 +1684,9 @@ extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, 
     int rc;
     const int out = dimg == nullptr ? 0 : (dgx ? 1 : 2);
     if (rsform) {
+        // (the ring is filled by 16-byte-per-lane LDS-DMA pieces: rows of the saved tensors and of dy 16-byte aligned)
+        FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dy) % 16 == 0 && ldy % 4 == 0 && reinterpret_cast<uintptr_t>(gates) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(cell) % 16 == 0);
         // LDS: 8 x 128 gather sums + 1024 dwords of dgates operands (16-row A tiles) + the ring (5 + 1 rows per slot) + 2 output rows
         const size_t lds_rs = sizeof(float) * ((size_t)8 * 128 + 1024 + (size_t)RING * 5 * 128 + (size_t)RING * 128 + (size_t)2 * 4 * 128);
         auto launch_rs = [&](auto kern) -> int {
