@@ -61,13 +61,6 @@ struct PersistP {
     long* prof;                          // debug: per-step phase stamps of one workgroup (ft_lstm_persist_debug_prof), or null
 };
 
-// a 128-bit value with unspecified contents at no cost (registers of lanes that a masked load leaves untouched)
-__device__ __forceinline__ u32x4 undef128() {
-    u32x4 v;
-    asm volatile("" : "=v"(v));
-    return v;
-}
-
 // Granule layout of one group's state vector (K = 32 NCW k-values x RPGP rows; NCW = k-chunks per wave).  A consumer wave w
 // owns the chunks c = w + 4 ci; ONE 16-byte-per-lane load fetches CPL = 16 / RPGP of its chunks at once -- lane (kg, li) gets
 // chunk ci = lg CPL + li / RPGP, row li % RPGP, k-group kg -- so every lane of every load carries real granules (a load per
@@ -90,11 +83,6 @@ __device__ __forceinline__ void dma_dword(const float* src, unsigned lds_addr) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(lds_addr) : "memory");
-}
-
-// the same with the LDS address made scalar by force (lstm_persist_bwd_rs_k: its loop shape leaves the address in a VGPR otherwise)
-__device__ __forceinline__ void dma_dword_u(const float* src, unsigned lds_addr) {
-    dma_dword(src, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr));
 }
 
 // lane l <- lane l + n of the same 16-lane row (DPP row_shl:n), n = 0 .. 15
@@ -1260,9 +1248,6 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
         }
     };
     const int wu = __builtin_amdgcn_readfirstlane(wave);
-    const int eh = (wave & 1) * 64 + lane;
-    const int hb = b0 + eh / UPC, hu = q * UPC + eh % UPC;
-    const bool hvalid = hb < B;
     // Ring fill: a slot is 6 rows x 128 floats = three 1 KiB LDS-DMA pieces (global_load_lds_dwordx4: 16 bytes per lane, eight lanes per
     // 128-byte row piece of one batch row) instead of twelve 256-byte ones -- a piece costs 60-185 cycles of issue time whatever its
     // size, and the two output waves that issue them gate the step's second barrier.  Wave 2 moves the gate rows (pieces 0, 1), wave 3
