@@ -101,7 +101,8 @@ SIGNATURES = {
     "ft_lstm_bidir_supported": ([_i, _i], _i),
     "ft_lstm_bidir_seq_fwd": ([_p] * 6 + [_l] + [_p] * 6 + [_i, _i, _i, _p], _i),
     "ft_lstm_bidir_seq_bwd": ([_p, _l] + [_p] * 11 + [_i, _i, _i, _p], _i),
-    "ft_cumm_attn_workspace_bytes": ([_i] * 8, _sz),
+    "ft_cumm_attn_workspace_bytes": ([_i] * 10, _sz),
+    "ft_cumm_attn_fused": ([C.POINTER(CummAttnArgs)], _i),
     "ft_cumm_attn_fwd": ([C.POINTER(CummAttnArgs), _p], _i),
     "ft_cumm_attn_bwd": ([C.POINTER(CummAttnArgs)] + [_p] * 13, _i),
     "ft_attention_fwd": ([_p] * 8 + [_i, _i, _i, _i, _f, _p], _i),
@@ -157,7 +158,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argt
             fn.restype = rest
-        if l.ft_abi_version() != 10:
+        if l.ft_abi_version() != 11:
             raise RuntimeError("libflowtron_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -171,4 +171,14 @@ __device__ __forceinline__ float wave_max(float v) {
 // gemm_bf16.hip: 1 = handled, 0 = not applicable (use the staging kernel), < 0 = error
 int FT_OPNAME(ftint_gemm_bf16)(const ft_gemm_args* a, hipStream_t st);
 
+// cumm_fused.hip (one object per operand format): the fused cumulative-attention frames behind ft_cumm_attn_fwd / _bwd
+#define FT_CUMMF_DECL(sfx)                                                                                                              \
+    int ftint_cummf_supported##sfx(const ft_cumm_attn_args* a);                                                                        \
+    size_t ftint_cummf_workspace_bytes##sfx(int T, int L, int B, int E, int A, int backward);                                          \
+    int ftint_cummf_fwd##sfx(const ft_cumm_attn_args* a, hipStream_t st);                                                              \
+    int ftint_cummf_bwd##sfx(const ft_cumm_attn_args* a, const float* dctx, const float* dattn, const float* dlogprob, float* dQ,      \
+                             float* dV, float* dtext, float* dw_key, float* dv, float* dw1, float* db1, float* dw2, float* db2, hipStream_t st);
+FT_CUMMF_DECL()
+FT_CUMMF_DECL(_f16)
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -18,6 +18,7 @@
 // Saved for backward: cumm_all [T,B,L] (cumulative attention BEFORE frame i), kproj_all [T][L*B][A] (the projected keys of every
 // frame: 11 GB per flow at T 862 -- sized for 288 GB of HBM; recomputing them would repeat the dominant GEMM), attn itself.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -278,15 +279,33 @@ int check(const ft_cumm_attn_args* a) {
     return FT_OK;
 }
 
+// the fused one-launch-per-frame path of the 16-bit operand modes (cumm_fused.hip, compiled once per format).
+// FT_CUMM_FUSED=0 keeps the launch chain below (the yardstick of tests/test_gpu_model.py); read per call.
+bool fused_on() { const char* e = getenv("FT_CUMM_FUSED"); return !e || atoi(e) != 0; }
+int fused_supported(const ft_cumm_attn_args* a) {
+    if (!fused_on()) return 0;
+    return a->mode == FT_F16 ? ftint_cummf_supported_f16(a) : ftint_cummf_supported(a);
+}
+
 }  // namespace
 
-extern "C" size_t ft_cumm_attn_workspace_bytes(int L, int B, int E, int A, int NF, int K1, int K2, int backward) {
-    return carve(nullptr, L, B, E, A, NF, K1, K2, backward != 0).total;
+extern "C" size_t ft_cumm_attn_workspace_bytes(int T, int L, int B, int E, int A, int NF, int K1, int K2, int mode, int backward) {
+    size_t n = carve(nullptr, L, B, E, A, NF, K1, K2, backward != 0).total;
+    ft_cumm_attn_args a{};
+    a.T = T; a.L = L; a.B = B; a.E = E; a.A = A; a.NF = NF; a.K1 = K1; a.K2 = K2; a.mode = mode;
+    if (fused_supported(&a)) {
+        const size_t f = mode == FT_F16 ? ftint_cummf_workspace_bytes_f16(T, L, B, E, A, backward) : ftint_cummf_workspace_bytes(T, L, B, E, A, backward);
+        if (f > n) n = f;
+    }
+    return n;
 }
+
+extern "C" int ft_cumm_attn_fused(const ft_cumm_attn_args* a) { return a ? fused_supported(a) : 0; }
 
 extern "C" int ft_cumm_attn_fwd(const ft_cumm_attn_args* a, void* stream) {
     CK(check(a));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (fused_supported(a)) return a->mode == FT_F16 ? ftint_cummf_fwd_f16(a, st) : ftint_cummf_fwd(a, st);
     const int T = a->T, B = a->B, L = a->L, E = a->E, A = a->A, R = L * B;
     const Buf b = carve(a->work, L, B, E, A, a->NF, a->K1, a->K2, false);
     FT_CHECK_ARG(a->work_bytes >= b.total);
@@ -313,6 +332,9 @@ extern "C" int ft_cumm_attn_bwd(const ft_cumm_attn_args* a, const float* dctx, c
     CK(check(a));
     FT_CHECK_ARG(dctx && dQ && dV && dtext && dw_key && dv && dw1 && db1 && dw2 && db2);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (fused_supported(a))
+        return a->mode == FT_F16 ? ftint_cummf_bwd_f16(a, dctx, dattn, dlogprob, dQ, dV, dtext, dw_key, dv, dw1, db1, dw2, db2, st)
+                                 : ftint_cummf_bwd(a, dctx, dattn, dlogprob, dQ, dV, dtext, dw_key, dv, dw1, db1, dw2, db2, st);
     const int T = a->T, B = a->B, L = a->L, E = a->E, A = a->A, R = L * B, NF = a->NF, C1 = 2 * a->K1, C2n = NF * a->K2;
     const Buf b = carve(a->work, L, B, E, A, NF, a->K1, a->K2, true);
     FT_CHECK_ARG(a->work_bytes >= b.total);

@@ -1083,7 +1083,7 @@ class CummAttnSeqFn(torch.autograd.Function):
         f = dict(device=Q.device, dtype=torch.float32)
         out_ctx, attn, logprob = torch.empty(T, B, A, **f), torch.empty(B, T, Lk, **f), torch.empty(B, T, Lk, **f)
         cumm_all, kproj_all = torch.empty(T, B, Lk, **f), torch.empty(T, Lk * B, A, **f)
-        work = torch.empty(L.lib().ft_cumm_attn_workspace_bytes(Lk, B, E, A, NF, K1, K2, 0) + 256, device=Q.device, dtype=torch.uint8)
+        work = torch.empty(L.lib().ft_cumm_attn_workspace_bytes(T, Lk, B, E, A, NF, K1, K2, int(mode), 0) + 256, device=Q.device, dtype=torch.uint8)
         args = CummAttnSeqFn._args(Q, V, text, w_key, v, w1, b1, w2, b2, in_lens, out_ctx, attn, logprob, cumm_all, kproj_all, work,
                                    temperature, mode)
         L.check(L.lib().ft_cumm_attn_fwd(C.byref(args), L.stream()), "ft_cumm_attn_fwd")
@@ -1114,7 +1114,7 @@ class CummAttnSeqFn(torch.autograd.Function):
         dlogprob = _c(dlogprob) if dlogprob is not None else None
         dQ, dV, dtext = torch.empty_like(Q), torch.empty_like(V), torch.empty_like(text)
         dwk, dv, dw1, db1, dw2, db2 = (torch.empty_like(t) for t in (w_key, v, w1, b1, w2, b2))
-        work = torch.empty(L.lib().ft_cumm_attn_workspace_bytes(Lk, B, E, A, NF, K1, K2, 1) + 256, device=Q.device, dtype=torch.uint8)
+        work = torch.empty(L.lib().ft_cumm_attn_workspace_bytes(T, Lk, B, E, A, NF, K1, K2, int(ctx.mode), 1) + 256, device=Q.device, dtype=torch.uint8)
         scratch = torch.empty(1, **f)                 # forward-only outputs are not written by the backward call
         args = CummAttnSeqFn._args(Q, V, text, w_key, v, w1, b1, w2, b2, in_lens, scratch, attn, scratch, cumm_all, kproj_all, work,
                                    ctx.temperature, ctx.mode)

@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 10
+#define FT_ABI_VERSION 11
 
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1, FT_F16 = 2 };
@@ -430,8 +430,13 @@ int ft_attn_ctc_bwd(const float* lp, const int32_t* in_lens, const int32_t* out_
  * flowtron.py:697-723 (run_cumm_attn_sequence), :129-152 (AttentionConditioningLayer), :544-592 (Attention.forward).  Per frame
  * i: cond = sigmoid(conv_K2(relu(conv_K1([cumm_i ; prev_i])))) over the text axis (2 -> NF -> E channels, zero padding at the ends),
  * keys = (text . cond) w_key^T, scores v . tanh(Q_i + keys) / temperature, softmax over l < in_lens[b], logprob = log(attn + 1e-8),
- * ctx_i = attn_i V, cumm_{i+1} = cumm_i + attn_i, prev_{i+1} = attn_i.  The LIBRARY walks the T dependent frames (8 launches per
- * frame forward, 22 backward, enqueued back to back on `stream`; no host synchronisation).
+ * ctx_i = attn_i V, cumm_{i+1} = cumm_i + attn_i, prev_{i+1} = attn_i.  The LIBRARY walks the T dependent frames, enqueued back to
+ * back on `stream`, no host synchronisation:
+ *   - 16-bit operand modes at the config.json width (E = A = 640, NF 32, K1 5, K2 3; ft_cumm_attn_fused() != 0, ABI 11): ONE fused
+ *     launch per frame and direction (csrc/cumm_fused.hip); context, dV, dctx . V and every weight gradient leave the frame loop
+ *     and run as a few large GEMMs over all frames (the backward keeps 16-bit streams of dK / km / dpre2 / col2 for a chunk of
+ *     frames in `work`).  kproj_all then holds tanh(Q_i + K_i) of the rows l < in_lens[b] instead of K_i.
+ *   - otherwise (fp32 parity mode, other widths, FT_CUMM_FUSED=0): a chain of 8 launches per frame forward, 22 backward.
  * Layouts: text [L][B][E] (encoder outputs), Q [T][B][A] and V [L][B][A] (already projected), w_key [A][E], v [A], w1 [NF][2][K1],
  * w2 [E][NF][K2]; outputs ctx [T][B][A], attn / logprob [B][T][L].  Saved for backward (caller-owned, filled by fwd):
  * cumm_all [T][B][L] and kproj_all [T][L*B][A].  work: ft_cumm_attn_workspace_bytes() bytes, 256-byte aligned.
@@ -446,7 +451,8 @@ typedef struct {
     float temperature;
     int mode;
 } ft_cumm_attn_args;
-size_t ft_cumm_attn_workspace_bytes(int L, int B, int E, int A, int NF, int K1, int K2, int backward);
+size_t ft_cumm_attn_workspace_bytes(int T, int L, int B, int E, int A, int NF, int K1, int K2, int mode, int backward);
+int ft_cumm_attn_fused(const ft_cumm_attn_args* a);     /* 1: fwd / bwd of these arguments take the fused one-launch-per-frame path */
 int ft_cumm_attn_fwd(const ft_cumm_attn_args* a, void* stream);
 int ft_cumm_attn_bwd(const ft_cumm_attn_args* a, const float* dctx, const float* dattn, const float* dlogprob,
                      float* dQ, float* dV, float* dtext, float* dw_key, float* dv, float* dw1, float* db1, float* dw2, float* db2,

@@ -1185,3 +1185,79 @@ def test_big_tile_image_gemm_is_bit_identical_to_the_128_tile_kernel(env, act, m
     ref = torch.cat([x1, x2], 2).bfloat16().float() @ W.bfloat16().float().t() + b
     ref = torch.tanh(ref) if act else ref
     assert mad(res["2"][0], ref) < 2e-3
+
+
+# ---------------------------------------------------------------- cumulative attention, fused frames (csrc/cumm_fused.hip)
+def _cumm_reference(Q, V, text, wk, v, w1, b1, w2, b2, in_lens, temp):
+    """flowtron.py:697-723 + :129-152 + :544-592 in float64 torch (the per-frame loop of the reference), with autograd."""
+    T, B, A = Q.shape
+    Lk = text.shape[0]
+    cumm = Q.new_zeros(B, 1, Lk)
+    prev = Q.new_zeros(B, 1, Lk)
+    mask = torch.arange(Lk)[None, :] >= in_lens[:, None]
+    ctxs, attns, lps = [], [], []
+    for i in range(T):
+        x = torch.cat([cumm, prev], 1)
+        h = torch.relu(F.conv1d(x, w1, b1, padding=2))
+        c = torch.sigmoid(F.conv1d(h, w2, b2, padding=1)).permute(2, 0, 1)          # [L,B,E]
+        K = (text * c) @ wk.t()                                                        # [L,B,A]
+        e = (torch.tanh(Q[i][None] + K) @ v / temp).t().masked_fill(mask, -float("inf"))
+        p = torch.softmax(e, 1)
+        ctxs.append(torch.einsum("bl,lba->ba", p, V))
+        attns.append(p)
+        lps.append(torch.log(p + 1e-8))
+        prev = p[:, None, :]
+        cumm = cumm + prev
+    return torch.stack(ctxs, 0), torch.stack(attns, 1), torch.stack(lps, 1)
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("T,Lk,lens", [(23, 57, [57, 52, 26, 7]), (5, 157, [157, 130, 33]), (9, 20, [20, 1])])
+def test_fused_cumulative_attention_frames_vs_float64_reference(env, monkeypatch, fmt, T, Lk, lens):
+    """ONE fused launch per frame and direction (ft_cumm_attn_fwd / _bwd -> csrc/cumm_fused.hip, the path of
+    the 16-bit operand modes at the config.json width E = A = 640) against the reference's per-frame loop in float64 torch, and
+    beside it the launch chain it replaces (FT_CUMM_FUSED=0) in the same operand format: forward outputs and every gradient.  The
+    lengths hit the tile edges of both kernels: in_len == L, a multiple of the backward's 26 own rows (52, 26), of the forward's
+    32 (rows beyond it exit), a single text position.  Bar: the fused path is as close to float64 as the chain (<= 2x its
+    deviation + a floor at operand-rounding level), and both within the 16-bit tolerance written below."""
+    L, ops = env
+    E = A = 640
+    B = len(lens)
+    gen = torch.Generator().manual_seed(100 + T + Lk)
+    rn = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64)
+    Q, V, text = rn(T, B, A) * 0.7, rn(Lk, B, A), rn(Lk, B, E) * 0.7
+    wk, v = rn(A, E) / E ** 0.5 * 1.5, rn(A) / A ** 0.5 * 6.0
+    w1, b1, w2, b2 = rn(32, 2, 5) * 0.6, rn(32) * 0.3, rn(E, 32, 3) * 0.25, rn(E) * 0.3
+    in_lens = torch.tensor(lens)
+    temp = 0.9
+    gc_, ga_, gl_ = rn(T, B, A), rn(B, T, Lk), rn(B, T, Lk) * 0.1
+    valid = (torch.arange(Lk)[None, :] < in_lens[:, None])[:, None, :].double()
+    leaves = [t.clone().requires_grad_(True) for t in (Q, V, text, wk, v, w1, b1, w2, b2)]
+    rc, ra, rl = _cumm_reference(*leaves, in_lens, temp)
+    ((rc * gc_).sum() + (ra * ga_).sum() + (rl * gl_ * valid).sum()).backward()
+    ref_out = [rc.detach(), ra.detach(), (rl * valid).detach()]
+    ref_grad = [t.grad for t in leaves]
+
+    def run(fused):
+        monkeypatch.setenv("FT_CUMM_FUSED", "1" if fused else "0")
+        lv = [t.float().cuda().requires_grad_(True) for t in (Q, V, text, wk, v.reshape(1, -1), w1, b1, w2, b2)]
+        c, a_, lp = ops.CummAttnSeqFn.apply(*lv, in_lens.int().cuda(), temp, fmt)
+        ((c * gc_.float().cuda()).sum() + (a_ * ga_.float().cuda()).sum() + (lp * (gl_ * valid).float().cuda()).sum()).backward()
+        torch.cuda.synchronize()
+        outs = [c.detach().cpu().double(), a_.detach().cpu().double(), (lp.detach().cpu().double() * valid)]
+        return outs, [t.grad.detach().cpu().double().reshape(r.shape) for t, r in zip(lv, ref_grad)]
+
+    names = ["Q", "V", "text", "w_key", "v", "w1", "b1", "w2", "b2"]
+    fo, fg = run(True)
+    co, cg = run(False)
+    report = []
+    for nm, f, c_, r in zip(["ctx", "attn", "logprob"], fo, co, ref_out):
+        ef, ec = (f - r).abs().max().item(), (c_ - r).abs().max().item()
+        report.append((nm, ef, ec))
+        assert ef <= 2.0 * ec + 4e-3 and ef < 6e-2, report
+    for nm, f, c_, r in zip(names, fg, cg, ref_grad):
+        nr = r.norm().item() + 1e-30
+        ef, ec = (f - r).norm().item() / nr, (c_ - r).norm().item() / nr
+        report.append(("d" + nm, ef, ec))
+        assert ef <= 2.0 * ec + 5e-3 and ef < 6e-2, report
+    print("\n[fused cumulative attention fmt %d T %d L %d] (name, fused vs f64, chain vs f64): %s" % (fmt, T, Lk, report))
