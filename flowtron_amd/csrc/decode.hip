@@ -639,7 +639,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
 template <int R, int NL, bool F32> using template_rows = typename std::conditional<F32, WRowsF<R, NL>, WRows<R, NL>>::type;
 
 // F32 = false: 16-bit weight images, all of them register-resident (the round-2 kernel).
-// F32 = true (round 4): fp32 weights and libm activations -- the precision of the reference's inference.py:68-71.  107 MB per flow do
+// F32 = true (round 4): fp32 weights and fp32 FMAs -- the operand precision of the reference's inference.py:68-71; activations by the
+//   v_exp_f32 / v_rcp_f32 forms (|err| ~ 1e-7, mel 2.4e-7 from the oracle over 400 frames; -DFT_DECODE_LIBM=1 selects libm: +10 us per frame).  107 MB per flow do
 //   not fit the register file (419 KB per CU against 512 KB of registers less the working set): the five recurrent / large input
 //   matrices of the LSTMs stay RESIDENT -- attention W_hh, layer-0 W_ih[:, :H] and W_hh, layer-1 W_hh in registers (256 per lane =
 //   the accumulation half of the register file, where the compiler parks them), layer-1 W_ih and layer-0 W_ih[:, H:] in 104 KB of

@@ -55,8 +55,12 @@ class DeferredMel:
         hop = stft.stft_fn.hop_length
         frames = [int(n) // hop + 1 for n in self.n_samples.tolist()]
         max_t = max(frames) if self.max_t is None else max(int(self.max_t), max(frames))
-        if stft.stft_fn.fast_path() and audio.shape[1] > stft.stft_fn.filter_length // 2:
-            # ONE launch for the batch: every utterance reflected about its own last sample, zeros behind its last frame
+        if (stft.stft_fn.fast_path() and stft.n_mel_channels <= 128
+                and int(self.n_samples.min()) > stft.stft_fn.filter_length // 2):
+            # ONE launch for the batch: every utterance reflected about its own last sample, zeros behind its last frame.
+            # Same preconditions as TacotronSTFT.mel_spectrogram's fast kernel: more than 128 mel channels, or an
+            # utterance no longer than the reflection pad (the reference's reflect pad raises on those), take the
+            # per-utterance loop below, whose mel_spectrogram falls back to the general front end (ft_stft_mel)
             return stft.mel_spectrogram_ragged(audio, self.n_samples.to(dev, dtype=torch.int32), max_t)
         mel = torch.zeros(len(frames), stft.n_mel_channels, max_t, device=dev, dtype=torch.float32)
         for i, (n, t) in enumerate(zip(self.n_samples.tolist(), frames)):       # reflect padding depends on each utterance's end

@@ -157,6 +157,7 @@ class FlatArena:
         .grad stays None."""
         skipped, dst, src = [], [], []
         views = self._views()
+        self.adopt_copied = False            # did this call move gradient VALUES into the arena (as opposed to zero-filling None slices)?
         idx = range(len(self.params)) if only is None else only
         for i in idx:
             p, off = self.params[i], self.offsets[i]
@@ -174,6 +175,7 @@ class FlatArena:
                         dst.append(views[i]); src.append(g)
                     else:
                         views[i].copy_(g)
+                    self.adopt_copied = True
                 p.grad = views[i]
         if len(dst) == 1:
             dst[0].copy_(src[0])

@@ -486,20 +486,31 @@ class Flowtron(nn.Module):
         x = mel.permute(2, 0, 1).contiguous().float()
         if attn_prior is not None:
             attn_prior = attn_prior.float()
-        log_s_list, attns_list, attns_logprob_list = [], [], []
-        gate = None
         # pack-by-length for the batched GEMMs of the 16-bit operand modes (one row map per forward, built on the device)
         rm = ops.row_map(out32, x.shape[0], x.shape[1]) if L.is16(L.mfma_mode()) else None
-        for flow in self.flows:
-            x, log_s, gate, attn, logprob = flow(x, enc, in32, out32, attn_prior, rowmap=rm)
-            log_s_list.append(log_s)
-            attns_list.append(attn)
-            attns_logprob_list.append(logprob)
+
+        def run_flows(x, enc):
+            log_s_list, attns_list, attns_logprob_list = [], [], []
+            gate = None
+            for flow in self.flows:
+                x, log_s, gate, attn, logprob = flow(x, enc, in32, out32, attn_prior, rowmap=rm)
+                log_s_list.append(log_s)
+                attns_list.append(attn)
+                attns_logprob_list.append(logprob)
+            return x, log_s_list, gate, attns_list, attns_logprob_list
+
+        x0 = x
+        x, log_s_list, gate, attns_list, attns_logprob_list = run_flows(x0, enc)
         if not torch.is_grad_enabled() and ops.PERSIST_LAUNCHES:
             # forward-only pass (validation, train.py:143-202): no optimizer step will look at the persistent kernels' status word,
-            # so a launch that timed out would hand back garbage silently and poison the NEXT training step -- check (one host
-            # read; the validation loop reads its losses with .item() anyway) and raise here
-            ops.check_persist_status(raise_on_failure=True)
+            # so a launch that timed out would hand back garbage silently.  One host read (the validation loop reads its losses
+            # with .item() anyway); on a failure -- this pass's, or a stale word of an earlier, already dropped training step --
+            # the device has been switched to the launch-per-step kernels (warned once) and the flows run AGAIN on those, like
+            # AR_Step.infer does: a validation pass must not kill a run that a training step would survive, and under DP the other
+            # ranks must not be left waiting at their next collective
+            if not ops.check_persist_status(raise_on_failure=False):
+                enc, in32 = self._encode(speaker_ids, text, in_lens)          # (the encoder's persistent BiLSTM may be the one that failed)
+                x, log_s_list, gate, attns_list, attns_logprob_list = run_flows(x0, enc)
         return x, log_s_list, gate, attns_list, attns_logprob_list, None, None, None
 
     def infer(self, residual, speaker_ids, text, temperature=1.0, gate_threshold=0.5, attns=None, attn_prior=None):

@@ -206,6 +206,13 @@ _HANDOFF = {"imgs": {}, "armed": False, "unwritten": set(), "nan_next": 0}
 _NAN_POOL = {}          # device -> 64 fp32 NaNs: one slot per image-only gradient alive in a backward pass
 
 
+def _current_graph_task():
+    try:
+        return torch._C._current_graph_task_id()
+    except Exception:                   # older torch: fall back to "one pass at a time" (the pre-round-5 behaviour)
+        return -1
+
+
 def _handoff_clear():
     _HANDOFF["imgs"].clear()
     _HANDOFF["unwritten"].clear()
@@ -228,12 +235,19 @@ def image_only_gradient(shape, device):
 
 
 def _handoff_put(t, img):
-    if not _HANDOFF["armed"]:
+    # one clear callback per backward PASS.  The engine drops its callbacks when a backward raises, which used to leave `armed`
+    # set for good: imgs / unwritten / nan_next were then never cleared again.  A pass is identified by the engine's
+    # current graph task; a put from another pass than the one that armed the state clears the leftovers and arms again.
+    gt = _current_graph_task()
+    if not _HANDOFF["armed"] or _HANDOFF.get("task") != gt:
+        if _HANDOFF["armed"]:
+            _handoff_clear()
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_handoff_clear)
         except RuntimeError:            # not inside a backward pass: no consumer can follow
             return
         _HANDOFF["armed"] = True
+        _HANDOFF["task"] = gt
     _HANDOFF["imgs"][(t.device.index, t.data_ptr(), tuple(t.shape))] = img
 
 
@@ -707,8 +721,36 @@ def check_persist_status(raise_on_failure=True):
     return ok
 
 
+def _persist_fwd_code(ng):
+    """transport code ft_lstm_persist_fwd is launched with.  FLOWTRON_LSTM_PERSIST = 1 (XCD-local groups):
+    FLOWTRON_LSTM_PERSIST_FWD = bare (default since the end of round 4) -> 11, the K-split kernel with bare operand pairs (sentinel
+    protocol, half the gather bytes; 1.84 against 1.87 us per step), ksplit -> 1 (tagged granules), ms -> 31 (the M-split kernel).
+    All bit-identical."""
+    fwd_form = _os.environ.get("FLOWTRON_LSTM_PERSIST_FWD", _PERSIST_FWD_DEFAULT)
+    if ng == 1 and fwd_form == "ms":
+        return 31
+    if ng == 1 and fwd_form == "bare":
+        return 11
+    return ng
+
+
+def _persist_bwd_code(ng):
+    """transport code ft_lstm_persist_bwd / _bwd_img are launched with: FLOWTRON_LSTM_PERSIST_BWD = rs (default) -> 21, the
+    reduce-scatter kernel (lstm_persist_bwd_rs_k); bare -> 11, tagged -> 1: the all-gather kernels."""
+    bwd_form = _os.environ.get("FLOWTRON_LSTM_PERSIST_BWD", "rs")
+    if ng == 1 and bwd_form == "rs":
+        return 21
+    if ng == 1 and bwd_form != "tagged":
+        return 11
+    return ng if ng in (1, 9, 8, 4, 11, 19, 18, 14, 21) else (18 if ng > 10 else 8)      # (no 2-group backward kernel)
+
+
 def _persist_selftest(device, ng):
-    """tiny forward + backward through the persistent kernels, checked synchronously (once per device)."""
+    """tiny forward + backward through the persistent kernels TRAINING LAUNCHES -- the effective forward and backward transport
+    codes of this environment (default: 11 and the reduce-scatter kernel 21, whose LDS size, workspace and sentinel protocol differ
+    from transport 1's), the backward once through ft_lstm_persist_bwd and once through the image-only entry the step itself uses
+    (ft_lstm_persist_bwd_img) -- checked synchronously, once per device (a device where only the tagged kernels are
+    co-resident must not pass the self-test and then drop its first optimizer steps)."""
     H, B, T = 1024, 8, 3
     f = dict(device=device, dtype=torch.float32)
     gx, w = torch.zeros(T, B, 4 * H, **f), torch.zeros(4 * H, H, **f)
@@ -719,9 +761,16 @@ def _persist_selftest(device, ng):
     st = _persist_state(device)
     try:
         L.check(L.lib().ft_lstm_persist_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(work),
-                                            L.ptr(st.status), T, B, H, ng, L.stream()), "ft_lstm_persist_fwd")
+                                            L.ptr(st.status), T, B, H, _persist_fwd_code(ng), L.stream()), "ft_lstm_persist_fwd")
         L.check(L.lib().ft_lstm_persist_bwd(L.ptr(y), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx), L.ptr(work),
-                                            L.ptr(st.status), T, B, H, ng, L.stream()), "ft_lstm_persist_bwd")
+                                            L.ptr(st.status), T, B, H, _persist_bwd_code(ng), L.stream()), "ft_lstm_persist_bwd")
+        if _PERSIST_IMG != "0":
+            rows, ld = T * B + B, (4 * H + 255) // 256 * 256
+            dimg = torch.empty(L.lib().ft_bf16_image_bytes(rows, 4 * H), device=device, dtype=torch.uint8)
+            dbias = torch.zeros(4 * H, **f)
+            L.check(L.lib().ft_lstm_persist_bwd_img(L.ptr(y), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), None, L.ptr(work),
+                                                    L.ptr(st.status), T, B, H, _persist_bwd_code(ng), L.ptr(dimg), ld,
+                                                    dimg.numel() // (2 * ld), L.ptr(dbias), L.stream()), "ft_lstm_persist_bwd_img")
         ok = int(st.status.item()) == 0
     except RuntimeError:
         ok = False
@@ -794,11 +843,7 @@ class LSTMSeqFn(torch.autograd.Function):
             # FLOWTRON_LSTM_PERSIST = 1 (XCD-local): FLOWTRON_LSTM_PERSIST_FWD = bare (default since the end of round 4) -> transport 11, the
             # K-split kernel with bare operand pairs (half the gather bytes; 1.84 against 1.87 us per step once the operand moves sit in
             # the MFMA gaps), ksplit -> transport 1 (tagged granules), ms -> transport 31 (the M-split kernel).  All bit-identical.
-            fwd_form = _os.environ.get("FLOWTRON_LSTM_PERSIST_FWD", _PERSIST_FWD_DEFAULT)
-            if ng == 1 and fwd_form == "ms":
-                ng = 31
-            elif ng == 1 and fwd_form == "bare":
-                ng = 11                              # the K-split kernel with bare operand pairs (sentinel protocol, half the gather bytes)
+            ng = _persist_fwd_code(ng)
             st = _persist_watch(gx.device)
             work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=gx.device, dtype=torch.uint8)
             L.check(L.op16("ft_lstm_persist_fwd", mode)(L.ptr(gx), L.ptr(w_hh), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
@@ -825,12 +870,7 @@ class LSTMSeqFn(torch.autograd.Function):
             # form (transport 21, round 4: 1.92 us per step against 2.84 for the bare all-gather of dgates -- every CU multiplies its
             # own dgates, fp32 partials cross the L2; equal to fp32 rounding).  FLOWTRON_LSTM_PERSIST_BWD=bare | tagged select the
             # all-gather kernels, which ARE bit-identical to the launch-per-step kernel.
-            bwd_form = _os.environ.get("FLOWTRON_LSTM_PERSIST_BWD", "rs")
-            if ng == 1 and bwd_form == "rs":
-                ng = 21
-            elif ng == 1 and bwd_form != "tagged":
-                ng = 11
-            ng = ng if ng in (1, 9, 8, 4, 11, 19, 18, 14, 21) else (18 if ng > 10 else 8)      # (no 2-group backward kernel)
+            ng = _persist_bwd_code(ng)
             st = _persist_watch(dy.device)
             work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=dy.device, dtype=torch.uint8)
             rm = ctx.rowmap

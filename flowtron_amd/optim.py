@@ -14,10 +14,10 @@ keeps one per parameter; they only differ for a parameter that was without a gra
 Guard: the fused kernel drops the whole update when the global gradient norm is NaN / Inf (ft_radam_step): the device-side
 equivalent of GradScaler's overflow skip (train.py:330), which also catches a step poisoned by a persistent recurrence that
 reported a time-out (`poison_from_status`) -- on every rank, because the poison travels through the gradient all-reduce.
-`skipped_steps` reads the device counter.  A dropped update leaves weights and moments untouched, but the host-side step count
-(bias correction, N_sma) still advances -- unlike a GradScaler skip; with a handful of dropped steps per run the drift of the
-step size is < 1 % after the first few hundred iterations, and a run that drops steps systematically shows up in
-`skipped_steps` (bench.py prints it; a training loop should log it at its logging cadence).
+`skipped_steps` reads the device counter.  A dropped update leaves weights and moments untouched; the host-side step count (bias
+correction, N_sma) is taken back by the number of dropped updates whenever the host next LOOKS at the counter -- `skipped_steps`,
+`state_dict()` (every checkpoint) -- so a GradScaler-style skip does not advance the schedule for good, without a
+host synchronisation per step; between two looks the step size of a run that dropped k updates is the one of step n + k.
 """
 from __future__ import annotations
 
@@ -50,6 +50,7 @@ class RAdam(Optimizer):
         self._skipped = torch.zeros(1, device=arena.flat_grad.device, dtype=torch.int32)
         self._have_norm = False
         self._step = 0
+        self._skipped_applied = 0        # device-dropped updates already taken back from _step
         self._bind_state()
 
     def _bind_state(self):
@@ -94,8 +95,20 @@ class RAdam(Optimizer):
 
     @property
     def skipped_steps(self) -> int:
-        """updates the device-side guard dropped so far (non-finite global gradient norm); one host read"""
-        return int(self._skipped.item())
+        """updates the device-side guard dropped so far (non-finite global gradient norm); one host read.  The step count that
+        drives bias correction / N_sma is taken back by the drops not yet accounted for (radam.py counts only updates it applied)."""
+        n = int(self._skipped.item())
+        if n > self._skipped_applied:
+            self._step = max(0, self._step - (n - self._skipped_applied))
+            self._skipped_applied = n
+            for st in self.state.values():
+                if isinstance(st, dict) and "step" in st:
+                    st["step"] = min(int(st["step"]), self._step)
+        return n
+
+    def state_dict(self):
+        _ = self.skipped_steps           # a checkpoint carries the step count of the updates that were APPLIED
+        return super().state_dict()
 
     def _norm_sq(self):
         """||g||^2 of the arena on device; a persistent recurrence that reported a time-out poisons it first (NaN)."""
@@ -119,7 +132,13 @@ class RAdam(Optimizer):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
         a = self.arena
+        # gradients that changed since clip_grad_norm_ took the norm (another backward in between: in-place accumulation bumps the
+        # arena's version, fresh p.grad tensors are copied in by the adoption below) need the norm again.  The version is
+        # read BEFORE the adoption: zero-filling the slice of a parameter without a gradient bumps it too, and used to cost one extra
+        # ft_sumsq over the 244 MB arena per step
+        stale = not self._have_norm or a.flat_grad._version != getattr(self, "_norm_version", -1)
         skipped = a.adopt_stray_grads(copy=True)
+        stale = stale or a.adopt_copied
         # radam.py:57-58: a parameter without a gradient is left untouched (rare: frozen / unused branches) -- the fused
         # kernel sweeps the whole arena, so its slices are restored afterwards
         keep = [(off, k, a.flat_param[off:off + k].clone(), self.flat_m[off:off + k].clone(), self.flat_v[off:off + k].clone())
@@ -128,9 +147,8 @@ class RAdam(Optimizer):
         beta1, beta2 = g["betas"]
         ss, rect = self.step_size_for(self._step, g["lr"], beta1, beta2)
         clip = getattr(self, "_clip", 0.0)
-        # no clip_grad_norm_ this iteration: the guard still needs the norm (clip stays 0); gradients that changed since the norm
-        # was taken (another backward between clip_grad_norm_ and step): the norm is taken again
-        if not self._have_norm or a.flat_grad._version != getattr(self, "_norm_version", -1):
+        # no clip_grad_norm_ this iteration: the guard still needs the norm (clip stays 0)
+        if stale:
             self._norm_sq()
         L.check(L.lib().ft_radam_step(L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.flat_m), L.ptr(self.flat_v),
                                       a.numel, L.ptr(self.gnorm_sq), clip, g["lr"], beta1, beta2,
