@@ -53,7 +53,8 @@ class DecodeArgs(C.Structure):
         ("work_bytes", _sz), ("N", _i), ("L", _i), ("H", _i), ("A", _i), ("M", _i),
         ("temperature", _f), ("gate_threshold", _f), ("use_graph", _i)] + [
         (n, _p) for n in ("cond_w1", "cond_b1", "cond_w2", "cond_b2", "w_key", "enc")] + [("E", _i), ("prior", _p), ("forced", _p),
-                                                                                         ("wimg", _p), ("wimg_bytes", _sz), ("persist_gran", _p), ("persist_status", _p)]
+                                                                                         ("wimg", _p), ("wimg_bytes", _sz), ("persist_gran", _p), ("persist_status", _p),
+                                                                                         ("n_layers", _i), ("extra_layers", _p)]
 
 
 SUMSQ_PARTIALS = 1024      # FT_SUMSQ_PARTIALS: floats of scratch ft_sumsq needs
@@ -103,6 +104,7 @@ SIGNATURES = {
     "ft_lstm_bidir_seq_bwd": ([_p, _l] + [_p] * 11 + [_i, _i, _i, _p], _i),
     "ft_cumm_attn_workspace_bytes": ([_i] * 10, _sz),
     "ft_cumm_attn_fused": ([C.POINTER(CummAttnArgs)], _i),
+    "ft_cumm_attn_debug_prof": ([_p], _i),
     "ft_cumm_attn_fwd": ([C.POINTER(CummAttnArgs), _p], _i),
     "ft_cumm_attn_bwd": ([C.POINTER(CummAttnArgs)] + [_p] * 13, _i),
     "ft_attention_fwd": ([_p] * 8 + [_i, _i, _i, _i, _f, _p], _i),
@@ -118,7 +120,7 @@ SIGNATURES = {
     "ft_act_bwd": ([_p, _p, _p, _l, _i, _p], _i),
     "ft_eltwise": ([_p, _p, _p, _l, _i, _p], _i),
     "ft_colsum": ([_p, _p, _l, _i, _l, _p], _i),
-    "ft_decode_workspace_bytes": ([_i, _i, _i, _i, _i], _sz),
+    "ft_decode_workspace_bytes": ([_i, _i, _i, _i, _i, _i], _sz),
     "ft_decode_wimg_bytes": ([_i, _i, _i], _sz),
     "ft_decode_persist_gran_bytes": ([], _sz),
     "ft_decode_debug_prof": ([_p], _i),

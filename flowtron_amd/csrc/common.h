@@ -174,6 +174,7 @@ int FT_OPNAME(ftint_gemm_bf16)(const ft_gemm_args* a, hipStream_t st);
 // cumm_fused.hip (one object per operand format): the fused cumulative-attention frames behind ft_cumm_attn_fwd / _bwd
 #define FT_CUMMF_DECL(sfx)                                                                                                              \
     int ftint_cummf_supported##sfx(const ft_cumm_attn_args* a);                                                                        \
+    void ftint_cummf_debug_prof##sfx(void* dev_buf);                                                                                   \
     size_t ftint_cummf_workspace_bytes##sfx(int T, int L, int B, int E, int A, int backward);                                          \
     int ftint_cummf_fwd##sfx(const ft_cumm_attn_args* a, hipStream_t st);                                                              \
     int ftint_cummf_bwd##sfx(const ft_cumm_attn_args* a, const float* dctx, const float* dattn, const float* dlogprob, float* dQ,      \

@@ -301,6 +301,7 @@ extern "C" size_t ft_cumm_attn_workspace_bytes(int T, int L, int B, int E, int A
 }
 
 extern "C" int ft_cumm_attn_fused(const ft_cumm_attn_args* a) { return a ? fused_supported(a) : 0; }
+extern "C" int ft_cumm_attn_debug_prof(void* dev_buf) { ftint_cummf_debug_prof(dev_buf); ftint_cummf_debug_prof_f16(dev_buf); return FT_OK; }
 
 extern "C" int ft_cumm_attn_fwd(const ft_cumm_attn_args* a, void* stream) {
     CK(check(a));

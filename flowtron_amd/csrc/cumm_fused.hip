@@ -47,6 +47,10 @@ constexpr int FWD_ROWS = 32, BWD_OWN = 26, HALO = 3;
 
 __device__ __forceinline__ bf16x8 ld_frag(const unsigned short* p) { return *reinterpret_cast<const bf16x8*>(p); }
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) { return make_uint2(pack_op16x2(a, b), pack_op16x2(c, d)); }
+// Workgroup barrier that publishes LDS writes only.  __syncthreads() also drains vmcnt: every frame kernel keeps weight fragments
+// of LATER phases in flight across its barriers (requested at the kernel's top: a frame is a chain of short phases, each of which
+// would otherwise start with an exposed L2 round trip), and nothing here communicates through global memory inside a launch.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // softmax of e[0 .. len) into ps (ps[l] = 0 for len <= l < Lp); red: 8 floats
 __device__ __forceinline__ void softmax_block(const float* __restrict__ e, float* ps, float* red, int len, int Lp, int tid) {
@@ -55,27 +59,22 @@ __device__ __forceinline__ void softmax_block(const float* __restrict__ e, float
     for (int l = tid; l < len; l += 256) { const float x = e[l]; ps[l] = x; m = fmaxf(m, x); }
     m = wave_max(m);
     if (lane == 0) red[wave] = m;
-    __syncthreads();
+    lds_barrier();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float s = 0.f;
     for (int l = tid; l < len; l += 256) { const float x = expf(ps[l] - m); ps[l] = x; s += x; }
     s = wave_sum(s);
     if (lane == 0) red[4 + wave] = s;
-    __syncthreads();
+    lds_barrier();
     s = (red[4] + red[5]) + (red[6] + red[7]);
     for (int l = tid; l < Lp; l += 256) ps[l] = l < len ? ps[l] / s : 0.f;
-    __syncthreads();
+    lds_barrier();
 }
 
 // h1s[jj][c], jj = 0 .. 33 <-> position l = r0 - 1 + jj: relu(b1[c] + sum_{ch,k} w1[c][ch][k] x[ch][l + k - 2]), 0 outside [0, L)
-// (the second convolution zero-pads h1 at the ends).  xs[ch][pos] <-> position r0 - 3 + pos.
-__device__ __forceinline__ void conv1_h1(const float* xs, float* h1s, const float* __restrict__ w1, const float* __restrict__ b1,
-                                          int r0, int L, int tid) {
+// (the second convolution zero-pads h1 at the ends).  xs[ch][pos] <-> position r0 - 3 + pos.  w = w1[c = tid & 31][:][:], bb = b1[c].
+__device__ __forceinline__ void conv1_h1(const float* xs, float* h1s, const float (&w)[2 * K1], float bb, int r0, int L, int tid) {
     const int c = tid & 31;
-    float w[2 * K1];
-#pragma unroll
-    for (int q = 0; q < 2 * K1; ++q) w[q] = w1[c * 2 * K1 + q];
-    const float bb = b1[c];
     for (int jj = tid >> 5; jj < 34; jj += 8) {
         const int l = r0 - 1 + jj;
         float h = 0.f;
@@ -105,13 +104,52 @@ __device__ __forceinline__ void col_frags(const float* h1s, int rt, int li, int 
     }
 }
 
-// pre-activation of cond^T for the e-tile t (rows e = 16 t + 4 kg + r) and the row tile behind cf: acc[r] <-> (e, l = li)
-__device__ __forceinline__ f32x4 cond_pre(const unsigned short* __restrict__ w2img, int t, int li, int kg, const bf16x8 (&cf)[3]) {
+// pre-activation of cond^T for one e-tile (weight fragments wa of its 3 k-steps) and the row tile behind cf: acc[r] <-> (e = 4 kg + r, l = li)
+__device__ __forceinline__ f32x4 cond_pre(const bf16x8 (&wa)[3], const bf16x8 (&cf)[3]) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const unsigned short* wp = w2img + (size_t)(16 * t + li) * CK + 8 * kg;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) acc = mfma16(ld_frag(wp + 32 * s), cf[s], acc);
+    for (int s = 0; s < 3; ++s) acc = mfma16(wa[s], cf[s], acc);
     return acc;
+}
+
+// stage stamp k of frame i (workgroup (0, 0), thread 0): prof[(dir * 4096 + i) * 16 + k]
+#define CUMMF_STAMP(dir, k) do { if (p.prof && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && i < 4096) p.prof[((dir) * 4096 + i) * 16 + (k)] = wall_clock64(); } while (0)
+
+// Weight images are kept in MFMA FRAGMENT ORDER: the 16 x 32 block (row tile t, k-step s) of a [rows][K] matrix is one contiguous
+// 1 KiB piece, lane (li, kg) -> 16 bytes at 16 * lane = W[16 t + li][32 s + 8 kg .. + 7]; piece index t * (K / 32) + s.  A fragment
+// load is then ONE fully coalesced 1 KiB request.  (Read straight from the row-major image the same load touches 16 rows x 64
+// bytes: the address unit takes it apart lane by lane -- 64 cycles instead of 16 -- and a frame was bound by exactly that:
+// 17 us for the 20 k-steps of the key projection, profiles/r05_cumm_stage_stamps.log.)
+constexpr int FRAG = 512;      // elements per fragment piece
+__device__ __forceinline__ const unsigned short* frag_base(const unsigned short* img, int tile0, int ns, int lane) {
+    return img + ((size_t)tile0 * ns * 64 + lane) * 8;
+}
+
+constexpr int PD = 4;          // k-steps of streamed weight fragments in flight per wave (16 bytes per lane and fragment)
+
+// acc[q][rt] += W[rows 16 (wave + 4 q) + li][k] . tile[row 16 rt + li][k] over NS k-steps of 32: the weight fragments stream from the L2
+// through a rotating window of PD k-steps (wf holds steps 0 .. PD-1 on entry: requested at the kernel's top), the activation tile
+// sits in LDS (pitch KP elements).  Fully unrolled: every register index is static.
+template <int NQ, int NS, int KP>
+__device__ __forceinline__ void stream_gemm(f32x4 (&acc)[NQ][2], bf16x8 (&wf)[PD][NQ], const unsigned short* __restrict__ wp,
+                                            const unsigned short* tile, int li, int kg) {
+    const unsigned short* k0 = tile + li * KP + 8 * kg;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bf16x8 b0 = ld_frag(k0 + 32 * s), b1 = ld_frag(k0 + 16 * KP + 32 * s);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            acc[q][0] = mfma16(wf[s % PD][q], b0, acc[q][0]);
+            acc[q][1] = mfma16(wf[s % PD][q], b1, acc[q][1]);
+        }
+        if (s + PD < NS) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) wf[s % PD][q] = ld_frag(wp + (size_t)q * 4 * NS * FRAG + FRAG * (s + PD));
+        }
+        // the machine scheduler otherwise sinks every request to right in front of its first use (register pressure), which turns the
+        // window into one exposed L2 round trip per k-step
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------------------------
@@ -120,12 +158,14 @@ struct FwdP {
     const unsigned short *w2img, *wkimg;                  // [E][96], [A][E] 16-bit images
     const int* in_lens;
     float *attn, *logprob, *cumm_all, *tsave, *ebuf;
+    const float4* text_f;                                 // text in the lane order of this kernel's tiles (text_lane_k)
     int T, B, L;
     float inv_temp;
+    long long* prof;                                      // debug (ft_cumm_debug_prof): stage stamps of workgroup (0, 0), 100 MHz clock
 };
 
 template <int NQE, int NQA>
-__global__ __launch_bounds__(256, 2) void cummf_fwd_k(FwdP p, int i) {
+__global__ __launch_bounds__(256, 1) void cummf_fwd_k(FwdP p, int i) {
     constexpr int E = 64 * NQE, A = 64 * NQA, KPE = E + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.y, j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kg = lane >> 4;
@@ -137,32 +177,80 @@ __global__ __launch_bounds__(256, 2) void cummf_fwd_k(FwdP p, int i) {
     float* xs = ps + Lp;                                  // [2][XW]
     float* h1s = xs + 2 * XW;                             // [34][H1P]
     float* red = h1s + 34 * H1P + 2;                      // [4][32] (first 8 also serve the softmax)
-    unsigned short* kmt = reinterpret_cast<unsigned short*>(red + 128);   // [32][KPE]   (offset (Lp + 80 + 1124 + 128) * 4: 16-byte aligned)
+    float* qs = red + 128;                                // [A] Q_i[b]
+    float* vs = qs + A;                                   // [A]
+    float* b2s = vs + A;                                  // [E]
+    unsigned short* kmt = reinterpret_cast<unsigned short*>(b2s + E);     // [32][KPE]   (float offset Lp + 1332 + 2 A + E: 16-byte aligned)
+    float* tst = b2s + E;                                 // [32][A + 4] fp32: the saved tanh on its way out (over kmt, after the last read of it)
+    const bool work = i < T && r0 < len;
+    CUMMF_STAMP(0, 0);
+
+    // 0. everything that does not depend on frame i-1 is requested now: the first PD k-steps of this wave's W_key rows, all of its
+    //    w2 rows, its text rows, Q_i / v / b2 / w1 -- they arrive under the softmax of the previous frame
+    bf16x8 wf[PD][NQA];
+    bf16x8 w2f[NQE][3];
+    float4 txv[NQE][2];
+    float w1r[2 * K1], b1r = 0.f;
+    float4 stage_q = make_float4(0.f, 0.f, 0.f, 0.f), stage_v = stage_q, stage_b = stage_q;
+    const unsigned short* wkp = frag_base(p.wkimg, wave, E / 32, lane);
+    if (work) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+#pragma unroll
+            for (int q = 0; q < NQA; ++q) wf[d][q] = ld_frag(wkp + (size_t)q * 4 * (E / 32) * FRAG + FRAG * d);
+        const unsigned short* w2p = frag_base(p.w2img, wave, 3, lane);
+        const float4* txp = p.text_f + ((size_t)(b * gridDim.x + j) * 4 + wave) * NQE * 2 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < NQE; ++q) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) w2f[q][s] = ld_frag(w2p + (size_t)q * 4 * 3 * FRAG + FRAG * s);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) txv[q][rt] = txp[(q * 2 + rt) * 64];
+        }
+#pragma unroll
+        for (int q = 0; q < 2 * K1; ++q) w1r[q] = p.w1[(tid & 31) * 2 * K1 + q];
+        b1r = p.b1[tid & 31];
+        if (tid < A / 4) {
+            stage_q = *reinterpret_cast<const float4*>(p.Q + ((size_t)i * B + b) * A + 4 * tid);
+            stage_v = *reinterpret_cast<const float4*>(p.v + 4 * tid);
+        }
+        if (tid < E / 4) stage_b = *reinterpret_cast<const float4*>(p.b2 + 4 * tid);
+    }
+    __builtin_amdgcn_sched_barrier(0);                   // (requests stay up here)
+    const float* cprev = i > 0 ? p.cumm_all + ((size_t)(i - 1) * B + b) * L : nullptr;
+    float cpx = 0.f, cp0 = 0.f;                            // cumm_{i-1} at this thread's x position / at l = tid
+    if (i > 0) {
+        if (tid < 2 * 38) { const int l = r0 - HALO + (tid % 38); if (l >= 0 && l < L) cpx = cprev[l]; }
+        if (j == 0 && tid < L) cp0 = cprev[tid];
+    }
 
     // 1. attention of the previous frame
     if (i > 0) softmax_block(p.ebuf + (size_t)b * L, ps, red, len, Lp, tid);
-    else { for (int l = tid; l < Lp; l += 256) ps[l] = 0.f; __syncthreads(); }
-    const float* cprev = i > 0 ? p.cumm_all + ((size_t)(i - 1) * B + b) * L : nullptr;
+    else { for (int l = tid; l < Lp; l += 256) ps[l] = 0.f; lds_barrier(); }
     if (j == 0 && i > 0) {
         const size_t row = ((size_t)b * T + (i - 1)) * L;
         for (int l = tid; l < L; l += 256) {
             const float pl = ps[l];
             p.attn[row + l] = pl;
             p.logprob[row + l] = logf(pl + 1e-8f);
-            if (i < T) p.cumm_all[((size_t)i * B + b) * L + l] = cprev[l] + pl;
+            if (i < T) p.cumm_all[((size_t)i * B + b) * L + l] = (l == tid ? cp0 : cprev[l]) + pl;
         }
     }
-    if (i >= T || r0 >= len) return;
+    if (!work) return;
+    CUMMF_STAMP(0, 1);
     // 2. x = [cumm_i ; prev_i] for positions r0 - 3 .. r0 + 34, first convolution
     if (tid < 2 * 38) {
         const int ch = tid / 38, pos = tid - 38 * ch, l = r0 - HALO + pos;
         float x = 0.f;
-        if (l >= 0 && l < L && i > 0) x = ch == 0 ? cprev[l] + ps[l] : ps[l];
+        if (l >= 0 && l < L && i > 0) x = ch == 0 ? cpx + ps[l] : ps[l];
         xs[ch * XW + pos] = x;
     }
-    __syncthreads();
-    conv1_h1(xs, h1s, p.w1, p.b1, r0, L, tid);
-    __syncthreads();
+    if (tid < A / 4) { *reinterpret_cast<float4*>(qs + 4 * tid) = stage_q; *reinterpret_cast<float4*>(vs + 4 * tid) = stage_v; }
+    if (tid < E / 4) *reinterpret_cast<float4*>(b2s + 4 * tid) = stage_b;
+    lds_barrier();
+    conv1_h1(xs, h1s, w1r, b1r, r0, L, tid);
+    lds_barrier();
+    CUMMF_STAMP(0, 2);
     // 3. cond = sigmoid(conv2(h1)), km = text . cond -> LDS tile [32 rows][E]
     {
         bf16x8 cf[2][3];
@@ -170,46 +258,34 @@ __global__ __launch_bounds__(256, 2) void cummf_fwd_k(FwdP p, int i) {
         col_frags(h1s, 1, li, kg, cf[1]);
 #pragma unroll
         for (int q = 0; q < NQE; ++q) {
-            const int t = wave + 4 * q, e0 = 16 * t + 4 * kg;
-            const float4 bv = *reinterpret_cast<const float4*>(p.b2 + e0);
+            const int e0 = 16 * (wave + 4 * q) + 4 * kg;
+            const float4 bv = *reinterpret_cast<const float4*>(b2s + e0);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                const f32x4 c = cond_pre(p.w2img, t, li, kg, cf[rt]);
-                const int l = r0 + 16 * rt + li;
-                float4 tx = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (l < L) tx = *reinterpret_cast<const float4*>(p.text + ((size_t)l * B + b) * E + e0);
+                const f32x4 c = cond_pre(w2f[q], cf[rt]);
+                const float4 tx = txv[q][rt];
                 *reinterpret_cast<uint2*>(kmt + (16 * rt + li) * KPE + e0) =
                     pack4(tx.x * sigm(c[0] + bv.x), tx.y * sigm(c[1] + bv.y), tx.z * sigm(c[2] + bv.z), tx.w * sigm(c[3] + bv.w));
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
+    CUMMF_STAMP(0, 3);
     // 4. K^T = W_key km^T: wave w owns the a-tiles w, w + 4, ...; both row tiles
     f32x4 acc[NQA][2];
 #pragma unroll
     for (int q = 0; q < NQA; ++q) { acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    {
-        const unsigned short* wp = p.wkimg + (size_t)(16 * wave + li) * E + 8 * kg;
-        const unsigned short* k0 = kmt + li * KPE + 8 * kg;
-#pragma unroll 2
-        for (int s = 0; s < E / 32; ++s) {
-            const bf16x8 b0 = ld_frag(k0 + 32 * s), b1 = ld_frag(k0 + 16 * KPE + 32 * s);
-#pragma unroll
-            for (int q = 0; q < NQA; ++q) {
-                const bf16x8 a = ld_frag(wp + (size_t)q * 64 * E + 32 * s);
-                acc[q][0] = mfma16(a, b0, acc[q][0]);
-                acc[q][1] = mfma16(a, b1, acc[q][1]);
-            }
-        }
-    }
+    stream_gemm<NQA, E / 32, KPE>(acc, wf, wkp, kmt, li, kg);
+    CUMMF_STAMP(0, 4);
+    lds_barrier();                                        // everybody is done with the km tile: the tanh tile goes over it
     // 5. t = tanh(Q_i + K) (saved), e = v . t / temperature
     float part[2] = {0.f, 0.f};
     const size_t RA = (size_t)L * B;
 #pragma unroll
     for (int q = 0; q < NQA; ++q) {
         const int a0 = 16 * (wave + 4 * q) + 4 * kg;
-        const float4 qv = *reinterpret_cast<const float4*>(p.Q + ((size_t)i * B + b) * A + a0);
-        const float4 vv = *reinterpret_cast<const float4*>(p.v + a0);
+        const float4 qv = *reinterpret_cast<const float4*>(qs + a0);
+        const float4 vv = *reinterpret_cast<const float4*>(vs + a0);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             float4 tv;
@@ -218,8 +294,7 @@ __global__ __launch_bounds__(256, 2) void cummf_fwd_k(FwdP p, int i) {
             tv.z = 1.f - 2.f * rsig(C2 * (qv.z + acc[q][rt][2]));
             tv.w = 1.f - 2.f * rsig(C2 * (qv.w + acc[q][rt][3]));
             part[rt] = fmaf(vv.x, tv.x, fmaf(vv.y, tv.y, fmaf(vv.z, tv.z, fmaf(vv.w, tv.w, part[rt]))));
-            const int l = r0 + 16 * rt + li;
-            if (l < len) *reinterpret_cast<float4*>(p.tsave + ((size_t)i * RA + (size_t)l * B + b) * A + a0) = tv;
+            *reinterpret_cast<float4*>(tst + (16 * rt + li) * (A + 4) + a0) = tv;
         }
     }
 #pragma unroll
@@ -228,9 +303,17 @@ __global__ __launch_bounds__(256, 2) void cummf_fwd_k(FwdP p, int i) {
         part[rt] += __shfl_xor(part[rt], 32, 64);
         if (kg == 0) red[wave * 32 + 16 * rt + li] = part[rt];
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < 32 && r0 + tid < len)
         p.ebuf[(size_t)b * L + r0 + tid] = ((red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid])) * p.inv_temp;
+    // the saved tanh leaves row by row (a lane of the MFMA layout holds 16 bytes of 16 DIFFERENT rows: stored from there the address
+    // unit takes every request apart)
+    for (int idx = tid; idx < FWD_ROWS * (A / 4); idx += 256) {
+        const int row = idx / (A / 4), c4 = idx - row * (A / 4), l = r0 + row;
+        if (l < len) *reinterpret_cast<float4*>(p.tsave + ((size_t)i * RA + (size_t)l * B + b) * A + 4 * c4) =
+                         *reinterpret_cast<const float4*>(tst + row * (A + 4) + 4 * c4);
+    }
+    CUMMF_STAMP(0, 5);
 }
 
 // ---- backward -----------------------------------------------------------------------------------------------------------------
@@ -240,15 +323,18 @@ struct BwdP {
     const int* in_lens;
     const float *attn, *cumm_all, *tsave, *DV, *dattn, *dlogprob;
     float* gbuf;                                          // [2 parity][2: prev, cumm][B][L]
-    float *dQ, *dtext, *dv_part, *db2_part, *dw1_part, *db1_part;
+    float *dQ, *dv_part, *db2_part, *dw1_part, *db1_part;
+    const float4* text_b;                                 // text in the lane order of this kernel's tiles (text_lane_k)
+    float4* dtx;                                          // the gradient of text in the same order (own rows), accumulated over the frames
     unsigned short *dK_s, *km_s, *dp2_s, *col2_s;         // streams, [slot][l*B + b][A | E | E | 96]
     int T, B, L;
     float inv_temp;
+    long long* prof;
 };
 
 template <int NQE, int NQA>
 __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
-    constexpr int E = 64 * NQE, A = 64 * NQA, KPE = E + 8, KPA = A + 8, DCP = CK + 1;
+    constexpr int E = 64 * NQE, A = 64 * NQA, KPE = E + 8, KPA = A + 8, DCP = CK + 1, NW1 = NF * 2 * K1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.y, j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kg = lane >> 4;
     const int T = p.T, B = p.B, L = p.L, Lp = (L + 3) & ~3;
@@ -258,35 +344,73 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
     const int wg = b * gridDim.x + j;
     float* ps = reinterpret_cast<float*>(smem);           // [Lp] attention of frame i
     float* ss = ps + Lp;                                  // [Lp] dp, then s
-    float* xs = ss + Lp;                                  // [2][XW]
+    float* gcs = ss + Lp;                                 // [Lp] carried gradient of cumm
+    float* xs = gcs + Lp;                                 // [2][XW]
     float* h1s = xs + 2 * XW;                             // [34][H1P]
     float* red = h1s + 34 * H1P + 2;                      // [8]
-    float* dqs = red + 8;                                 // [A]
-    float* dvs = dqs + A;                                 // [A]
-    float* dcs = dvs + A;                                 // [32][DCP]  dcol2
-    float* dp1 = dcs + 32 * DCP;                          // [32][H1P]  dpre1 (rows 1 .. 30)
+    float* b2s = red + 8;                                 // [E]
+    float* w1s = b2s + E;                                 // [NW1]
+    float* dcs = w1s + NW1;                               // [4 waves][32][DCP]  dcol2 partials (K split over the waves)
+    float* dp1 = dcs + 4 * 32 * DCP;                      // [32][H1P]  dpre1 (rows 1 .. 30)
     unsigned short* dkt = reinterpret_cast<unsigned short*>(dp1 + 32 * H1P);      // [32][KPA]
     unsigned short* dpt = dkt + 32 * KPA;                                         // [32][KPE]
+    float* dqs = reinterpret_cast<float*>(dpt);           // [4 waves][dq A | dv A]: phase 2 only, before the dpre2 tile exists
+    static_assert(8 * A * 4 <= 32 * KPE * 2, "the dq / dv partials must fit the dpre2 tile they borrow");
     const size_t RA = (size_t)L * B;
     const size_t fr = (size_t)slot * RA;                  // first stream row of this frame
     const float* g_in = p.gbuf + (size_t)((i + 1) & 1) * 2 * B * L;
     float* g_out = p.gbuf + (size_t)(i & 1) * 2 * B * L;
+
+    CUMMF_STAMP(1, 0);
+    // 0. requests that do not depend on the carried gradients: the first PD k-steps of this wave's W_key^T rows, the saved tanh of
+    //    the tile's rows, v, w1 / b1 / b2
+    bf16x8 wf[PD][NQE];
+    const unsigned short* wtp = frag_base(p.wkT, wave, A / 32, lane);
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+#pragma unroll
+        for (int q = 0; q < NQE; ++q) wf[d][q] = ld_frag(wtp + (size_t)q * 4 * (A / 32) * FRAG + FRAG * d);
+    const int ag = tid & 31, rg = tid >> 5;
+    float4 tvr[4][A / 128], vv[A / 128];
+#pragma unroll
+    for (int m = 0; m < A / 128; ++m) vv[m] = *reinterpret_cast<const float4*>(p.v + 4 * ag + 128 * m);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int l = r0 + rg + 8 * n;
+#pragma unroll
+        for (int m = 0; m < A / 128; ++m) {
+            tvr[n][m] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (l >= 0 && l < len) tvr[n][m] = *reinterpret_cast<const float4*>(p.tsave + ((size_t)i * RA + (size_t)l * B + b) * A + 4 * ag + 128 * m);
+        }
+    }
+    float w1r[2 * K1];
+#pragma unroll
+    for (int q = 0; q < 2 * K1; ++q) w1r[q] = p.w1[(tid & 31) * 2 * K1 + q];
+    const float b1r = p.b1[tid & 31];
+    float4 stage_b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < E / 4) stage_b = *reinterpret_cast<const float4*>(p.b2 + 4 * tid);
+    float stage_w1[2] = {0.f, 0.f};
+    if (tid < NW1) stage_w1[0] = p.w1[tid];
+    if (tid + 256 < NW1) stage_w1[1] = p.w1[tid + 256];
+    __builtin_amdgcn_sched_barrier(0);                   // (requests stay up here)
 
     // 1. softmax backward: s_l = p_l (dp_l - sum_m p_m dp_m) / temperature
     const size_t arow = ((size_t)b * T + i) * L;
     float sum = 0.f;
     for (int l = tid; l < len; l += 256) {
         const float pl = p.attn[arow + l];
-        float d = p.DV[arow + l] + g_in[(size_t)b * L + l] + g_in[(size_t)B * L + (size_t)b * L + l];
+        const float gc = g_in[(size_t)B * L + (size_t)b * L + l];
+        float d = p.DV[arow + l] + g_in[(size_t)b * L + l] + gc;
         if (p.dattn) d += p.dattn[arow + l];
         if (p.dlogprob) d += p.dlogprob[arow + l] / (pl + 1e-8f);
-        ps[l] = pl; ss[l] = d;
+        ps[l] = pl; ss[l] = d; gcs[l] = gc;
         sum = fmaf(pl, d, sum);
     }
     sum = wave_sum(sum);
     if (lane == 0) red[wave] = sum;
-    for (int q = tid; q < 2 * A; q += 256) dqs[q] = 0.f;               // dqs | dvs
-    for (int q = tid; q < 32 * DCP; q += 256) dcs[q] = 0.f;
+    if (tid < E / 4) *reinterpret_cast<float4*>(b2s + 4 * tid) = stage_b;
+    if (tid < NW1) w1s[tid] = stage_w1[0];
+    if (tid + 256 < NW1) w1s[tid + 256] = stage_w1[1];
     // x_i for the positions r0 - 3 .. r0 + 34
     if (tid < 2 * 38) {
         const int ch = tid / 38, pos = tid - 38 * ch, l = r0 - HALO + pos;
@@ -294,11 +418,12 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
         if (l >= 0 && l < L) x = ch == 0 ? p.cumm_all[((size_t)i * B + b) * L + l] : (i > 0 ? p.attn[arow - L + l] : 0.f);
         xs[ch * XW + pos] = x;
     }
-    __syncthreads();
+    lds_barrier();
     sum = (red[0] + red[1]) + (red[2] + red[3]);
     for (int l = tid; l < len; l += 256) ss[l] = ps[l] * (ss[l] - sum) * p.inv_temp;
-    conv1_h1(xs, h1s, p.w1, p.b1, r0, L, tid);
-    __syncthreads();
+    conv1_h1(xs, h1s, w1r, b1r, r0, L, tid);
+    lds_barrier();
+    CUMMF_STAMP(1, 1);
     // col2 rows of the own positions -> stream (B operand of the dw2 GEMM)
     for (int idx = tid; idx < BWD_OWN * CK; idx += 256) {
         const int jo = idx / CK, ck = idx - CK * jo, l = o0 + jo;
@@ -307,16 +432,13 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
             p.col2_s[(fr + (size_t)l * B + b) * CK + ck] = f2op16(h1s[(l - r0 + k) * H1P + c]);
         }
     }
+    CUMMF_STAMP(1, 8);
     // 2. dK = s v (1 - t^2) for the 32 computed rows -> LDS tile (B operand of the dkm GEMM) + stream (own rows);
     //    dQ_i = sum_l dK, dv += sum_l s t over the own rows
     {
-        const int ag = tid & 31, rg = tid >> 5;
-        float4 dq[A / 128], dvp[A / 128], vv[A / 128];
+        float4 dq[A / 128], dvp[A / 128];
 #pragma unroll
-        for (int m = 0; m < A / 128; ++m) {
-            dq[m] = make_float4(0.f, 0.f, 0.f, 0.f); dvp[m] = dq[m];
-            vv[m] = *reinterpret_cast<const float4*>(p.v + 4 * ag + 128 * m);
-        }
+        for (int m = 0; m < A / 128; ++m) { dq[m] = make_float4(0.f, 0.f, 0.f, 0.f); dvp[m] = dq[m]; }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int row = rg + 8 * n, l = r0 + row;
@@ -326,8 +448,7 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
 #pragma unroll
             for (int m = 0; m < A / 128; ++m) {
                 const int a = 4 * ag + 128 * m;
-                float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid) tv = *reinterpret_cast<const float4*>(p.tsave + ((size_t)i * RA + (size_t)l * B + b) * A + a);
+                const float4 tv = tvr[n][m];
                 float4 dk;
                 dk.x = sl * vv[m].x * fmaf(-tv.x, tv.x, 1.f);
                 dk.y = sl * vv[m].y * fmaf(-tv.y, tv.y, 1.f);
@@ -343,53 +464,68 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
                 }
             }
         }
+        // the two row groups of a wave combine by one shuffle, the four waves through LDS ([wave][2 A]: dq | dv)
 #pragma unroll
         for (int m = 0; m < A / 128; ++m) {
-            const int a = 4 * ag + 128 * m;
-            atomicAdd(dqs + a, dq[m].x); atomicAdd(dqs + a + 1, dq[m].y); atomicAdd(dqs + a + 2, dq[m].z); atomicAdd(dqs + a + 3, dq[m].w);
-            atomicAdd(dvs + a, dvp[m].x); atomicAdd(dvs + a + 1, dvp[m].y); atomicAdd(dvs + a + 2, dvp[m].z); atomicAdd(dvs + a + 3, dvp[m].w);
+            dq[m].x += __shfl_xor(dq[m].x, 32, 64); dq[m].y += __shfl_xor(dq[m].y, 32, 64);
+            dq[m].z += __shfl_xor(dq[m].z, 32, 64); dq[m].w += __shfl_xor(dq[m].w, 32, 64);
+            dvp[m].x += __shfl_xor(dvp[m].x, 32, 64); dvp[m].y += __shfl_xor(dvp[m].y, 32, 64);
+            dvp[m].z += __shfl_xor(dvp[m].z, 32, 64); dvp[m].w += __shfl_xor(dvp[m].w, 32, 64);
+            if (lane < 32) {
+                *reinterpret_cast<float4*>(dqs + wave * 2 * A + 4 * ag + 128 * m) = dq[m];
+                *reinterpret_cast<float4*>(dqs + wave * 2 * A + A + 4 * ag + 128 * m) = dvp[m];
+            }
         }
     }
-    __syncthreads();
-    for (int a = tid; a < A; a += 256) {
-        atomicAdd(p.dQ + ((size_t)i * B + b) * A + a, dqs[a]);
-        p.dv_part[(size_t)wg * A + a] += dvs[a];
+    lds_barrier();
+    CUMMF_STAMP(1, 2);
+    for (int a = tid; a < 2 * A; a += 256) {              // (fire and forget: dQ is shared by an utterance's tiles, the dv slot is this workgroup's own)
+        const float x = (dqs[a] + dqs[2 * A + a]) + (dqs[4 * A + a] + dqs[6 * A + a]);
+        if (a < A) atomicAdd(p.dQ + ((size_t)i * B + b) * A + a, x);
+        else atomicAdd(p.dv_part + (size_t)wg * A + (a - A), x);
     }
     // 3. dkm^T = W_key^T dK^T: wave w owns the e-tiles w, w + 4, ...
     f32x4 acc[NQE][2];
 #pragma unroll
     for (int q = 0; q < NQE; ++q) { acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    stream_gemm<NQE, A / 32, KPA>(acc, wf, wtp, dkt, li, kg);
+    CUMMF_STAMP(1, 3);
+    lds_barrier();                                        // everybody is done with the dK tile: the km tile goes over it
+    unsigned short* kmt = dkt;                            // [32][KPE]
+    // 4. cond again (MFMA, K = 96); km -> stream; dtext += dkm . cond; dpre2 = dkm . text . cond (1 - cond) -> LDS + stream; db2.
+    //    All of the phase's reads are requested first; the w2^T fragments of phase 5 are requested as registers fall free.
+    bf16x8 w2t[(E / 32 / 4) * (CK / 16)];                 // this wave's k-steps (wave, wave + 4, ...) x the 6 row tiles of w2^T
     {
-        const unsigned short* wp = p.wkT + (size_t)(16 * wave + li) * A + 8 * kg;
-        const unsigned short* k0 = dkt + li * KPA + 8 * kg;
-#pragma unroll 2
-        for (int s = 0; s < A / 32; ++s) {
-            const bf16x8 b0 = ld_frag(k0 + 32 * s), b1 = ld_frag(k0 + 16 * KPA + 32 * s);
+        bf16x8 w2f[NQE][3];
+        float4 txv[NQE][2], dold[NQE][2];
+        const unsigned short* w2p = frag_base(p.w2img, wave, 3, lane);
+        const size_t lo = ((size_t)(b * gridDim.x + j) * 4 + wave) * NQE * 2 * 64 + lane;       // this lane's slot in the lane-order images
 #pragma unroll
-            for (int q = 0; q < NQE; ++q) {
-                const bf16x8 a = ld_frag(wp + (size_t)q * 64 * A + 32 * s);
-                acc[q][0] = mfma16(a, b0, acc[q][0]);
-                acc[q][1] = mfma16(a, b1, acc[q][1]);
+        for (int q = 0; q < NQE; ++q) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) w2f[q][s] = ld_frag(w2p + (size_t)q * 4 * 3 * FRAG + FRAG * s);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                txv[q][rt] = p.text_b[lo + (q * 2 + rt) * 64];
+                dold[q][rt] = p.dtx[lo + (q * 2 + rt) * 64];
             }
         }
-    }
-    // 4. cond again (MFMA, K = 96); km -> stream; dtext += dkm . cond; dpre2 = dkm . text . cond (1 - cond) -> LDS + stream; db2
-    {
+        __builtin_amdgcn_sched_barrier(0);
         bf16x8 cf[2][3];
         col_frags(h1s, 0, li, kg, cf[0]);
         col_frags(h1s, 1, li, kg, cf[1]);
+        const unsigned short* w2tp = frag_base(p.w2T, 0, E / 32, lane) + (size_t)wave * FRAG;     // k-steps wave, wave + 4, ...
 #pragma unroll
         for (int q = 0; q < NQE; ++q) {
-            const int t = wave + 4 * q, e0 = 16 * t + 4 * kg;
-            const float4 bv = *reinterpret_cast<const float4*>(p.b2 + e0);
+            const int e0 = 16 * (wave + 4 * q) + 4 * kg;
+            const float4 bv = *reinterpret_cast<const float4*>(b2s + e0);
             float4 dbv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                const f32x4 cp = cond_pre(p.w2img, t, li, kg, cf[rt]);
+                const f32x4 cp = cond_pre(w2f[q], cf[rt]);
                 const int row = 16 * rt + li, l = r0 + row;
                 const bool inl = l >= 0 && l < len;                    // beyond len: dK = 0, hence dkm = 0
-                float4 tx = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (inl) tx = *reinterpret_cast<const float4*>(p.text + ((size_t)l * B + b) * E + e0);
+                const float4 tx = txv[q][rt];
                 const float c0 = sigm(cp[0] + bv.x), c1 = sigm(cp[1] + bv.y), c2 = sigm(cp[2] + bv.z), c3 = sigm(cp[3] + bv.w);
                 const float d0 = acc[q][rt][0], d1 = acc[q][rt][1], d2 = acc[q][rt][2], d3 = acc[q][rt][3];
                 float4 dp;
@@ -397,14 +533,11 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
                 dp.z = d2 * tx.z * c2 * (1.f - c2); dp.w = d3 * tx.w * c3 * (1.f - c3);
                 const uint2 pk = pack4(dp.x, dp.y, dp.z, dp.w);
                 *reinterpret_cast<uint2*>(dpt + row * KPE + e0) = pk;
+                *reinterpret_cast<uint2*>(kmt + row * KPE + e0) = pack4(tx.x * c0, tx.y * c1, tx.z * c2, tx.w * c3);
                 if (inl && row >= HALO && row < HALO + BWD_OWN) {
-                    const size_t g = (fr + (size_t)l * B + b) * E + e0;
-                    *reinterpret_cast<uint2*>(p.km_s + g) = pack4(tx.x * c0, tx.y * c1, tx.z * c2, tx.w * c3);
-                    *reinterpret_cast<uint2*>(p.dp2_s + g) = pk;
-                    float4* dt = reinterpret_cast<float4*>(p.dtext + ((size_t)l * B + b) * E + e0);
-                    float4 o = *dt;
+                    float4 o = dold[q][rt];
                     o.x = fmaf(d0, c0, o.x); o.y = fmaf(d1, c1, o.y); o.z = fmaf(d2, c2, o.z); o.w = fmaf(d3, c3, o.w);
-                    *dt = o;
+                    p.dtx[lo + (q * 2 + rt) * 64] = o;
                     dbv.x += dp.x; dbv.y += dp.y; dbv.z += dp.z; dbv.w += dp.w;
                 }
             }
@@ -414,28 +547,46 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
                 dbv.z += __shfl_xor(dbv.z, off, 64); dbv.w += __shfl_xor(dbv.w, off, 64);
             }
             if (li == 0) {
-                float4* d = reinterpret_cast<float4*>(p.db2_part + (size_t)wg * E + e0);
-                float4 o = *d;
-                o.x += dbv.x; o.y += dbv.y; o.z += dbv.z; o.w += dbv.w;
-                *d = o;
+                float* d = p.db2_part + (size_t)wg * E + e0;
+                atomicAdd(d, dbv.x); atomicAdd(d + 1, dbv.y); atomicAdd(d + 2, dbv.z); atomicAdd(d + 3, dbv.w);
+            }
+            // w2^T fragments of the next phase: three per e-tile pass (k-step sk = q / 2 of this wave, row tiles 3 (q & 1) ..)
+            if (q < 2 * (E / 32 / 4)) {
+#pragma unroll
+                for (int mm = 0; mm < 3; ++mm) {
+                    const int sk = q / 2, m = 3 * (q & 1) + mm;
+                    w2t[sk * (CK / 16) + m] = ld_frag(w2tp + (size_t)m * (E / 32) * FRAG + (size_t)4 * FRAG * sk);
+                }
             }
         }
     }
-    __syncthreads();
-    // 5. dcol2^T [96][32 rows] = w2^T dpre2^T, the K = E reduction split over the waves, combined by LDS atomics
+    lds_barrier();
+    CUMMF_STAMP(1, 4);
+    // km and dpre2 of the own rows leave for the streams row by row, 16 bytes per lane (from the MFMA layout a request would cover
+    // 8 bytes of 16 different rows each)
+    for (int idx = tid; idx < BWD_OWN * (E / 8); idx += 256) {
+        const int jo = idx / (E / 8), c8 = idx - jo * (E / 8), l = o0 + jo;
+        if (l < len) {
+            const size_t g = (fr + (size_t)l * B + b) * E + 8 * c8;
+            *reinterpret_cast<uint4*>(p.km_s + g) = *reinterpret_cast<const uint4*>(kmt + (HALO + jo) * KPE + 8 * c8);
+            *reinterpret_cast<uint4*>(p.dp2_s + g) = *reinterpret_cast<const uint4*>(dpt + (HALO + jo) * KPE + 8 * c8);
+        }
+    }
+    CUMMF_STAMP(1, 7);
+    // 5. dcol2^T [96][32 rows] = w2^T dpre2^T, the K = E reduction split over the waves (partials side by side in LDS, summed by phase 6)
     {
+        static_assert(NQE >= 2 * (E / 32 / 4), "the w2^T fragments are requested during the e-tile passes");
         f32x4 a3[CK / 16][2];
 #pragma unroll
         for (int m = 0; m < CK / 16; ++m) { a3[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; a3[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        const unsigned short* wp = p.w2T + (size_t)li * E + 8 * kg;
-        const unsigned short* k0 = dpt + li * KPE + 8 * kg;
-        for (int s = wave; s < E / 32; s += 4) {
-            const bf16x8 b0 = ld_frag(k0 + 32 * s), b1 = ld_frag(k0 + 16 * KPE + 32 * s);
+        const unsigned short* k0 = dpt + li * KPE + 8 * kg + 32 * wave;
+#pragma unroll
+        for (int sk = 0; sk < E / 32 / 4; ++sk) {
+            const bf16x8 b0 = ld_frag(k0 + 128 * sk), b1 = ld_frag(k0 + 16 * KPE + 128 * sk);
 #pragma unroll
             for (int m = 0; m < CK / 16; ++m) {
-                const bf16x8 a = ld_frag(wp + (size_t)m * 16 * E + 32 * s);
-                a3[m][0] = mfma16(a, b0, a3[m][0]);
-                a3[m][1] = mfma16(a, b1, a3[m][1]);
+                a3[m][0] = mfma16(w2t[sk * (CK / 16) + m], b0, a3[m][0]);
+                a3[m][1] = mfma16(w2t[sk * (CK / 16) + m], b1, a3[m][1]);
             }
         }
 #pragma unroll
@@ -443,18 +594,22 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(dcs + (16 * rt + li) * DCP + 16 * m + 4 * kg + r, a3[m][rt][r]);
+                for (int r = 0; r < 4; ++r) dcs[(wave * 32 + 16 * rt + li) * DCP + 16 * m + 4 * kg + r] = a3[m][rt][r];
     }
-    __syncthreads();
+    lds_barrier();
+    CUMMF_STAMP(1, 5);
     // 6. dh1[l][c] = sum_k dcol2[l - k + 1][c, k]; dpre1 = dh1 where h1 > 0 (rows 1 .. 30 of the tile)
     for (int idx = tid; idx < 30 * 32; idx += 256) {
         const int jj = 1 + (idx >> 5), c = idx & 31, l = r0 + jj;
         float d = 0.f;
-        if (l >= 0 && l < L && h1s[(jj + 1) * H1P + c] > 0.f)
-            d = dcs[(jj + 1) * DCP + 3 * c] + dcs[jj * DCP + 3 * c + 1] + dcs[(jj - 1) * DCP + 3 * c + 2];
+        if (l >= 0 && l < L && h1s[(jj + 1) * H1P + c] > 0.f) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                d += dcs[(w * 32 + jj + 1) * DCP + 3 * c] + dcs[(w * 32 + jj) * DCP + 3 * c + 1] + dcs[(w * 32 + jj - 1) * DCP + 3 * c + 2];
+        }
         dp1[jj * H1P + c] = d;
     }
-    __syncthreads();
+    lds_barrier();
     // 7. gradients of this frame's inputs (own rows): ds2[l][ch] = sum_{c,k} w1[c][ch][k] dpre1[l - k + 2][c];
     //    prev feeds attn_{i-1} only, cumm every earlier attention
     {
@@ -466,7 +621,7 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
             for (int cc = 0; cc < 8; ++cc) {
                 const int c = 8 * part + cc;
 #pragma unroll
-                for (int k = 0; k < K1; ++k) d = fmaf(p.w1[c * 2 * K1 + ch * K1 + k], dp1[(jj - k + 2) * H1P + c], d);
+                for (int k = 0; k < K1; ++k) d = fmaf(w1s[c * 2 * K1 + ch * K1 + k], dp1[(jj - k + 2) * H1P + c], d);
             }
         }
         d += __shfl_xor(d, 1, 64);
@@ -474,30 +629,69 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
         const int l = o0 + jo;
         if (o < 2 * BWD_OWN && part == 0 && l < len) {
             if (ch == 1) g_out[(size_t)b * L + l] = d;
-            else g_out[(size_t)B * L + (size_t)b * L + l] = g_in[(size_t)B * L + (size_t)b * L + l] + d;
+            else g_out[(size_t)B * L + (size_t)b * L + l] = gcs[l] + d;
         }
     }
     // 8. dw1[c][ch][k] += sum_{own l} dpre1[l][c] x[ch][l + k - 2], db1[c] += sum_{own l} dpre1[l][c]
-    for (int idx = tid; idx < NF * 2 * K1 + NF; idx += 256) {
+    for (int idx = tid; idx < NW1 + NF; idx += 256) {
         float d = 0.f;
-        if (idx < NF * 2 * K1) {
+        if (idx < NW1) {
             const int c = idx / (2 * K1), rest = idx - c * 2 * K1, ch = rest / K1, k = rest - ch * K1;
             for (int jj = HALO; jj < HALO + BWD_OWN; ++jj) d = fmaf(dp1[jj * H1P + c], xs[ch * XW + jj + k + 1], d);
-            p.dw1_part[(size_t)wg * NF * 2 * K1 + idx] += d;
+            atomicAdd(p.dw1_part + (size_t)wg * NW1 + idx, d);
         } else {
-            const int c = idx - NF * 2 * K1;
+            const int c = idx - NW1;
             for (int jj = HALO; jj < HALO + BWD_OWN; ++jj) d += dp1[jj * H1P + c];
-            p.db1_part[(size_t)wg * NF + c] += d;
+            atomicAdd(p.db1_part + (size_t)wg * NF + c, d);
         }
     }
+    CUMMF_STAMP(1, 6);
 }
 
-// 16-bit image of a row-major fp32 matrix [rows][cols], optionally transposed: dst [cols][rows]
-__global__ void cvt16_k(const float* __restrict__ src, int rows, int cols, unsigned short* __restrict__ dst, int transpose) {
-    const long n = (long)rows * cols;
+// fragment-order 16-bit image of the logical matrix W [rows][K] (rows % 16 == 0, K % 32 == 0): W = src (row-major [rows][K]) or, with
+// `transpose`, W[r][c] = src[c][r] (src row-major [K][rows])
+__global__ void cvt16_frag_k(const float* __restrict__ src, int rows, int K, unsigned short* __restrict__ dst, int transpose) {
+    const long n = (long)rows * K;
+    const int ns = K / 32;
     for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
-        const int r = (int)(q / cols), c = (int)(q - (long)r * cols);
-        dst[transpose ? (size_t)c * rows + r : (size_t)q] = f2op16(src[q]);
+        const int r = (int)(q / K), c = (int)(q - (long)r * K);
+        const float v = transpose ? src[(size_t)c * rows + r] : src[q];
+        dst[((size_t)((r >> 4) * ns + (c >> 5)) * 64 + ((c & 31) >> 3) * 16 + (r & 15)) * 8 + (c & 7)] = f2op16(v);
+    }
+}
+// text [L][B][E] in the lane order of the frame kernels: out[(((b NJ + j) 4 + w) NQ + q) 2 + rt][lane] = the float4
+// text[l = own * j + off + 16 rt + li][b][16 (w + 4 q) + 4 kg ..], zeros outside [0, L)   (NQ = E / 64)
+__global__ void text_lane_k(const float* __restrict__ text, int B, int L, int E, int NJ, int own, int off, float4* __restrict__ out) {
+    const int NQ = E / 64;
+    const long n = (long)B * NJ * 4 * NQ * 2 * 64;
+    for (long x = blockIdx.x * (long)blockDim.x + threadIdx.x; x < n; x += (long)gridDim.x * blockDim.x) {
+        long y = x;
+        const int lane = (int)(y & 63); y >>= 6;
+        const int rt = (int)(y & 1); y >>= 1;
+        const int q = (int)(y % NQ); y /= NQ;
+        const int w = (int)(y & 3); y >>= 2;
+        const int j = (int)(y % NJ), b = (int)(y / NJ);
+        const int l = own * j + off + 16 * rt + (lane & 15), e0 = 16 * (w + 4 * q) + 4 * (lane >> 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l >= 0 && l < L) v = *reinterpret_cast<const float4*>(text + ((size_t)l * B + b) * E + e0);
+        out[x] = v;
+    }
+}
+// the inverse for the gradient: dtext[l][b][e0 ..] = the float4 of l's OWNER tile (j = l / own), zero beyond in_lens[b]
+__global__ void dtext_gather_k(const float4* __restrict__ dtx, const int* __restrict__ in_lens, int B, int L, int E, int NJ, float* __restrict__ dtext) {
+    const int NQ = E / 64, E4 = E / 4;
+    const long n = (long)L * B * E4;
+    for (long x = blockIdx.x * (long)blockDim.x + threadIdx.x; x < n; x += (long)gridDim.x * blockDim.x) {
+        const int e4 = (int)(x % E4);
+        const long lb = x / E4;
+        const int b = (int)(lb % B), l = (int)(lb / B);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l < in_lens[b]) {
+            const int j = l / BWD_OWN, row = l - BWD_OWN * j + HALO, rt = row >> 4, li = row & 15;
+            const int t = e4 >> 2, kg = e4 & 3, w = t & 3, q = t >> 2;
+            v = dtx[((((size_t)(b * NJ + j) * 4 + w) * NQ + q) * 2 + rt) * 64 + kg * 16 + li];
+        }
+        *reinterpret_cast<float4*>(dtext + ((size_t)l * B + b) * E + 4 * e4) = v;
     }
 }
 // out[c] = sum_w part[w][c]
@@ -514,6 +708,8 @@ inline size_t up256(size_t v) { return (v + 255) & ~size_t(255); }
 struct Carve {
     unsigned short *w2img, *wkimg, *wkT, *w2T;
     float *ebuf, *gbuf, *DV, *dv_part, *db2_part, *dw1_part, *db1_part;
+    float4 *text_l, *dtx;                                  // lane-order text (forward or backward tiling) and its gradient
+    size_t lane_bytes;
     unsigned short *dK_s, *km_s, *dp2_s, *col2_s;
     int Tc, nwg;
     size_t part_floats, stream_bytes, total;
@@ -526,7 +722,10 @@ Carve carve(void* base, int T, int L, int B, int E, int A, bool bwd) {
     c.w2img = reinterpret_cast<unsigned short*>(take((size_t)E * CK * 2 + 256));
     c.wkimg = reinterpret_cast<unsigned short*>(take((size_t)A * E * 2 + 256));
     c.ebuf = reinterpret_cast<float*>(take((size_t)B * L * 4));
+    c.lane_bytes = (size_t)B * cdiv(L, bwd ? BWD_OWN : FWD_ROWS) * 4 * (E / 64) * 2 * 64 * sizeof(float4);
+    c.text_l = reinterpret_cast<float4*>(take(c.lane_bytes));
     if (bwd) {
+        c.dtx = reinterpret_cast<float4*>(take(c.lane_bytes));
         c.wkT = reinterpret_cast<unsigned short*>(take((size_t)A * E * 2 + 256));
         c.w2T = reinterpret_cast<unsigned short*>(take((size_t)E * CK * 2 + 256));
         c.gbuf = reinterpret_cast<float*>(take((size_t)4 * B * L * 4));
@@ -562,9 +761,15 @@ int bgemm(const float* A, const float* Bm, float* C, int M, int N, int K, long s
     return ft_gemm(&a, st);
 }
 
+long long* g_cummf_prof = nullptr;
+
 #define CK_(x) do { int rc_ = (x); if (rc_ != FT_OK) return rc_; } while (0)
 
 }  // namespace
+
+// debug hook: device buffer [2][4096][16] int64 that later fused launches of THIS operand format fill with the stage stamps of
+// workgroup (0, 0) (100 MHz wall clock); NULL switches it off
+void FT_OPNAME(ftint_cummf_debug_prof)(void* dev_buf) { g_cummf_prof = reinterpret_cast<long long*>(dev_buf); }
 
 // shapes the fused kernels are instantiated for (config.json: n_text_dim 512 + n_speaker_dim 128 = 640 = n_attn_channels)
 int FT_OPNAME(ftint_cummf_supported)(const ft_cumm_attn_args* a) {
@@ -579,15 +784,17 @@ int FT_OPNAME(ftint_cummf_fwd)(const ft_cumm_attn_args* a, hipStream_t st) {
     const int T = a->T, B = a->B, L = a->L, E = a->E, A = a->A;
     const Carve c = carve(a->work, T, L, B, E, A, false);
     FT_CHECK_ARG(a->work_bytes >= c.total);
-    hipLaunchKernelGGL(cvt16_k, dim3(240), dim3(256), 0, st, a->w2, E, CK, c.w2img, 0);
-    hipLaunchKernelGGL(cvt16_k, dim3(1024), dim3(256), 0, st, a->w_key, A, E, c.wkimg, 0);
+    hipLaunchKernelGGL(cvt16_frag_k, dim3(240), dim3(256), 0, st, a->w2, E, CK, c.w2img, 0);
+    hipLaunchKernelGGL(cvt16_frag_k, dim3(1024), dim3(256), 0, st, a->w_key, A, E, c.wkimg, 0);
+    hipLaunchKernelGGL(text_lane_k, dim3(2048), dim3(256), 0, st, a->text, B, L, E, cdiv(L, FWD_ROWS), FWD_ROWS, 0, c.text_l);
     FT_CHECK_HIP(hipMemsetAsync(a->cumm_all, 0, sizeof(float) * (size_t)B * L, st));           // cumm_0 = 0
     FwdP p{};
     p.text = a->text; p.Q = a->Q; p.v = a->v; p.w1 = a->w1; p.b1 = a->b1; p.b2 = a->b2; p.w2img = c.w2img; p.wkimg = c.wkimg;
-    p.in_lens = a->in_lens; p.attn = a->attn; p.logprob = a->logprob; p.cumm_all = a->cumm_all; p.tsave = a->kproj_all; p.ebuf = c.ebuf;
-    p.T = T; p.B = B; p.L = L; p.inv_temp = 1.0f / a->temperature;
+    p.in_lens = a->in_lens; p.attn = a->attn; p.logprob = a->logprob; p.cumm_all = a->cumm_all; p.tsave = a->kproj_all; p.ebuf = c.ebuf; p.text_f = c.text_l;
+    p.T = T; p.B = B; p.L = L; p.inv_temp = 1.0f / a->temperature; p.prof = g_cummf_prof;
     const int Lp = (L + 3) & ~3;
-    const size_t lds = sizeof(float) * ((size_t)Lp + 2 * XW + 34 * H1P + 2 + 128) + (size_t)32 * (E + 8) * 2;
+    const size_t lds = sizeof(float) * ((size_t)Lp + 2 * XW + 34 * H1P + 2 + 128 + 2 * A + E) + sizeof(float) * 32 * (A + 4);   // (>= the km tile)
+    FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cummf_fwd_k<10, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const dim3 grid(cdiv(L, FWD_ROWS), B);
     for (int i = 0; i <= T; ++i)                     // launch T only closes frame T-1 (softmax, attn, logprob)
         hipLaunchKernelGGL((cummf_fwd_k<10, 10>), grid, dim3(256), lds, st, p, i);
@@ -603,25 +810,26 @@ int FT_OPNAME(ftint_cummf_bwd)(const ft_cumm_attn_args* a, const float* dctx, co
     const int T = a->T, B = a->B, L = a->L, E = a->E, A = a->A;
     const Carve c = carve(a->work, T, L, B, E, A, true);
     FT_CHECK_ARG(a->work_bytes >= c.total);
-    hipLaunchKernelGGL(cvt16_k, dim3(240), dim3(256), 0, st, a->w2, E, CK, c.w2img, 0);
-    hipLaunchKernelGGL(cvt16_k, dim3(240), dim3(256), 0, st, a->w2, E, CK, c.w2T, 1);
-    hipLaunchKernelGGL(cvt16_k, dim3(1024), dim3(256), 0, st, a->w_key, A, E, c.wkT, 1);
+    hipLaunchKernelGGL(cvt16_frag_k, dim3(240), dim3(256), 0, st, a->w2, E, CK, c.w2img, 0);
+    hipLaunchKernelGGL(cvt16_frag_k, dim3(240), dim3(256), 0, st, a->w2, CK, E, c.w2T, 1);           // w2^T [96][E]
+    hipLaunchKernelGGL(cvt16_frag_k, dim3(1024), dim3(256), 0, st, a->w_key, E, A, c.wkT, 1);        // W_key^T [E][A]
+    hipLaunchKernelGGL(text_lane_k, dim3(2048), dim3(256), 0, st, a->text, B, L, E, cdiv(L, BWD_OWN), BWD_OWN, -HALO, c.text_l);
+    FT_CHECK_HIP(hipMemsetAsync(c.dtx, 0, c.lane_bytes, st));
     FT_CHECK_HIP(hipMemsetAsync(c.gbuf, 0, sizeof(float) * (size_t)4 * B * L, st));
     FT_CHECK_HIP(hipMemsetAsync(c.dv_part, 0, sizeof(float) * c.part_floats, st));
     FT_CHECK_HIP(hipMemsetAsync(c.dK_s, 0, c.stream_bytes, st));          // rows nobody owns (l >= in_len, slack) stay zero for good
     FT_CHECK_HIP(hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)T * B * A, st));
-    FT_CHECK_HIP(hipMemsetAsync(dtext, 0, sizeof(float) * (size_t)L * B * E, st));
     // DV[b][t][l] = dctx[t][b] . V[l][b]  and  dV[l][b][:] = sum_t attn[b][t][l] dctx[t][b][:]
     CK_(bgemm(dctx, a->V, c.DV, T, L, A, (long)B * A, 1, 1, (long)B * A, L, B, A, A, (long)T * L, a->mode, st));
     CK_(bgemm(a->attn, dctx, dV, L, A, T, 1, L, (long)B * A, 1, (long)B * A, B, (long)T * L, A, A, a->mode, st));
     BwdP p{};
     p.text = a->text; p.v = a->v; p.w1 = a->w1; p.b1 = a->b1; p.b2 = a->b2; p.w2img = c.w2img; p.wkT = c.wkT; p.w2T = c.w2T;
     p.in_lens = a->in_lens; p.attn = a->attn; p.cumm_all = a->cumm_all; p.tsave = a->kproj_all; p.DV = c.DV; p.dattn = dattn; p.dlogprob = dlogprob;
-    p.gbuf = c.gbuf; p.dQ = dQ; p.dtext = dtext; p.dv_part = c.dv_part; p.db2_part = c.db2_part; p.dw1_part = c.dw1_part; p.db1_part = c.db1_part;
+    p.gbuf = c.gbuf; p.dQ = dQ; p.text_b = c.text_l; p.dtx = c.dtx; p.dv_part = c.dv_part; p.db2_part = c.db2_part; p.dw1_part = c.dw1_part; p.db1_part = c.db1_part;
     p.dK_s = c.dK_s; p.km_s = c.km_s; p.dp2_s = c.dp2_s; p.col2_s = c.col2_s;
-    p.T = T; p.B = B; p.L = L; p.inv_temp = 1.0f / a->temperature;
+    p.T = T; p.B = B; p.L = L; p.inv_temp = 1.0f / a->temperature; p.prof = g_cummf_prof;
     const int Lp = (L + 3) & ~3;
-    const size_t lds = sizeof(float) * ((size_t)2 * Lp + 2 * XW + 34 * H1P + 2 + 8 + 2 * A + 32 * (CK + 1) + 32 * H1P) +
+    const size_t lds = sizeof(float) * ((size_t)3 * Lp + 2 * XW + 34 * H1P + 2 + 8 + E + NF * 2 * K1 + 4 * 32 * (CK + 1) + 32 * H1P) +
                        (size_t)32 * (A + 8) * 2 + (size_t)32 * (E + 8) * 2;
     FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cummf_bwd_k<10, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const dim3 grid(cdiv(L, BWD_OWN), B);
@@ -643,6 +851,7 @@ int FT_OPNAME(ftint_cummf_bwd)(const ft_cumm_attn_args* a, const float* dctx, co
         first = false;
         hi = lo;
     }
+    hipLaunchKernelGGL(dtext_gather_k, dim3(2048), dim3(256), 0, st, c.dtx, a->in_lens, B, L, E, cdiv(L, BWD_OWN), dtext);
     hipLaunchKernelGGL(part_sum_k, dim3(cdiv(A, 256)), dim3(256), 0, st, c.dv_part, c.nwg, A, dv);
     hipLaunchKernelGGL(part_sum_k, dim3(cdiv(E, 256)), dim3(256), 0, st, c.db2_part, c.nwg, E, db2);
     hipLaunchKernelGGL(part_sum_k, dim3(cdiv(NF * 2 * K1, 256)), dim3(256), 0, st, c.dw1_part, c.nwg, NF * 2 * K1, dw1);

@@ -640,7 +640,7 @@ template <int R, int NL, bool F32> using template_rows = typename std::condition
 
 // F32 = false: 16-bit weight images, all of them register-resident (the round-2 kernel).
 // F32 = true (round 4): fp32 weights and fp32 FMAs -- the operand precision of the reference's inference.py:68-71; activations by the
-//   v_exp_f32 / v_rcp_f32 forms (|err| ~ 1e-7, mel 2.4e-7 from the oracle over 400 frames; -DFT_DECODE_LIBM=1 selects libm: +10 us per frame).  107 MB per flow do
+//   v_exp_f32 / v_rcp_f32 forms (|err| ~ 1e-7, mel 2.4e-7 from the fp32 CPU restatement over 400 frames; -DFT_DECODE_LIBM=1 selects libm: +10 us per frame).  107 MB per flow do
 //   not fit the register file (419 KB per CU against 512 KB of registers less the working set): the five recurrent / large input
 //   matrices of the LSTMs stay RESIDENT -- attention W_hh, layer-0 W_ih[:, :H] and W_hh, layer-1 W_hh in registers (256 per lane =
 //   the accumulation half of the register file, where the compiler parks them), layer-1 W_ih and layer-0 W_ih[:, H:] in 104 KB of
@@ -969,9 +969,10 @@ __global__ __launch_bounds__(256, 1) void dec_persist_k(const DecP p) {
 struct Layout {
     size_t off_dev, off_state, n_state, off_ctl, total;
     size_t h_att, c_att, h0, c0, h1, c1, q, ctx, u1, u2, prev, cumm, prev_attn, keyin, Kdyn, escore, obuf;
+    size_t hx, cx;             // state of the decoder layers beyond the second: [n_layers - 2][2][H], [n_layers - 2][H]
 };
 
-Layout make_layout(int H, int A, int M, int L, int E) {
+Layout make_layout(int H, int A, int M, int L, int E, int n_layers = 2) {
     Layout l{};
     auto up = [](size_t v) { return (v + 63) & ~size_t(63); };
     l.off_dev = 0;
@@ -982,6 +983,8 @@ Layout make_layout(int H, int A, int M, int L, int E) {
     l.q = take(A); l.ctx = take(A); l.u1 = take(H); l.u2 = take(H); l.prev = take(M);
     l.cumm = take(L); l.prev_attn = take(L); l.keyin = take((size_t)L * E); l.Kdyn = take((size_t)L * A);
     l.escore = take(L); l.obuf = take(2 * (size_t)M);
+    const size_t nx = n_layers > 2 ? (size_t)(n_layers - 2) : 0;
+    l.hx = take(2 * (size_t)H * nx + 16); l.cx = take((size_t)H * nx + 16);
     l.n_state = f;
     l.off_ctl = l.off_state + f * sizeof(float);
     l.total = l.off_ctl + 64;
@@ -1001,7 +1004,16 @@ __global__ void f32_to_bf16_k(const float* __restrict__ src, bf16_t* __restrict_
     }
 }
 
-int enqueue_frame(const DecodeDev& dP, int H, int A, int L, int M, bool cumm, hipStream_t st) {
+// decoder LSTM stack of any depth on the staged chain: layer 0 and 1 are stages 4 / 5 of the parameter block; a layer k >= 2 is stage 5
+// again with the block's layer-1 slots pointing at ITS weights and state (every stage kernel takes the block by value), and the
+// dense stage reads the last layer's output through the block's h1 slot
+struct Depth {
+    int n_layers = 2;
+    const float* const* extra = nullptr;       // 4 device pointers per layer >= 2
+    float *hx = nullptr, *cx = nullptr;
+};
+
+int enqueue_frame(const DecodeDev& dP, int H, int A, int L, int M, bool cumm, hipStream_t st, const Depth& dep = Depth()) {
     const dim3 b256(256), b1024(1024);
     const bool w16 = dP.att_w_hh16 != nullptr;
     if (w16) hipLaunchKernelGGL(dec_lstm16_k<0>, dim3(H), b256, 0, st, dP);
@@ -1013,14 +1025,28 @@ int enqueue_frame(const DecodeDev& dP, int H, int A, int L, int M, bool cumm, hi
     }
     hipLaunchKernelGGL(dec_score_k, dim3(cdiv(L, 4)), b256, 0, st, dP);
     hipLaunchKernelGGL(dec_ctx_k, dim3(cdiv(A, 64)), b256, sizeof(float) * (L + 4 + 256), st, dP);
-    if (w16) {
-        hipLaunchKernelGGL(dec_lstm16_k<1>, dim3(H), b256, 0, st, dP);
-        hipLaunchKernelGGL(dec_lstm16_k<2>, dim3(H), b256, 0, st, dP);
+    if (w16) hipLaunchKernelGGL(dec_lstm16_k<1>, dim3(H), b256, 0, st, dP);
+    else hipLaunchKernelGGL(dec_lstm_k<1>, dim3(cdiv(H, 4)), b256, 0, st, dP);
+    DecodeDev top = dP;                         // the block the dense stage sees: h1 = output of the LAST layer
+    if (dep.n_layers == 1) {
+        top.h1 = dP.h0;
     } else {
-        hipLaunchKernelGGL(dec_lstm_k<1>, dim3(cdiv(H, 4)), b256, 0, st, dP);
-        hipLaunchKernelGGL(dec_lstm_k<2>, dim3(cdiv(H, 4)), b256, 0, st, dP);
+        if (w16) hipLaunchKernelGGL(dec_lstm16_k<2>, dim3(H), b256, 0, st, dP);
+        else hipLaunchKernelGGL(dec_lstm_k<2>, dim3(cdiv(H, 4)), b256, 0, st, dP);
+        const float* below = dP.h1;
+        for (int k = 2; k < dep.n_layers; ++k) {
+            DecodeDev lk = dP;
+            const float* const* w = dep.extra + 4 * (k - 2);
+            lk.l1_w_ih = w[0]; lk.l1_w_hh = w[1]; lk.l1_b_ih = w[2]; lk.l1_b_hh = w[3];
+            lk.l1_w_ih16 = nullptr; lk.l1_w_hh16 = nullptr;
+            lk.h0 = const_cast<float*>(below);
+            lk.h1 = dep.hx + (size_t)(k - 2) * 2 * H; lk.c1 = dep.cx + (size_t)(k - 2) * H;
+            hipLaunchKernelGGL(dec_lstm_k<2>, dim3(cdiv(H, 4)), b256, 0, st, lk);
+            below = lk.h1;
+        }
+        top.h1 = const_cast<float*>(below);
     }
-    hipLaunchKernelGGL(dec_gemv_k<1>, dim3(cdiv(H, 4)), b256, 0, st, dP);
+    hipLaunchKernelGGL(dec_gemv_k<1>, dim3(cdiv(H, 4)), b256, 0, st, top);
     hipLaunchKernelGGL(dec_gemv_k<2>, dim3(cdiv(H, 4)), b256, 0, st, dP);
     hipLaunchKernelGGL(dec_conv_k, dim3(cdiv(2 * M, 4)), b256, 0, st, dP);
     hipLaunchKernelGGL(dec_fin_k, dim3(1), b256, 0, st, dP);
@@ -1029,8 +1055,8 @@ int enqueue_frame(const DecodeDev& dP, int H, int A, int L, int M, bool cumm, hi
 
 }  // namespace
 
-extern "C" size_t ft_decode_workspace_bytes(int L, int H, int A, int M, int E) {
-    return make_layout(H, A, M, L, E).total;
+extern "C" size_t ft_decode_workspace_bytes(int L, int H, int A, int M, int E, int n_layers) {
+    return make_layout(H, A, M, L, E, n_layers > 0 ? n_layers : 2).total;
 }
 
 namespace {
@@ -1059,7 +1085,11 @@ extern "C" size_t ft_decode_wimg_bytes(int H, int A, int M) {
 extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
     FT_CHECK_ARG(a != nullptr);
     FT_CHECK_ARG(a->att_w_ih && a->att_w_hh && a->att_b_ih && a->att_b_hh && a->w_query && a->v && a->K && a->V);
-    FT_CHECK_ARG(a->l0_w_ih && a->l0_w_hh && a->l0_b_ih && a->l0_b_hh && a->l1_w_ih && a->l1_w_hh && a->l1_b_ih && a->l1_b_hh);
+    const int n_layers = a->n_layers > 0 ? a->n_layers : 2;
+    FT_CHECK_ARG(a->l0_w_ih && a->l0_w_hh && a->l0_b_ih && a->l0_b_hh);
+    FT_CHECK_ARG(n_layers == 1 || (a->l1_w_ih && a->l1_w_hh && a->l1_b_ih && a->l1_b_hh));
+    FT_CHECK_ARG(n_layers <= 2 || a->extra_layers);
+    for (int k = 0; k < 4 * (n_layers - 2); ++k) FT_CHECK_ARG(a->extra_layers[k] != nullptr);
     FT_CHECK_ARG(a->d0_w && a->d0_b && a->d1_w && a->d1_b && a->conv_w && a->conv_b);
     FT_CHECK_ARG((a->gate_w == nullptr) == (a->gate_b == nullptr));
     FT_CHECK_ARG(a->residual && a->mel_out && a->attn_out && a->n_done_dev && a->work);
@@ -1067,7 +1097,7 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(a->work) % 64 == 0);
     const bool cumm = a->cond_w1 != nullptr;
     FT_CHECK_ARG(!cumm || (a->cond_b1 && a->cond_w2 && a->cond_b2 && a->w_key && a->enc && a->E >= 1));
-    const Layout lay = make_layout(a->H, a->A, a->M, a->L, cumm ? a->E : 1);
+    const Layout lay = make_layout(a->H, a->A, a->M, a->L, cumm ? a->E : 1, n_layers);
     FT_CHECK_ARG(a->work_bytes >= lay.total);
     if (sizeof(float) * ((size_t)a->L + 4 + 256) > 160 * 1024)
         return ft_fail(FT_EUNSUPPORTED, "ft_decode_flow: L=%d exceeds the LDS probability tile", a->L);
@@ -1099,7 +1129,9 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
         FT_CHECK_ARG(a->H % 8 == 0 && a->A % 8 == 0 && a->M % 8 == 0);
         size_t n[10];
         wimg_counts(a->H, a->A, a->M, n);
-        const float* src[10] = {a->att_w_ih, a->att_w_hh, a->w_query, a->l0_w_ih, a->l0_w_hh, a->l1_w_ih, a->l1_w_hh, a->d0_w, a->d1_w, a->conv_w};
+        // (depth 1: the layer-1 image slots hold copies of layer 0's recurrent matrix -- never read)
+        const float* src[10] = {a->att_w_ih, a->att_w_hh, a->w_query, a->l0_w_ih, a->l0_w_hh, n_layers == 1 ? a->l0_w_hh : a->l1_w_ih,
+                                n_layers == 1 ? a->l0_w_hh : a->l1_w_hh, a->d0_w, a->d1_w, a->conv_w};
         const bf16_t** dstp[10] = {&h.att_w_ih16, &h.att_w_hh16, &h.w_query16, &h.l0_w_ih16, &h.l0_w_hh16, &h.l1_w_ih16, &h.l1_w_hh16,
                                    &h.d0_w16, &h.d1_w16, &h.conv_w16};
         char* wp = reinterpret_cast<char*>(a->wimg);
@@ -1122,7 +1154,9 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
 
     // persistent path: 16-bit images or (round 4) the fp32 originals, the default model geometry, plain attention, every workgroup
     // resident on its own CU
-    if (a->persist_status && !cumm && !a->prior && !a->forced && a->H == 1024 && a->A == 640 && a->M == 80 && a->L <= 1024) {
+    Depth dep;
+    dep.n_layers = n_layers; dep.extra = a->extra_layers; dep.hx = fs + lay.hx; dep.cx = fs + lay.cx;
+    if (a->persist_status && n_layers == 2 && !cumm && !a->prior && !a->forced && a->H == 1024 && a->A == 640 && a->M == 80 && a->L <= 1024) {
         static int cus = -1;
         if (cus < 0) {
             int dev = 0;
@@ -1145,7 +1179,7 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
         }
     }
     if (!a->use_graph) {
-        for (int i = 0; i < a->N; ++i) enqueue_frame(dP, a->H, a->A, a->L, a->M, cumm, st);
+        for (int i = 0; i < a->N; ++i) enqueue_frame(dP, a->H, a->A, a->L, a->M, cumm, st, dep);
         FT_CHECK_LAUNCH();
         return FT_OK;
     }
@@ -1156,6 +1190,8 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
     {
         const unsigned char* c = reinterpret_cast<const unsigned char*>(&h);
         for (size_t k = 0; k < sizeof(DecodeDev); ++k) { key ^= c[k]; key *= 1099511628211ull; }
+        key ^= (uint64_t)n_layers; key *= 1099511628211ull;
+        for (int k = 0; k < 4 * (n_layers - 2); ++k) { key ^= reinterpret_cast<uintptr_t>(a->extra_layers[k]); key *= 1099511628211ull; }
     }
     hipGraphExec_t exec = nullptr;
     {
@@ -1178,7 +1214,7 @@ extern "C" int ft_decode_flow(const ft_decode_args* a, void* stream) {
             hipGraph_t graph = nullptr;
             hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
-                for (int f = 0; f < GRAPH_FRAMES; ++f) enqueue_frame(dP, a->H, a->A, a->L, a->M, cumm, cs);
+                for (int f = 0; f < GRAPH_FRAMES; ++f) enqueue_frame(dP, a->H, a->A, a->L, a->M, cumm, cs, dep);
                 e = hipStreamEndCapture(cs, &graph);
             }
             if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);

@@ -187,8 +187,8 @@ class AR_Step(nn.Module):
         super().__init__()
         if n_lstm_layers < 1:
             raise ValueError("n_lstm_layers must be >= 1")
-        self.n_lstm_layers = int(n_lstm_layers)       # training: any depth (one recurrence + one batched projection per layer);
-        self.use_cumm_attention = use_cumm_attention  # the decode kernels (infer) are built for the config.json depth of 2
+        self.n_lstm_layers = int(n_lstm_layers)       # any depth: training = one recurrence + one batched projection per layer; decode:
+        self.use_cumm_attention = use_cumm_attention  # depth 2 on the persistent launch, any other depth on the staged chain
         self.conv = nn.Conv1d(n_hidden, 2 * n_mel_channels, 1)
         self.conv.weight.data = 0.0 * self.conv.weight.data
         self.conv.bias.data = 0.0 * self.conv.bias.data
@@ -306,14 +306,29 @@ class AR_Step(nn.Module):
         return torch.cat(ctxs, 0), torch.cat(attns, 1), torch.cat(lps, 1)
 
     def infer(self, residual, text, attns=None, attn_prior=None, use_graph=None):
-        """Sequential inverse (flowtron.py:775-828), batch 1. residual [N,1,M], text [L,1,E].
-        Returns (mel [N',1,M], list of N' attention rows [1,1,L])."""
+        """Sequential inverse (flowtron.py:775-828). residual [N,B,M], text [L,B,E].
+        Returns (mel [N',B,M], list of N' attention rows [B,1,L]).
+        The decode kernels are batch-1 chains of GEMVs (inference.py decodes one utterance); B > 1 (round 5: the reference's loop takes
+        any batch, flowtron.py:775-828) decodes the utterances one after the other through the same kernels -- AR decode does not
+        shard, so a batch is B replicas.  With a gate layer every utterance stops at its OWN frame (the reference's
+        `if sigmoid(gate) > thr` raises for B > 1); frames behind an utterance's stop are zero, N' = the longest."""
         N, B, M = residual.shape
         if B != 1:
-            raise ValueError("Flowtron.infer is batch-1 (flowtron.py:901-930)")
-        if self.n_lstm_layers != 2:
-            raise NotImplementedError("the decode kernels (csrc/decode.hip) are built for n_lstm_layers == 2 (config.json:58); "
-                                      "training supports any depth")
+            outs = []
+            for b_ in range(B):
+                pr = None if attn_prior is None else attn_prior[b_:b_ + 1]
+                if attns is not None:
+                    raise ValueError("forced alignments (attns=) are taken one utterance at a time")
+                outs.append(self.infer(residual[:, b_:b_ + 1].contiguous(), text[:, b_:b_ + 1].contiguous(), None, pr, use_graph))
+            n = max(o[0].shape[0] for o in outs)
+            mel = residual.new_zeros(n, B, M)
+            Lk = text.shape[0]
+            att = residual.new_zeros(n, B, 1, Lk)
+            for b_, (m_, rows) in enumerate(outs):
+                mel[:m_.shape[0], b_] = m_[:, 0]
+                if rows:
+                    att[:len(rows), b_] = torch.stack([r_.reshape(1, Lk) for r_ in rows])
+            return mel, [att[t_] for t_ in range(n)]
         L.require_cuda(residual, text)
         Lk = text.shape[0]
         att = self.attention_layer
@@ -353,7 +368,8 @@ class AR_Step(nn.Module):
         cumm = self.use_cumm_attention
         E = text.shape[2]
         enc2d = text.reshape(Lk, E).contiguous()
-        nbytes = L.lib().ft_decode_workspace_bytes(Lk, H, A, M, E if cumm else 1)
+        nl = self.n_lstm_layers
+        nbytes = L.lib().ft_decode_workspace_bytes(Lk, H, A, M, E if cumm else 1, nl)
         work = bufs.get("work")
         if work is None or work.numel() < nbytes:
             work = bufs["work"] = torch.empty(nbytes, device=dev, dtype=torch.uint8)
@@ -367,7 +383,7 @@ class AR_Step(nn.Module):
             L.ptr(a.weight_ih_l0), L.ptr(a.weight_hh_l0), L.ptr(a.bias_ih_l0), L.ptr(a.bias_hh_l0),
             L.ptr(att.query.linear_layer.weight), L.ptr(att.v.linear_layer.weight), L.ptr(K), L.ptr(V),
             L.ptr(p.weight_ih_l0), L.ptr(p.weight_hh_l0), L.ptr(p.bias_ih_l0), L.ptr(p.bias_hh_l0),
-            L.ptr(p.weight_ih_l1), L.ptr(p.weight_hh_l1), L.ptr(p.bias_ih_l1), L.ptr(p.bias_hh_l1),
+            *([L.ptr(p.weight_ih_l1), L.ptr(p.weight_hh_l1), L.ptr(p.bias_ih_l1), L.ptr(p.bias_hh_l1)] if nl >= 2 else [None] * 4),
             L.ptr(d[0].linear_layer.weight), L.ptr(d[0].linear_layer.bias),
             L.ptr(d[1].linear_layer.weight), L.ptr(d[1].linear_layer.bias),
             L.ptr(self.conv.weight), L.ptr(self.conv.bias),
@@ -379,7 +395,13 @@ class AR_Step(nn.Module):
             L.ptr(cc.location_conv_hidden.conv.weight) if cumm else None, L.ptr(cc.location_conv_hidden.conv.bias) if cumm else None,
             L.ptr(cc.location_conv_out.conv.weight) if cumm else None, L.ptr(cc.location_conv_out.conv.bias) if cumm else None,
             L.ptr(att.key.linear_layer.weight) if cumm else None, L.ptr(enc2d) if cumm else None, E,
-            L.ptr(prior_rows), L.ptr(forced_rows), None, 0, None, None)
+            L.ptr(prior_rows), L.ptr(forced_rows), None, 0, None, None, nl, None)
+        if nl > 2:
+            # decoder layers beyond the second (any n_lstm_layers, flowtron.py:654-655): a host array of their four tensors each
+            ptrs = [L.ptr(getattr(p, "%s_l%d" % (nm, k))) for k in range(2, nl) for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+            extra = (C.c_void_p * len(ptrs))(*ptrs)
+            keep.append(extra)
+            args.extra_layers = C.cast(extra, C.c_void_p)
         persist = None
         if L.is16(L.mfma_mode()):               # 16-bit operand modes: bf16 images of the weights (half the bytes; fp32 activations)
             nb = L.lib().ft_decode_wimg_bytes(H, A, M)
@@ -387,7 +409,7 @@ class AR_Step(nn.Module):
             if wimg is None or wimg.numel() < nb or wimg.device != dev:
                 wimg = self._decode_wimg = torch.empty(nb, device=dev, dtype=torch.uint8)
             args.wimg, args.wimg_bytes = L.ptr(wimg), wimg.numel()
-        if os.environ.get("FLOWTRON_DECODE_PERSIST", "1") != "0" and ops.persist_usable(dev):
+        if nl == 2 and os.environ.get("FLOWTRON_DECODE_PERSIST", "1") != "0" and ops.persist_usable(dev):
             # one persistent launch per flow (csrc/decode.hip dec_persist_k) where its geometry applies: 16-bit weight images fully
             # register-resident, or (fp32 mode = the reference's inference precision, round 4) the fp32 originals with the recurrent
             # matrices resident and the rest streamed from the L2 / Infinity Cache

@@ -385,8 +385,13 @@ typedef struct {
      * stage's output vector to one another through tag-checked granules) instead of ten launches per frame.  *persist_status
      * becomes non-zero if a hand-off wait times out; the caller must check it before trusting the output. */
     void* persist_gran; int32_t* persist_status;
+    /* decoder LSTM depth (ABI 11; nn.LSTM(n_hidden + n_attn, n_hidden, n_lstm_layers), flowtron.py:654-655): 0 or 2 = the two layers
+     * above; 1 = layer 0 only (l1_* NULL); n > 2 = layers 2 .. n-1 from `extra_layers`, a HOST array of 4 (n - 2) device pointers
+     * {w_ih [4H,H], w_hh [4H,H], b_ih, b_hh} per layer.  Depths other than 2 run on the staged chain (one launch per stage and
+     * frame, hipGraph of 8 frames); layers beyond the second stream their fp32 weights in every operand mode. */
+    int n_layers; const float* const* extra_layers;
 } ft_decode_args;
-size_t ft_decode_workspace_bytes(int L, int H, int A, int M, int E);
+size_t ft_decode_workspace_bytes(int L, int H, int A, int M, int E, int n_layers);
 size_t ft_decode_wimg_bytes(int H, int A, int M);
 size_t ft_decode_persist_gran_bytes(void);
 int ft_decode_debug_prof(void* dev_buf);   /* debug: [512][12] int64 stage stamps of the persistent decode, NULL = off */
@@ -453,6 +458,9 @@ typedef struct {
 } ft_cumm_attn_args;
 size_t ft_cumm_attn_workspace_bytes(int T, int L, int B, int E, int A, int NF, int K1, int K2, int mode, int backward);
 int ft_cumm_attn_fused(const ft_cumm_attn_args* a);     /* 1: fwd / bwd of these arguments take the fused one-launch-per-frame path */
+/* debug: device buffer [2][4096][16] int64 that later fused launches fill with stage stamps of workgroup (0, 0) (100 MHz clock;
+ * [0] = forward, [1] = backward, second index = frame); NULL switches it off (scripts/exp/cumm_prof.py) */
+int ft_cumm_attn_debug_prof(void* dev_buf);
 int ft_cumm_attn_fwd(const ft_cumm_attn_args* a, void* stream);
 int ft_cumm_attn_bwd(const ft_cumm_attn_args* a, const float* dctx, const float* dattn, const float* dlogprob,
                      float* dQ, float* dV, float* dtext, float* dw_key, float* dv, float* dw1, float* db1, float* dw2, float* db2,
