@@ -47,16 +47,27 @@ constexpr int FWD_ROWS = 32, BWD_OWN = 26, HALO = 3;
 
 __device__ __forceinline__ bf16x8 ld_frag(const unsigned short* p) { return *reinterpret_cast<const bf16x8*>(p); }
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) { return make_uint2(pack_op16x2(a, b), pack_op16x2(c, d)); }
+// streamed-once traffic (the saved tanh, the 16-bit streams of the weight-gradient GEMMs) goes past the L2's working set -- the
+// weight fragments, the lane-order text and its gradient, which every frame touches again -- with the non-temporal hint
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+__device__ __forceinline__ void nt_store16(void* p, const void* lds_src) {
+    __builtin_nontemporal_store(*reinterpret_cast<const u32x4_t*>(lds_src), reinterpret_cast<u32x4_t*>(p));
+}
+__device__ __forceinline__ float4 nt_load16(const float* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 // Workgroup barrier that publishes LDS writes only.  __syncthreads() also drains vmcnt: every frame kernel keeps weight fragments
 // of LATER phases in flight across its barriers (requested at the kernel's top: a frame is a chain of short phases, each of which
 // would otherwise start with an exposed L2 round trip), and nothing here communicates through global memory inside a launch.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // softmax of e[0 .. len) into ps (ps[l] = 0 for len <= l < Lp); red: 8 floats
-__device__ __forceinline__ void softmax_block(const float* __restrict__ e, float* ps, float* red, int len, int Lp, int tid) {
+// (e0 = e[tid], requested by the caller ahead of everything else)
+__device__ __forceinline__ void softmax_block(const float* __restrict__ e, float e0, float* ps, float* red, int len, int Lp, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     float m = -INFINITY;
-    for (int l = tid; l < len; l += 256) { const float x = e[l]; ps[l] = x; m = fmaxf(m, x); }
+    for (int l = tid; l < len; l += 256) { const float x = l == tid ? e0 : e[l]; ps[l] = x; m = fmaxf(m, x); }
     m = wave_max(m);
     if (lane == 0) red[wave] = m;
     lds_barrier();
@@ -157,22 +168,48 @@ struct FwdP {
     const float *text, *Q, *v, *w1, *b1, *b2;
     const unsigned short *w2img, *wkimg;                  // [E][96], [A][E] 16-bit images
     const int* in_lens;
-    float *attn, *logprob, *cumm_all, *tsave, *ebuf;
+    float *attn, *logprob, *cumm_all, *tsave, *ebuf;      // ebuf [3][B][L]: scores of frame i accumulate in slot i % 3 (both column halves add)
     const float4* text_f;                                 // text in the lane order of this kernel's tiles (text_lane_k)
-    int T, B, L;
+    const int* items;                                     // [0] = count, then one word per workgroup: (b << 16) | (j << 4) | (zh0 << 1) | (nz - 1)
+    int T, B, L, NJ;
     float inv_temp;
     long long* prof;                                      // debug (ft_cumm_debug_prof): stage stamps of workgroup (0, 0), 100 MHz clock
 };
 
+// One workgroup per ITEM = (utterance b, 32-row tile j, column halves [zh0, zh0 + nz)) of a list built once per call from in_lens
+// (fwd_items_k): only tiles with valid rows, and -- when twice their number still fits the chip -- every tile as TWO workgroups that
+// own one column half each (wave w: a-tiles w + 4 q of its half).  A frame is bound by what ONE CU can pull from the L2 (64 bytes
+// per clock: 0.8 MB of W_key fragments per tile), and ~120 valid tiles leave half the chip idle; both halves redo the (small)
+// location convolutions and add their partial scores.  (A plain 3-D grid dealt the valid tiles unevenly to the XCDs: one XCD with
+// 33 of them on its 32 CUs made every frame two rounds.)
+constexpr int NSP = 2;
 template <int NQE, int NQA>
 __global__ __launch_bounds__(256, 1) void cummf_fwd_k(FwdP p, int i) {
-    constexpr int E = 64 * NQE, A = 64 * NQA, KPE = E + 8;
+    constexpr int E = 64 * NQE, A = 64 * NQA, KPE = E + 8, NQH = NQA / NSP, AH = A / NSP;
+    static_assert(NQA % NSP == 0 && AH == 64 * NQH, "column halves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.y, j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kg = lane >> 4;
+    if ((int)blockIdx.x >= p.items[0]) return;
+    const int item = p.items[1 + blockIdx.x];
+    const int b = item >> 16, j = (item >> 4) & 0xfff, zh0 = (item >> 1) & 1, nz = (item & 1) + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kg = lane >> 4;
     const int T = p.T, B = p.B, L = p.L, Lp = (L + 3) & ~3;
     const int len = min(p.in_lens[b], L);
     const int r0 = j * FWD_ROWS;
-    if (r0 >= len && j != 0) return;
+    const bool writer = j == 0 && zh0 == 0;               // closes frame i-1: attn, logprob, the running sum
+    if (r0 >= len && !writer) return;
+    const size_t BL = (size_t)B * L;
+    const float* e_in = p.ebuf + (size_t)((i + 2) % 3) * BL + (size_t)b * L;      // scores of frame i-1
+    float* e_out = p.ebuf + (size_t)(i % 3) * BL + (size_t)b * L;
+    float* e_zero = p.ebuf + (size_t)((i + 1) % 3) * BL + (size_t)b * L;         // last read by frame i-1: zeroed for frame i+1
+    // the inputs of the softmax first: vmcnt retires in order, so whatever is requested before them stands in front of them
+    float e_reg = -INFINITY;
+    if (i > 0 && tid < len) e_reg = e_in[tid];
+    const float* cprev = i > 0 ? p.cumm_all + ((size_t)(i - 1) * B + b) * L : nullptr;
+    float cpx = 0.f, cp0 = 0.f;                            // cumm_{i-1} at this thread's x position / at l = tid
+    if (i > 0) {
+        if (tid < 2 * 38) { const int l = r0 - HALO + (tid % 38); if (l >= 0 && l < L) cpx = cprev[l]; }
+        if (writer && tid < L) cp0 = cprev[tid];
+    }
     float* ps = reinterpret_cast<float*>(smem);           // [Lp]  attention of frame i-1
     float* xs = ps + Lp;                                  // [2][XW]
     float* h1s = xs + 2 * XW;                             // [34][H1P]
@@ -181,25 +218,25 @@ __global__ __launch_bounds__(256, 1) void cummf_fwd_k(FwdP p, int i) {
     float* vs = qs + A;                                   // [A]
     float* b2s = vs + A;                                  // [E]
     unsigned short* kmt = reinterpret_cast<unsigned short*>(b2s + E);     // [32][KPE]   (float offset Lp + 1332 + 2 A + E: 16-byte aligned)
-    float* tst = b2s + E;                                 // [32][A + 4] fp32: the saved tanh on its way out (over kmt, after the last read of it)
+    float* tst = b2s + E + 32 * KPE / 2;                  // [32][AH + 4] fp32: the saved tanh of a column half on its way out
     const bool work = i < T && r0 < len;
     CUMMF_STAMP(0, 0);
 
     // 0. everything that does not depend on frame i-1 is requested now: the first PD k-steps of this wave's W_key rows, all of its
     //    w2 rows, its text rows, Q_i / v / b2 / w1 -- they arrive under the softmax of the previous frame
-    bf16x8 wf[PD][NQA];
+    bf16x8 wf[PD][NQH];
     bf16x8 w2f[NQE][3];
     float4 txv[NQE][2];
     float w1r[2 * K1], b1r = 0.f;
     float4 stage_q = make_float4(0.f, 0.f, 0.f, 0.f), stage_v = stage_q, stage_b = stage_q;
-    const unsigned short* wkp = frag_base(p.wkimg, wave, E / 32, lane);
+    const unsigned short* wkp = frag_base(p.wkimg, wave + 4 * NQH * zh0, E / 32, lane);
     if (work) {
 #pragma unroll
         for (int d = 0; d < PD; ++d)
 #pragma unroll
-            for (int q = 0; q < NQA; ++q) wf[d][q] = ld_frag(wkp + (size_t)q * 4 * (E / 32) * FRAG + FRAG * d);
+            for (int q = 0; q < NQH; ++q) wf[d][q] = ld_frag(wkp + (size_t)q * 4 * (E / 32) * FRAG + FRAG * d);
         const unsigned short* w2p = frag_base(p.w2img, wave, 3, lane);
-        const float4* txp = p.text_f + ((size_t)(b * gridDim.x + j) * 4 + wave) * NQE * 2 * 64 + lane;
+        const float4* txp = p.text_f + ((size_t)(b * p.NJ + j) * 4 + wave) * NQE * 2 * 64 + lane;
 #pragma unroll
         for (int q = 0; q < NQE; ++q) {
 #pragma unroll
@@ -217,17 +254,12 @@ __global__ __launch_bounds__(256, 1) void cummf_fwd_k(FwdP p, int i) {
         if (tid < E / 4) stage_b = *reinterpret_cast<const float4*>(p.b2 + 4 * tid);
     }
     __builtin_amdgcn_sched_barrier(0);                   // (requests stay up here)
-    const float* cprev = i > 0 ? p.cumm_all + ((size_t)(i - 1) * B + b) * L : nullptr;
-    float cpx = 0.f, cp0 = 0.f;                            // cumm_{i-1} at this thread's x position / at l = tid
-    if (i > 0) {
-        if (tid < 2 * 38) { const int l = r0 - HALO + (tid % 38); if (l >= 0 && l < L) cpx = cprev[l]; }
-        if (j == 0 && tid < L) cp0 = cprev[tid];
-    }
 
     // 1. attention of the previous frame
-    if (i > 0) softmax_block(p.ebuf + (size_t)b * L, ps, red, len, Lp, tid);
+    if (i > 0) softmax_block(e_in, e_reg, ps, red, len, Lp, tid);
     else { for (int l = tid; l < Lp; l += 256) ps[l] = 0.f; lds_barrier(); }
-    if (j == 0 && i > 0) {
+    if (zh0 == 0 && r0 < len && tid < FWD_ROWS && r0 + tid < L) e_zero[r0 + tid] = 0.f;
+    if (writer && i > 0) {
         const size_t row = ((size_t)b * T + (i - 1)) * L;
         for (int l = tid; l < L; l += 256) {
             const float pl = ps[l];
@@ -271,47 +303,56 @@ __global__ __launch_bounds__(256, 1) void cummf_fwd_k(FwdP p, int i) {
     }
     lds_barrier();
     CUMMF_STAMP(0, 3);
-    // 4. K^T = W_key km^T: wave w owns the a-tiles w, w + 4, ...; both row tiles
-    f32x4 acc[NQA][2];
-#pragma unroll
-    for (int q = 0; q < NQA; ++q) { acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    stream_gemm<NQA, E / 32, KPE>(acc, wf, wkp, kmt, li, kg);
-    CUMMF_STAMP(0, 4);
-    lds_barrier();                                        // everybody is done with the km tile: the tanh tile goes over it
-    // 5. t = tanh(Q_i + K) (saved), e = v . t / temperature
-    float part[2] = {0.f, 0.f};
     const size_t RA = (size_t)L * B;
+    for (int zz = 0; zz < nz; ++zz) {
+        const int zh = zh0 + zz;
+        if (zz > 0) {                                     // (unsplit items only: the other half's fragments, one exposed round trip)
+            wkp = frag_base(p.wkimg, wave + 4 * NQH * zh, E / 32, lane);
 #pragma unroll
-    for (int q = 0; q < NQA; ++q) {
-        const int a0 = 16 * (wave + 4 * q) + 4 * kg;
-        const float4 qv = *reinterpret_cast<const float4*>(qs + a0);
-        const float4 vv = *reinterpret_cast<const float4*>(vs + a0);
+            for (int d = 0; d < PD; ++d)
+#pragma unroll
+                for (int q = 0; q < NQH; ++q) wf[d][q] = ld_frag(wkp + (size_t)q * 4 * (E / 32) * FRAG + FRAG * d);
+        }
+        // 4. K^T = W_key km^T: wave w owns the a-tiles w, w + 4, ... of the column half; both row tiles
+        f32x4 acc[NQH][2];
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) { acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        stream_gemm<NQH, E / 32, KPE>(acc, wf, wkp, kmt, li, kg);
+        if (zz == 0) CUMMF_STAMP(0, 4);
+        // 5. t = tanh(Q_i + K) (saved), e = v . t / temperature
+        float part[2] = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) {
+            const int ah = 16 * (wave + 4 * q) + 4 * kg, a0 = AH * zh + ah;       // column inside this half / in A
+            const float4 qv = *reinterpret_cast<const float4*>(qs + a0);
+            const float4 vv = *reinterpret_cast<const float4*>(vs + a0);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                float4 tv;
+                tv.x = 1.f - 2.f * rsig(C2 * (qv.x + acc[q][rt][0]));
+                tv.y = 1.f - 2.f * rsig(C2 * (qv.y + acc[q][rt][1]));
+                tv.z = 1.f - 2.f * rsig(C2 * (qv.z + acc[q][rt][2]));
+                tv.w = 1.f - 2.f * rsig(C2 * (qv.w + acc[q][rt][3]));
+                part[rt] = fmaf(vv.x, tv.x, fmaf(vv.y, tv.y, fmaf(vv.z, tv.z, fmaf(vv.w, tv.w, part[rt]))));
+                *reinterpret_cast<float4*>(tst + (16 * rt + li) * (AH + 4) + ah) = tv;
+            }
+        }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            float4 tv;
-            tv.x = 1.f - 2.f * rsig(C2 * (qv.x + acc[q][rt][0]));
-            tv.y = 1.f - 2.f * rsig(C2 * (qv.y + acc[q][rt][1]));
-            tv.z = 1.f - 2.f * rsig(C2 * (qv.z + acc[q][rt][2]));
-            tv.w = 1.f - 2.f * rsig(C2 * (qv.w + acc[q][rt][3]));
-            part[rt] = fmaf(vv.x, tv.x, fmaf(vv.y, tv.y, fmaf(vv.z, tv.z, fmaf(vv.w, tv.w, part[rt]))));
-            *reinterpret_cast<float4*>(tst + (16 * rt + li) * (A + 4) + a0) = tv;
+            part[rt] += __shfl_xor(part[rt], 16, 64);
+            part[rt] += __shfl_xor(part[rt], 32, 64);
+            if (kg == 0) red[wave * 32 + 16 * rt + li] = part[rt];
         }
-    }
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        part[rt] += __shfl_xor(part[rt], 16, 64);
-        part[rt] += __shfl_xor(part[rt], 32, 64);
-        if (kg == 0) red[wave * 32 + 16 * rt + li] = part[rt];
-    }
-    lds_barrier();
-    if (tid < 32 && r0 + tid < len)
-        p.ebuf[(size_t)b * L + r0 + tid] = ((red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid])) * p.inv_temp;
-    // the saved tanh leaves row by row (a lane of the MFMA layout holds 16 bytes of 16 DIFFERENT rows: stored from there the address
-    // unit takes every request apart)
-    for (int idx = tid; idx < FWD_ROWS * (A / 4); idx += 256) {
-        const int row = idx / (A / 4), c4 = idx - row * (A / 4), l = r0 + row;
-        if (l < len) *reinterpret_cast<float4*>(p.tsave + ((size_t)i * RA + (size_t)l * B + b) * A + 4 * c4) =
-                         *reinterpret_cast<const float4*>(tst + row * (A + 4) + 4 * c4);
+        lds_barrier();
+        if (tid < 32 && r0 + tid < len)
+            atomicAdd(e_out + r0 + tid, ((red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid])) * p.inv_temp);   // (two addends: order-free)
+        // the saved tanh leaves row by row (a lane of the MFMA layout holds 16 bytes of 16 DIFFERENT rows: stored from there the
+        // address unit takes every request apart)
+        for (int idx = tid; idx < FWD_ROWS * (AH / 4); idx += 256) {
+            const int row = idx / (AH / 4), c4 = idx - row * (AH / 4), l = r0 + row;
+            if (l < len) nt_store16(p.tsave + ((size_t)i * RA + (size_t)l * B + b) * A + AH * zh + 4 * c4, tst + row * (AH + 4) + 4 * c4);
+        }
+        if (zz + 1 < nz) lds_barrier();                   // (red / the tanh tile are written again)
     }
     CUMMF_STAMP(0, 5);
 }
@@ -326,7 +367,8 @@ struct BwdP {
     float *dQ, *dv_part, *db2_part, *dw1_part, *db1_part;
     const float4* text_b;                                 // text in the lane order of this kernel's tiles (text_lane_k)
     float4* dtx;                                          // the gradient of text in the same order (own rows), accumulated over the frames
-    unsigned short *dK_s, *km_s, *dp2_s, *col2_s;         // streams, [slot][l*B + b][A | E | E | 96]
+    unsigned short *dK_s, *km_s, *dp2_s, *col2_s;         // streams, [slot][rowbase[b] + l][A | E | E | 96]: VALID rows only, packed
+    const int* rowbase;                                   // [B + 1] exclusive prefix of min(in_lens, L): rows of a frame = rowbase[B]
     int T, B, L;
     float inv_temp;
     long long* prof;
@@ -357,11 +399,27 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
     float* dqs = reinterpret_cast<float*>(dpt);           // [4 waves][dq A | dv A]: phase 2 only, before the dpre2 tile exists
     static_assert(8 * A * 4 <= 32 * KPE * 2, "the dq / dv partials must fit the dpre2 tile they borrow");
     const size_t RA = (size_t)L * B;
-    const size_t fr = (size_t)slot * RA;                  // first stream row of this frame
+    const size_t fr = (size_t)slot * p.rowbase[B] + p.rowbase[b];      // stream row of (this frame, utterance b, l = 0)
     const float* g_in = p.gbuf + (size_t)((i + 1) & 1) * 2 * B * L;
     float* g_out = p.gbuf + (size_t)(i & 1) * 2 * B * L;
 
     CUMMF_STAMP(1, 0);
+    // the inputs of the softmax backward first (vmcnt retires in order): attention of frame i, dctx . V, the carried gradients
+    const size_t arow = ((size_t)b * T + i) * L;
+    float in_p = 0.f, in_d = 0.f, in_gc = 0.f;
+    if (tid < len) {
+        in_p = p.attn[arow + tid];
+        in_gc = g_in[(size_t)B * L + (size_t)b * L + tid];
+        in_d = p.DV[arow + tid] + g_in[(size_t)b * L + tid] + in_gc;
+        if (p.dattn) in_d += p.dattn[arow + tid];
+        if (p.dlogprob) in_d += p.dlogprob[arow + tid] / (in_p + 1e-8f);
+    }
+    float in_x = 0.f;                                     // x_i at this thread's position (r0 - 3 + tid % 38)
+    if (tid < 2 * 38) {
+        const int ch = tid / 38, l = r0 - HALO + (tid - 38 * ch);
+        if (l >= 0 && l < L) in_x = ch == 0 ? p.cumm_all[((size_t)i * B + b) * L + l] : (i > 0 ? p.attn[arow - L + l] : 0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // 0. requests that do not depend on the carried gradients: the first PD k-steps of this wave's W_key^T rows, the saved tanh of
     //    the tile's rows, v, w1 / b1 / b2
     bf16x8 wf[PD][NQE];
@@ -380,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
 #pragma unroll
         for (int m = 0; m < A / 128; ++m) {
             tvr[n][m] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (l >= 0 && l < len) tvr[n][m] = *reinterpret_cast<const float4*>(p.tsave + ((size_t)i * RA + (size_t)l * B + b) * A + 4 * ag + 128 * m);
+            if (l >= 0 && l < len) tvr[n][m] = nt_load16(p.tsave + ((size_t)i * RA + (size_t)l * B + b) * A + 4 * ag + 128 * m);
         }
     }
     float w1r[2 * K1];
@@ -395,14 +453,16 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
     __builtin_amdgcn_sched_barrier(0);                   // (requests stay up here)
 
     // 1. softmax backward: s_l = p_l (dp_l - sum_m p_m dp_m) / temperature
-    const size_t arow = ((size_t)b * T + i) * L;
     float sum = 0.f;
     for (int l = tid; l < len; l += 256) {
-        const float pl = p.attn[arow + l];
-        const float gc = g_in[(size_t)B * L + (size_t)b * L + l];
-        float d = p.DV[arow + l] + g_in[(size_t)b * L + l] + gc;
-        if (p.dattn) d += p.dattn[arow + l];
-        if (p.dlogprob) d += p.dlogprob[arow + l] / (pl + 1e-8f);
+        float pl = in_p, gc = in_gc, d = in_d;
+        if (l != tid) {                                   // (L > 256 only)
+            pl = p.attn[arow + l];
+            gc = g_in[(size_t)B * L + (size_t)b * L + l];
+            d = p.DV[arow + l] + g_in[(size_t)b * L + l] + gc;
+            if (p.dattn) d += p.dattn[arow + l];
+            if (p.dlogprob) d += p.dlogprob[arow + l] / (pl + 1e-8f);
+        }
         ps[l] = pl; ss[l] = d; gcs[l] = gc;
         sum = fmaf(pl, d, sum);
     }
@@ -412,12 +472,7 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
     if (tid < NW1) w1s[tid] = stage_w1[0];
     if (tid + 256 < NW1) w1s[tid + 256] = stage_w1[1];
     // x_i for the positions r0 - 3 .. r0 + 34
-    if (tid < 2 * 38) {
-        const int ch = tid / 38, pos = tid - 38 * ch, l = r0 - HALO + pos;
-        float x = 0.f;
-        if (l >= 0 && l < L) x = ch == 0 ? p.cumm_all[((size_t)i * B + b) * L + l] : (i > 0 ? p.attn[arow - L + l] : 0.f);
-        xs[ch * XW + pos] = x;
-    }
+    if (tid < 2 * 38) xs[(tid / 38) * XW + tid % 38] = in_x;
     lds_barrier();
     sum = (red[0] + red[1]) + (red[2] + red[3]);
     for (int l = tid; l < len; l += 256) ss[l] = ps[l] * (ss[l] - sum) * p.inv_temp;
@@ -429,7 +484,7 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
         const int jo = idx / CK, ck = idx - CK * jo, l = o0 + jo;
         if (l < len) {
             const int c = ck / 3, k = ck - 3 * c;
-            p.col2_s[(fr + (size_t)l * B + b) * CK + ck] = f2op16(h1s[(l - r0 + k) * H1P + c]);
+            p.col2_s[(fr + l) * CK + ck] = f2op16(h1s[(l - r0 + k) * H1P + c]);
         }
     }
     CUMMF_STAMP(1, 8);
@@ -457,7 +512,7 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
                 const uint2 pk = pack4(dk.x, dk.y, dk.z, dk.w);
                 *reinterpret_cast<uint2*>(dkt + row * KPA + a) = pk;
                 if (own) {
-                    *reinterpret_cast<uint2*>(p.dK_s + (fr + (size_t)l * B + b) * A + a) = pk;
+                    *reinterpret_cast<uint2*>(p.dK_s + (fr + l) * A + a) = pk;
                     dq[m].x += dk.x; dq[m].y += dk.y; dq[m].z += dk.z; dq[m].w += dk.w;
                     dvp[m].x = fmaf(sl, tv.x, dvp[m].x); dvp[m].y = fmaf(sl, tv.y, dvp[m].y);
                     dvp[m].z = fmaf(sl, tv.z, dvp[m].z); dvp[m].w = fmaf(sl, tv.w, dvp[m].w);
@@ -506,8 +561,12 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
             for (int s = 0; s < 3; ++s) w2f[q][s] = ld_frag(w2p + (size_t)q * 4 * 3 * FRAG + FRAG * s);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                txv[q][rt] = p.text_b[lo + (q * 2 + rt) * 64];
-                dold[q][rt] = p.dtx[lo + (q * 2 + rt) * 64];
+                const int row = 16 * rt + li, l = r0 + row;
+                txv[q][rt] = make_float4(0.f, 0.f, 0.f, 0.f); dold[q][rt] = txv[q][rt];
+                if (l >= 0 && l < len) {                   // (beyond len: dK = 0, hence dkm = 0 and nothing of the row is kept)
+                    txv[q][rt] = p.text_b[lo + (q * 2 + rt) * 64];
+                    if (row >= HALO && row < HALO + BWD_OWN) dold[q][rt] = p.dtx[lo + (q * 2 + rt) * 64];
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -567,9 +626,9 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
     for (int idx = tid; idx < BWD_OWN * (E / 8); idx += 256) {
         const int jo = idx / (E / 8), c8 = idx - jo * (E / 8), l = o0 + jo;
         if (l < len) {
-            const size_t g = (fr + (size_t)l * B + b) * E + 8 * c8;
-            *reinterpret_cast<uint4*>(p.km_s + g) = *reinterpret_cast<const uint4*>(kmt + (HALO + jo) * KPE + 8 * c8);
-            *reinterpret_cast<uint4*>(p.dp2_s + g) = *reinterpret_cast<const uint4*>(dpt + (HALO + jo) * KPE + 8 * c8);
+            const size_t g = (fr + l) * E + 8 * c8;
+            nt_store16(p.km_s + g, kmt + (HALO + jo) * KPE + 8 * c8);
+            nt_store16(p.dp2_s + g, dpt + (HALO + jo) * KPE + 8 * c8);
         }
     }
     CUMMF_STAMP(1, 7);
@@ -648,6 +707,24 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
     CUMMF_STAMP(1, 6);
 }
 
+// work list of the forward frames (one thread: B is small): tiles with valid rows only; every tile as two column-half workgroups
+// when 2 x tiles <= n_cu, else as one workgroup that walks both halves
+__global__ void fwd_items_k(const int* __restrict__ in_lens, int B, int L, int n_cu, int* __restrict__ items) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int nt = 0;
+    for (int b = 0; b < B; ++b) { const int len = min(max(in_lens[b], 1), L); nt += (len + FWD_ROWS - 1) / FWD_ROWS; }
+    const bool split = NSP * nt <= n_cu;
+    int n = 0;
+    for (int b = 0; b < B; ++b) {
+        const int len = min(max(in_lens[b], 1), L), tiles = (len + FWD_ROWS - 1) / FWD_ROWS;
+        for (int j = 0; j < tiles; ++j) {
+            if (split) { for (int z = 0; z < NSP; ++z) items[1 + n++] = (b << 16) | (j << 4) | (z << 1); }
+            else items[1 + n++] = (b << 16) | (j << 4) | (NSP - 1);
+        }
+    }
+    items[0] = n;
+}
+
 // fragment-order 16-bit image of the logical matrix W [rows][K] (rows % 16 == 0, K % 32 == 0): W = src (row-major [rows][K]) or, with
 // `transpose`, W[r][c] = src[c][r] (src row-major [K][rows])
 __global__ void cvt16_frag_k(const float* __restrict__ src, int rows, int K, unsigned short* __restrict__ dst, int transpose) {
@@ -695,12 +772,36 @@ __global__ void dtext_gather_k(const float4* __restrict__ dtx, const int* __rest
     }
 }
 // out[c] = sum_w part[w][c]
-__global__ void part_sum_k(const float* __restrict__ part, int nw, int n, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
+__global__ __launch_bounds__(256) void part_sum_k(const float* __restrict__ part, int nw, int n, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), y = threadIdx.x >> 6;
     float s = 0.f;
-    for (int w = 0; w < nw; ++w) s += part[(size_t)w * n + c];
-    out[c] = s;
+    if (c < n) for (int w = y; w < nw; w += 4) s += part[(size_t)w * n + c];
+    red[y][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (y == 0 && c < n) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// per call: rowbase [B + 1] (packed stream rows), rows_dev = {rows of a full chunk, rows of the top chunk}, and zeros in the 64 rows
+// behind either extent of the four streams (the GEMMs' last 32-row k-step and their tile over-reads end there; every row in front of
+// an extent is written by its owner tile in every chunk)
+__global__ __launch_bounds__(256) void bwd_setup_k(const int* __restrict__ in_lens, int B, int L, int Tc, int nf_top, int* __restrict__ rowbase,
+                                                   int* __restrict__ rows_dev, unsigned short* dK_s, unsigned short* km_s, unsigned short* dp2_s,
+                                                   unsigned short* col2_s, int A, int E) {
+    __shared__ int rv;
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < B; ++b) { rowbase[b] = acc; acc += min(max(in_lens[b], 0), L); }
+        rowbase[B] = acc;
+        rows_dev[0] = Tc * acc; rows_dev[1] = nf_top * acc;
+        rv = acc;
+    }
+    __syncthreads();
+    for (int e = 0; e < 2; ++e) {
+        const size_t r0 = (size_t)(e == 0 ? Tc : nf_top) * rv;
+        for (size_t x = threadIdx.x; x < (size_t)64 * A; x += 256) dK_s[r0 * A + x] = 0;
+        for (size_t x = threadIdx.x; x < (size_t)64 * E; x += 256) { km_s[r0 * E + x] = 0; dp2_s[r0 * E + x] = 0; }
+        for (size_t x = threadIdx.x; x < (size_t)64 * CK; x += 256) col2_s[r0 * CK + x] = 0;
+    }
 }
 
 inline size_t up256(size_t v) { return (v + 255) & ~size_t(255); }
@@ -708,6 +809,8 @@ inline size_t up256(size_t v) { return (v + 255) & ~size_t(255); }
 struct Carve {
     unsigned short *w2img, *wkimg, *wkT, *w2T;
     float *ebuf, *gbuf, *DV, *dv_part, *db2_part, *dw1_part, *db1_part;
+    int* items;                                            // forward work list
+    int *rowbase, *rows_dev;                               // backward: packed stream rows
     float4 *text_l, *dtx;                                  // lane-order text (forward or backward tiling) and its gradient
     size_t lane_bytes;
     unsigned short *dK_s, *km_s, *dp2_s, *col2_s;
@@ -721,11 +824,14 @@ Carve carve(void* base, int T, int L, int B, int E, int A, bool bwd) {
     auto take = [&](size_t bytes) { char* q = base ? reinterpret_cast<char*>(base) + off : nullptr; off += up256(bytes); return q; };
     c.w2img = reinterpret_cast<unsigned short*>(take((size_t)E * CK * 2 + 256));
     c.wkimg = reinterpret_cast<unsigned short*>(take((size_t)A * E * 2 + 256));
-    c.ebuf = reinterpret_cast<float*>(take((size_t)B * L * 4));
+    c.ebuf = reinterpret_cast<float*>(take((size_t)3 * B * L * 4));
+    c.items = reinterpret_cast<int*>(take(sizeof(int) * (1 + (size_t)NSP * B * cdiv(L, FWD_ROWS))));
     c.lane_bytes = (size_t)B * cdiv(L, bwd ? BWD_OWN : FWD_ROWS) * 4 * (E / 64) * 2 * 64 * sizeof(float4);
     c.text_l = reinterpret_cast<float4*>(take(c.lane_bytes));
     if (bwd) {
         c.dtx = reinterpret_cast<float4*>(take(c.lane_bytes));
+        c.rowbase = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)B + 1)));
+        c.rows_dev = reinterpret_cast<int*>(take(sizeof(int) * 2));
         c.wkT = reinterpret_cast<unsigned short*>(take((size_t)A * E * 2 + 256));
         c.w2T = reinterpret_cast<unsigned short*>(take((size_t)E * CK * 2 + 256));
         c.gbuf = reinterpret_cast<float*>(take((size_t)4 * B * L * 4));
@@ -736,11 +842,11 @@ Carve carve(void* base, int T, int L, int B, int E, int A, bool bwd) {
         c.db2_part = c.dv_part ? c.dv_part + (size_t)c.nwg * A : nullptr;
         c.dw1_part = c.dv_part ? c.db2_part + (size_t)c.nwg * E : nullptr;
         c.db1_part = c.dv_part ? c.dw1_part + (size_t)c.nwg * NF * 2 * K1 : nullptr;
-        // frames per chunk: ~1.5 GB of streams (the weight-gradient GEMMs run once per chunk)
+        // frames per chunk: <= ~0.8 GB of streams at full-length utterances (the weight-gradient GEMMs run once per chunk)
         const size_t per_frame = (size_t)L * B * (A + 2 * E + CK) * 2;
-        long tc = (long)(1500000000ull / per_frame);
+        long tc = (long)(800000000ull / per_frame);
         c.Tc = (int)(tc < 4 ? 4 : (tc > T ? T : tc));
-        const size_t rows = (size_t)c.Tc * L * B + 288;             // slack: the GEMM tiles read up to 256 columns / 32 rows past the end
+        const size_t rows = (size_t)c.Tc * L * B + 320;             // slack: the GEMM tiles read up to 256 columns / 32 rows past the end
         const size_t s0 = off;
         c.dK_s = reinterpret_cast<unsigned short*>(take(rows * A * 2));
         c.km_s = reinterpret_cast<unsigned short*>(take(rows * E * 2));
@@ -788,14 +894,24 @@ int FT_OPNAME(ftint_cummf_fwd)(const ft_cumm_attn_args* a, hipStream_t st) {
     hipLaunchKernelGGL(cvt16_frag_k, dim3(1024), dim3(256), 0, st, a->w_key, A, E, c.wkimg, 0);
     hipLaunchKernelGGL(text_lane_k, dim3(2048), dim3(256), 0, st, a->text, B, L, E, cdiv(L, FWD_ROWS), FWD_ROWS, 0, c.text_l);
     FT_CHECK_HIP(hipMemsetAsync(a->cumm_all, 0, sizeof(float) * (size_t)B * L, st));           // cumm_0 = 0
+    FT_CHECK_HIP(hipMemsetAsync(c.ebuf, 0, sizeof(float) * (size_t)3 * B * L, st));
+    static int n_cu = -1;
+    if (n_cu < 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const char* split_env = getenv("FT_CUMM_SPLIT");       // 0: never split a tile's columns over two workgroups (tests both item forms)
+    hipLaunchKernelGGL(fwd_items_k, dim3(1), dim3(64), 0, st, a->in_lens, B, L, (split_env && atoi(split_env) == 0) ? 0 : n_cu, c.items);
     FwdP p{};
     p.text = a->text; p.Q = a->Q; p.v = a->v; p.w1 = a->w1; p.b1 = a->b1; p.b2 = a->b2; p.w2img = c.w2img; p.wkimg = c.wkimg;
-    p.in_lens = a->in_lens; p.attn = a->attn; p.logprob = a->logprob; p.cumm_all = a->cumm_all; p.tsave = a->kproj_all; p.ebuf = c.ebuf; p.text_f = c.text_l;
-    p.T = T; p.B = B; p.L = L; p.inv_temp = 1.0f / a->temperature; p.prof = g_cummf_prof;
+    p.in_lens = a->in_lens; p.attn = a->attn; p.logprob = a->logprob; p.cumm_all = a->cumm_all; p.tsave = a->kproj_all; p.ebuf = c.ebuf; p.text_f = c.text_l; p.items = c.items;
+    p.T = T; p.B = B; p.L = L; p.NJ = cdiv(L, FWD_ROWS); p.inv_temp = 1.0f / a->temperature; p.prof = g_cummf_prof;
     const int Lp = (L + 3) & ~3;
-    const size_t lds = sizeof(float) * ((size_t)Lp + 2 * XW + 34 * H1P + 2 + 128 + 2 * A + E) + sizeof(float) * 32 * (A + 4);   // (>= the km tile)
+    const size_t lds = sizeof(float) * ((size_t)Lp + 2 * XW + 34 * H1P + 2 + 128 + 2 * A + E) + (size_t)32 * (E + 8) * 2 + sizeof(float) * 32 * (A / NSP + 4);
     FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cummf_fwd_k<10, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const dim3 grid(cdiv(L, FWD_ROWS), B);
+    FT_CHECK_ARG(B < 32768 && cdiv(L, FWD_ROWS) < 4096);
+    const dim3 grid(NSP * B * cdiv(L, FWD_ROWS));
     for (int i = 0; i <= T; ++i)                     // launch T only closes frame T-1 (softmax, attn, logprob)
         hipLaunchKernelGGL((cummf_fwd_k<10, 10>), grid, dim3(256), lds, st, p, i);
     FT_CHECK_LAUNCH();
@@ -817,7 +933,11 @@ int FT_OPNAME(ftint_cummf_bwd)(const ft_cumm_attn_args* a, const float* dctx, co
     FT_CHECK_HIP(hipMemsetAsync(c.dtx, 0, c.lane_bytes, st));
     FT_CHECK_HIP(hipMemsetAsync(c.gbuf, 0, sizeof(float) * (size_t)4 * B * L, st));
     FT_CHECK_HIP(hipMemsetAsync(c.dv_part, 0, sizeof(float) * c.part_floats, st));
-    FT_CHECK_HIP(hipMemsetAsync(c.dK_s, 0, c.stream_bytes, st));          // rows nobody owns (l >= in_len, slack) stay zero for good
+    {
+        const int n_chunks = cdiv(T, c.Tc), nf_top = T - (n_chunks - 1) * c.Tc;
+        hipLaunchKernelGGL(bwd_setup_k, dim3(1), dim3(256), 0, st, a->in_lens, B, L, c.Tc, nf_top, c.rowbase, c.rows_dev, c.dK_s, c.km_s, c.dp2_s,
+                           c.col2_s, A, E);
+    }
     FT_CHECK_HIP(hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)T * B * A, st));
     // DV[b][t][l] = dctx[t][b] . V[l][b]  and  dV[l][b][:] = sum_t attn[b][t][l] dctx[t][b][:]
     CK_(bgemm(dctx, a->V, c.DV, T, L, A, (long)B * A, 1, 1, (long)B * A, L, B, A, A, (long)T * L, a->mode, st));
@@ -826,7 +946,7 @@ int FT_OPNAME(ftint_cummf_bwd)(const ft_cumm_attn_args* a, const float* dctx, co
     p.text = a->text; p.v = a->v; p.w1 = a->w1; p.b1 = a->b1; p.b2 = a->b2; p.w2img = c.w2img; p.wkT = c.wkT; p.w2T = c.w2T;
     p.in_lens = a->in_lens; p.attn = a->attn; p.cumm_all = a->cumm_all; p.tsave = a->kproj_all; p.DV = c.DV; p.dattn = dattn; p.dlogprob = dlogprob;
     p.gbuf = c.gbuf; p.dQ = dQ; p.text_b = c.text_l; p.dtx = c.dtx; p.dv_part = c.dv_part; p.db2_part = c.db2_part; p.dw1_part = c.dw1_part; p.db1_part = c.db1_part;
-    p.dK_s = c.dK_s; p.km_s = c.km_s; p.dp2_s = c.dp2_s; p.col2_s = c.col2_s;
+    p.dK_s = c.dK_s; p.km_s = c.km_s; p.dp2_s = c.dp2_s; p.col2_s = c.col2_s; p.rowbase = c.rowbase;
     p.T = T; p.B = B; p.L = L; p.inv_temp = 1.0f / a->temperature; p.prof = g_cummf_prof;
     const int Lp = (L + 3) & ~3;
     const size_t lds = sizeof(float) * ((size_t)3 * Lp + 2 * XW + 34 * H1P + 2 + 8 + E + NF * 2 * K1 + 4 * 32 * (CK + 1) + 32 * H1P) +
@@ -839,11 +959,12 @@ int FT_OPNAME(ftint_cummf_bwd)(const ft_cumm_attn_args* a, const float* dctx, co
         const int lo = ((hi - 1) / c.Tc) * c.Tc, nf = hi - lo;
         for (int i = hi - 1; i >= lo; --i) hipLaunchKernelGGL((cummf_bwd_k<10, 10>), grid, dim3(256), lds, st, p, i, i - lo);
         FT_CHECK_LAUNCH();
-        // weight gradients of the chunk: both operands k-major (the reduction runs over frames x rows), split-K
+        // weight gradients of the chunk: both operands k-major (the reduction runs over frames x VALID rows: K is the capacity,
+        // k-steps beyond the device-side row count are not visited -- ft_gemm_img's compact reduction), split-K
         const long Kr = ((long)nf * (long)RA + 31) / 32 * 32;
         ft_gemm_img_args g{};
         g.alpha = 1.f; g.beta = first ? 0.f : 1.f; g.act = FT_ACT_NONE; g.flags = FT_GEMM_SPLITK; g.a_kmajor = 1; g.b_kmajor = 1;
-        g.K = (int)Kr;
+        g.K = (int)Kr; g.compact = 2; g.k_shift = 0; g.rows_dev = c.rows_dev + (nf == c.Tc ? 0 : 1);
         g.A = c.dK_s; g.lda = A; g.B = c.km_s; g.ldb = E; g.C = dw_key; g.ldc = E; g.M = A; g.N = E;
         CK_(FT_OPNAME(ft_gemm_img)(&g, st));
         g.A = c.dp2_s; g.lda = E; g.B = c.col2_s; g.ldb = CK; g.C = dw2; g.ldc = CK; g.M = E; g.N = CK;
@@ -852,9 +973,9 @@ int FT_OPNAME(ftint_cummf_bwd)(const ft_cumm_attn_args* a, const float* dctx, co
         hi = lo;
     }
     hipLaunchKernelGGL(dtext_gather_k, dim3(2048), dim3(256), 0, st, c.dtx, a->in_lens, B, L, E, cdiv(L, BWD_OWN), dtext);
-    hipLaunchKernelGGL(part_sum_k, dim3(cdiv(A, 256)), dim3(256), 0, st, c.dv_part, c.nwg, A, dv);
-    hipLaunchKernelGGL(part_sum_k, dim3(cdiv(E, 256)), dim3(256), 0, st, c.db2_part, c.nwg, E, db2);
-    hipLaunchKernelGGL(part_sum_k, dim3(cdiv(NF * 2 * K1, 256)), dim3(256), 0, st, c.dw1_part, c.nwg, NF * 2 * K1, dw1);
+    hipLaunchKernelGGL(part_sum_k, dim3(cdiv(A, 64)), dim3(256), 0, st, c.dv_part, c.nwg, A, dv);
+    hipLaunchKernelGGL(part_sum_k, dim3(cdiv(E, 64)), dim3(256), 0, st, c.db2_part, c.nwg, E, db2);
+    hipLaunchKernelGGL(part_sum_k, dim3(cdiv(NF * 2 * K1, 64)), dim3(256), 0, st, c.dw1_part, c.nwg, NF * 2 * K1, dw1);
     hipLaunchKernelGGL(part_sum_k, dim3(1), dim3(256), 0, st, c.db1_part, c.nwg, NF, db1);
     FT_CHECK_LAUNCH();
     return FT_OK;

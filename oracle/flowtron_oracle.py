@@ -394,7 +394,10 @@ def ar_step_infer(sd: SD, pfx: str, residual, enc, has_gate, temperature=1.0, ga
     v = sd[ap + "v.linear_layer.weight"][0]
     z = residual.new_zeros
     ha, ca = z(B, H), z(B, H)
-    h0, c0, h1, c1 = z(B, H), z(B, H), z(B, H), z(B, H)
+    n_layers = 0
+    while (pfx + "lstm.weight_ih_l%d" % n_layers) in sd:
+        n_layers += 1
+    hs, cs = [z(B, H) for _ in range(n_layers)], [z(B, H) for _ in range(n_layers)]
     prev = z(B, M)
     outs, attn_rows = [], []
     cumm_on = (pfx + "attn_cond_layer.location_conv_hidden.conv.weight") in sd
@@ -418,11 +421,11 @@ def ar_step_infer(sd: SD, pfx: str, residual, enc, has_gate, temperature=1.0, ga
             cumm = cumm + prev_attn
         ctx = torch.bmm(p[:, None, :], V)[:, 0]                           # [B,A]
         d = torch.cat([ha, ctx], 1)
-        h0, c0 = _lstm_step(d, h0, c0, sd[pfx + "lstm.weight_ih_l0"], sd[pfx + "lstm.weight_hh_l0"],
-                            sd[pfx + "lstm.bias_ih_l0"], sd[pfx + "lstm.bias_hh_l0"])
-        h1, c1 = _lstm_step(h0, h1, c1, sd[pfx + "lstm.weight_ih_l1"], sd[pfx + "lstm.weight_hh_l1"],
-                            sd[pfx + "lstm.bias_ih_l1"], sd[pfx + "lstm.bias_hh_l1"])
-        u = h1
+        u = d                                                              # nn.LSTM(.., n_lstm_layers) with carried (h, c), flowtron.py:654-655, :811-814
+        for k in range(len(hs)):
+            hs[k], cs[k] = _lstm_step(u, hs[k], cs[k], sd[pfx + "lstm.weight_ih_l%d" % k], sd[pfx + "lstm.weight_hh_l%d" % k],
+                                      sd[pfx + "lstm.bias_ih_l%d" % k], sd[pfx + "lstm.bias_hh_l%d" % k])
+            u = hs[k]
         for j in range(2):
             u = torch.tanh(u @ sd[pfx + "dense_layer.layers.%d.linear_layer.weight" % j].t()
                            + sd[pfx + "dense_layer.layers.%d.linear_layer.bias" % j])
@@ -430,7 +433,7 @@ def ar_step_infer(sd: SD, pfx: str, residual, enc, has_gate, temperature=1.0, ga
         log_s, b = o[:, :M], o[:, M:]
         prev = (residual[i] - b) / torch.exp(log_s)
         outs.append(prev)
-        attn_rows.append(p[0])
+        attn_rows.append(p[0] if B == 1 else p)                          # [L], or [B,L] for a batch (no gate: flowtron.py:823 needs B = 1)
         if has_gate:
             g = d @ sd[pfx + "gate_layer.linear_layer.weight"].t() + sd[pfx + "gate_layer.linear_layer.bias"]
             if gates_out is not None:

@@ -101,6 +101,44 @@ def test_infer_vs_reference_golden(name, use_graph):
         assert mad(mel_f, mel) < 1e-5
 
 
+@pytest.mark.parametrize("use_graph", ["0", "1"])
+def test_infer_depth_and_batch_vs_reference_golden(use_graph):
+    """Decode breadth: Flowtron.infer at decoder depths 1 and 3 (flowtron.py:654-655; staged chain: a layer beyond
+    the second is stage 5 again with its own weights and state) and for a batch of two utterances (flowtron.py:775-828; decoded one
+    after the other through the batch-1 kernels) against golden vectors of the REAL reference (tests/golden/infer_depth.pt,
+    make_golden_r5.py): mel 1e-4, attention rows 1e-5, the gated frame count.  fp32 operand mode, hipGraph on and off."""
+    import sys
+    import flowtron
+    sys.path.insert(0, GOLDEN)
+    import make_golden_r5 as G5
+    os.environ["FLOWTRON_DECODE_GRAPH"] = use_graph
+    os.environ["FLOWTRON_MFMA"] = "f32"
+    g = _load("infer_depth.pt")
+    for ref in g["cases"]:
+        case = ref["case"]
+        cfg, sd, residual, spk, text = G5.case_inputs(case)
+        m = flowtron.Flowtron(**cfg)
+        m.load_state_dict(sd)
+        m = m.cuda().eval()
+        mel, attns = m.infer(residual.cuda(), spk.cuda(), text.cuda(), gate_threshold=1.0)
+        assert mel.shape == ref["mel"].shape, case["name"]
+        assert mad(mel, ref["mel"]) < 1e-4, (case["name"], mad(mel, ref["mel"]))
+        for a, ra in zip(attns, ref["attn"]):                  # decode order; ours: N rows of [B,1,L], reference [B,N,L]
+            assert mad(torch.cat(a, 1), ra) < 1e-5, case["name"]
+        if "gated_frames" in ref:
+            mel_g, _ = m.infer(residual.cuda(), spk.cuda(), text.cuda(), gate_threshold=0.5)
+            assert mel_g.shape[2] == ref["gated_frames"], case["name"]
+    # 16-bit operand mode at depth 3: the layers beyond the second stream fp32 weights beside the images of the rest
+    os.environ["FLOWTRON_MFMA"] = "bf16"
+    ref = g["cases"][1]
+    cfg, sd, residual, spk, text = G5.case_inputs(ref["case"])
+    m = flowtron.Flowtron(**cfg)
+    m.load_state_dict(sd)
+    mel, _ = m.cuda().eval().infer(residual.cuda(), spk.cuda(), text.cuda(), gate_threshold=1.0)
+    os.environ["FLOWTRON_MFMA"] = "f32"
+    assert mad(mel, ref["mel"]) < 5e-2, mad(mel, ref["mel"])
+
+
 def test_infer_bf16_weight_images_and_persistent_decode_track_fp32_full_width():
     """bf16 operand mode decodes from bf16 IMAGES of the weights, by default as ONE persistent launch per flow (csrc/decode.hip
     dec_persist_k: 256 workgroups hand every stage vector to one another through tag-checked granules), else as the staged

@@ -2,6 +2,7 @@
 tests/golden/make_golden.py produced by executing the REAL reference
 (/root/reference/flowtron.py, audio_processing.py, scipy betabinom)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -309,3 +310,23 @@ def test_decoder_lstm_depths_one_and_three_vs_real_reference(golden_dir):
         for k, ref in c["grads"].items():
             denom = max(ref.norm().item(), 1e-5 * ref.numel() ** 0.5)
             assert (sd[k].grad - ref).norm().item() / denom < 2e-4, (case["n_lstm_layers"], k)
+
+
+def test_infer_depth_and_batch_vs_reference_golden(golden_dir):
+    """Flowtron.infer of the REAL reference (tests/golden/infer_depth.pt, make_golden_r5.py) at decoder depths 1 and 3
+    (flowtron.py:654-655) and for a batch of two utterances (:775-828 takes any batch when there is no gate layer): the oracle's
+    infer loop follows it -- mel, the attention rows of both flows, the gated frame count."""
+    sys.path.insert(0, golden_dir)
+    import make_golden_r5 as G5
+    g = _load(golden_dir, "infer_depth.pt")
+    for ref in g["cases"]:
+        case = ref["case"]
+        cfg, sd, residual, spk, text = G5.case_inputs(case)
+        mel, attns = O.infer(sd, cfg, residual, spk, text, gate_threshold=1.0)
+        assert mel.shape == ref["mel"].shape and _maxdiff(mel, ref["mel"]) < TOL, case["name"]
+        for a, ra in zip(attns, ref["attn"]):                      # decode order; reference rows [B, N, L]
+            a = a[None] if a.dim() == 2 else a.permute(1, 0, 2)
+            assert _maxdiff(a, ra) < TOL, case["name"]
+        if "gated_frames" in ref:
+            mel_g, _ = O.infer(sd, cfg, residual, spk, text, gate_threshold=0.5)
+            assert mel_g.shape[2] == ref["gated_frames"], case["name"]
