@@ -41,6 +41,7 @@ __device__ __forceinline__ float rsig(float x) { return __builtin_amdgcn_rcpf(__
 __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-L2E * x)); }
 
 constexpr int NF = 32, K1 = 5, K2 = 3, CK = NF * K2;      // location convolutions 2 -> 32 (k5) -> E (k3); CK = 96 = 3 k-steps
+constexpr int CKP = 128;                                   // row pitch of the col2 stream: 96 taps, a ONE (the bias gradient rides on the GEMM), zeros
 constexpr int XW = 40;                                     // x staging: 38 positions (32 rows + 3 either side) per channel
 constexpr int H1P = 33;                                    // h1 staging pitch (34 positions x 32 channels)
 constexpr int FWD_ROWS = 32, BWD_OWN = 26, HALO = 3;
@@ -364,7 +365,7 @@ struct BwdP {
     const int* in_lens;
     const float *attn, *cumm_all, *tsave, *DV, *dattn, *dlogprob;
     float* gbuf;                                          // [2 parity][2: prev, cumm][B][L]
-    float *dQ, *dv_part, *db2_part, *dw1_part, *db1_part;
+    float *dQ, *dv_part, *dw1_part, *db1_part;
     const float4* text_b;                                 // text in the lane order of this kernel's tiles (text_lane_k)
     float4* dtx;                                          // the gradient of text in the same order (own rows), accumulated over the frames
     unsigned short *dK_s, *km_s, *dp2_s, *col2_s;         // streams, [slot][rowbase[b] + l][A | E | E | 96]: VALID rows only, packed
@@ -480,11 +481,11 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
     lds_barrier();
     CUMMF_STAMP(1, 1);
     // col2 rows of the own positions -> stream (B operand of the dw2 GEMM)
-    for (int idx = tid; idx < BWD_OWN * CK; idx += 256) {
-        const int jo = idx / CK, ck = idx - CK * jo, l = o0 + jo;
+    for (int idx = tid; idx < BWD_OWN * CKP; idx += 256) {
+        const int jo = idx / CKP, ck = idx - CKP * jo, l = o0 + jo;
         if (l < len) {
             const int c = ck / 3, k = ck - 3 * c;
-            p.col2_s[(fr + l) * CK + ck] = f2op16(h1s[(l - r0 + k) * H1P + c]);
+            p.col2_s[(fr + l) * CKP + ck] = ck < CK ? f2op16(h1s[(l - r0 + k) * H1P + c]) : f2op16(ck == CK ? 1.f : 0.f);
         }
     }
     CUMMF_STAMP(1, 8);
@@ -578,7 +579,6 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
         for (int q = 0; q < NQE; ++q) {
             const int e0 = 16 * (wave + 4 * q) + 4 * kg;
             const float4 bv = *reinterpret_cast<const float4*>(b2s + e0);
-            float4 dbv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const f32x4 cp = cond_pre(w2f[q], cf[rt]);
@@ -597,17 +597,7 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
                     float4 o = dold[q][rt];
                     o.x = fmaf(d0, c0, o.x); o.y = fmaf(d1, c1, o.y); o.z = fmaf(d2, c2, o.z); o.w = fmaf(d3, c3, o.w);
                     p.dtx[lo + (q * 2 + rt) * 64] = o;
-                    dbv.x += dp.x; dbv.y += dp.y; dbv.z += dp.z; dbv.w += dp.w;
                 }
-            }
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                dbv.x += __shfl_xor(dbv.x, off, 64); dbv.y += __shfl_xor(dbv.y, off, 64);
-                dbv.z += __shfl_xor(dbv.z, off, 64); dbv.w += __shfl_xor(dbv.w, off, 64);
-            }
-            if (li == 0) {
-                float* d = p.db2_part + (size_t)wg * E + e0;
-                atomicAdd(d, dbv.x); atomicAdd(d + 1, dbv.y); atomicAdd(d + 2, dbv.z); atomicAdd(d + 3, dbv.w);
             }
             // w2^T fragments of the next phase: three per e-tile pass (k-step sk = q / 2 of this wave, row tiles 3 (q & 1) ..)
             if (q < 2 * (E / 32 / 4)) {
@@ -781,6 +771,14 @@ __global__ __launch_bounds__(256) void part_sum_k(const float* __restrict__ part
     __syncthreads();
     if (y == 0 && c < n) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+// dw2 [E][CK] and db2 [E] out of the GEMM's [E][CKP] result (column CK = the ones column's product = column sums of dpre2)
+__global__ void dw2_split_k(const float* __restrict__ x, int E, float* __restrict__ dw2, float* __restrict__ db2) {
+    const long q = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (q >= (long)E * (CK + 1)) return;
+    const int e = (int)(q / (CK + 1)), ck = (int)(q - (long)e * (CK + 1));
+    if (ck < CK) dw2[(size_t)e * CK + ck] = x[(size_t)e * CKP + ck];
+    else db2[e] = x[(size_t)e * CKP + CK];
+}
 // per call: rowbase [B + 1] (packed stream rows), rows_dev = {rows of a full chunk, rows of the top chunk}, and zeros in the 64 rows
 // behind either extent of the four streams (the GEMMs' last 32-row k-step and their tile over-reads end there; every row in front of
 // an extent is written by its owner tile in every chunk)
@@ -800,7 +798,7 @@ __global__ __launch_bounds__(256) void bwd_setup_k(const int* __restrict__ in_le
         const size_t r0 = (size_t)(e == 0 ? Tc : nf_top) * rv;
         for (size_t x = threadIdx.x; x < (size_t)64 * A; x += 256) dK_s[r0 * A + x] = 0;
         for (size_t x = threadIdx.x; x < (size_t)64 * E; x += 256) { km_s[r0 * E + x] = 0; dp2_s[r0 * E + x] = 0; }
-        for (size_t x = threadIdx.x; x < (size_t)64 * CK; x += 256) col2_s[r0 * CK + x] = 0;
+        for (size_t x = threadIdx.x; x < (size_t)64 * CKP; x += 256) col2_s[r0 * CKP + x] = 0;
     }
 }
 
@@ -808,12 +806,13 @@ inline size_t up256(size_t v) { return (v + 255) & ~size_t(255); }
 
 struct Carve {
     unsigned short *w2img, *wkimg, *wkT, *w2T;
-    float *ebuf, *gbuf, *DV, *dv_part, *db2_part, *dw1_part, *db1_part;
+    float *ebuf, *gbuf, *DV, *dv_part, *dw1_part, *db1_part;
     int* items;                                            // forward work list
     int *rowbase, *rows_dev;                               // backward: packed stream rows
     float4 *text_l, *dtx;                                  // lane-order text (forward or backward tiling) and its gradient
     size_t lane_bytes;
     unsigned short *dK_s, *km_s, *dp2_s, *col2_s;
+    float* dw2x;                                           // [E][CKP]: dw2 | db2 (column CK) as the GEMM leaves them
     int Tc, nwg;
     size_t part_floats, stream_bytes, total;
 };
@@ -837,22 +836,24 @@ Carve carve(void* base, int T, int L, int B, int E, int A, bool bwd) {
         c.gbuf = reinterpret_cast<float*>(take((size_t)4 * B * L * 4));
         c.DV = reinterpret_cast<float*>(take((size_t)B * T * L * 4));
         c.nwg = B * cdiv(L, BWD_OWN);
-        c.part_floats = (size_t)c.nwg * (A + E + NF * 2 * K1 + NF);
+        c.part_floats = (size_t)c.nwg * (A + NF * 2 * K1 + NF);
         c.dv_part = reinterpret_cast<float*>(take(c.part_floats * 4));
-        c.db2_part = c.dv_part ? c.dv_part + (size_t)c.nwg * A : nullptr;
-        c.dw1_part = c.dv_part ? c.db2_part + (size_t)c.nwg * E : nullptr;
+        c.dw1_part = c.dv_part ? c.dv_part + (size_t)c.nwg * A : nullptr;
         c.db1_part = c.dv_part ? c.dw1_part + (size_t)c.nwg * NF * 2 * K1 : nullptr;
-        // frames per chunk: <= ~0.8 GB of streams at full-length utterances (the weight-gradient GEMMs run once per chunk)
-        const size_t per_frame = (size_t)L * B * (A + 2 * E + CK) * 2;
-        long tc = (long)(800000000ull / per_frame);
-        c.Tc = (int)(tc < 4 ? 4 : (tc > T ? T : tc));
+        // frames per chunk: <= ~1.6 GB of streams at full-length utterances (the weight-gradient GEMMs run once per chunk)
+        const size_t per_frame = (size_t)L * B * (A + 2 * E + CKP) * 2;
+        long tc = (long)(1600000000ull / per_frame);
+        const char* tc_env = getenv("FT_CUMM_CHUNK");          // test hook: frames per chunk (the multi-chunk / two-set path at small T)
+        if (tc_env && atoi(tc_env) > 0) tc = atoi(tc_env);
+        c.Tc = (int)(tc < 1 ? 1 : (tc > T ? T : tc));
         const size_t rows = (size_t)c.Tc * L * B + 320;             // slack: the GEMM tiles read up to 256 columns / 32 rows past the end
         const size_t s0 = off;
         c.dK_s = reinterpret_cast<unsigned short*>(take(rows * A * 2));
         c.km_s = reinterpret_cast<unsigned short*>(take(rows * E * 2));
         c.dp2_s = reinterpret_cast<unsigned short*>(take(rows * E * 2));
-        c.col2_s = reinterpret_cast<unsigned short*>(take(rows * CK * 2));
+        c.col2_s = reinterpret_cast<unsigned short*>(take(rows * CKP * 2));
         c.stream_bytes = off - s0;
+        c.dw2x = reinterpret_cast<float*>(take((size_t)E * CKP * 4));
     }
     c.total = off + 256;
     return c;
@@ -945,7 +946,7 @@ int FT_OPNAME(ftint_cummf_bwd)(const ft_cumm_attn_args* a, const float* dctx, co
     BwdP p{};
     p.text = a->text; p.v = a->v; p.w1 = a->w1; p.b1 = a->b1; p.b2 = a->b2; p.w2img = c.w2img; p.wkT = c.wkT; p.w2T = c.w2T;
     p.in_lens = a->in_lens; p.attn = a->attn; p.cumm_all = a->cumm_all; p.tsave = a->kproj_all; p.DV = c.DV; p.dattn = dattn; p.dlogprob = dlogprob;
-    p.gbuf = c.gbuf; p.dQ = dQ; p.text_b = c.text_l; p.dtx = c.dtx; p.dv_part = c.dv_part; p.db2_part = c.db2_part; p.dw1_part = c.dw1_part; p.db1_part = c.db1_part;
+    p.gbuf = c.gbuf; p.dQ = dQ; p.text_b = c.text_l; p.dtx = c.dtx; p.dv_part = c.dv_part; p.dw1_part = c.dw1_part; p.db1_part = c.db1_part;
     p.dK_s = c.dK_s; p.km_s = c.km_s; p.dp2_s = c.dp2_s; p.col2_s = c.col2_s; p.rowbase = c.rowbase;
     p.T = T; p.B = B; p.L = L; p.inv_temp = 1.0f / a->temperature; p.prof = g_cummf_prof;
     const int Lp = (L + 3) & ~3;
@@ -954,27 +955,30 @@ int FT_OPNAME(ftint_cummf_bwd)(const ft_cumm_attn_args* a, const float* dctx, co
     FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cummf_bwd_k<10, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const dim3 grid(cdiv(L, BWD_OWN), B);
     const size_t RA = (size_t)L * B;
-    bool first = true;
-    for (int hi = T; hi > 0;) {
+    // (Measured and NOT taken: the chunk GEMMs on a side stream confined to 4 .. 24 CUs per XCD (hipExtStreamCreateWithCUMask), beside
+    // the next chunk's frames, which occupy only ~150 CUs: 155 - 190 ms per training step against 125 with everything in stream
+    // order -- the frames are bound by what their CU pulls from the L2, and the GEMMs' traffic sits in front of it.)
+    int k = 0;
+    for (int hi = T; hi > 0; ++k) {
         const int lo = ((hi - 1) / c.Tc) * c.Tc, nf = hi - lo;
         for (int i = hi - 1; i >= lo; --i) hipLaunchKernelGGL((cummf_bwd_k<10, 10>), grid, dim3(256), lds, st, p, i, i - lo);
         FT_CHECK_LAUNCH();
         // weight gradients of the chunk: both operands k-major (the reduction runs over frames x VALID rows: K is the capacity,
-        // k-steps beyond the device-side row count are not visited -- ft_gemm_img's compact reduction), split-K
+        // k-steps beyond the device-side row count are not visited -- ft_gemm_img's compact reduction), split-K.  The col2 stream
+        // carries a column of ones behind its 96 taps, so the second GEMM leaves db2 = column sums of dpre2 in column CK.
         const long Kr = ((long)nf * (long)RA + 31) / 32 * 32;
         ft_gemm_img_args g{};
-        g.alpha = 1.f; g.beta = first ? 0.f : 1.f; g.act = FT_ACT_NONE; g.flags = FT_GEMM_SPLITK; g.a_kmajor = 1; g.b_kmajor = 1;
+        g.alpha = 1.f; g.beta = k == 0 ? 0.f : 1.f; g.act = FT_ACT_NONE; g.flags = FT_GEMM_SPLITK; g.a_kmajor = 1; g.b_kmajor = 1;
         g.K = (int)Kr; g.compact = 2; g.k_shift = 0; g.rows_dev = c.rows_dev + (nf == c.Tc ? 0 : 1);
         g.A = c.dK_s; g.lda = A; g.B = c.km_s; g.ldb = E; g.C = dw_key; g.ldc = E; g.M = A; g.N = E;
         CK_(FT_OPNAME(ft_gemm_img)(&g, st));
-        g.A = c.dp2_s; g.lda = E; g.B = c.col2_s; g.ldb = CK; g.C = dw2; g.ldc = CK; g.M = E; g.N = CK;
+        g.A = c.dp2_s; g.lda = E; g.B = c.col2_s; g.ldb = CKP; g.C = c.dw2x; g.ldc = CKP; g.M = E; g.N = CK + 1;
         CK_(FT_OPNAME(ft_gemm_img)(&g, st));
-        first = false;
         hi = lo;
     }
+    hipLaunchKernelGGL(dw2_split_k, dim3(cdiv((long)E * (CK + 1), 256)), dim3(256), 0, st, c.dw2x, E, dw2, db2);
     hipLaunchKernelGGL(dtext_gather_k, dim3(2048), dim3(256), 0, st, c.dtx, a->in_lens, B, L, E, cdiv(L, BWD_OWN), dtext);
     hipLaunchKernelGGL(part_sum_k, dim3(cdiv(A, 64)), dim3(256), 0, st, c.dv_part, c.nwg, A, dv);
-    hipLaunchKernelGGL(part_sum_k, dim3(cdiv(E, 64)), dim3(256), 0, st, c.db2_part, c.nwg, E, db2);
     hipLaunchKernelGGL(part_sum_k, dim3(cdiv(NF * 2 * K1, 64)), dim3(256), 0, st, c.dw1_part, c.nwg, NF * 2 * K1, dw1);
     hipLaunchKernelGGL(part_sum_k, dim3(1), dim3(256), 0, st, c.db1_part, c.nwg, NF, db1);
     FT_CHECK_LAUNCH();
