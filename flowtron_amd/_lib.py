@@ -63,6 +63,7 @@ SUMSQ_PARTIALS = 1024      # FT_SUMSQ_PARTIALS: floats of scratch ft_sumsq needs
 SIGNATURES = {
     "ft_abi_version": ([], _i),
     "ft_last_error": ([], C.c_char_p),
+    "ft_debug_hold_cus": ([_i, _l, _p], _i),
     "ft_gemm": ([C.POINTER(GemmArgs), _p], _i),
     "ft_gemm_workspace_bytes": ([C.POINTER(GemmArgs)], _sz),
     "ft_bf16_image_bytes": ([_l, _l], _sz),

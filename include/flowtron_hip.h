@@ -75,6 +75,9 @@ enum { FT_GEMM_SPLITK = 1 };
 
 int ft_abi_version(void);
 const char* ft_last_error(void);
+/* test hook: n_wg workgroups that each hold a whole CU for `ticks` of the 100 MHz wall clock (clamped to 5 s) on `stream` -- a
+ * stand-in for a foreign kernel (an in-flight collective) beside a whole-chip persistent launch (tests/test_gpu_dist.py) */
+int ft_debug_hold_cus(int n_wg, int64_t ticks, void* stream);
 
 /* ---- GEMM ---------------------------------------------------------------
  * C[b][m][n] = act( alpha * sum_k A[b](m,k) * B[b](k,n) + beta * C[b][m][n] + bias[n] )

@@ -6,6 +6,7 @@
   * world_size 2 (self-skips unless two GPUs are visible): two ranks, different utterances; both end with the same averaged
     arena, equal to the mean of the two local gradients.
 Every world runs in spawned processes so the pytest process never owns a process group."""
+import math
 import os
 import socket
 import sys
@@ -196,6 +197,90 @@ def test_two_ranks_on_one_gpu_over_gloo_with_the_persistent_kernels():
     print("\n[two ranks, one GPU, gloo] clean=%s skipped=%s persistent launches %s / %s" %
           (clean, r0["skipped"], r0["persist_launches"], r1["persist_launches"])
           + "  failures %s / %s" % (r0["persist_failures"], r1["persist_failures"]))
+
+
+def _busy_worker(port, q, overlap):
+    """world-size-1 RCCL job at full width (bf16: every step launches the whole-chip persistent recurrences) with a FOREIGN kernel
+    holding eight CUs for 0.8 s across one step -- what an in-flight collective of another stream does to a persistent grid."""
+    try:
+        import warnings
+        for p_ in (ROOT, HERE):
+            if p_ not in sys.path:
+                sys.path.insert(0, p_)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FLOWTRON_MFMA="bf16", LOCAL_RANK="0",
+                          HSA_ENABLE_IPC_MODE_LEGACY="0", FLOWTRON_DP_OVERLAP=overlap, FLOWTRON_LSTM_PERSIST="1")
+        import distributed as D
+        import flowtron
+        from flowtron_amd import _lib as L
+        from flowtron_amd import ops
+        from flowtron_amd.optim import RAdam
+        from oracle import synth
+        D.init_distributed(0, 1, "nccl", None)
+        dev = torch.device("cuda", 0)
+        cfg = dict(synth.DEFAULT_MODEL_CONFIG)
+        m = flowtron.Flowtron(**cfg).to(dev).eval()
+        m.load_state_dict(synth.make_state_dict(cfg, seed=3))
+        opt = RAdam(m.parameters(), lr=1e-3, weight_decay=1e-6)
+        m = D.apply_gradient_allreduce(m)
+        crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)
+        b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.make_batch(cfg, [40, 33, 21], [12, 9, 7], seed=10, with_prior=True).items()}
+        side = torch.cuda.Stream()
+        res = {"usable_before": bool(ops.persist_usable(dev)), "losses": [], "params_finite": []}
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            for it in range(6):
+                if it == 2:                                  # eight CUs taken for 0.8 s (the persistent kernels give up after 0.5 s)
+                    torch.cuda.synchronize()
+                    L.check(L.lib().ft_debug_hold_cus(8, 80000000, side.cuda_stream), "hold")
+                m.zero_grad()
+                out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+                nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+                (nll + gl + 0.01 * ctc).backward()
+                opt.clip_grad_norm_(1.0)
+                opt.step()
+                torch.cuda.synchronize()
+                res["losses"].append(float(nll))
+                res["params_finite"].append(bool(torch.isfinite(m._grad_arena.flat_param).all()))
+                if it == 1:
+                    res["launches_clean"] = int(ops.PERSIST_LAUNCHES)
+        res["warnings"] = [str(w.message) for w in caught if "persistent recurrence" in str(w.message)]
+        res["skipped"] = int(opt.skipped_steps)
+        res["usable_after"] = bool(ops.persist_usable(dev))
+        res["failures"] = int(ops._PERSIST[dev].failures)
+        res["status"] = int(ops.persist_status(dev).item())
+        res["launches_end"] = int(ops.PERSIST_LAUNCHES)
+        q.put((0, res))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((0, {"error": traceback.format_exc()}))
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_persistent_recurrences_beside_a_foreign_kernel_time_out_once_and_the_run_continues(overlap):
+    """Multi-GPU readiness without a multi-GPU box: in an N > 1 job a collective kernel of another stream may hold
+    CUs while a step's whole-chip persistent recurrences are launched.  Here a stand-in (ft_debug_hold_cus: eight workgroups that
+    each take a whole CU for 0.8 s, on a second stream) does exactly that across one step of a world-size-1 RCCL job, in both DP
+    regimes: the persistent grid is not co-resident, its bounded spins give up (0.5 s), the status word poisons that step's
+    gradients in front of the all-reduce, the fused RAdam drops the update, the host warns ONCE and switches the device to the
+    launch-per-step kernels, and the loss sequence continues on them -- finite weights throughout, no hang, no exception."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_busy_worker, args=(_free_port(), q, overlap))
+    pr.start()
+    _, r = q.get(timeout=500)
+    pr.join(timeout=120)
+    assert "error" not in r, r.get("error")
+    if not r["usable_before"]:
+        pytest.skip("persistent recurrences not usable on this device")
+    assert len(r["warnings"]) == 1, r["warnings"]
+    assert r["failures"] == 1 and not r["usable_after"] and r["status"] == 0
+    assert 1 <= r["skipped"] <= 2, r["skipped"]                  # the step beside the foreign kernel (+ at most the one after it)
+    assert all(r["params_finite"]) and all(math.isfinite(x) for x in r["losses"]), r
+    assert r["launches_clean"] > 0 and r["losses"][-1] != r["losses"][2]          # training went on after the dropped step
+    print("\n[foreign kernel, overlap=%s] losses %s skipped %d persistent launches %d -> %d" %
+          (overlap, ["%.4f" % x for x in r["losses"]], r["skipped"], r["launches_clean"], r["launches_end"]))
 
 
 def test_bench_script_with_two_ranks_as_the_driver_launches_it():
