@@ -70,6 +70,8 @@ SIGNATURES = {
     "ft_bf16_image": ([_p, _l, _l, _l, _p, _p], _i),
     "ft_bf16_image_colsum": ([_p, _l, _l, _l, _p, _p, _p], _i),
     "ft_gemm_img": ([C.POINTER(GemmImgArgs), _p], _i),
+    "ft_bf16_image_split3": ([_p, _l, _l, _l, _p, _i, _p], _i),
+    "ft_bf16_image_split3_f16": ([_p, _l, _l, _l, _p, _i, _p], _i),
     "ft_rowmap_build": ([_p, _p, _p, _i, _i, _p], _i),
     "ft_bf16_image_rows": ([_p, _l, _l, _l, _p, _p, _p, _p, _p], _i),
     "ft_bf16_image_rows_into": ([_p, _l, _l, _l, _p, _l, _l, _l, _p, _p, _p], _i),

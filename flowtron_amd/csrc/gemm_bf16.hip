@@ -72,6 +72,36 @@ __global__ __launch_bounds__(256) void img_rows_k(const float* __restrict__ src,
     }
 }
 
+// Split image (ft_bf16_image_split3): x = hi + lo with hi = op16(x), lo = op16(x - hi) (the pair carries ~16 significand bits).  The
+// image is three column blocks of K: an ACTIVATION as [hi | lo | hi], a WEIGHT as [hi | hi | lo], so that ONE 16-bit GEMM over
+// 3 K columns yields x_hi w_hi + x_lo w_hi + x_hi w_lo = x w up to the dropped lo . lo term (2^-18): fp32-grade products at three
+// times a 16-bit GEMM's cost instead of the fp32 MFMA's sixteen.  Rows [R, Rp) and columns [3 K, Cp) are zero.  K % 8 == 0.
+__global__ __launch_bounds__(256) void img_split3_k(const float* __restrict__ src, long sr, int R, int K, unsigned short* __restrict__ dst,
+                                                    int Rp, int Cp, int weight) {
+    const int kq = K >> 3, cq = Cp >> 3;
+    const size_t total = (size_t)Rp * cq;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cq), q = (int)(i % cq);
+        uint4 out = make_uint4(0u, 0u, 0u, 0u);
+        if (r < R && q < 3 * kq) {
+            const int blk = q / kq, c = (q - blk * kq) * 8;
+            const float* p = src + (size_t)r * sr + c;
+            float v[8], lo[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = p[e];
+            const bool want_lo = weight ? blk == 2 : blk == 1;
+            if (want_lo) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) lo[e] = v[e] - op16_to_f(f2op16(v[e]));
+                out = pack8(lo);
+            } else {
+                out = pack8(v);
+            }
+        }
+        *reinterpret_cast<uint4*>(dst + (size_t)r * Cp + (size_t)q * 8) = out;
+    }
+}
+
 // same image, plus the fp32 column sums of the SOURCE (bias gradients: the conversion pass reads the output gradient
 // anyway, so ft_colsum's second sweep over it disappears).  Block = 32 column groups x 8 row lanes over a 256-row slab;
 // grid (Cp/256, Rp/256); colsum [Cc] must be zero on entry, slabs combine with fp32 atomics (as ft_colsum does).
@@ -901,6 +931,19 @@ extern "C" int FT_OPNAME(ft_bf16_image)(const float* src, int64_t ld, int64_t ro
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);
     make_image(src, ld, 1, (int)rows, (int)cols, reinterpret_cast<unsigned short*>(dst), (int)up((size_t)rows + 32, 256),
                (int)up((size_t)cols, 256), reinterpret_cast<hipStream_t>(stream));
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+
+// dst: ft_bf16_image_bytes(rows, 3 * cols) bytes; row stride ceil256(3 * cols) elements
+extern "C" int FT_OPNAME(ft_bf16_image_split3)(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, int weight, void* stream) {
+    FT_CHECK_ARG(src && dst && rows >= 1 && cols >= 8 && cols % 8 == 0 && ld >= cols && rows < (1ll << 31) - 256 && 3 * cols < (1ll << 31) - 256);
+    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);
+    const int Rp = (int)up((size_t)rows + 32, 256), Cp = (int)up((size_t)3 * cols, 256);
+    const size_t chunks = (size_t)Rp * (Cp >> 3);
+    const int blocks = (int)((chunks + 255) / 256 < 16384 ? (chunks + 255) / 256 : 16384);
+    hipLaunchKernelGGL(img_split3_k, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, (long)ld, (int)rows, (int)cols,
+                       reinterpret_cast<unsigned short*>(dst), Rp, Cp, weight ? 1 : 0);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

@@ -117,6 +117,26 @@ class Bf16Image:
         assert col_off % 8 == 0
         return self.buf.data_ptr() + 2 * (row_off * self.ld + col_off)
 
+    def view_cols(self, cols):
+        """the first `cols` columns as an image of their own (same storage and row stride): the [hi] block of a split image IS the
+        plain image of the matrix"""
+        v = Bf16Image.__new__(Bf16Image)
+        v.buf, v.rows, v.cols, v.ld, v.colsum, v.fmt, v.rowmap = self.buf, self.rows, int(cols), self.ld, None, self.fmt, self.rowmap
+        return v
+
+    @classmethod
+    def split3(cls, t2d, mode, weight):
+        """[hi | lo | hi] (activation) / [hi | hi | lo] (weight) image of t2d [rows, K]: one 16-bit GEMM over 3 K columns then gives
+        fp32-grade products (ft_bf16_image_split3)"""
+        assert t2d.dim() == 2 and t2d.stride(1) == 1 and t2d.dtype == torch.float32 and t2d.shape[1] % 8 == 0
+        self = cls.__new__(cls)
+        self.rows, self.cols, self.fmt, self.rowmap, self.colsum = int(t2d.shape[0]), 3 * int(t2d.shape[1]), mode, None, None
+        self.ld = (self.cols + 255) // 256 * 256
+        self.buf = torch.empty(L.lib().ft_bf16_image_bytes(self.rows, self.cols), device=t2d.device, dtype=torch.uint8)
+        L.check(L.op16("ft_bf16_image_split3", mode)(L.ptr(t2d), int(t2d.stride(0)), self.rows, int(t2d.shape[1]), L.ptr(self.buf),
+                                                     1 if weight else 0, L.stream()), "ft_bf16_image_split3")
+        return self
+
     @classmethod
     def cat_rows(cls, xs2d, mode, rowmap):
         """ONE compact image of the column-wise concatenation [x_0 | x_1 | ..] of time-major activations (each [T*B, K_i] fp32,
@@ -306,10 +326,31 @@ class LinearFn(torch.autograd.Function):
         N, Ktot = W.shape
         rows = xs[0].numel() // xs[0].shape[-1]
         y = torch.empty(xs[0].shape[:-1] + (N,), device=W.device, dtype=torch.float32)
-        use_img = linear_uses_images(mode, rows, N, xs)
+        # mode = one operand format, or (forward, input gradient, weight gradient): mixed formats (the encoder convolutions keep
+        # fp32 operands where 16-bit rounding is amplified, model.Encoder) take the per-GEMM path without shared images
+        mode_dx = mode_dw = mode
+        if isinstance(mode, tuple):
+            mode, mode_dx, mode_dw = mode
+        split_fwd = mode == "split3"                 # forward products from [hi | lo | hi] x [hi | hi | lo] images of the backward's format
+        if split_fwd:
+            assert len(xs) == 1 and act == L.ACT_NONE and L.is16(mode_dx) and mode_dx == mode_dw
+            x2d = xs[0].reshape(rows, Ktot)
+            split_imgs = None
+            if Ktot % 32 == 0 and images_apply(mode_dx, rows, N, Ktot):
+                xi, wi = Bf16Image.split3(x2d, mode_dx, False), Bf16Image.split3(W, mode_dx, True)
+                gemm_img(xi, 0, xi.ptr(), wi, 0, wi.ptr(), y, rows, N, 3 * Ktot, N, bias=bias)
+                split_imgs = (wi.view_cols(Ktot), [xi.view_cols(Ktot)])      # their [hi] blocks serve the backward's GEMMs as they are
+            else:
+                gemm_raw(x2d, W, y, rows, N, Ktot, Ktot, 1, 1, Ktot, N, bias=bias, mode=L.FT_F32)
+            mode = L.FT_F32                          # (what the rest of this node records as its forward format)
+        mixed = not (mode == mode_dx == mode_dw)
+        ctx.mode_dx, ctx.mode_dw = mode_dx, mode_dw
+        use_img = (not mixed) and linear_uses_images(mode, rows, N, xs)
+        # fp32 forward, 16-bit backward: the backward makes the operand images itself (the forward had none to share)
+        ctx.lazy_img_mode = mode_dx if (mixed and mode_dx == mode_dw and linear_uses_images(mode_dx, rows, N, xs)) else None
         if rowmap is not None and (not use_img or rows != rowmap.T * rowmap.B):
             rowmap = None
-        ctx.imgs = None
+        ctx.imgs = split_imgs if split_fwd else None
         ctx.cat = False
         if use_img:
             w_img = Bf16Image(W, mode=mode)
@@ -325,7 +366,7 @@ class LinearFn(torch.autograd.Function):
                 ctx.imgs = (w_img, x_imgs)          # reused by backward (dX reads W k-major, dW reads x k-major)
         off = 0
         for i, x in enumerate(xs):
-            if ctx.cat:
+            if ctx.cat or split_fwd:
                 off = Ktot
                 break
             K = x.shape[-1]
@@ -352,6 +393,9 @@ class LinearFn(torch.autograd.Function):
         N, Ktot = W.shape
         rows = dy.numel() // N
         rowmap = ctx.rowmap
+        if ctx.imgs is None and ctx.lazy_img_mode is not None:
+            lm = ctx.lazy_img_mode
+            ctx.imgs = (Bf16Image(W, mode=lm), [shared_image(x, rows, x.shape[-1], lm, rowmap) for x in xs])
         # an image handed over by the producer of dy (the LSTM backward) is looked up on dy AS IT ARRIVES: an image-only gradient is
         # a zero-stride NaN tensor (image_only_gradient) that must not be materialised
         d_img_in = _handoff_take(dy) if (ctx.act == L.ACT_NONE and ctx.imgs is not None) else None
@@ -399,7 +443,7 @@ class LinearFn(torch.autograd.Function):
                     if rowmap is not None and "dx" in ctx.fill:
                         rowmap.fill(dx.reshape(rows, K), K, copy_separator=False)
                 else:
-                    gemm_raw(dpre, W[:, off:], dx, rows, K, N, N, 1, Ktot, 1, K, mode=ctx.mode)
+                    gemm_raw(dpre, W[:, off:], dx, rows, K, N, N, 1, Ktot, 1, K, mode=ctx.mode_dx)
                 dxs.append(dx)
             else:
                 dxs.append(None)
@@ -412,7 +456,7 @@ class LinearFn(torch.autograd.Function):
                     gemm_img(d_img, 1, d_img.ptr(), x_imgs[i], 1, x_imgs[i].ptr(), dW[:, off:], N, K, mrows, Ktot, splitk=True,
                              rowmap=rowmap, compact=2)
                 else:
-                    gemm_raw(dpre, x, dW[:, off:], N, K, rows, 1, N, K, 1, Ktot, mode=ctx.mode, splitk=True)
+                    gemm_raw(dpre, x, dW[:, off:], N, K, rows, 1, N, K, 1, Ktot, mode=ctx.mode_dw, splitk=True)
             off += K
         ctx.imgs = None
         return (dW, db, None, None, None, None, *dxs)

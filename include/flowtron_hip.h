@@ -140,6 +140,14 @@ int ft_bf16_image(const float* src, int64_t ld, int64_t rows, int64_t cols, void
  * gradient; colsum [cols] is overwritten; row slabs combine with fp32 atomics like ft_colsum) */
 int ft_bf16_image_colsum(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, float* colsum, void* stream);
 int ft_gemm_img(const ft_gemm_img_args* a, void* stream);
+/* Split images (ABI 11): x = hi + lo, hi = op16(x), lo = op16(x - hi).  dst = [rows][3 cols] 16-bit (ft_bf16_image_bytes(rows, 3 cols),
+ * row stride ceil256(3 cols)): an activation (weight = 0) as [hi | lo | hi], a weight matrix (weight = 1) as [hi | hi | lo], so that ONE
+ * ft_gemm_img with K = 3 cols computes x_hi w_hi + x_lo w_hi + x_hi w_lo = x . w to ~2^-17 -- fp32-grade products at three times a
+ * 16-bit GEMM's cost.  Used for the FORWARD of the encoder's convolutions (flowtron.py:499-502): their 16-bit rounding, renormalised
+ * by the instance norm behind them, was the source of the 0.11 relative deviation of the text-embedding gradient in bf16 training
+ * (measured round 5: fp32 forward products alone bring it to 0.008).  cols % 8 == 0. */
+int ft_bf16_image_split3(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, int weight, void* stream);
+int ft_bf16_image_split3_f16(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, int weight, void* stream);
 /* Pack-by-length row map of a time-major [T][B][*] activation (flowtron.py:689-694 packs, here without a host sync): compact
  * rows are batch-major -- utterance b contributes rows (t, b), t < lens[b], then ONE separator: row (lens[b], b) when
  * lens[b] < T (the utterance's first padded frame, which stands for all of them: every padded frame of b holds the same
