@@ -166,7 +166,7 @@ class Bf16Image:
         self.rows, self.cols, self.fmt, self.rowmap = rowmap.cap, int(cols), mode, rowmap
         self.ld = (self.cols + 255) // 256 * 256
         self.buf = torch.empty(L.lib().ft_bf16_image_bytes(self.rows, self.cols), device=device, dtype=torch.uint8)
-        self.colsum = torch.zeros(self.cols, device=device, dtype=torch.float32)
+        self.colsum = zeroed((self.cols,), device)
         return self
 
 
@@ -288,6 +288,35 @@ def _require_written(t):
     if _HANDOFF["unwritten"] and (t.device.index, t.data_ptr(), tuple(t.shape)) in _HANDOFF["unwritten"]:
         raise RuntimeError("flowtron_amd: this gradient exists only as a 16-bit operand image (ft_lstm_persist_bwd_img); its consumer "
                            "must take the image (set FLOWTRON_LSTM_PERSIST_IMG=both to keep the fp32 copy)")
+
+
+# Split-K weight-gradient GEMMs accumulate with fp32 atomics into an output that must start at zero.  One memset per output was 37
+# dispatches per training step (hipMemset2DAsync / zeros_like: 0.28 ms of ~5 us fills, profiles/r04_final_step_timeline.txt);
+# the outputs of a backward pass now come out of ONE zeroed allocation sized by the previous pass's demand, and the GEMMs run with
+# beta = 1 ("C holds the addend").  FLOWTRON_ZERO_SLAB=0: one zeroed tensor per output.
+_ZSLAB = {"buf": None, "off": 0, "need": 0, "last": 0, "task": None}
+_ZSLAB_ON = _os.environ.get("FLOWTRON_ZERO_SLAB", "1") != "0"
+
+
+def zeroed(shape, device):
+    """a zero-filled fp32 tensor for an accumulating kernel; inside a backward pass a view into the pass's zeroed slab"""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    gt = _current_graph_task() if _ZSLAB_ON else -1
+    if gt == -1:
+        return torch.zeros(shape, device=device, dtype=torch.float32)
+    z = _ZSLAB
+    if z["task"] != (gt, str(device)):
+        z["last"], z["need"], z["off"], z["task"] = max(z["need"], 0), 0, 0, (gt, str(device))
+        z["buf"] = torch.zeros(z["last"], device=device, dtype=torch.float32) if z["last"] > 0 else None
+    step = (n + 63) // 64 * 64                           # 256-byte aligned slices (vector atomics / float4 epilogues)
+    z["need"] += step
+    if z["buf"] is not None and z["off"] + step <= z["buf"].numel():
+        v = z["buf"][z["off"]:z["off"] + n].view(shape)
+        z["off"] += step
+        return v
+    return torch.zeros(shape, device=device, dtype=torch.float32)
 
 
 def colsum(x2d: torch.Tensor, rows: int, N: int, ld: int) -> torch.Tensor:
@@ -413,7 +442,9 @@ class LinearFn(torch.autograd.Function):
             L.check(L.lib().ft_act_bwd(L.ptr(y), L.ptr(dy), L.ptr(dpre), dy.numel(), ctx.act, L.stream()), "ft_act_bwd")
         else:
             dpre = dy
-        dW = torch.empty_like(W) if ctx.needs_input_grad[0] else None
+        dW = None
+        if ctx.needs_input_grad[0]:
+            dW = zeroed(W.shape, W.device) if ctx.imgs is not None else torch.empty_like(W)      # (image path: split-K with beta = 1)
         want_db = ctx.has_bias and ctx.needs_input_grad[1]
         db = None
         dxs = []
@@ -449,11 +480,11 @@ class LinearFn(torch.autograd.Function):
                 dxs.append(None)
             if dW is not None and ctx.cat:
                 if i == 0:      # one split-K GEMM over the concatenated image: dW[n, :] = sum_r dpre[r,n] [x_0 | x_1][r, :]
-                    gemm_img(d_img, 1, d_img.ptr(), x_imgs[0], 1, x_imgs[0].ptr(), dW, N, Ktot, mrows, Ktot, splitk=True, rowmap=rowmap, compact=2)
+                    gemm_img(d_img, 1, d_img.ptr(), x_imgs[0], 1, x_imgs[0].ptr(), dW, N, Ktot, mrows, Ktot, beta=1.0, splitk=True, rowmap=rowmap, compact=2)
             elif dW is not None:
                 # dW[n, off+k] = sum_r dpre[r,n] x[r,k]
                 if imgs is not None:
-                    gemm_img(d_img, 1, d_img.ptr(), x_imgs[i], 1, x_imgs[i].ptr(), dW[:, off:], N, K, mrows, Ktot, splitk=True,
+                    gemm_img(d_img, 1, d_img.ptr(), x_imgs[i], 1, x_imgs[i].ptr(), dW[:, off:], N, K, mrows, Ktot, beta=1.0, splitk=True,
                              rowmap=rowmap, compact=2)
                 else:
                     gemm_raw(dpre, x, dW[:, off:], N, K, rows, 1, N, K, 1, Ktot, mode=ctx.mode_dw, splitk=True)
@@ -538,11 +569,11 @@ class LinearGateFn(torch.autograd.Function):
             off += K
         dW = None
         if ctx.needs_input_grad[0]:
-            dW = torch.empty_like(W)
-            gemm_img(d_img, 1, d_img.ptr(), x_cat, 1, x_cat.ptr(), dW, N, Ktot, rowmap.cap, Ktot, splitk=True, rowmap=rowmap, compact=2)
+            dW = zeroed(W.shape, W.device)
+            gemm_img(d_img, 1, d_img.ptr(), x_cat, 1, x_cat.ptr(), dW, N, Ktot, rowmap.cap, Ktot, beta=1.0, splitk=True, rowmap=rowmap, compact=2)
         dWg = dbg = None
         if dgate is not None and (ctx.needs_input_grad[2] or (ctx.has_gbias and ctx.needs_input_grad[3])):
-            acc = torch.zeros(Ktot + 1, device=W.device, dtype=torch.float32)
+            acc = zeroed((Ktot + 1,), W.device)
             L.check(L.op16("ft_img_gemv_rows_bwd", w_img.fmt)(L.ptr(x_cat.buf), x_cat.ld, Ktot, L.ptr(dgate), 1, L.ptr(acc), acc.data_ptr() + 4 * Ktot,
                                                               L.ptr(rowmap.map), L.ptr(rowmap.rows), rowmap.cap, L.stream()), "ft_img_gemv_rows_bwd")
             dWg = acc[:Ktot].reshape(1, Ktot) if ctx.needs_input_grad[2] else None
@@ -949,14 +980,14 @@ class LSTMSeqFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # dW_hh[r,j] = sum_{t,b} da_t[b,r] * h_prev(t)[b,j];  h_prev = y[t-1] (fwd) / y[t+1] (reverse)
             rows = (T - 1) * B
-            dW = torch.zeros_like(w_hh)
+            dW = zeroed(w_hh.shape, w_hh.device)
             rm = ctx.rowmap
             if T > 1 and images_apply(ctx.mode, 4 * H, H, rows) and rm is not None:
                 # compact images (valid frames only, batch-major with one zero separator row per utterance): the one-step shift
                 # dgates_t <-> h_{t-1} is a shift by ONE compact row, and the utterance boundaries multiply with a separator
                 d_img = d_img_k if d_img_k is not None else Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True, mode=ctx.mode, rowmap=rm)
                 y_img = shared_image(y, T * B, H, ctx.mode, rm)
-                gemm_img(d_img, 1, d_img.ptr(1), y_img, 1, y_img.ptr(0), dW, 4 * H, H, rm.cap, H, splitk=True, rowmap=rm, compact=2, k_shift=1)
+                gemm_img(d_img, 1, d_img.ptr(1), y_img, 1, y_img.ptr(0), dW, 4 * H, H, rm.cap, H, beta=1.0, splitk=True, rowmap=rm, compact=2, k_shift=1)
                 if img_only:
                     _handoff_put_image_only(dgx, d_img)     # ... and ONLY the image exists
                 else:
@@ -965,7 +996,7 @@ class LSTMSeqFn(torch.autograd.Function):
                 # images of dgates / outputs over all T*B rows; the one-step shift is a row offset into them
                 d_img, y_img = Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True, mode=ctx.mode), shared_image(y, T * B, H, ctx.mode)
                 fwd = not ctx.reverse
-                gemm_img(d_img, 1, d_img.ptr(B if fwd else 0), y_img, 1, y_img.ptr(0 if fwd else B), dW, 4 * H, H, rows, H, splitk=True)
+                gemm_img(d_img, 1, d_img.ptr(B if fwd else 0), y_img, 1, y_img.ptr(0 if fwd else B), dW, 4 * H, H, rows, H, beta=1.0, splitk=True)
                 _handoff_put(dgx, d_img)        # the input projection's backward reads the same dgates
             elif T > 1:
                 da = dgx[1:] if not ctx.reverse else dgx[:-1]

@@ -784,7 +784,7 @@ def test_ragged_batch_mel_equals_per_utterance_mel_and_zero_padding():
 def test_decoder_lstm_depths_one_and_three_vs_real_reference_golden(mode, tol):
     """VERDICT r3 missing #6: `n_lstm_layers` other than config.json's 2 (flowtron.py:655 passes it to nn.LSTM) -- training runs layer
     after layer through the same projection + recurrence pair; against the REAL reference's z, losses and gradients at depth 1 and 3
-    (tests/golden/lstm_depth.pt).  The decode kernels stay built for depth 2: infer raises NotImplementedError."""
+    (tests/golden/lstm_depth.pt)."""
     import flowtron
     from oracle import synth
     g = _load("lstm_depth.pt")
@@ -814,7 +814,8 @@ def test_decoder_lstm_depths_one_and_three_vs_real_reference_golden(mode, tol):
                 if r > worst[1]:
                     worst = (k, r)
             assert worst[1] < tol, (case["n_lstm_layers"], worst)
-            with pytest.raises(NotImplementedError, match="n_lstm_layers == 2"):
-                m.infer(torch.randn(1, 80, 4, device="cuda"), b["speaker_ids"][:1], b["text"][:1, :5])
+            # (decode at these depths: test_infer_depth_and_batch_vs_reference_golden; here only that it runs in this operand mode)
+            mel, _ = m.infer(torch.randn(1, 80, 4, device="cuda"), b["speaker_ids"][:1], b["text"][:1, :5], gate_threshold=1.0)
+            assert mel.shape == (1, 80, 4) and torch.isfinite(mel).all()
     finally:
         os.environ["FLOWTRON_MFMA"] = "f32"
