@@ -254,7 +254,7 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
     # reduce-scatter of fp32 partials (transport 21: 16 KB gathered + 16 KB published) or the all-gather of dgates (32 / 64 KB)
     rs_form = ng_bwd == 21
     for name, per_row, repl, gran_kb in (("lstm_persist_bwd_k", 4 * (4 * H + H + H) + bwd_out, "lstm_bwd_step_bf16", 32 if ng_bwd > 10 else 64),
-                                         ("lstm_persist_fwd_k", 4 * (4 * H + H + 4 * H + H), "lstm_fwd_step", 8 if ng_fwd in (11, 19, 18, 14, 12) else 16)):
+                                         ("lstm_persist_fwd_k", 4 * (4 * H + H + 4 * H + H), "lstm_fwd_step", 8 if ng_fwd in (11, 19) else 16)):
         nbytes = 2 * 4 * H * H + rows * per_row
         ach = nbytes / (us[name] * 1e-6) / 1e9
         per_step = us[name] / T

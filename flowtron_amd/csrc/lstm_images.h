@@ -81,24 +81,4 @@ __global__ void make_wfrag_rs(const float* __restrict__ w, unsigned short* __res
 }
 
 
-// W_hh [4H][H] fp32 -> fragment image of the M-split forward recurrence (lstm_persist_fwd_ms_k) [H/32][4 waves][2 tiles][H/32][64][8]:
-//   CU slot q, wave wv, tile, k-chunk c, lane (kg, li), e  <-  W_hh[g*H + q*32 + 8 wv + 2 ui + tile][c*32 + kg*8 + e],  ui = li >> 2, g = li & 3
-// i.e. the A operand (rows m = li) of  gates[m][batch] = sum_k W[m][k] h[batch][k]:  a 16-row tile holds the four gates of four units
-// (tile 0: the even units of the wave's eight, tile 1: the odd ones), so D row kg*4 + r is gate r of unit kg -- all four gates of an
-// element in ONE lane -- and the (even, odd) unit pair of a lane is one 32-bit operand pair of the state vector.
-__global__ void make_wfrag_ms(const float* __restrict__ w, unsigned short* __restrict__ out, int H, WfragAux aux) {
-    wfrag_aux(aux);
-    const size_t total = (size_t)4 * H * H;
-    const int nchunk = H >> 5;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
-        size_t rest = i >> 9;
-        const int c = (int)(rest % nchunk); rest /= nchunk;
-        const int tile = (int)(rest & 1), wv = (int)((rest >> 1) & 3), q = (int)(rest >> 3);
-        const int li = lane & 15, kg = lane >> 4, ui = li >> 2, g = li & 3;
-        const size_t row = (size_t)g * H + q * 32 + 8 * wv + 2 * ui + tile;
-        out[i] = f2op16(w[row * H + c * 32 + kg * 8 + e]);
-    }
-}
-
 }  // namespace

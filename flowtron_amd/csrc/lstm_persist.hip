@@ -529,298 +529,6 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
         for (int t = tg; t < T; ++t) p.y[((size_t)t * B + eb) * p.ldy + eu] = 0.f;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Forward recurrence, M-SPLIT form (transport 31, round 4).  lstm_persist_fwd_k splits K over the four waves of a CU: each wave
-// multiplies its quarter of h straight out of the gathered granules, the four partial gate vectors meet in LDS behind a barrier,
-// and TWO waves run the 128 cell updates while the other two store the saved tensors.  Here every wave owns 32 gate ROWS (eight
-// units x four gates, the whole K):
-//   gather (a quarter of the group's state vector per wave, as before) -> 16-bit payloads into an LDS copy of h [4 rows][1024]
-//   -> ONE barrier -> every wave reads all 32 B fragments from LDS (lanes li < 4: one batch row each; a 2 064-byte row pitch keeps
-//   the four rows on distinct banks) and issues its 64 MFMAs with the WEIGHTS as the A operand (resident in AGPRs): D row kg*4 + r
-//   is gate r of unit kg, column li the batch row -- lane (kg, li < 4) ends up with all four gates of (unit, row) for an even and
-//   an odd unit (tile 0 / tile 1) -> cell update in registers on all four waves at once (two elements on 16 lanes each) -> the
-//   (even, odd) pair leaves as one tagged granule -> the saved tensors are stored by the lane that computed them.
-// No reduce through LDS after the MFMAs, no second barrier, no staging of outputs.  Four accumulators per tile keep the k-quarters
-// apart (chunk c adds into accumulator c & 3, ascending), and the epilogue adds them in wave order before gx: the same sums in
-// the same order as lstm_persist_fwd_k and the launch-per-step kernel.
-// MEASURED (profiles/r04_persist_fwd_msplit.log): 2.02 - 2.06 us per step against 1.92 for lstm_persist_fwd_k, bit-identical -- kept as
-// transport 31 (FLOWTRON_LSTM_PERSIST_FWD=ms), not the default.  Where the expected gain went: the MFMA block fed from LDS costs
-// 0.68 us in isolation (scripts/exp/mfma_rate_probe.hip: barrier + first-fragment latency in front of 64 MFMAs that take 0.45 us
-// on their own), the K-split kernel starts its MFMAs straight out of the gather registers; the cell update did shrink (0.25 us
-// against 0.45) and the second barrier went, but the saved tensors have no idle wave to carry them: 24 scattered 8-byte stores
-// from the epilogue lanes cost 0.3 us per step, three coalesced 16-byte stores out of an LDS staging tile still 0.13.
-// Granules (8 bytes {pair, epoch}) of a group and parity: [k quarter w'][row][64 L][2]: index ((w' 4 + b) 64 + L) 2 + sub holds
-// k = 256 w' + 4 L + 2 sub (+ 1): consumer wave w' reads 16 bytes per lane and row = four consecutive k, written to LDS as 8 bytes.
-__device__ __forceinline__ void mfma16_aagpr_first(f32x4& acc, const bf16x8& a, const u32x4& b) {      // acc = a x b, A in AGPRs
-#if FT_OPFMT == 1
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(a), "v"(b));
-#else
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(a), "v"(b));
-#endif
-}
-__device__ __forceinline__ void mfma16_aagpr(f32x4& acc, const bf16x8& a, const u32x4& b) {
-#if FT_OPFMT == 1
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
-#else
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
-#endif
-}
-
-template <bool PROF>
-__global__ __launch_bounds__(256, 1) void lstm_persist_fwd_ms_k(PersistP p) {
-    constexpr int NG = 8, CPG = NCU / NG, UPC = PH / CPG, RPGP = 4, NE = RPGP * UPC;
-    constexpr int GRAN_PER_GROUP = NCHUNK * 4 * RPGP * 4;
-    constexpr int HROW = 2 * PH + 16;                       // bytes per batch row of the LDS state vector (bank spread)
-    static_assert(UPC == 32 && NE == 128, "geometry");
-    // LDS: two parities of the state vector [4 rows][HROW bytes] | SB steps of gx rows [s][gate][e] | two parities of the saved
-    // tensors of a step [y, i, f, g, o, c][4 rows][32 units]
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned char* hs = reinterpret_cast<unsigned char*>(smem);
-    float* gxs = smem + (2 * RPGP * HROW) / 4;
-    float* outs = gxs + SB * 4 * NE;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kg = lane >> 4;
-    int grp, q;
-    if (!join_group_local<CPG>(p.census, p.status, tid, grp, q)) return;
-    const int B = p.B, T = p.T;
-    const int b0 = grp * RPGP;
-
-    // ---- resident weights: A fragments of this wave's two tiles, all 32 k-chunks (64 fragments = 256 accumulation registers)
-    bf16x8 w[2][NCHUNK];
-    {
-        const bf16x8* wf = reinterpret_cast<const bf16x8*>(p.wfrag);
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-            for (int c = 0; c < NCHUNK; ++c) w[tl][c] = wf[((size_t)((q * 4 + wave) * 2 + tl) * NCHUNK + c) * 64 + lane];
-    }
-    // ---- element role: lane (kg, li < 4) owns batch row li and the units q*32 + 8*wave + 2*kg (+ 1) for the whole sequence
-    const bool erole = li < RPGP;
-    const int eb = b0 + (li & 3), eu = q * UPC + 8 * wave + 2 * kg;
-    const bool ev = erole && eb < B;
-    const int len = ev ? p.lens[eb] : 0;
-    int tg = 0;
-#pragma unroll
-    for (int r = 0; r < RPGP; ++r) {
-        const int bb = b0 + r;
-        if (bb < B) { const int l = p.lens[bb]; tg = l > tg ? l : tg; }
-    }
-    tg = tg < T ? tg : T;
-    const bool y16 = (reinterpret_cast<uintptr_t>(p.y) % 16 == 0) && (p.ldy % 4 == 0);     // 16-byte stores of y rows
-
-    // gx rows by LDS-DMA in bursts of SB steps (as lstm_persist_fwd_k): element e = row * 32 + unit-in-CU
-    const int wu = __builtin_amdgcn_readfirstlane(wave);
-    const int eh = (wave & 1) * 64 + lane;
-    const int hb = b0 + eh / UPC, hu = q * UPC + eh % UPC;
-    const bool hvalid = hb < B;
-    auto burst = [&](int t) {
-        __syncthreads();
-        const int nst = (tg - t) < SB ? (tg - t) : SB;
-        if (hvalid) {
-            const float* src0 = p.gx + ((size_t)t * B + hb) * 4 * PH + hu;
-            const unsigned dst0 = (unsigned)(size_t)(lds_void*)gxs + (unsigned)(wu & 1) * 256u;
-#pragma unroll
-            for (int kk = 0; kk < SB * 2; ++kk) {
-                const int k = 2 * kk + (wu >> 1);
-                if (k < nst * 4) dma_dword(src0 + (size_t)(k >> 2) * B * 4 * PH + (size_t)(k & 3) * PH, dst0 + (unsigned)k * NE * 4u);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-    };
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0x0F70);                              // (told to the compiler's wait-count pass too: see lstm_persist_bwd_rs_k)
-#pragma unroll
-    for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-        for (int c = 0; c < NCHUNK; ++c) asm volatile("" : "+a"(w[tl][c]));
-    asm volatile("" :: "v"(len));
-
-    float c_state[2] = {0.f, 0.f}, h_state[2] = {0.f, 0.f};
-    __amdgpu_buffer_rsrc_t rs[2];
-#pragma unroll
-    for (int par = 0; par < 2; ++par)
-        rs[par] = __builtin_amdgcn_make_buffer_rsrc(p.hgran + ((size_t)par * NG + grp) * GRAN_PER_GROUP, 0, GRAN_PER_GROUP * 8, 0x00020000);
-    const int voff = lane * 16;
-    const int soff_w = __builtin_amdgcn_readfirstlane(wave) * 4096;
-    // this lane's granule: row li & 3, k = eu (even): quarter eu >> 8, L = (eu & 255) >> 2, sub = (eu >> 1) & 1
-    const int gidx = ((((eu >> 8) * 4 + (li & 3)) * 64 + ((eu & 255) >> 2)) << 1) + ((eu >> 1) & 1);
-    // LDS: write side (gather payload of row j: k = 256 wave + 4 lane), read side (row li & 3, k-group kg)
-    const unsigned hs_w = (unsigned)((256 * wave + 4 * lane) * 2);
-    const unsigned hs_r = (unsigned)((li & 3) * HROW + kg * 16);
-    const int egx = (li & 3) * UPC + 8 * wave + 2 * kg;              // element index of the even unit inside a gx slot
-    const long t_start = wall_clock64();
-    bool dead = false;
-    const bool prof = PROF && p.prof != nullptr && grp == 0 && q == 0 && lane == 0;
-    // Saved tensors (y, the four gates, the cell) of a step: the lane that computed an element drops its values into LDS, and right
-    // after the NEXT step's barrier waves 0 - 2 write them out as three full-width 16-byte-per-lane stores (eight lanes per 128-byte
-    // row piece).  Stores from the epilogue lanes themselves -- 16 lanes, 8 bytes each, six instructions per wave -- cost 0.3 us per
-    // step of issue time, and at the end of a step they sit in front of the next gather's loads (vmcnt retires in order).
-    const int oseg = wave * 8 + (lane >> 3);                         // store role: segment = kind * 4 + row, piece = lane & 7
-    const int okind = oseg >> 2, orow = b0 + (oseg & 3);
-    const bool ovalid = wave < 3 && orow < B;
-    const int olen = ovalid ? p.lens[orow] : 0;
-    float* obase = nullptr;
-    size_t ostep = 0;                                                // floats per time step
-    if (ovalid) {
-        const int ocol = q * UPC + 4 * (lane & 7);
-        if (okind == 0) { obase = p.y + (size_t)orow * p.ldy + ocol; ostep = (size_t)B * p.ldy; }
-        else if (okind == 5) { obase = p.cell ? p.cell + (size_t)orow * PH + ocol : nullptr; ostep = (size_t)B * PH; }
-        else { obase = p.gates ? p.gates + ((size_t)orow * 4 + (okind - 1)) * PH + ocol : nullptr; ostep = (size_t)B * 4 * PH; }
-    }
-    // (split in two: the LDS read goes out in front of the step's fragment reads, the global store follows a few MFMAs later, when
-    // the data has long arrived -- read, wait, store in one place put an LDS round trip in front of the MFMA block)
-    const int oread = (wave < 3 ? wave : 0) * 256 + lane * 4;
-    auto load_saved = [&](int t) -> f32x4 { return *reinterpret_cast<const f32x4*>(outs + (t & 1) * 6 * NE + oread); };
-    auto store_saved = [&](int t, const f32x4& v, float* dst) {     // step t's tensors (read from outs[t & 1] behind a barrier)
-        if (!ovalid || obase == nullptr) return;
-        if (okind != 0 && t >= olen) return;                         // gates / cell of frozen rows are not saved
-        if (okind != 0 || y16) *reinterpret_cast<f32x4*>(dst) = v;
-        else { dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
-    };
-    asm volatile("" :: "v"(olen));
-
-    for (int t = 0; t < tg; ++t) {
-        if ((t % SB) == 0) burst(t);
-        long st0 = 0, st1 = 0, st2 = 0, st3 = 0, npass = 0;
-        if (prof) st0 = wall_clock64();
-        const int par = (t - 1) & 1;
-        unsigned char* const hsp = hs + (unsigned)(par & 1) * (RPGP * HROW);
-        // gx of this lane's two elements (adjacent units): four 8-byte LDS reads, under the gather
-        float2 gxv[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-        if (t > 0) {
-            const unsigned epoch = (unsigned)t;
-            u32x4 ld[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ld[j] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, soff_w + j * 1024, 2);
-            if (erole) {
-                const float* gxr = gxs + (t % SB) * 4 * NE + egx;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) gxv[g] = *reinterpret_cast<const float2*>(gxr + g * NE);
-            }
-            unsigned ready = 0;
-            for (unsigned spins = 0;; ++spins) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (!((ready >> j) & 1u)) {
-                        if (__all((ld[j][1] == epoch) & (ld[j][3] == epoch))) ready |= 1u << j;
-                    }
-                }
-                if (ready == 15u) break;
-                if ((spins & 15) == 15) {
-                    const int st_now = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    if (wall_clock64() - t_start > p.timeout_ticks || st_now != 0) {
-                        dead = true;
-                        break;
-                    }
-                }
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (!((ready >> j) & 1u)) ld[j] = __builtin_amdgcn_raw_buffer_load_b128(rs[par], voff, soff_w + j * 1024, 2);
-                }
-            }
-            if (dead) break;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<uint2*>(hsp + j * HROW + hs_w) = make_uint2(ld[j][0], ld[j][2]);
-        } else if (erole) {
-            const float* gxr = gxs + egx;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) gxv[g] = *reinterpret_cast<const float2*>(gxr + g * NE);
-        }
-        if (prof) st1 = wall_clock64();
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();                                             // the group's h_{t-1} is in LDS (and the copy of step t - 2 is free)
-        if (prof) npass = wall_clock64();                             // (PROF: slot 4 = barrier passed)
-        f32x4 acc[2][4];
-        if (t > 0) {
-            const unsigned char* hb_ = hsp + hs_r;
-            // B fragments: 16 reads in flight, then one more behind every MFMA pair -- pinned with scheduling barriers (left alone, the
-            // compiler moved the reads of chunks 0 and 1 to the END of a 32-read block, and the first MFMA waited for all of them)
-            u32x4 bfr[NCHUNK];
-            const f32x4 sv = load_saved(t - 1);
-            float* const sdst = obase + (size_t)(t - 1) * ostep;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) bfr[c] = *reinterpret_cast<const u32x4*>(hb_ + c * 64);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < NCHUNK; ++c) {
-                if (c < 4) {
-                    mfma16_aagpr_first(acc[0][c], w[0][c], bfr[c]);
-                    mfma16_aagpr_first(acc[1][c], w[1][c], bfr[c]);
-                } else {
-                    mfma16_aagpr(acc[0][c & 3], w[0][c], bfr[c]);
-                    mfma16_aagpr(acc[1][c & 3], w[1][c], bfr[c]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (c == 5) {
-                    store_saved(t - 1, sv, sdst);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (c + 16 < NCHUNK) {
-                    bfr[c + 16] = *reinterpret_cast<const u32x4*>(hb_ + (c + 16) * 64);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");           // MFMA -> VALU read of the last accumulators
-            // the store's data and address registers stay allocated to the end of the block: handed to a fragment read right behind the
-            // store (as the allocator did), the read -- and every MFMA queued behind it -- waited until the memory pipeline had fetched
-            // the store's operands (0.2 us)
-            asm volatile("" :: "v"(sv), "v"(sdst));
-        } else {
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) acc[tl][qd] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        if (prof) st2 = wall_clock64();
-        if (erole) {
-            const bool active = t < len;
-            // both elements side by side (independent dependency chains for the transcendental pipe), selected afterwards
-            float pre[2][4], ig[2], fg[2], gg[2], og[2], c_new[2], h_new[2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                pre[0][g] = acc[0][0][g] + acc[0][1][g] + acc[0][2][g] + acc[0][3][g] + gxv[g].x;
-                pre[1][g] = acc[1][0][g] + acc[1][1][g] + acc[1][2][g] + acc[1][3][g] + gxv[g].y;
-            }
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl) lstm_cell<true>(pre[tl], c_state[tl], ig[tl], fg[tl], gg[tl], og[tl], c_new[tl], h_new[tl]);
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl) {
-                if (active) { c_state[tl] = c_new[tl]; h_state[tl] = h_new[tl]; }
-            }
-            // ---- publish h_t first (frozen rows re-publish their state)
-            const unsigned long long gran = ((unsigned long long)(unsigned)(t + 1) << 32) | pack_op16x2(h_state[0], h_state[1]);
-            unsigned long long* dst = p.hgran + ((size_t)(t & 1) * NG + grp) * GRAN_PER_GROUP + gidx;
-            __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (prof) st3 = wall_clock64();
-            // saved tensors -> LDS [kind][row][unit] (this lane: row li, units 8 wave + 2 kg, + 1)
-            float* o = outs + (t & 1) * 6 * NE + (li & 3) * UPC + 8 * wave + 2 * kg;
-            *reinterpret_cast<float2*>(o) = make_float2(active ? h_state[0] : 0.f, active ? h_state[1] : 0.f);
-            *reinterpret_cast<float2*>(o + NE) = make_float2(ig[0], ig[1]);
-            *reinterpret_cast<float2*>(o + 2 * NE) = make_float2(fg[0], fg[1]);
-            *reinterpret_cast<float2*>(o + 3 * NE) = make_float2(gg[0], gg[1]);
-            *reinterpret_cast<float2*>(o + 4 * NE) = make_float2(og[0], og[1]);
-            *reinterpret_cast<float2*>(o + 5 * NE) = make_float2(c_state[0], c_state[1]);
-        }
-        if (prof && t < 1024) {
-            long* o = p.prof + ((size_t)t * 4 + wave) * 5;
-            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = npass;
-        }
-    }
-    if (dead) {
-        if (lane == 0) atomicExch(p.status, 1);
-        return;
-    }
-    __syncthreads();
-    if (tg > 0) store_saved(tg - 1, load_saved(tg - 1), obase + (size_t)(tg - 1) * ostep);
-    // pad rows beyond the group's longest sequence: y = 0 (pad_packed_sequence semantics)
-    if (ev)
-        for (int t = tg; t < T; ++t) { float* yp = p.y + ((size_t)t * B + eb) * p.ldy + eu; yp[0] = 0.f; yp[1] = 0.f; }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Backward recurrence, same organisation: dh_rec[b][j] = sum_r dgates_{s+1}[b][r] W_hh[r][j]  (K = 4H, N = H).
@@ -1561,13 +1269,12 @@ extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh
     FT_CHECK_ARG(gx && w_hh && lens && y && work && status);
     FT_CHECK_ARG((gates == nullptr) == (cell == nullptr));
     FT_CHECK_ARG(T >= 0 && ldy >= H && reinterpret_cast<uintptr_t>(work) % 256 == 0 && reinterpret_cast<uintptr_t>(gx) % 16 == 0);
-    // ng: 1 / 9 = XCD-local transport (nt / sc1 loads), 8 | 4 | 2 = placement-independent fabric transport, all with tagged
-    // granules; + 10 (11, 19, 18, 14, 12) = the same transports with BARE operand pairs and the sentinel protocol
-    // ng = 31: the M-split form (lstm_persist_fwd_ms_k: XCD-local, tagged granules, every wave a full-K slice of the gate rows)
-    const bool msform = ng == 31;
-    const bool bare = ng > 10 && !msform;
-    const int ngb = msform ? 1 : (bare ? ng - 10 : ng);
-    FT_CHECK_ARG(ngb == 1 || ngb == 9 || ngb == 8 || ngb == 4 || ngb == 2);
+    // ng: 1 / 9 = XCD-local transport (nt / sc1 loads) with tagged granules; 11 / 19 = the same with BARE operand pairs and the sentinel
+    // protocol.  (Round 5 pruned what no box has run since round 3: the placement-independent fabric transports 8 | 4 | 2 | 18 | 14 | 12
+    // -- the kernel templates still carry their LOCAL = false branches -- and the M-split kernel of transport 31, a measured loser.)
+    const bool bare = ng > 10;
+    const int ngb = bare ? ng - 10 : ng;
+    FT_CHECK_ARG(ngb == 1 || ngb == 9);
     if (!ft_lstm_persist_supported(B, H))
         return ft_fail(FT_EUNSUPPORTED, "ft_lstm_persist_fwd: needs H == 1024, B <= 32 and a 256-CU device (H=%d B=%d)", H, B);
     if (T == 0) return FT_OK;
@@ -1580,22 +1287,8 @@ extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh
     unsigned* census = reinterpret_cast<unsigned*>(base + al256p((size_t)4 * H * H * 2) + al256p((size_t)2 * 32 * (4 * H / 2) * 8));
     // tags = 0: no epoch matches (epochs start at 1); bare: sentinels.  Preset by the fragment kernel (lstm_images.h: WfragAux)
     const WfragAux aux{reinterpret_cast<uint4*>(hgran), (unsigned long)(gran_bytes / 16), bare ? 0xFFFFFFFFu : 0u, census};
-    if (msform) hipLaunchKernelGGL(make_wfrag_ms, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H, aux);
-    else hipLaunchKernelGGL(make_wfrag_fwd_ug, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H, aux);
+    hipLaunchKernelGGL(make_wfrag_fwd_ug, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H, aux);
     PersistP p{gx, lens, y, (long)ldy, gates, cell, wfrag, hgran, status, census, T, B, 100000000L / 2, g_persist_prof};   // 0.5 s
-    if (msform) {
-        // LDS: 2 parities x 4 rows x (2 H + 16) bytes of state + SB steps of gx rows + 2 parities of saved tensors
-        const size_t lds_ms = (size_t)2 * 4 * (2 * 1024 + 16) + sizeof(float) * ((size_t)SB * 4 * 128 + (size_t)2 * 6 * 128);
-        auto launch_ms = [&](auto kern) -> int {
-            FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ms));
-            hipLaunchKernelGGL(kern, dim3(NCU), dim3(256), lds_ms, st, p);
-            return FT_OK;
-        };
-        const int rc = g_persist_prof ? launch_ms(lstm_persist_fwd_ms_k<true>) : launch_ms(lstm_persist_fwd_ms_k<false>);
-        if (rc != FT_OK) return rc;
-        FT_CHECK_LAUNCH();
-        return FT_OK;
-    }
     // dynamic LDS: reduce buffers (2*4*TPC*RPGP*20 = 2*4*32*20 floats) + SB staged gx rows + 2 output rows
     const size_t lds = sizeof(float) * ((size_t)2 * 4 * 32 * 20 + (size_t)SB * 4 * 128 + (size_t)2 * 6 * 128);
     auto launch = [&](auto kern) -> int {
@@ -1604,19 +1297,8 @@ extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh
         return FT_OK;
     };
     int rc;
-    if (!bare) {
-        if (ngb == 1) rc = launch(lstm_persist_fwd_k<8, true, 2, false>);
-        else if (ngb == 9) rc = launch(lstm_persist_fwd_k<8, true, 16, false>);
-        else if (ngb == 8) rc = launch(lstm_persist_fwd_k<8, false, 16, false>);
-        else if (ngb == 4) rc = launch(lstm_persist_fwd_k<4, false, 16, false>);
-        else rc = launch(lstm_persist_fwd_k<2, false, 16, false>);
-    } else {
-        if (ngb == 1) rc = launch(lstm_persist_fwd_k<8, true, 2, true>);
-        else if (ngb == 9) rc = launch(lstm_persist_fwd_k<8, true, 16, true>);
-        else if (ngb == 8) rc = launch(lstm_persist_fwd_k<8, false, 16, true>);
-        else if (ngb == 4) rc = launch(lstm_persist_fwd_k<4, false, 16, true>);
-        else rc = launch(lstm_persist_fwd_k<2, false, 16, true>);
-    }
+    if (!bare) rc = ngb == 1 ? launch(lstm_persist_fwd_k<8, true, 2, false>) : launch(lstm_persist_fwd_k<8, true, 16, false>);
+    else rc = ngb == 1 ? launch(lstm_persist_fwd_k<8, true, 2, true>) : launch(lstm_persist_fwd_k<8, true, 16, true>);
     if (rc != FT_OK) return rc;
     FT_CHECK_LAUNCH();
     return FT_OK;
@@ -1643,7 +1325,7 @@ extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, 
     const bool rsform = ng == 21;
     const bool bare = ng > 10 && !rsform;
     const int ngb = rsform ? 1 : (bare ? ng - 10 : ng);
-    FT_CHECK_ARG(ngb == 1 || ngb == 9 || ngb == 8 || ngb == 4);
+    FT_CHECK_ARG(ngb == 1 || ngb == 9);
     if (!ft_lstm_persist_supported(B, H))
         return ft_fail(FT_EUNSUPPORTED, "ft_lstm_persist_bwd: needs H == 1024, B <= 32 and a 256-CU device (H=%d B=%d)", H, B);
     if (T == 0) return FT_OK;
@@ -1688,17 +1370,8 @@ extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, 
 #define FT_PBWD(NG_, LOCAL_, LAUX_, BARE_) \
     (out == 0 ? launch(lstm_persist_bwd_k<NG_, LOCAL_, LAUX_, BARE_, 0>) : out == 1 ? launch(lstm_persist_bwd_k<NG_, LOCAL_, LAUX_, BARE_, 1>) \
                                                                                   : launch(lstm_persist_bwd_k<NG_, LOCAL_, LAUX_, BARE_, 2>))
-    if (!bare) {
-        if (ngb == 1) rc = FT_PBWD(8, true, 2, false);
-        else if (ngb == 9) rc = FT_PBWD(8, true, 16, false);
-        else if (ngb == 8) rc = FT_PBWD(8, false, 16, false);
-        else rc = FT_PBWD(4, false, 16, false);
-    } else {
-        if (ngb == 1) rc = FT_PBWD(8, true, 2, true);
-        else if (ngb == 9) rc = FT_PBWD(8, true, 16, true);
-        else if (ngb == 8) rc = FT_PBWD(8, false, 16, true);
-        else rc = FT_PBWD(4, false, 16, true);
-    }
+    if (!bare) rc = ngb == 1 ? FT_PBWD(8, true, 2, false) : FT_PBWD(8, true, 16, false);
+    else rc = ngb == 1 ? FT_PBWD(8, true, 2, true) : FT_PBWD(8, true, 16, true);
 #undef FT_PBWD
     if (rc != FT_OK) return rc;
     FT_CHECK_LAUNCH();

@@ -799,11 +799,9 @@ def check_persist_status(raise_on_failure=True):
 def _persist_fwd_code(ng):
     """transport code ft_lstm_persist_fwd is launched with.  FLOWTRON_LSTM_PERSIST = 1 (XCD-local groups):
     FLOWTRON_LSTM_PERSIST_FWD = bare (default since the end of round 4) -> 11, the K-split kernel with bare operand pairs (sentinel
-    protocol, half the gather bytes; 1.84 against 1.87 us per step), ksplit -> 1 (tagged granules), ms -> 31 (the M-split kernel).
-    All bit-identical."""
+    protocol, half the gather bytes; 1.84 against 1.87 us per step), ksplit -> 1 (tagged granules).  Bit-identical.  (The M-split
+    kernel of round 4, transport 31, was a measured loser -- 2.05 against 1.92 us per step -- and is gone since round 5.)"""
     fwd_form = _os.environ.get("FLOWTRON_LSTM_PERSIST_FWD", _PERSIST_FWD_DEFAULT)
-    if ng == 1 and fwd_form == "ms":
-        return 31
     if ng == 1 and fwd_form == "bare":
         return 11
     return ng
@@ -817,7 +815,7 @@ def _persist_bwd_code(ng):
         return 21
     if ng == 1 and bwd_form != "tagged":
         return 11
-    return ng if ng in (1, 9, 8, 4, 11, 19, 18, 14, 21) else (18 if ng > 10 else 8)      # (no 2-group backward kernel)
+    return ng if ng in (1, 9, 11, 19, 21) else (11 if ng > 10 else 1)
 
 
 def _persist_selftest(device, ng):
@@ -869,10 +867,13 @@ def persist_usable(device):
 
 def lstm_persist_groups(B, H, reverse, mode, device=None):
     """transport / group code of the persistent recurrence kernels for this shape (0 = use the launch-per-step kernels).
-    FLOWTRON_LSTM_PERSIST: 0 = off, 1 (default) = 8 XCD-local groups, 9 = the same with sc1 polls, 8 | 4 | 2 = placement-independent
-    fabric transport; + 10 (11, 19, 18, 14, 12) = the same transport with BARE operand pairs (sentinel protocol, half the hand-off
-    bytes; csrc/lstm_persist.hip)."""
+    FLOWTRON_LSTM_PERSIST: 0 = off, 1 (default) = 8 XCD-local groups, 9 = the same with sc1 polls; + 10 (11, 19) = the same transport
+    with BARE operand pairs (sentinel protocol, half the hand-off bytes; csrc/lstm_persist.hip).  The placement-independent fabric
+    transports (8 | 4 | 2 | 18 | 14 | 12: never run on any box since round 3) were pruned in round 5: a device whose XCD census does
+    not come out fails the self-test and uses the launch-per-step kernels."""
     ng = int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "1"))
+    if ng not in (0, 1, 9, 11, 19):
+        raise ValueError("FLOWTRON_LSTM_PERSIST must be 0, 1, 9, 11 or 19 (the fabric transports were removed in round 5)")
     if not ng or reverse or not L.is16(mode) or not L.lib().ft_lstm_persist_supported(B, H):
         return 0
     if device is not None:
