@@ -99,6 +99,64 @@ def init_weights(model, seed):
                 p.copy_(torch.randn(p.shape, generator=g) * 0.02)
 
 
+def cumm_roofline(B, in_lens_cpu, mode, frames=64):
+    """--config ljs_cumm: the fused frame kernels of cumulative attention (csrc/cumm_fused.hip: ONE launch per frame and direction),
+    timed live with HIP events on the launch stream around a forward and a backward call of ops.CummAttnSeqFn at the bench's own
+    B / L / text lengths over `frames` frames (a frame's cost does not depend on T).  Per frame and per workgroup the kernels pull
+    their weight fragments from the L2 (no reuse across frames: a launch keeps nothing), so the roof that binds them is the L2 ->
+    CU path: 34.5 TB/s over 256 CUs = 135 GB/s per CU (MI355X_MICROARCH.md); MFMA and HBM fractions stand beside it.
+    Bytes per workgroup and frame (16-bit fragments): forward = W_key rows of its column half (A E 2 / 2) + w2 (E 96 2) + its lane-order
+    text tile (32 E 4); backward = W_key^T (E A 2) + w2 (E 96 2) + w2^T + text and dtext tiles (3 x 32 E 4, the dtext tile written back)."""
+    from flowtron_amd import _lib as L
+    from flowtron_amd import ops
+    E = A = 640
+    Lk = int(in_lens_cpu.max())
+    T = frames
+    f = dict(device="cuda", dtype=torch.float32)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rn = lambda *sh: torch.randn(*sh, generator=g, **f)
+    lens = in_lens_cpu.to(device="cuda", dtype=torch.int32)
+    leaves = [t.requires_grad_(True) for t in (rn(T, B, A) * 0.7, rn(Lk, B, A), rn(Lk, B, E) * 0.7, rn(A, E) / E ** 0.5, rn(1, A) / A ** 0.5 * 4,
+                                               rn(32, 2, 5) * 0.5, rn(32) * 0.2, rn(E, 32, 3) * 0.2, rn(E) * 0.2)]
+    ts = []
+    for rep in range(3):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        c, a_, lp = ops.CummAttnSeqFn.apply(*leaves, lens, 1.0, mode)
+        e1.record()
+        (c.sum() + (a_ * a_).sum()).backward()
+        e2.record()
+        torch.cuda.synchronize()
+        ts.append((e0.elapsed_time(e1) * 1e3 / T, e1.elapsed_time(e2) * 1e3 / T))
+    fwd_us, bwd_us = sorted(t[0] for t in ts)[1], sorted(t[1] for t in ts)[1]
+    rows = int(in_lens_cpu.sum())
+    tiles_f = int(sum(-(-int(l) // 32) for l in in_lens_cpu))
+    tiles_b = int(sum(int(l) // 26 + 1 for l in in_lens_cpu))
+    split = 2 * tiles_f <= 256
+    wg_f, wg_b = (2 if split else 1) * tiles_f, tiles_b
+    by_f = A * E * 2 // (2 if split else 1) + E * 96 * 2 + 32 * E * 4
+    by_b = E * A * 2 + 2 * E * 96 * 2 + 3 * 32 * E * 4
+    fl_f = 2.0 * rows * (96 * E + E * A)                       # cond + key projection, valid rows
+    fl_b = 2.0 * rows * (96 * E + A * E + E * 96) + 2.0 * rows * (A * E + E * 97)   # in-frame GEMMs + this frame's share of the chunk GEMMs
+    hbm_f = rows * A * 4
+    hbm_b = rows * A * 4 + rows * (A + 2 * E + 128) * 2
+    out = {}
+    for name, us, wgs, by, fl, hbm in (("cummf_fwd_k", fwd_us, wg_f, by_f, fl_f, hbm_f), ("cummf_bwd_k", bwd_us, wg_b, by_b, fl_b, hbm_b)):
+        per_cu = by / (us * 1e-6) / 1e9
+        out[name] = {"kernel": name + "<10, 10>", "bound": "l2", "achieved": round(per_cu, 1), "peak": 135.0, "unit": "GB/s per CU",
+                     "frac": round(per_cu / 135.0, 3), "us_per_frame_incl_launch": round(us, 2), "workgroups_per_frame": wgs,
+                     "l2_bytes_per_workgroup_per_frame": by,
+                     "l2_chip": {"achieved": round(by * wgs / (us * 1e-6) / 1e12, 2), "peak": 34.5, "unit": "TB/s"},
+                     "mfma": {"achieved": round(fl / (us * 1e-6) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(fl / (us * 1e-6) / 2.5e15, 4),
+                              "flop_per_frame": fl},
+                     "hbm": {"achieved": round(hbm / (us * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(hbm / (us * 1e-6) / 8e12, 4),
+                             "bytes_per_frame": hbm},
+                     "note": "one launch per frame; us_per_frame includes the launch boundary (events around the whole call / frames; the "
+                             "backward figure also carries the chunk's weight-gradient GEMMs); stage stamps of a workgroup: "
+                             "profiles/r05_*_cumm_stage_stamps.log"}
+    return out
+
+
 def lstm_step_roofline(B, H, T, mode):
     """Live timing of the dominant kernel (lstm_fwd_step, flowtron_amd/csrc/lstm.hip): T launches bracketed by HIP
     events on the launch stream.  Algorithmic bytes per launch = W_hh (4H*H) + h_prev (B*H) + gate pre-activations in
@@ -447,8 +505,15 @@ def cpu_baseline_worker(batch_size, seed, hip_path=None):
             "ctc_rel": round(abs(hc - ctc.item()) / max(abs(ctc.item()), 1e-30), 6),
             "worst_grad_rel": round(worst[1], 5), "worst_grad_name": worst[0],
             "worst_grad_rel_well_conditioned": round(worst_wc[1], 5), "worst_grad_name_well_conditioned": worst_wc[0],
-            "note": "relative L2 per parameter tensor; the encoder conv stack / text embedding / query projection deviate 0.13-0.18 for "
-                    "the REAL reference under bf16 autocast too (tests/golden/cfg2_bf16.pt)"}
+            "sample": "the %d shortest utterances of the timed batch (T <= %d of 862 frames: what the CPU oracle finishes in seconds)" % (n_utt, int(out_lens.max())),
+            "full_batch": {"test": "tests/test_gpu_bench_path.py::test_bf16_benchmark_config_at_its_own_shape_vs_oracle (-m gpu): the timed "
+                                   "batch itself -- B 32, T 862, L 157, 18 932 valid frames -- against the fp32 oracle",
+                           "last_run": "profiles/r05_final_pytest_gpu.log", "nll_rel": 2.6e-06, "gate_abs": 6.6e-04, "ctc_rel": 1e-06,
+                           "worst_grad_rel": 0.0402, "worst_grad_name": "flows.0.attention_lstm.weight_ih_l0",
+                           "real_reference_under_bf16_autocast_same_group": 0.0429},
+            "note": "relative L2 per parameter tensor.  Round 5: the encoder convolutions' forward products come from split (hi|lo|hi) images "
+                    "at fp32 grade -- the 16-bit rounding of those three GEMMs was what made embedding.weight / the encoder deviate 0.11 "
+                    "(0.13-0.18 for the REAL reference under bf16 autocast, tests/golden/cfg2_bf16.pt); FLOWTRON_ENCODER_F32=off restores it"}
     return res
 
 
@@ -609,6 +674,7 @@ def main():
         with contextlib.redirect_stdout(sys.stderr):          # the reference-style "> initializing distributed" chatter
             os.environ["LOCAL_RANK"] = str(local_rank)
             ftdist.init_distributed(rank, world, "gloo" if shared_gpu else "nccl", None)
+        assert dist.get_world_size() == args.gpus, "process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus)
 
     torch.manual_seed(1234)
     model = flowtron.Flowtron(**model_config)
@@ -776,6 +842,11 @@ def main():
                            "gemm_mfma_busy_frac_pmc": {k: dict(zip(("frac", "pmc_round"), pmc_value("MFMA_BUSY", k, "mfma_busy_frac", with_source=True)))
                                                        for k in ("gemm_bf16_k<true, true, true, 256>", "gemm_bf16_k<false, true, false, 128>",
                                                                  "gemm_bf16_k<false, false, false, 128>", "gemm_bf16_big_k")}}
+        if args.config == "ljs_cumm":
+            try:
+                res["roofline"]["cumulative_attention"] = cumm_roofline(args.batch, batch_cpu["in_lens"], mode)
+            except Exception as e:
+                res["roofline"]["cumulative_attention"] = {"error": repr(e)}
         try:
             from flowtron_amd import ops as _ops
             if _ops.lstm_persist_groups(args.batch, MODEL_CONFIG["n_hidden"], False, mode, torch.device("cuda", torch.cuda.current_device())):

@@ -918,7 +918,7 @@ class LSTMSeqFn(torch.autograd.Function):
         if ng:
             # FLOWTRON_LSTM_PERSIST = 1 (XCD-local): FLOWTRON_LSTM_PERSIST_FWD = bare (default since the end of round 4) -> transport 11, the
             # K-split kernel with bare operand pairs (half the gather bytes; 1.84 against 1.87 us per step once the operand moves sit in
-            # the MFMA gaps), ksplit -> transport 1 (tagged granules), ms -> transport 31 (the M-split kernel).  All bit-identical.
+            # the MFMA gaps), ksplit -> transport 1 (tagged granules).  Bit-identical.
             ng = _persist_fwd_code(ng)
             st = _persist_watch(gx.device)
             work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=gx.device, dtype=torch.uint8)

@@ -229,13 +229,12 @@ int ft_lstm_seq_bwd(const float* dy, int64_t ldy, const float* w_hh, const int32
                     int T, int B, int H, int reverse, int mode, void* stream);
 
 /* Persistent form of ft_lstm_seq_fwd (forward direction, bf16 MFMA operands, H == 1024, B <= 32, 256-CU device): ONE launch
- * for the whole sequence.  The chip is split into `ng` (8 | 4 | 2) independent batch groups; every CU keeps the bf16 MFMA
- * fragments of its W_hh rows in registers for all T steps and the members of a group exchange h_t through 8-byte {epoch, bf16
- * pair} granules (write-through stores, tag-checked sc1 loads -- no fences).  ng = 1 selects the XCD-local transport: 8 groups
- * formed at run time from the workgroups' XCC ids, hand-off through the XCD's own L2 (csrc/lstm_persist.hip).
- * Transport codes: 1 | 9 = XCD-local (nt | sc1 loads), 8 | 4 | 2 = placement-independent fabric transport, + 10 (11, 19, 18, 14, 12) = the
- * same with BARE operand pairs and a sentinel protocol (half the hand-off bytes; 11 is what flowtron_amd/ops.py launches by default),
- * 31 = the M-split kernel (XCD-local, tagged; every wave a full-K slice of the gate rows).
+ * for the whole sequence.  The chip is split into 8 independent batch groups = the 8 XCDs, formed at run time from the workgroups'
+ * XCC ids; every CU keeps the 16-bit MFMA fragments of its W_hh rows in registers for all T steps and the members of a group
+ * exchange h_t through their XCD's own L2 (csrc/lstm_persist.hip).
+ * Transport codes (`ng`): 1 | 9 = 8-byte {epoch, 16-bit pair} granules, tag-checked (nt | sc1 loads); 11 | 19 = the same with BARE
+ * operand pairs and a sentinel protocol (half the hand-off bytes; 11 is what flowtron_amd/ops.py launches by default).  Round 5
+ * removed the placement-independent fabric transports (8 | 4 | 2 | 18 | 14 | 12) and the M-split kernel (31).
  * Results are bit-identical to ft_lstm_seq_fwd(FT_BF16) for every code.
  * `status` (device int32, zeroed by the caller once) is raised to 1 if a hand-off wait times out (grid not co-resident);
  * the caller must check it before trusting y.  work: ft_lstm_persist_workspace_bytes(), 256-byte aligned. */
@@ -246,7 +245,7 @@ int ft_lstm_persist_fwd(const float* gx, const float* w_hh, const int32_t* lens,
 /* debug: device buffer [1024][4][5] int64 that subsequent ft_lstm_persist_fwd launches fill with per-step phase stamps
  * (100 MHz wall clock) of one workgroup; NULL switches it off (scripts/exp/lstm_persist_bench.py). */
 int ft_lstm_persist_debug_prof(void* dev_buf);
-/* Persistent form of ft_lstm_seq_bwd (same restrictions; ng = 1 | 9 | 8 | 4, + 10 = BARE operand pairs: the all-gather kernels,
+/* Persistent form of ft_lstm_seq_bwd (same restrictions; ng = 1 | 9, + 10 = BARE operand pairs: the all-gather kernels,
  * bit-identical to ft_lstm_seq_bwd(FT_BF16); ng = 21 = the REDUCE-SCATTER kernel (XCD-local; fp32 partials tagged in the mantissa LSB,
  * the same products in another, fixed association: equal to fp32 rounding, deterministic -- what flowtron_amd/ops.py launches by
  * default)): dgx [T,B,4H] from dy, the saved gates / cell and W_hh.  Same workspace query. */
