@@ -140,9 +140,22 @@ def cumm_roofline(B, in_lens_cpu, mode, frames=64):
     fl_b = 2.0 * rows * (96 * E + A * E + E * 96) + 2.0 * rows * (A * E + E * 97)   # in-frame GEMMs + this frame's share of the chunk GEMMs
     hbm_f = rows * A * 4
     hbm_b = rows * A * 4 + rows * (A + 2 * E + 128) * 2
+    def pmc(name, what):
+        """committed PMC pass over scripts/exp/cumm_prof.py (same B / L, lengths 60..157): per-launch average of a counter"""
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_cumm_%s.json" % what)))
+            for k, v in d.items():
+                if name in k:
+                    key = {"FETCH_SIZE": "FETCH_SIZE", "WRITE_SIZE": "WRITE_SIZE", "MFMA_BUSY": "mfma_busy_frac"}[what]
+                    x = v[key]
+                    return float(x["avg"] if isinstance(x, dict) else x)
+        except Exception:
+            pass
+        return None
     out = {}
     for name, us, wgs, by, fl, hbm in (("cummf_fwd_k", fwd_us, wg_f, by_f, fl_f, hbm_f), ("cummf_bwd_k", bwd_us, wg_b, by_b, fl_b, hbm_b)):
         per_cu = by / (us * 1e-6) / 1e9
+        fs, ws, mb = pmc(name, "FETCH_SIZE"), pmc(name, "WRITE_SIZE"), pmc(name, "MFMA_BUSY")
         out[name] = {"kernel": name + "<10, 10>", "bound": "l2", "achieved": round(per_cu, 1), "peak": 135.0, "unit": "GB/s per CU",
                      "frac": round(per_cu / 135.0, 3), "us_per_frame_incl_launch": round(us, 2), "workgroups_per_frame": wgs,
                      "l2_bytes_per_workgroup_per_frame": by,
@@ -150,7 +163,9 @@ def cumm_roofline(B, in_lens_cpu, mode, frames=64):
                      "mfma": {"achieved": round(fl / (us * 1e-6) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(fl / (us * 1e-6) / 2.5e15, 4),
                               "flop_per_frame": fl},
                      "hbm": {"achieved": round(hbm / (us * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(hbm / (us * 1e-6) / 8e12, 4),
-                             "bytes_per_frame": hbm},
+                             "bytes_per_frame": hbm,
+                             "traffic": None if fs is None or ws is None else int((2 * fs + ws) * 1024), "pmc_round": "r05 (profiles/r05_pmc_cumm_*.json)"},
+                     "mfma_busy_frac_pmc": None if mb is None else round(mb, 4),
                      "note": "one launch per frame; us_per_frame includes the launch boundary (events around the whole call / frames; the "
                              "backward figure also carries the chunk's weight-gradient GEMMs); stage stamps of a workgroup: "
                              "profiles/r05_*_cumm_stage_stamps.log"}
@@ -362,7 +377,7 @@ def handoff_hops():
         return {"same_xcd_hop_us": 0.2985, "cross_xcd_hop_us": 0.6432}
 
 
-PMC_PREFIXES = ("r04_pmc_", "r03_pmc_", "r02_pmc_", "r01_pmc_lstm_")
+PMC_PREFIXES = ("r05_pmc_", "r04_pmc_", "r03_pmc_", "r02_pmc_", "r01_pmc_lstm_")
 
 
 def _pmc_file(prefix, counter_file):

@@ -880,7 +880,7 @@ void FT_OPNAME(ftint_cummf_debug_prof)(void* dev_buf) { g_cummf_prof = reinterpr
 
 // shapes the fused kernels are instantiated for (config.json: n_text_dim 512 + n_speaker_dim 128 = 640 = n_attn_channels)
 int FT_OPNAME(ftint_cummf_supported)(const ft_cumm_attn_args* a) {
-    return a->mode == FT_OP16 && a->E == 640 && a->A == 640 && a->NF == NF && a->K1 == K1 && a->K2 == K2 && a->L <= 2048 && a->B <= 65535;
+    return a->mode == FT_OP16 && a->E == 640 && a->A == 640 && a->NF == NF && a->K1 == K1 && a->K2 == K2 && a->L <= 1024 && a->B < 32768;    // (L: the backward tile needs 12 L + 146 KB of LDS)
 }
 
 size_t FT_OPNAME(ftint_cummf_workspace_bytes)(int T, int L, int B, int E, int A, int backward) {
