@@ -41,7 +41,7 @@ class GemmImgArgs(C.Structure):
 class CummAttnArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("text", "Q", "V", "w_key", "v", "w1", "b1", "w2", "b2", "in_lens", "ctx", "attn", "logprob",
                                   "cumm_all", "kproj_all", "work")] + [("work_bytes", _sz)] + [
-        (n, _i) for n in ("T", "B", "L", "E", "A", "NF", "K1", "K2")] + [("temperature", _f), ("mode", _i)]
+        (n, _i) for n in ("T", "B", "L", "E", "A", "NF", "K1", "K2")] + [("temperature", _f), ("mode", _i), ("persist_status", _p)]
 
 
 class DecodeArgs(C.Structure):

@@ -172,6 +172,8 @@ struct FwdP {
     float *attn, *logprob, *cumm_all, *tsave, *ebuf;      // ebuf [3][B][L]: scores of frame i accumulate in slot i % 3 (both column halves add)
     const float4* text_f;                                 // text in the lane order of this kernel's tiles (text_lane_k)
     const int* items;                                     // [0] = count, then one word per workgroup: (b << 16) | (j << 4) | (zh0 << 1) | (nz - 1)
+    unsigned long long* gran;                             // persistent form: [2 parities][NSP][B][L] {epoch, partial score} granules
+    int* status;                                          // persistent form: raised when a hand-off wait gives up
     int T, B, L, NJ;
     float inv_temp;
     long long* prof;                                      // debug (ft_cumm_debug_prof): stage stamps of workgroup (0, 0), 100 MHz clock
@@ -184,8 +186,41 @@ struct FwdP {
 // location convolutions and add their partial scores.  (A plain 3-D grid dealt the valid tiles unevenly to the XCDs: one XCD with
 // 33 of them on its 32 CUs made every frame two rounds.)
 constexpr int NSP = 2;
-template <int NQE, int NQA>
-__global__ __launch_bounds__(256, 1) void cummf_fwd_k(FwdP p, int i) {
+
+// In-launch hand-off of the PERSISTENT forms (one launch walks many frames): the few hundred floats that cross workgroups per frame
+// travel as 8-byte {epoch, value} granules -- the data is the flag (cdna_hip_programming.md G16 R2): one relaxed agent-scope store
+// each (write-through: visible across XCDs), tag-checked relaxed agent-scope loads, no fences.  Two buffers alternate by the
+// epoch's parity: a workgroup can run at most one frame ahead of the slowest workgroup of its utterance, so a buffer is rewritten
+// only after everybody has read it.  Every spin is bounded (0.5 s of wall clock): a grid that is not co-resident raises the status word.
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+__device__ __forceinline__ void put_granule(unsigned long long* g, unsigned epoch, float v) {
+    __hip_atomic_store((gu64_t*)g, ((unsigned long long)epoch << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// two values (the same slot of two granule arrays), waited for together; false = gave up (time-out, or somebody else's failure seen
+// in *status)
+__device__ __forceinline__ bool get_granules2(const unsigned long long* g0, const unsigned long long* g1, unsigned epoch, float& v0, float& v1,
+                                              int* status, long long t0, long long limit) {
+    for (int spin = 0;; ++spin) {
+        const unsigned long long x0 = __hip_atomic_load((gu64_t*)g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long x1 = __hip_atomic_load((gu64_t*)g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x0 >> 32) == epoch && (unsigned)(x1 >> 32) == epoch) {
+            v0 = __uint_as_float((unsigned)x0); v1 = __uint_as_float((unsigned)x1);
+            return true;
+        }
+        if ((spin & 63) == 63) {
+            if (wall_clock64() - t0 > limit || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+constexpr long long PERSIST_TIMEOUT = 50000000LL;       // 0.5 s of the 100 MHz wall clock per wait
+
+// PERSIST = false: frame i_first == i_last of one launch per frame (scores of frame i-1 from ebuf, running sum from cumm_all).
+// PERSIST = true: ONE launch walks the frames i_first .. i_last (0 .. T): the work list guarantees a co-resident grid (<= one
+// workgroup per CU), the partial scores of a tile's column halves cross workgroups as granules (gran [2][NSP][B][L]), the running sum
+// lives in LDS, and what does not depend on the frame -- the w2 fragments, the text tile, v, b2, w1 -- is requested ONCE.
+template <int NQE, int NQA, bool PERSIST>
+__global__ __launch_bounds__(256, 1) void cummf_fwd_k(FwdP p, int i_first, int i_last) {
     constexpr int E = 64 * NQE, A = 64 * NQA, KPE = E + 8, NQH = NQA / NSP, AH = A / NSP;
     static_assert(NQA % NSP == 0 && AH == 64 * NQH, "column halves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -197,20 +232,9 @@ __global__ __launch_bounds__(256, 1) void cummf_fwd_k(FwdP p, int i) {
     const int len = min(p.in_lens[b], L);
     const int r0 = j * FWD_ROWS;
     const bool writer = j == 0 && zh0 == 0;               // closes frame i-1: attn, logprob, the running sum
-    if (r0 >= len && !writer) return;
+    const bool has_rows = r0 < len;
+    if (!has_rows && !writer) return;
     const size_t BL = (size_t)B * L;
-    const float* e_in = p.ebuf + (size_t)((i + 2) % 3) * BL + (size_t)b * L;      // scores of frame i-1
-    float* e_out = p.ebuf + (size_t)(i % 3) * BL + (size_t)b * L;
-    float* e_zero = p.ebuf + (size_t)((i + 1) % 3) * BL + (size_t)b * L;         // last read by frame i-1: zeroed for frame i+1
-    // the inputs of the softmax first: vmcnt retires in order, so whatever is requested before them stands in front of them
-    float e_reg = -INFINITY;
-    if (i > 0 && tid < len) e_reg = e_in[tid];
-    const float* cprev = i > 0 ? p.cumm_all + ((size_t)(i - 1) * B + b) * L : nullptr;
-    float cpx = 0.f, cp0 = 0.f;                            // cumm_{i-1} at this thread's x position / at l = tid
-    if (i > 0) {
-        if (tid < 2 * 38) { const int l = r0 - HALO + (tid % 38); if (l >= 0 && l < L) cpx = cprev[l]; }
-        if (writer && tid < L) cp0 = cprev[tid];
-    }
     float* ps = reinterpret_cast<float*>(smem);           // [Lp]  attention of frame i-1
     float* xs = ps + Lp;                                  // [2][XW]
     float* h1s = xs + 2 * XW;                             // [34][H1P]
@@ -220,142 +244,205 @@ __global__ __launch_bounds__(256, 1) void cummf_fwd_k(FwdP p, int i) {
     float* b2s = vs + A;                                  // [E]
     unsigned short* kmt = reinterpret_cast<unsigned short*>(b2s + E);     // [32][KPE]   (float offset Lp + 1332 + 2 A + E: 16-byte aligned)
     float* tst = b2s + E + 32 * KPE / 2;                  // [32][AH + 4] fp32: the saved tanh of a column half on its way out
-    const bool work = i < T && r0 < len;
-    CUMMF_STAMP(0, 0);
+    float* cums = tst + 32 * (AH + 4);                    // [Lp] PERSIST: the running sum of the attention (cumm_i)
+    const size_t RA = (size_t)L * B;
 
-    // 0. everything that does not depend on frame i-1 is requested now: the first PD k-steps of this wave's W_key rows, all of its
-    //    w2 rows, its text rows, Q_i / v / b2 / w1 -- they arrive under the softmax of the previous frame
-    bf16x8 wf[PD][NQH];
-    bf16x8 w2f[NQE][3];
-    float4 txv[NQE][2];
-    float w1r[2 * K1], b1r = 0.f;
-    float4 stage_q = make_float4(0.f, 0.f, 0.f, 0.f), stage_v = stage_q, stage_b = stage_q;
-    const unsigned short* wkp = frag_base(p.wkimg, wave + 4 * NQH * zh0, E / 32, lane);
-    if (work) {
-#pragma unroll
-        for (int d = 0; d < PD; ++d)
-#pragma unroll
-            for (int q = 0; q < NQH; ++q) wf[d][q] = ld_frag(wkp + (size_t)q * 4 * (E / 32) * FRAG + FRAG * d);
-        const unsigned short* w2p = frag_base(p.w2img, wave, 3, lane);
-        const float4* txp = p.text_f + ((size_t)(b * p.NJ + j) * 4 + wave) * NQE * 2 * 64 + lane;
-#pragma unroll
-        for (int q = 0; q < NQE; ++q) {
-#pragma unroll
-            for (int s = 0; s < 3; ++s) w2f[q][s] = ld_frag(w2p + (size_t)q * 4 * 3 * FRAG + FRAG * s);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) txv[q][rt] = txp[(q * 2 + rt) * 64];
+    // one launch per frame: the inputs of the softmax first (vmcnt retires in order: whatever is requested before them stands in front)
+    float e_reg = -INFINITY, cpx = 0.f, cp0 = 0.f;        // score of frame i-1 at l = tid; cumm_{i-1} at this thread's x position / at l = tid
+    if constexpr (!PERSIST) {
+        if (i_first > 0) {
+            const float* cprev = p.cumm_all + ((size_t)(i_first - 1) * B + b) * L;
+            if (tid < len) e_reg = p.ebuf[(size_t)((i_first + 2) % 3) * BL + (size_t)b * L + tid];
+            if (tid < 2 * 38) { const int l = r0 - HALO + (tid % 38); if (l >= 0 && l < L) cpx = cprev[l]; }
+            if (writer && tid < L) cp0 = cprev[tid];
         }
+    }
+    // frame-independent requests: v / b2 / w1 (the w2 fragments and the text tile would stay too, but 200 more registers per lane
+    // spill: they are requested again every frame)
+    float w1r[2 * K1], b1r = 0.f;
+    const unsigned short* w2p = frag_base(p.w2img, wave, 3, lane);
+    const float4* txp = p.text_f + ((size_t)(b * p.NJ + j) * 4 + wave) * NQE * 2 * 64 + lane;
+    if (has_rows) {
 #pragma unroll
         for (int q = 0; q < 2 * K1; ++q) w1r[q] = p.w1[(tid & 31) * 2 * K1 + q];
         b1r = p.b1[tid & 31];
-        if (tid < A / 4) {
-            stage_q = *reinterpret_cast<const float4*>(p.Q + ((size_t)i * B + b) * A + 4 * tid);
-            stage_v = *reinterpret_cast<const float4*>(p.v + 4 * tid);
-        }
-        if (tid < E / 4) stage_b = *reinterpret_cast<const float4*>(p.b2 + 4 * tid);
+        if (tid < A / 4) *reinterpret_cast<float4*>(vs + 4 * tid) = *reinterpret_cast<const float4*>(p.v + 4 * tid);
+        if (tid < E / 4) *reinterpret_cast<float4*>(b2s + 4 * tid) = *reinterpret_cast<const float4*>(p.b2 + 4 * tid);
     }
-    __builtin_amdgcn_sched_barrier(0);                   // (requests stay up here)
+    if constexpr (PERSIST) { for (int l = tid; l < Lp; l += 256) cums[l] = 0.f; }
+    long long t_wait = 0;
 
-    // 1. attention of the previous frame
-    if (i > 0) softmax_block(e_in, e_reg, ps, red, len, Lp, tid);
-    else { for (int l = tid; l < Lp; l += 256) ps[l] = 0.f; lds_barrier(); }
-    if (zh0 == 0 && r0 < len && tid < FWD_ROWS && r0 + tid < L) e_zero[r0 + tid] = 0.f;
-    if (writer && i > 0) {
-        const size_t row = ((size_t)b * T + (i - 1)) * L;
-        for (int l = tid; l < L; l += 256) {
-            const float pl = ps[l];
-            p.attn[row + l] = pl;
-            p.logprob[row + l] = logf(pl + 1e-8f);
-            if (i < T) p.cumm_all[((size_t)i * B + b) * L + l] = (l == tid ? cp0 : cprev[l]) + pl;
-        }
-    }
-    if (!work) return;
-    CUMMF_STAMP(0, 1);
-    // 2. x = [cumm_i ; prev_i] for positions r0 - 3 .. r0 + 34, first convolution
-    if (tid < 2 * 38) {
-        const int ch = tid / 38, pos = tid - 38 * ch, l = r0 - HALO + pos;
-        float x = 0.f;
-        if (l >= 0 && l < L && i > 0) x = ch == 0 ? cpx + ps[l] : ps[l];
-        xs[ch * XW + pos] = x;
-    }
-    if (tid < A / 4) { *reinterpret_cast<float4*>(qs + 4 * tid) = stage_q; *reinterpret_cast<float4*>(vs + 4 * tid) = stage_v; }
-    if (tid < E / 4) *reinterpret_cast<float4*>(b2s + 4 * tid) = stage_b;
-    lds_barrier();
-    conv1_h1(xs, h1s, w1r, b1r, r0, L, tid);
-    lds_barrier();
-    CUMMF_STAMP(0, 2);
-    // 3. cond = sigmoid(conv2(h1)), km = text . cond -> LDS tile [32 rows][E]
-    {
-        bf16x8 cf[2][3];
-        col_frags(h1s, 0, li, kg, cf[0]);
-        col_frags(h1s, 1, li, kg, cf[1]);
-#pragma unroll
-        for (int q = 0; q < NQE; ++q) {
-            const int e0 = 16 * (wave + 4 * q) + 4 * kg;
-            const float4 bv = *reinterpret_cast<const float4*>(b2s + e0);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const f32x4 c = cond_pre(w2f[q], cf[rt]);
-                const float4 tx = txv[q][rt];
-                *reinterpret_cast<uint2*>(kmt + (16 * rt + li) * KPE + e0) =
-                    pack4(tx.x * sigm(c[0] + bv.x), tx.y * sigm(c[1] + bv.y), tx.z * sigm(c[2] + bv.z), tx.w * sigm(c[3] + bv.w));
-            }
-        }
-    }
-    lds_barrier();
-    CUMMF_STAMP(0, 3);
-    const size_t RA = (size_t)L * B;
-    for (int zz = 0; zz < nz; ++zz) {
-        const int zh = zh0 + zz;
-        if (zz > 0) {                                     // (unsplit items only: the other half's fragments, one exposed round trip)
-            wkp = frag_base(p.wkimg, wave + 4 * NQH * zh, E / 32, lane);
+    const int i_end = PERSIST ? i_last : i_first;           // (one launch per frame: a single trip, known to the compiler)
+#pragma unroll 1
+    for (int i = i_first; i <= i_end; ++i) {
+        const bool work = i < T && has_rows;
+        float* e_out = p.ebuf + (size_t)(i % 3) * BL + (size_t)b * L;
+        const float* cprev = i > 0 ? p.cumm_all + ((size_t)(i - 1) * B + b) * L : nullptr;
+        CUMMF_STAMP(0, 0);
+        // per-frame requests: the first PD k-steps of this wave's W_key rows, its w2 rows, Q_i -- they arrive under the softmax of the
+        // previous frame
+        bf16x8 wf[PD][NQH];
+        bf16x8 w2f[NQE][3];
+        float4 txv[NQE][2];
+        float4 stage_q = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (the fragment addresses do not depend on the frame: without an opaque term the compiler hoists these requests out of the
+        // frame loop of the persistent form and keeps 280 registers of weights alive across it -- 192 spilled)
+        int opaque = 0;
+        if constexpr (PERSIST) asm volatile("" : "+s"(opaque));
+        const unsigned short* wkp = frag_base(p.wkimg, wave + 4 * NQH * zh0, E / 32, lane) + opaque;
+        const unsigned short* w2q = w2p + opaque;
+        if (work) {
 #pragma unroll
             for (int d = 0; d < PD; ++d)
 #pragma unroll
                 for (int q = 0; q < NQH; ++q) wf[d][q] = ld_frag(wkp + (size_t)q * 4 * (E / 32) * FRAG + FRAG * d);
+#pragma unroll
+            for (int q = 0; q < NQE; ++q) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s) w2f[q][s] = ld_frag(w2q + (size_t)q * 4 * 3 * FRAG + FRAG * s);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) txv[q][rt] = txp[(q * 2 + rt) * 64 + opaque];
+            }
+            if (tid < A / 4) stage_q = *reinterpret_cast<const float4*>(p.Q + ((size_t)i * B + b) * A + 4 * tid);
         }
-        // 4. K^T = W_key km^T: wave w owns the a-tiles w, w + 4, ... of the column half; both row tiles
-        f32x4 acc[NQH][2];
+        __builtin_amdgcn_sched_barrier(0);               // (requests stay up here)
+
+        // 1. attention of the previous frame
+        if (i > 0) {
+            if constexpr (PERSIST) {
+                // the partial scores of frame i-1 (epoch i) of every tile of this utterance, both column halves
+                const unsigned long long* g = p.gran + (size_t)(i & 1) * NSP * BL + (size_t)b * L;
+                if (t_wait == 0) t_wait = wall_clock64();
+                bool ok = true;
+                for (int l = tid; l < len; l += 256) {
+                    float e0 = 0.f, e1 = 0.f;
+                    ok = ok && get_granules2(g + l, g + BL + l, (unsigned)i, e0, e1, p.status, t_wait, PERSIST_TIMEOUT);
+                    ps[l] = e0 + e1;
+                }
+                if (!__syncthreads_and(ok ? 1 : 0)) {     // somebody gave up: the launch cannot complete (grid not co-resident)
+                    if (tid == 0) atomicMax(p.status, 3);
+                    return;
+                }
+                t_wait = wall_clock64();
+                softmax_block(ps, ps[tid < len ? tid : 0], ps, red, len, Lp, tid);
+            } else {
+                softmax_block(p.ebuf + (size_t)((i + 2) % 3) * BL + (size_t)b * L, e_reg, ps, red, len, Lp, tid);
+            }
+        } else {
+            for (int l = tid; l < Lp; l += 256) ps[l] = 0.f;
+            lds_barrier();
+        }
+        if constexpr (PERSIST) {
+            if (i > 0) { for (int l = tid; l < Lp; l += 256) cums[l] += ps[l]; }        // cumm_i = cumm_{i-1} + attn_{i-1} (own elements: no barrier)
+        } else {
+            if (zh0 == 0 && has_rows && tid < FWD_ROWS && r0 + tid < L) p.ebuf[(size_t)((i + 1) % 3) * BL + (size_t)b * L + r0 + tid] = 0.f;
+        }
+        // the writer closes frame i-1 (one launch per frame: now; persistent: behind this frame's publication -- every workgroup of
+        // the utterance waits for the writer's scores, nobody for these stores)
+        auto close_prev = [&]() {
+            const size_t row = ((size_t)b * T + (i - 1)) * L;
+            for (int l = tid; l < L; l += 256) {
+                const float pl = ps[l];
+                p.attn[row + l] = pl;
+                p.logprob[row + l] = logf(pl + 1e-8f);
+                if (i < T) p.cumm_all[((size_t)i * B + b) * L + l] = PERSIST ? cums[l] : (l == tid ? cp0 : cprev[l]) + pl;
+            }
+        };
+        if (writer && i > 0 && (!PERSIST || !work)) close_prev();
+        if (!work) {
+            if constexpr (PERSIST) { if (i < T) { lds_barrier(); continue; } }
+            break;
+        }
+        CUMMF_STAMP(0, 1);
+        if constexpr (PERSIST) lds_barrier();            // (cums complete for the x gather below)
+        // 2. x = [cumm_i ; prev_i] for positions r0 - 3 .. r0 + 34, first convolution
+        if (tid < 2 * 38) {
+            const int ch = tid / 38, pos = tid - 38 * ch, l = r0 - HALO + pos;
+            float x = 0.f;
+            if (l >= 0 && l < L && i > 0) x = ch == 0 ? (PERSIST ? cums[l] : cpx + ps[l]) : ps[l];
+            xs[ch * XW + pos] = x;
+        }
+        if (tid < A / 4) *reinterpret_cast<float4*>(qs + 4 * tid) = stage_q;
+        lds_barrier();
+        conv1_h1(xs, h1s, w1r, b1r, r0, L, tid);
+        lds_barrier();
+        CUMMF_STAMP(0, 2);
+        // 3. cond = sigmoid(conv2(h1)), km = text . cond -> LDS tile [32 rows][E]
+        {
+            bf16x8 cf[2][3];
+            col_frags(h1s, 0, li, kg, cf[0]);
+            col_frags(h1s, 1, li, kg, cf[1]);
 #pragma unroll
-        for (int q = 0; q < NQH; ++q) { acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        stream_gemm<NQH, E / 32, KPE>(acc, wf, wkp, kmt, li, kg);
-        if (zz == 0) CUMMF_STAMP(0, 4);
-        // 5. t = tanh(Q_i + K) (saved), e = v . t / temperature
-        float part[2] = {0.f, 0.f};
+            for (int q = 0; q < NQE; ++q) {
+                const int e0 = 16 * (wave + 4 * q) + 4 * kg;
+                const float4 bv = *reinterpret_cast<const float4*>(b2s + e0);
 #pragma unroll
-        for (int q = 0; q < NQH; ++q) {
-            const int ah = 16 * (wave + 4 * q) + 4 * kg, a0 = AH * zh + ah;       // column inside this half / in A
-            const float4 qv = *reinterpret_cast<const float4*>(qs + a0);
-            const float4 vv = *reinterpret_cast<const float4*>(vs + a0);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                float4 tv;
-                tv.x = 1.f - 2.f * rsig(C2 * (qv.x + acc[q][rt][0]));
-                tv.y = 1.f - 2.f * rsig(C2 * (qv.y + acc[q][rt][1]));
-                tv.z = 1.f - 2.f * rsig(C2 * (qv.z + acc[q][rt][2]));
-                tv.w = 1.f - 2.f * rsig(C2 * (qv.w + acc[q][rt][3]));
-                part[rt] = fmaf(vv.x, tv.x, fmaf(vv.y, tv.y, fmaf(vv.z, tv.z, fmaf(vv.w, tv.w, part[rt]))));
-                *reinterpret_cast<float4*>(tst + (16 * rt + li) * (AH + 4) + ah) = tv;
+                for (int rt = 0; rt < 2; ++rt) {
+                    const f32x4 c = cond_pre(w2f[q], cf[rt]);
+                    const float4 tx = txv[q][rt];
+                    *reinterpret_cast<uint2*>(kmt + (16 * rt + li) * KPE + e0) =
+                        pack4(tx.x * sigm(c[0] + bv.x), tx.y * sigm(c[1] + bv.y), tx.z * sigm(c[2] + bv.z), tx.w * sigm(c[3] + bv.w));
+                }
             }
         }
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            part[rt] += __shfl_xor(part[rt], 16, 64);
-            part[rt] += __shfl_xor(part[rt], 32, 64);
-            if (kg == 0) red[wave * 32 + 16 * rt + li] = part[rt];
-        }
         lds_barrier();
-        if (tid < 32 && r0 + tid < len)
-            atomicAdd(e_out + r0 + tid, ((red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid])) * p.inv_temp);   // (two addends: order-free)
-        // the saved tanh leaves row by row (a lane of the MFMA layout holds 16 bytes of 16 DIFFERENT rows: stored from there the
-        // address unit takes every request apart)
-        for (int idx = tid; idx < FWD_ROWS * (AH / 4); idx += 256) {
-            const int row = idx / (AH / 4), c4 = idx - row * (AH / 4), l = r0 + row;
-            if (l < len) nt_store16(p.tsave + ((size_t)i * RA + (size_t)l * B + b) * A + AH * zh + 4 * c4, tst + row * (AH + 4) + 4 * c4);
+        CUMMF_STAMP(0, 3);
+        for (int zz = 0; zz < nz; ++zz) {
+            const int zh = zh0 + zz;
+            if (zz > 0) {                                 // (unsplit items only: the other half's fragments, one exposed round trip)
+                wkp = frag_base(p.wkimg, wave + 4 * NQH * zh, E / 32, lane) + opaque;
+#pragma unroll
+                for (int d = 0; d < PD; ++d)
+#pragma unroll
+                    for (int q = 0; q < NQH; ++q) wf[d][q] = ld_frag(wkp + (size_t)q * 4 * (E / 32) * FRAG + FRAG * d);
+            }
+            // 4. K^T = W_key km^T: wave w owns the a-tiles w, w + 4, ... of the column half; both row tiles
+            f32x4 acc[NQH][2];
+#pragma unroll
+            for (int q = 0; q < NQH; ++q) { acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            stream_gemm<NQH, E / 32, KPE>(acc, wf, wkp, kmt, li, kg);
+            if (zz == 0) CUMMF_STAMP(0, 4);
+            // 5. t = tanh(Q_i + K) (saved), e = v . t / temperature
+            float part[2] = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NQH; ++q) {
+                const int ah = 16 * (wave + 4 * q) + 4 * kg, a0 = AH * zh + ah;       // column inside this half / in A
+                const float4 qv = *reinterpret_cast<const float4*>(qs + a0);
+                const float4 vv = *reinterpret_cast<const float4*>(vs + a0);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    float4 tv;
+                    tv.x = 1.f - 2.f * rsig(C2 * (qv.x + acc[q][rt][0]));
+                    tv.y = 1.f - 2.f * rsig(C2 * (qv.y + acc[q][rt][1]));
+                    tv.z = 1.f - 2.f * rsig(C2 * (qv.z + acc[q][rt][2]));
+                    tv.w = 1.f - 2.f * rsig(C2 * (qv.w + acc[q][rt][3]));
+                    part[rt] = fmaf(vv.x, tv.x, fmaf(vv.y, tv.y, fmaf(vv.z, tv.z, fmaf(vv.w, tv.w, part[rt]))));
+                    *reinterpret_cast<float4*>(tst + (16 * rt + li) * (AH + 4) + ah) = tv;
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                part[rt] += __shfl_xor(part[rt], 16, 64);
+                part[rt] += __shfl_xor(part[rt], 32, 64);
+                if (kg == 0) red[wave * 32 + 16 * rt + li] = part[rt];
+            }
+            lds_barrier();
+            if (tid < 32 && r0 + tid < len) {
+                const float e = ((red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid])) * p.inv_temp;
+                if constexpr (PERSIST) put_granule(p.gran + (size_t)((i + 1) & 1) * NSP * BL + (size_t)zh * BL + (size_t)b * L + r0 + tid, (unsigned)(i + 1), e);
+                else atomicAdd(e_out + r0 + tid, e);       // (two addends: order-free)
+            }
+            // the saved tanh leaves row by row (a lane of the MFMA layout holds 16 bytes of 16 DIFFERENT rows: stored from there the
+            // address unit takes every request apart)
+            for (int idx = tid; idx < FWD_ROWS * (AH / 4); idx += 256) {
+                const int row = idx / (AH / 4), c4 = idx - row * (AH / 4), l = r0 + row;
+                if (l < len) nt_store16(p.tsave + ((size_t)i * RA + (size_t)l * B + b) * A + AH * zh + 4 * c4, tst + row * (AH + 4) + 4 * c4);
+            }
+            if (zz + 1 < nz || PERSIST) lds_barrier();    // (red / the tanh tile are written again)
         }
-        if (zz + 1 < nz) lds_barrier();                   // (red / the tanh tile are written again)
+        if constexpr (PERSIST) { if (writer && i > 0) close_prev(); }
+        CUMMF_STAMP(0, 5);
     }
-    CUMMF_STAMP(0, 5);
 }
 
 // ---- backward -----------------------------------------------------------------------------------------------------------------
@@ -481,11 +568,17 @@ __global__ __launch_bounds__(256, 1) void cummf_bwd_k(BwdP p, int i, int slot) {
     lds_barrier();
     CUMMF_STAMP(1, 1);
     // col2 rows of the own positions -> stream (B operand of the dw2 GEMM)
-    for (int idx = tid; idx < BWD_OWN * CKP; idx += 256) {
-        const int jo = idx / CKP, ck = idx - CKP * jo, l = o0 + jo;
+    for (int idx = tid; idx < BWD_OWN * (CKP / 8); idx += 256) {      // 16 bytes (8 taps) per lane and store
+        const int jo = idx / (CKP / 8), c8 = idx - (CKP / 8) * jo, l = o0 + jo;
         if (l < len) {
-            const int c = ck / 3, k = ck - 3 * c;
-            p.col2_s[(fr + l) * CKP + ck] = ck < CK ? f2op16(h1s[(l - r0 + k) * H1P + c]) : f2op16(ck == CK ? 1.f : 0.f);
+            float v[8];
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+                const int ck = 8 * c8 + e8, c = ck / 3, k = ck - 3 * c;
+                v[e8] = ck < CK ? h1s[(l - r0 + k) * H1P + c] : (ck == CK ? 1.f : 0.f);
+            }
+            const uint4 u = make_uint4(pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3]), pack_op16x2(v[4], v[5]), pack_op16x2(v[6], v[7]));
+            __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, u), reinterpret_cast<u32x4_t*>(p.col2_s + (fr + l) * CKP + 8 * c8));
         }
     }
     CUMMF_STAMP(1, 8);
@@ -808,6 +901,7 @@ struct Carve {
     unsigned short *w2img, *wkimg, *wkT, *w2T;
     float *ebuf, *gbuf, *DV, *dv_part, *dw1_part, *db1_part;
     int* items;                                            // forward work list
+    unsigned long long* gran;                              // forward, persistent form: score granules
     int *rowbase, *rows_dev;                               // backward: packed stream rows
     float4 *text_l, *dtx;                                  // lane-order text (forward or backward tiling) and its gradient
     size_t lane_bytes;
@@ -825,6 +919,7 @@ Carve carve(void* base, int T, int L, int B, int E, int A, bool bwd) {
     c.wkimg = reinterpret_cast<unsigned short*>(take((size_t)A * E * 2 + 256));
     c.ebuf = reinterpret_cast<float*>(take((size_t)3 * B * L * 4));
     c.items = reinterpret_cast<int*>(take(sizeof(int) * (1 + (size_t)NSP * B * cdiv(L, FWD_ROWS))));
+    c.gran = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long) * (size_t)2 * NSP * B * L));
     c.lane_bytes = (size_t)B * cdiv(L, bwd ? BWD_OWN : FWD_ROWS) * 4 * (E / 64) * 2 * 64 * sizeof(float4);
     c.text_l = reinterpret_cast<float4*>(take(c.lane_bytes));
     if (bwd) {
@@ -909,12 +1004,24 @@ int FT_OPNAME(ftint_cummf_fwd)(const ft_cumm_attn_args* a, hipStream_t st) {
     p.in_lens = a->in_lens; p.attn = a->attn; p.logprob = a->logprob; p.cumm_all = a->cumm_all; p.tsave = a->kproj_all; p.ebuf = c.ebuf; p.text_f = c.text_l; p.items = c.items;
     p.T = T; p.B = B; p.L = L; p.NJ = cdiv(L, FWD_ROWS); p.inv_temp = 1.0f / a->temperature; p.prof = g_cummf_prof;
     const int Lp = (L + 3) & ~3;
-    const size_t lds = sizeof(float) * ((size_t)Lp + 2 * XW + 34 * H1P + 2 + 128 + 2 * A + E) + (size_t)32 * (E + 8) * 2 + sizeof(float) * 32 * (A / NSP + 4);
-    FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cummf_fwd_k<10, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = sizeof(float) * ((size_t)2 * Lp + 2 * XW + 34 * H1P + 2 + 128 + 2 * A + E) + (size_t)32 * (E + 8) * 2 + sizeof(float) * 32 * (A / NSP + 4);
     FT_CHECK_ARG(B < 32768 && cdiv(L, FWD_ROWS) < 4096);
     const dim3 grid(NSP * B * cdiv(L, FWD_ROWS));
-    for (int i = 0; i <= T; ++i)                     // launch T only closes frame T-1 (softmax, attn, logprob)
-        hipLaunchKernelGGL((cummf_fwd_k<10, 10>), grid, dim3(256), lds, st, p, i);
+    // ONE persistent launch for all frames where the work list is co-resident by construction: it holds min(2 x valid tiles, n_cu)
+    // or (unsplit) valid tiles <= B x ceil(L / 32) workgroups of one per CU (96 KB of LDS), the rest of the grid exits at once.
+    // Needs the caller's status word (a->persist_status: the wait that gives up raises it; FT_CUMM_PERSIST=0 keeps one launch per frame).
+    const char* pe = getenv("FT_CUMM_PERSIST");
+    const bool persist = a->persist_status != nullptr && !(pe && atoi(pe) == 0) && B * cdiv(L, FWD_ROWS) <= n_cu;
+    if (persist) {
+        FT_CHECK_HIP(hipMemsetAsync(c.gran, 0, sizeof(unsigned long long) * (size_t)2 * NSP * B * L, st));       // epoch 0: never awaited
+        p.gran = c.gran; p.status = a->persist_status;
+        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cummf_fwd_k<10, 10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((cummf_fwd_k<10, 10, true>), grid, dim3(256), lds, st, p, 0, T);
+    } else {
+        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cummf_fwd_k<10, 10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (int i = 0; i <= T; ++i)                 // launch T only closes frame T-1 (softmax, attn, logprob)
+            hipLaunchKernelGGL((cummf_fwd_k<10, 10, false>), grid, dim3(256), lds, st, p, i, i);
+    }
     FT_CHECK_LAUNCH();
     // ctx[t][b][:] = sum_l attn[b][t][l] V[l][b][:]   (not part of the frame-to-frame dependency: one batched GEMM)
     CK_(bgemm(a->attn, a->V, a->ctx, T, A, L, L, 1, (long)B * A, 1, (long)B * A, B, (long)T * L, A, A, a->mode, st));

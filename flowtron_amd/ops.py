@@ -325,8 +325,35 @@ def colsum(x2d: torch.Tensor, rows: int, N: int, ld: int) -> torch.Tensor:
     return out
 
 
+_LENS_CACHE = {}
+
+
+def _lens_entry(lens: torch.Tensor):
+    """int32 copy and element sum of a length vector, made ONCE per tensor (keyed by storage address + version): the same in_lens /
+    out_lens reach the model, every flow, the three losses and their backward passes -- a copy + a reduction + a cast of four-byte
+    kernels each time (~20 dispatches of ~5 us per training step)"""
+    key = (lens.data_ptr(), lens._version, lens.numel(), lens.dtype, lens.device)
+    e = _LENS_CACHE.get(key)
+    if e is None or e[0]() is not lens:
+        import weakref
+        if len(_LENS_CACHE) > 64:
+            _LENS_CACHE.clear()
+        i32 = lens if (lens.dtype == torch.int32 and lens.is_contiguous()) else lens.to(dtype=torch.int32).contiguous()
+        e = _LENS_CACHE[key] = (weakref.ref(lens), i32, {})
+    return e
+
+
 def lens32(lens: torch.Tensor) -> torch.Tensor:
-    return lens.to(dtype=torch.int32).contiguous()
+    return _lens_entry(lens)[1]
+
+
+def lens_total(lens: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """float32 device scalar sum(lens) * scale (the normalisers of the losses, flowtron.py:206-243)"""
+    e = _lens_entry(lens)
+    t = e[2].get(scale)
+    if t is None:
+        t = e[2][scale] = e[1].sum().to(torch.float32) * scale if scale != 1.0 else e[1].sum().to(torch.float32)
+    return t
 
 
 # --------------------------------------------------------------------------
@@ -367,7 +394,9 @@ class LinearFn(torch.autograd.Function):
             split_imgs = None
             if Ktot % 32 == 0 and images_apply(mode_dx, rows, N, Ktot):
                 xi, wi = Bf16Image.split3(x2d, mode_dx, False), Bf16Image.split3(W, mode_dx, True)
-                gemm_img(xi, 0, xi.ptr(), wi, 0, wi.ptr(), y, rows, N, 3 * Ktot, N, bias=bias)
+                # K = 3 Ktot over only (rows / 128) x (N / 128) output tiles (160 for the encoder: a sixth of the chip's workgroup slots,
+                # 240 k-steps each: 130 us): split-K fills the chip (the bias rides on the first slice)
+                gemm_img(xi, 0, xi.ptr(), wi, 0, wi.ptr(), y, rows, N, 3 * Ktot, N, bias=bias, splitk=True)
                 split_imgs = (wi.view_cols(Ktot), [xi.view_cols(Ktot)])      # their [hi] blocks serve the backward's GEMMs as they are
             else:
                 gemm_raw(x2d, W, y, rows, N, Ktot, Ktot, 1, 1, Ktot, N, bias=bias, mode=L.FT_F32)
@@ -1202,7 +1231,14 @@ class CummAttnSeqFn(torch.autograd.Function):
         work = torch.empty(L.lib().ft_cumm_attn_workspace_bytes(T, Lk, B, E, A, NF, K1, K2, int(mode), 0) + 256, device=Q.device, dtype=torch.uint8)
         args = CummAttnSeqFn._args(Q, V, text, w_key, v, w1, b1, w2, b2, in_lens, out_ctx, attn, logprob, cumm_all, kproj_all, work,
                                    temperature, mode)
+        # the fused frames as persistent launches (one for all forward frames, one per chunk of backward frames) on a device whose
+        # whole-chip grids passed the self-test: same status word, same watch / poison / fallback chain as the persistent recurrences
+        st = _persist_watch(Q.device) if (L.is16(mode) and _os.environ.get("FLOWTRON_CUMM_PERSIST", "1") != "0" and persist_usable(Q.device)) else None
+        if st is not None:
+            args.persist_status = L.ptr(st.status)
         L.check(L.lib().ft_cumm_attn_fwd(C.byref(args), L.stream()), "ft_cumm_attn_fwd")
+        if st is not None and L.lib().ft_cumm_attn_fused(C.byref(args)):
+            _persist_arm(st)
         ctx.save_for_backward(Q, V, text, w_key, v, w1, b1, w2, b2, in_lens, attn, cumm_all, kproj_all)
         ctx.temperature, ctx.mode = float(temperature), mode
         return out_ctx, attn, logprob
@@ -1215,7 +1251,7 @@ class CummAttnSeqFn(torch.autograd.Function):
         return L.CummAttnArgs(L.ptr(text), L.ptr(Q), L.ptr(V), L.ptr(w_key), L.ptr(v), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2),
                               L.ptr(in_lens), L.ptr(out_ctx), L.ptr(attn), L.ptr(logprob), L.ptr(cumm_all), L.ptr(kproj_all),
                               base, work.numel() - (base - work.data_ptr()), T, B, Lk, E, A, w1.shape[0], w1.shape[2], w2.shape[2],
-                              float(temperature), int(mode))
+                              float(temperature), int(mode), None)
 
     @staticmethod
     def backward(ctx, dctx, dattn, dlogprob):
@@ -1315,7 +1351,7 @@ class NLLFn(torch.autograd.Function):
             assert ls.shape == z.shape and ls.stride(2) == 1 and ls.stride(1) * B == ls.stride(0)
             lds.append(ls.stride(1))
             L.check(L.lib().ft_masked_sum(L.ptr(ls), ls.stride(1), L.ptr(lens), L.ptr(acc[1:]), 0, T, B, M, st), "ft_masked_sum")
-        n = lens.sum().to(torch.float32) * M
+        n = lens_total(lens, float(M))
         nll = (acc[0] / (2.0 * sigma * sigma) - acc[1]) / n
         ctx.save_for_backward(z, lens, n)
         ctx.sigma, ctx.n_ls = sigma, len(log_s)
@@ -1348,7 +1384,7 @@ class GateBCEFn(torch.autograd.Function):
         T, B = gate.shape[0], gate.shape[1]
         acc = torch.zeros(1, device=gate.device, dtype=torch.float32)
         L.check(L.lib().ft_gate_bce_fwd(L.ptr(gate), L.ptr(target), L.ptr(lens), L.ptr(acc), T, B, L.stream()), "ft_gate_bce_fwd")
-        n = lens.sum().to(torch.float32)
+        n = lens_total(lens)
         ctx.save_for_backward(gate, target, lens, n)
         return (acc / n).reshape(())
 

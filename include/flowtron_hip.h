@@ -465,6 +465,11 @@ typedef struct {
     int T, B, L, E, A, NF, K1, K2;
     float temperature;
     int mode;
+    /* optional (ABI 11): a device status word (zeroed by the caller once; the one the persistent recurrences use will do).  When given,
+     * and the fused path's work list is co-resident by construction (B x ceil(L / 32) <= CUs), the forward frames run as ONE
+     * persistent launch (per-utterance granule hand-offs instead of a launch boundary per frame); *persist_status becomes non-zero if
+     * a hand-off wait gives up (grid not co-resident: a foreign kernel holds CUs) -- the caller must then not trust the outputs. */
+    int32_t* persist_status;
 } ft_cumm_attn_args;
 size_t ft_cumm_attn_workspace_bytes(int T, int L, int B, int E, int A, int NF, int K1, int K2, int mode, int backward);
 int ft_cumm_attn_fused(const ft_cumm_attn_args* a);     /* 1: fwd / bwd of these arguments take the fused one-launch-per-frame path */

@@ -1211,7 +1211,7 @@ def _cumm_reference(Q, V, text, wk, v, w1, b1, w2, b2, in_lens, temp):
     return torch.stack(ctxs, 0), torch.stack(attns, 1), torch.stack(lps, 1)
 
 
-@pytest.mark.parametrize("fmt,split", [(1, "1"), (2, "1"), (1, "0"), (1, "chunk4")])
+@pytest.mark.parametrize("fmt,split", [(1, "1"), (2, "1"), (1, "0"), (1, "chunk4"), (1, "frames")])
 @pytest.mark.parametrize("T,Lk,lens", [(23, 57, [57, 52, 26, 7]), (5, 157, [157, 130, 33]), (9, 20, [20, 1])])
 def test_fused_cumulative_attention_frames_vs_float64_reference(env, monkeypatch, fmt, split, T, Lk, lens):
     """ONE fused launch per frame and direction (ft_cumm_attn_fwd / _bwd -> csrc/cumm_fused.hip, the path of
@@ -1242,6 +1242,8 @@ def test_fused_cumulative_attention_frames_vs_float64_reference(env, monkeypatch
         monkeypatch.setenv("FT_CUMM_FUSED", "1" if fused else "0")
         # split: forward tiles as two column-half workgroups (default when they fit the chip) / one; chunk4: the backward's streams in
         # chunks of four frames -- several accumulated rounds of the weight-gradient GEMMs, a partial top chunk
+        # default: the frames of a pass inside PERSISTENT launches (granule hand-offs); frames: one launch per frame
+        monkeypatch.setenv("FLOWTRON_CUMM_PERSIST", "0" if split == "frames" else "1")
         monkeypatch.setenv("FT_CUMM_SPLIT", "0" if split == "0" else "1")
         if split.startswith("chunk"):
             monkeypatch.setenv("FT_CUMM_CHUNK", "4")
