@@ -119,6 +119,8 @@ SIGNATURES = {
     "ft_masked_sum_bwd": ([_p, _l, _p, _p, _f, _i, _p, _l, _i, _i, _i, _p], _i),
     "ft_gate_bce_fwd": ([_p, _p, _p, _p, _i, _i, _p], _i),
     "ft_gate_bce_bwd": ([_p, _p, _p, _p, _f, _p, _i, _i, _p], _i),
+    "ft_flowtron_loss_fwd": ([_p, _p, _i, _l, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _p], _i),
+    "ft_flowtron_loss_bwd": ([_p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "ft_reverse_by_length": ([_p, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_act_bwd": ([_p, _p, _p, _l, _i, _p], _i),
     "ft_eltwise": ([_p, _p, _p, _l, _i, _p], _i),
@@ -134,6 +136,8 @@ SIGNATURES = {
     "ft_attn_ctc_workspace_floats": ([_i, _i, _i], _sz),
     "ft_attn_ctc_fwd": ([_p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_attn_ctc_bwd": ([_p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "ft_attn_ctc_fwd_multi": ([_p, _p, _i, _p, _p, _f, _p, _p, _i, _i, _i, _i, _p], _i),
+    "ft_attn_ctc_bwd_multi": ([_p, _p, _i, _p, _p, _f, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_beta_binomial_prior": ([_p, _p, _p, _i, _i, _i, _f, _p], _i),
     "ft_sumsq": ([_p, _p, _l, _p, _p], _i),
     "ft_radam_step": ([_p, _p, _p, _p, _l, _p, _d, _d, _d, _d, _d, _d, _d, _i, _p, _p], _i),
@@ -163,7 +167,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argt
             fn.restype = rest
-        if l.ft_abi_version() != 11:
+        if l.ft_abi_version() != 12:
             raise RuntimeError("libflowtron_hip.so ABI version mismatch")
         _lib = l
     return _lib

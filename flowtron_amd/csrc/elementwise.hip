@@ -202,6 +202,81 @@ __global__ void gate_bce_bwd_k(const float* __restrict__ gate, const float* __re
     }
 }
 
+// ---------------- FlowtronLoss in four launches (flowtron.py:200-243) ----------------
+// The per-term kernels above leave the scalar arithmetic (the frame count, the normalisers, g / n in backward) to the caller: ~40
+// four-byte torch kernels per training step, right where the host waits for the losses (train.py:300-303 .item()).  Here the sums of
+// z and of every flow's log_s come from ONE pass, a one-workgroup kernel forms n = sum(lens) and the two losses on the device and
+// leaves 1 / (n M) and 1 / n for the backward kernels, which read the incoming gradients through pointers.
+// acc: [0] sum z^2, [1] sum log_s, [2] sum BCE, [4] 1 / (n M), [5] 1 / n, [6] n
+struct LsPtrs { const float* p[8]; };
+
+__global__ void nll_sums_k(const float* __restrict__ z, LsPtrs ls, int n_ls, long ld_ls, const int* __restrict__ lens,
+                           float* __restrict__ acc, int T, int B, int M) {
+    __shared__ float red[NT / 64];
+    const long total = (long)T * B * M;
+    float s2 = 0.f, sl = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / M;
+        const int c = (int)(i - row * M);
+        const int t = (int)(row / B), b = (int)(row - (long)t * B);
+        if (t < lens[b]) {
+            const float v = z[i];
+            s2 += v * v;
+            for (int f = 0; f < n_ls; ++f) sl += ls.p[f][row * ld_ls + c];
+        }
+    }
+    s2 = block_sum(s2, red);
+    sl = block_sum(sl, red);
+    if (threadIdx.x == 0) { atomicAdd(acc, s2); atomicAdd(acc + 1, sl); }
+}
+
+__global__ void loss_finalize_k(float* __restrict__ acc, const int* __restrict__ lens, int B, int M, float two_sigma2,
+                                float* __restrict__ nll_out, float* __restrict__ gate_out) {
+    __shared__ float red[NT / 64];
+    float n = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) n += (float)lens[b];
+    n = block_sum(n, red);
+    if (threadIdx.x == 0) {
+        const float nm = n * (float)M;
+        nll_out[0] = (acc[0] / two_sigma2 - acc[1]) / nm;
+        if (gate_out) gate_out[0] = acc[2] / n;
+        acc[4] = 1.f / nm;
+        acc[5] = 1.f / n;
+        acc[6] = n;
+    }
+}
+
+// dz = g inv_nm z / sigma^2, dls = -g inv_nm at valid frames, 0 at padded ones (dls: ONE tensor, the gradient of every flow's log_s)
+__global__ void nll_bwd_k(const float* __restrict__ z, const int* __restrict__ lens, const float* __restrict__ g,
+                          const float* __restrict__ inv_nm, float inv_sigma2, float* __restrict__ dz, float* __restrict__ dls,
+                          int T, int B, int M) {
+    const long total = (long)T * B * M;
+    const float sc = g[0] * inv_nm[0];
+    const float scz = sc * inv_sigma2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / M;
+        const int t = (int)(row / B), b = (int)(row - (long)t * B);
+        const bool valid = t < lens[b];
+        dz[i] = valid ? scz * z[i] : 0.f;
+        if (dls) dls[i] = valid ? -sc : 0.f;
+    }
+}
+
+__global__ void gate_bce_bwd2_k(const float* __restrict__ gate, const float* __restrict__ target, const int* __restrict__ lens,
+                                const float* __restrict__ g, const float* __restrict__ inv_n, float* __restrict__ dgate, int T, int B) {
+    const long total = (long)T * B;
+    const float sc = g[0] * inv_n[0];
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i / B), b = (int)(i - (long)t * B);
+        float v = 0.f;
+        if (t < lens[b]) {
+            const float gl = gate[i], y = target[(long)b * T + t];
+            v = sc * (1.f / (1.f + expf(-gl)) - y);
+        }
+        dgate[i] = v;
+    }
+}
+
 // ---------------- column sums ----------------
 // grid.x = column blocks of 64, grid.y = row slabs; 256 threads = 4 row-lanes x 64 columns.
 __global__ void colsum_k(const float* __restrict__ x, float* __restrict__ out, long rows, int N, long ld, long rows_per_slab) {
@@ -441,6 +516,39 @@ extern "C" int ft_gate_bce_bwd(const float* gate, const float* target, const int
     FT_CHECK_ARG(gate && target && lens && scale_dev && dgate && T >= 0 && B >= 1);
     if (T == 0) return FT_OK;
     hipLaunchKernelGGL(gate_bce_bwd_k, dim3(grid_for((int64_t)T * B)), dim3(NT), 0, ST(stream), gate, target, lens, scale_dev, coef, dgate, T, B);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_flowtron_loss_fwd(const float* z, const float* const* log_s, int n_ls, int64_t ld_ls, const float* gate,
+                                    const float* gate_target, const int32_t* out_lens, float sigma, float* acc, float* nll_out,
+                                    float* gate_out, int T, int B, int M, void* stream) {
+    FT_CHECK_ARG(z && out_lens && acc && nll_out && T >= 1 && B >= 1 && M >= 1 && sigma > 0.f);
+    FT_CHECK_ARG(n_ls >= 0 && n_ls <= 8 && (n_ls == 0 || (log_s && ld_ls >= M)));
+    FT_CHECK_ARG((gate == nullptr) == (gate_out == nullptr) && (gate == nullptr || gate_target != nullptr));
+    LsPtrs ls{};
+    for (int f = 0; f < n_ls; ++f) { FT_CHECK_ARG(log_s[f] != nullptr); ls.p[f] = log_s[f]; }
+    FT_CHECK_HIP(hipMemsetAsync(acc, 0, 8 * sizeof(float), ST(stream)));
+    hipLaunchKernelGGL(nll_sums_k, dim3(grid_for((int64_t)T * B * M, NT, 1024)), dim3(NT), 0, ST(stream), z, ls, n_ls, (long)ld_ls, out_lens,
+                       acc, T, B, M);
+    if (gate)
+        hipLaunchKernelGGL(gate_bce_fwd_k, dim3(grid_for((int64_t)T * B, NT, 256)), dim3(NT), 0, ST(stream), gate, gate_target, out_lens, acc + 2,
+                           T, B);
+    hipLaunchKernelGGL(loss_finalize_k, dim3(1), dim3(NT), 0, ST(stream), acc, out_lens, B, M, 2.0f * sigma * sigma, nll_out, gate_out);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_flowtron_loss_bwd(const float* z, const float* gate, const float* gate_target, const int32_t* out_lens, float sigma,
+                                    const float* acc, const float* g_nll, const float* g_gate, float* dz, float* dls, float* dgate,
+                                    int T, int B, int M, void* stream) {
+    FT_CHECK_ARG(out_lens && acc && T >= 1 && B >= 1 && M >= 1 && sigma > 0.f);
+    FT_CHECK_ARG((g_nll == nullptr) == (dz == nullptr) && (dz == nullptr || z != nullptr) && (dls == nullptr || dz != nullptr));
+    FT_CHECK_ARG((g_gate == nullptr) == (dgate == nullptr) && (dgate == nullptr || (gate && gate_target)));
+    if (dz)
+        hipLaunchKernelGGL(nll_bwd_k, dim3(grid_for((int64_t)T * B * M)), dim3(NT), 0, ST(stream), z, out_lens, g_nll, acc + 4,
+                           1.0f / (sigma * sigma), dz, dls, T, B, M);
+    if (dgate)
+        hipLaunchKernelGGL(gate_bce_bwd2_k, dim3(grid_for((int64_t)T * B)), dim3(NT), 0, ST(stream), gate, gate_target, out_lens, g_gate,
+                           acc + 5, dgate, T, B);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

@@ -610,6 +610,16 @@ class FlowtronLoss(nn.Module):
     def forward(self, model_output, gate_target, in_lengths, out_lengths, is_validation=False):
         z, log_s_list, gate_pred, attn_list, attn_logprob_list = model_output[:5]
         out32 = ops.lens32(out_lengths)
+        use_gate = self.gate_loss > 0
+        lps = list(attn_logprob_list) if self.use_ctc_loss else []
+        if ops.FUSED_LOSS and len(log_s_list) <= 8 and len(lps) <= 8 and all(lp is not None for lp in lps):
+            # one autograd node, ten launches forward + backward (ops.FlowtronLossFn); the per-term path below is its restatement
+            loss, gate_loss, loss_ctc = ops.FlowtronLossFn.apply(z, gate_pred if use_gate else None, gate_target if use_gate else None,
+                                                                 out32, ops.lens32(in_lengths), float(self.sigma),
+                                                                 float(self.blank_logprob), len(log_s_list), *log_s_list, *lps)
+            if not self.use_ctc_loss:
+                loss_ctc = torch.zeros_like(gate_loss)
+            return loss, gate_loss, loss_ctc
         loss = ops.NLLFn.apply(z, out32, float(self.sigma), *log_s_list)
         gate_loss = torch.zeros(1, device=z.device)
         if self.gate_loss > 0:

@@ -1485,6 +1485,97 @@ class AttnCTCFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------
+# FlowtronLoss as ONE autograd node (flowtron.py:200-274): NLL + gate + attention-CTC of all flows
+# --------------------------------------------------------------------------
+FUSED_LOSS = _os.environ.get("FLOWTRON_FUSED_LOSS", "1") != "0"
+
+
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+class FlowtronLossFn(torch.autograd.Function):
+    """(nll, gate_loss, ctc) from seven launches, their gradients from three -- where NLLFn + GateBCEFn + AttnCTCFn and the torch
+    arithmetic around them (frame counts, normalisers, `g / n`, the concatenation of the flows' log-probabilities, the flip of the
+    back-step flows', `lens.repeat(F)`) took ~55 dispatches of 4-20 us per training step, most of them in front of the host's
+    .item() reads (train.py:300-303) and at the head of backward, where the GPU waits for the host.
+    tensors = n_ls log_s views [T,B,M] (strided views of the coupling outputs) followed by the flows' attention log-probabilities
+    [B,T,L] in flows order, each in ITS flow's time order (odd flows reversed: ft_attn_ctc_fwd_multi mirrors the row index)."""
+
+    @staticmethod
+    def forward(ctx, z, gate_pred, gate_target, out32, in32, sigma, blank, n_ls, *tensors):
+        z = _c(z)
+        log_s, lps = list(tensors[:n_ls]), [_c(t) for t in tensors[n_ls:]]
+        L.require_cuda(z, gate_pred, gate_target, out32, in32, *log_s, *lps)
+        T, B, M = z.shape
+        dev = z.device
+        st = L.stream()
+        ld = M
+        for ls in log_s:
+            assert ls.shape == z.shape and ls.dtype == torch.float32 and ls.stride(2) == 1 and ls.stride(1) * B == ls.stride(0)
+        if log_s:
+            ld = int(log_s[0].stride(1))
+            assert all(int(ls.stride(1)) == ld for ls in log_s)
+        acc = torch.empty(8, device=dev, dtype=torch.float32)
+        nll = torch.empty((), device=dev, dtype=torch.float32)
+        gate_loss = None
+        if gate_pred is not None:
+            gate_pred, gate_target = _c(gate_pred), _c(gate_target.float())
+            assert gate_pred.numel() == T * B and gate_target.shape == (B, T)
+            gate_loss = torch.empty((), device=dev, dtype=torch.float32)
+        L.check(L.lib().ft_flowtron_loss_fwd(L.ptr(z), _ptr_array(log_s) if log_s else None, len(log_s), ld, L.ptr(gate_pred),
+                                             L.ptr(gate_target), L.ptr(out32), float(sigma), L.ptr(acc), L.ptr(nll), L.ptr(gate_loss),
+                                             T, B, M, st), "ft_flowtron_loss_fwd")
+        ctc = work = None
+        ctx.with_beta = 0
+        if lps:
+            F_, (Bl, Tl, Lk) = len(lps), lps[0].shape
+            assert Bl == B and all(lp.shape == lps[0].shape and lp.dtype == torch.float32 for lp in lps)
+            ctx.rev = (C.c_int32 * F_)(*[f % 2 for f in range(F_)])          # back-step flows: reversed time (flowtron.py:250-256)
+            ctx.with_beta = int(any(ctx.needs_input_grad[8 + n_ls + f] for f in range(F_)))
+            work = torch.empty(L.lib().ft_attn_ctc_workspace_floats(F_ * B, Tl, Lk), device=dev, dtype=torch.float32)
+            ctc = torch.empty((), device=dev, dtype=torch.float32)
+            L.check(L.lib().ft_attn_ctc_fwd_multi(_ptr_array(lps), ctx.rev, F_, L.ptr(in32), L.ptr(out32), float(blank), L.ptr(work),
+                                                  L.ptr(ctc), B, Tl, Lk, ctx.with_beta, st), "ft_attn_ctc_fwd_multi")
+        ctx.save_for_backward(z, gate_pred, gate_target, out32, in32, acc, work, *lps)
+        ctx.sigma, ctx.blank, ctx.n_ls, ctx.n_lp = float(sigma), float(blank), n_ls, len(lps)
+        outs = (nll, gate_loss if gate_loss is not None else torch.zeros(1, device=dev),
+                ctc if ctc is not None else torch.zeros(1, device=dev))
+        ctx.mark_non_differentiable(*[o for o, live in zip(outs[1:], (gate_loss is not None, ctc is not None)) if not live])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_nll, g_gate, g_ctc):
+        z, gate_pred, gate_target, out32, in32, acc, work, *lps = ctx.saved_tensors
+        T, B, M = z.shape
+        st = L.stream()
+
+        def scalar(g):
+            return None if g is None else _c(g.reshape(1).to(torch.float32))
+
+        g_nll = scalar(g_nll) if (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[8:8 + ctx.n_ls])) else None
+        g_gate = scalar(g_gate) if (gate_pred is not None and ctx.needs_input_grad[1]) else None
+        dz = dls = dgate = None
+        if g_nll is not None:
+            dz = torch.empty_like(z)
+            dls = torch.empty_like(z) if ctx.n_ls else None
+        if g_gate is not None:
+            dgate = torch.empty_like(gate_pred)
+        if dz is not None or dgate is not None:
+            L.check(L.lib().ft_flowtron_loss_bwd(L.ptr(z), L.ptr(gate_pred), L.ptr(gate_target), L.ptr(out32), ctx.sigma, L.ptr(acc),
+                                                 L.ptr(g_nll), L.ptr(g_gate), L.ptr(dz), L.ptr(dls), L.ptr(dgate), T, B, M, st),
+                    "ft_flowtron_loss_bwd")
+        dlps = [None] * ctx.n_lp
+        if lps and g_ctc is not None and any(ctx.needs_input_grad[8 + ctx.n_ls:]):
+            g_ctc = scalar(g_ctc)
+            dlps = [torch.empty_like(lp) for lp in lps]
+            _, Tl, Lk = lps[0].shape
+            L.check(L.lib().ft_attn_ctc_bwd_multi(_ptr_array(lps), ctx.rev, len(lps), L.ptr(in32), L.ptr(out32), ctx.blank, L.ptr(work),
+                                                  L.ptr(g_ctc), _ptr_array(dlps), B, Tl, Lk, ctx.with_beta, st), "ft_attn_ctc_bwd_multi")
+        return (dz, dgate, None, None, None, None, None, None) + (dls,) * ctx.n_ls + tuple(dlps)
+
+
+# --------------------------------------------------------------------------
 # two stacked LSTM layers as one launch chain (csrc/lstm2.hip)
 # --------------------------------------------------------------------------
 class LSTM2SeqFn(torch.autograd.Function):

@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 11
+#define FT_ABI_VERSION 12
 
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1, FT_F16 = 2 };
@@ -344,6 +344,23 @@ int ft_gate_bce_fwd(const float* gate, const float* target, const int32_t* lens,
 int ft_gate_bce_bwd(const float* gate, const float* target, const int32_t* lens, const float* scale_dev, float coef,
                     float* dgate, int T, int B, void* stream);
 
+/* ---- FlowtronLoss.forward's NLL + gate terms in four launches, their backward in two (flowtron.py:200-243; ABI 12) ------------
+ * The per-term entry points above leave the scalar arithmetic (frame count, normalisers, g / n) to the caller -- ~40 four-byte
+ * kernels per training step right where train.py:300-303 waits for the losses.  fwd: acc (8 floats, zeroed here) receives
+ * [0] sum_valid z^2, [1] sum_f sum_valid log_s[f], [2] sum_valid BCE, and from a one-workgroup kernel [4] 1 / (n M), [5] 1 / n,
+ * [6] n = sum(out_lens); nll_out[0] = (acc[0] / (2 sigma^2) - acc[1]) / (n M), gate_out[0] = acc[2] / n (gate, gate_target,
+ * gate_out all NULL: no gate term).  z [T,B,M] contiguous; log_s = HOST array of n_ls (<= 8) device pointers to [T,B,M] views
+ * with row stride ld_ls; gate [T,B], gate_target [B,T].
+ * bwd (reads acc as fwd left it; g_nll / g_gate = device scalars, the gradients of the two outputs): dz = g_nll z / (sigma^2 n M),
+ * dls = -g_nll / (n M) (ONE tensor: the gradient of every flow's log_s; may be NULL), dgate = g_gate (sigmoid(gate) - target) / n,
+ * all zero at padded frames.  (g_nll, dz) and (g_gate, dgate) are each both NULL or both set. */
+int ft_flowtron_loss_fwd(const float* z, const float* const* log_s, int n_ls, int64_t ld_ls, const float* gate,
+                         const float* gate_target, const int32_t* out_lens, float sigma, float* acc, float* nll_out,
+                         float* gate_out, int T, int B, int M, void* stream);
+int ft_flowtron_loss_bwd(const float* z, const float* gate, const float* gate_target, const int32_t* out_lens, float sigma,
+                         const float* acc, const float* g_nll, const float* g_gate, float* dz, float* dls, float* dgate,
+                         int T, int B, int M, void* stream);
+
 /* ---- reverse-by-length (flowtron.py:606-622, the flip+roll involution) --------
  * time_major=1: x,y [T,B,C]; time_major=0: x,y [B,T,C].
  * y[t] = x[len-1-t] (t < len), x[T-1+len-t] (t >= len). */
@@ -440,6 +457,17 @@ int ft_attn_ctc_fwd(const float* lp, const int32_t* in_lens, const int32_t* out_
                     float* work, float* loss, int B, int T, int L, int with_beta, void* stream);
 int ft_attn_ctc_bwd(const float* lp, const int32_t* in_lens, const int32_t* out_lens, float blank_logprob,
                     float* work, const float* gout_dev, float* dlp, int B, int T, int L, int beta_ready, void* stream);
+/* The same loss over F flows at once (FlowtronLoss, flowtron.py:245-274: the per-flow losses averaged): F * B stacked samples,
+ * sample f * B + b = flow f's log-probabilities of utterance b; loss[0] = mean over flows of the per-flow batch means.  lp / dlp:
+ * HOST arrays of F (<= 8) device pointers to [B,T,L] tensors; reversed[f] != 0 (host array): flow f's tensor is in REVERSED time
+ * (an AR_Back_Step: frame t of utterance b is row out_lens[b] - 1 - t) -- the reference flips + rolls the tensor there and back
+ * (:250-271), here the row index is mirrored in the kernels, for the loss and for dlp[f] (which comes out in the flow's own order).
+ * No concatenated or re-reversed copy exists.  work: ft_attn_ctc_workspace_floats(F * B, T, L) floats.  (ABI 12) */
+int ft_attn_ctc_fwd_multi(const float* const* lp, const int32_t* reversed, int F, const int32_t* in_lens, const int32_t* out_lens,
+                          float blank_logprob, float* work, float* loss, int B, int T, int L, int with_beta, void* stream);
+int ft_attn_ctc_bwd_multi(const float* const* lp, const int32_t* reversed, int F, const int32_t* in_lens, const int32_t* out_lens,
+                          float blank_logprob, float* work, const float* gout_dev, float* const* dlp, int B, int T, int L,
+                          int beta_ready, void* stream);
 
 /* ---- cumulative ("location-sensitive") attention of a teacher-forced flow, one call per sequence ----------
  * flowtron.py:697-723 (run_cumm_attn_sequence), :129-152 (AttentionConditioningLayer), :544-592 (Attention.forward).  Per frame

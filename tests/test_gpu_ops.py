@@ -510,6 +510,67 @@ def test_attention_ctc_kernel_vs_oracle(env, blank):
     assert float(lpd2.grad[2].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("n_flows", [1, 2, 3])
+def test_fused_flowtron_loss_vs_oracle_and_per_term_path(env, n_flows):
+    """ops.FlowtronLossFn (ft_flowtron_loss_fwd/bwd + ft_attn_ctc_fwd/bwd_multi: one autograd node, the odd flows' log-probabilities
+    read in reversed time by the kernels) against (a) the oracle's FlowtronLoss restatement (flowtron.py:200-274, which flips and rolls
+    them) and (b) the per-term path (NLLFn + GateBCEFn + reverse_by_length + cat + AttnCTCFn) on the same device inputs."""
+    L, ops = env
+    from oracle import flowtron_oracle as O
+    from flowtron_amd.model import FlowtronLoss
+    torch.manual_seed(40 + n_flows)
+    T, B, M, Lk = 29, 4, 80, 11
+    out_lens = torch.tensor([29, 21, 12, 5])
+    in_lens = torch.tensor([11, 9, 6, 2])
+    outs = [(torch.randn(T, B, 2 * M) * 0.3).requires_grad_(True) for _ in range(n_flows)]
+    z = torch.randn(T, B, M, requires_grad=True)
+    gate = torch.randn(T, B, 1, requires_grad=True)
+    target = torch.zeros(B, T)
+    for b in range(B):
+        target[b, out_lens[b] - 1:] = 1
+    lps = [torch.log_softmax(torch.randn(B, T, Lk) * 2, 2).requires_grad_(True) for _ in range(n_flows)]
+    w = (0.7, 1.3, 0.11)
+
+    def total(l3):
+        return w[0] * l3[0] + w[1] * l3[1].sum() + w[2] * l3[2].sum()
+
+    ref = O.loss((z, [o[..., :M] for o in outs], gate, [None] * n_flows, lps), target, in_lens, out_lens, 0.8, True, True, blank_logprob=-4.0)
+    total(ref).backward()
+    crit = FlowtronLoss(sigma=0.8, gate_loss=True, use_ctc_loss=True, ctc_loss_weight=0.1, blank_logprob=-4.0)
+
+    def run(fused):
+        old = ops.FUSED_LOSS
+        ops.FUSED_LOSS = fused
+        try:
+            od = [o.detach().cuda().requires_grad_(True) for o in outs]
+            zd, gd = z.detach().cuda().requires_grad_(True), gate.detach().cuda().requires_grad_(True)
+            ld = [lp.detach().cuda().requires_grad_(True) for lp in lps]
+            l3 = crit((zd, [o[..., :M] for o in od], gd, [None] * n_flows, ld), g(target), g(in_lens), g(out_lens))
+            total(l3).backward()
+            torch.cuda.synchronize()
+            return l3, od, zd, gd, ld
+        finally:
+            ops.FUSED_LOSS = old
+
+    for fused in (True, False):
+        l3, od, zd, gd, ld = run(fused)
+        assert l3[0].dim() == 0 and l3[1].dim() == 0 and l3[2].dim() == 0
+        for a, b in zip(l3, ref):
+            assert abs(float(a) - float(b)) < 2e-5 * max(1.0, abs(float(b))), (fused, float(a), float(b))
+        assert rel(zd.grad, z.grad) < 1e-5 and rel(gd.grad, gate.grad) < 1e-5
+        for a, b in zip(od, outs):
+            assert rel(a.grad, b.grad) < 1e-5
+            assert float(a.grad[..., M:].abs().max()) == 0.0                       # (the bias half of the coupling output: no loss term)
+        for a, b in zip(ld, lps):
+            assert mad(a.grad, torch.nan_to_num(b.grad)) < 2e-6, (fused, mad(a.grad, b.grad))
+    # gate and CTC switched off: shapes of the reference's placeholders (flowtron.py:237, :245)
+    crit0 = FlowtronLoss(sigma=1.0, gate_loss=False, use_ctc_loss=False)
+    l3 = crit0((g(z.detach()), [g(outs[0].detach())[..., :M]], None, [None], [None]), g(target), g(in_lens), g(out_lens))
+    assert l3[1].shape == (1,) and l3[2].shape == (1,) and float(l3[1]) == 0.0 and float(l3[2]) == 0.0
+    ref0 = O.loss((z.detach(), [outs[0].detach()[..., :M]], None, [None], [None]), target, in_lens, out_lens, 1.0, False, False)
+    assert abs(float(l3[0]) - float(ref0[0])) < 2e-5 * abs(float(ref0[0]))
+
+
 @pytest.mark.parametrize("T,B,H", [(9, 20, 256), (7, 32, 1024), (6, 33, 128), (11, 3, 128)])
 def test_lstm2_wavefront_chain_vs_oracle_and_unfused(env, T, B, H):
     """csrc/lstm2.hip: both decoder layers as one launch chain (layer 1 one step behind layer 0, input projection of
