@@ -81,6 +81,7 @@ SIGNATURES = {
     "ft_pad_rows_fill": ([_p, _l, _i, _p, _i, _i, _i, _p], _i),
     "ft_embedding_fwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
     "ft_embedding_bwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
+    "ft_embedding_bwd_runs": ([_p, _p, _p, _i, _i, _l, _i, _p], _i),
     "ft_im2col": ([_p, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_col2im": ([_p, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_instnorm_relu_fwd": ([_p] * 8 + [_i, _i, _i, _f, _p], _i),

@@ -16,6 +16,7 @@ all_reduce, /= world, 68 copy_ back                 param.grad is a VIEW into it
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Iterable, List
 
 import torch
@@ -89,6 +90,25 @@ def reduce_tensors(tensors: Iterable[torch.Tensor], num_gpus: int) -> List[torch
     return list(flat.unbind(0))
 
 
+_ARENAS = []          # weak references to the live arenas (one per process in practice)
+
+
+def arena_slot(W):
+    """(arena, parameter index) if W is exactly the storage of a parameter of a live arena (FlatArena.slot_of), else None"""
+    dead = False
+    for r in _ARENAS:
+        a = r()
+        if a is None:
+            dead = True
+            continue
+        i = a.slot_of(W)
+        if i is not None:
+            return a, i
+    if dead:
+        _ARENAS[:] = [r for r in _ARENAS if r() is not None]
+    return None
+
+
 class FlatArena:
     """Flat fp32 storage for a list of parameters: `params` (optional) and `grads` as views."""
 
@@ -119,6 +139,10 @@ class FlatArena:
         self._ptr_hi = self._ptr_lo + self.flat_grad.numel() * 4
         for p in self.params:
             p._ft_arena = self
+        # weight gradients written IN PLACE (grad_view_for_pass): parameter storage address -> index, the backward pass being served
+        self._by_ptr = {p.data_ptr(): i for i, p in enumerate(self.params)}
+        self._pass, self._pass_clean, self._handed = None, False, set()
+        _ARENAS.append(weakref.ref(self))
 
     @classmethod
     def for_params(cls, params, flatten_params: bool = True) -> "FlatArena":
@@ -142,6 +166,36 @@ class FlatArena:
             return
         self.flat_grad.zero_()
         self.adopt_stray_grads(copy=False)
+
+    def slot_of(self, W):
+        """index of the parameter whose storage W covers exactly (the parameter itself, or a reshape of it: a Conv1d weight viewed as
+        a matrix), else None; checked against the LIVE parameter, so a stale address can never match"""
+        i = self._by_ptr.get(W.data_ptr())
+        if i is None:
+            return None
+        p = self.params[i]
+        if p.data_ptr() != W.data_ptr() or p.numel() != W.numel() or not W.is_contiguous() or W.dtype != torch.float32:
+            return None
+        return i
+
+    def grad_view_for_pass(self, i, task, shape):
+        """The arena slice of parameter i as the ZEROED output of its weight-gradient kernel in backward pass `task` (the autograd
+        engine's graph-task id), or None.  Served only in a pass that begins with every .grad None (zero_grad's default): the arena
+        is then zeroed ONCE (one fill instead of the zeroed slab of the same size), the split-K GEMMs accumulate straight into it,
+        autograd adopts the returned view as .grad (a fresh tensor object each time: AccumulateGrad takes it over without a copy) and
+        adopt_stray_grads finds it already in place -- no 2 x 244 MB multi-tensor copy per step.  A second contribution to the same
+        parameter in the pass, or any pass that starts with gradients in place (accumulation), gets None: the caller's own buffer is
+        then accumulated by autograd as before."""
+        if self._pass != task:
+            self._pass, self._handed = task, set()
+            self._pass_clean = all(p.grad is None for p in self.params)
+            if self._pass_clean:
+                self.flat_grad.zero_()
+        if not self._pass_clean or i in self._handed or self.params[i].grad is not None:
+            return None
+        self._handed.add(i)
+        off = self.offsets[i]
+        return self.flat_grad[off:off + self.params[i].numel()].view(shape)
 
     def _views(self):
         v = getattr(self, "_grad_views", None)

@@ -506,7 +506,7 @@ class Flowtron(nn.Module):
         # speaker row broadcast over L by the gather kernel itself (ids repeated), so its backward is the
         # same atomic scatter-add kernel (flowtron.py:886-887 expand + cat)
         spk_ids = speaker_ids.reshape(1, -1).expand(Lt, -1).reshape(-1)
-        spk = ops.embedding(spk_ids, self.speaker_embedding.weight).reshape(Lt, B, -1)          # [L,B,S]
+        spk = ops.embedding(spk_ids, self.speaker_embedding.weight, run_stride=B).reshape(Lt, B, -1)   # [L,B,S]; backward: one atomic per 32 positions
         emb = ops.embedding(text.t().contiguous(), self.embedding.weight).reshape(Lt, B, -1)   # time-major [L,B,C]
         if in_lens is None:
             lens = torch.full((B,), Lt, dtype=torch.int32, device=text.device)

@@ -319,6 +319,25 @@ def zeroed(shape, device):
     return torch.zeros(shape, device=device, dtype=torch.float32)
 
 
+_ARENA_GRADS = _os.environ.get("FLOWTRON_ARENA_GRADS", "1") != "0"
+
+
+def weight_grad_out(W):
+    """the zero-filled fp32 output of W's weight-gradient kernel (split-K / atomic accumulation): inside a backward pass the slice of
+    the flat gradient arena the parameter's .grad will live in anyway (dist.FlatArena.grad_view_for_pass: no copy into the arena
+    afterwards), else a piece of the pass's zeroed slab.  FLOWTRON_ARENA_GRADS=0: always the slab."""
+    if _ARENA_GRADS and _ZSLAB_ON:
+        gt = _current_graph_task()
+        if gt != -1:
+            from .dist import arena_slot
+            slot = arena_slot(W)
+            if slot is not None:
+                v = slot[0].grad_view_for_pass(slot[1], gt, W.shape)
+                if v is not None:
+                    return v
+    return zeroed(W.shape, W.device)
+
+
 def colsum(x2d: torch.Tensor, rows: int, N: int, ld: int) -> torch.Tensor:
     out = torch.empty(N, device=x2d.device, dtype=torch.float32)
     L.check(L.lib().ft_colsum(L.ptr(x2d), L.ptr(out), rows, N, ld, L.stream()), "ft_colsum")
@@ -473,7 +492,7 @@ class LinearFn(torch.autograd.Function):
             dpre = dy
         dW = None
         if ctx.needs_input_grad[0]:
-            dW = zeroed(W.shape, W.device) if ctx.imgs is not None else torch.empty_like(W)      # (image path: split-K with beta = 1)
+            dW = weight_grad_out(W) if ctx.imgs is not None else torch.empty_like(W)      # (image path: split-K with beta = 1)
         want_db = ctx.has_bias and ctx.needs_input_grad[1]
         db = None
         dxs = []
@@ -598,7 +617,7 @@ class LinearGateFn(torch.autograd.Function):
             off += K
         dW = None
         if ctx.needs_input_grad[0]:
-            dW = zeroed(W.shape, W.device)
+            dW = weight_grad_out(W)
             gemm_img(d_img, 1, d_img.ptr(), x_cat, 1, x_cat.ptr(), dW, N, Ktot, rowmap.cap, Ktot, beta=1.0, splitk=True, rowmap=rowmap, compact=2)
         dWg = dbg = None
         if dgate is not None and (ctx.needs_input_grad[2] or (ctx.has_gbias and ctx.needs_input_grad[3])):
@@ -625,29 +644,35 @@ def linear(xs, W, bias=None, act=L.ACT_NONE, mode=None, rowmap=None, fill="y+dx"
 # --------------------------------------------------------------------------
 class EmbeddingFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, W):
+    def forward(ctx, ids, W, run_stride=0):
         L.require_cuda(ids, W)
         ids = _c(ids.reshape(-1).to(torch.int64))
         W = _c(W)
         out = torch.empty(ids.numel(), W.shape[1], device=W.device, dtype=torch.float32)
         L.check(L.lib().ft_embedding_fwd(L.ptr(ids), L.ptr(W), L.ptr(out), ids.numel(), W.shape[1], W.shape[1], L.stream()),
                 "ft_embedding_fwd")
-        ctx.save_for_backward(ids)
-        ctx.wshape = W.shape
+        ctx.save_for_backward(ids, W)
+        ctx.run_stride = int(run_stride)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (ids,) = ctx.saved_tensors
+        ids, W = ctx.saved_tensors
         dout = _c(dout)
-        dW = torch.zeros(ctx.wshape, device=dout.device, dtype=torch.float32)
-        L.check(L.lib().ft_embedding_bwd(L.ptr(ids), L.ptr(dout), L.ptr(dW), ids.numel(), ctx.wshape[1], ctx.wshape[1], L.stream()),
-                "ft_embedding_bwd")
-        return None, dW
+        dW = weight_grad_out(W)                     # zero-filled; the scatter-add accumulates
+        if ctx.run_stride > 0:
+            L.check(L.lib().ft_embedding_bwd_runs(L.ptr(ids), L.ptr(dout), L.ptr(dW), ids.numel(), W.shape[1], W.shape[1], ctx.run_stride,
+                                                  L.stream()), "ft_embedding_bwd_runs")
+        else:
+            L.check(L.lib().ft_embedding_bwd(L.ptr(ids), L.ptr(dout), L.ptr(dW), ids.numel(), W.shape[1], W.shape[1], L.stream()),
+                    "ft_embedding_bwd")
+        return None, dW, None
 
 
-def embedding(ids, W):
-    return EmbeddingFn.apply(ids, W)
+def embedding(ids, W, run_stride=0):
+    """run_stride > 0: the ids repeat with this period (row r carries ids[r % run_stride]'s value in practice) -- the backward then
+    sums runs in registers (ft_embedding_bwd_runs); any ids are handled correctly"""
+    return EmbeddingFn.apply(ids, W, run_stride)
 
 
 # --------------------------------------------------------------------------
@@ -1010,7 +1035,7 @@ class LSTMSeqFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # dW_hh[r,j] = sum_{t,b} da_t[b,r] * h_prev(t)[b,j];  h_prev = y[t-1] (fwd) / y[t+1] (reverse)
             rows = (T - 1) * B
-            dW = zeroed(w_hh.shape, w_hh.device)
+            dW = weight_grad_out(w_hh)
             rm = ctx.rowmap
             if T > 1 and images_apply(ctx.mode, 4 * H, H, rows) and rm is not None:
                 # compact images (valid frames only, batch-major with one zero separator row per utterance): the one-step shift
@@ -1115,12 +1140,12 @@ class BiLSTMSeqFn(torch.autograd.Function):
         rows = (T - 1) * B
         for d in range(2):
             if ctx.needs_input_grad[2 + d]:
-                dWs[d] = torch.zeros_like(w_f)
+                dWs[d] = weight_grad_out(w_f if d == 0 else w_r)         # zero-filled: the GEMM accumulates (beta = 1)
                 if T > 1:
                     # dW_hh[r,j] = sum da_t[b,r] h_prev(t)[b,j];  h_prev = y[t-1] (forward) / y[t+1] (reverse), y row stride 2H
                     da = dgx[d][1:] if d == 0 else dgx[d][:-1]
                     hp = y[:-1, :, :H] if d == 0 else y[1:, :, H:]
-                    gemm_raw(da, hp, dWs[d], 4 * H, H, rows, 1, 4 * H, 2 * H, 1, H, mode=ctx.mode, splitk=True)
+                    gemm_raw(da, hp, dWs[d], 4 * H, H, rows, 1, 4 * H, 2 * H, 1, H, beta=1.0, mode=ctx.mode, splitk=True)
         return dgx[0], dgx[1], dWs[0], dWs[1], None, None
 
 

@@ -193,6 +193,10 @@ int ft_pad_rows_fill(float* y, int64_t ld, int cols, const int32_t* lens, int T,
  * out[r][0:dim] = W[ids[r]] for r < n (out row stride ld_out).  bwd: dW[ids[r]] += dout[r]. */
 int ft_embedding_fwd(const int64_t* ids, const float* W, float* out, int n, int dim, int64_t ld_out, void* stream);
 int ft_embedding_bwd(const int64_t* ids, const float* dout, float* dW, int n, int dim, int64_t ld_dout, void* stream);
+/* The same sums with the rows walked at a stride (row r = i * stride + j): a thread adds its rows in a register while the id stays
+ * the same and sends one atomic per run.  For ids that repeat with period `stride` -- the speaker embedding gathered for every text
+ * position of a [L,B] batch (flowtron.py:886-887): stride = B -- that is 1 / 32 of the atomics; correct for ANY ids.  (ABI 12) */
+int ft_embedding_bwd_runs(const int64_t* ids, const float* dout, float* dW, int n, int dim, int64_t ld_dout, int stride, void* stream);
 
 /* ---- encoder conv as im2col (flowtron.py:499-502) --------------------------
  * x [L,B,C] time-major (must already be zero at l >= lens[b]);

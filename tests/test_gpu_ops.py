@@ -241,6 +241,19 @@ def test_embedding(env):
     out.backward(g(go))
     assert torch.equal(out.cpu(), ref.detach())
     assert mad(Wd.grad, W.grad) < 1e-5
+    # ft_embedding_bwd_runs (rows walked at a stride, one atomic per run of equal ids): ids that repeat with the stride (the speaker
+    # embedding of a [L,B] batch), arbitrary ids, a row count that is not a multiple of the stride, one chunk and several
+    for Lx, Bx, periodic in ((70, 4, True), (70, 4, False), (1, 5, True), (33, 32, True)):
+        ids2 = torch.randint(0, 17, (1, Bx)).expand(Lx, Bx).contiguous() if periodic else torch.randint(0, 17, (Lx, Bx))
+        ids2 = ids2.reshape(-1)[:Lx * Bx - (1 if Lx > 1 else 0)]
+        W2 = torch.randn(17, 24, requires_grad=True)
+        go2 = torch.randn(ids2.numel(), 24)
+        W2[ids2].backward(go2)
+        Wd2 = W2.detach().cuda().requires_grad_(True)
+        out2 = ops.embedding(g(ids2), Wd2, run_stride=Bx)
+        out2.backward(g(go2))
+        assert torch.equal(out2.cpu(), W2.detach()[ids2])
+        assert mad(Wd2.grad, W2.grad) < 2e-5, (Lx, Bx, periodic)
 
 
 def test_reverse_by_length(env):
