@@ -59,6 +59,8 @@ struct PersistP {
     int T, B;
     long timeout_ticks;                  // wall_clock64 ticks (100 MHz)
     long* prof;                          // debug: per-step phase stamps of one workgroup (ft_lstm_persist_debug_prof), or null
+    int LB;                              // batch rows per time step IN MEMORY (>= B: the launch may cover a slice b0 .. b0 + B - 1 of a
+                                         // wider batch -- every pointer then starts at row b0; ft_lstm_persist_fwd_rows)
 };
 
 // Granule layout of one group's state vector (K = 32 NCW k-values x RPGP rows; NCW = k-chunks per wave).  A consumer wave w
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
     } else {
         grp = blockIdx.x % NG; q = blockIdx.x / NG;              // speed only: consecutive block ids land on different XCDs
     }
-    const int B = p.B, T = p.T;
+    const int B = p.B, T = p.T, LB = p.LB;
     const int b0 = grp * RPGP;
 
     // ---- resident weights: tile j, k-chunk (wave + 4 i).  NG == 8 (64 fragments = 256 registers per lane): parked in ACCUMULATION
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
         const int nst = (tg - t) < SB ? (tg - t) : SB;
         if constexpr (RPGP == 4) {
             if (pvalid) {
-                const float* src0 = p.gx + ((size_t)t * B + b0 + pb) * 4 * PH + (size_t)pr * PH + q * UPC + pu;
+                const float* src0 = p.gx + ((size_t)t * LB + b0 + pb) * 4 * PH + (size_t)pr * PH + q * UPC + pu;
                 const unsigned dst0 = (unsigned)(size_t)(lds_void*)gxs;
 #pragma unroll
                 for (int kk = 0; kk < SB / 2; ++kk) {
@@ -293,18 +295,18 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
                     if (st < nst) {
                         unsigned keep;
                         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                                     : "=&s"(keep) : "v"(src0 + (size_t)st * B * 4 * PH + (size_t)(2 * h) * PH),
+                                     : "=&s"(keep) : "v"(src0 + (size_t)st * LB * 4 * PH + (size_t)(2 * h) * PH),
                                        "s"(dst0 + (unsigned)((st * 4 + 2 * h) * NE * 4)) : "memory");
                     }
                 }
             }
         } else if (hvalid) {
-            const float* src0 = p.gx + ((size_t)t * B + hb) * 4 * PH + hu;
+            const float* src0 = p.gx + ((size_t)t * LB + hb) * 4 * PH + hu;
             const unsigned dst0 = (unsigned)(size_t)(lds_void*)gxs + (unsigned)(wu & 1) * 256u;
 #pragma unroll
             for (int kk = 0; kk < SB * 2; ++kk) {                // pair k = (step, gate), LDS slot [k][e]; all DMAs in flight
                 const int k = 2 * kk + (wu >> 1);
-                if (k < nst * 4) dma_dword(src0 + (size_t)(k >> 2) * B * 4 * PH + (size_t)(k & 3) * PH, dst0 + (unsigned)k * NE * 4u);
+                if (k < nst * 4) dma_dword(src0 + (size_t)(k >> 2) * LB * 4 * PH + (size_t)(k & 3) * PH, dst0 + (unsigned)k * NE * 4u);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the DMA writes are this wave's own VM operations
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
     auto store_outputs = [&](int t) {                            // saved tensors of step t from outs[t & 1]
         if (!ovalid) return;
         const float* o = outs + (t & 1) * 6 * NE + oe;
-        const size_t row = (size_t)t * B + ob;
+        const size_t row = (size_t)t * LB + ob;
         p.y[row * p.ldy + ou] = o[0];
         if (p.gates && t < olen) {
             float* gp = p.gates + row * 4 * PH + ou;
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
     if (tg > 0) store_outputs(tg - 1);
     // pad rows beyond the group's longest sequence: y = 0 (pad_packed_sequence semantics)
     if (ev)
-        for (int t = tg; t < T; ++t) p.y[((size_t)t * B + eb) * p.ldy + eu] = 0.f;
+        for (int t = tg; t < T; ++t) p.y[((size_t)t * LB + eb) * p.ldy + eu] = 0.f;
 }
 
 
@@ -553,6 +555,7 @@ struct PersistBwdP {
     // ceil256(R + 32)) -- written by the output waves beside the fp32 rows, and the column sums of dgates (the bias gradient)
     // added to dbias[4H]: the weight-gradient / input-gradient GEMMs then start without a conversion pass over dgx.
     unsigned short* dimg; long dimg_ld; int dimg_rows; float* dbias;
+    int LB;                              // batch rows per time step in memory (see PersistP; the image output needs LB == B)
 };
 
 // OUT: 0 = fp32 dgx rows only, 1 = dgx and the compact 16-bit image, 2 = the image only (compile-time: the plain path carries none
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     } else {
         grp = blockIdx.x % NG; q = blockIdx.x / NG;
     }
-    const int B = p.B, T = p.T;
+    const int B = p.B, T = p.T, LB = p.LB;
     const int b0 = grp * RPGP;
 
     bf16x8 w[TL][CPW];
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
         const int so = tg - 1 - n;
         const float v0 = o[0], v1 = o[NE], v2 = o[2 * NE], v3 = o[3 * NE];
         if constexpr (WF32) {
-            float* dg = p.dgx + ((size_t)so * B + ob) * 4 * PH + ou;
+            float* dg = p.dgx + ((size_t)so * LB + ob) * 4 * PH + ou;
             dg[0] = v0; dg[(size_t)PH] = v1; dg[(size_t)2 * PH] = v2; dg[(size_t)3 * PH] = v3;
         }
         if (WIMG && so < olen) {
@@ -651,15 +654,15 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     auto prefetch = [&](int m) {                                 // waves 2-3 (from the epilogue waves instead: 3.13 vs 3.07 us)
         if (wu >= 2 && m < tg && hvalid) {
             const int sm = tg - 1 - m;
-            const size_t row = (size_t)sm * B + hb;
+            const size_t row = (size_t)sm * LB + hb;
             const unsigned dst = ins0 + (unsigned)((m % RING) * 5 * NE * 4);
 #pragma unroll
             for (int f = 0; f < 4; ++f) dma_dword(p.gates + row * 4 * PH + (size_t)f * PH + hu, dst + (unsigned)(f * NE * 4));
             dma_dword(p.dy + row * p.ldy + hu, dst + (unsigned)(4 * NE * 4));
-            if (sm > 0) dma_dword(p.cell + (row - B) * PH + hu, cells0 + (unsigned)((m % RING) * NE * 4));
+            if (sm > 0) dma_dword(p.cell + (row - LB) * PH + hu, cells0 + (unsigned)((m % RING) * NE * 4));
         }
     };
-    if (wu >= 2 && tg > 0 && hvalid) dma_dword(p.cell + ((size_t)(tg - 1) * B + hb) * PH + hu, cells0 + (unsigned)((RING - 1) * NE * 4));
+    if (wu >= 2 && tg > 0 && hvalid) dma_dword(p.cell + ((size_t)(tg - 1) * LB + hb) * PH + hu, cells0 + (unsigned)((RING - 1) * NE * 4));
 #pragma unroll
     for (int m = 0; m < DIST; ++m) prefetch(m);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
     if (tg > 0) store_outputs(tg - 1);
     if (WF32 && ev)                                                     // pad rows beyond the group's longest sequence
         for (int t = tg; t < T; ++t) {
-            float* dg = p.dgx + ((size_t)t * B + eb) * 4 * PH + eu;
+            float* dg = p.dgx + ((size_t)t * LB + eb) * 4 * PH + eu;
 #pragma unroll
             for (int g = 0; g < 4; ++g) dg[(size_t)g * PH] = 0.f;
         }
@@ -902,7 +905,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
     const int li = lane & 15, kg = lane >> 4;
     int grp, q;
     if (!join_group_local<CPG>(p.census, p.status, tid, grp, q)) return;
-    const int B = p.B, T = p.T;
+    const int B = p.B, T = p.T, LB = p.LB;
     const int b0 = grp * RPGP;
     for (int i2 = tid; i2 < 1024; i2 += 256) daop[i2] = 0u;          // (made visible by the barrier behind the first ring fill)
 
@@ -945,7 +948,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
         const int so = tg - 1 - n;
         const float v0 = o[0], v1 = o[NE], v2 = o[2 * NE], v3 = o[3 * NE];
         if constexpr (WF32) {
-            float* dg = p.dgx + ((size_t)so * B + ob) * 4 * PH + ou;
+            float* dg = p.dgx + ((size_t)so * LB + ob) * 4 * PH + ou;
             dg[0] = v0; dg[(size_t)PH] = v1; dg[(size_t)2 * PH] = v2; dg[(size_t)3 * PH] = v3;
         }
         if (WIMG && so < olen) {
@@ -972,7 +975,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
     auto prefetch = [&](int m) {
         if (wu < 2 || m >= tg) return;
         const int sm = tg - 1 - m;
-        const size_t row = (size_t)sm * B + b0 + pb;
+        const size_t row = (size_t)sm * LB + b0 + pb;
         const unsigned dst = ring0 + (unsigned)((m % RING) * 6 * NE * 4);
         if (wu == 2) {
             if (pvalid) {
@@ -981,13 +984,13 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
             }
         } else {
             // piece 2: row 4 = dy of step sm, row 5 = cell of step sm - 1 (absent for sm == 0: those lanes stay out)
-            const float* src = pr == 0 ? p.dy + row * p.ldy + q * UPC + pu : p.cell + (row - B) * PH + q * UPC + pu;
+            const float* src = pr == 0 ? p.dy + row * p.ldy + q * UPC + pu : p.cell + (row - LB) * PH + q * UPC + pu;
             if (pvalid && (pr == 0 || sm > 0)) dma16(src, dst + 4 * NE * 4);
         }
     };
     // the cell of the LAST step (c_t of n = 0) goes to row 5 of slot RING - 1: upper half of a piece-2 DMA by wave 3
     if (wu == 3 && tg > 0 && pvalid && pr == 1)
-        dma16(p.cell + ((size_t)(tg - 1) * B + b0 + pb) * PH + q * UPC + pu, ring0 + (unsigned)(((RING - 1) * 6 + 4) * NE * 4));
+        dma16(p.cell + ((size_t)(tg - 1) * LB + b0 + pb) * PH + q * UPC + pu, ring0 + (unsigned)(((RING - 1) * 6 + 4) * NE * 4));
 #pragma unroll
     for (int m = 0; m < DIST; ++m) prefetch(m);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1201,7 +1204,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
     if (tg > 0) store_outputs(tg - 1);
     if (WF32 && ev)
         for (int t = tg; t < T; ++t) {
-            float* dg = p.dgx + ((size_t)t * B + eb) * 4 * PH + eu;
+            float* dg = p.dgx + ((size_t)t * LB + eb) * 4 * PH + eu;
 #pragma unroll
             for (int g = 0; g < 4; ++g) dg[(size_t)g * PH] = 0.f;
         }
@@ -1263,10 +1266,11 @@ extern "C" size_t ft_lstm_persist_workspace_bytes(int B, int H) {
 }
 #endif
 
-extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
-                                   float* gates, float* cell, void* work, int32_t* status, int T, int B, int H, int ng,
-                                   void* stream) {
-    FT_CHECK_ARG(gx && w_hh && lens && y && work && status);
+// ldb = batch rows per time step in memory (B, or the width of the batch this launch covers a slice of: ft_lstm_persist_fwd_rows)
+static int persist_fwd_impl(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
+                            float* gates, float* cell, void* work, int32_t* status, int T, int B, int ldb, int H, int ng,
+                            void* stream) {
+    FT_CHECK_ARG(gx && w_hh && lens && y && work && status && ldb >= B);
     FT_CHECK_ARG((gates == nullptr) == (cell == nullptr));
     FT_CHECK_ARG(T >= 0 && ldy >= H && reinterpret_cast<uintptr_t>(work) % 256 == 0 && reinterpret_cast<uintptr_t>(gx) % 16 == 0);
     // ng: 1 / 9 = XCD-local transport (nt / sc1 loads) with tagged granules; 11 / 19 = the same with BARE operand pairs and the sentinel
@@ -1288,7 +1292,7 @@ extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh
     // tags = 0: no epoch matches (epochs start at 1); bare: sentinels.  Preset by the fragment kernel (lstm_images.h: WfragAux)
     const WfragAux aux{reinterpret_cast<uint4*>(hgran), (unsigned long)(gran_bytes / 16), bare ? 0xFFFFFFFFu : 0u, census};
     hipLaunchKernelGGL(make_wfrag_fwd_ug, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H, aux);
-    PersistP p{gx, lens, y, (long)ldy, gates, cell, wfrag, hgran, status, census, T, B, 100000000L / 2, g_persist_prof};   // 0.5 s
+    PersistP p{gx, lens, y, (long)ldy, gates, cell, wfrag, hgran, status, census, T, B, 100000000L / 2, g_persist_prof, ldb};   // 0.5 s
     // dynamic LDS: reduce buffers (2*4*TPC*RPGP*20 = 2*4*32*20 floats) + SB staged gx rows + 2 output rows
     const size_t lds = sizeof(float) * ((size_t)2 * 4 * 32 * 20 + (size_t)SB * 4 * 128 + (size_t)2 * 6 * 128);
     auto launch = [&](auto kern) -> int {
@@ -1308,16 +1312,42 @@ extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, 
                                    const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
                                    void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream);
 
+extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
+                                   float* gates, float* cell, void* work, int32_t* status, int T, int B, int H, int ng,
+                                   void* stream) {
+    return persist_fwd_impl(gx, w_hh, lens, y, ldy, gates, cell, work, status, T, B, B, H, ng, stream);
+}
+extern "C" int FT_OPNAME(ft_lstm_persist_fwd_rows)(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
+                                   float* gates, float* cell, void* work, int32_t* status, int T, int B, int ldb, int H, int ng,
+                                   void* stream) {
+    return persist_fwd_impl(gx, w_hh, lens, y, ldy, gates, cell, work, status, T, B, ldb, H, ng, stream);
+}
+
+static int persist_bwd_impl(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
+                            const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int ldb, int H, int ng,
+                            void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream);
+
 extern "C" int FT_OPNAME(ft_lstm_persist_bwd)(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
                                    const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
                                    void* stream) {
-    return FT_OPNAME(ft_lstm_persist_bwd_img)(dy, ldy, w_hh, lens, gates, cell, dgx, work, status, T, B, H, ng, nullptr, 0, 0, nullptr, stream);
+    return persist_bwd_impl(dy, ldy, w_hh, lens, gates, cell, dgx, work, status, T, B, B, H, ng, nullptr, 0, 0, nullptr, stream);
+}
+extern "C" int FT_OPNAME(ft_lstm_persist_bwd_rows)(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
+                                   const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int ldb, int H, int ng,
+                                   void* stream) {
+    return persist_bwd_impl(dy, ldy, w_hh, lens, gates, cell, dgx, work, status, T, B, ldb, H, ng, nullptr, 0, 0, nullptr, stream);
 }
 
 extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
                                    const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
                                    void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream) {
-    FT_CHECK_ARG(dy && w_hh && lens && gates && cell && (dgx || dimg) && work && status);
+    return persist_bwd_impl(dy, ldy, w_hh, lens, gates, cell, dgx, work, status, T, B, B, H, ng, dimg, dimg_ld, dimg_rows, dbias, stream);
+}
+
+static int persist_bwd_impl(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
+                            const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int ldb, int H, int ng,
+                            void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream) {
+    FT_CHECK_ARG(dy && w_hh && lens && gates && cell && (dgx || dimg) && work && status && ldb >= B && (dimg == nullptr || ldb == B));
     FT_CHECK_ARG(dimg == nullptr || (dbias && dimg_ld >= 4 * (int64_t)H && dimg_ld % 8 == 0 && dimg_rows >= (int64_t)T * B + B &&
                                      reinterpret_cast<uintptr_t>(dimg) % 16 == 0));
     FT_CHECK_ARG(T >= 0 && ldy >= H && reinterpret_cast<uintptr_t>(work) % 256 == 0);
@@ -1340,7 +1370,7 @@ extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, 
     if (rsform) hipLaunchKernelGGL(make_wfrag_rs, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H, aux);
     else hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H, aux);
     PersistBwdP p{dy, (long)ldy, lens, gates, cell, dgx, wTfrag, dgran, status, census, T, B, 100000000L / 2, g_persist_prof,
-                  reinterpret_cast<unsigned short*>(dimg), (long)dimg_ld, (int)dimg_rows, dbias};
+                  reinterpret_cast<unsigned short*>(dimg), (long)dimg_ld, (int)dimg_rows, dbias, ldb};
     // dynamic LDS: 16-partial reduce (2 x 16 x 32 unit-rows... = 2*16*TL*RPGP*17 = 2*16*8*17 floats) + staged steps
     const size_t lds = sizeof(float) * ((size_t)2 * 16 * 8 * 17 + (size_t)RING * 5 * 128 + (size_t)RING * 128 + (size_t)2 * 4 * 128);
     auto launch = [&](auto kern) -> int {

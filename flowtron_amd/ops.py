@@ -939,6 +939,21 @@ def lstm_persist_groups(B, H, reverse, mode, device=None):
     return ng
 
 
+_PERSIST_WIDE = _os.environ.get("FLOWTRON_LSTM_PERSIST_WIDE", "1") != "0"
+
+
+def lstm_persist_slices(B, H, reverse, mode, device=None):
+    """(transport code, [(b0, rows)]) for a batch wider than one persistent launch holds (32 < B <= 64): the batch is walked in
+    slices of <= 32 rows, one persistent launch each (ft_lstm_persist_*_rows: 2 x 1.6-1.8 us per step against 5-6 us per step of
+    the launch-per-step kernels); None: one launch, or the launch-per-step kernels (three slices would not beat them)."""
+    if not _PERSIST_WIDE or B <= 32 or B > 64:
+        return None
+    ng = lstm_persist_groups(32, H, reverse, mode, device)
+    if not ng:
+        return None
+    return ng, [(b0, min(32, B - b0)) for b0 in range(0, B, 32)]
+
+
 def bilstm_persist_ok(B, H, mode, device):
     """the encoder-shaped persistent bidirectional kernels (H 256, B <= 32, 16-bit operands) on a device whose persistent grids
     passed the self-test; FLOWTRON_BILSTM_PERSIST=0 or FLOWTRON_LSTM_PERSIST=0 keep the launch-per-step pair chain"""
@@ -969,7 +984,19 @@ class LSTMSeqFn(torch.autograd.Function):
         gates = torch.empty(T, B, H4, device=gx.device, dtype=torch.float32)
         cell = torch.empty(T, B, H, device=gx.device, dtype=torch.float32)
         ng = lstm_persist_groups(B, H, reverse, mode, gx.device)
-        if ng:
+        wide = None if ng else lstm_persist_slices(B, H, reverse, mode, gx.device)
+        if wide:
+            # 32 < B <= 64: one persistent launch per slice of 32 rows, back to back (pointers offset to the slice's first row)
+            code = _persist_fwd_code(wide[0])
+            st = _persist_watch(gx.device)
+            work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(32, H), device=gx.device, dtype=torch.uint8)
+            for b0, nb in wide[1]:
+                L.check(L.op16("ft_lstm_persist_fwd_rows", mode)(gx.data_ptr() + 16 * H * b0, L.ptr(w_hh), lens.data_ptr() + 4 * b0,
+                                                                 y.data_ptr() + 4 * H * b0, H, gates.data_ptr() + 16 * H * b0,
+                                                                 cell.data_ptr() + 4 * H * b0, L.ptr(work), L.ptr(st.status), T, nb, B, H,
+                                                                 code, L.stream()), "ft_lstm_persist_fwd_rows")
+            _persist_arm(st)
+        elif ng:
             # FLOWTRON_LSTM_PERSIST = 1 (XCD-local): FLOWTRON_LSTM_PERSIST_FWD = bare (default since the end of round 4) -> transport 11, the
             # K-split kernel with bare operand pairs (half the gather bytes; 1.84 against 1.87 us per step once the operand moves sit in
             # the MFMA gaps), ksplit -> transport 1 (tagged granules).  Bit-identical.
@@ -994,8 +1021,20 @@ class LSTMSeqFn(torch.autograd.Function):
         T, B, H = y.shape
         dgx = None                                   # allocated below unless the gradient leaves as an image only
         ng = lstm_persist_groups(B, H, ctx.reverse, ctx.mode, dy.device)
+        wide = None if ng else lstm_persist_slices(B, H, ctx.reverse, ctx.mode, dy.device)
         d_img_k, img_only = None, False
-        if ng:
+        if wide:
+            code = _persist_bwd_code(wide[0])
+            st = _persist_watch(dy.device)
+            work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(32, H), device=dy.device, dtype=torch.uint8)
+            dgx = torch.empty(T, B, 4 * H, device=dy.device, dtype=torch.float32)
+            for b0, nb in wide[1]:
+                L.check(L.op16("ft_lstm_persist_bwd_rows", ctx.mode)(dy.data_ptr() + 4 * H * b0, H, L.ptr(w_hh), lens.data_ptr() + 4 * b0,
+                                                                     gates.data_ptr() + 16 * H * b0, cell.data_ptr() + 4 * H * b0,
+                                                                     dgx.data_ptr() + 16 * H * b0, L.ptr(work), L.ptr(st.status), T, nb, B, H,
+                                                                     code, L.stream()), "ft_lstm_persist_bwd_rows")
+            _persist_arm(st)
+        elif ng:
             # default (1): the forward recurrence keeps the all-gather of h as tagged granules; the backward one runs in REDUCE-SCATTER
             # form (transport 21, round 4: 1.92 us per step against 2.84 for the bare all-gather of dgates -- every CU multiplies its
             # own dgates, fp32 partials cross the L2; equal to fp32 rounding).  FLOWTRON_LSTM_PERSIST_BWD=bare | tagged select the

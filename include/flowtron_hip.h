@@ -264,6 +264,15 @@ int ft_lstm_persist_bwd(const float* dy, int64_t ldy, const float* w_hh, const i
 int ft_lstm_persist_bwd_img(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
                             const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
                             void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream);
+/* Batches wider than one launch holds (B_total > 32; the reference's nn.LSTM has no such limit, flowtron.py:654-655, :689-694):
+ * the same kernels over a SLICE of the batch -- rows b0 .. b0 + B - 1 (B <= 32) of tensors whose time steps are ldb = B_total rows
+ * apart.  Every pointer (gx / y / gates / cell / dy / dgx and lens) is passed ALREADY OFFSET to row b0; a caller walks the batch in
+ * slices of 32, one launch each, back to back (ops.LSTMSeqFn: 2 x 1.8 us per step at B 64 against 5-6 us for the launch-per-step
+ * kernels).  No image output (ft_bf16_image_rows on the fp32 dgx).  (ABI 12) */
+int ft_lstm_persist_fwd_rows(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
+                             float* gates, float* cell, void* work, int32_t* status, int T, int B, int ldb, int H, int ng, void* stream);
+int ft_lstm_persist_bwd_rows(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
+                             const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int ldb, int H, int ng, void* stream);
 
 /* Two stacked layers (the decoder nn.LSTM(.., num_layers=2), flowtron.py:654, :760-765) as ONE launch chain: layer 1 at
  * time t-1 and layer 0 at time t are two workgroup groups of the same launch, and layer 1's input projection
@@ -562,6 +571,10 @@ int ft_lstm_persist_bwd_f16(const float* dy, int64_t ldy, const float* w_hh, con
 int ft_lstm_persist_bwd_img_f16(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
                             const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
                             void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream);
+int ft_lstm_persist_fwd_rows_f16(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
+                                 float* gates, float* cell, void* work, int32_t* status, int T, int B, int ldb, int H, int ng, void* stream);
+int ft_lstm_persist_bwd_rows_f16(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
+                                 const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int ldb, int H, int ng, void* stream);
 int ft_lstm2_seq_fwd_f16(const float* gx0, const float* w_hh0, const float* w_ih1, const float* bias1, const float* w_hh1,
                      const int32_t* lens, float* y0, float* gates0, float* cell0, float* y1, float* gates1, float* cell1,
                      void* work, int T, int B, int H, void* stream);

@@ -859,6 +859,39 @@ def test_persistent_lstm_backward_is_bit_identical_to_launch_per_step(env, ng, T
     assert float(d1[~act].abs().max() if (~act).any() else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("B", [33, 48, 64])
+def test_wide_batch_runs_as_sliced_persistent_launches(env, B, monkeypatch):
+    """32 < B <= 64 (the reference's nn.LSTM has no batch limit, flowtron.py:654-655): ops.LSTMSeqFn walks the batch in slices of 32
+    rows, one persistent launch each (ft_lstm_persist_fwd_rows / _bwd_rows: the same kernels with the batch stride of the full
+    tensors).  Forward: bit-identical to the launch-per-step kernels (valid rows; zeros on pad rows); backward (reduce-scatter form):
+    equal to fp32 rounding, like the single-launch case; W_hh gradient from both."""
+    L, ops = env
+    H, T = 1024, 21
+    if not ops.persist_usable(torch.empty(1, device="cuda").device):
+        pytest.skip("persistent kernels not usable on this device")
+    torch.manual_seed(900 + B)
+    gx0 = torch.randn(T, B, 4 * H, device="cuda") * 0.5
+    w0 = torch.randn(4 * H, H, device="cuda") / H ** 0.5
+    dy = torch.randn(T, B, H, device="cuda") * 0.1
+    lens = torch.tensor([max(1, T - (i * 7) % T) for i in range(B)], dtype=torch.int32, device="cuda")
+    act = (torch.arange(T, device="cuda")[:, None] < lens[None, :])
+    res = []
+    for wide in (True, False):
+        monkeypatch.setattr(ops, "_PERSIST_WIDE", wide)
+        assert bool(ops.lstm_persist_slices(B, H, False, 1, gx0.device)) == wide
+        n0 = ops.PERSIST_LAUNCHES
+        gx, w = gx0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        y = ops.LSTMSeqFn.apply(gx, w, lens, False, 1)
+        (y * dy).sum().backward()
+        torch.cuda.synchronize()
+        assert ops.check_persist_status()
+        res.append((y.detach(), gx.grad, w.grad))
+    (y1, g1, dw1), (y0, g0, dw0) = res
+    assert torch.equal(y1, y0)
+    assert float(y1[~act].abs().max()) == 0.0 and float(g1[~act].abs().max()) == 0.0
+    assert rel(g1, g0) < 1e-5 and rel(dw1, dw0) < 2e-3, (rel(g1, g0), rel(dw1, dw0))
+
+
 @pytest.mark.parametrize("fmt", [1, 2])
 @pytest.mark.parametrize("ng", [1, 11])
 @pytest.mark.parametrize("T,B,lens", [(37, 32, None), (9, 5, [9, 9, 4, 2, 1]), (40, 32, "ragged0"), (862, 32, "bench")])
