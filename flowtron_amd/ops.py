@@ -75,6 +75,10 @@ class RowMap:
 
 _COMPACT = _os.environ.get("FLOWTRON_GEMM_COMPACT", "1") != "0"
 _FUSE_ACT_BWD = _os.environ.get("FLOWTRON_FUSE_ACT_BWD", "1") != "0"    # activation backward inside the gradient's image pass
+# split-K (fp32 atomics) on the encoder's FORWARD split-image GEMM: -0.2 ms per step, but the order of the atomics makes the forward
+# itself differ from run to run (z up to 8e-4, bf16 gradients up to 1e-2 rel-L2 on the same batch and weights:
+# scripts/exp/noise_debug.py, profiles/r05b_forward_noise.log) -- off by default: a forward pass is a function of its inputs
+_ENC_SPLITK = _os.environ.get("FLOWTRON_ENC_SPLITK", "0") != "0"
 _CAT_IMAGES = _os.environ.get("FLOWTRON_GEMM_CAT", "1") != "0"      # a Linear over two inputs as ONE GEMM over a concatenated image
 _PERSIST_IMG = _os.environ.get("FLOWTRON_LSTM_PERSIST_IMG", "1")      # 1: the persistent backward emits the dgates image INSTEAD of fp32 dgx where its only consumer is the projection's backward; both; 0
 
@@ -414,8 +418,8 @@ class LinearFn(torch.autograd.Function):
             if Ktot % 32 == 0 and images_apply(mode_dx, rows, N, Ktot):
                 xi, wi = Bf16Image.split3(x2d, mode_dx, False), Bf16Image.split3(W, mode_dx, True)
                 # K = 3 Ktot over only (rows / 128) x (N / 128) output tiles (160 for the encoder: a sixth of the chip's workgroup slots,
-                # 240 k-steps each: 130 us): split-K fills the chip (the bias rides on the first slice)
-                gemm_img(xi, 0, xi.ptr(), wi, 0, wi.ptr(), y, rows, N, 3 * Ktot, N, bias=bias, splitk=True)
+                # 240 k-steps each: 130 us): split-K would fill the chip (the bias rides on the first slice) -- FLOWTRON_ENC_SPLITK=1
+                gemm_img(xi, 0, xi.ptr(), wi, 0, wi.ptr(), y, rows, N, 3 * Ktot, N, bias=bias, splitk=_ENC_SPLITK)
                 split_imgs = (wi.view_cols(Ktot), [xi.view_cols(Ktot)])      # their [hi] blocks serve the backward's GEMMs as they are
             else:
                 gemm_raw(x2d, W, y, rows, N, Ktot, Ktot, 1, 1, Ktot, N, bias=bias, mode=L.FT_F32)

@@ -889,7 +889,8 @@ def test_wide_batch_runs_as_sliced_persistent_launches(env, B, monkeypatch):
     (y1, g1, dw1), (y0, g0, dw0) = res
     assert torch.equal(y1, y0)
     assert float(y1[~act].abs().max()) == 0.0 and float(g1[~act].abs().max()) == 0.0
-    assert rel(g1, g0) < 1e-5 and rel(dw1, dw0) < 2e-3, (rel(g1, g0), rel(dw1, dw0))
+    # (reduce-scatter backward: the same products in another fixed association, rel-L2 ~1e-4 like the single-launch case)
+    assert rel(g1, g0) < 5e-4 and rel(dw1, dw0) < 2e-3, (rel(g1, g0), rel(dw1, dw0))
 
 
 @pytest.mark.parametrize("fmt", [1, 2])
