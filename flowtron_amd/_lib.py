@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libflowtron_hip.so")
 
 FT_F32, FT_BF16, FT_F16 = 0, 1, 2
 GEMM_SPLITK = 1
+GEMM_SPLITK_DET = 2
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 
 _p, _i, _l, _f, _sz, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_double
@@ -35,7 +36,8 @@ class GemmImgArgs(C.Structure):
     _fields_ = [("A", _p), ("B", _p), ("C", _p), ("bias", _p), ("M", _i), ("N", _i), ("K", _i),
                 ("lda", _l), ("ldb", _l), ("ldc", _l), ("a_kmajor", _i), ("b_kmajor", _i),
                 ("alpha", _f), ("beta", _f), ("act", _i), ("flags", _i),
-                ("rowmap", _p), ("rows_dev", _p), ("compact", _i), ("k_shift", _i), ("r1_row", _p), ("r1_col", _p)]
+                ("rowmap", _p), ("rows_dev", _p), ("compact", _i), ("k_shift", _i), ("r1_row", _p), ("r1_col", _p),
+                ("split_work", _p), ("split_work_bytes", _sz)]
 
 
 class CummAttnArgs(C.Structure):
@@ -70,6 +72,7 @@ SIGNATURES = {
     "ft_bf16_image": ([_p, _l, _l, _l, _p, _p], _i),
     "ft_bf16_image_colsum": ([_p, _l, _l, _l, _p, _p, _p], _i),
     "ft_gemm_img": ([C.POINTER(GemmImgArgs), _p], _i),
+    "ft_gemm_img_split_work_bytes": ([_i, _i, _i], _sz),
     "ft_bf16_image_split3": ([_p, _l, _l, _l, _p, _i, _p], _i),
     "ft_bf16_image_split3_f16": ([_p, _l, _l, _l, _p, _i, _p], _i),
     "ft_rowmap_build": ([_p, _p, _p, _i, _i, _p], _i),

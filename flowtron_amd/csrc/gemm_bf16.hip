@@ -200,6 +200,9 @@ struct BfP {
     int chunk_w;                            // > 0: L2-aware tile order with column chunks of this many tiles (no split-K)
     // rank-1 epilogue term (ft_gemm_img_args.r1_row / r1_col): C[row][col] += r1row[row] * r1col[col], row = the OUTPUT row
     const float* r1row; const float* r1col;
+    // deterministic split-K (FT_GEMM_SPLITK_DET): slice blockIdx.y of the reduction writes ITS partial product, with plain stores, to
+    // C + blockIdx.y * c_slice (a workspace); splitk_reduce_k adds the slices in a fixed order.  0: one slice, C is the output
+    long c_slice;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
         for (int j = 0; j < 4; ++j) {
             const int col = n0 + wn * 64 + j * 16 + kg * 4;
             if (col >= p.N) continue;
-            float* cp = p.C + (long)row * p.ldc + col;
+            float* cp = p.C + (size_t)blockIdx.y * p.c_slice + (long)row * p.ldc + col;
             float v[4] = {p.alpha * acc[i][j][0], p.alpha * acc[i][j][1], p.alpha * acc[i][j][2], p.alpha * acc[i][j][3]};
             const int nv = (p.N - col < 4) ? p.N - col : 4;
             const bool full = vec && nv == 4;
@@ -688,30 +691,38 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_k(BfP p) {
 
 template <bool AKM, bool BKM>
 void launch_s(const BfP& p, dim3 grid, bool big, hipStream_t st) {
+    const bool atomics = p.splits > 1 && p.c_slice == 0;       // (deterministic split-K runs the store epilogue, one C slice per k-slice)
     if (big) {
-        if (p.splits > 1) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, true, 256>), grid, dim3(256), 0, st, p);
+        if (atomics) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, true, 256>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 256>), grid, dim3(256), 0, st, p);
     } else {
-        if (p.splits > 1) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, true, 128>), grid, dim3(256), 0, st, p);
+        if (atomics) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, true, 128>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 128>), grid, dim3(256), 0, st, p);
     }
 }
 
-// images -> C.  a_km / b_km: the operand image is k-major ([k][row]) instead of k-contiguous ([row][k]).
-// Images are padded to multiples of 256 in both dimensions (ft_bf16_image), so either tile height may run off the logical M.
-int run_images(const unsigned short* A, long lda, int a_km, const unsigned short* B, long ldb, int b_km, float* C, long ldc,
-               const float* bias, int M, int N, int K, float alpha, float beta, int act, int flags, hipStream_t st,
-               const int* rowmap = nullptr, const int* rows_dev = nullptr, int compact = 0, int k_shift = 0,
-               const float* r1row = nullptr, const float* r1col = nullptr) {
+// C[m][n] = sum_s work[s][m][n] (s ascending: a fixed association) + bias[n]; work = [S][M][N] fp32, N % 4 == 0
+__global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__ work, int S, long MN, int N, float* __restrict__ C, long ldc,
+                                                       const float* __restrict__ bias) {
+    const long n4 = MN >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long e = i << 2;
+        const long m = e / N;
+        const int n = (int)(e - m * N);
+        float4 a = *reinterpret_cast<const float4*>(work + e);
+        for (int sl = 1; sl < S; ++sl) {
+            const float4 b = *reinterpret_cast<const float4*>(work + (size_t)sl * MN + e);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (bias) { a.x += bias[n]; a.y += bias[n + 1]; a.z += bias[n + 2]; a.w += bias[n + 3]; }
+        *reinterpret_cast<float4*>(C + m * ldc + n) = a;
+    }
+}
+
+// tile height (256 x 128 workgroup tiles, 2 per CU, when they still fill the chip, possibly with split-K; else 128 x 128, 4 per CU)
+// and the number of k-slices of a GEMM that may split its reduction
+long plan_slices(int M, int N, int K, bool can_split, int compact, bool* big_out) {
     static const int force_tile = [] { const char* e = getenv("FT_GEMM_BF16_TILE"); return e ? atoi(e) : 0; }();
-    BfP p;
-    p.A = A; p.B = B; p.C = C; p.bias = bias;
-    p.M = M; p.N = N; p.nk = cdiv(K, 32); p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.alpha = alpha; p.beta = beta; p.act = act;
-    p.rowmap = rowmap; p.rows_dev = rows_dev; p.compact = compact; p.k_shift = k_shift;
-    p.r1row = r1row; p.r1col = r1col;
-    const bool can_split = (flags & FT_GEMM_SPLITK) && act == FT_ACT_NONE && (beta == 0.f || beta == 1.f) && K >= 2048 && !r1row;
-    // 256 x 128 workgroup tiles (2 per CU) when they still fill the chip, possibly with split-K; else 128 x 128 (4 per CU)
     const long tiles_big = (long)cdiv(M, 256) * cdiv(N, TB);
     // measured (scripts/exp/gemm_bench.py): the tall tile pays for the long-K weight-gradient shapes (+9 %), is neutral to
     // slightly slower for the forward / input-gradient shapes -- those keep the 128 x 128 tile at 4 workgroups per CU
@@ -720,9 +731,7 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
     if (force_tile == 256) big = M >= 256;
     const int RTA = big ? 256 : TB;
     const long slots = big ? 512 : 1024;
-    p.gx = cdiv(N, TB); p.gy = cdiv(M, RTA);
-    p.vec_c = (reinterpret_cast<uintptr_t>(C) % 16 == 0 && ldc % 4 == 0) ? 1 : 0;
-    const long tiles = (long)p.gx * p.gy;
+    const long tiles = (long)cdiv(N, TB) * cdiv(M, RTA);
     long s = 1;
     if (can_split && tiles < slots / 2) {
         s = slots / tiles;                     // fill all workgroup slots of the 256 CUs
@@ -734,9 +743,47 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
     if (compact == 1) s = 1;                   // scattered output rows: no split-K (the zero fill would have to be scattered too)
     // compact reduction: K is the capacity, ~30 % of the k-slices of a typical batch are empty -- over-split to keep the slots filled
     if (compact == 2 && s > 1) { s = s * 4 / 3; if (s > K / 512) s = K / 512; if (s > 64) s = 64; if (s < 1) s = 1; }
+    *big_out = big;
+    return s;
+}
+
+// images -> C.  a_km / b_km: the operand image is k-major ([k][row]) instead of k-contiguous ([row][k]).
+// Images are padded to multiples of 256 in both dimensions (ft_bf16_image), so either tile height may run off the logical M.
+int run_images(const unsigned short* A, long lda, int a_km, const unsigned short* B, long ldb, int b_km, float* C, long ldc,
+               const float* bias, int M, int N, int K, float alpha, float beta, int act, int flags, hipStream_t st,
+               const int* rowmap = nullptr, const int* rows_dev = nullptr, int compact = 0, int k_shift = 0,
+               const float* r1row = nullptr, const float* r1col = nullptr, float* split_work = nullptr, size_t split_work_bytes = 0) {
+    BfP p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias;
+    p.M = M; p.N = N; p.nk = cdiv(K, 32); p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.alpha = alpha; p.beta = beta; p.act = act;
+    p.rowmap = rowmap; p.rows_dev = rows_dev; p.compact = compact; p.k_shift = k_shift;
+    p.r1row = r1row; p.r1col = r1col;
+    p.c_slice = 0;
+    // deterministic split-K: the slices' partial products side by side in a workspace + a fixed-order reduction (for FORWARD GEMMs
+    // with few output tiles and a long K: a forward pass must be a function of its inputs, which the atomics' order is not)
+    const bool det = (flags & FT_GEMM_SPLITK_DET) && split_work && act == FT_ACT_NONE && beta == 0.f && compact == 0 && !r1row && K >= 2048 &&
+                     N % 4 == 0 && ldc % 4 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0 && reinterpret_cast<uintptr_t>(split_work) % 16 == 0;
+    const bool can_split = det || ((flags & FT_GEMM_SPLITK) && act == FT_ACT_NONE && (beta == 0.f || beta == 1.f) && K >= 2048 && !r1row);
+    bool big;
+    long s = plan_slices(M, N, K, can_split, compact, &big);
+    const int RTA = big ? 256 : TB;
+    p.gx = cdiv(N, TB); p.gy = cdiv(M, RTA);
+    p.vec_c = (reinterpret_cast<uintptr_t>(C) % 16 == 0 && ldc % 4 == 0) ? 1 : 0;
+    if (det) {                                   // as many slices as the workspace holds
+        const long fit = (long)(split_work_bytes / ((size_t)M * N * sizeof(float)));
+        if (s > fit) s = fit;
+        if (s < 1) s = 1;
+    }
     p.ksteps = cdiv(p.nk, s);
     p.splits = cdiv(p.nk, p.ksteps);
-    if (p.splits > 1 && beta == 0.f) FT_CHECK_HIP(hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, st));
+    const bool det_on = det && p.splits > 1;
+    if (det_on) {
+        p.C = split_work; p.ldc = N; p.c_slice = (long)M * N; p.bias = nullptr;
+        p.vec_c = 1;
+    } else if (p.splits > 1 && beta == 0.f) {
+        FT_CHECK_HIP(hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, st));
+    }
     // L2-aware tile order for the un-split kernels: column chunks whose B panels (chunk_w x TB rows x K) fit ~2 MB of an XCD's L2
     static const int order_on = [] { const char* e = getenv("FT_GEMM_BF16_ORDER"); return e ? atoi(e) : 1; }();
     p.chunk_w = 0;
@@ -772,6 +819,11 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
     const dim3 grid(gridx, p.splits);
     if (a_km) { if (b_km) launch_s<true, true>(p, grid, big, st); else launch_s<true, false>(p, grid, big, st); }
     else      { if (b_km) launch_s<false, true>(p, grid, big, st); else launch_s<false, false>(p, grid, big, st); }
+    if (det_on) {
+        const long n4 = ((long)M * N) >> 2;
+        const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+        hipLaunchKernelGGL(splitk_reduce_k, dim3(blocks), dim3(256), 0, st, split_work, p.splits, (long)M * N, N, C, ldc, bias);
+    }
     FT_CHECK_LAUNCH();
     return FT_OK;
 }
@@ -962,6 +1014,16 @@ extern "C" int FT_OPNAME(ft_bf16_image_colsum)(const float* src, int64_t ld, int
     return FT_OK;
 }
 
+#if FT_OPFMT == 0
+// fp32 bytes of workspace a deterministic split-K ft_gemm_img of this shape can use (FT_GEMM_SPLITK_DET); 0: it would not split
+extern "C" size_t ft_gemm_img_split_work_bytes(int M, int N, int K) {
+    if (M < 1 || N < 1 || K < 2048 || N % 4 != 0) return 0;
+    bool big;
+    const long s = plan_slices(M, N, K, true, 0, &big);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+#endif
+
 extern "C" int FT_OPNAME(ft_gemm_img)(const ft_gemm_img_args* a, void* stream) {
     FT_CHECK_ARG(a != nullptr);
     FT_CHECK_ARG(a->A && a->B && a->C && a->M >= 1 && a->N >= 1 && a->K >= 1);
@@ -971,7 +1033,8 @@ extern "C" int FT_OPNAME(ft_gemm_img)(const ft_gemm_img_args* a, void* stream) {
     FT_CHECK_ARG((a->r1_row == nullptr) == (a->r1_col == nullptr));
     return run_images(reinterpret_cast<const unsigned short*>(a->A), a->lda, a->a_kmajor, reinterpret_cast<const unsigned short*>(a->B),
                       a->ldb, a->b_kmajor, a->C, a->ldc, a->bias, a->M, a->N, a->K, a->alpha, a->beta, a->act, a->flags,
-                      reinterpret_cast<hipStream_t>(stream), a->rowmap, a->rows_dev, a->compact, a->k_shift, a->r1_row, a->r1_col);
+                      reinterpret_cast<hipStream_t>(stream), a->rowmap, a->rows_dev, a->compact, a->k_shift, a->r1_row, a->r1_col,
+                      reinterpret_cast<float*>(a->split_work), a->split_work_bytes);
 }
 
 // compact image: image row i = source row rowmap[i] (i < *rows_dev; -1 = zero row); buffer sized for cap_rows

@@ -75,10 +75,12 @@ class RowMap:
 
 _COMPACT = _os.environ.get("FLOWTRON_GEMM_COMPACT", "1") != "0"
 _FUSE_ACT_BWD = _os.environ.get("FLOWTRON_FUSE_ACT_BWD", "1") != "0"    # activation backward inside the gradient's image pass
-# split-K (fp32 atomics) on the encoder's FORWARD split-image GEMM: -0.2 ms per step, but the order of the atomics makes the forward
-# itself differ from run to run (z up to 8e-4, bf16 gradients up to 1e-2 rel-L2 on the same batch and weights:
-# scripts/exp/noise_debug.py, profiles/r05b_forward_noise.log) -- off by default: a forward pass is a function of its inputs
-_ENC_SPLITK = _os.environ.get("FLOWTRON_ENC_SPLITK", "0") != "0"
+# split-K on the encoder's FORWARD split-image GEMM (160 output tiles, K = 7 680).  With fp32 atomics (FLOWTRON_ENC_SPLITK=atomic: the
+# first form, -0.2 ms per step) the order of the atomics makes the forward itself differ from run to run (z up to 8e-4, bf16 gradients
+# up to 1e-2 rel-L2 on the same batch and weights: scripts/exp/noise_debug.py, profiles/r05b_forward_noise.log).  Default "det": the
+# slices' partial products side by side + a fixed-order reduction (FT_GEMM_SPLITK_DET) -- a forward pass is a function of its inputs;
+# "0": one slice
+_ENC_SPLITK = {"det": "det", "atomic": True, "1": True, "0": False}.get(_os.environ.get("FLOWTRON_ENC_SPLITK", "det"), "det")
 _CAT_IMAGES = _os.environ.get("FLOWTRON_GEMM_CAT", "1") != "0"      # a Linear over two inputs as ONE GEMM over a concatenated image
 _PERSIST_IMG = _os.environ.get("FLOWTRON_LSTM_PERSIST_IMG", "1")      # 1: the persistent backward emits the dgates image INSTEAD of fp32 dgx where its only consumer is the projection's backward; both; 0
 
@@ -214,11 +216,18 @@ def gemm_img(A, a_km, a_ptr, B, b_km, b_ptr, Cm, M, N, K, ldc, bias=None, act=L.
     2 = the reduction runs over compact rows (pass K = rowmap.cap; k_shift = a row shift already applied to a_ptr).
     rank1 = (r [C rows] fp32, c_ptr -> N floats): C[row][col] += r[row] * c[col] in the epilogue (row = the output row)."""
     L.require_cuda(Cm, bias)
+    flags, work, need = (L.GEMM_SPLITK if splitk else 0), None, 0
+    if splitk == "det":
+        # deterministic split-K (forward GEMMs): partial products side by side in a workspace, added in a fixed order
+        need = L.lib().ft_gemm_img_split_work_bytes(M, N, K)
+        flags = L.GEMM_SPLITK_DET if need else 0
+        work = torch.empty(need, device=Cm.device, dtype=torch.uint8) if need else None
     a = L.GemmImgArgs(a_ptr, b_ptr, L.ptr(Cm), L.ptr(bias), M, N, K, A.ld, B.ld, ldc, int(a_km), int(b_km),
-                      alpha, beta, act, L.GEMM_SPLITK if splitk else 0,
+                      alpha, beta, act, flags,
                       L.ptr(rowmap.map) if rowmap is not None else None, L.ptr(rowmap.rows) if rowmap is not None else None,
                       int(compact) if rowmap is not None else 0, int(k_shift),
-                      L.ptr(rank1[0]) if rank1 is not None else None, rank1[1] if rank1 is not None else None)
+                      L.ptr(rank1[0]) if rank1 is not None else None, rank1[1] if rank1 is not None else None,
+                      L.ptr(work), need)
     assert A.fmt == B.fmt, "operand images of different formats"
     L.check(L.op16("ft_gemm_img", A.fmt)(C.byref(a), L.stream()), "ft_gemm_img")
 
@@ -418,7 +427,7 @@ class LinearFn(torch.autograd.Function):
             if Ktot % 32 == 0 and images_apply(mode_dx, rows, N, Ktot):
                 xi, wi = Bf16Image.split3(x2d, mode_dx, False), Bf16Image.split3(W, mode_dx, True)
                 # K = 3 Ktot over only (rows / 128) x (N / 128) output tiles (160 for the encoder: a sixth of the chip's workgroup slots,
-                # 240 k-steps each: 130 us): split-K would fill the chip (the bias rides on the first slice) -- FLOWTRON_ENC_SPLITK=1
+                # 240 k-steps each: 130 us): split-K fills the chip -- in its deterministic form (see _ENC_SPLITK)
                 gemm_img(xi, 0, xi.ptr(), wi, 0, wi.ptr(), y, rows, N, 3 * Ktot, N, bias=bias, splitk=_ENC_SPLITK)
                 split_imgs = (wi.view_cols(Ktot), [xi.view_cols(Ktot)])      # their [hi] blocks serve the backward's GEMMs as they are
             else:

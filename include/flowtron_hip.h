@@ -71,7 +71,7 @@ extern "C" {
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1, FT_F16 = 2 };
 enum { FT_ACT_NONE = 0, FT_ACT_TANH = 1, FT_ACT_RELU = 2, FT_ACT_SIGMOID = 3 };
-enum { FT_GEMM_SPLITK = 1 };
+enum { FT_GEMM_SPLITK = 1, FT_GEMM_SPLITK_DET = 2 };
 
 int ft_abi_version(void);
 const char* ft_last_error(void);
@@ -133,7 +133,14 @@ typedef struct {
      * row map), before the activation; both NULL = none; not with split-K.  The gate layer's input gradient dgate (x) w_gate rides
      * on the decoder input projection's dX GEMM this way (flowtron.py:758-761: both read [h_att ; ctx]). */
     const float* r1_row; const float* r1_col;
+    /* deterministic split-K (ABI 12; flags & FT_GEMM_SPLITK_DET, beta = 0, no activation, compact = 0, N % 4 == 0): the k-slices
+     * write their partial products side by side into split_work (ft_gemm_img_split_work_bytes(M, N, K) bytes, 16-byte aligned) with
+     * plain stores and a second kernel adds them in ascending slice order (+ bias): the result is a function of the operands, which
+     * the fp32 atomics of FT_GEMM_SPLITK are not (their order varies from run to run).  For FORWARD GEMMs with few output tiles and
+     * a long reduction (the encoder convolutions' split-image product, flowtron.py:499-502); NULL / 0: never splits. */
+    void* split_work; size_t split_work_bytes;
 } ft_gemm_img_args;
+size_t ft_gemm_img_split_work_bytes(int M, int N, int K);
 size_t ft_bf16_image_bytes(int64_t rows, int64_t cols);
 int ft_bf16_image(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, void* stream);
 /* the same image plus colsum[c] = sum_r src[r][c] in fp32 (bias gradients ride on the conversion pass of the output

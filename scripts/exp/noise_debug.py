@@ -30,6 +30,7 @@ def report(tag):
     print("%-28s losses equal %s z maxdiff %.2e | worst rel-L2:" % (tag, l0 == l1, float(np.abs(z0 - z1).max())), ["%s %.1e" % (k.replace("ar_step.", "")[-38:], w) for w, k in rl2[:5]])
 
 report("default")
+ops._ENC_SPLITK = True; report("encoder fwd split-K with atomics")
 ops._ENC_SPLITK = False; report("encoder fwd split-K off")
 ops.FUSED_LOSS = False; report("+ fused loss off")
 ops.FUSED_LOSS = True

@@ -523,6 +523,31 @@ def test_attention_ctc_kernel_vs_oracle(env, blank):
     assert float(lpd2.grad[2].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(5024, 512, 7680), (300, 128, 4096), (96, 36, 2560)])
+def test_deterministic_split_k_is_a_function_of_its_operands(env, fmt, M, N, K):
+    """ft_gemm_img with FT_GEMM_SPLITK_DET (the encoder convolutions' forward split-image product): the k-slices' partial products go to a
+    workspace and are added in a fixed order -- two runs are BIT-identical (the fp32 atomics of FT_GEMM_SPLITK are not: their order
+    varies), the result equals the fp64 product of the rounded operands to fp32 accumulation error, and the un-split GEMM to rounding."""
+    L, ops = env
+    torch.manual_seed(M + N)
+    dt = torch.bfloat16 if fmt == 1 else torch.float16
+    x = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") / K ** 0.5
+    bias = torch.randn(N, device="cuda")
+    xi, wi = ops.Bf16Image(x, mode=fmt), ops.Bf16Image(w, mode=fmt)
+    ref = (x.to(dt).double() @ w.to(dt).double().t() + bias.double()).float()
+    outs = []
+    for split in ("det", "det", False):
+        y = torch.full((M, N), 7.0, device="cuda")
+        ops.gemm_img(xi, 0, xi.ptr(), wi, 0, wi.ptr(), y, M, N, K, N, bias=bias, splitk=split)
+        torch.cuda.synchronize()
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    assert mad(outs[0], ref) < 2e-4 and mad(outs[2], ref) < 2e-4
+    assert L.lib().ft_gemm_img_split_work_bytes(M, N, K) > 0 and L.lib().ft_gemm_img_split_work_bytes(M, N, 1024) == 0   # (short K: one slice)
+
+
 @pytest.mark.parametrize("n_flows", [1, 2, 3])
 def test_fused_flowtron_loss_vs_oracle_and_per_term_path(env, n_flows):
     """ops.FlowtronLossFn (ft_flowtron_loss_fwd/bwd + ft_attn_ctc_fwd/bwd_multi: one autograd node, the odd flows' log-probabilities
