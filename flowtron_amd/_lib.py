@@ -71,16 +71,19 @@ SIGNATURES = {
     "ft_bf16_image_bytes": ([_l, _l], _sz),
     "ft_bf16_image": ([_p, _l, _l, _l, _p, _p], _i),
     "ft_bf16_image_colsum": ([_p, _l, _l, _l, _p, _p, _p], _i),
+    "ft_bf16_image_colsum_acc": ([_p, _l, _l, _l, _p, _p, _p], _i),
     "ft_gemm_img": ([C.POINTER(GemmImgArgs), _p], _i),
     "ft_gemm_img_split_work_bytes": ([_i, _i, _i], _sz),
     "ft_bf16_image_split3": ([_p, _l, _l, _l, _p, _i, _p], _i),
     "ft_bf16_image_split3_f16": ([_p, _l, _l, _l, _p, _i, _p], _i),
     "ft_rowmap_build": ([_p, _p, _p, _i, _i, _p], _i),
     "ft_bf16_image_rows": ([_p, _l, _l, _l, _p, _p, _p, _p, _p], _i),
+    "ft_bf16_image_rows_acc": ([_p, _l, _l, _l, _p, _p, _p, _p, _p], _i),
     "ft_bf16_image_rows_into": ([_p, _l, _l, _l, _p, _l, _l, _l, _p, _p, _p], _i),
     "ft_img_gemv_rows": ([_p, _l, _i, _p, _p, _p, _l, _p, _p, _p, _i, _i, _p], _i),
     "ft_img_gemv_rows_bwd": ([_p, _l, _i, _p, _l, _p, _p, _p, _p, _l, _p], _i),
     "ft_bf16_image_rows_act_bwd": ([_p, _l, _p, _l, _i, _l, _l, _p, _p, _p, _p, _p], _i),
+    "ft_bf16_image_rows_act_bwd_acc": ([_p, _l, _p, _l, _i, _l, _l, _p, _p, _p, _p, _p], _i),
     "ft_pad_rows_fill": ([_p, _l, _i, _p, _i, _i, _i, _p], _i),
     "ft_embedding_fwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
     "ft_embedding_bwd": ([_p, _p, _p, _i, _i, _l, _p], _i),
@@ -151,7 +154,7 @@ SIGNATURES = {
 }
 
 # fp16-operand twins (include/flowtron_hip.h, end): same signatures, suffix _f16
-OP16_TWINS = ("ft_gemm", "ft_bf16_image", "ft_bf16_image_colsum", "ft_gemm_img", "ft_bf16_image_rows", "ft_bf16_image_rows_into", "ft_bf16_image_rows_act_bwd", "ft_img_gemv_rows", "ft_img_gemv_rows_bwd", "ft_lstm_seq_fwd", "ft_lstm_seq_bwd",
+OP16_TWINS = ("ft_gemm", "ft_bf16_image", "ft_bf16_image_colsum", "ft_bf16_image_colsum_acc", "ft_bf16_image_rows_acc", "ft_bf16_image_rows_act_bwd_acc", "ft_gemm_img", "ft_bf16_image_rows", "ft_bf16_image_rows_into", "ft_bf16_image_rows_act_bwd", "ft_img_gemv_rows", "ft_img_gemv_rows_bwd", "ft_lstm_seq_fwd", "ft_lstm_seq_bwd",
               "ft_lstm_persist_fwd", "ft_lstm_persist_bwd", "ft_lstm_persist_bwd_img", "ft_lstm_persist_fwd_rows", "ft_lstm_persist_bwd_rows", "ft_lstm2_seq_fwd", "ft_lstm2_seq_bwd",
               "ft_lstm_bidir_seq_fwd", "ft_lstm_bidir_seq_bwd", "ft_bilstm_persist_fwd", "ft_bilstm_persist_bwd")
 for _n in OP16_TWINS:

@@ -1001,17 +1001,25 @@ extern "C" int FT_OPNAME(ft_bf16_image_split3)(const float* src, int64_t ld, int
     return FT_OK;
 }
 
-extern "C" int FT_OPNAME(ft_bf16_image_colsum)(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, float* colsum, void* stream) {
+// (the _acc forms below ADD the column sums to a colsum the caller has zeroed -- a slice of the backward pass's zeroed slab -- instead
+// of clearing it here: one memset dispatch less per bias gradient, 11 per training step)
+static int image_colsum_impl(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, float* colsum, bool clear, void* stream) {
     FT_CHECK_ARG(src && dst && colsum && rows >= 1 && cols >= 1 && ld >= cols && rows < (1ll << 31) - 256 && cols < (1ll << 31) - 256);
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int Rp = (int)up((size_t)rows + 32, 256), Cp = (int)up((size_t)cols, 256);
     const int vec = (reinterpret_cast<uintptr_t>(src) % 16 == 0 && ld % 4 == 0) ? 1 : 0;
-    FT_CHECK_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)cols, st));
+    if (clear) FT_CHECK_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)cols, st));
     hipLaunchKernelGGL(img_rows_sum_k, dim3(cdiv(Cp, 256), cdiv(Rp, 256)), dim3(256), 0, st, src, (long)ld, (int)rows, (int)cols,
                        reinterpret_cast<unsigned short*>(dst), Rp, Cp, vec, colsum, nullptr, nullptr);
     FT_CHECK_LAUNCH();
     return FT_OK;
+}
+extern "C" int FT_OPNAME(ft_bf16_image_colsum)(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, float* colsum, void* stream) {
+    return image_colsum_impl(src, ld, rows, cols, dst, colsum, true, stream);
+}
+extern "C" int FT_OPNAME(ft_bf16_image_colsum_acc)(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, float* colsum, void* stream) {
+    return image_colsum_impl(src, ld, rows, cols, dst, colsum, false, stream);
 }
 
 #if FT_OPFMT == 0
@@ -1041,20 +1049,30 @@ extern "C" int FT_OPNAME(ft_gemm_img)(const ft_gemm_img_args* a, void* stream) {
 // The output gradient of an ACTIVATED dense layer straight into its operand image: dst = image(dy * act'(pre)) over the compact
 // rows of `rowmap`, with act' expressed through the saved output y (ft_act_bwd's formulas), colsum [cols] = the bias gradient.
 // Replaces ft_act_bwd + ft_bf16_image_rows (one fp32 [rows, cols] tensor written and read back per dense layer).
-extern "C" int FT_OPNAME(ft_bf16_image_rows_act_bwd)(const float* dy, int64_t ld, const float* y, int64_t ldy, int act, int64_t cap_rows,
-                                                     int64_t cols, void* dst, float* colsum, const int32_t* rowmap,
-                                                     const int32_t* rows_dev, void* stream) {
+static int image_rows_act_bwd_impl(const float* dy, int64_t ld, const float* y, int64_t ldy, int act, int64_t cap_rows,
+                                   int64_t cols, void* dst, float* colsum, const int32_t* rowmap,
+                                   const int32_t* rows_dev, bool clear, void* stream) {
     FT_CHECK_ARG(dy && y && dst && colsum && rowmap && rows_dev && cap_rows >= 1 && cols >= 1 && ld >= cols && ldy >= cols);
     FT_CHECK_ARG(act >= FT_ACT_NONE && act <= FT_ACT_SIGMOID && cap_rows < (1ll << 31) - 512 && cols < (1ll << 31) - 256);
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int Rp = (int)up((size_t)cap_rows + 32, 256), Cp = (int)up((size_t)cols, 256);
     const int vec = (reinterpret_cast<uintptr_t>(dy) % 16 == 0 && ld % 4 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 && ldy % 4 == 0) ? 1 : 0;
-    FT_CHECK_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)cols, st));
+    if (clear) FT_CHECK_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)cols, st));
     hipLaunchKernelGGL(img_rows_sum_k, dim3(cdiv(Cp, 256), cdiv(Rp, 256)), dim3(256), 0, st, dy, (long)ld, (int)cap_rows, (int)cols,
                        reinterpret_cast<unsigned short*>(dst), Rp, Cp, vec, colsum, rowmap, rows_dev, y, (long)ldy, act);
     FT_CHECK_LAUNCH();
     return FT_OK;
+}
+extern "C" int FT_OPNAME(ft_bf16_image_rows_act_bwd)(const float* dy, int64_t ld, const float* y, int64_t ldy, int act, int64_t cap_rows,
+                                                     int64_t cols, void* dst, float* colsum, const int32_t* rowmap,
+                                                     const int32_t* rows_dev, void* stream) {
+    return image_rows_act_bwd_impl(dy, ld, y, ldy, act, cap_rows, cols, dst, colsum, rowmap, rows_dev, true, stream);
+}
+extern "C" int FT_OPNAME(ft_bf16_image_rows_act_bwd_acc)(const float* dy, int64_t ld, const float* y, int64_t ldy, int act, int64_t cap_rows,
+                                                         int64_t cols, void* dst, float* colsum, const int32_t* rowmap,
+                                                         const int32_t* rows_dev, void* stream) {
+    return image_rows_act_bwd_impl(dy, ld, y, ldy, act, cap_rows, cols, dst, colsum, rowmap, rows_dev, false, stream);
 }
 
 // One COLUMN BLOCK of a compact image (LinearFn over two inputs: [h_att ; ctx] -> one image, one K loop): the piece src [*, cols]
@@ -1074,8 +1092,8 @@ extern "C" int FT_OPNAME(ft_bf16_image_rows_into)(const float* src, int64_t ld, 
     return FT_OK;
 }
 
-extern "C" int FT_OPNAME(ft_bf16_image_rows)(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, float* colsum,
-                                             const int32_t* rowmap, const int32_t* rows_dev, void* stream) {
+static int image_rows_impl(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, float* colsum,
+                           const int32_t* rowmap, const int32_t* rows_dev, bool clear, void* stream) {
     FT_CHECK_ARG(src && dst && rowmap && rows_dev && cap_rows >= 1 && cols >= 1 && ld >= cols && cap_rows < (1ll << 31) - 512 && cols < (1ll << 31) - 256);
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1084,12 +1102,20 @@ extern "C" int FT_OPNAME(ft_bf16_image_rows)(const float* src, int64_t ld, int64
         make_image(src, ld, 1, (int)cap_rows, (int)cols, reinterpret_cast<unsigned short*>(dst), Rp, Cp, st, rowmap, rows_dev);
     } else {
         const int vec = (reinterpret_cast<uintptr_t>(src) % 16 == 0 && ld % 4 == 0) ? 1 : 0;
-        FT_CHECK_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)cols, st));
+        if (clear) FT_CHECK_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)cols, st));
         hipLaunchKernelGGL(img_rows_sum_k, dim3(cdiv(Cp, 256), cdiv(Rp, 256)), dim3(256), 0, st, src, (long)ld, (int)cap_rows, (int)cols,
                            reinterpret_cast<unsigned short*>(dst), Rp, Cp, vec, colsum, rowmap, rows_dev);
     }
     FT_CHECK_LAUNCH();
     return FT_OK;
+}
+extern "C" int FT_OPNAME(ft_bf16_image_rows)(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, float* colsum,
+                                             const int32_t* rowmap, const int32_t* rows_dev, void* stream) {
+    return image_rows_impl(src, ld, cap_rows, cols, dst, colsum, rowmap, rows_dev, true, stream);
+}
+extern "C" int FT_OPNAME(ft_bf16_image_rows_acc)(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, float* colsum,
+                                                 const int32_t* rowmap, const int32_t* rows_dev, void* stream) {
+    return image_rows_impl(src, ld, cap_rows, cols, dst, colsum, rowmap, rows_dev, false, stream);
 }
 
 // y[rowmap[c]] = sum_k img[c][k] w[k] + bias[0] over the compact rows of an image (img_gemv_rows_k above); y [T*B] rows of stride ldy,

@@ -104,18 +104,19 @@ class Bf16Image:
         self.fmt = L.mfma_mode() if mode is None else mode      # FT_BF16 or FT_F16: 16-bit payloads of that operand format
         self.ld = (self.cols + 255) // 256 * 256
         self.rowmap = rowmap
-        self.colsum = torch.empty(self.cols, device=t2d.device, dtype=torch.float32) if colsum else None
+        # column sums (bias gradients) are ADDED to a zeroed slice of the backward pass's slab (the _acc entry points: no memset each)
+        self.colsum = zeroed((self.cols,), t2d.device) if colsum else None
         if rowmap is not None:
             assert self.rows == rowmap.T * rowmap.B, "row map built for another [T, B]"
             self.rows = rowmap.cap
             self.buf = torch.empty(L.lib().ft_bf16_image_bytes(self.rows, self.cols), device=t2d.device, dtype=torch.uint8)
-            L.check(L.op16("ft_bf16_image_rows", self.fmt)(L.ptr(t2d), int(t2d.stride(0)), self.rows, self.cols, L.ptr(self.buf), L.ptr(self.colsum),
-                                                            L.ptr(rowmap.map), L.ptr(rowmap.rows), L.stream()), "ft_bf16_image_rows")
+            L.check(L.op16("ft_bf16_image_rows_acc", self.fmt)(L.ptr(t2d), int(t2d.stride(0)), self.rows, self.cols, L.ptr(self.buf), L.ptr(self.colsum),
+                                                                L.ptr(rowmap.map), L.ptr(rowmap.rows), L.stream()), "ft_bf16_image_rows_acc")
             return
         self.buf = torch.empty(L.lib().ft_bf16_image_bytes(self.rows, self.cols), device=t2d.device, dtype=torch.uint8)
         if colsum:
-            L.check(L.op16("ft_bf16_image_colsum", self.fmt)(L.ptr(t2d), int(t2d.stride(0)), self.rows, self.cols, L.ptr(self.buf), L.ptr(self.colsum),
-                                                 L.stream()), "ft_bf16_image_colsum")
+            L.check(L.op16("ft_bf16_image_colsum_acc", self.fmt)(L.ptr(t2d), int(t2d.stride(0)), self.rows, self.cols, L.ptr(self.buf), L.ptr(self.colsum),
+                                                     L.stream()), "ft_bf16_image_colsum_acc")
         else:
             L.check(L.op16("ft_bf16_image", self.fmt)(L.ptr(t2d), int(t2d.stride(0)), self.rows, self.cols, L.ptr(self.buf), L.stream()), "ft_bf16_image")
 
@@ -351,6 +352,34 @@ def weight_grad_out(W):
     return zeroed(W.shape, W.device)
 
 
+# An activation with several consumers (h_att feeds the query projection AND the decoder LSTM's input projection; the encoder output
+# feeds the key and value projections of every flow) gets one input gradient per consumer, which autograd then adds: a [T,B,1024]
+# fp32 add of 340 MB of traffic per flow (49 us) for h_att.  The image-path Linear backward instead ACCUMULATES into the buffer the
+# first consumer of the same tensor produced in this pass (its dX GEMM runs with beta = 1) and returns None for that input -- the
+# engine hands the producer the one buffer.  Safe because the engine runs an activation's producer only after ALL its consumers,
+# and because forward activations never share an address while alive.  Buffers are held weakly: nothing outlives its consumer.
+_DX_INPLACE = _os.environ.get("FLOWTRON_DX_INPLACE", "1") != "0"
+_DXACC = {"task": None, "bufs": {}}
+
+
+def _dx_buffer(x):
+    """(buffer for the input gradient of x, accumulate: the buffer already holds another consumer's contribution)"""
+    gt = _current_graph_task() if _DX_INPLACE else -1
+    if gt == -1:
+        return torch.empty_like(x), False
+    d = _DXACC
+    if d["task"] != gt:
+        d["task"], d["bufs"] = gt, {}
+    key = (x.device.index, x.data_ptr(), tuple(x.shape))
+    ref = d["bufs"].get(key)
+    buf = ref() if ref is not None else None
+    if buf is not None:
+        return buf, True
+    buf = torch.empty_like(x)
+    d["bufs"][key] = _weakref.ref(buf)
+    return buf, False
+
+
 def colsum(x2d: torch.Tensor, rows: int, N: int, ld: int) -> torch.Tensor:
     out = torch.empty(N, device=x2d.device, dtype=torch.float32)
     L.check(L.lib().ft_colsum(L.ptr(x2d), L.ptr(out), rows, N, ld, L.stream()), "ft_colsum")
@@ -516,9 +545,9 @@ class LinearFn(torch.autograd.Function):
             d_img = d_img_in                                                   # e.g. the LSTM backward already made it
             if d_img is None and fuse_act:
                 d_img = Bf16Image.empty_rows(N, rowmap, w_img.fmt, dy.device)
-                L.check(L.op16("ft_bf16_image_rows_act_bwd", w_img.fmt)(L.ptr(dy), N, L.ptr(y), N, ctx.act, d_img.rows, N, L.ptr(d_img.buf),
-                                                                         L.ptr(d_img.colsum), L.ptr(rowmap.map), L.ptr(rowmap.rows), L.stream()),
-                        "ft_bf16_image_rows_act_bwd")
+                L.check(L.op16("ft_bf16_image_rows_act_bwd_acc", w_img.fmt)(L.ptr(dy), N, L.ptr(y), N, ctx.act, d_img.rows, N, L.ptr(d_img.buf),
+                                                                             L.ptr(d_img.colsum), L.ptr(rowmap.map), L.ptr(rowmap.rows), L.stream()),
+                        "ft_bf16_image_rows_act_bwd_acc")            # (empty_rows' colsum is a zeroed slab slice)
             elif d_img is None:
                 d_img = Bf16Image(dpre.reshape(rows, N), colsum=want_db, mode=w_img.fmt, rowmap=rowmap)   # bias gradient rides on the conversion pass
             db = d_img.colsum if want_db else None
@@ -528,13 +557,17 @@ class LinearFn(torch.autograd.Function):
         for i, x in enumerate(xs):
             K = x.shape[-1]
             if ctx.needs_input_grad[6 + i]:
-                dx = torch.empty_like(x)
                 # dx[r,k] = sum_n dpre[r,n] W[n, off+k]
                 if imgs is not None:
-                    gemm_img(d_img, 0, d_img.ptr(), w_img, 1, w_img.ptr(0, off), dx, mrows, K, N, K, rowmap=rowmap, compact=1)
+                    dx, acc = _dx_buffer(x)            # (another consumer of x may have left its contribution there: beta = 1)
+                    gemm_img(d_img, 0, d_img.ptr(), w_img, 1, w_img.ptr(0, off), dx, mrows, K, N, K, beta=1.0 if acc else 0.0,
+                             rowmap=rowmap, compact=1)
                     if rowmap is not None and "dx" in ctx.fill:
                         rowmap.fill(dx.reshape(rows, K), K, copy_separator=False)
+                    if acc:
+                        dx = None                      # autograd already holds the buffer through the first consumer
                 else:
+                    dx = torch.empty_like(x)
                     gemm_raw(dpre, W[:, off:], dx, rows, K, N, N, 1, Ktot, 1, K, mode=ctx.mode_dx)
                 dxs.append(dx)
             else:
@@ -618,13 +651,14 @@ class LinearGateFn(torch.autograd.Function):
         for i, x in enumerate(xs):
             K = x.shape[-1]
             if ctx.needs_input_grad[7 + i]:
-                dx = torch.empty_like(x)
+                dx, acc = _dx_buffer(x)
                 if dgate is not None:
                     rank1 = (dgate, Wg.data_ptr() + 4 * off)
-                gemm_img(d_img, 0, d_img.ptr(), w_img, 1, w_img.ptr(0, off), dx, rowmap.cap, K, N, K, rowmap=rowmap, compact=1, rank1=rank1)
+                gemm_img(d_img, 0, d_img.ptr(), w_img, 1, w_img.ptr(0, off), dx, rowmap.cap, K, N, K, beta=1.0 if acc else 0.0,
+                         rowmap=rowmap, compact=1, rank1=rank1)
                 if "dx" in ctx.fill:
                     rowmap.fill(dx.reshape(rows, K), K, copy_separator=False)
-                dxs.append(dx)
+                dxs.append(None if acc else dx)
             else:
                 dxs.append(None)
             off += K

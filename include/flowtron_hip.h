@@ -147,6 +147,19 @@ int ft_bf16_image(const float* src, int64_t ld, int64_t rows, int64_t cols, void
  * gradient; colsum [cols] is overwritten; row slabs combine with fp32 atomics like ft_colsum) */
 int ft_bf16_image_colsum(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, float* colsum, void* stream);
 int ft_gemm_img(const ft_gemm_img_args* a, void* stream);
+/* _acc forms (ABI 12) of the three image passes that also produce column sums (ft_bf16_image_colsum, ft_bf16_image_rows with a colsum,
+ * ft_bf16_image_rows_act_bwd): the sums are ADDED to colsum, which the caller has zeroed (a slice of one zeroed slab per backward
+ * pass) -- the plain forms clear it with a memset dispatch of their own, 11 per training step. */
+int ft_bf16_image_colsum_acc(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, float* colsum, void* stream);
+int ft_bf16_image_rows_acc(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, float* colsum,
+                           const int32_t* rowmap, const int32_t* rows_dev, void* stream);
+int ft_bf16_image_rows_act_bwd_acc(const float* dy, int64_t ld, const float* y, int64_t ldy, int act, int64_t cap_rows, int64_t cols,
+                                   void* dst, float* colsum, const int32_t* rowmap, const int32_t* rows_dev, void* stream);
+int ft_bf16_image_colsum_acc_f16(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, float* colsum, void* stream);
+int ft_bf16_image_rows_acc_f16(const float* src, int64_t ld, int64_t cap_rows, int64_t cols, void* dst, float* colsum,
+                               const int32_t* rowmap, const int32_t* rows_dev, void* stream);
+int ft_bf16_image_rows_act_bwd_acc_f16(const float* dy, int64_t ld, const float* y, int64_t ldy, int act, int64_t cap_rows, int64_t cols,
+                                       void* dst, float* colsum, const int32_t* rowmap, const int32_t* rows_dev, void* stream);
 /* Split images (ABI 11): x = hi + lo, hi = op16(x), lo = op16(x - hi).  dst = [rows][3 cols] 16-bit (ft_bf16_image_bytes(rows, 3 cols),
  * row stride ceil256(3 cols)): an activation (weight = 0) as [hi | lo | hi], a weight matrix (weight = 1) as [hi | hi | lo], so that ONE
  * ft_gemm_img with K = 3 cols computes x_hi w_hi + x_lo w_hi + x_hi w_lo = x . w to ~2^-17 -- fp32-grade products at three times a

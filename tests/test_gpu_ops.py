@@ -523,6 +523,38 @@ def test_attention_ctc_kernel_vs_oracle(env, blank):
     assert float(lpd2.grad[2].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("with_rowmap", [False, True])
+def test_input_gradient_of_a_shared_activation_accumulates_in_place(env, monkeypatch, with_rowmap):
+    """An activation read by several image-path Linears (h_att: query projection + decoder input projection, flowtron.py:735-765): the
+    second consumer's dX GEMM runs with beta = 1 into the first one's buffer and returns None (ops._dx_buffer) instead of leaving a
+    [T,B,K] fp32 add to autograd.  Same gradients as the plain path (fp32 rounding of one addition order), pad rows zero where asked."""
+    L, ops = env
+    torch.manual_seed(77)
+    T, B, K = 40, 8, 256
+    lens = torch.tensor([40, 33, 33, 20, 11, 9, 4, 1], dtype=torch.int32, device="cuda")
+    x0 = torch.randn(T, B, K, device="cuda")
+    Ws = [torch.randn(n, K, device="cuda") / K ** 0.5 for n in (128, 64, 96)]
+    gs = [torch.randn(T, B, n, device="cuda") for n in (128, 64, 96)]
+    res = []
+    for inplace in (True, False):
+        monkeypatch.setattr(ops, "_DX_INPLACE", inplace)
+        x = x0.clone().requires_grad_(True)
+        h = ops.AddFn.apply(x, torch.zeros_like(x))                   # a non-leaf activation with three consumers
+        rm = ops.row_map(lens, T, B) if with_rowmap else None
+        ys = [ops.linear(h, W.clone().requires_grad_(True), None, mode=1, rowmap=rm, fill="y+dx") for W in Ws]
+        torch.autograd.backward(ys, gs)
+        torch.cuda.synchronize()
+        res.append(x.grad.clone())
+    assert rel(res[0], res[1]) < 1e-6, rel(res[0], res[1])
+    ref = sum((g.reshape(-1, g.shape[-1]).to(torch.bfloat16).double() @ W.to(torch.bfloat16).double()).reshape(T, B, K) for g, W in zip(gs, Ws))
+    act = (torch.arange(T, device="cuda")[:, None] < lens[None, :])
+    if with_rowmap:
+        assert float(res[0][~act].abs().max()) == 0.0
+        assert rel(res[0][act], ref[act].float()) < 2e-3
+    else:
+        assert rel(res[0], ref.float()) < 2e-3
+
+
 @pytest.mark.parametrize("fmt", [1, 2])
 @pytest.mark.parametrize("M,N,K", [(5024, 512, 7680), (300, 128, 4096), (96, 36, 2560)])
 def test_deterministic_split_k_is_a_function_of_its_operands(env, fmt, M, N, K):
