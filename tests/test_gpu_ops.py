@@ -549,7 +549,8 @@ def test_input_gradient_of_a_shared_activation_accumulates_in_place(env, monkeyp
     ref = sum((g.reshape(-1, g.shape[-1]).to(torch.bfloat16).double() @ W.to(torch.bfloat16).double()).reshape(T, B, K) for g, W in zip(gs, Ws))
     act = (torch.arange(T, device="cuda")[:, None] < lens[None, :])
     if with_rowmap:
-        assert float(res[0][~act].abs().max()) == 0.0
+        beyond = (torch.arange(T, device="cuda")[:, None] > lens[None, :])      # (row t == len_b is the utterance's separator: it keeps its value)
+        assert float(res[0][beyond].abs().max()) == 0.0 and float(res[1][beyond].abs().max()) == 0.0
         assert rel(res[0][act], ref[act].float()) < 2e-3
     else:
         assert rel(res[0], ref.float()) < 2e-3
