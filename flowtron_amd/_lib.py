@@ -150,6 +150,7 @@ SIGNATURES = {
     "ft_beta_binomial_prior": ([_p, _p, _p, _i, _i, _i, _f, _p], _i),
     "ft_sumsq": ([_p, _p, _l, _p, _p], _i),
     "ft_radam_step": ([_p, _p, _p, _p, _l, _p, _d, _d, _d, _d, _d, _d, _d, _i, _p, _p], _i),
+    "ft_radam_step_dev": ([_p, _p, _p, _p, _l, _p, _d, _d, _d, _d, _d, _d, _i, _p, _p], _i),
     "ft_poison_if_nonzero": ([_p, _p, _p], _i),
 }
 

@@ -456,6 +456,59 @@ __global__ void radam_k(float* __restrict__ p, const float* __restrict__ g, floa
     }
 }
 
+// The same update with the step count formed ON THE DEVICE: step = calls - *skipped (calls = optimizer.step() invocations so far,
+// this one included; *skipped = updates the guard has dropped so far), so bias correction and N_sma (radam.py:82-106) follow the
+// updates that were APPLIED -- what radam.py's per-parameter state['step'] counts under GradScaler, which simply does not call
+// step() after an overflow (train.py:330) -- without the host ever reading the drop decision.  One thread per workgroup evaluates
+// the closed form in double (the arithmetic of ops/optim.py: RAdam.step_size_for) and broadcasts it through LDS.  No race on
+// *skipped: it is written only when this launch is dropped, and then nobody uses the coefficients.
+__global__ void radam_dev_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, const float* __restrict__ gnorm_sq, float clip, float wd_lr, float b1, float b2, float omb1,
+                            float omb2, float eps, double lr, double beta1, double beta2, int calls, int* __restrict__ skipped) {
+    __shared__ float coef[2];
+    float cs = 1.f;
+    {
+        const float sq = gnorm_sq[0];
+        if (!(sq <= 3.0e38f)) {                     // NaN or Inf: drop the step
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
+            return;
+        }
+        if (clip > 0.f) cs = fminf(1.f, clip / (sqrtf(sq) + 1e-6f));
+    }
+    if (threadIdx.x == 0) {
+        int step = calls - skipped[0];
+        if (step < 1) step = 1;
+        const double beta2_t = pow(beta2, (double)step);
+        const double n_sma_max = 2.0 / (1.0 - beta2) - 1.0;
+        const double n_sma = n_sma_max - 2.0 * step * beta2_t / (1.0 - beta2_t);
+        const double bc1 = 1.0 - pow(beta1, (double)step);
+        double ss;
+        float rect;
+        if (n_sma >= 5.0) {
+            ss = lr * sqrt((1.0 - beta2_t) * (n_sma - 4.0) / (n_sma_max - 4.0) * (n_sma - 2.0) / n_sma * n_sma_max / (n_sma_max - 2.0)) / bc1;
+            rect = 1.f;
+        } else {
+            ss = lr / bc1;
+            rect = 0.f;
+        }
+        coef[0] = (float)ss;
+        coef[1] = rect;
+    }
+    __syncthreads();
+    const float step_size = coef[0];
+    const bool rectified = coef[1] != 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * cs;
+        const float vi = __fmaf_rn(omb2, __fmul_rn(gi, gi), __fmul_rn(b2, v[i]));
+        const float mi = __fmaf_rn(omb1, gi, __fmul_rn(b1, m[i]));
+        float pi = p[i];
+        if (wd_lr != 0.f) pi = __fmaf_rn(-wd_lr, pi, pi);
+        if (rectified) pi += -step_size * (mi / (sqrtf(vi) + eps));
+        else pi += -step_size * mi;
+        v[i] = vi; m[i] = mi; p[i] = pi;
+    }
+}
+
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -650,6 +703,17 @@ extern "C" int ft_radam_step(float* p, const float* g, float* m, float* v, int64
     hipLaunchKernelGGL(radam_k, dim3(grid_for(n, NT, 4096)), dim3(NT), 0, ST(stream), p, g, m, v, (long)n, gnorm_sq_dev, (float)clip,
                        (float)(weight_decay * lr), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
                        (float)step_size, rectified, skipped_dev);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+extern "C" int ft_radam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* gnorm_sq_dev, double clip,
+                                 double lr, double beta1, double beta2, double eps, double weight_decay, int calls,
+                                 int32_t* skipped_dev, void* stream) {
+    FT_CHECK_ARG(p && g && m && v && gnorm_sq_dev && skipped_dev && n >= 0 && calls >= 1);
+    if (n == 0) return FT_OK;
+    hipLaunchKernelGGL(radam_dev_k, dim3(grid_for(n, NT, 4096)), dim3(NT), 0, ST(stream), p, g, m, v, (long)n, gnorm_sq_dev, (float)clip,
+                       (float)(weight_decay * lr), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
+                       lr, beta1, beta2, calls, skipped_dev);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

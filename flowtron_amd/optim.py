@@ -26,8 +26,12 @@ import math
 import torch
 from torch.optim.optimizer import Optimizer
 
+import os
+
 from . import _lib as L
 from .dist import FlatArena
+
+_DEV_STEP = os.environ.get("FLOWTRON_RADAM_DEVSTEP", "1") != "0"      # bias-correction step count formed on the device (calls - drops)
 
 
 class RAdam(Optimizer):
@@ -51,6 +55,12 @@ class RAdam(Optimizer):
         self._have_norm = False
         self._step = 0
         self._skipped_applied = 0        # device-dropped updates already taken back from _step
+        # torch.amp.GradScaler.step (train.py:330 `scaler.step(optimizer)`): an optimizer with this attribute is handed `found_inf` /
+        # `grad_scale` as DEVICE tensors and called unconditionally, instead of the scaler reading found_inf on the host (one queue drain
+        # per fp16 step) and skipping the call.  The fused kernel's guard drops the update exactly then (an Inf / NaN gradient makes
+        # the global norm non-finite), and the step count the schedule uses is formed on the device from the drops
+        # (ft_radam_step_dev), so the trajectory is the one of the skipped call.
+        self._step_supports_amp_scaling = os.environ.get("FLOWTRON_AMP_HOST_SKIP", "0") != "1"     # (=1: torch's host-side skip, for A/B)
         self._bind_state()
 
     def _bind_state(self):
@@ -145,14 +155,27 @@ class RAdam(Optimizer):
                 for off, k in skipped]
         self._step += 1
         beta1, beta2 = g["betas"]
-        ss, rect = self.step_size_for(self._step, g["lr"], beta1, beta2)
         clip = getattr(self, "_clip", 0.0)
+        # GradScaler.step on a `_step_supports_amp_scaling` optimizer: gradients still scaled (no scaler.unscale_ before) arrive with
+        # their scale as a device tensor -- divided out here, on the device.  found_inf needs no look: a non-finite gradient makes the
+        # norm below non-finite, and the kernel drops the update on that.
+        grad_scale = getattr(self, "grad_scale", None)
+        if grad_scale is not None:
+            a.flat_grad.mul_(grad_scale.to(a.flat_grad.dtype).reciprocal())
+            stale = True
         # no clip_grad_norm_ this iteration: the guard still needs the norm (clip stays 0)
         if stale:
             self._norm_sq()
-        L.check(L.lib().ft_radam_step(L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.flat_m), L.ptr(self.flat_v),
-                                      a.numel, L.ptr(self.gnorm_sq), clip, g["lr"], beta1, beta2,
-                                      g["eps"], g["weight_decay"], ss, int(rect), L.ptr(self._skipped), L.stream()), "ft_radam_step")
+        if _DEV_STEP:
+            # the schedule's step count = calls - drops, formed on the device (no host read of the guard's decision)
+            L.check(L.lib().ft_radam_step_dev(L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.flat_m), L.ptr(self.flat_v), a.numel,
+                                              L.ptr(self.gnorm_sq), clip, g["lr"], beta1, beta2, g["eps"], g["weight_decay"],
+                                              self._step + self._skipped_applied, L.ptr(self._skipped), L.stream()), "ft_radam_step_dev")
+        else:
+            ss, rect = self.step_size_for(self._step, g["lr"], beta1, beta2)
+            L.check(L.lib().ft_radam_step(L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.flat_m), L.ptr(self.flat_v),
+                                          a.numel, L.ptr(self.gnorm_sq), clip, g["lr"], beta1, beta2,
+                                          g["eps"], g["weight_decay"], ss, int(rect), L.ptr(self._skipped), L.stream()), "ft_radam_step")
         self._clip = 0.0
         self._have_norm = False
         for off, k, pv, mv, vv in keep:

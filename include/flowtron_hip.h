@@ -565,6 +565,15 @@ int ft_sumsq(const float* x, float* acc, int64_t n, float* partials, void* strea
 int ft_radam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   const float* gnorm_sq_dev, double clip, double lr, double beta1, double beta2, double eps,
                   double weight_decay, double step_size, int rectified, int32_t* skipped_dev, void* stream);
+/* The same update with the step count formed on the device (ABI 12): step = calls - *skipped_dev, where calls = the number of
+ * optimizer steps issued so far (this one included) and *skipped_dev the updates the guard has dropped so far; step_size and the
+ * rectification switch (radam.py:82-106) are evaluated from it in double inside the kernel.  The schedule then follows the APPLIED
+ * updates exactly -- radam.py's state['step'] under GradScaler, which does not call step() after an overflow (train.py:330) --
+ * without the host reading the drop decision: an optimizer that sets `_step_supports_amp_scaling` lets torch's GradScaler.step
+ * hand over `found_inf` as a device tensor instead of synchronising on it (one host sync per fp16 step gone). */
+int ft_radam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* gnorm_sq_dev, double clip,
+                      double lr, double beta1, double beta2, double eps, double weight_decay, int calls,
+                      int32_t* skipped_dev, void* stream);
 /* if (*status_dev != 0) dst[0] = NaN.  Enqueued behind the last persistent recurrence launch of a backward pass on the first
  * element of a gradient bucket BEFORE its all-reduce / the norm reduction: a recurrence that reported a time-out (status word of
  * ft_lstm_persist_*) poisons the global gradient norm on EVERY rank, and the guard of ft_radam_step drops that step everywhere. */

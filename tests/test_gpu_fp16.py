@@ -248,11 +248,26 @@ def test_gradscaler_skips_the_step_on_fp16_overflow_and_steps_otherwise(monkeypa
 
     before = {k: p.detach().clone() for k, p in m.named_parameters()}
     s_big = torch.amp.GradScaler("cuda", init_scale=2.0 ** 40)
+    torch.manual_seed(5)
     one_step(s_big)
     assert s_big.get_scale() == 2.0 ** 39                           # inf found: backoff
-    assert opt._step == 0 and all(torch.equal(before[k], p) for k, p in m.named_parameters())
+    # (round 5: RAdam sets `_step_supports_amp_scaling`, so GradScaler.step calls step() WITHOUT reading found_inf on the host; the
+    # fused kernel drops the update on the non-finite norm and counts it on the device -- the host's count follows at the next look)
+    assert all(torch.equal(before[k], p) for k, p in m.named_parameters())
+    assert opt.skipped_steps == 1 and opt._step == 0
     s_ok = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10)
+    torch.manual_seed(6)
     one_step(s_ok)
-    assert s_ok.get_scale() == 2.0 ** 10 and opt._step == 1
+    assert s_ok.get_scale() == 2.0 ** 10 and opt._step == 1 and opt.skipped_steps == 1
     assert any(not torch.equal(before[k], p) for k, p in m.named_parameters())
     assert all(torch.isfinite(p).all() for p in m.parameters())
+    # the applied update used the schedule of step 1 (calls 2 - drops 1, formed on the device): a fresh optimizer that takes the same
+    # step as ITS first one lands on the same parameters (split-K atomics: equal to rounding; step 2's coefficients would be 1.9x off)
+    after = {k: p.detach().clone() for k, p in m.named_parameters()}
+    m.load_state_dict(sd)
+    opt = RAdam(m.parameters(), lr=1e-3, weight_decay=1e-6)
+    torch.manual_seed(6)
+    one_step(torch.amp.GradScaler("cuda", init_scale=2.0 ** 10))
+    for k, p in m.named_parameters():
+        d0, d1 = (after[k] - before[k]).float(), (p.detach() - before[k]).float()
+        assert float((d0 - d1).abs().max()) <= 2e-2 * float(d0.abs().max()) + 1e-9, k
