@@ -11,7 +11,13 @@ TR=$(find /tmp/kt2 -name "*kernel_trace.csv" | head -1)
 cp $(find /tmp/kt2 -name "*kernel_stats.csv" | head -1) "$OUT/train_kernel_stats.csv" 2>/dev/null
 grep '^{' "$OUT/train_under_rocprof.log" | tail -1 > "$OUT/bench_line_under_rocprof.json"
 for k in 1 2 3 4; do python $REPO/scripts/step_timeline.py "$TR" $k > "$OUT/step_timeline_$k.txt" 2>&1; head -n 1 "$OUT/step_timeline_$k.txt"; done
-BEST=$(for k in 1 2 3 4; do echo "$(head -n 1 $OUT/step_timeline_$k.txt | sed 's/.*span \([0-9.]*\) ms.*/\1/') $k"; done | sort -n | head -1 | cut -d' ' -f2)
+BEST=$(python -c "
+import re
+best=None
+for k in (1,2,3,4):
+    m=re.search(r'span ([0-9.]+) ms', open('$OUT/step_timeline_%d.txt' % k).readline())
+    if m and (best is None or float(m.group(1)) < best[0]): best=(float(m.group(1)), k)
+print(best[1] if best else 1)")
 cp "$OUT/step_timeline_$BEST.txt" "$OUT/step_timeline.txt"
 python $REPO/scripts/kernel_trace_table.py "$TR" 30 > "$OUT/kernel_instances.txt" 2>&1
 head -n 70 "$OUT/step_timeline.txt"

@@ -12,7 +12,7 @@ for r in rows:
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short,
                "%sx%sx%s" % (r.get("Grid_Size_X", ""), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""))))
 ev.sort()
-marks = [i for i, e in enumerate(ev) if e[2].startswith("radam_k")]
+marks = [i for i, e in enumerate(ev) if e[2].startswith(("radam_k", "radam_dev_k"))]
 if len(marks) < back + 1:
     print("not enough optimizer steps in the trace (%d radam_k launches)" % len(marks))
     sys.exit(0)
