@@ -185,7 +185,8 @@ class FlatArena:
         autograd adopts the returned view as .grad (a fresh tensor object each time: AccumulateGrad takes it over without a copy) and
         adopt_stray_grads finds it already in place -- no 2 x 244 MB multi-tensor copy per step.  A second contribution to the same
         parameter in the pass, or any pass that starts with gradients in place (accumulation), gets None: the caller's own buffer is
-        then accumulated by autograd as before."""
+        then accumulated by autograd as before (the engine adds two contributions of one pass out of place when their storage is
+        shared, as an arena view's is: that sum is a stray tensor and the adoption copies it in -- tests/test_host_cpu.py)."""
         if self._pass != task:
             self._pass, self._handed = task, set()
             self._pass_clean = all(p.grad is None for p in self.params)

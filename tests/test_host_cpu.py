@@ -319,6 +319,65 @@ def test_radam_load_state_dict_restores_the_flat_arenas():
     assert torch.equal(o2.flat_m[off[2]:off[2] + 33], o.flat_m[o.arena.offsets[2]:o.arena.offsets[2] + 33])
 
 
+def test_weight_gradients_land_in_the_arena_without_a_copy():
+    """dist.FlatArena.grad_view_for_pass / arena_slot (host logic; CPU tensors): in a backward pass that starts with every .grad None
+    the arena is zeroed once and a weight-gradient producer gets its parameter's arena slice -- autograd adopts the returned view as
+    .grad (no copy: the address lies inside the arena) and adopt_stray_grads finds nothing to move; a reshape of a parameter is
+    recognised, a slice of it is not; a second contribution to the same parameter and a pass that starts with gradients in place
+    (accumulation) get None and accumulate through autograd as before."""
+    from flowtron_amd import dist as D
+    from flowtron_amd import ops
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(6, 4)), torch.nn.Parameter(torch.randn(3, 2, 2)), torch.nn.Parameter(torch.randn(5))]
+    arena = D.FlatArena(ps)
+    lo, hi = arena._ptr_lo, arena._ptr_hi
+    assert D.arena_slot(ps[0]) == (arena, 0) and D.arena_slot(ps[1].reshape(3, 4)) == (arena, 1)
+    assert D.arena_slot(ps[0][:3]) is None and D.arena_slot(torch.randn(6, 4)) is None
+
+    class MulW(torch.autograd.Function):                      # y = x * W, dW through a zero-filled accumulating buffer like the GEMMs'
+        @staticmethod
+        def forward(ctx, x, W):
+            ctx.save_for_backward(x, W)
+            return x * W
+
+        @staticmethod
+        def backward(ctx, g):
+            x, W = ctx.saved_tensors
+            slot = D.arena_slot(W)
+            dW = slot[0].grad_view_for_pass(slot[1], ops._current_graph_task(), W.shape) if slot else None
+            served.append(dW is not None)
+            if dW is None:
+                dW = torch.zeros_like(W)
+            dW += g * x
+            return None, dW
+
+    x0, x1, x2 = torch.randn(6, 4), torch.randn(3, 4), torch.randn(5)
+    served = []
+    arena.flat_grad.fill_(7.0)                                # stale values of an earlier step
+    arena.zero_grad()
+    (MulW.apply(x0, ps[0]).sum() + MulW.apply(x1, ps[1].reshape(3, 4)).sum()).backward()
+    assert served == [True, True] or served == [True, True][::-1]
+    assert all(lo <= p.grad.data_ptr() < hi for p in ps[:2]) and ps[2].grad is None       # adopted as they are: no copy
+    assert torch.allclose(ps[0].grad, x0) and torch.allclose(ps[1].grad.reshape(3, 4), x1)
+    skipped = arena.adopt_stray_grads(copy=True)
+    assert not arena.adopt_copied and skipped == [(arena.offsets[2], 5)]
+    off = arena.offsets
+    assert torch.allclose(arena.flat_grad[off[0]:off[0] + 24].view(6, 4), x0) and float(arena.flat_grad[off[2]:off[2] + 5].abs().max()) == 0.0
+    # a second pass WITHOUT zero_grad accumulates: nothing is served, the arena is not zeroed again
+    served = []
+    MulW.apply(x0, ps[0]).sum().backward()
+    assert served == [False] and torch.allclose(ps[0].grad, 2 * x0) and lo <= ps[0].grad.data_ptr() < hi
+    # a parameter read twice in one pass: the second request is not served; whatever tensor autograd forms of the two contributions,
+    # the adoption leaves their SUM in the arena (the engine adds contributions of shared storage out of place: that one is copied)
+    served = []
+    arena.zero_grad()
+    (MulW.apply(x2, ps[2]).sum() + MulW.apply(2 * x2, ps[2]).sum() + MulW.apply(x0, ps[0]).sum()).backward()
+    assert sorted(served) == [False, True, True]
+    arena.adopt_stray_grads(copy=True)
+    assert torch.allclose(arena.flat_grad[off[2]:off[2] + 5], 3 * x2) and torch.allclose(arena.flat_grad[off[0]:off[0] + 24].view(6, 4), x0)
+    assert all(lo <= p.grad.data_ptr() < hi for p in (ps[0], ps[2]))
+
+
 def test_gradient_buckets_cover_the_arena_flow_by_flow():
     """dist.gradient_buckets on the default model: contiguous, exhaustive, one bucket per flow (110.7 MB each) between the
     embeddings and the encoder -- the ranges the data-parallel wrapper hands to RCCL one by one."""
