@@ -357,7 +357,12 @@ def weight_grad_out(W):
 # fp32 add of 340 MB of traffic per flow (49 us) for h_att.  The image-path Linear backward instead ACCUMULATES into the buffer the
 # first consumer of the same tensor produced in this pass (its dX GEMM runs with beta = 1) and returns None for that input -- the
 # engine hands the producer the one buffer.  Safe because the engine runs an activation's producer only after ALL its consumers,
-# and because forward activations never share an address while alive.  Buffers are held weakly: nothing outlives its consumer.
+# and because forward activations never share an address while alive.  Buffers are held weakly (a weak reference survives while
+# the engine's input buffer owns the tensor and dies with it): nothing outlives its consumer, and a buffer the engine has folded
+# into another tensor (a third, foreign contribution arriving first and adding ours in place) is simply not found again.
+# Caveat, by construction outside this model: if a FOREIGN owner (a user hook that stores gradient tensors) keeps the first buffer
+# alive AND a third contribution of another kind makes the engine replace it by an out-of-place sum, a later accumulation would
+# go into the orphan -- h_att and the encoder output have image-path consumers only; FLOWTRON_DX_INPLACE=0 restores autograd's adds.
 _DX_INPLACE = _os.environ.get("FLOWTRON_DX_INPLACE", "1") != "0"
 _DXACC = {"task": None, "bufs": {}}
 
