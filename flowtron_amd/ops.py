@@ -995,9 +995,11 @@ _PERSIST_WIDE = _os.environ.get("FLOWTRON_LSTM_PERSIST_WIDE", "1") != "0"
 
 
 def lstm_persist_slices(B, H, reverse, mode, device=None):
-    """(transport code, [(b0, rows)]) for a batch wider than one persistent launch holds (32 < B <= 64): the batch is walked in
-    slices of <= 32 rows, one persistent launch each (ft_lstm_persist_*_rows: 2 x 1.6-1.8 us per step against 5-6 us per step of
-    the launch-per-step kernels); None: one launch, or the launch-per-step kernels (three slices would not beat them)."""
+    """(transport code, [(b0, rows)]) for a batch wider than one persistent launch holds (32 < B <= 64, the widest batch the
+    launch-per-step kernels and the encoder's pair chain take -- the library's batch limit): the batch is walked in two slices of
+    <= 32 rows, one persistent launch each (ft_lstm_persist_*_rows: 1.6-1.8 us per step and slice against 6.8 us per step of the
+    launch-per-step kernels at B = 48 -- the configs[1] step at B = 48: 47.9 against 89.6 ms, profiles/r05b_wide_batch.log);
+    None: one launch suffices, or the shape is not the persistent kernels'."""
     if not _PERSIST_WIDE or B <= 32 or B > 64:
         return None
     ng = lstm_persist_groups(32, H, reverse, mode, device)

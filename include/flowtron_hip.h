@@ -287,7 +287,7 @@ int ft_lstm_persist_bwd_img(const float* dy, int64_t ldy, const float* w_hh, con
 /* Batches wider than one launch holds (B_total > 32; the reference's nn.LSTM has no such limit, flowtron.py:654-655, :689-694):
  * the same kernels over a SLICE of the batch -- rows b0 .. b0 + B - 1 (B <= 32) of tensors whose time steps are ldb = B_total rows
  * apart.  Every pointer (gx / y / gates / cell / dy / dgx and lens) is passed ALREADY OFFSET to row b0; a caller walks the batch in
- * slices of 32, one launch each, back to back (ops.LSTMSeqFn: 2 x 1.8 us per step at B 64 against 5-6 us for the launch-per-step
+ * slices of 32, one launch each, back to back (ops.LSTMSeqFn: 2 x 1.8 us per step at B 64 against 6.8 us at B 48 for the launch-per-step
  * kernels).  No image output (ft_bf16_image_rows on the fp32 dgx).  (ABI 12) */
 int ft_lstm_persist_fwd_rows(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
                              float* gates, float* cell, void* work, int32_t* status, int T, int B, int ldb, int H, int ng, void* stream);
