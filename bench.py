@@ -864,11 +864,17 @@ def main():
                 res["roofline"]["cumulative_attention"] = {"error": repr(e)}
         try:
             from flowtron_amd import ops as _ops
-            if _ops.lstm_persist_groups(args.batch, MODEL_CONFIG["n_hidden"], False, mode, torch.device("cuda", torch.cuda.current_device())):
-                # dominant kernels of the step: the persistent recurrences, six launches each per step (3 LSTMs x 2 flows)
-                dom, second = persist_roofline(args.batch, MODEL_CONFIG["n_hidden"], T, batch_cpu["out_lens"], mode)
+            _dev = torch.device("cuda", torch.cuda.current_device())
+            _slices = _ops.lstm_persist_slices(args.batch, MODEL_CONFIG["n_hidden"], False, mode, _dev)
+            if _ops.lstm_persist_groups(args.batch, MODEL_CONFIG["n_hidden"], False, mode, _dev) or _slices:
+                # dominant kernels of the step: the persistent recurrences, six launches each per step (3 LSTMs x 2 flows) -- times the
+                # batch slices of 32 rows a wider batch is walked in (--batch > 32: the first slice is timed)
+                n_sl = len(_slices[1]) if _slices else 1
+                dom, second = persist_roofline(min(args.batch, 32), MODEL_CONFIG["n_hidden"], T, batch_cpu["out_lens"][:32], mode)
                 for blk in (dom, second):
-                    blk["share_of_step"] = round(6 * blk["us_per_launch"] * 1e-3 / res["ms_per_step"], 3)
+                    blk["share_of_step"] = round(6 * n_sl * blk["us_per_launch"] * 1e-3 / res["ms_per_step"], 3)
+                    if n_sl > 1:
+                        blk["launches_per_sequence"] = n_sl
                 if second["share_of_step"] > dom["share_of_step"]:       # dominant = the larger share of the step
                     dom, second = second, dom
                 res["roofline"]["dominant_kernel"], res["roofline"]["second_kernel"] = dom, second

@@ -995,12 +995,12 @@ _PERSIST_WIDE = _os.environ.get("FLOWTRON_LSTM_PERSIST_WIDE", "1") != "0"
 
 
 def lstm_persist_slices(B, H, reverse, mode, device=None):
-    """(transport code, [(b0, rows)]) for a batch wider than one persistent launch holds (32 < B <= 64, the widest batch the
-    launch-per-step kernels and the encoder's pair chain take -- the library's batch limit): the batch is walked in two slices of
+    """(transport code, [(b0, rows)]) for a batch wider than one persistent launch holds (B > 32): the batch is walked in slices of
     <= 32 rows, one persistent launch each (ft_lstm_persist_*_rows: 1.6-1.8 us per step and slice against 6.8 us per step of the
-    launch-per-step kernels at B = 48 -- the configs[1] step at B = 48: 47.9 against 89.6 ms, profiles/r05b_wide_batch.log);
+    launch-per-step kernels at B = 48 -- the configs[1] step at B = 48: 47.9 against 89.6 ms, profiles/r05b_wide_batch.log; those
+    kernels stop at B = 64, so beyond that this is also the only path that does not go through batch chunks, lstm_layer).
     None: one launch suffices, or the shape is not the persistent kernels'."""
-    if not _PERSIST_WIDE or B <= 32 or B > 64:
+    if not _PERSIST_WIDE or B <= 32:
         return None
     ng = lstm_persist_groups(32, H, reverse, mode, device)
     if not ng:
@@ -1040,7 +1040,7 @@ class LSTMSeqFn(torch.autograd.Function):
         ng = lstm_persist_groups(B, H, reverse, mode, gx.device)
         wide = None if ng else lstm_persist_slices(B, H, reverse, mode, gx.device)
         if wide:
-            # 32 < B <= 64: one persistent launch per slice of 32 rows, back to back (pointers offset to the slice's first row)
+            # B > 32: one persistent launch per slice of 32 rows, back to back (pointers offset to the slice's first row)
             code = _persist_fwd_code(wide[0])
             st = _persist_watch(gx.device)
             work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(32, H), device=gx.device, dtype=torch.uint8)
@@ -1153,6 +1153,13 @@ class LSTMSeqFn(torch.autograd.Function):
         return dgx, dW, None, None, None, None, None
 
 
+MAX_STEP_BATCH = 64          # batch rows the launch-per-step recurrences and the bidirectional pair chain take (csrc/lstm.hip)
+
+
+def batch_chunks(B, cap):
+    return [(b0, min(cap, B - b0)) for b0 in range(0, B, cap)]
+
+
 def lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=False, mode=None, xs_extra=None, rowmap=None, fill="", gate=None):
     """One LSTM layer over a padded sequence: input projection for all T*B rows (valid rows only with a RowMap) as one MFMA
     GEMM, then the sequential recurrence.  The recurrence kernels never use a padded frame's gx / dy row and write zeros to its
@@ -1174,7 +1181,14 @@ def lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=False, mode=None, xs_ext
         if gate is not None:
             gates = linear(xs, gate[0], gate[1], mode=mode)
     private = rowmap is not None and rowmap.T == T and rowmap.B == B and linear_uses_images(mode, T * B, w_ih.shape[0], xs)
-    h = LSTMSeqFn.apply(gx, w_hh, lens, reverse, mode, rowmap, private)
+    H = w_hh.shape[1]
+    if B > MAX_STEP_BATCH and not lstm_persist_slices(B, H, reverse, mode, gx.device):
+        # the launch-per-step kernels take at most 64 batch rows (the reference's nn.LSTM takes any, flowtron.py:654-655): the rows
+        # are independent, so the recurrence runs per batch chunk on contiguous copies and autograd splits the gradients again
+        h = torch.cat([LSTMSeqFn.apply(gx[:, b0:b0 + nb].contiguous(), w_hh, lens[b0:b0 + nb], reverse, mode, None, False)
+                       for b0, nb in batch_chunks(B, MAX_STEP_BATCH)], 1)
+    else:
+        h = LSTMSeqFn.apply(gx, w_hh, lens, reverse, mode, rowmap, private)
     return h if gate is None else (h, gates)
 
 
@@ -1248,6 +1262,11 @@ def bilstm_layer(x, lens, wf, wr, mode=None):
     T, B, _ = x.shape
     H = wf[1].shape[1]
     import os
+    if B > MAX_STEP_BATCH:
+        # wider than the recurrence kernels take: batch chunks (independent rows; 32 rows each where the persistent bidirectional
+        # kernels apply, else 64), concatenated again -- autograd splits the gradient
+        cap = 32 if bilstm_persist_ok(32, H, mode, x.device) else MAX_STEP_BATCH
+        return torch.cat([bilstm_layer(x[:, b0:b0 + nb], lens[b0:b0 + nb], wf, wr, mode) for b0, nb in batch_chunks(B, cap)], 1)
     if L.is16(mode) and os.environ.get("FLOWTRON_BILSTM", "1") != "0" and L.lib().ft_lstm_bidir_supported(B, H):
         gx_f = LinearFn.apply(wf[0], wf[2] + wf[3], L.ACT_NONE, mode, None, "", x)
         gx_r = LinearFn.apply(wr[0], wr[2] + wr[3], L.ACT_NONE, mode, None, "", x)

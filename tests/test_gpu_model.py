@@ -410,6 +410,65 @@ def test_full_config_invertibility_and_padding_invariance():
     assert mad(out3[3][0][1, :N, :Lt], out[3][0][0]) < 1e-5
 
 
+@pytest.mark.parametrize("mode,width,tol", [("f32", "small", 2e-5), ("bf16", "small", 2e-2), ("bf16", "full", 2e-2)])
+def test_batches_wider_than_the_recurrence_kernels_take(mode, width, tol):
+    """B = 80 (the reference's nn.LSTM takes any batch, flowtron.py:654-655, :505-512; the launch-per-step kernels and the encoder's
+    pair chain stop at 64, one persistent launch at 32): the recurrences run per batch chunk (ops.lstm_layer / bilstm_layer) or, at
+    the persistent kernels' geometry, as sliced persistent launches (ft_lstm_persist_*_rows).  The rows of a batch are independent,
+    so the first 40 utterances must come out as they do in a batch of their own: z, log_s, attention on valid frames, and every
+    gradient of the 80-utterance step equal to the sum of the two 40-utterance halves' (the loss is a sum over utterances once the
+    normaliser is taken out)."""
+    import flowtron
+    from oracle import synth
+    cfg = dict(synth.DEFAULT_MODEL_CONFIG if width == "full" else synth.SMALL_MODEL_CONFIG)
+    cfg["n_flows"] = 2
+    m, _ = build(cfg, 31, mode)
+    try:
+        B = 80
+        rs = np.random.RandomState(3)
+        out_lens = [int(v) for v in rs.randint(20, 61, size=B)]
+        in_lens = sorted((int(v) for v in rs.randint(5, 16, size=B)), reverse=True)
+        T, Lt = max(out_lens), max(in_lens)
+
+        def sub(lo, hi):                                        # the utterances lo .. hi - 1 as a batch of their own, padded to the same T / L
+            b = synth.make_batch(cfg, [T] + out_lens[lo:hi], [Lt] + in_lens[lo:hi], seed=50 + lo, with_prior=True)
+            return b
+
+        full = None
+        halves = [sub(0, 40), sub(40, 80)]
+        # one 80-utterance batch out of the two halves (each half carries a full-length dummy in front that pins T and L: dropped)
+        def cat(key, dim=0):
+            return torch.cat([h[key][1:] for h in halves], dim)
+        full = {k: cat(k) for k in ("mel", "speaker_ids", "text", "in_lens", "out_lens", "gate_target", "attn_prior")}
+        order = torch.argsort(full["in_lens"], descending=True, stable=True)      # data.py:200-202: sorted by text length
+        assert torch.equal(order, torch.arange(B))
+
+        def run(b):
+            for p in m.parameters():
+                p.grad = None
+            b = cuda_batch(b)
+            out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+            n = b["out_lens"].sum().float()
+            crit = flowtron.FlowtronLoss(1.0, False, True, False)
+            nll, gl, _ = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+            ((nll + gl) * n).backward()                          # un-normalised: a sum over utterances
+            torch.cuda.synchronize()
+            return out, {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+        out80, g80 = run(full)
+        outs, gs = zip(*[run({k: v[1:] for k, v in h.items()}) for h in halves])
+        for hi, (o, lo) in enumerate(zip(outs, (0, 40))):
+            for b in range(40):
+                t, l = out_lens[lo + b], in_lens[lo + b]
+                assert mad(out80[0][:t, lo + b], o[0][:t, b]) <= tol * 10, (hi, b)
+                assert mad(out80[3][0][lo + b, :t, :l], o[3][0][b, :t, :l]) <= tol, (hi, b)
+        for k in g80:
+            ref = gs[0][k] + gs[1][k]
+            assert float((g80[k] - ref).norm()) <= tol * 5 * float(ref.norm()) + 1e-6, (k, float((g80[k] - ref).norm() / (ref.norm() + 1e-30)))
+    finally:
+        os.environ["FLOWTRON_MFMA"] = "f32"
+
+
 def test_bf16_mode_close_to_fp32():
     """bf16 MFMA operands, fp32 accumulate/storage: NLL within 2e-2 relative of the fp32 path."""
     import flowtron
