@@ -287,7 +287,7 @@ def apply_gradient_allreduce(module):
                          starting earlier -- and four back-to-back bucket collectives would only pay four latencies.
       FLOWTRON_DP_OVERLAP=1 (on every rank)   one bucket per flow (~111 MB) plus encoder + embeddings; a bucket is handed to RCCL
                          the moment the last of its gradients has been accumulated (post-accumulate-grad hooks), under the
-                         remaining backward.  Meant for the launch-per-step kernels (FLOWTRON_LSTM_PERSIST=0, batches > 32,
+                         remaining backward.  Meant for the launch-per-step kernels (FLOWTRON_LSTM_PERSIST=0, fp32 mode,
                          H != 1024), whose launch chains leave most of the chip idle.
     Launch order inside a regime is a function of the autograd graph only (completion order of the buckets, then arena order
     for whatever was not launched by a hook), identical on all ranks.
