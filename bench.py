@@ -377,7 +377,7 @@ def handoff_hops():
         return {"same_xcd_hop_us": 0.2985, "cross_xcd_hop_us": 0.6432}
 
 
-PMC_PREFIXES = ("r05_pmc_", "r04_pmc_", "r03_pmc_", "r02_pmc_", "r01_pmc_lstm_")
+PMC_PREFIXES = ("r05b_pmc_", "r05_pmc_", "r04_pmc_", "r03_pmc_", "r02_pmc_", "r01_pmc_lstm_")
 
 
 def _pmc_file(prefix, counter_file):
@@ -408,7 +408,7 @@ def pmc_value(counter_file, kernel_substr, field, with_source=False):
         for k, v in d.items():
             if _pmc_key_matches(k, kernel_substr) and field in v:
                 val = round(_pmc_scalar(v[field]), 4)
-                return (val, prefix[:3]) if with_source else val
+                return (val, prefix.split("_pmc")[0]) if with_source else val
     return (None, None) if with_source else None
 
 
