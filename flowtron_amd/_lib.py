@@ -40,6 +40,10 @@ class GemmImgArgs(C.Structure):
                 ("split_work", _p), ("split_work_bytes", _sz)]
 
 
+class ImgDesc(C.Structure):
+    _fields_ = [("src", _p), ("ld", _l), ("rows", _l), ("cols", _l), ("dst", _p), ("kind", _i)]
+
+
 class CummAttnArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("text", "Q", "V", "w_key", "v", "w1", "b1", "w2", "b2", "in_lens", "ctx", "attn", "logprob",
                                   "cumm_all", "kproj_all", "work")] + [("work_bytes", _sz)] + [
@@ -75,6 +79,8 @@ SIGNATURES = {
     "ft_gemm_img": ([C.POINTER(GemmImgArgs), _p], _i),
     "ft_gemm_img_split_work_bytes": ([_i, _i, _i], _sz),
     "ft_bf16_image_split3": ([_p, _l, _l, _l, _p, _i, _p], _i),
+    "ft_bf16_image_table": ([C.POINTER(ImgDesc), _i, _p], _i),
+    "ft_bf16_image_table_f16": ([C.POINTER(ImgDesc), _i, _p], _i),
     "ft_bf16_image_split3_f16": ([_p, _l, _l, _l, _p, _i, _p], _i),
     "ft_rowmap_build": ([_p, _p, _p, _i, _i, _p], _i),
     "ft_bf16_image_rows": ([_p, _l, _l, _l, _p, _p, _p, _p, _p], _i),

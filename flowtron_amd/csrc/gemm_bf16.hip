@@ -45,15 +45,17 @@ __device__ __forceinline__ int mapped_rows(const int* rdev, int Rp, int& Rz) {
     return R;
 }
 
-// src(r,c) = src[r*sr + c*sc]; vec: sc == 1, 16-byte aligned rows
-__global__ __launch_bounds__(256) void img_rows_k(const float* __restrict__ src, long sr, long sc, int R, int Cc,
-                                                  unsigned short* __restrict__ dst, int Rp, int Cp, int vec,
-                                                  const int* __restrict__ rowmap, const int* __restrict__ rdev, long dld) {
+// src(r,c) = src[r*sr + c*sc]; vec: sc == 1, 16-byte aligned rows.  (first, stride): this thread's first chunk and the launch's
+// chunk stride -- the whole grid for img_rows_k, a block range of the descriptor-table launch for img_table_k
+__device__ __forceinline__ void img_rows_body(const float* __restrict__ src, long sr, long sc, int R, int Cc,
+                                              unsigned short* __restrict__ dst, int Rp, int Cp, int vec,
+                                              const int* __restrict__ rowmap, const int* __restrict__ rdev, long dld,
+                                              size_t first, size_t stride) {
     const int cq = Cp >> 3;
     int Rz = Rp;
     if (rdev) R = mapped_rows(rdev, Rp, Rz);
     const size_t total = (size_t)Rz * cq;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = first; i < total; i += stride) {
         const int ri = (int)(i / cq), c = (int)(i % cq) * 8;
         int r = ri;
         if (rowmap) r = ri < R ? rowmap[ri] : -1;
@@ -71,17 +73,23 @@ __global__ __launch_bounds__(256) void img_rows_k(const float* __restrict__ src,
         *reinterpret_cast<uint4*>(dst + (size_t)ri * dld + c) = pack8(v);
     }
 }
+__global__ __launch_bounds__(256) void img_rows_k(const float* __restrict__ src, long sr, long sc, int R, int Cc,
+                                                  unsigned short* __restrict__ dst, int Rp, int Cp, int vec,
+                                                  const int* __restrict__ rowmap, const int* __restrict__ rdev, long dld) {
+    img_rows_body(src, sr, sc, R, Cc, dst, Rp, Cp, vec, rowmap, rdev, dld, blockIdx.x * (size_t)blockDim.x + threadIdx.x,
+                  (size_t)gridDim.x * blockDim.x);
+}
 
 // Split image (ft_bf16_image_split3): x = hi + lo with hi = op16(x), lo = op16(x - hi) (the pair carries ~16 significand bits).  The
 // image is three column blocks of K: an ACTIVATION as [hi | lo | hi], a WEIGHT as [hi | hi | lo], so that ONE 16-bit GEMM over
 // 3 K columns yields x_hi w_hi + x_lo w_hi + x_hi w_lo = x w up to the dropped lo . lo term (2^-18): fp32-grade products at three
 // times a 16-bit GEMM's cost instead of the fp32 MFMA's sixteen.  Rows [R, Rp) and columns [3 K, Cp) are zero.  K % 8 == 0.
 // (Both correction terms are needed: with either one left out the encoder's worst gradient deviation reads 0.096 instead of 0.008.)
-__global__ __launch_bounds__(256) void img_split3_k(const float* __restrict__ src, long sr, int R, int K, unsigned short* __restrict__ dst,
-                                                    int Rp, int Cp, int weight) {
+__device__ __forceinline__ void img_split3_body(const float* __restrict__ src, long sr, int R, int K, unsigned short* __restrict__ dst,
+                                                int Rp, int Cp, int weight, size_t first, size_t stride) {
     const int kq = K >> 3, cq = Cp >> 3;
     const size_t total = (size_t)Rp * cq;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = first; i < total; i += stride) {
         const int r = (int)(i / cq), q = (int)(i % cq);
         uint4 out = make_uint4(0u, 0u, 0u, 0u);
         if (r < R && q < 3 * kq) {
@@ -101,6 +109,31 @@ __global__ __launch_bounds__(256) void img_split3_k(const float* __restrict__ sr
         }
         *reinterpret_cast<uint4*>(dst + (size_t)r * Cp + (size_t)q * 8) = out;
     }
+}
+__global__ __launch_bounds__(256) void img_split3_k(const float* __restrict__ src, long sr, int R, int K, unsigned short* __restrict__ dst,
+                                                    int Rp, int Cp, int weight) {
+    img_split3_body(src, sr, R, K, dst, Rp, Cp, weight, blockIdx.x * (size_t)blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+}
+
+// Descriptor table (ft_bf16_image_table): the plain and split WEIGHT images of one forward pass in ONE launch -- a training step
+// rounds 23 weight matrices (60 M parameters) afresh, each in a launch of 5-15 us for 1-5 us of work.  Workgroup ranges per image
+// (blk0), each range walks its image with the single-image kernels' own bodies.
+constexpr int IMG_TABLE_MAX = 32;
+struct ImgTable {
+    const float* src[IMG_TABLE_MAX];
+    unsigned short* dst[IMG_TABLE_MAX];
+    long sr[IMG_TABLE_MAX];
+    int R[IMG_TABLE_MAX], Cc[IMG_TABLE_MAX], Rp[IMG_TABLE_MAX], Cp[IMG_TABLE_MAX], kind[IMG_TABLE_MAX], vec[IMG_TABLE_MAX];
+    int blk0[IMG_TABLE_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void img_table_k(ImgTable t) {
+    int d = 0;
+    while (d + 1 < t.n && (int)blockIdx.x >= t.blk0[d + 1]) ++d;               // (uniform)
+    const size_t first = (size_t)((int)blockIdx.x - t.blk0[d]) * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)(t.blk0[d + 1] - t.blk0[d]) * blockDim.x;
+    if (t.kind[d] == 0) img_rows_body(t.src[d], t.sr[d], 1, t.R[d], t.Cc[d], t.dst[d], t.Rp[d], t.Cp[d], t.vec[d], nullptr, nullptr, (long)t.Cp[d], first, stride);
+    else img_split3_body(t.src[d], t.sr[d], t.R[d], t.Cc[d], t.dst[d], t.Rp[d], t.Cp[d], 1, first, stride);
 }
 
 // same image, plus the fp32 column sums of the SOURCE (bias gradients: the conversion pass reads the output gradient
@@ -989,6 +1022,33 @@ extern "C" int FT_OPNAME(ft_bf16_image)(const float* src, int64_t ld, int64_t ro
 }
 
 // dst: ft_bf16_image_bytes(rows, 3 * cols) bytes; row stride ceil256(3 * cols) elements
+// n (<= 32) weight images in one launch: kind 0 = ft_bf16_image(src, ld, rows, cols, dst), 1 = ft_bf16_image_split3(src, ld, rows, cols,
+// dst, weight = 1); descs is a HOST array
+extern "C" int FT_OPNAME(ft_bf16_image_table)(const ft_img_desc* descs, int n, void* stream) {
+    FT_CHECK_ARG(descs && n >= 1 && n <= IMG_TABLE_MAX);
+    ImgTable t{};
+    t.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const ft_img_desc& d = descs[i];
+        FT_CHECK_ARG(d.src && d.dst && d.rows >= 1 && d.cols >= 1 && d.ld >= d.cols && d.rows < (1ll << 31) - 256 && 3 * d.cols < (1ll << 31) - 256);
+        FT_CHECK_ARG(reinterpret_cast<uintptr_t>(d.dst) % 256 == 0 && (d.kind == 0 || (d.kind == 1 && d.cols % 8 == 0)));
+        t.src[i] = d.src; t.dst[i] = reinterpret_cast<unsigned short*>(d.dst); t.sr[i] = (long)d.ld;
+        t.R[i] = (int)d.rows; t.Cc[i] = (int)d.cols; t.kind[i] = d.kind;
+        t.Rp[i] = (int)up((size_t)d.rows + 32, 256);
+        t.Cp[i] = (int)up((size_t)(d.kind == 1 ? 3 * d.cols : d.cols), 256);
+        t.vec[i] = (reinterpret_cast<uintptr_t>(d.src) % 16 == 0 && d.ld % 4 == 0) ? 1 : 0;
+        const size_t chunks = (size_t)t.Rp[i] * (t.Cp[i] >> 3);
+        const int nb = (int)((chunks + 255) / 256 < 2048 ? (chunks + 255) / 256 : 2048);
+        t.blk0[i] = blocks;
+        blocks += nb;
+    }
+    t.blk0[n] = blocks;
+    hipLaunchKernelGGL(img_table_k, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+
 extern "C" int FT_OPNAME(ft_bf16_image_split3)(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, int weight, void* stream) {
     FT_CHECK_ARG(src && dst && rows >= 1 && cols >= 8 && cols % 8 == 0 && ld >= cols && rows < (1ll << 31) - 256 && 3 * cols < (1ll << 31) - 256);
     FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dst) % 256 == 0);

@@ -520,6 +520,13 @@ class Flowtron(nn.Module):
         """mel [B,M,T], speaker_ids [B], text [B,L] (sorted by in_lens desc), in_lens/out_lens [B],
         attn_prior [B,T,L] | None -> the reference's 8-tuple (flowtron.py:898-899)."""
         L.require_cuda(mel, text, in_lens, out_lens, attn_prior)
+        ops.weight_images_begin(self)                # (the weights this model's previous forward rounded: one launch at the first request)
+        try:
+            return self._forward(mel, speaker_ids, text, in_lens, out_lens, attn_prior)
+        finally:
+            ops.weight_images_end(self)
+
+    def _forward(self, mel, speaker_ids, text, in_lens, out_lens, attn_prior=None):
         enc, in32 = self._encode(speaker_ids, text, in_lens)
         out32 = ops.lens32(out_lens)
         x = mel.permute(2, 0, 1).contiguous().float()

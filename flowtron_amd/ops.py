@@ -145,6 +145,44 @@ class Bf16Image:
         return self
 
     @classmethod
+    def _blank(cls, rows, cols, mode, device):
+        self = cls.__new__(cls)
+        self.rows, self.cols, self.fmt, self.rowmap, self.colsum = int(rows), int(cols), mode, None, None
+        self.ld = (self.cols + 255) // 256 * 256
+        self.buf = torch.empty(L.lib().ft_bf16_image_bytes(self.rows, self.cols), device=device, dtype=torch.uint8)
+        return self
+
+    @classmethod
+    def of_weight(cls, W, mode, split=False):
+        """the (plain | split [hi | hi | lo]) image of a WEIGHT matrix.  Inside a Flowtron.forward (weight_images_begin) the images of
+        all weights the previous forward of that model asked for are rounded in ONE launch at the first request
+        (ft_bf16_image_table: 23 dispatches of 5-15 us -> 1) -- from the CURRENT values, every forward anew: nothing is cached across
+        steps (a weight changed through `.data` would not bump its version).  Outside, or for a weight not in the plan: one launch."""
+        w = _WIMG
+        key = (W.data_ptr(), tuple(W.shape), mode, bool(split))
+        if w["plan_next"] is not None:
+            w["plan_next"][key] = W
+        if w["armed"]:
+            w["armed"] = False
+            plan = [(k, t) for k, t in w["plan"].items() if t.is_cuda and t.device == W.device and t.dtype == torch.float32 and t.is_contiguous()]
+            for lo in range(0, len(plan), 32):
+                part = plan[lo:lo + 32]
+                by_fmt = {}
+                for k, t in part:
+                    by_fmt.setdefault(k[2], []).append((k, t))
+                for fmt, items in by_fmt.items():
+                    descs = (L.ImgDesc * len(items))()
+                    for i, (k, t) in enumerate(items):
+                        img = cls._blank(t.shape[0], (3 if k[3] else 1) * t.shape[1], fmt, t.device)
+                        descs[i] = L.ImgDesc(t.data_ptr(), int(t.stride(0)), int(t.shape[0]), int(t.shape[1]), img.buf.data_ptr(), 1 if k[3] else 0)
+                        w["cache"][k] = img
+                    L.check(L.op16("ft_bf16_image_table", fmt)(descs, len(items), L.stream()), "ft_bf16_image_table")
+        img = w["cache"].get(key)
+        if img is not None:
+            return img
+        return cls.split3(W, mode, True) if split else cls(W, mode=mode)
+
+    @classmethod
     def cat_rows(cls, xs2d, mode, rowmap):
         """ONE compact image of the column-wise concatenation [x_0 | x_1 | ..] of time-major activations (each [T*B, K_i] fp32,
         K_i % 8 == 0 except the last): a Linear over several inputs then runs as one GEMM with one K loop (flowtron.py:758-765
@@ -175,6 +213,29 @@ class Bf16Image:
         self.buf = torch.empty(L.lib().ft_bf16_image_bytes(self.rows, self.cols), device=device, dtype=torch.uint8)
         self.colsum = zeroed((self.cols,), device)
         return self
+
+
+# weight images of one forward pass in one launch (Bf16Image.of_weight): the plan = what the previous forward of the same model asked for
+_WIMG_ON = _os.environ.get("FLOWTRON_WEIGHT_TABLE", "1") != "0"
+_WIMG = {"plan": {}, "plan_next": None, "cache": {}, "armed": False, "plans": None}
+
+
+def weight_images_begin(model):
+    """called at the head of Flowtron.forward: arm the one-launch conversion of the weights this model's previous forward used"""
+    if not _WIMG_ON:
+        return
+    w = _WIMG
+    if w["plans"] is None:
+        w["plans"] = _weakref.WeakKeyDictionary()
+    w["plan"] = w["plans"].get(model, {})
+    w["plan_next"], w["cache"], w["armed"] = {}, {}, bool(w["plan"])
+
+
+def weight_images_end(model):
+    w = _WIMG
+    if w["plan_next"] is not None and w["plans"] is not None:
+        w["plans"][model] = w["plan_next"]
+    w["plan"], w["plan_next"], w["cache"], w["armed"] = {}, None, {}, False
 
 
 # images of activations are shared between every consumer of the SAME tensor (h_att feeds the query projection, the gate and
@@ -459,7 +520,7 @@ class LinearFn(torch.autograd.Function):
             x2d = xs[0].reshape(rows, Ktot)
             split_imgs = None
             if Ktot % 32 == 0 and images_apply(mode_dx, rows, N, Ktot):
-                xi, wi = Bf16Image.split3(x2d, mode_dx, False), Bf16Image.split3(W, mode_dx, True)
+                xi, wi = Bf16Image.split3(x2d, mode_dx, False), Bf16Image.of_weight(W, mode_dx, split=True)
                 # K = 3 Ktot over only (rows / 128) x (N / 128) output tiles (160 for the encoder: a sixth of the chip's workgroup slots,
                 # 240 k-steps each: 130 us): split-K fills the chip -- in its deterministic form (see _ENC_SPLITK)
                 gemm_img(xi, 0, xi.ptr(), wi, 0, wi.ptr(), y, rows, N, 3 * Ktot, N, bias=bias, splitk=_ENC_SPLITK)
@@ -477,7 +538,7 @@ class LinearFn(torch.autograd.Function):
         ctx.imgs = split_imgs if split_fwd else None
         ctx.cat = False
         if use_img:
-            w_img = Bf16Image(W, mode=mode)
+            w_img = Bf16Image.of_weight(W, mode)
             if len(xs) > 1 and rowmap is not None and _CAT_IMAGES:
                 # [x_0 | x_1] as ONE compact image: one K loop over K_0 + K_1 (the 256 x 256 x 64 kernel applies at K >= 1536), one
                 # weight-gradient GEMM -- instead of two K pieces accumulating through C (measured 259 + 316 us for the decoder
@@ -621,7 +682,7 @@ class LinearGateFn(torch.autograd.Function):
         rows = rowmap.T * rowmap.B
         y = torch.empty(xs[0].shape[:-1] + (N,), device=W.device, dtype=torch.float32)
         gate = torch.empty(xs[0].shape[:-1] + (1,), device=W.device, dtype=torch.float32)
-        w_img = Bf16Image(W, mode=mode)
+        w_img = Bf16Image.of_weight(W, mode)
         x_cat = Bf16Image.cat_rows([x.reshape(rows, x.shape[-1]) for x in xs], mode, rowmap)
         gemm_img(x_cat, 0, x_cat.ptr(), w_img, 0, w_img.ptr(), y, rowmap.cap, N, Ktot, N, bias=bias, rowmap=rowmap, compact=1)
         L.check(L.op16("ft_img_gemv_rows", mode)(L.ptr(x_cat.buf), x_cat.ld, Ktot, L.ptr(Wg), L.ptr(bg), L.ptr(gate), 1, L.ptr(rowmap.map),

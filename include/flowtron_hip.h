@@ -168,6 +168,12 @@ int ft_bf16_image_rows_act_bwd_acc_f16(const float* dy, int64_t ld, const float*
  * (measured round 5: fp32 forward products alone bring it to 0.008).  cols % 8 == 0. */
 int ft_bf16_image_split3(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, int weight, void* stream);
 int ft_bf16_image_split3_f16(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, int weight, void* stream);
+/* The weight images of one forward pass in ONE launch (ABI 12): descs = HOST array of n <= 32 descriptors, kind 0 = what
+ * ft_bf16_image(src, ld, rows, cols, dst) writes, kind 1 = ft_bf16_image_split3(src, ld, rows, cols, dst, weight = 1).  A training step
+ * rounds its 23 weight matrices afresh every iteration; one dispatch instead of 23 of 5-15 us each. */
+typedef struct { const float* src; int64_t ld; int64_t rows; int64_t cols; void* dst; int kind; } ft_img_desc;
+int ft_bf16_image_table(const ft_img_desc* descs, int n, void* stream);
+int ft_bf16_image_table_f16(const ft_img_desc* descs, int n, void* stream);
 /* Pack-by-length row map of a time-major [T][B][*] activation (flowtron.py:689-694 packs, here without a host sync): compact
  * rows are batch-major -- utterance b contributes rows (t, b), t < lens[b], then ONE separator: row (lens[b], b) when
  * lens[b] < T (the utterance's first padded frame, which stands for all of them: every padded frame of b holds the same
