@@ -40,6 +40,17 @@ class GemmImgArgs(C.Structure):
                 ("split_work", _p), ("split_work_bytes", _sz)]
 
 
+class LstmFwdRole(C.Structure):
+    _fields_ = [("gx", _p), ("lens", _p), ("y", _p), ("ldy", _l), ("gates", _p), ("cell", _p), ("wimg", _p), ("state_h", _p), ("state_c", _p),
+                ("B", C.c_int32), ("ldb", C.c_int32), ("t0", C.c_int32), ("t1", C.c_int32)]
+
+
+class LstmBwdRole(C.Structure):
+    _fields_ = [("dy", _p), ("ldy", _l), ("lens", _p), ("gates", _p), ("cell", _p), ("dgx", _p), ("wimg", _p),
+                ("dimg", _p), ("dimg_ld", _l), ("dimg_rows", _l), ("dbias", _p), ("state_da", _p), ("state_dc", _p),
+                ("B", C.c_int32), ("ldb", C.c_int32), ("t0", C.c_int32), ("t1", C.c_int32), ("carry_in", C.c_int32)]
+
+
 class ImgDesc(C.Structure):
     _fields_ = [("src", _p), ("ld", _l), ("rows", _l), ("cols", _l), ("dst", _p), ("kind", _i)]
 
@@ -111,6 +122,14 @@ SIGNATURES = {
     "ft_bilstm_persist_fwd": ([_p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "ft_bilstm_persist_bwd": ([_p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "ft_lstm_persist_bwd_img": ([_p, _l, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _l, _l, _p, _p], _i),
+    "ft_lstm_roles_ctx_bytes": ([], _sz),
+    "ft_lstm_roles_wimg_bytes": ([_i], _sz),
+    "ft_lstm_roles_ctx_init": ([_p, _p], _i),
+    "ft_lstm_roles_debug_prof": ([_p], _i),
+    "ft_lstm_roles_prepare_fwd": ([_p, _p, _i, _p], _i),
+    "ft_lstm_roles_prepare_bwd": ([_p, _p, _i, _p], _i),
+    "ft_lstm_roles_fwd": ([C.POINTER(LstmFwdRole), _i, _i, _i, _p, _i, _p, _i, _p], _i),
+    "ft_lstm_roles_bwd": ([C.POINTER(LstmBwdRole), _i, _i, _i, _p, _i, _p, _i, _p], _i),
     "ft_lstm_persist_fwd_rows": ([_p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "ft_lstm_persist_bwd_rows": ([_p, _l, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "ft_lstm2_supported": ([_i, _i], _i),
@@ -162,7 +181,7 @@ SIGNATURES = {
 
 # fp16-operand twins (include/flowtron_hip.h, end): same signatures, suffix _f16
 OP16_TWINS = ("ft_gemm", "ft_bf16_image", "ft_bf16_image_colsum", "ft_bf16_image_colsum_acc", "ft_bf16_image_rows_acc", "ft_bf16_image_rows_act_bwd_acc", "ft_gemm_img", "ft_bf16_image_rows", "ft_bf16_image_rows_into", "ft_bf16_image_rows_act_bwd", "ft_img_gemv_rows", "ft_img_gemv_rows_bwd", "ft_lstm_seq_fwd", "ft_lstm_seq_bwd",
-              "ft_lstm_persist_fwd", "ft_lstm_persist_bwd", "ft_lstm_persist_bwd_img", "ft_lstm_persist_fwd_rows", "ft_lstm_persist_bwd_rows", "ft_lstm2_seq_fwd", "ft_lstm2_seq_bwd",
+              "ft_lstm_persist_fwd", "ft_lstm_persist_bwd", "ft_lstm_persist_bwd_img", "ft_lstm_persist_fwd_rows", "ft_lstm_persist_bwd_rows", "ft_lstm_roles_prepare_fwd", "ft_lstm_roles_prepare_bwd", "ft_lstm_roles_fwd", "ft_lstm_roles_bwd", "ft_lstm2_seq_fwd", "ft_lstm2_seq_bwd",
               "ft_lstm_bidir_seq_fwd", "ft_lstm_bidir_seq_bwd", "ft_bilstm_persist_fwd", "ft_bilstm_persist_bwd")
 for _n in OP16_TWINS:
     SIGNATURES[_n + "_f16"] = SIGNATURES[_n]
@@ -183,7 +202,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argt
             fn.restype = rest
-        if l.ft_abi_version() != 12:
+        if l.ft_abi_version() != 13:
             raise RuntimeError("libflowtron_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -36,7 +36,7 @@ def _digest(paths) -> str:
 
 
 # the operand-typed files are compiled twice: bf16 operands (default) and fp16 operands (-DFT_OPFMT=1, entries suffixed _f16)
-OP16_SOURCES = ("gemm.hip", "gemm_bf16.hip", "lstm.hip", "lstm2.hip", "lstm_persist.hip", "bilstm_persist.hip", "cumm_fused.hip")
+OP16_SOURCES = ("gemm.hip", "gemm_bf16.hip", "lstm.hip", "lstm2.hip", "lstm_persist.hip", "lstm_roles.hip", "bilstm_persist.hip", "cumm_fused.hip")
 
 
 def sources():

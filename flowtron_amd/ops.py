@@ -1084,6 +1084,72 @@ def bilstm_persist_ok(B, H, mode, device):
     return bool(st.usable)
 
 
+# ---- round 6: rows per XCD group / time windows / two roles per launch (csrc/lstm_roles.hip) ------------------------------------
+class RolesCtx:
+    """Launch context of the ft_lstm_roles_* kernels on one device: hand-off sets + census counters (initialised once) and the
+    launch counters of the two kernel kinds (a launch works in set phase & 1 and presets the other one for its successor)."""
+
+    def __init__(self, device):
+        self.buf = torch.empty(L.lib().ft_lstm_roles_ctx_bytes(), device=device, dtype=torch.uint8)
+        L.check(L.lib().ft_lstm_roles_ctx_init(L.ptr(self.buf), L.stream()), "ft_lstm_roles_ctx_init")
+        self.phase = [0, 0]          # forward, backward
+        self.reset_rows = 8          # the largest R any later launch of a kind may use (roles_reset_rows)
+
+
+_ROLES_CTX = {}
+
+
+def roles_ctx(device):
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    c = _ROLES_CTX.get(device)
+    if c is None:
+        c = _ROLES_CTX[device] = RolesCtx(device)
+    return c
+
+
+def roles_wimg(w_hh, mode, backward):
+    """MFMA fragment image of W_hh for the roles kernels (forward: gate-adjacent tiles; backward: the reduce-scatter layout)."""
+    img = torch.empty(L.lib().ft_lstm_roles_wimg_bytes(w_hh.shape[1]), device=w_hh.device, dtype=torch.uint8)
+    fn = L.op16("ft_lstm_roles_prepare_bwd" if backward else "ft_lstm_roles_prepare_fwd", mode)
+    L.check(fn(L.ptr(_c(w_hh)), L.ptr(img), w_hh.shape[1], L.stream()), "ft_lstm_roles_prepare")
+    return img
+
+
+def fwd_role(gx, lens, y, gates, cell, wimg, t0=0, t1=None, state=None, B=None):
+    T, LB = gx.shape[0], gx.shape[1]
+    return L.LstmFwdRole(L.ptr(gx), L.ptr(lens), L.ptr(y), y.stride(1), L.ptr(gates), L.ptr(cell), L.ptr(wimg),
+                         L.ptr(state[0]) if state is not None else None, L.ptr(state[1]) if state is not None else None,
+                         LB if B is None else B, LB, t0, T if t1 is None else t1)
+
+
+def bwd_role(dy, lens, gates, cell, dgx, wimg, t0=0, t1=None, state=None, carry_in=False, dimg=None, B=None):
+    T, LB = gates.shape[0], gates.shape[1]
+    return L.LstmBwdRole(L.ptr(dy), dy.stride(1), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx), L.ptr(wimg),
+                         L.ptr(dimg.buf) if dimg is not None else None, dimg.ld if dimg is not None else 0,
+                         dimg.buf.numel() // (2 * dimg.ld) if dimg is not None else 0, L.ptr(dimg.colsum) if dimg is not None else None,
+                         L.ptr(state[0]) if state is not None else None, L.ptr(state[1]) if state is not None else None,
+                         LB if B is None else B, LB, t0, T if t1 is None else t1, int(bool(carry_in)))
+
+
+def roles_launch(roles, R, mode, device, backward=False, H=1024):
+    """one launch of lstm_roles_fwd_k / _bwd_k: `roles` = one or two role structs; R rows per XCD group"""
+    c = roles_ctx(device)
+    if R > c.reset_rows:
+        # wider groups than any launch on this context has preset for: start over with the sets preset for R rows (rare: the first
+        # batch wider than 64 on a device)
+        L.check(L.lib().ft_lstm_roles_ctx_init(L.ptr(c.buf), L.stream()), "ft_lstm_roles_ctx_init")
+        c.phase, c.reset_rows = [0, 0], R
+    st = _persist_watch(c.buf.device)
+    k = 1 if backward else 0
+    arr = ((L.LstmBwdRole if backward else L.LstmFwdRole) * len(roles))(*roles)
+    fn = L.op16("ft_lstm_roles_bwd" if backward else "ft_lstm_roles_fwd", mode)
+    L.check(fn(arr, len(roles), R, c.reset_rows, L.ptr(c.buf), c.phase[k], L.ptr(st.status), H, L.stream()), "ft_lstm_roles")
+    c.phase[k] += 1
+    _persist_arm(st)
+
+
 class LSTMSeqFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gx, w_hh, lens, reverse, mode, rowmap=None, gx_private=False):

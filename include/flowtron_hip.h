@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 12
+#define FT_ABI_VERSION 13
 
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1, FT_F16 = 2 };
@@ -299,6 +299,45 @@ int ft_lstm_persist_fwd_rows(const float* gx, const float* w_hh, const int32_t* 
                              float* gates, float* cell, void* work, int32_t* status, int T, int B, int ldb, int H, int ng, void* stream);
 int ft_lstm_persist_bwd_rows(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
                              const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int ldb, int H, int ng, void* stream);
+
+/* Round 6 (ABI 13): the persistent recurrences with the geometry as PARAMETERS (csrc/lstm_roles.hip) -- rows per XCD group R = 4 | 8 | 16
+ * (an MFMA tile has 16 rows; the kernels above use 4), a time WINDOW [t0, t1) per launch with the recurrent state carried through
+ * small fp32 buffers, and up to two ROLES (independent recurrences) per launch, role i on XCD groups i * 8 / n_roles .. (batch rows
+ * <= (8 / n_roles) * R each).  What they replace is still cuDNN's nn.LSTM over packed sequences (flowtron.py:654-655, 689-694, 760-765):
+ *   - a batch of 64 / 128 as ONE launch per sequence (n_roles 1, R 8 / 16) instead of 2 / 4 sliced launches;
+ *   - the two decoder layers of a flow CONCURRENTLY, layer 1 one time chunk behind layer 0 (backward: the other way round), the chunk's
+ *     input projection GEMM between the launches (flowtron_amd/ops.py DecoderPairFn).
+ * wimg: MFMA fragment image of W_hh (ft_lstm_roles_wimg_bytes, 256-byte aligned), made once per pass by ft_lstm_roles_prepare_fwd / _bwd
+ * (the backward image is the reduce-scatter layout).  ctx: launch context of ft_lstm_roles_ctx_bytes() bytes, 256-byte aligned,
+ * initialised ONCE by ft_lstm_roles_ctx_init and then owned by the launches: `phase` = number of earlier launches of the same kind
+ * (forward / backward) on this ctx -- a launch works in hand-off set phase & 1 and presets set (phase + 1) & 1 for `reset_rows` (>= the R
+ * of the next launch of its kind) while it runs, so no preset dispatch precedes a launch.  Launches on one ctx must be serialised on
+ * one stream.  `status` as for ft_lstm_persist_*.  Forward results are bit-identical to ft_lstm_seq_fwd for every R / windowing / role
+ * placement; backward to fp32 rounding (R = 4: bit-identical to ft_lstm_persist_bwd's reduce-scatter transport). */
+typedef struct {
+    const float* gx; const int32_t* lens; float* y; int64_t ldy; float* gates; float* cell;   /* as ft_lstm_seq_fwd; time steps ldb rows apart */
+    const void* wimg;
+    float* state_h; float* state_c;      /* [B][H] fp32: read when t0 > 0, written at the end of the window; NULL (both) for t0 == 0 without successor */
+    int32_t B, ldb, t0, t1;
+} ft_lstm_fwd_role;
+typedef struct {
+    const float* dy; int64_t ldy; const int32_t* lens; const float* gates; const float* cell;
+    float* dgx;                          /* fp32 dgates rows [T][ldb][4H], or NULL when only the image is wanted */
+    const void* wimg;
+    void* dimg; int64_t dimg_ld; int64_t dimg_rows; float* dbias;    /* optional: as ft_lstm_persist_bwd_img (needs ldb == B) */
+    float* state_da; float* state_dc;    /* [B][4H], [B][H] fp32: read when carry_in, written at the end of the window */
+    int32_t B, ldb, t0, t1, carry_in;    /* carry_in: the window [t1, ..) has run before and left its state */
+} ft_lstm_bwd_role;
+size_t ft_lstm_roles_ctx_bytes(void);
+size_t ft_lstm_roles_wimg_bytes(int H);
+int ft_lstm_roles_ctx_init(void* ctx, void* stream);
+int ft_lstm_roles_debug_prof(void* dev_buf);        /* as ft_lstm_persist_debug_prof, for the kernels below */
+int ft_lstm_roles_prepare_fwd(const float* w_hh, void* wimg, int H, void* stream);
+int ft_lstm_roles_prepare_bwd(const float* w_hh, void* wimg, int H, void* stream);
+int ft_lstm_roles_fwd(const ft_lstm_fwd_role* roles, int n_roles, int rows_per_group, int reset_rows, void* ctx, int phase,
+                      int32_t* status, int H, void* stream);
+int ft_lstm_roles_bwd(const ft_lstm_bwd_role* roles, int n_roles, int rows_per_group, int reset_rows, void* ctx, int phase,
+                      int32_t* status, int H, void* stream);
 
 /* Two stacked layers (the decoder nn.LSTM(.., num_layers=2), flowtron.py:654, :760-765) as ONE launch chain: layer 1 at
  * time t-1 and layer 0 at time t are two workgroup groups of the same launch, and layer 1's input projection
@@ -606,6 +645,12 @@ int ft_lstm_persist_bwd_f16(const float* dy, int64_t ldy, const float* w_hh, con
 int ft_lstm_persist_bwd_img_f16(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
                             const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
                             void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream);
+int ft_lstm_roles_prepare_fwd_f16(const float* w_hh, void* wimg, int H, void* stream);
+int ft_lstm_roles_prepare_bwd_f16(const float* w_hh, void* wimg, int H, void* stream);
+int ft_lstm_roles_fwd_f16(const ft_lstm_fwd_role* roles, int n_roles, int rows_per_group, int reset_rows, void* ctx, int phase,
+                          int32_t* status, int H, void* stream);
+int ft_lstm_roles_bwd_f16(const ft_lstm_bwd_role* roles, int n_roles, int rows_per_group, int reset_rows, void* ctx, int phase,
+                          int32_t* status, int H, void* stream);
 int ft_lstm_persist_fwd_rows_f16(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
                                  float* gates, float* cell, void* work, int32_t* status, int T, int B, int ldb, int H, int ng, void* stream);
 int ft_lstm_persist_bwd_rows_f16(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
