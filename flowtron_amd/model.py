@@ -269,6 +269,13 @@ class AR_Step(nn.Module):
             for l in range(1, self.n_lstm_layers):
                 h = ops.lstm_layer(h, out_lens32, getattr(p, "weight_ih_l%d" % l), getattr(p, "weight_hh_l%d" % l),
                                    getattr(p, "bias_ih_l%d" % l), getattr(p, "bias_hh_l%d" % l), mode=mode, rowmap=rm)
+        elif persist and rm is not None and ops.decoder_pair_chunks(B, p.weight_hh_l0.shape[1], mode, mel.device, T):
+            # both layers CONCURRENTLY on four XCDs each, layer 1 one time chunk behind layer 0, the chunk's input projection between
+            # the launches (ops.DecoderPairFn, csrc/lstm_roles.hip): the pair's chain of 2 T dependent steps becomes (1 + 1/n) T
+            h, gates_f = ops.decoder_pair(h_att, out_lens32, p, mode, [ctx], rm, "dx", (g.weight, g.bias) if fuse_gate else None,
+                                          ops.decoder_pair_chunks(B, p.weight_hh_l0.shape[1], mode, mel.device, T))
+            if fuse_gate:
+                gates = gates_f
         elif persist:
             # two persistent single-layer recurrences (csrc/lstm_persist.hip, ~2 us per step each) with layer 1's input
             # projection as one batched GEMM between them: faster than the two-layer wavefront launch chain (~8 us per step)

@@ -1117,20 +1117,25 @@ def roles_wimg(w_hh, mode, backward):
     return img
 
 
-def fwd_role(gx, lens, y, gates, cell, wimg, t0=0, t1=None, state=None, B=None):
-    T, LB = gx.shape[0], gx.shape[1]
-    return L.LstmFwdRole(L.ptr(gx), L.ptr(lens), L.ptr(y), y.stride(1), L.ptr(gates), L.ptr(cell), L.ptr(wimg),
-                         L.ptr(state[0]) if state is not None else None, L.ptr(state[1]) if state is not None else None,
-                         LB if B is None else B, LB, t0, T if t1 is None else t1)
+def fwd_role(gx, lens, y, gates, cell, wimg, t0=0, t1=None, state=None, b0=0, nb=None):
+    """one forward recurrence of a roles launch over the batch rows [b0, b0 + nb) of time-major tensors, window [t0, t1)"""
+    T, LB, H = gx.shape[0], gx.shape[1], y.shape[2]
+    nb = LB - b0 if nb is None else nb
+    return L.LstmFwdRole(gx.data_ptr() + 16 * H * b0, lens.data_ptr() + 4 * b0, y.data_ptr() + 4 * y.stride(1) * b0, y.stride(1),
+                         gates.data_ptr() + 16 * H * b0 if gates is not None else None, cell.data_ptr() + 4 * H * b0 if cell is not None else None,
+                         L.ptr(wimg), L.ptr(state[0]) if state is not None else None, L.ptr(state[1]) if state is not None else None,
+                         nb, LB, t0, T if t1 is None else t1)
 
 
-def bwd_role(dy, lens, gates, cell, dgx, wimg, t0=0, t1=None, state=None, carry_in=False, dimg=None, B=None):
-    T, LB = gates.shape[0], gates.shape[1]
-    return L.LstmBwdRole(L.ptr(dy), dy.stride(1), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx), L.ptr(wimg),
+def bwd_role(dy, lens, gates, cell, dgx, wimg, t0=0, t1=None, state=None, carry_in=False, dimg=None, b0=0, nb=None):
+    T, LB, H = gates.shape[0], gates.shape[1], cell.shape[2]
+    nb = LB - b0 if nb is None else nb
+    return L.LstmBwdRole(dy.data_ptr() + 4 * dy.stride(1) * b0, dy.stride(1), lens.data_ptr() + 4 * b0, gates.data_ptr() + 16 * H * b0,
+                         cell.data_ptr() + 4 * H * b0, dgx.data_ptr() + 16 * H * b0 if dgx is not None else None, L.ptr(wimg),
                          L.ptr(dimg.buf) if dimg is not None else None, dimg.ld if dimg is not None else 0,
                          dimg.buf.numel() // (2 * dimg.ld) if dimg is not None else 0, L.ptr(dimg.colsum) if dimg is not None else None,
                          L.ptr(state[0]) if state is not None else None, L.ptr(state[1]) if state is not None else None,
-                         LB if B is None else B, LB, t0, T if t1 is None else t1, int(bool(carry_in)))
+                         nb, LB, t0, T if t1 is None else t1, int(bool(carry_in)))
 
 
 def roles_launch(roles, R, mode, device, backward=False, H=1024):
@@ -1150,6 +1155,229 @@ def roles_launch(roles, R, mode, device, backward=False, H=1024):
     _persist_arm(st)
 
 
+_ROLES = _os.environ.get("FLOWTRON_LSTM_ROLES", "1") != "0"          # the R / window / role kernels (csrc/lstm_roles.hip) where they win
+
+
+def roles_plan(B, backward):
+    """[(first row, rows, rows per XCD group)] of the roles launches that cover a batch of B rows"""
+    cap = 64 if backward else 128
+    out = []
+    for b0 in range(0, B, cap):
+        nb = min(cap, B - b0)
+        out.append((b0, nb, 4 if nb <= 32 else 8 if nb <= 64 else 16))
+    return out
+
+
+_PAIR_CHUNKS_BWD = int(_os.environ.get("FLOWTRON_LSTM_PAIR_BWD", "0"))   # chunks of the pair's BACKWARD pipeline; 0 = sequential, -1 = as forward
+_PAIR_CHUNKS = int(_os.environ.get("FLOWTRON_LSTM_PAIR", "6"))       # time chunks of the decoder layer pair pipeline; 0 = one recurrence per launch
+
+
+def decoder_pair_chunks(B, H, mode, device, T):
+    """number of time chunks the two decoder layers are pipelined over (DecoderPairFn), or 0: the pair needs both recurrences on
+    R = 8 rows per XCD, four XCDs each (B <= 32), the persistent kernels' shape and a sequence long enough to chunk"""
+    if _PAIR_CHUNKS <= 0 or B > 32 or T < 4 * _PAIR_CHUNKS or not lstm_persist_groups(B, H, False, mode, device):
+        return 0
+    return _PAIR_CHUNKS
+
+
+def _chunk_edges(T, n):
+    return [(k * T + n // 2) // n for k in range(n + 1)]
+
+
+_EDGE_CACHE = {}
+
+
+def _chunk_rowmaps(lens, edges, B):
+    """per time chunk [e_k, e_k+1): the chunk as a padded batch of its own -- lengths clamp(len - e_k, 0, width) -- and its RowMap
+    (the edge vectors are made on the device once per (edges, device): no host-to-device copy in a step)"""
+    key = (tuple(edges), lens.device)
+    ev = _EDGE_CACHE.get(key)
+    if ev is None:
+        T, n = edges[-1], len(edges) - 1
+        k = torch.arange(n + 1, device=lens.device, dtype=torch.int64)
+        e = torch.div(k * T + n // 2, n, rounding_mode="floor").to(torch.int32)
+        if len(_EDGE_CACHE) > 64:
+            _EDGE_CACHE.clear()
+        ev = _EDGE_CACHE[key] = (e[:-1].contiguous(), (e[1:] - e[:-1]).contiguous())
+    lk = torch.minimum((lens[None, :] - ev[0][:, None]).clamp_(min=0), ev[1][:, None])
+    return [RowMap(lk[k], edges[k + 1] - edges[k], B) for k in range(len(edges) - 1)]
+
+
+class DecoderPairFn(torch.autograd.Function):
+    """Both decoder LSTM layers of a flow (nn.LSTM(.., num_layers=2), flowtron.py:654-655, 689-694) as ONE pipeline over n time chunks:
+    launch k runs layer 0 on chunk k (XCDs 0-3, 8 batch rows each) and layer 1 on chunk k - 1 (XCDs 4-7) CONCURRENTLY
+    (csrc/lstm_roles.hip: two roles per launch, carried state), and layer 1's input projection of chunk k -- a chip-filling GEMM
+    over the chunk's valid rows -- runs between launch k and launch k + 1.  Backward the other way round: layer 1 on chunk c, layer 0 on
+    chunk c + 1, the chunk's dX GEMM (dy0 = dgates1 W_ih1) in between.  The dependency chain of the pair is (1 + 1/n) T steps of the
+    8-row kernel instead of 2 T steps of the 4-row one; the arithmetic is that of two single launches (forward bit-identical)."""
+
+    @staticmethod
+    def forward(ctx, gx0, w_hh0, w_ih1, b_ih1, b_hh1, w_hh1, lens, mode, rowmap, gx_private, nchunks):
+        gx0, w_hh0, w_ih1, w_hh1 = _c(gx0), _c(w_hh0), _c(w_ih1), _c(w_hh1)
+        L.require_cuda(gx0, w_hh0, w_ih1, w_hh1, lens)
+        T, B, H4 = gx0.shape
+        H = H4 // 4
+        dev = gx0.device
+        f = dict(device=dev, dtype=torch.float32)
+        y0, g0, c0 = torch.empty(T, B, H, **f), torch.empty(T, B, H4, **f), torch.empty(T, B, H, **f)
+        y1, g1, c1 = torch.empty(T, B, H, **f), torch.empty(T, B, H4, **f), torch.empty(T, B, H, **f)
+        gx1 = torch.empty(T, B, H4, **f)
+        st0, st1 = torch.zeros(2, B, H, **f), torch.zeros(2, B, H, **f)
+        wi0, wi1 = roles_wimg(w_hh0, mode, False), roles_wimg(w_hh1, mode, False)
+        w_img = Bf16Image.of_weight(w_ih1, mode)
+        b1 = b_ih1 + b_hh1
+        edges = _chunk_edges(T, nchunks)
+        rms = _chunk_rowmaps(lens, edges, B)
+        for k in range(nchunks + 1):
+            roles = []
+            if k < nchunks:
+                roles.append(fwd_role(gx0, lens, y0, g0, c0, wi0, edges[k], edges[k + 1], st0))
+            if k > 0:
+                roles.append(fwd_role(gx1, lens, y1, g1, c1, wi1, edges[k - 1], edges[k], st1))
+            roles_launch(roles, 8 if len(roles) == 2 else 4, mode, dev)
+            if k < nchunks:
+                # layer 1's input projection of chunk k over its valid rows, scattered into gx1[e_k : e_k+1]
+                a, b = edges[k], edges[k + 1]
+                x_img = Bf16Image(y0[a:b].reshape((b - a) * B, H), mode=mode, rowmap=rms[k])
+                gemm_img(x_img, 0, x_img.ptr(), w_img, 0, w_img.ptr(), gx1[a:b], rms[k].cap, H4, H, H4, bias=b1, rowmap=rms[k], compact=1)
+        ctx.save_for_backward(w_hh0, w_ih1, w_hh1, lens, y0, g0, c0, y1, g1, c1)
+        ctx.mode, ctx.rowmap, ctx.gx_private, ctx.nchunks = mode, rowmap, bool(gx_private), nchunks
+        ctx.chunk_maps, ctx.w_img = (edges, rms), w_img
+        return y1
+
+    @staticmethod
+    def backward(ctx, dy1):
+        w_hh0, w_ih1, w_hh1, lens, y0, g0, c0, y1, g1, c1 = ctx.saved_tensors
+        dy1 = _c(dy1)
+        T, B, H = y1.shape
+        H4, mode, rm, n = 4 * H, ctx.mode, ctx.rowmap, ctx.nchunks
+        dev = dy1.device
+        f = dict(device=dev, dtype=torch.float32)
+        edges, rms = ctx.chunk_maps
+        dgx1 = torch.empty(T, B, H4, **f)
+        dy0 = torch.empty(T, B, H, **f)
+        # layer 0's dgates leave as the compact 16-bit image alone where the only consumer is the input projection's backward
+        img_ok = rm is not None and _PERSIST_IMG != "0" and images_apply(mode, H4, H, (T - 1) * B) and (ctx.gx_private or _PERSIST_IMG == "both")
+        img_only = img_ok and _PERSIST_IMG != "both" and not torch.is_anomaly_enabled()
+        d_img0 = Bf16Image.empty_rows(H4, rm, mode, dev) if img_ok else None
+        dgx0 = None if img_only else torch.empty(T, B, H4, **f)
+        sb1 = (torch.zeros(B, H4, **f), torch.zeros(B, H, **f))
+        sb0 = (torch.zeros(B, H4, **f), torch.zeros(B, H, **f))
+        w_img = ctx.w_img
+        ctx.w_img = None
+        nb = _PAIR_CHUNKS_BWD if _PAIR_CHUNKS_BWD >= 0 else n
+        if nb == 0 and rm is not None and img_ok and ctx.needs_input_grad[1] and ctx.needs_input_grad[5]:
+            return DecoderPairFn._backward_sequential(ctx, dy1, w_img, img_only)
+        if nb != n and nb > 0:
+            n = nb
+            edges = _chunk_edges(T, n)
+            rms = _chunk_rowmaps(lens, edges, B)
+        wb0, wb1 = roles_wimg(w_hh0, mode, True), roles_wimg(w_hh1, mode, True)
+        for j in range(n + 1):
+            c = n - 1 - j                                        # layer 1's chunk in this launch; layer 0 runs chunk c + 1
+            roles = []
+            if j < n:
+                roles.append(bwd_role(dy1, lens, g1, c1, dgx1, wb1, edges[c], edges[c + 1], sb1, carry_in=c < n - 1))
+            if j > 0:
+                roles.append(bwd_role(dy0, lens, g0, c0, dgx0, wb0, edges[c + 1], edges[c + 2], sb0, carry_in=c + 1 < n - 1, dimg=d_img0))
+            roles_launch(roles, 8 if len(roles) == 2 else 4, mode, dev, backward=True)
+            if j < n:
+                # dy0 of chunk c = dgates1 W_ih1 over the chunk's valid rows
+                a, b = edges[c], edges[c + 1]
+                d_img = Bf16Image(dgx1[a:b].reshape((b - a) * B, H4), mode=mode, rowmap=rms[c])
+                gemm_img(d_img, 0, d_img.ptr(), w_img, 1, w_img.ptr(), dy0[a:b], rms[c].cap, H, H4, H, rowmap=rms[c], compact=1)
+        # weight / bias gradients over the whole sequence (compact rows; the one-step shift of dW_hh = one compact row)
+        dW_hh0 = dW_ih1 = dW_hh1 = db1 = None
+        need = ctx.needs_input_grad
+        compact_ok = rm is not None and T > 1 and images_apply(mode, H4, H, (T - 1) * B)
+        if need[1] or need[2] or need[3] or need[4] or need[5]:
+            if compact_ok:
+                d_img1 = Bf16Image(dgx1.reshape(T * B, H4), colsum=True, mode=mode, rowmap=rm)
+                db1 = d_img1.colsum
+                y0_img, y1_img = shared_image(y0, T * B, H, mode, rm), shared_image(y1, T * B, H, mode, rm)
+                if need[5]:
+                    dW_hh1 = weight_grad_out(w_hh1)
+                    gemm_img(d_img1, 1, d_img1.ptr(1), y1_img, 1, y1_img.ptr(0), dW_hh1, H4, H, rm.cap, H, beta=1.0, splitk=True, rowmap=rm, compact=2, k_shift=1)
+                if need[2]:
+                    dW_ih1 = weight_grad_out(w_ih1)
+                    gemm_img(d_img1, 1, d_img1.ptr(), y0_img, 1, y0_img.ptr(), dW_ih1, H4, H, rm.cap, H, beta=1.0, splitk=True, rowmap=rm, compact=2)
+                if need[1]:
+                    d0 = d_img0 if d_img0 is not None else Bf16Image(dgx0.reshape(T * B, H4), colsum=True, mode=mode, rowmap=rm)
+                    dW_hh0 = weight_grad_out(w_hh0)
+                    gemm_img(d0, 1, d0.ptr(1), y0_img, 1, y0_img.ptr(0), dW_hh0, H4, H, rm.cap, H, beta=1.0, splitk=True, rowmap=rm, compact=2, k_shift=1)
+                    d_img0 = d0
+            else:
+                rows = (T - 1) * B
+                db1 = colsum(dgx1, T * B, H4, H4)
+                dW_hh1, dW_ih1, dW_hh0 = torch.zeros_like(w_hh1), torch.zeros_like(w_ih1), torch.zeros_like(w_hh0)
+                if T > 1:
+                    gemm_raw(dgx1[1:], y1[:-1], dW_hh1, H4, H, rows, 1, H4, H, 1, H, mode=mode, splitk=True)
+                    gemm_raw(dgx0[1:], y0[:-1], dW_hh0, H4, H, rows, 1, H4, H, 1, H, mode=mode, splitk=True)
+                gemm_raw(dgx1, y0, dW_ih1, H4, H, T * B, 1, H4, H, 1, H, mode=mode, splitk=True)
+        if img_only:
+            dgx0 = image_only_gradient((T, B, H4), dev)
+            _handoff_put_image_only(dgx0, d_img0)
+        elif d_img0 is not None:
+            _handoff_put(dgx0, d_img0)
+        return dgx0, dW_hh0, dW_ih1, db1, db1, dW_hh1, None, None, None, None, None
+
+
+def _pair_backward_sequential(ctx, dy1, w_img, img_only):
+    """DecoderPairFn.backward without the pipeline: layer 1's recurrence, ONE dX GEMM over all valid rows, layer 0's recurrence -- the
+    round-5 sequence (4-row kernels, dgates of both layers as compact images only).  The backward kernel at 8 rows per group and two
+    roles runs 2.55 us per step against 2 x 1.62, and the chunked dX GEMMs (N = 1024, K = 4096: 224 tiles of a chunk) cost 3 x the one
+    GEMM -- measured a loss of 0.25 ms per flow (profiles/r06_pair_pipeline.log); the forward pipeline stands on its own."""
+    w_hh0, w_ih1, w_hh1, lens, y0, g0, c0, y1, g1, c1 = ctx.saved_tensors
+    T, B, H = y1.shape
+    H4, mode, rm = 4 * H, ctx.mode, ctx.rowmap
+    dev = dy1.device
+    st = _persist_watch(dev)
+    code = _persist_bwd_code(int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "1")) or 1)
+    work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=dev, dtype=torch.uint8)
+
+    def recurrence(dy, g, c, w_hh):
+        img = Bf16Image.empty_rows(H4, rm, mode, dev)
+        L.check(L.op16("ft_lstm_persist_bwd_img", mode)(L.ptr(dy), H, L.ptr(w_hh), L.ptr(lens), L.ptr(g), L.ptr(c), None, L.ptr(work), L.ptr(st.status),
+                                                        T, B, H, code, L.ptr(img.buf), img.ld, img.buf.numel() // (2 * img.ld), L.ptr(img.colsum), L.stream()),
+                "ft_lstm_persist_bwd_img")
+        _persist_arm(st)
+        return img
+
+    d_img1 = recurrence(dy1, g1, c1, w_hh1)
+    y0_img, y1_img = shared_image(y0, T * B, H, mode, rm), shared_image(y1, T * B, H, mode, rm)
+    dW_hh1, dW_ih1, dW_hh0 = weight_grad_out(w_hh1), weight_grad_out(w_ih1), weight_grad_out(w_hh0)
+    gemm_img(d_img1, 1, d_img1.ptr(1), y1_img, 1, y1_img.ptr(0), dW_hh1, H4, H, rm.cap, H, beta=1.0, splitk=True, rowmap=rm, compact=2, k_shift=1)
+    dy0 = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+    gemm_img(d_img1, 0, d_img1.ptr(), w_img, 1, w_img.ptr(), dy0, rm.cap, H, H4, H, rowmap=rm, compact=1)
+    gemm_img(d_img1, 1, d_img1.ptr(), y0_img, 1, y0_img.ptr(), dW_ih1, H4, H, rm.cap, H, beta=1.0, splitk=True, rowmap=rm, compact=2)
+    d_img0 = recurrence(dy0, g0, c0, w_hh0)
+    gemm_img(d_img0, 1, d_img0.ptr(1), y0_img, 1, y0_img.ptr(0), dW_hh0, H4, H, rm.cap, H, beta=1.0, splitk=True, rowmap=rm, compact=2, k_shift=1)
+    dgx0 = image_only_gradient((T, B, H4), dev)
+    _handoff_put_image_only(dgx0, d_img0)
+    db1 = d_img1.colsum
+    return dgx0, dW_hh0, dW_ih1, db1, db1, dW_hh1, None, None, None, None, None
+
+
+DecoderPairFn._backward_sequential = staticmethod(_pair_backward_sequential)
+
+
+def decoder_pair(x, lens, p, mode, xs_extra, rowmap, fill, gate, nchunks):
+    """the decoder nn.LSTM `p` (two layers) over [x ; xs_extra]: layer 0's input projection (with the gate layer riding on its image,
+    lstm_layer) + DecoderPairFn; returns (h, gates)"""
+    xs = [x] + list(xs_extra)
+    T, B = x.shape[0], x.shape[1]
+    gates = None
+    if gate is not None and linear_gate_fusable(mode, rowmap, xs, p.weight_ih_l0.shape[0]):
+        gx, gates = LinearGateFn.apply(p.weight_ih_l0, p.bias_ih_l0 + p.bias_hh_l0, gate[0], gate[1], mode, rowmap, fill, *xs)
+    else:
+        gx = LinearFn.apply(p.weight_ih_l0, p.bias_ih_l0 + p.bias_hh_l0, L.ACT_NONE, mode, rowmap, fill, *xs)
+        if gate is not None:
+            gates = linear(xs, gate[0], gate[1], mode=mode)
+    private = rowmap is not None and rowmap.T == T and rowmap.B == B and linear_uses_images(mode, T * B, p.weight_ih_l0.shape[0], xs)
+    h = DecoderPairFn.apply(gx, p.weight_hh_l0, p.weight_ih_l1, p.bias_ih_l1, p.bias_hh_l1, p.weight_hh_l1, lens, mode, rowmap, private, nchunks)
+    return h, gates
+
+
 class LSTMSeqFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gx, w_hh, lens, reverse, mode, rowmap=None, gx_private=False):
@@ -1166,7 +1394,15 @@ class LSTMSeqFn(torch.autograd.Function):
         cell = torch.empty(T, B, H, device=gx.device, dtype=torch.float32)
         ng = lstm_persist_groups(B, H, reverse, mode, gx.device)
         wide = None if ng else lstm_persist_slices(B, H, reverse, mode, gx.device)
-        if wide:
+        plan = roles_plan(B, False) if (ng or wide) and _ROLES else None
+        if plan:
+            # round 6 (csrc/lstm_roles.hip): rows per XCD group follow the batch -- B <= 32: 4 rows (1.62 us per step against 1.76 for the
+            # round-5 kernel), B <= 64: 8 rows in ONE launch (1.93 against 2 x 1.76), wider: slices of 128 rows at 16 per group (2.77
+            # against 4 x 1.76).  Bit-identical to the launch-per-step kernel for every geometry.
+            wimg = roles_wimg(w_hh, mode, False)
+            for b0, nb, R in plan:
+                roles_launch([fwd_role(gx, lens, y, gates, cell, wimg, b0=b0, nb=nb)], R, mode, gx.device)
+        elif wide:
             # B > 32: one persistent launch per slice of 32 rows, back to back (pointers offset to the slice's first row)
             code = _persist_fwd_code(wide[0])
             st = _persist_watch(gx.device)
@@ -1204,7 +1440,14 @@ class LSTMSeqFn(torch.autograd.Function):
         ng = lstm_persist_groups(B, H, ctx.reverse, ctx.mode, dy.device)
         wide = None if ng else lstm_persist_slices(B, H, ctx.reverse, ctx.mode, dy.device)
         d_img_k, img_only = None, False
-        if wide:
+        if wide and _ROLES:
+            # slices of 64 rows at 8 per XCD group (2.5 us per step against 2 x 1.65; 16 rows per group lose in the backward kernel:
+            # 7.2 us per step for 128 rows, profiles/r06_persist_rows_per_group.log)
+            dgx = torch.empty(T, B, 4 * H, device=dy.device, dtype=torch.float32)
+            wimg = roles_wimg(w_hh, ctx.mode, True)
+            for b0, nb, R in roles_plan(B, True):
+                roles_launch([bwd_role(dy, lens, gates, cell, dgx, wimg, b0=b0, nb=nb)], R, ctx.mode, dy.device, backward=True)
+        elif wide:
             code = _persist_bwd_code(wide[0])
             st = _persist_watch(dy.device)
             work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(32, H), device=dy.device, dtype=torch.uint8)
