@@ -1113,7 +1113,8 @@ def roles_wimg(w_hh, mode, backward):
     """MFMA fragment image of W_hh for the roles kernels (forward: gate-adjacent tiles; backward: the reduce-scatter layout)."""
     img = torch.empty(L.lib().ft_lstm_roles_wimg_bytes(w_hh.shape[1]), device=w_hh.device, dtype=torch.uint8)
     fn = L.op16("ft_lstm_roles_prepare_bwd" if backward else "ft_lstm_roles_prepare_fwd", mode)
-    L.check(fn(L.ptr(_c(w_hh)), L.ptr(img), w_hh.shape[1], L.stream()), "ft_lstm_roles_prepare")
+    w = _c(w_hh)                 # (named: a temporary copy would be recycled by the allocator before the launch reads it)
+    L.check(fn(L.ptr(w), L.ptr(img), w.shape[1], L.stream()), "ft_lstm_roles_prepare")
     return img
 
 

@@ -464,7 +464,10 @@ def test_batches_wider_than_the_recurrence_kernels_take(mode, width, tol):
                 assert mad(out80[3][0][lo + b, :t, :l], o[3][0][b, :t, :l]) <= tol, (hi, b)
         for k in g80:
             ref = gs[0][k] + gs[1][k]
-            assert float((g80[k] - ref).norm()) <= tol * 5 * float(ref.norm()) + 1e-6, (k, float((g80[k] - ref).norm() / (ref.norm() + 1e-30)))
+            # (the conv biases in front of an instance norm have analytically zero gradients: |g| ~ 1e-6 of rounding residue, compared
+            #  absolutely like in the golden tests -- the recurrences of the wide batch sum in another association, round 6)
+            slack = 1e-5 if (k.startswith("encoder.convolutions") and k.endswith("conv.bias")) else 1e-6
+            assert float((g80[k] - ref).norm()) <= tol * 5 * float(ref.norm()) + slack, (k, float((g80[k] - ref).norm() / (ref.norm() + 1e-30)))
     finally:
         os.environ["FLOWTRON_MFMA"] = "f32"
 
