@@ -114,7 +114,6 @@ SIGNATURES = {
     "ft_lstm_seq_bwd": ([_p, _l, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "ft_lstm_persist_supported": ([_i, _i], _i),
     "ft_lstm_persist_workspace_bytes": ([_i, _i], _sz),
-    "ft_lstm_persist_fwd": ([_p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_lstm_persist_debug_prof": ([_p], _i),
     "ft_lstm_persist_bwd": ([_p, _l, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "ft_bilstm_persist_supported": ([_i, _i], _i),
@@ -130,8 +129,6 @@ SIGNATURES = {
     "ft_lstm_roles_prepare_bwd": ([_p, _p, _i, _p], _i),
     "ft_lstm_roles_fwd": ([C.POINTER(LstmFwdRole), _i, _i, _i, _p, _i, _p, _i, _p], _i),
     "ft_lstm_roles_bwd": ([C.POINTER(LstmBwdRole), _i, _i, _i, _p, _i, _p, _i, _p], _i),
-    "ft_lstm_persist_fwd_rows": ([_p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
-    "ft_lstm_persist_bwd_rows": ([_p, _l, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "ft_lstm2_supported": ([_i, _i], _i),
     "ft_lstm2_workspace_bytes": ([_i, _i], _sz),
     "ft_lstm2_seq_fwd": ([_p] * 13 + [_i, _i, _i, _p], _i),
@@ -181,7 +178,7 @@ SIGNATURES = {
 
 # fp16-operand twins (include/flowtron_hip.h, end): same signatures, suffix _f16
 OP16_TWINS = ("ft_gemm", "ft_bf16_image", "ft_bf16_image_colsum", "ft_bf16_image_colsum_acc", "ft_bf16_image_rows_acc", "ft_bf16_image_rows_act_bwd_acc", "ft_gemm_img", "ft_bf16_image_rows", "ft_bf16_image_rows_into", "ft_bf16_image_rows_act_bwd", "ft_img_gemv_rows", "ft_img_gemv_rows_bwd", "ft_lstm_seq_fwd", "ft_lstm_seq_bwd",
-              "ft_lstm_persist_fwd", "ft_lstm_persist_bwd", "ft_lstm_persist_bwd_img", "ft_lstm_persist_fwd_rows", "ft_lstm_persist_bwd_rows", "ft_lstm_roles_prepare_fwd", "ft_lstm_roles_prepare_bwd", "ft_lstm_roles_fwd", "ft_lstm_roles_bwd", "ft_lstm2_seq_fwd", "ft_lstm2_seq_bwd",
+              "ft_lstm_persist_bwd", "ft_lstm_persist_bwd_img", "ft_lstm_roles_prepare_fwd", "ft_lstm_roles_prepare_bwd", "ft_lstm_roles_fwd", "ft_lstm_roles_bwd", "ft_lstm2_seq_fwd", "ft_lstm2_seq_bwd",
               "ft_lstm_bidir_seq_fwd", "ft_lstm_bidir_seq_bwd", "ft_bilstm_persist_fwd", "ft_bilstm_persist_bwd")
 for _n in OP16_TWINS:
     SIGNATURES[_n + "_f16"] = SIGNATURES[_n]

@@ -165,10 +165,9 @@ class TacotronSTFT(torch.nn.Module):
         """y [B,N] float32 in [-1,1] (device tensor) -> [B, n_mel_channels, N // hop + 1]."""
         L.require_cuda(y)
         assert y.dim() == 2
-        # the reference asserts the value range with two host syncs (audio_processing.py:127-128); checked on
-        # device only when FLOWTRON_CHECK_AUDIO_RANGE is set, to keep the front end sync-free
-        import os
-        if os.environ.get("FLOWTRON_CHECK_AUDIO_RANGE"):
+        # the reference asserts the value range with two host syncs (audio_processing.py:127-128); done only when the caller asks
+        # (TacotronSTFT.check_audio_range = True), to keep the front end sync-free
+        if getattr(self, "check_audio_range", False):
             assert float(y.min()) >= -1 and float(y.max()) <= 1
         y = y.contiguous().float()
         if self.mel_basis.device != y.device:

@@ -31,7 +31,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 // log-sum-exp of the DP recursions through the hardware transcendentals (v_exp_f32 / v_log_f32, ~1 ulp): the arguments of exp are
 // <= 0 and the sum lies in [1, 3], so the libm range handling bought nothing -- and its ~60 instructions per step were most of the
-// recursion's 0.55 us per frame (round 6: 479 -> us in profiles/r06_*; the loss agrees with the oracle to the same 1e-5)
+// recursion's 0.55 us per frame (round 6: 479 -> 385 us per call, profiles/r06_*; the parity tests hold the loss to the same 1e-5)
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 __device__ __forceinline__ float lse3(float a, float b, float c) {

@@ -1,440 +1,25 @@
-// Persistent LSTM recurrence (forward): ONE launch for the whole sequence, weights resident in the register file.
+// Persistent LSTM recurrence, BACKWARD, reduce-scatter form (round 4): ONE launch for the whole sequence, W_hh resident in the
+// accumulation registers, 8 batch groups = the 8 XCDs (run-time XCC census), 4 batch rows each, hand-offs through the XCD's own L2.
 //
-// The launch-per-step kernels of lstm.hip re-stream W_hh (8.4 MB bf16 at H = 1024) from the memory side every time step
-// because nothing survives a kernel boundary in registers/LDS, and every CU pulls the whole [B,H] state image: ~5.3 us per
-// step, 2.5x the ~2 us a dependent step needs.  Here the chip is split into NG independent BATCH GROUPS:
-//
-//   group g  = 256/NG workgroups (one per CU, 4 waves, one wave per SIMD = the whole 512-register file per wave)
-//              owns batch rows [g*RPG, (g+1)*RPG) for the WHOLE sequence -- no traffic between groups, ever;
-//   CU q of a group owns UPC = H*NG/256 hidden units = TPC = NG tiles of (4 units x 4 gates) gate rows and keeps
-//              their W_hh rows as bf16 MFMA fragments in registers (wave w: k-chunks w, w+4, ..: 32*NG VGPRs);
-//   per step   each wave reads its quarter of the group's h_{t-1} (RPG rows x H bf16, <= 8 KB per group) straight into
-//              MFMA A-fragments, TPC x 8 MFMAs per wave, 4-wave reduce in LDS, cell update for RPG x UPC (= 128) elements,
-//              h_t published to the group.
-//
-// W_hh is replicated NG times across the chip (registers are plentiful: 512 KB per CU), which shrinks the per-step all-gather
-// from the full [32,1024] state to [RPG,1024] and makes it group-local.
-//
-// Hand-off (cdna_hip_programming.md G16, form R2 "the data IS the flag"): h_t travels as 8-byte granules
-// {hi = epoch t+1, lo = two bf16}, one aligned 8-byte store each; consumers re-read their granules with L1-bypassing
-// 16-byte loads (two granules) until every tag matches -- no fences, no separate flag.  Two parity buffers: a producer can
-// only overwrite slot parity p two steps later, after every consumer of the group has published the step in between, i.e.
-// has finished reading p.  Two transports (template LOCAL):
-//   LOCAL = false  placement independent: write-through (sc1) stores, sc1 loads -- the data crosses the fabric each step
-//                  (~2 us per hop measured); groups are formed from block ids; NG = 8 | 4 | 2.
-//   LOCAL = true   NG = 8, group == XCD: every workgroup reads its XCC id and draws its slot in that XCD's group from a
-//                  per-XCD counter (a census: membership is a FACT established at run time, not a dispatch-order
-//                  assumption; with one 512-register workgroup per CU each XCD hosts exactly 32).  Producers then use
-//                  PLAIN stores -- the CU's L1 is write-through, so the granule sits in the XCD's own L2 -- and consumers
-//                  sc1 loads, which bypass L1 and are served by that same L2: one L2 round trip per hop instead of the fabric.
-//                  A stale tag can never be mistaken for data; if the census does not come out (partitioned device, foreign
-//                  kernel on some CUs) the waits time out and the status word sends the caller to the launch-per-step path.
-// Every spin is bounded by a wall-clock timeout that raises status[0] (the host checks it; a chip with fewer than 256 free
-// CUs cannot host the grid).
-//
-// Saved tensors (gates, cell), y, masks: identical to ft_lstm_seq_fwd (FT_BF16 path) -- same fragment rounding, same
-// k-chunk-per-wave accumulation order, so results are bit-identical to the launch-per-step kernel.
+// History of this file: rounds 2-3 built the forward kernel (lstm_persist_fwd_k: all-gather of h as tagged
+// granules, later bare operand pairs behind a sentinel) and the all-gather backward (lstm_persist_bwd_k); round 4 the reduce-scatter
+// backward below, which has been the step's backward recurrence since.  Round 6 removed what it superseded: the forward recurrence
+// lives in lstm_roles.hip (rows per XCD group / windows / roles; 1.62 us per step at 4 rows against 1.76 for lstm_persist_fwd_k,
+// bit-identical), the all-gather backward (2.84 us per step against 1.62), the tagged-granule transport and the placement-
+// independent (fabric) template branches are gone.  Every spin is bounded by a wall-clock timeout that raises status[0]; the host
+// checks it (a chip with fewer than 256 free CUs cannot host the grid) and falls back to the launch-per-step kernels of lstm.hip.
 #include "lstm_persist_common.h"
 
 namespace {
 
-struct PersistP {
-    const float* gx; const int* lens;
-    float* y; long ldy; float* gates; float* cell;
-    const unsigned short* wfrag;         // [H/4][H/32][64][8] bf16 (make_wfrag_fwd layout)
-    unsigned long long* hgran;           // [2 parity][NG][NCHUNK][4 kg][RPGP][4] granules
-    int* status;
-    unsigned* census;                    // LOCAL: [8] per-XCD arrival counters (zeroed by the host before the launch)
-    int T, B;
-    long timeout_ticks;                  // wall_clock64 ticks (100 MHz)
-    long* prof;                          // debug: per-step phase stamps of one workgroup (ft_lstm_persist_debug_prof), or null
-    int LB;                              // batch rows per time step IN MEMORY (>= B: the launch may cover a slice b0 .. b0 + B - 1 of a
-                                         // wider batch -- every pointer then starts at row b0; ft_lstm_persist_fwd_rows)
-};
-
-// Granule layout of one group's state vector (K = 32 NCW k-values x RPGP rows; NCW = k-chunks per wave).  A consumer wave w
-// owns the chunks c = w + 4 ci; ONE 16-byte-per-lane load fetches CPL = 16 / RPGP of its chunks at once -- lane (kg, li) gets
-// chunk ci = lg CPL + li / RPGP, row li % RPGP, k-group kg -- so every lane of every load carries real granules (a load per
-// chunk would leave the lanes of the padding rows, 3/4 of the wave at RPGP = 4, fetching duplicates).  MFMA wants chunk j's rows
-// in lanes li < RPGP of each 16-lane row: a DPP row shift by j RPGP lanes puts them there (the other lanes are padding rows
-// whose products nobody reads).  Buffer: [w][lg][half][64 lanes][2 granules]; half = which 4 of the lane's 8 k-values.
-template <int RPGP, int NCW>
-__device__ __forceinline__ int gran_index(int b, int k) {
-    constexpr int CPL = 16 / RPGP, NLG = NCW / CPL;
-    const int c = k >> 5, w = c & 3, ci = c >> 2, kg = (k >> 3) & 3, e = k & 7;
-    const int lg = ci / CPL, j = ci % CPL, lane = kg * 16 + j * RPGP + b;
-    return ((((w * NLG + lg) * 2 + (e >> 2)) * 64 + lane) << 1) + ((e >> 1) & 1);
-}
-
-// the eight operands of one lane from the load(s) of a load group: tagged = two loads {v, tag, v, tag}, bare = one load
-template <bool BARE>
-__device__ __forceinline__ u32x4 payload(const u32x4* l) {
-    if constexpr (BARE) return l[0];
-    else return (u32x4){l[0][0], l[0][2], l[1][0], l[1][2]};
-}
-template <bool BARE>
-__device__ __forceinline__ bool fresh(const u32x4* l, unsigned epoch) {
-    if constexpr (BARE) return (l[0][0] != SENT) & (l[0][1] != SENT) & (l[0][2] != SENT) & (l[0][3] != SENT);
-    else return (l[0][1] == epoch) & (l[0][3] == epoch) & (l[1][1] == epoch) & (l[1][3] == epoch);
-}
-// Staging of the HBM rows the recurrence reads.
-// Forward: gx rows arrive in synchronous bursts of SB steps (one HBM round trip per 32 steps, ~0.1 us per step).
-// Backward (saved gates, cell, dy: 6 rows per step, 97 KB per burst -- measured 20 us of whole-workgroup stall per 32 steps,
-// 0.6 us per step): a RING of LDS slots, one step per slot, filled DIST steps ahead by LDS-DMA from waves 2-3 -- six dwords per
-// lane and step, issued right after the reduce barrier together with the output stores of the previous step.  Those waves have
-// ~1 us of slack per step (they wait for the group's publish), which hides the HBM round trip that, vmcnt retiring in order,
-// sits in front of their next poll; the forward kernel's waves have no such slack (tried: 1.93 -> 2.15 us per step), and a DMA
-// issued BEFORE the barrier stalls everybody (LDS-DMA also counts in lgkmcnt, which every LDS barrier has to drain).
-// Slot reuse: the occupant of slot m % RING (step m - RING) is last read in step m - RING + 1 (cell ring); its successor is
-// requested in step m - DIST > m - RING + 1.
-constexpr int SB = 32;
-constexpr int RING = 8, DIST = 6;
+constexpr int RING = 8, DIST = 6;        // LDS ring of staged steps: a slot is filled DIST steps ahead by LDS-DMA from waves 2-3
 static_assert(DIST < RING - 1, "slot reuse");
 
-template <int NG, bool LOCAL, int LAUX, bool BARE>
-__global__ __launch_bounds__(256, 1) void lstm_persist_fwd_k(PersistP p) {
-    static_assert(!LOCAL || NG == 8, "the L2-local transport needs group == XCD");
-    constexpr int CPG = NCU / NG;                  // CUs (workgroups) per group
-    constexpr int UPC = PH / CPG;                  // hidden units per CU: 32, 16, 8
-    constexpr int TPC = UPC / 4;                   // gate-row tiles per CU (= NG)
-    constexpr int RPGP = 32 / NG;                  // batch rows per group (padded): 4, 8, 16
-    constexpr int NE = RPGP * UPC;                 // (row, unit) elements per CU = 128 epilogue threads
-    constexpr int CPL = 16 / RPGP, NLG = 8 / CPL;  // chunks per load, load groups per wave (x 2 halves)
-    constexpr int GRAN_PER_GROUP = NCHUNK * 4 * RPGP * 4;
-    static_assert(NE == 128, "one epilogue element per thread of waves 0-1");
-    // LDS: 4-wave reduce (double buffered) | SB steps of gx rows [s][gate][e] | 2 steps of outputs [parity][y,i,f,g,o,c][e]
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    // (rows of 16 gate columns at a 20-float pitch: 16-byte aligned for the epilogue's f32x4 reads, column n = unit * 4 + gate)
-    float (*red)[4][TPC][RPGP][20] = reinterpret_cast<float (*)[4][TPC][RPGP][20]>(smem);
-    float* gxs = smem + 2 * 4 * TPC * RPGP * 20;
-    float* outs = gxs + SB * 4 * NE;
-
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kg = lane >> 4;
-    int grp, q;
-    if constexpr (LOCAL) {
-        if (!join_group_local<CPG>(p.census, p.status, tid, grp, q)) return;
-    } else {
-        grp = blockIdx.x % NG; q = blockIdx.x / NG;              // speed only: consecutive block ids land on different XCDs
-    }
-    const int B = p.B, T = p.T, LB = p.LB;
-    const int b0 = grp * RPGP;
-
-    // ---- resident weights: tile j, k-chunk (wave + 4 i).  NG == 8 (64 fragments = 256 registers per lane): parked in ACCUMULATION
-    // registers for the whole launch and fed to the MFMAs from there (mfma16_bagpr: round 4 -- the builtin takes B from VGPRs only, so
-    // the ~17 fragments the allocator had to keep in AGPRs cost four v_accvgpr_read each on every use, issue slots the step's MFMA
-    // block does not hide); accumulators in VGPRs.  Same MFMA order per accumulator: bit-identical to the launch-per-step kernel.
-    constexpr bool WAGPR = NG == 8;
-    bf16x8 w[TPC][8];
-    {
-        const bf16x8* wf = reinterpret_cast<const bf16x8*>(p.wfrag);
-#pragma unroll
-        for (int j = 0; j < TPC; ++j)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w[j][i] = wf[((size_t)(q * TPC + j) * NCHUNK + (wave + 4 * i)) * 64 + lane];
-        if constexpr (WAGPR) {
-#pragma unroll
-            for (int j = 0; j < TPC; ++j)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) asm volatile("" : "+a"(w[j][i]));
-        }
-    }
-
-    // ---- epilogue role: thread e < 128 owns (batch row eb, unit eu) of this CU for the whole sequence
-    const bool erole = tid < NE;
-    const int el = tid % UPC, ebl = tid / UPC;     // unit within CU, row within group
-    const int eb = b0 + ebl, eu = q * UPC + el;
-    const bool ev = erole && eb < B;
-    const int len = ev ? p.lens[eb] : 0;
-    // steps this group runs: the longest sequence among its rows (uniform per workgroup)
-    int tg = 0;
-#pragma unroll
-    for (int r = 0; r < RPGP; ++r) {
-        const int bb = b0 + r;
-        if (bb < B) { const int l = p.lens[bb]; tg = l > tg ? l : tg; }
-    }
-    tg = tg < T ? tg : T;
-
-    // ---- HBM traffic is kept out of the sweeping waves' way.  hipcc waits vmcnt(0) at the block joins of the poll loop, and
-    // vmcnt retires in order and counts stores, so anything in flight when a sweep starts sits in front of its first wait:
-    //   * gx rows come in bursts of SB steps by LDS-DMA (global_load_lds: no VGPR staging), one HBM round trip per SB steps;
-    //   * the saved tensors of step t-1 are stored by waves 2-3 right after the reduce barrier of step t, while waves 0-1 run
-    //     the cell update: waves 2-3 start polling before the group has published, so their first (failing) pass hides the
-    //     store acknowledgements.
-    const int wu = __builtin_amdgcn_readfirstlane(wave);         // wave id as a scalar
-    const int eh = (wave & 1) * 64 + lane;                       // burst: wave w serves elements 64 (w & 1) + lane
-    const int hb = b0 + eh / UPC, hu = q * UPC + eh % UPC;
-    const bool hvalid = hb < B;
-    // (RPGP == 4: 1 KiB pieces -- global_load_lds_dwordx4, 16 bytes per lane, eight lanes per 128-byte row piece: one piece = two gates of
-    //  one step for the group's four rows; 16 pieces per wave and burst instead of 64 dword pieces: a piece costs 60-185 cycles of issue
-    //  time whatever its size.  Piece c = 4 kk + wave: step c >> 1, gates 2 (c & 1) + (lane >> 5); lane -> row (lane & 31) >> 3, units 4 (lane & 7))
-    const int pr = lane >> 5, pb = (lane & 31) >> 3, pu = 4 * (lane & 7);
-    const bool pvalid = b0 + pb < B;
-    auto burst = [&](int t) {                                    // t % SB == 0: gx rows of steps [t, t + SB)
-        __syncthreads();
-        const int nst = (tg - t) < SB ? (tg - t) : SB;
-        if constexpr (RPGP == 4) {
-            if (pvalid) {
-                const float* src0 = p.gx + ((size_t)t * LB + b0 + pb) * 4 * PH + (size_t)pr * PH + q * UPC + pu;
-                const unsigned dst0 = (unsigned)(size_t)(lds_void*)gxs;
-#pragma unroll
-                for (int kk = 0; kk < SB / 2; ++kk) {
-                    const int c = 4 * kk + wu, st = c >> 1, h = c & 1;
-                    if (st < nst) {
-                        unsigned keep;
-                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                                     : "=&s"(keep) : "v"(src0 + (size_t)st * LB * 4 * PH + (size_t)(2 * h) * PH),
-                                       "s"(dst0 + (unsigned)((st * 4 + 2 * h) * NE * 4)) : "memory");
-                    }
-                }
-            }
-        } else if (hvalid) {
-            const float* src0 = p.gx + ((size_t)t * LB + hb) * 4 * PH + hu;
-            const unsigned dst0 = (unsigned)(size_t)(lds_void*)gxs + (unsigned)(wu & 1) * 256u;
-#pragma unroll
-            for (int kk = 0; kk < SB * 2; ++kk) {                // pair k = (step, gate), LDS slot [k][e]; all DMAs in flight
-                const int k = 2 * kk + (wu >> 1);
-                if (k < nst * 4) dma_dword(src0 + (size_t)(k >> 2) * LB * 4 * PH + (size_t)(k & 3) * PH, dst0 + (unsigned)k * NE * 4u);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the DMA writes are this wave's own VM operations
-        __syncthreads();
-    };
-    // output role of waves 2-3: thread tid >= 128 stores element e = tid - 128 of the previous step
-    const int oe = tid - NE;
-    const int ob = b0 + oe / UPC, ou = q * UPC + oe % UPC;
-    const bool ovalid = tid >= NE && ob < B;
-    const int olen = ovalid ? p.lens[ob] : 0;
-    auto store_outputs = [&](int t) {                            // saved tensors of step t from outs[t & 1]
-        if (!ovalid) return;
-        const float* o = outs + (t & 1) * 6 * NE + oe;
-        const size_t row = (size_t)t * LB + ob;
-        p.y[row * p.ldy + ou] = o[0];
-        if (p.gates && t < olen) {
-            float* gp = p.gates + row * 4 * PH + ou;
-            gp[0] = o[NE]; gp[(size_t)PH] = o[2 * NE]; gp[(size_t)2 * PH] = o[3 * NE]; gp[(size_t)3 * PH] = o[4 * NE];
-            p.cell[row * PH + ou] = o[5 * NE];
-        }
-    };
-
-    float c_state = 0.f, h_state = 0.f;
-    // hand-off buffers of this group.  Tagged: two parity buffers of 8-byte granules.  BARE: three rotating buffers of bare
-    // operand pairs behind ONE resource, the buffer of a step selected by a scalar byte offset.
-    constexpr int LPG = BARE ? 1 : 2;                            // 16-byte loads per load group
-    constexpr int DW_PER_GROUP = NCHUNK * 32 * RPGP / 2;         // BARE: dwords per buffer and group
-    __amdgpu_buffer_rsrc_t rs[2];
-#pragma unroll
-    for (int par = 0; par < 2; ++par)
-        rs[par] = __builtin_amdgcn_make_buffer_rsrc(p.hgran + ((size_t)par * NG + grp) * GRAN_PER_GROUP, 0,
-                                                    GRAN_PER_GROUP * 8, 0x00020000);
-    unsigned* const bare0 = reinterpret_cast<unsigned*>(p.hgran) + (size_t)grp * 3 * DW_PER_GROUP;
-    const __amdgpu_buffer_rsrc_t rbare = __builtin_amdgcn_make_buffer_rsrc(bare0, 0, 3 * DW_PER_GROUP * 4, 0x00020000);
-    int m3 = 0;                                                  // t % 3
-    // load h of load group lg of this wave = 1 KiB at ((wave NLG + lg) LPG + h) KiB: lane offset in the VGPR, the rest scalar
-    const int voff = lane * 16;
-    const int soff_w = __builtin_amdgcn_readfirstlane(wave) * (NLG * LPG * 1024);
-    const long t_start = wall_clock64();
-    bool dead = false;
-    // debug stamps (100 MHz wall clock): [step][wave][0..4] = loop top, sweep+MFMA done, reduce barrier passed, published,
-    // passes of the poll loop
-    const bool prof = p.prof != nullptr && grp == 0 && q == 0 && lane == 0;
-
-    for (int t = 0; t < tg; ++t) {
-        if ((t % SB) == 0) burst(t);
-        long st0 = 0, st1 = 0, st2 = 0, st3 = 0, npass = 0;
-        if (prof) st0 = wall_clock64();
-        f32x4 acc[TPC];
-#pragma unroll
-        for (int j = 0; j < TPC; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if constexpr (WAGPR) {
-            // zeroed HERE, in front of the gather: the compiler otherwise sinks each zeroing move to right in front of the inline-asm MFMA
-            // that first reads the register -- a VALU write -> MFMA SrcC hazard it does not pad for an asm statement
-#pragma unroll
-            for (int j = 0; j < TPC; ++j) asm volatile("" : "+v"(acc[j]));
-        }
-        if (t > 0) {
-            // ---- sweep: this wave's 8 chunks of h_{t-1} (epoch t) straight into A fragments.  Every pass re-reads ALL chunks
-            // that have not shown the epoch yet (one L2 round trip for the lot).  The poll loop holds loads and tag compares
-            // only; the 8 x TPC MFMAs follow as ONE straight-line block (MFMAs inside the data-dependent control flow made
-            // hipcc shuffle accumulators and weight fragments through v_accvgpr_mov on every chunk).
-            const unsigned epoch = (unsigned)t;
-            const int par = (t - 1) & 1;
-            const int boff = BARE ? (m3 == 0 ? 2 : m3 - 1) * (DW_PER_GROUP * 4) : 0;     // BARE: buffer (t - 1) % 3
-            u32x4 ld[NLG][LPG];
-            auto issue = [&](int g) {
-#pragma unroll
-                for (int h = 0; h < LPG; ++h)                                              // LAUX: 16 = sc1, 2 = nt
-                    ld[g][h] = __builtin_amdgcn_raw_buffer_load_b128(BARE ? rbare : rs[par], voff, soff_w + (g * LPG + h) * 1024 + boff, LAUX);
-            };
-#pragma unroll
-            for (int g = 0; g < NLG; ++g) issue(g);
-            unsigned ready = 0;                    // wave-uniform bit per load group: every lane holds the data of this step
-            for (unsigned spins = 0;; ++spins) {
-#pragma unroll
-                for (int g = 0; g < NLG; ++g) {
-                    if (!((ready >> g) & 1u)) {
-                        if (__all(fresh<BARE>(ld[g], epoch))) ready |= 1u << g;
-                    }
-                }
-                npass = spins + 1;
-                if (ready == (1u << NLG) - 1u) break;
-                if ((spins & 15) == 15) {
-                    if (wall_clock64() - t_start > p.timeout_ticks ||
-                        __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        dead = true;
-                        break;
-                    }
-                }
-                asm volatile("" ::: "memory");     // the builtin loads are not atomics: keep the re-reads inside the loop
-#pragma unroll
-                for (int g = 0; g < NLG; ++g) {
-                    if (!((ready >> g) & 1u)) issue(g);
-                }
-            }
-            if (dead) break;
-            if constexpr (WAGPR) {
-                // chunk i of this wave = load group i / CPL, member i % CPL.  The four moves that assemble a chunk's A operand (payload
-                // dwords of two loads, shifted into the MFMA row positions by DPP) are issued one per MFMA gap of the PREVIOUS chunk,
-                // into the other of two operand buffers: in a block of their own they cost the one-wave-per-SIMD kernel their whole
-                // issue time (4 moves + wait states per chunk, ~0.1 us per step)
-                auto operand_word = [&](int i, int c) -> unsigned {
-                    const u32x4 pl = payload<BARE>(ld[i / CPL]);
-                    switch (i % CPL) {
-                        case 0: {       // (an explicit move IN this slot: a plain copy is materialised by the compiler right in front of the
-                            unsigned r; //  consuming asm MFMA -- VALU write -> MFMA source read without the two wait states: wrong operands)
-                            asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(pl[c]));
-                            return r;
-                        }
-                        case 1: return row_shl<RPGP & 15>(pl[c]);
-                        case 2: return row_shl<(2 * RPGP) & 15>(pl[c]);
-                        default: return row_shl<(3 * RPGP) & 15>(pl[c]);
-                    }
-                };
-                u32x4 au[3];                                                      // three buffers: the one being assembled was last read a whole
-#pragma unroll                                                                    // chunk (8 MFMAs) ago
-                for (int c = 0; c < 4; ++c) au[0][c] = operand_word(0, c);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                    for (int j = 0; j < TPC; ++j) {
-                        if (i == 0 && j == 0) mfma16_bagpr_nop(acc[0], au[0], __builtin_bit_cast(u32x4, w[0][0]));   // (two wait states behind the moves above)
-                        else mfma16_bagpr(acc[j], au[i % 3], __builtin_bit_cast(u32x4, w[j][i]));
-                        if (i + 1 < 8 && j < 4) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            au[(i + 1) % 3][j] = operand_word(i + 1, j);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, member<RPGP>(payload<BARE>(ld[i / CPL]), i % CPL));
-#pragma unroll
-                    for (int j = 0; j < TPC; ++j) acc[j] = mfma16(a, w[j][i], acc[j]);
-                }
-            }
-            // (asm MFMAs: the compiler does not know their result latency -- 12 wait states before anything reads the last one's)
-            if constexpr (WAGPR) asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
-        }
-        // D[m = batch row (lane>>4)*4 + r][n = li]: rows >= RPGP are padding
-        const int rb = t & 1;
-        if (prof) st1 = wall_clock64();
-        if (kg * 4 < RPGP) {
-#pragma unroll
-            for (int j = 0; j < TPC; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[rb][wave][j][kg * 4 + r][li] = acc[j][r];
-        }
-        __syncthreads();
-        if (prof) st2 = wall_clock64();
-        if (t > 0) store_outputs(t - 1);
-        if (erole) {
-            const bool active = t < len;
-            const int j = el >> 2, ul = el & 3;
-            if constexpr (BARE) {
-                // reset this thread's slot of buffer (t + 1) % 3 (it holds step t - 2, which everybody has consumed) first: the
-                // acknowledgement returns under the cell update below, and the publish waits for it
-                if ((el & 1) == 0) {
-                    unsigned* dst = bare0 + (m3 == 2 ? 0 : m3 + 1) * DW_PER_GROUP + bare_index<RPGP, 8>(ebl, eu);
-                    if constexpr (LOCAL) __hip_atomic_store((gu32*)dst, SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else __hip_atomic_store((gu32*)dst, SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            const float* gxr = gxs + (t % SB) * 4 * NE + tid;
-            float pre[4];
-            {
-                // the four gates of (unit ul, row ebl) are adjacent (make_wfrag_fwd_ug): one 16-byte read per wave partial; the sum
-                // keeps its order (wave 0 + 1 + 2 + 3, then gx)
-                const f32x4 p0 = *reinterpret_cast<const f32x4*>(&red[rb][0][j][ebl][ul * 4]), p1 = *reinterpret_cast<const f32x4*>(&red[rb][1][j][ebl][ul * 4]);
-                const f32x4 p2 = *reinterpret_cast<const f32x4*>(&red[rb][2][j][ebl][ul * 4]), p3 = *reinterpret_cast<const f32x4*>(&red[rb][3][j][ebl][ul * 4]);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) pre[g] = p0[g] + p1[g] + p2[g] + p3[g] + gxr[g * NE];
-            }
-            float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f;
-            if (active) {
-                float c_new, h_new;
-                lstm_cell<true>(pre, c_state, ig, fg, gg, og, c_new, h_new);
-                c_state = c_new; h_state = h_new;
-            }
-            // ---- publish h_t first: one 8-byte {epoch, bf16 pair} granule per even unit (frozen rows re-publish their state)
-            const float h_nb = __uint_as_float(row_shl<1>(__float_as_uint(h_state)));     // lane + 1 of the row: the odd unit of the pair
-            if constexpr (BARE) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the reset above is in the L2 before the publish leaves
-                if ((el & 1) == 0) {
-                    unsigned* dst = bare0 + m3 * DW_PER_GROUP + bare_index<RPGP, 8>(ebl, eu);
-                    const unsigned val = pack_op16x2(h_state, h_nb);
-                    if constexpr (LOCAL) __hip_atomic_store((gu32*)dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else __hip_atomic_store((gu32*)dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else if ((el & 1) == 0) {
-                const unsigned long long gran = ((unsigned long long)(unsigned)(t + 1) << 32) | pack_op16x2(h_state, h_nb);
-                unsigned long long* dst = p.hgran + ((size_t)(t & 1) * NG + grp) * GRAN_PER_GROUP + gran_index<RPGP, 8>(ebl, eu);
-                // LOCAL: workgroup-scope relaxed store = ONE aligned 8-byte global_store (sc0) whose line stays in this XCD's L2;
-                // otherwise agent scope = sc1, write-through to the memory side
-                if constexpr (LOCAL) __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                else __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (prof) st3 = wall_clock64();
-            float* o = outs + (t & 1) * 6 * NE + tid;            // waves 2-3 store it during the next step
-            o[0] = active ? h_state : 0.f;
-            o[NE] = ig; o[2 * NE] = fg; o[3 * NE] = gg; o[4 * NE] = og; o[5 * NE] = c_state;
-        }
-        if (prof && t < 1024) {
-            long* o = p.prof + ((size_t)t * 4 + wave) * 5;
-            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = npass;
-        }
-        m3 = m3 == 2 ? 0 : m3 + 1;
-    }
-    if (dead) {
-        if (lane == 0) atomicExch(p.status, 1);
-        return;
-    }
-    __syncthreads();
-    if (tg > 0) store_outputs(tg - 1);
-    // pad rows beyond the group's longest sequence: y = 0 (pad_packed_sequence semantics)
-    if (ev)
-        for (int t = tg; t < T; ++t) p.y[((size_t)t * LB + eb) * p.ldy + eu] = 0.f;
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// Backward recurrence, same organisation: dh_rec[b][j] = sum_r dgates_{s+1}[b][r] W_hh[r][j]  (K = 4H, N = H).
-// CU q of a group owns UPC hidden units j (UPC/16 column tiles of W_hh^T, fragments resident in registers: wave w holds
-// k-chunks w, w+4, .. of K = 4H = 128 chunks) and runs the cell backward of those units for the group's rows, publishing
-// dgates_s (4 gates x UPC units x RPGP rows) as granules over k = gate*H + j.  The group's dgates vector is 4x the forward
-// state (RPGP x 4H bf16), so a wave sweeps its 32 chunks in 4 batches of 8 with the next batch's loads in flight.
-// Accumulation mimics lstm_bwd_step_bf16's 16-wave split (partial a of wave w = chunks w+4a, w+4a+16, ..; the 16 partials
-// are summed in wave order), so the result is bit-identical to the launch-per-step kernel.  Saved gates / cell / dy come
-// in through the same LDS ring as the forward kernel (dgx goes out from waves 2-3).
 struct PersistBwdP {
     const float* dy; long ldy; const int* lens;
     const float* gates; const float* cell; float* dgx;
-    const unsigned short* wTfrag;        // [H/16][4H/32][64][8] bf16 (make_wfrag_bwd layout)
-    unsigned long long* dgran;           // [2 parity][NG][4H/32][4 kg][RPGP][4] granules
+    const unsigned short* wTfrag;        // make_wfrag_rs image
+    unsigned long long* dgran;           // partial buffers [2 parity][8 groups][consumer 32][producer 32][32 units][4 rows] fp32
     int* status; unsigned* census;
     int T, B;
     long timeout_ticks;
@@ -446,306 +31,6 @@ struct PersistBwdP {
     unsigned short* dimg; long dimg_ld; int dimg_rows; float* dbias;
     int LB;                              // batch rows per time step in memory (see PersistP; the image output needs LB == B)
 };
-
-// OUT: 0 = fp32 dgx rows only, 1 = dgx and the compact 16-bit image, 2 = the image only (compile-time: the plain path carries none
-// of the image code, the image-only path none of the fp32 stores)
-template <int NG, bool LOCAL, int LAUX, bool BARE, int OUT = 0>
-__global__ __launch_bounds__(256, 1) void lstm_persist_bwd_k(PersistBwdP p) {
-    constexpr bool WF32 = OUT != 2, WIMG = OUT != 0;
-    static_assert(!LOCAL || NG == 8, "the L2-local transport needs group == XCD");
-    constexpr int CPG = NCU / NG;                  // workgroups per group
-    constexpr int UPC = PH / CPG;                  // hidden units per CU: 32 (NG 8), 16 (NG 4)
-    constexpr int TL = UPC / 16;                   // column tiles per CU
-    constexpr int RPGP = 32 / NG;
-    constexpr int NE = RPGP * UPC;
-    constexpr int KCH = 4 * PH / 32;               // 128 k-chunks
-    constexpr int CPW = KCH / 4;                   // chunks per wave: 32
-    constexpr int GRAN_PER_GROUP = KCH * 4 * RPGP * 4;
-    constexpr int CPL = 16 / RPGP, NLG = CPW / CPL; // chunks per load, load groups per wave (x 2 halves): 8 (NG 8), 16 (NG 4)
-    constexpr int NBT = NLG > 8 ? 2 : 1, LPB = NLG / NBT;   // sweep batches per step (<= 16 loads in flight each), load groups per batch
-    static_assert(TL >= 1, "NG = 2 would leave half a column tile per CU");
-    static_assert(NE == 128, "one epilogue element per thread of waves 0-1");
-    // LDS: 16-partial reduce (double buffered) | RING steps in [slot][gates x4, dy][e] | RING cells [slot][e] | 2 steps out [parity][4][e]
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float (*red)[16][TL][RPGP][17] = reinterpret_cast<float (*)[16][TL][RPGP][17]>(smem);
-    float* ins = smem + 2 * 16 * TL * RPGP * 17;
-    float* cells = ins + RING * 5 * NE;
-    float* outs = cells + RING * NE;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kg = lane >> 4;
-    int grp, q;
-    if constexpr (LOCAL) {
-        if (!join_group_local<CPG>(p.census, p.status, tid, grp, q)) return;
-    } else {
-        grp = blockIdx.x % NG; q = blockIdx.x / NG;
-    }
-    const int B = p.B, T = p.T, LB = p.LB;
-    const int b0 = grp * RPGP;
-
-    bf16x8 w[TL][CPW];
-    {
-        const bf16x8* wf = reinterpret_cast<const bf16x8*>(p.wTfrag);
-#pragma unroll
-        for (int j = 0; j < TL; ++j)
-#pragma unroll
-            for (int i = 0; i < CPW; ++i) w[j][i] = wf[((size_t)(q * TL + j) * KCH + (wave + 4 * i)) * 64 + lane];
-    }
-
-    const bool erole = tid < NE;
-    const int el = tid % UPC, ebl = tid / UPC;
-    const int eb = b0 + ebl, eu = q * UPC + el;
-    const bool ev = erole && eb < B;
-    const int len = ev ? p.lens[eb] : 0;
-    int tg = 0;
-#pragma unroll
-    for (int r = 0; r < RPGP; ++r) {
-        const int bb = b0 + r;
-        if (bb < B) { const int l = p.lens[bb]; tg = l > tg ? l : tg; }
-    }
-    tg = tg < T ? tg : T;
-
-    // step counter n = 0 .. tg-1 walks time s = tg-1-n downwards
-    // output role of waves 2-3 (see the forward kernel): thread tid >= 128 stores the dgx row of the previous step
-    const int oe = tid - NE;
-    const int ob = b0 + oe / UPC, ou = q * UPC + oe % UPC;
-    const bool ovalid = tid >= NE && ob < B;
-    int olen = 0, ooff = 0;                                      // image: this row's length and its first compact row
-    if (WIMG && ovalid) {
-        olen = p.lens[ob];
-        for (int bb = 0; bb < ob; ++bb) ooff += p.lens[bb] + 1;
-    }
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    auto store_outputs = [&](int n) {                            // dgx row of step counter n from outs[n & 1]
-        if (!ovalid) return;
-        const float* o = outs + (n & 1) * 4 * NE + oe;
-        const int so = tg - 1 - n;
-        const float v0 = o[0], v1 = o[NE], v2 = o[2 * NE], v3 = o[3 * NE];
-        if constexpr (WF32) {
-            float* dg = p.dgx + ((size_t)so * LB + ob) * 4 * PH + ou;
-            dg[0] = v0; dg[(size_t)PH] = v1; dg[(size_t)2 * PH] = v2; dg[(size_t)3 * PH] = v3;
-        }
-        if (WIMG && so < olen) {
-            unsigned short* ip = p.dimg + (size_t)(ooff + so) * p.dimg_ld + ou;
-            ip[0] = (unsigned short)pack_op16x2(v0, 0.f); ip[PH] = (unsigned short)pack_op16x2(v1, 0.f);
-            ip[2 * PH] = (unsigned short)pack_op16x2(v2, 0.f); ip[3 * PH] = (unsigned short)pack_op16x2(v3, 0.f);
-            bsum[0] += v0; bsum[1] += v1; bsum[2] += v2; bsum[3] += v3;
-        }
-    };
-    // ring slot n % RING: saved gates x4 + dy of step n; cell slot n % RING = cell[s(n) - 1] (c_prev of step n = c_t of step n+1),
-    // cell slot RING-1 starts out as cell[tg - 1] (c_t of step 0)
-    const int wu = __builtin_amdgcn_readfirstlane(wave);
-    const int eh = (wave & 1) * 64 + lane;
-    const int hb = b0 + eh / UPC, hu = q * UPC + eh % UPC;
-    const bool hvalid = hb < B;
-    const unsigned ins0 = (unsigned)(size_t)(lds_void*)ins + (unsigned)(wu & 1) * 256u;
-    const unsigned cells0 = (unsigned)(size_t)(lds_void*)cells + (unsigned)(wu & 1) * 256u;
-    auto prefetch = [&](int m) {                                 // waves 2-3 (from the epilogue waves instead: 3.13 vs 3.07 us)
-        if (wu >= 2 && m < tg && hvalid) {
-            const int sm = tg - 1 - m;
-            const size_t row = (size_t)sm * LB + hb;
-            const unsigned dst = ins0 + (unsigned)((m % RING) * 5 * NE * 4);
-#pragma unroll
-            for (int f = 0; f < 4; ++f) dma_dword(p.gates + row * 4 * PH + (size_t)f * PH + hu, dst + (unsigned)(f * NE * 4));
-            dma_dword(p.dy + row * p.ldy + hu, dst + (unsigned)(4 * NE * 4));
-            if (sm > 0) dma_dword(p.cell + (row - LB) * PH + hu, cells0 + (unsigned)((m % RING) * NE * 4));
-        }
-    };
-    if (wu >= 2 && tg > 0 && hvalid) dma_dword(p.cell + ((size_t)(tg - 1) * LB + hb) * PH + hu, cells0 + (unsigned)((RING - 1) * NE * 4));
-#pragma unroll
-    for (int m = 0; m < DIST; ++m) prefetch(m);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    float dc_carry = 0.f;
-    constexpr int LPG = BARE ? 1 : 2;                            // 16-byte loads per load group (see the forward kernel)
-    constexpr int DW_PER_GROUP = KCH * 32 * RPGP / 2;            // BARE: dwords per buffer and group
-    __amdgpu_buffer_rsrc_t rs[2];
-#pragma unroll
-    for (int par = 0; par < 2; ++par)
-        rs[par] = __builtin_amdgcn_make_buffer_rsrc(p.dgran + ((size_t)par * NG + grp) * GRAN_PER_GROUP, 0,
-                                                    GRAN_PER_GROUP * 8, 0x00020000);
-    unsigned* const bare0 = reinterpret_cast<unsigned*>(p.dgran) + (size_t)grp * 3 * DW_PER_GROUP;
-    const __amdgpu_buffer_rsrc_t rbare = __builtin_amdgcn_make_buffer_rsrc(bare0, 0, 3 * DW_PER_GROUP * 4, 0x00020000);
-    int m3 = 0;                                                  // n % 3
-    const int voff = lane * 16;
-    const int soff_w = __builtin_amdgcn_readfirstlane(wave) * (NLG * LPG * 1024);
-    const long t_start = wall_clock64();
-    bool dead = false;
-
-    // debug stamps: [step][wave][0..4] = loop top, polls + MFMAs done, partials written + barrier passed, published, poll passes
-    const bool prof = p.prof != nullptr && grp == 0 && q == 0 && lane == 0;
-    for (int n = 0; n < tg; ++n) {                 // n-th step of the sweep: time index s = tg-1-n
-        long st0 = 0, st1 = 0, st2 = 0, st3 = 0, npass = 0;
-        if (prof) st0 = wall_clock64();
-        const int s = tg - 1 - n;
-        f32x4 acc[TL][4];
-#pragma unroll
-        for (int j = 0; j < TL; ++j)
-#pragma unroll
-            for (int a = 0; a < 4; ++a) acc[j][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (n > 0) {
-            const unsigned epoch = (unsigned)n;
-            const int par = (n - 1) & 1;
-            const int boff = BARE ? (m3 == 0 ? 2 : m3 - 1) * (DW_PER_GROUP * 4) : 0;     // BARE: buffer (n - 1) % 3
-            u32x4 ld[2][LPB][LPG];
-            auto issue1 = [&](int bt, int g, u32x4 (&l_)[LPG]) {
-#pragma unroll
-                for (int h = 0; h < LPG; ++h)
-                    l_[h] = __builtin_amdgcn_raw_buffer_load_b128(BARE ? rbare : rs[par], voff, soff_w + ((bt * LPB + g) * LPG + h) * 1024 + boff, LAUX);
-            };
-            auto issue = [&](int bt, u32x4 (&l_)[LPB][LPG]) {
-#pragma unroll
-                for (int g = 0; g < LPB; ++g) issue1(bt, g, l_[g]);
-            };
-            issue(0, ld[0]);
-#pragma unroll
-            for (int bt = 0; bt < NBT; ++bt) {
-                if (bt < NBT - 1) issue(bt + 1, ld[(bt + 1) & 1]);
-                u32x4 (&L_)[LPB][LPG] = ld[bt & 1];
-                unsigned ready = 0;
-                for (unsigned spins = 0;; ++spins) {             // loads and tag compares only (see the forward kernel)
-#pragma unroll
-                    for (int g = 0; g < LPB; ++g) {
-                        if (!((ready >> g) & 1u)) {
-                            if (__all(fresh<BARE>(L_[g], epoch))) ready |= 1u << g;
-                        }
-                    }
-                    if (ready == (1u << LPB) - 1u) break;
-                    if (prof) ++npass;
-                    if ((spins & 15) == 15) {
-                        if (wall_clock64() - t_start > p.timeout_ticks ||
-                            __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                            dead = true;
-                            break;
-                        }
-                    }
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int g = 0; g < LPB; ++g) {
-                        if (!((ready >> g) & 1u)) issue1(bt, g, L_[g]);
-                    }
-                }
-                if (dead) break;
-#pragma unroll
-                for (int i = 0; i < LPB * CPL; ++i) {                // chunk ci of this wave = load group ci / CPL, member ci % CPL
-                    const int ci = bt * LPB * CPL + i;
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, member<RPGP>(payload<BARE>(L_[i / CPL]), i % CPL));
-#pragma unroll
-                    for (int j = 0; j < TL; ++j)
-                        acc[j][ci & 3] = mfma16(a, w[j][ci], acc[j][ci & 3]);
-                }
-            }
-            if (dead) break;
-        }
-        const int rb = n & 1;
-        if (prof) st1 = wall_clock64();
-        if (kg * 4 < RPGP) {
-#pragma unroll
-            for (int j = 0; j < TL; ++j)
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) red[rb][wave + 4 * a][j][kg * 4 + r][li] = acc[j][a][r];
-        }
-        __syncthreads();
-        if (prof) st2 = wall_clock64();
-        if (n > 0) store_outputs(n - 1);
-        prefetch(n + DIST);
-        // the output waves' next poll could not be consumed before these stores / DMAs have landed anyway (vmcnt retires in
-        // order); issued now it would read the granules BEFORE the group has published and cost a second round trip
-        if (wu >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (erole) {
-            const int i = n % RING;
-            const bool active = s < len;
-            float da[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (BARE) {
-                // reset this thread's four slots of buffer (n + 1) % 3 (step n - 2: consumed by everybody); acknowledged under the
-                // cell backward below (waves 0-1 have nothing else outstanding: the ring DMAs and dgx stores belong to waves 2-3)
-                if ((el & 1) == 0) {
-                    unsigned* base = bare0 + (m3 == 2 ? 0 : m3 + 1) * DW_PER_GROUP;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        unsigned* dst = base + bare_index<RPGP, CPW>(ebl, g * PH + eu);
-                        if constexpr (LOCAL) __hip_atomic_store((gu32*)dst, SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        else __hip_atomic_store((gu32*)dst, SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-            if (active) {
-                const int j = el >> 4, nn = el & 15;
-                const float* in = ins + i * 5 * NE + tid;
-                float dh = in[4 * NE];
-#pragma unroll
-                for (int w16 = 0; w16 < 16; ++w16) dh += red[rb][w16][j][ebl][nn];
-                const float c_t = cells[((n + RING - 1) % RING) * NE + tid], c_prev = s > 0 ? cells[i * NE + tid] : 0.f;
-                float carry;
-                lstm_cell_bwd<true>(dh, dc_carry, in[0], in[NE], in[2 * NE], in[3 * NE], c_t, c_prev, da, carry);
-                dc_carry = carry;
-            }
-            // ---- publish dgates_s: one granule per gate per even unit (k = gate*H + unit)
-            if constexpr (BARE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the resets above have reached the L2
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float nb = __uint_as_float(row_shl<1>(__float_as_uint(da[g])));
-                if ((el & 1) == 0) {
-                    if constexpr (BARE) {
-                        unsigned* dst = bare0 + m3 * DW_PER_GROUP + bare_index<RPGP, CPW>(ebl, g * PH + eu);
-                        const unsigned val = pack_op16x2(da[g], nb);
-                        if constexpr (LOCAL) __hip_atomic_store((gu32*)dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        else __hip_atomic_store((gu32*)dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else {
-                        const unsigned long long gran = ((unsigned long long)(unsigned)(n + 1) << 32) | pack_op16x2(da[g], nb);
-                        unsigned long long* dst = p.dgran + ((size_t)(n & 1) * NG + grp) * GRAN_PER_GROUP + gran_index<RPGP, CPW>(ebl, g * PH + eu);
-                        if constexpr (LOCAL) __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        else __hip_atomic_store((gu64*)dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-            if (prof) st3 = wall_clock64();
-            float* o = outs + (n & 1) * 4 * NE + tid;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) o[g * NE] = da[g];
-        }
-        if (prof && n < 1024) {
-            long* o = p.prof + ((size_t)n * 4 + wave) * 5;
-            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = npass;
-        }
-        m3 = m3 == 2 ? 0 : m3 + 1;
-    }
-    if (dead) {
-        if (lane == 0) atomicExch(p.status, 1);
-        return;
-    }
-    __syncthreads();
-    if (tg > 0) store_outputs(tg - 1);
-    if (WF32 && ev)                                                     // pad rows beyond the group's longest sequence
-        for (int t = tg; t < T; ++t) {
-            float* dg = p.dgx + ((size_t)t * LB + eb) * 4 * PH + eu;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) dg[(size_t)g * PH] = 0.f;
-        }
-    if constexpr (WIMG) {
-        if (ovalid) {                                                   // bias gradient; the utterance's zero separator row
-            unsigned short* ip = p.dimg + (size_t)(ooff + olen) * p.dimg_ld + ou;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                atomicAdd(p.dbias + g * PH + ou, bsum[g]);
-                ip[g * PH] = 0;
-            }
-        }
-        // zero rows behind the last utterance up to ceil256(R + 32) (gemm_bf16.hip mapped_rows): workgroup w takes rows R + w, R + w + 256
-        int R = 0;
-        for (int bb = 0; bb < B; ++bb) R += p.lens[bb] + 1;
-        int Rz = (R + 32 + 255) & ~255;
-        Rz = Rz < p.dimg_rows ? Rz : p.dimg_rows;
-        for (int r = R + grp * CPG + q; r < Rz; r += NCU) {
-            uint4* row = reinterpret_cast<uint4*>(p.dimg + (size_t)r * p.dimg_ld);
-            for (int c = tid; c < 4 * PH / 8; c += 256) row[c] = make_uint4(0u, 0u, 0u, 0u);
-        }
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // Backward recurrence, REDUCE-SCATTER form (round 4).  The all-gather form above hands the group's dgates vector (RPGP x 4H
@@ -821,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs_k(PersistBwdP p) {
     }
     tg = tg < T ? tg : T;
 
-    // output role of waves 2-3 (as in lstm_persist_bwd_k)
+    // output role of waves 2-3: thread tid >= 128 stores the dgates row / image entries of the previous step
     const int oe = tid - NE;
     const int ob = b0 + oe / UPC, ou = q * UPC + oe % UPC;
     const bool ovalid = tid >= NE && ob < B;
@@ -1126,8 +411,8 @@ long* ftint_persist_prof = nullptr;                  // shared with the fp16 bui
 extern long* ftint_persist_prof;
 #endif
 #define g_persist_prof ftint_persist_prof
-// debug hook (scripts/exp/lstm_persist_bench.py): device buffer of 1024 x 4 x 5 int64 that the NEXT forward launches fill
-// with per-step phase stamps of workgroup (group 0, slot 0); nullptr switches it off
+// debug hook (scripts/exp/lstm_roles_bench.py): device buffer of 1024 x 4 x 5 int64 that the NEXT backward launches fill with per-step
+// phase stamps of workgroup (group 0, slot 0); nullptr switches it off
 #if FT_OPFMT == 0
 extern "C" int ft_lstm_persist_debug_prof(void* dev_buf) { g_persist_prof = reinterpret_cast<long*>(dev_buf); return FT_OK; }
 
@@ -1147,92 +432,13 @@ extern "C" int ft_lstm_persist_supported(int B, int H) {
 
 extern "C" size_t ft_lstm_persist_workspace_bytes(int B, int H) {
     (void)B;
-    // W_hh fragment image + granule buffers (2 parities x 32 rows x K/2 granules x 8 B, independent of NG; K = H forward,
-    // 4H backward) + census counters
-    // (the reduce-scatter backward, transport 21, takes 2 parities x 8 groups x [32 x 32 x 32 x 4] fp32 partials = 8 MB instead)
-    const size_t gran = (size_t)2 * 32 * (4 * H / 2) * 8, rs = (size_t)2 * 8 * 32 * 32 * 32 * 4 * sizeof(float);
-    return al256p((size_t)4 * H * H * 2) + al256p(gran > rs ? gran : rs) + 256;
+    // W_hh fragment image + the partial buffers of the reduce-scatter hand-off (2 parities x 8 groups x [32 x 32 x 32 x 4] fp32 = 8 MB)
+    // + census counters
+    return al256p((size_t)4 * H * H * 2) + al256p((size_t)2 * 8 * 32 * 32 * 32 * 4 * sizeof(float)) + 256;
 }
 #endif
 
-// ldb = batch rows per time step in memory (B, or the width of the batch this launch covers a slice of: ft_lstm_persist_fwd_rows)
-static int persist_fwd_impl(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
-                            float* gates, float* cell, void* work, int32_t* status, int T, int B, int ldb, int H, int ng,
-                            void* stream) {
-    FT_CHECK_ARG(gx && w_hh && lens && y && work && status && ldb >= B);
-    FT_CHECK_ARG((gates == nullptr) == (cell == nullptr));
-    FT_CHECK_ARG(T >= 0 && ldy >= H && reinterpret_cast<uintptr_t>(work) % 256 == 0 && reinterpret_cast<uintptr_t>(gx) % 16 == 0);
-    // ng: 1 / 9 = XCD-local transport (nt / sc1 loads) with tagged granules; 11 / 19 = the same with BARE operand pairs and the sentinel
-    // protocol.  (Round 5 pruned what no box has run since round 3: the placement-independent fabric transports 8 | 4 | 2 | 18 | 14 | 12
-    // -- the kernel templates still carry their LOCAL = false branches -- and the M-split kernel of transport 31, a measured loser.)
-    const bool bare = ng > 10;
-    const int ngb = bare ? ng - 10 : ng;
-    FT_CHECK_ARG(ngb == 1 || ngb == 9);
-    if (!ft_lstm_persist_supported(B, H))
-        return ft_fail(FT_EUNSUPPORTED, "ft_lstm_persist_fwd: needs H == 1024, B <= 32 and a 256-CU device (H=%d B=%d)", H, B);
-    if (T == 0) return FT_OK;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    char* base = reinterpret_cast<char*>(work);
-    unsigned short* wfrag = reinterpret_cast<unsigned short*>(base);
-    unsigned long long* hgran = reinterpret_cast<unsigned long long*>(base + al256p((size_t)4 * H * H * 2));
-    // tagged: 2 parities x 32 rows x H/2 granules x 8 B; bare: 3 buffers x 32 rows x H/2 dwords (smaller)
-    const size_t gran_bytes = al256p((size_t)2 * 32 * (H / 2) * 8);
-    unsigned* census = reinterpret_cast<unsigned*>(base + al256p((size_t)4 * H * H * 2) + al256p((size_t)2 * 32 * (4 * H / 2) * 8));
-    // tags = 0: no epoch matches (epochs start at 1); bare: sentinels.  Preset by the fragment kernel (lstm_images.h: WfragAux)
-    const WfragAux aux{reinterpret_cast<uint4*>(hgran), (unsigned long)(gran_bytes / 16), bare ? 0xFFFFFFFFu : 0u, census};
-    hipLaunchKernelGGL(make_wfrag_fwd_ug, dim3(2048), dim3(256), 0, st, w_hh, wfrag, H, aux);
-    PersistP p{gx, lens, y, (long)ldy, gates, cell, wfrag, hgran, status, census, T, B, 100000000L / 2, g_persist_prof, ldb};   // 0.5 s
-    // dynamic LDS: reduce buffers (2*4*TPC*RPGP*20 = 2*4*32*20 floats) + SB staged gx rows + 2 output rows
-    const size_t lds = sizeof(float) * ((size_t)2 * 4 * 32 * 20 + (size_t)SB * 4 * 128 + (size_t)2 * 6 * 128);
-    auto launch = [&](auto kern) -> int {
-        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(NCU), dim3(256), lds, st, p);
-        return FT_OK;
-    };
-    int rc;
-    if (!bare) rc = ngb == 1 ? launch(lstm_persist_fwd_k<8, true, 2, false>) : launch(lstm_persist_fwd_k<8, true, 16, false>);
-    else rc = ngb == 1 ? launch(lstm_persist_fwd_k<8, true, 2, true>) : launch(lstm_persist_fwd_k<8, true, 16, true>);
-    if (rc != FT_OK) return rc;
-    FT_CHECK_LAUNCH();
-    return FT_OK;
-}
-
-extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
-                                   const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
-                                   void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream);
-
-extern "C" int FT_OPNAME(ft_lstm_persist_fwd)(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
-                                   float* gates, float* cell, void* work, int32_t* status, int T, int B, int H, int ng,
-                                   void* stream) {
-    return persist_fwd_impl(gx, w_hh, lens, y, ldy, gates, cell, work, status, T, B, B, H, ng, stream);
-}
-extern "C" int FT_OPNAME(ft_lstm_persist_fwd_rows)(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
-                                   float* gates, float* cell, void* work, int32_t* status, int T, int B, int ldb, int H, int ng,
-                                   void* stream) {
-    return persist_fwd_impl(gx, w_hh, lens, y, ldy, gates, cell, work, status, T, B, ldb, H, ng, stream);
-}
-
-static int persist_bwd_impl(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
-                            const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int ldb, int H, int ng,
-                            void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream);
-
-extern "C" int FT_OPNAME(ft_lstm_persist_bwd)(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
-                                   const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
-                                   void* stream) {
-    return persist_bwd_impl(dy, ldy, w_hh, lens, gates, cell, dgx, work, status, T, B, B, H, ng, nullptr, 0, 0, nullptr, stream);
-}
-extern "C" int FT_OPNAME(ft_lstm_persist_bwd_rows)(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
-                                   const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int ldb, int H, int ng,
-                                   void* stream) {
-    return persist_bwd_impl(dy, ldy, w_hh, lens, gates, cell, dgx, work, status, T, B, ldb, H, ng, nullptr, 0, 0, nullptr, stream);
-}
-
-extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
-                                   const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
-                                   void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream) {
-    return persist_bwd_impl(dy, ldy, w_hh, lens, gates, cell, dgx, work, status, T, B, B, H, ng, dimg, dimg_ld, dimg_rows, dbias, stream);
-}
-
+// ldb = batch rows per time step in memory (B here; the kernel takes the stride separately)
 static int persist_bwd_impl(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
                             const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int ldb, int H, int ng,
                             void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream) {
@@ -1240,11 +446,9 @@ static int persist_bwd_impl(const float* dy, int64_t ldy, const float* w_hh, con
     FT_CHECK_ARG(dimg == nullptr || (dbias && dimg_ld >= 4 * (int64_t)H && dimg_ld % 8 == 0 && dimg_rows >= (int64_t)T * B + B &&
                                      reinterpret_cast<uintptr_t>(dimg) % 16 == 0));
     FT_CHECK_ARG(T >= 0 && ldy >= H && reinterpret_cast<uintptr_t>(work) % 256 == 0);
-    // ng = 21: the reduce-scatter form (lstm_persist_bwd_rs_k: XCD-local, fp32 partials tagged in the mantissa LSB)
-    const bool rsform = ng == 21;
-    const bool bare = ng > 10 && !rsform;
-    const int ngb = rsform ? 1 : (bare ? ng - 10 : ng);
-    FT_CHECK_ARG(ngb == 1 || ngb == 9);
+    // ng: 21 = the reduce-scatter form (lstm_persist_bwd_rs_k: XCD-local, fp32 partials tagged in the mantissa LSB) -- the one
+    // transport left (round 6 removed the all-gather kernels 1 / 9 / 11 / 19); 1 is accepted as "the default"
+    FT_CHECK_ARG(ng == 21 || ng == 1);
     if (!ft_lstm_persist_supported(B, H))
         return ft_fail(FT_EUNSUPPORTED, "ft_lstm_persist_bwd: needs H == 1024, B <= 32 and a 256-CU device (H=%d B=%d)", H, B);
     if (T == 0) return FT_OK;
@@ -1252,47 +456,40 @@ static int persist_bwd_impl(const float* dy, int64_t ldy, const float* w_hh, con
     char* base = reinterpret_cast<char*>(work);
     unsigned short* wTfrag = reinterpret_cast<unsigned short*>(base);
     unsigned long long* dgran = reinterpret_cast<unsigned long long*>(base + al256p((size_t)4 * H * H * 2));
-    const size_t rs_bytes = (size_t)2 * 8 * 32 * 32 * 32 * 4 * sizeof(float);
-    const size_t gran_bytes = al256p(rsform ? rs_bytes : (size_t)2 * 32 * (4 * H / 2) * 8);
+    const size_t gran_bytes = al256p((size_t)2 * 8 * 32 * 32 * 32 * 4 * sizeof(float));
     unsigned* census = reinterpret_cast<unsigned*>(base + ft_lstm_persist_workspace_bytes(B, H) - 256);
-    const WfragAux aux{reinterpret_cast<uint4*>(dgran), (unsigned long)(gran_bytes / 16), (bare || rsform) ? 0xFFFFFFFFu : 0u, census};
-    if (rsform) hipLaunchKernelGGL(make_wfrag_rs, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H, aux);
-    else hipLaunchKernelGGL(make_wfrag_bwd, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H, aux);
+    // hand-off preset (0xFF: tag 1 != the tag of steps 0 / 1) and census zero ride on the fragment kernel (lstm_images.h: WfragAux)
+    const WfragAux aux{reinterpret_cast<uint4*>(dgran), (unsigned long)(gran_bytes / 16), 0xFFFFFFFFu, census};
+    hipLaunchKernelGGL(make_wfrag_rs, dim3(2048), dim3(256), 0, st, w_hh, wTfrag, H, aux);
     PersistBwdP p{dy, (long)ldy, lens, gates, cell, dgx, wTfrag, dgran, status, census, T, B, 100000000L / 2, g_persist_prof,
                   reinterpret_cast<unsigned short*>(dimg), (long)dimg_ld, (int)dimg_rows, dbias, ldb};
-    // dynamic LDS: 16-partial reduce (2 x 16 x 32 unit-rows... = 2*16*TL*RPGP*17 = 2*16*8*17 floats) + staged steps
-    const size_t lds = sizeof(float) * ((size_t)2 * 16 * 8 * 17 + (size_t)RING * 5 * 128 + (size_t)RING * 128 + (size_t)2 * 4 * 128);
-    auto launch = [&](auto kern) -> int {
-        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(NCU), dim3(256), lds, st, p);
+    // (the ring is filled by 16-byte-per-lane LDS-DMA pieces: rows of the saved tensors and of dy 16-byte aligned)
+    FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dy) % 16 == 0 && ldy % 4 == 0 && reinterpret_cast<uintptr_t>(gates) % 16 == 0 &&
+                 reinterpret_cast<uintptr_t>(cell) % 16 == 0);
+    // LDS: 8 x 128 gather sums + 1024 dwords of dgates operands (16-row A tiles) + the ring (5 + 1 rows per slot) + 2 output rows
+    const size_t lds_rs = sizeof(float) * ((size_t)8 * 128 + 1024 + (size_t)RING * 5 * 128 + (size_t)RING * 128 + (size_t)2 * 4 * 128);
+    auto launch_rs = [&](auto kern) -> int {
+        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs));
+        hipLaunchKernelGGL(kern, dim3(NCU), dim3(256), lds_rs, st, p);
         return FT_OK;
     };
-    int rc;
     const int out = dimg == nullptr ? 0 : (dgx ? 1 : 2);
-    if (rsform) {
-        // (the ring is filled by 16-byte-per-lane LDS-DMA pieces: rows of the saved tensors and of dy 16-byte aligned)
-        FT_CHECK_ARG(reinterpret_cast<uintptr_t>(dy) % 16 == 0 && ldy % 4 == 0 && reinterpret_cast<uintptr_t>(gates) % 16 == 0 &&
-                     reinterpret_cast<uintptr_t>(cell) % 16 == 0);
-        // LDS: 8 x 128 gather sums + 1024 dwords of dgates operands (16-row A tiles) + the ring (5 + 1 rows per slot) + 2 output rows
-        const size_t lds_rs = sizeof(float) * ((size_t)8 * 128 + 1024 + (size_t)RING * 5 * 128 + (size_t)RING * 128 + (size_t)2 * 4 * 128);
-        auto launch_rs = [&](auto kern) -> int {
-            FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs));
-            hipLaunchKernelGGL(kern, dim3(NCU), dim3(256), lds_rs, st, p);
-            return FT_OK;
-        };
-        if (g_persist_prof) rc = launch_rs(lstm_persist_bwd_rs_k<0, true>);      // debug stamps: fp32 rows, whatever was asked for
-        else rc = out == 0 ? launch_rs(lstm_persist_bwd_rs_k<0>) : out == 1 ? launch_rs(lstm_persist_bwd_rs_k<1>) : launch_rs(lstm_persist_bwd_rs_k<2>);
-        if (rc != FT_OK) return rc;
-        FT_CHECK_LAUNCH();
-        return FT_OK;
-    }
-#define FT_PBWD(NG_, LOCAL_, LAUX_, BARE_) \
-    (out == 0 ? launch(lstm_persist_bwd_k<NG_, LOCAL_, LAUX_, BARE_, 0>) : out == 1 ? launch(lstm_persist_bwd_k<NG_, LOCAL_, LAUX_, BARE_, 1>) \
-                                                                                  : launch(lstm_persist_bwd_k<NG_, LOCAL_, LAUX_, BARE_, 2>))
-    if (!bare) rc = ngb == 1 ? FT_PBWD(8, true, 2, false) : FT_PBWD(8, true, 16, false);
-    else rc = ngb == 1 ? FT_PBWD(8, true, 2, true) : FT_PBWD(8, true, 16, true);
-#undef FT_PBWD
+    int rc;
+    if (g_persist_prof) rc = launch_rs(lstm_persist_bwd_rs_k<0, true>);      // debug stamps: fp32 rows, whatever was asked for
+    else rc = out == 0 ? launch_rs(lstm_persist_bwd_rs_k<0>) : out == 1 ? launch_rs(lstm_persist_bwd_rs_k<1>) : launch_rs(lstm_persist_bwd_rs_k<2>);
     if (rc != FT_OK) return rc;
     FT_CHECK_LAUNCH();
     return FT_OK;
+}
+
+extern "C" int FT_OPNAME(ft_lstm_persist_bwd)(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
+                                   const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
+                                   void* stream) {
+    return persist_bwd_impl(dy, ldy, w_hh, lens, gates, cell, dgx, work, status, T, B, B, H, ng, nullptr, 0, 0, nullptr, stream);
+}
+
+extern "C" int FT_OPNAME(ft_lstm_persist_bwd_img)(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
+                                   const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
+                                   void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream) {
+    return persist_bwd_impl(dy, ldy, w_hh, lens, gates, cell, dgx, work, status, T, B, B, H, ng, dimg, dimg_ld, dimg_rows, dbias, stream);
 }

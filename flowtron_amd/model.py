@@ -567,8 +567,30 @@ class Flowtron(nn.Module):
         return x, log_s_list, gate, attns_list, attns_logprob_list, None, None, None
 
     def infer(self, residual, speaker_ids, text, temperature=1.0, gate_threshold=0.5, attns=None, attn_prior=None):
-        """residual [1,M,N], speaker_ids [1] or [1,1], text [1,L] -> (mel [1,M,N'], attention_weights)."""
+        """residual [B,M,N], speaker_ids [B] or [B,1], text [B,L] -> (mel [B,M,N'], attention_weights: per flow a list of N' rows
+        [B,1,L]).  The decode kernels are batch-1 chains (inference.py decodes one utterance).  A batch (the reference's loop takes any,
+        flowtron.py:775-828, 901-930) is decoded utterance by utterance through ALL flows and padded only at the very end: with a gate
+        layer every utterance stops at its OWN frame of the last flow (decoded first), and the flows behind it must see exactly that
+        utterance's frames -- padding the batch after each flow would put the shorter utterances' pad frames IN FRONT of their real
+        ones once the next (reversed) flow flips the tensor.  Frames behind an utterance's stop are zero; N' = the longest."""
         L.require_cuda(residual, text)
+        B = residual.shape[0]
+        if B > 1:
+            if attns is not None:
+                raise ValueError("forced alignments (attns=) are taken one utterance at a time")
+            sid = speaker_ids.reshape(B, -1)
+            outs = [self.infer(residual[b:b + 1], sid[b], text[b:b + 1], temperature, gate_threshold, None,
+                               None if attn_prior is None else attn_prior[b:b + 1]) for b in range(B)]
+            n = max(int(m.shape[2]) for m, _ in outs)
+            mel = residual.new_zeros(B, outs[0][0].shape[1], n, dtype=torch.float32)
+            Lk = text.shape[1]
+            atts = [residual.new_zeros(n, B, 1, Lk, dtype=torch.float32) for _ in self.flows]
+            for b, (m, aws) in enumerate(outs):
+                mel[b, :, :m.shape[2]] = m[0]
+                for f, rows in enumerate(aws):
+                    if rows:
+                        atts[f][:len(rows), b] = torch.stack([r.reshape(1, Lk) for r in rows])
+            return mel, [[a[t] for t in range(n)] for a in atts]
         with torch.no_grad():
             enc, _ = self._encode(speaker_ids, text, None)
             x = residual.permute(2, 0, 1).contiguous().float()

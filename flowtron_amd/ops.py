@@ -27,7 +27,7 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 
 
 import os as _os
-_BF16_IMAGES = _os.environ.get("FLOWTRON_GEMM_IMAGES", "1") != "0"
+_BF16_IMAGES = True        # large 16-bit GEMMs run from shared operand images (round 1; the switch was retired in round 6)
 
 
 def gemm_raw(A, B, Cm, M, N, K, sAm, sAk, sBk, sBn, ldc, bias=None, act=L.ACT_NONE, alpha=1.0, beta=0.0,
@@ -74,14 +74,14 @@ class RowMap:
 
 
 _COMPACT = _os.environ.get("FLOWTRON_GEMM_COMPACT", "1") != "0"
-_FUSE_ACT_BWD = _os.environ.get("FLOWTRON_FUSE_ACT_BWD", "1") != "0"    # activation backward inside the gradient's image pass
+_FUSE_ACT_BWD = True       # activation backward inside the gradient's image pass (round 4)
 # split-K on the encoder's FORWARD split-image GEMM (160 output tiles, K = 7 680).  With fp32 atomics (FLOWTRON_ENC_SPLITK=atomic: the
 # first form, -0.2 ms per step) the order of the atomics makes the forward itself differ from run to run (z up to 8e-4, bf16 gradients
 # up to 1e-2 rel-L2 on the same batch and weights: scripts/exp/noise_debug.py, profiles/r05b_forward_noise.log).  Default "det": the
 # slices' partial products side by side + a fixed-order reduction (FT_GEMM_SPLITK_DET) -- a forward pass is a function of its inputs;
 # "0": one slice
-_ENC_SPLITK = {"det": "det", "atomic": True, "1": True, "0": False}.get(_os.environ.get("FLOWTRON_ENC_SPLITK", "det"), "det")
-_CAT_IMAGES = _os.environ.get("FLOWTRON_GEMM_CAT", "1") != "0"      # a Linear over two inputs as ONE GEMM over a concatenated image
+_ENC_SPLITK = "det"
+_CAT_IMAGES = True         # a Linear over two inputs as ONE GEMM over a concatenated image (round 4)
 _PERSIST_IMG = _os.environ.get("FLOWTRON_LSTM_PERSIST_IMG", "1")      # 1: the persistent backward emits the dgates image INSTEAD of fp32 dgx where its only consumer is the projection's backward; both; 0
 
 
@@ -164,7 +164,11 @@ class Bf16Image:
             w["plan_next"][key] = W
         if w["armed"]:
             w["armed"] = False
-            plan = [(k, t) for k, t in w["plan"].items() if t.is_cuda and t.device == W.device and t.dtype == torch.float32 and t.is_contiguous()]
+            # (a planned tensor whose storage moved since the previous forward -- FlatArena flattening after the first forward, a p.data
+            #  swap -- or changed shape is dropped: its image would sit under a stale key that no request finds, or that a same-shape
+            #  tensor reusing the old address could pick up)
+            plan = [(k, t) for k, t in w["plan"].items() if t.is_cuda and t.device == W.device and t.dtype == torch.float32 and t.is_contiguous()
+                    and t.data_ptr() == k[0] and tuple(t.shape) == k[1]]
             for lo in range(0, len(plan), 32):
                 part = plan[lo:lo + 32]
                 by_fmt = {}
@@ -216,7 +220,7 @@ class Bf16Image:
 
 
 # weight images of one forward pass in one launch (Bf16Image.of_weight): the plan = what the previous forward of the same model asked for
-_WIMG_ON = _os.environ.get("FLOWTRON_WEIGHT_TABLE", "1") != "0"
+_WIMG_ON = True
 _WIMG = {"plan": {}, "plan_next": None, "cache": {}, "armed": False, "plans": None}
 
 
@@ -370,7 +374,7 @@ def _require_written(t):
 # the outputs of a backward pass now come out of ONE zeroed allocation sized by the previous pass's demand, and the GEMMs run with
 # beta = 1 ("C holds the addend").  FLOWTRON_ZERO_SLAB=0: one zeroed tensor per output.
 _ZSLAB = {"buf": None, "off": 0, "need": 0, "last": 0, "task": None}
-_ZSLAB_ON = _os.environ.get("FLOWTRON_ZERO_SLAB", "1") != "0"
+_ZSLAB_ON = True
 
 
 def zeroed(shape, device):
@@ -394,7 +398,7 @@ def zeroed(shape, device):
     return torch.zeros(shape, device=device, dtype=torch.float32)
 
 
-_ARENA_GRADS = _os.environ.get("FLOWTRON_ARENA_GRADS", "1") != "0"
+_ARENA_GRADS = True
 
 
 def weight_grad_out(W):
@@ -424,7 +428,7 @@ def weight_grad_out(W):
 # Caveat, by construction outside this model: if a FOREIGN owner (a user hook that stores gradient tensors) keeps the first buffer
 # alive AND a third contribution of another kind makes the engine replace it by an out-of-place sum, a later accumulation would
 # go into the orphan -- h_att and the encoder output have image-path consumers only; FLOWTRON_DX_INPLACE=0 restores autograd's adds.
-_DX_INPLACE = _os.environ.get("FLOWTRON_DX_INPLACE", "1") != "0"
+_DX_INPLACE = True
 _DXACC = {"task": None, "bufs": {}}
 
 
@@ -653,8 +657,7 @@ class LinearFn(torch.autograd.Function):
         return (dW, db, None, None, None, None, *dxs)
 
 
-_PERSIST_FWD_DEFAULT = "bare"
-_GATE_ON_CAT = _os.environ.get("FLOWTRON_GATE_ON_CAT", "1") != "0"   # the gate layer on the decoder input projection's concatenated image
+_GATE_ON_CAT = True        # the gate layer on the decoder input projection's concatenated image (round 4)
 
 
 def linear_gate_fusable(mode, rowmap, xs, N):
@@ -963,34 +966,15 @@ def check_persist_status(raise_on_failure=True):
     return ok
 
 
-def _persist_fwd_code(ng):
-    """transport code ft_lstm_persist_fwd is launched with.  FLOWTRON_LSTM_PERSIST = 1 (XCD-local groups):
-    FLOWTRON_LSTM_PERSIST_FWD = bare (default since the end of round 4) -> 11, the K-split kernel with bare operand pairs (sentinel
-    protocol, half the gather bytes; 1.84 against 1.87 us per step), ksplit -> 1 (tagged granules).  Bit-identical.  (The M-split
-    kernel of round 4, transport 31, was a measured loser -- 2.05 against 1.92 us per step -- and is gone since round 5.)"""
-    fwd_form = _os.environ.get("FLOWTRON_LSTM_PERSIST_FWD", _PERSIST_FWD_DEFAULT)
-    if ng == 1 and fwd_form == "bare":
-        return 11
-    return ng
+PERSIST_BWD_CODE = 21        # ft_lstm_persist_bwd's one transport: the reduce-scatter kernel (csrc/lstm_persist.hip)
 
 
-def _persist_bwd_code(ng):
-    """transport code ft_lstm_persist_bwd / _bwd_img are launched with: FLOWTRON_LSTM_PERSIST_BWD = rs (default) -> 21, the
-    reduce-scatter kernel (lstm_persist_bwd_rs_k); bare -> 11, tagged -> 1: the all-gather kernels."""
-    bwd_form = _os.environ.get("FLOWTRON_LSTM_PERSIST_BWD", "rs")
-    if ng == 1 and bwd_form == "rs":
-        return 21
-    if ng == 1 and bwd_form != "tagged":
-        return 11
-    return ng if ng in (1, 9, 11, 19, 21) else (11 if ng > 10 else 1)
-
-
-def _persist_selftest(device, ng):
-    """tiny forward + backward through the persistent kernels TRAINING LAUNCHES -- the effective forward and backward transport
-    codes of this environment (default: 11 and the reduce-scatter kernel 21, whose LDS size, workspace and sentinel protocol differ
-    from transport 1's), the backward once through ft_lstm_persist_bwd and once through the image-only entry the step itself uses
-    (ft_lstm_persist_bwd_img) -- checked synchronously, once per device (a device where only the tagged kernels are
-    co-resident must not pass the self-test and then drop its first optimizer steps)."""
+def _persist_selftest(device, ng=1):
+    """tiny forward + backward through the persistent kernels the TRAINING step launches -- the roles forward at 4 and at 8 rows per
+    XCD group with two roles (csrc/lstm_roles.hip: its own launch context and LDS sizes), the reduce-scatter backward once through
+    ft_lstm_persist_bwd and once through the image-only entry the step itself uses (ft_lstm_persist_bwd_img) -- checked
+    synchronously, once per device (a device where only some of the kernels are co-resident must not pass the self-test
+    and then drop its first optimizer steps)."""
     H, B, T = 1024, 8, 3
     f = dict(device=device, dtype=torch.float32)
     gx, w = torch.zeros(T, B, 4 * H, **f), torch.zeros(4 * H, H, **f)
@@ -999,22 +983,25 @@ def _persist_selftest(device, ng):
     dgx = torch.empty(T, B, 4 * H, **f)
     work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=device, dtype=torch.uint8)
     st = _persist_state(device)
+    st.usable = True                     # (roles_launch consults the state it is about to establish)
     try:
-        L.check(L.lib().ft_lstm_persist_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(work),
-                                            L.ptr(st.status), T, B, H, _persist_fwd_code(ng), L.stream()), "ft_lstm_persist_fwd")
+        wimg = roles_wimg(w, L.FT_BF16, False)
+        roles_launch([fwd_role(gx, lens, y, gates, cell, wimg)], 4, L.FT_BF16, device)
+        roles_launch([fwd_role(gx, lens, y, gates, cell, wimg), fwd_role(gx, lens, y, gates, cell, wimg)], 8, L.FT_BF16, device)
         L.check(L.lib().ft_lstm_persist_bwd(L.ptr(y), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx), L.ptr(work),
-                                            L.ptr(st.status), T, B, H, _persist_bwd_code(ng), L.stream()), "ft_lstm_persist_bwd")
+                                            L.ptr(st.status), T, B, H, PERSIST_BWD_CODE, L.stream()), "ft_lstm_persist_bwd")
         if _PERSIST_IMG != "0":
             rows, ld = T * B + B, (4 * H + 255) // 256 * 256
             dimg = torch.empty(L.lib().ft_bf16_image_bytes(rows, 4 * H), device=device, dtype=torch.uint8)
             dbias = torch.zeros(4 * H, **f)
             L.check(L.lib().ft_lstm_persist_bwd_img(L.ptr(y), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), None, L.ptr(work),
-                                                    L.ptr(st.status), T, B, H, _persist_bwd_code(ng), L.ptr(dimg), ld,
+                                                    L.ptr(st.status), T, B, H, PERSIST_BWD_CODE, L.ptr(dimg), ld,
                                                     dimg.numel() // (2 * ld), L.ptr(dbias), L.stream()), "ft_lstm_persist_bwd_img")
         ok = int(st.status.item()) == 0
     except RuntimeError:
         ok = False
     st.status.zero_()
+    st.event = None
     if not ok:
         import warnings
         warnings.warn("flowtron_amd: the persistent LSTM kernels are not usable on %s (grid not co-resident / XCD census failed); "
@@ -1033,14 +1020,12 @@ def persist_usable(device):
 
 
 def lstm_persist_groups(B, H, reverse, mode, device=None):
-    """transport / group code of the persistent recurrence kernels for this shape (0 = use the launch-per-step kernels).
-    FLOWTRON_LSTM_PERSIST: 0 = off, 1 (default) = 8 XCD-local groups, 9 = the same with sc1 polls; + 10 (11, 19) = the same transport
-    with BARE operand pairs (sentinel protocol, half the hand-off bytes; csrc/lstm_persist.hip).  The placement-independent fabric
-    transports (8 | 4 | 2 | 18 | 14 | 12: never run on any box since round 3) were pruned in round 5: a device whose XCD census does
-    not come out fails the self-test and uses the launch-per-step kernels."""
+    """1 when the persistent recurrence kernels take this shape in one launch per sequence (H 1024, B <= 32, forward direction,
+    16-bit operands, a device that passed the self-test), else 0 = the launch-per-step kernels.  FLOWTRON_LSTM_PERSIST=0 switches
+    the persistent kernels off (the yardstick path of the tests)."""
     ng = int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "1"))
-    if ng not in (0, 1, 9, 11, 19):
-        raise ValueError("FLOWTRON_LSTM_PERSIST must be 0, 1, 9, 11 or 19 (the fabric transports were removed in round 5)")
+    if ng not in (0, 1):
+        raise ValueError("FLOWTRON_LSTM_PERSIST must be 0 or 1 (the transport variants were removed in round 6)")
     if not ng or reverse or not L.is16(mode) or not L.lib().ft_lstm_persist_supported(B, H):
         return 0
     if device is not None:
@@ -1049,24 +1034,16 @@ def lstm_persist_groups(B, H, reverse, mode, device=None):
             st.usable = _persist_selftest(device, ng)
         if not st.usable:
             return 0
-    return ng
-
-
-_PERSIST_WIDE = _os.environ.get("FLOWTRON_LSTM_PERSIST_WIDE", "1") != "0"
+    return 1
 
 
 def lstm_persist_slices(B, H, reverse, mode, device=None):
-    """(transport code, [(b0, rows)]) for a batch wider than one persistent launch holds (B > 32): the batch is walked in slices of
-    <= 32 rows, one persistent launch each (ft_lstm_persist_*_rows: 1.6-1.8 us per step and slice against 6.8 us per step of the
-    launch-per-step kernels at B = 48 -- the configs[1] step at B = 48: 47.9 against 89.6 ms, profiles/r05b_wide_batch.log; those
-    kernels stop at B = 64, so beyond that this is also the only path that does not go through batch chunks, lstm_layer).
-    None: one launch suffices, or the shape is not the persistent kernels'."""
-    if not _PERSIST_WIDE or B <= 32:
-        return None
-    ng = lstm_persist_groups(32, H, reverse, mode, device)
-    if not ng:
-        return None
-    return ng, [(b0, min(32, B - b0)) for b0 in range(0, B, 32)]
+    """True for a batch wider than the 4-row kernels hold (B > 32) where the roles kernels apply: 8 rows per XCD group up to B 64, 16
+    up to 128 per launch forward / slices of 64 backward (roles_plan; 1.93 us per step at B 64 against 2 x 1.76 for two sliced launches
+    of the round-5 kernel, 6.8 us for the launch-per-step kernels at B 48).  False: one launch suffices, or the shape is not theirs."""
+    if B <= 32:
+        return False
+    return bool(lstm_persist_groups(32, H, reverse, mode, device))
 
 
 def bilstm_persist_ok(B, H, mode, device):
@@ -1074,7 +1051,7 @@ def bilstm_persist_ok(B, H, mode, device):
     passed the self-test; FLOWTRON_BILSTM_PERSIST=0 or FLOWTRON_LSTM_PERSIST=0 keep the launch-per-step pair chain"""
     # (the kernels form their groups from the XCD census like transports 1 / 9: not for the placement-independent fabric
     # transports 8 / 4 / 2, which are what one selects on a device where the census cannot come out)
-    if _os.environ.get("FLOWTRON_BILSTM_PERSIST", "1") == "0" or int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "1")) not in (1, 9, 11, 19):
+    if int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "1")) != 1:
         return False
     if not L.is16(mode) or not L.lib().ft_bilstm_persist_supported(B, H):
         return False
@@ -1154,9 +1131,6 @@ def roles_launch(roles, R, mode, device, backward=False, H=1024):
     L.check(fn(arr, len(roles), R, c.reset_rows, L.ptr(c.buf), c.phase[k], L.ptr(st.status), H, L.stream()), "ft_lstm_roles")
     c.phase[k] += 1
     _persist_arm(st)
-
-
-_ROLES = _os.environ.get("FLOWTRON_LSTM_ROLES", "1") != "0"          # the R / window / role kernels (csrc/lstm_roles.hip) where they win
 
 
 def roles_plan(B, backward):
@@ -1333,7 +1307,7 @@ def _pair_backward_sequential(ctx, dy1, w_img, img_only):
     H4, mode, rm = 4 * H, ctx.mode, ctx.rowmap
     dev = dy1.device
     st = _persist_watch(dev)
-    code = _persist_bwd_code(int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "1")) or 1)
+    code = PERSIST_BWD_CODE
     work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=dev, dtype=torch.uint8)
 
     def recurrence(dy, g, c, w_hh):
@@ -1393,37 +1367,14 @@ class LSTMSeqFn(torch.autograd.Function):
         y = torch.empty(T, B, H, device=gx.device, dtype=torch.float32)
         gates = torch.empty(T, B, H4, device=gx.device, dtype=torch.float32)
         cell = torch.empty(T, B, H, device=gx.device, dtype=torch.float32)
-        ng = lstm_persist_groups(B, H, reverse, mode, gx.device)
-        wide = None if ng else lstm_persist_slices(B, H, reverse, mode, gx.device)
-        plan = roles_plan(B, False) if (ng or wide) and _ROLES else None
-        if plan:
-            # round 6 (csrc/lstm_roles.hip): rows per XCD group follow the batch -- B <= 32: 4 rows (1.62 us per step against 1.76 for the
-            # round-5 kernel), B <= 64: 8 rows in ONE launch (1.93 against 2 x 1.76), wider: slices of 128 rows at 16 per group (2.77
-            # against 4 x 1.76).  Bit-identical to the launch-per-step kernel for every geometry.
+        if lstm_persist_groups(B, H, reverse, mode, gx.device) or lstm_persist_slices(B, H, reverse, mode, gx.device):
+            # persistent forward recurrence (csrc/lstm_roles.hip, round 6): rows per XCD group follow the batch -- B <= 32: 4 rows, ONE
+            # launch per sequence (1.62 us per step; the round-5 kernel it replaced: 1.76), B <= 64: 8 rows in one launch (1.93 against
+            # 2 x 1.76 for two slices), wider: slices of 128 rows at 16 per group (2.77 against 4 x 1.76).  Bit-identical to the
+            # launch-per-step kernel for every geometry.
             wimg = roles_wimg(w_hh, mode, False)
-            for b0, nb, R in plan:
+            for b0, nb, R in roles_plan(B, False):
                 roles_launch([fwd_role(gx, lens, y, gates, cell, wimg, b0=b0, nb=nb)], R, mode, gx.device)
-        elif wide:
-            # B > 32: one persistent launch per slice of 32 rows, back to back (pointers offset to the slice's first row)
-            code = _persist_fwd_code(wide[0])
-            st = _persist_watch(gx.device)
-            work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(32, H), device=gx.device, dtype=torch.uint8)
-            for b0, nb in wide[1]:
-                L.check(L.op16("ft_lstm_persist_fwd_rows", mode)(gx.data_ptr() + 16 * H * b0, L.ptr(w_hh), lens.data_ptr() + 4 * b0,
-                                                                 y.data_ptr() + 4 * H * b0, H, gates.data_ptr() + 16 * H * b0,
-                                                                 cell.data_ptr() + 4 * H * b0, L.ptr(work), L.ptr(st.status), T, nb, B, H,
-                                                                 code, L.stream()), "ft_lstm_persist_fwd_rows")
-            _persist_arm(st)
-        elif ng:
-            # FLOWTRON_LSTM_PERSIST = 1 (XCD-local): FLOWTRON_LSTM_PERSIST_FWD = bare (default since the end of round 4) -> transport 11, the
-            # K-split kernel with bare operand pairs (half the gather bytes; 1.84 against 1.87 us per step once the operand moves sit in
-            # the MFMA gaps), ksplit -> transport 1 (tagged granules).  Bit-identical.
-            ng = _persist_fwd_code(ng)
-            st = _persist_watch(gx.device)
-            work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=gx.device, dtype=torch.uint8)
-            L.check(L.op16("ft_lstm_persist_fwd", mode)(L.ptr(gx), L.ptr(w_hh), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
-                                                L.ptr(work), L.ptr(st.status), T, B, H, ng, L.stream()), "ft_lstm_persist_fwd")
-            _persist_arm(st)
         else:
             work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device=gx.device, dtype=torch.uint8)
             L.check(L.lib().ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w_hh), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell),
@@ -1439,32 +1390,19 @@ class LSTMSeqFn(torch.autograd.Function):
         T, B, H = y.shape
         dgx = None                                   # allocated below unless the gradient leaves as an image only
         ng = lstm_persist_groups(B, H, ctx.reverse, ctx.mode, dy.device)
-        wide = None if ng else lstm_persist_slices(B, H, ctx.reverse, ctx.mode, dy.device)
+        wide = (not ng) and lstm_persist_slices(B, H, ctx.reverse, ctx.mode, dy.device)
         d_img_k, img_only = None, False
-        if wide and _ROLES:
-            # slices of 64 rows at 8 per XCD group (2.5 us per step against 2 x 1.65; 16 rows per group lose in the backward kernel:
-            # 7.2 us per step for 128 rows, profiles/r06_persist_rows_per_group.log)
+        if wide:
+            # slices of 64 rows at 8 per XCD group (2.5 us per step against 2 x 1.65 for two 32-row launches; 16 rows per group lose in the
+            # backward kernel: 7.2 us per step for 128 rows, profiles/r06_persist_rows_per_group.log)
             dgx = torch.empty(T, B, 4 * H, device=dy.device, dtype=torch.float32)
             wimg = roles_wimg(w_hh, ctx.mode, True)
             for b0, nb, R in roles_plan(B, True):
                 roles_launch([bwd_role(dy, lens, gates, cell, dgx, wimg, b0=b0, nb=nb)], R, ctx.mode, dy.device, backward=True)
-        elif wide:
-            code = _persist_bwd_code(wide[0])
-            st = _persist_watch(dy.device)
-            work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(32, H), device=dy.device, dtype=torch.uint8)
-            dgx = torch.empty(T, B, 4 * H, device=dy.device, dtype=torch.float32)
-            for b0, nb in wide[1]:
-                L.check(L.op16("ft_lstm_persist_bwd_rows", ctx.mode)(dy.data_ptr() + 4 * H * b0, H, L.ptr(w_hh), lens.data_ptr() + 4 * b0,
-                                                                     gates.data_ptr() + 16 * H * b0, cell.data_ptr() + 4 * H * b0,
-                                                                     dgx.data_ptr() + 16 * H * b0, L.ptr(work), L.ptr(st.status), T, nb, B, H,
-                                                                     code, L.stream()), "ft_lstm_persist_bwd_rows")
-            _persist_arm(st)
         elif ng:
-            # default (1): the forward recurrence keeps the all-gather of h as tagged granules; the backward one runs in REDUCE-SCATTER
-            # form (transport 21, round 4: 1.92 us per step against 2.84 for the bare all-gather of dgates -- every CU multiplies its
-            # own dgates, fp32 partials cross the L2; equal to fp32 rounding).  FLOWTRON_LSTM_PERSIST_BWD=bare | tagged select the
-            # all-gather kernels, which ARE bit-identical to the launch-per-step kernel.
-            ng = _persist_bwd_code(ng)
+            # B <= 32: the REDUCE-SCATTER kernel (csrc/lstm_persist.hip, round 4: every CU multiplies its own dgates, fp32 partials cross
+            # the XCD's L2; 1.62 us per step -- the roles backward kernel at 4 rows measures 1.71, so this one stays)
+            ng = PERSIST_BWD_CODE
             st = _persist_watch(dy.device)
             work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device=dy.device, dtype=torch.uint8)
             rm = ctx.rowmap
@@ -1995,7 +1933,7 @@ class AttnCTCFn(torch.autograd.Function):
 # --------------------------------------------------------------------------
 # FlowtronLoss as ONE autograd node (flowtron.py:200-274): NLL + gate + attention-CTC of all flows
 # --------------------------------------------------------------------------
-FUSED_LOSS = _os.environ.get("FLOWTRON_FUSED_LOSS", "1") != "0"
+FUSED_LOSS = True
 
 
 def _ptr_array(ts):

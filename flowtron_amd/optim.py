@@ -31,7 +31,7 @@ import os
 from . import _lib as L
 from .dist import FlatArena
 
-_DEV_STEP = os.environ.get("FLOWTRON_RADAM_DEVSTEP", "1") != "0"      # bias-correction step count formed on the device (calls - drops)
+_DEV_STEP = True      # bias-correction step count formed on the device (calls - drops)
 
 
 class RAdam(Optimizer):
@@ -60,7 +60,7 @@ class RAdam(Optimizer):
         # per fp16 step) and skipping the call.  The fused kernel's guard drops the update exactly then (an Inf / NaN gradient makes
         # the global norm non-finite), and the step count the schedule uses is formed on the device from the drops
         # (ft_radam_step_dev), so the trajectory is the one of the skipped call.
-        self._step_supports_amp_scaling = os.environ.get("FLOWTRON_AMP_HOST_SKIP", "0") != "1"     # (=1: torch's host-side skip, for A/B)
+        self._step_supports_amp_scaling = True     # (=1: torch's host-side skip, for A/B)
         self._bind_state()
 
     def _bind_state(self):
@@ -89,6 +89,9 @@ class RAdam(Optimizer):
                     self.flat_m[off:off + k].zero_()
                     self.flat_v[off:off + k].zero_()
         self._step = step
+        # the loaded count is of APPLIED updates: drops the device counter holds that the host has not accounted for yet belong to the
+        # run before the load and must not be subtracted from it later
+        self._skipped_applied = int(self._skipped.item())
         self._bind_state()
 
     @staticmethod
@@ -166,6 +169,12 @@ class RAdam(Optimizer):
         # no clip_grad_norm_ this iteration: the guard still needs the norm (clip stays 0)
         if stale:
             self._norm_sq()
+        # GradScaler's own verdict folded into the guard on the device: if anything between unscale_ and step has sanitised
+        # the gradients (nan_to_num, a custom clip), the norm is finite again while the scaler still backs its scale off -- the
+        # reference would skip that step.  found_inf > 0 makes the norm non-finite: inf * 0 would be NaN, hence the where.
+        found_inf = getattr(self, "found_inf", None)
+        if found_inf is not None:
+            self.gnorm_sq.copy_(torch.where(found_inf.to(self.gnorm_sq.device).reshape(-1)[:1] > 0, torch.full_like(self.gnorm_sq, float("inf")), self.gnorm_sq))
         if _DEV_STEP:
             # the schedule's step count = calls - drops, formed on the device (no host read of the guard's decision)
             L.check(L.lib().ft_radam_step_dev(L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.flat_m), L.ptr(self.flat_v), a.numel,

@@ -258,27 +258,20 @@ int ft_lstm_seq_bwd(const float* dy, int64_t ldy, const float* w_hh, const int32
                     const float* gates, const float* cell, float* dgx, void* work,
                     int T, int B, int H, int reverse, int mode, void* stream);
 
-/* Persistent form of ft_lstm_seq_fwd (forward direction, bf16 MFMA operands, H == 1024, B <= 32, 256-CU device): ONE launch
- * for the whole sequence.  The chip is split into 8 independent batch groups = the 8 XCDs, formed at run time from the workgroups'
- * XCC ids; every CU keeps the 16-bit MFMA fragments of its W_hh rows in registers for all T steps and the members of a group
- * exchange h_t through their XCD's own L2 (csrc/lstm_persist.hip).
- * Transport codes (`ng`): 1 | 9 = 8-byte {epoch, 16-bit pair} granules, tag-checked (nt | sc1 loads); 11 | 19 = the same with BARE
- * operand pairs and a sentinel protocol (half the hand-off bytes; 11 is what flowtron_amd/ops.py launches by default).  Round 5
- * removed the placement-independent fabric transports (8 | 4 | 2 | 18 | 14 | 12) and the M-split kernel (31).
- * Results are bit-identical to ft_lstm_seq_fwd(FT_BF16) for every code.
+/* Persistent form of ft_lstm_seq_bwd (16-bit MFMA operands, H == 1024, B <= 32, 256-CU device): ONE launch for the whole sequence
+ * (csrc/lstm_persist.hip, lstm_persist_bwd_rs_k).  The chip is split into 8 independent batch groups = the 8 XCDs, formed at run
+ * time from the workgroups' XCC ids; every CU keeps the 16-bit MFMA fragments of its W_hh rows in registers for all T steps,
+ * multiplies its OWN dgates with them and the fp32 partials are REDUCE-SCATTERED through the XCD's own L2, tagged in the mantissa LSB:
+ * the same products as ft_lstm_seq_bwd(FT_BF16) in another, fixed association -- equal to fp32 rounding, deterministic.
+ * `ng` = 21 (1 is accepted as "the default"); round 6 removed the all-gather transports 1 | 9 | 11 | 19 and the round-2..5 forward
+ * kernel ft_lstm_persist_fwd / _fwd_rows / _bwd_rows: the forward recurrence and every batch wider than 32 run on ft_lstm_roles_* below.
  * `status` (device int32, zeroed by the caller once) is raised to 1 if a hand-off wait times out (grid not co-resident);
- * the caller must check it before trusting y.  work: ft_lstm_persist_workspace_bytes(), 256-byte aligned. */
+ * the caller must check it before trusting dgx.  work: ft_lstm_persist_workspace_bytes(), 256-byte aligned. */
 int ft_lstm_persist_supported(int B, int H);
 size_t ft_lstm_persist_workspace_bytes(int B, int H);
-int ft_lstm_persist_fwd(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
-                        float* gates, float* cell, void* work, int32_t* status, int T, int B, int H, int ng, void* stream);
-/* debug: device buffer [1024][4][5] int64 that subsequent ft_lstm_persist_fwd launches fill with per-step phase stamps
- * (100 MHz wall clock) of one workgroup; NULL switches it off (scripts/exp/lstm_persist_bench.py). */
+/* debug: device buffer [1024][4][5] int64 that subsequent ft_lstm_persist_bwd launches fill with per-step phase stamps
+ * (100 MHz wall clock) of one workgroup; NULL switches it off. */
 int ft_lstm_persist_debug_prof(void* dev_buf);
-/* Persistent form of ft_lstm_seq_bwd (same restrictions; ng = 1 | 9, + 10 = BARE operand pairs: the all-gather kernels,
- * bit-identical to ft_lstm_seq_bwd(FT_BF16); ng = 21 = the REDUCE-SCATTER kernel (XCD-local; fp32 partials tagged in the mantissa LSB,
- * the same products in another, fixed association: equal to fp32 rounding, deterministic -- what flowtron_amd/ops.py launches by
- * default)): dgx [T,B,4H] from dy, the saved gates / cell and W_hh.  Same workspace query. */
 int ft_lstm_persist_bwd(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
                         const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng, void* stream);
 /* The same launch, additionally leaving the 16-bit operand image of dgates in pack-by-length row order in `dimg` -- exactly what
@@ -286,19 +279,10 @@ int ft_lstm_persist_bwd(const float* dy, int64_t ldy, const float* w_hh, const i
  * row, batch-major; zero rows up to ceil256(R + 32); dimg: ft_bf16_image_bytes(T*B + B, 4H), row stride dimg_ld elements,
  * dimg_rows rows allocated) -- and ADDING the column sums of dgates (the bias gradient of the layer) to dbias[4H] (zeroed by the
  * caller; fp32 atomics, one per workgroup row and column).  The weight- and input-gradient GEMMs (flowtron.py:689-694's
- * autograd transposes) then start without a conversion pass over the 450 MB dgx.  dimg == NULL: identical to ft_lstm_persist_bwd. */
+ * autograd transposes) then start without a conversion pass over the 450 MB dgx.  dgx == NULL: the image only. */
 int ft_lstm_persist_bwd_img(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
                             const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng,
                             void* dimg, int64_t dimg_ld, int64_t dimg_rows, float* dbias, void* stream);
-/* Batches wider than one launch holds (B_total > 32; the reference's nn.LSTM has no such limit, flowtron.py:654-655, :689-694):
- * the same kernels over a SLICE of the batch -- rows b0 .. b0 + B - 1 (B <= 32) of tensors whose time steps are ldb = B_total rows
- * apart.  Every pointer (gx / y / gates / cell / dy / dgx and lens) is passed ALREADY OFFSET to row b0; a caller walks the batch in
- * slices of 32, one launch each, back to back (ops.LSTMSeqFn: 2 x 1.8 us per step at B 64 against 6.8 us at B 48 for the launch-per-step
- * kernels).  No image output (ft_bf16_image_rows on the fp32 dgx).  (ABI 12) */
-int ft_lstm_persist_fwd_rows(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
-                             float* gates, float* cell, void* work, int32_t* status, int T, int B, int ldb, int H, int ng, void* stream);
-int ft_lstm_persist_bwd_rows(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
-                             const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int ldb, int H, int ng, void* stream);
 
 /* Round 6 (ABI 13): the persistent recurrences with the geometry as PARAMETERS (csrc/lstm_roles.hip) -- rows per XCD group R = 4 | 8 | 16
  * (an MFMA tile has 16 rows; the kernels above use 4), a time WINDOW [t0, t1) per launch with the recurrent state carried through
@@ -638,8 +622,6 @@ int ft_lstm_seq_fwd_f16(const float* gx, const float* w_hh, const int32_t* lens,
 int ft_lstm_seq_bwd_f16(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens,
                     const float* gates, const float* cell, float* dgx, void* work,
                     int T, int B, int H, int reverse, int mode, void* stream);
-int ft_lstm_persist_fwd_f16(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
-                        float* gates, float* cell, void* work, int32_t* status, int T, int B, int H, int ng, void* stream);
 int ft_lstm_persist_bwd_f16(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
                         const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int H, int ng, void* stream);
 int ft_lstm_persist_bwd_img_f16(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
@@ -651,10 +633,6 @@ int ft_lstm_roles_fwd_f16(const ft_lstm_fwd_role* roles, int n_roles, int rows_p
                           int32_t* status, int H, void* stream);
 int ft_lstm_roles_bwd_f16(const ft_lstm_bwd_role* roles, int n_roles, int rows_per_group, int reset_rows, void* ctx, int phase,
                           int32_t* status, int H, void* stream);
-int ft_lstm_persist_fwd_rows_f16(const float* gx, const float* w_hh, const int32_t* lens, float* y, int64_t ldy,
-                                 float* gates, float* cell, void* work, int32_t* status, int T, int B, int ldb, int H, int ng, void* stream);
-int ft_lstm_persist_bwd_rows_f16(const float* dy, int64_t ldy, const float* w_hh, const int32_t* lens, const float* gates,
-                                 const float* cell, float* dgx, void* work, int32_t* status, int T, int B, int ldb, int H, int ng, void* stream);
 int ft_lstm2_seq_fwd_f16(const float* gx0, const float* w_hh0, const float* w_ih1, const float* bias1, const float* w_hh1,
                      const int32_t* lens, float* y0, float* gates0, float* cell0, float* y1, float* gates1, float* cell1,
                      void* work, int T, int B, int H, void* stream);

@@ -1,5 +1,5 @@
 """Round 6 probe: the persistent recurrences with R = 4 / 8 / 16 rows per XCD group, windows and two roles (csrc/lstm_roles.hip)
-against the round-5 kernels (csrc/lstm_persist.hip: 8 groups x 4 rows).  Prints us/step and equality for:
+against the launch-per-step kernels (csrc/lstm.hip).  Prints us/step and equality for:
   forward / backward, one role: R 4 (B 32), R 8 (B 32 on four XCDs; B 64), R 16 (B 128)
   windows: the B 32 sequence in chunks with carried state vs one launch
   two roles: two different recurrences in one launch vs one launch each
@@ -50,22 +50,28 @@ status = ops.persist_status(dev)
 
 
 def old_fwd(gx, w, lens, y, g, c):
-    """round-5 kernels: sliced launches of 32 rows"""
+    """the yardstick: the launch-per-step kernels (csrc/lstm.hip), batch chunks of 64 rows.  (The committed
+    profiles/r06_persist_rows_per_group.log was measured against the round-5 persistent kernel lstm_persist_fwd_k, 1.76 us per
+    step, which round 6 then removed.)"""
     B = gx.shape[1]
-    work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(32, H), device=dev, dtype=torch.uint8)
-    for b0 in range(0, B, 32):
-        nb = min(32, B - b0)
-        L.check(L.lib().ft_lstm_persist_fwd_rows(gx.data_ptr() + 16 * H * b0, L.ptr(w), lens.data_ptr() + 4 * b0, y.data_ptr() + 4 * H * b0, H,
-                                               g.data_ptr() + 16 * H * b0, c.data_ptr() + 4 * H * b0, L.ptr(work), L.ptr(status), T, nb, B, H, 11, L.stream()), "old fwd")
+    for b0 in range(0, B, 64):
+        nb = min(64, B - b0)
+        work = torch.empty(L.lib().ft_lstm_workspace_bytes(nb, H), device=dev, dtype=torch.uint8)
+        gxs, ls = gx[:, b0:b0 + nb].contiguous(), lens[b0:b0 + nb].contiguous()
+        ys, gs, cs = torch.empty(T, nb, H, device=dev), torch.empty(T, nb, 4 * H, device=dev), torch.empty(T, nb, H, device=dev)
+        L.check(L.lib().ft_lstm_seq_fwd(L.ptr(gxs), L.ptr(w), L.ptr(ls), L.ptr(ys), H, L.ptr(gs), L.ptr(cs), L.ptr(work), T, nb, H, 0, mode, L.stream()), "step fwd")
+        y[:, b0:b0 + nb], g[:, b0:b0 + nb], c[:, b0:b0 + nb] = ys, gs, cs
 
 
 def old_bwd(dy, w, lens, g, c, dgx):
     B = dy.shape[1]
-    work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(32, H), device=dev, dtype=torch.uint8)
-    for b0 in range(0, B, 32):
-        nb = min(32, B - b0)
-        L.check(L.lib().ft_lstm_persist_bwd_rows(dy.data_ptr() + 4 * H * b0, H, L.ptr(w), lens.data_ptr() + 4 * b0, g.data_ptr() + 16 * H * b0,
-                                               c.data_ptr() + 4 * H * b0, dgx.data_ptr() + 16 * H * b0, L.ptr(work), L.ptr(status), T, nb, B, H, 21, L.stream()), "old bwd")
+    for b0 in range(0, B, 64):
+        nb = min(64, B - b0)
+        work = torch.empty(L.lib().ft_lstm_workspace_bytes(nb, H), device=dev, dtype=torch.uint8)
+        dys, ls, gs, cs = dy[:, b0:b0 + nb].contiguous(), lens[b0:b0 + nb].contiguous(), g[:, b0:b0 + nb].contiguous(), c[:, b0:b0 + nb].contiguous()
+        d = torch.empty(T, nb, 4 * H, device=dev)
+        L.check(L.lib().ft_lstm_seq_bwd(L.ptr(dys), H, L.ptr(w), L.ptr(ls), L.ptr(gs), L.ptr(cs), L.ptr(d), L.ptr(work), T, nb, H, 0, mode, L.stream()), "step bwd")
+        dgx[:, b0:b0 + nb] = d
 
 
 def act_mask(lens):
@@ -91,11 +97,11 @@ for B, R in ((32, 4), (32, 8), (64, 8), (128, 16), (64, 16)):
     run = lambda: ops.roles_launch([ops.fwd_role(gx, lens, out[0], out[1], out[2], wimg)], R, mode, dev)
     run(); torch.cuda.synchronize()
     eq, s_ = same_fwd(lens, ref, out), st()
-    line = "fwd  B %3d R %2d: bit-identical to the round-5 kernels %s  status %d" % (B, R, eq, s_)
+    line = "fwd  B %3d R %2d: bit-identical to the launch-per-step kernels %s  status %d" % (B, R, eq, s_)
     if not os.environ.get("CHECK_ONLY"):
         t_new = timeit(run); t_old = timeit(lambda: old_fwd(gx, w, lens, *ref))
-        res["fwd_B%d_R%d" % (B, R)] = {"us_per_step": t_new[0], "median": t_new[1], "round5_sliced_us_per_step": t_old[0], "identical": eq}
-        line += "  | %.3f us/step (median %.3f) against %.3f for the round-5 launches (%d x 32 rows)" % (t_new[0], t_new[1], t_old[0], (B + 31) // 32)
+        res["fwd_B%d_R%d" % (B, R)] = {"us_per_step": t_new[0], "median": t_new[1], "launch_per_step_us_per_step": t_old[0], "identical": eq}
+        line += "  | %.3f us/step (median %.3f) against %.3f for the launch-per-step kernels (%d x 64 rows)" % (t_new[0], t_new[1], t_old[0], (B + 63) // 64)
     print(line, flush=True)
 
 # ---------------------------------------------------------------- forward, windows (B 32, R 4 and R 8) and two roles
@@ -147,7 +153,7 @@ line = "fwd  skewed pipeline of two recurrences in %d windows (%d launches): bit
 if not os.environ.get("CHECK_ONLY"):
     tp = timeit(pipeline)
     res["fwd_pipeline_8"] = {"us_per_step_pair": tp[0], "median": tp[1]}
-    line += "  | %.3f us per step of the PAIR (median %.3f; two round-5 launches: 2 x 1.8)" % tp
+    line += "  | %.3f us per step of the PAIR (median %.3f; two single launches at 4 rows: 2 x 1.62)" % tp
 print(line, flush=True)
 
 # ---------------------------------------------------------------- backward, one role
@@ -163,11 +169,11 @@ for B, R in ((32, 4), (32, 8), (64, 8), (128, 16)):
     run = lambda: ops.roles_launch([ops.bwd_role(dy, lens, g, c, d1, wimgb)], R, mode, dev, backward=True)
     run(); torch.cuda.synchronize()
     rel = float((d0 - d1).norm() / d0.norm())
-    line = "bwd  B %3d R %2d: bit-identical to the round-5 kernel %s  rel-L2 %.2e  max %.2e  status %d" % (B, R, bool(torch.equal(d0, d1)), rel, float((d0 - d1).abs().max()), st())
+    line = "bwd  B %3d R %2d: bit-identical to the launch-per-step kernel %s  rel-L2 %.2e  max %.2e  status %d" % (B, R, bool(torch.equal(d0, d1)), rel, float((d0 - d1).abs().max()), st())
     if not os.environ.get("CHECK_ONLY"):
         t_new = timeit(run); t_old = timeit(lambda: old_bwd(dy, w, lens, g, c, d0))
-        res["bwd_B%d_R%d" % (B, R)] = {"us_per_step": t_new[0], "median": t_new[1], "round5_sliced_us_per_step": t_old[0], "rel_l2": rel}
-        line += "  | %.3f us/step (median %.3f) against %.3f for the round-5 launches" % (t_new[0], t_new[1], t_old[0])
+        res["bwd_B%d_R%d" % (B, R)] = {"us_per_step": t_new[0], "median": t_new[1], "launch_per_step_us_per_step": t_old[0], "rel_l2": rel}
+        line += "  | %.3f us/step (median %.3f) against %.3f for the launch-per-step kernels" % (t_new[0], t_new[1], t_old[0])
     print(line, flush=True)
     if B == 32:
         # windows with carried state against ONE launch of the same R; image output against the fp32 rows

@@ -1,4 +1,4 @@
-"""STFT/mel front end on a LJSpeech-shaped batch (32 x 10 s at 22 050 Hz) -- workload for the rocprofv3 passes of scripts/profile_r2.sh."""
+"""STFT/mel front end on a LJSpeech-shaped batch (32 x 10 s at 22 050 Hz) -- a stand-alone workload for rocprofv3 passes over the front end."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

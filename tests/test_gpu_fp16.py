@@ -99,19 +99,21 @@ def test_lstm_layer_fp16_vs_fp32_oracle(env, T, B, H):
         assert rel(mine.grad, r.grad) < 8e-3, (name, rel(mine.grad, r.grad))
 
 
-@pytest.mark.parametrize("ng", [1, 11])
-def test_persistent_lstm_fp16_bit_identical_to_launch_per_step(env, ng):
+def test_persistent_lstm_fp16_forward_bit_identical_backward_to_rounding(env):
+    """the fp16 twins of the persistent recurrences (ft_lstm_roles_fwd_f16: bit-identical to the launch-per-step kernel; the
+    reduce-scatter backward ft_lstm_persist_bwd_f16: fp32 rounding, 2e-4 -- 11 significand bits against bf16's 8)"""
     L, _ = env
+    from flowtron_amd import ops
     T, B, H = 23, 32, 1024
-    if not L.lib().ft_lstm_persist_supported(B, H):
-        pytest.skip("needs a 256-CU device")
+    if not ops.persist_usable(torch.device("cuda", 0)):
+        pytest.skip("persistent kernels not usable on this device")
     lib = L.lib()
     torch.manual_seed(77)
     gx = torch.randn(T, B, 4 * H, device="cuda") * 0.5
     w = torch.randn(4 * H, H, device="cuda") / H ** 0.5
     dy = torch.randn(T, B, H, device="cuda") * 0.1
     lens_t = torch.tensor([max(1, T - i) for i in range(B)], dtype=torch.int32, device="cuda")
-    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    status = ops.persist_status(gx.device)
     res = []
     for persist in (False, True):
         y = torch.full((T, B, H), 7.0, device="cuda")
@@ -119,10 +121,9 @@ def test_persistent_lstm_fp16_bit_identical_to_launch_per_step(env, ng):
         dgx = torch.full((T, B, 4 * H), 7.0, device="cuda")
         if persist:
             work = torch.empty(lib.ft_lstm_persist_workspace_bytes(B, H), device="cuda", dtype=torch.uint8)
-            L.check(lib.ft_lstm_persist_fwd_f16(L.ptr(gx), L.ptr(w), L.ptr(lens_t), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(work),
-                                                L.ptr(status), T, B, H, ng, L.stream()), "fwd")
+            ops.roles_launch([ops.fwd_role(gx, lens_t, y, gates, cell, ops.roles_wimg(w, F16, False))], 4, F16, gx.device)
             L.check(lib.ft_lstm_persist_bwd_f16(L.ptr(dy), H, L.ptr(w), L.ptr(lens_t), L.ptr(gates), L.ptr(cell), L.ptr(dgx), L.ptr(work),
-                                                L.ptr(status), T, B, H, ng, L.stream()), "bwd")
+                                                L.ptr(status), T, B, H, 21, L.stream()), "bwd")
         else:
             work = torch.empty(lib.ft_lstm_workspace_bytes(B, H), device="cuda", dtype=torch.uint8)
             L.check(lib.ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens_t), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(work),
@@ -131,9 +132,10 @@ def test_persistent_lstm_fp16_bit_identical_to_launch_per_step(env, ng):
                                         T, B, H, 0, F16, L.stream()), "bwd")
         torch.cuda.synchronize()
         res.append((y, gates, cell, dgx))
-    assert int(status.item()) == 0
+    assert ops.check_persist_status()
     act = torch.arange(T, device="cuda")[:, None] < lens_t[None, :]
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][3], res[1][3])
+    assert torch.equal(res[0][0], res[1][0])
+    assert float((res[0][3] - res[1][3]).norm() / res[0][3].norm()) <= 2e-4
     assert torch.equal(res[0][1][act], res[1][1][act]) and torch.equal(res[0][2][act], res[1][2][act])
     # and it is NOT the bf16 result
     y16 = torch.empty(T, B, H, device="cuda")

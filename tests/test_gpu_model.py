@@ -36,7 +36,7 @@ def cuda_batch(b):
     return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
 
 
-@pytest.mark.parametrize("name", ["small_f2.pt", "small_f3.pt", "small_cumm.pt"])
+@pytest.mark.parametrize("name", ["small_f2.pt", "small_f3.pt", "small_cumm.pt", "small_dummy_spk.pt"])
 def test_forward_loss_grads_vs_reference_golden(name):
     import flowtron
     from oracle import synth
@@ -68,7 +68,7 @@ def test_forward_loss_grads_vs_reference_golden(name):
     assert worst[1] < 1e-4, worst          # SURVEY 8c's fp32 gradient tolerance (observed ~2e-5)
 
 
-@pytest.mark.parametrize("name", ["small_f2.pt", "small_f3.pt", "small_cumm.pt"])
+@pytest.mark.parametrize("name", ["small_f2.pt", "small_f3.pt", "small_cumm.pt", "small_dummy_spk.pt"])
 @pytest.mark.parametrize("use_graph", ["0", "1"])
 def test_infer_vs_reference_golden(name, use_graph):
     from oracle import synth
@@ -137,6 +137,46 @@ def test_infer_depth_and_batch_vs_reference_golden(use_graph):
     mel, _ = m.cuda().eval().infer(residual.cuda(), spk.cuda(), text.cuda(), gate_threshold=1.0)
     os.environ["FLOWTRON_MFMA"] = "f32"
     assert mad(mel, ref["mel"]) < 5e-2, mad(mel, ref["mel"])
+
+
+def test_gated_batch_decode_equals_the_utterances_decoded_alone():
+    """with a gate layer every utterance of a batch stops at its OWN frame of the last flow, and the flows decoded after it
+    must see exactly that utterance's frames (flowtron.py:775-828 per utterance; 901-930).  A batch of three against the same three
+    utterances decoded alone, at a gate threshold where the stops differ: mel and attention rows identical on each utterance's frames,
+    zero behind its stop."""
+    import flowtron
+    from oracle import synth
+    os.environ["FLOWTRON_MFMA"] = "f32"
+    cfg = dict(synth.DEFAULT_MODEL_CONFIG, n_text=60, n_flows=2)
+    sd = synth.make_state_dict(cfg, seed=17)
+    gk = [k for k in sd if "gate_layer" in k and k.endswith("weight")][0]
+    torch.manual_seed(4)
+    sd[gk] = torch.randn_like(sd[gk]) * 0.05               # gate logits of about one unit spread around the bias: stops at different frames
+    sd[gk.replace("weight", "bias")] = torch.full_like(sd[gk.replace("weight", "bias")], -2.0)
+    m = flowtron.Flowtron(**cfg)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    B, N, Lk = 3, 90, 21
+    residual = (torch.randn(B, cfg["n_mel_channels"], N) * 0.5).cuda()
+    text = torch.randint(1, 60, (B, Lk)).cuda()
+    spk = torch.zeros(B, dtype=torch.long).cuda()
+    found = False
+    for thr in (0.03, 0.05, 0.08, 0.12, 0.16, 0.2, 0.25, 0.3, 0.4, 0.5):
+        alone = [m.infer(residual[b:b + 1], spk[b:b + 1], text[b:b + 1], gate_threshold=thr) for b in range(B)]
+        lens = [int(a[0].shape[2]) for a in alone]
+        if len(set(lens)) > 1 and min(lens) < N:
+            found = True
+            break
+    assert found, "no threshold separated the stops: %r" % (lens,)
+    mel, attns = m.infer(residual, spk, text, gate_threshold=thr)
+    assert mel.shape[2] == max(lens)
+    for b in range(B):
+        assert torch.equal(mel[b, :, :lens[b]], alone[b][0][0]), (b, lens)
+        assert float(mel[b, :, lens[b]:].abs().max()) == 0.0 if lens[b] < max(lens) else True
+        for f in range(cfg["n_flows"]):
+            rows_b = torch.cat([r[b] for r in attns[f][:lens[b]]], 0)
+            rows_a = torch.cat([r[0] for r in alone[b][1][f]], 0)
+            assert torch.equal(rows_b, rows_a), (b, f)
 
 
 def test_infer_bf16_weight_images_and_persistent_decode_track_fp32_full_width():

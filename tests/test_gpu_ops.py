@@ -833,96 +833,53 @@ def _bench_lens(lens, ng):
     geometry the benchmark times; only for the default transport (ng = 1) -- the others are covered at the short shapes."""
     if lens != "bench":
         return lens
-    if ng not in (1, 11):
-        pytest.skip("bench shape: the XCD-local transports only")
     import bench
     return [int(v) for v in bench.synth_batch(32, 1234 + 7)["out_lens"]]
 
 
-@pytest.mark.parametrize("ng", [1, 9, 11, 19])   # 1 | 9 = XCD-local transport with nt | sc1 loads (8 groups = 8 XCDs); + 10 = bare operand pairs
 @pytest.mark.parametrize("T,B,lens", [(37, 32, None), (9, 5, [9, 9, 4, 2, 1]), (20, 17, None), (862, 32, "bench")])
-def test_persistent_lstm_forward_is_bit_identical_to_launch_per_step(env, ng, T, B, lens):
-    """ft_lstm_persist_fwd (one launch per sequence, W_hh fragments resident in registers, ng independent batch groups,
-    tag-checked granule hand-off) against ft_lstm_seq_fwd(FT_BF16): same rounding and accumulation order -> bit-identical
-    y / saved gates / saved cell on every valid (t, b), zeros on pad rows, status word clean."""
-    L, _ = env
+def test_persistent_lstm_forward_is_bit_identical_to_launch_per_step(env, T, B, lens):
+    """the persistent forward recurrence (ft_lstm_roles_fwd at 4 rows per XCD group, csrc/lstm_roles.hip: one launch per sequence, W_hh
+    fragments resident in registers, bare operand pairs behind a sentinel) against ft_lstm_seq_fwd(FT_BF16): same rounding and
+    accumulation order -> bit-identical y / saved gates / saved cell on every valid (t, b), zeros on pad rows, status word clean --
+    at the short shapes and at the bench's own launch geometry (tests/test_gpu_roles.py: every other R / windowing / role placement)."""
+    L, ops = env
     H = 1024
-    if not L.lib().ft_lstm_persist_supported(B, H):
-        pytest.skip("needs a 256-CU device")
+    if not ops.persist_usable(torch.device("cuda", 0)):
+        pytest.skip("persistent kernels not usable on this device")
     torch.manual_seed(T * 100 + B)
     gx = torch.randn(T, B, 4 * H, device="cuda") * 0.5
     w = torch.randn(4 * H, H, device="cuda") / H ** 0.5
-    lens = _bench_lens(lens, ng)
+    lens = _bench_lens(lens, 1)
     if lens is None:
         lens = [max(1, T - 2 * i) for i in range(B)]
     lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda")
     outs = []
-    status = torch.zeros(1, dtype=torch.int32, device="cuda")
     for persist in (False, True):
         y = torch.full((T, B, H), 7.0, device="cuda")
         gates = torch.zeros(T, B, 4 * H, device="cuda")
         cell = torch.zeros(T, B, H, device="cuda")
         if persist:
-            work = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device="cuda", dtype=torch.uint8)
-            L.check(L.lib().ft_lstm_persist_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens_t), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(work),
-                                                L.ptr(status), T, B, H, ng, L.stream()), "ft_lstm_persist_fwd")
+            ops.roles_launch([ops.fwd_role(gx, lens_t, y, gates, cell, ops.roles_wimg(w, 1, False))], 4, 1, gx.device)
         else:
             work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device="cuda", dtype=torch.uint8)
             L.check(L.lib().ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens_t), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(work),
                                             T, B, H, 0, 1, L.stream()), "ft_lstm_seq_fwd")
         torch.cuda.synchronize()
         outs.append((y, gates, cell))
-    assert int(status.item()) == 0
+    assert ops.check_persist_status()
     act = torch.arange(T, device="cuda")[:, None] < lens_t[None, :]
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1][act], outs[1][1][act]) and torch.equal(outs[0][2][act], outs[1][2][act])
     assert float(outs[1][0][~act].abs().max() if (~act).any() else 0.0) == 0.0
 
 
-@pytest.mark.parametrize("ng", [1, 9, 11, 19])
-@pytest.mark.parametrize("T,B,lens", [(37, 32, None), (9, 5, [9, 9, 4, 2, 1]), (20, 17, None), (862, 32, "bench")])
-def test_persistent_lstm_backward_is_bit_identical_to_launch_per_step(env, ng, T, B, lens):
-    """ft_lstm_persist_bwd against ft_lstm_seq_bwd(FT_BF16) on the saved tensors of a real forward: same fragment rounding,
-    same 16-partial accumulation order, same pinned cell arithmetic -> bit-identical dgx, zeros on pad rows."""
-    L, _ = env
-    H = 1024
-    if not L.lib().ft_lstm_persist_supported(B, H):
-        pytest.skip("needs a 256-CU device")
-    torch.manual_seed(T * 100 + B + 1)
-    gx = torch.randn(T, B, 4 * H, device="cuda") * 0.5
-    w = torch.randn(4 * H, H, device="cuda") / H ** 0.5
-    dy = torch.randn(T, B, H, device="cuda") * 0.1
-    lens = _bench_lens(lens, ng)
-    if lens is None:
-        lens = [max(1, T - 2 * i) for i in range(B)]
-    lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda")
-    y = torch.empty(T, B, H, device="cuda")
-    gates = torch.zeros(T, B, 4 * H, device="cuda")
-    cell = torch.zeros(T, B, H, device="cuda")
-    work = torch.empty(L.lib().ft_lstm_workspace_bytes(B, H), device="cuda", dtype=torch.uint8)
-    L.check(L.lib().ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens_t), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(work),
-                                    T, B, H, 0, 1, L.stream()), "ft_lstm_seq_fwd")
-    status = torch.zeros(1, dtype=torch.int32, device="cuda")
-    d0 = torch.full((T, B, 4 * H), 7.0, device="cuda")
-    d1 = torch.full((T, B, 4 * H), 7.0, device="cuda")
-    L.check(L.lib().ft_lstm_seq_bwd(L.ptr(dy), H, L.ptr(w), L.ptr(lens_t), L.ptr(gates), L.ptr(cell), L.ptr(d0), L.ptr(work),
-                                    T, B, H, 0, 1, L.stream()), "ft_lstm_seq_bwd")
-    wp = torch.empty(L.lib().ft_lstm_persist_workspace_bytes(B, H), device="cuda", dtype=torch.uint8)
-    L.check(L.lib().ft_lstm_persist_bwd(L.ptr(dy), H, L.ptr(w), L.ptr(lens_t), L.ptr(gates), L.ptr(cell), L.ptr(d1), L.ptr(wp),
-                                        L.ptr(status), T, B, H, ng, L.stream()), "ft_lstm_persist_bwd")
-    torch.cuda.synchronize()
-    assert int(status.item()) == 0
-    assert torch.equal(d0, d1)
-    act = torch.arange(T, device="cuda")[:, None] < lens_t[None, :]
-    assert float(d1[~act].abs().max() if (~act).any() else 0.0) == 0.0
-
-
-@pytest.mark.parametrize("B", [33, 48, 64])
-def test_wide_batch_runs_as_sliced_persistent_launches(env, B, monkeypatch):
-    """32 < B <= 64 (the reference's nn.LSTM has no batch limit, flowtron.py:654-655): ops.LSTMSeqFn walks the batch in slices of 32
-    rows, one persistent launch each (ft_lstm_persist_fwd_rows / _bwd_rows: the same kernels with the batch stride of the full
-    tensors).  Forward: bit-identical to the launch-per-step kernels (valid rows; zeros on pad rows); backward (reduce-scatter form):
-    equal to fp32 rounding, like the single-launch case; W_hh gradient from both."""
+@pytest.mark.parametrize("B", [33, 48, 64, 100])
+def test_wide_batch_runs_on_wider_xcd_groups(env, B, monkeypatch):
+    """B > 32 (the reference's nn.LSTM has no batch limit, flowtron.py:654-655): ops.LSTMSeqFn runs the persistent recurrences with 8
+    (B <= 64) or 16 rows per XCD group forward, slices of 64 rows at 8 per group backward (ops.roles_plan).  Forward: bit-identical to
+    the launch-per-step kernels (valid rows; zeros on pad rows); backward (reduce-scatter form): equal to fp32 rounding, like the
+    single-launch case; W_hh gradient from both."""
     L, ops = env
     H, T = 1024, 21
     if not ops.persist_usable(torch.empty(1, device="cuda").device):
@@ -935,14 +892,19 @@ def test_wide_batch_runs_as_sliced_persistent_launches(env, B, monkeypatch):
     act = (torch.arange(T, device="cuda")[:, None] < lens[None, :])
     res = []
     for wide in (True, False):
-        monkeypatch.setattr(ops, "_PERSIST_WIDE", wide)
+        monkeypatch.setenv("FLOWTRON_LSTM_PERSIST", "1" if wide else "0")
         assert bool(ops.lstm_persist_slices(B, H, False, 1, gx0.device)) == wide
         n0 = ops.PERSIST_LAUNCHES
         gx, w = gx0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
-        y = ops.LSTMSeqFn.apply(gx, w, lens, False, 1)
+        if wide or B <= ops.MAX_STEP_BATCH:
+            y = ops.LSTMSeqFn.apply(gx, w, lens, False, 1)
+        else:                                                   # (the launch-per-step kernels take 64 rows: per batch chunk, like ops.lstm_layer)
+            y = torch.cat([ops.LSTMSeqFn.apply(gx[:, b0:b0 + nb].contiguous(), w, lens[b0:b0 + nb].contiguous(), False, 1)
+                           for b0, nb in ops.batch_chunks(B, ops.MAX_STEP_BATCH)], 1)
         (y * dy).sum().backward()
         torch.cuda.synchronize()
         assert ops.check_persist_status()
+        assert (ops.PERSIST_LAUNCHES - n0 > 0) == wide
         res.append((y.detach(), gx.grad, w.grad))
     (y1, g1, dw1), (y0, g0, dw0) = res
     assert torch.equal(y1, y0)
@@ -952,7 +914,7 @@ def test_wide_batch_runs_as_sliced_persistent_launches(env, B, monkeypatch):
 
 
 @pytest.mark.parametrize("fmt", [1, 2])
-@pytest.mark.parametrize("ng", [1, 11])
+@pytest.mark.parametrize("ng", [21])
 @pytest.mark.parametrize("T,B,lens", [(37, 32, None), (9, 5, [9, 9, 4, 2, 1]), (40, 32, "ragged0"), (862, 32, "bench")])
 def test_persistent_backward_emits_the_compact_dgates_image(env, fmt, ng, T, B, lens):
     """ft_lstm_persist_bwd_img: the same dgx as ft_lstm_persist_bwd, plus the compact 16-bit image of dgates -- bit-identical to

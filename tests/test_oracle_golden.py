@@ -22,7 +22,7 @@ def _maxdiff(a, b):
     return (a - b).abs().max().item()
 
 
-@pytest.mark.parametrize("name", ["small_f2.pt", "small_f3.pt", "small_cumm.pt"])
+@pytest.mark.parametrize("name", ["small_f2.pt", "small_f3.pt", "small_cumm.pt", "small_dummy_spk.pt"])
 def test_forward_loss_grads_small(golden_dir, name):
     g = _load(golden_dir, name)
     cfg = g["cfg"]
@@ -49,7 +49,7 @@ def test_forward_loss_grads_small(golden_dir, name):
         assert (mine - ref).norm().item() / denom < 2e-4, (k, (mine - ref).norm().item() / denom)
 
 
-@pytest.mark.parametrize("name", ["small_f2.pt", "small_f3.pt", "small_cumm.pt"])
+@pytest.mark.parametrize("name", ["small_f2.pt", "small_f3.pt", "small_cumm.pt", "small_dummy_spk.pt"])
 def test_infer_small(golden_dir, name):
     g = _load(golden_dir, name)
     cfg = g["cfg"]
