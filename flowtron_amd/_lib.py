@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libflowtron_hip.so")
 FT_F32, FT_BF16, FT_F16 = 0, 1, 2
 GEMM_SPLITK = 1
 GEMM_SPLITK_DET = 2
+GEMM_C16 = 4
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 
 _p, _i, _l, _f, _sz, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_double
@@ -42,7 +43,7 @@ class GemmImgArgs(C.Structure):
 
 class LstmFwdRole(C.Structure):
     _fields_ = [("gx", _p), ("lens", _p), ("y", _p), ("ldy", _l), ("gates", _p), ("cell", _p), ("wimg", _p), ("state_h", _p), ("state_c", _p),
-                ("B", C.c_int32), ("ldb", C.c_int32), ("t0", C.c_int32), ("t1", C.c_int32)]
+                ("B", C.c_int32), ("ldb", C.c_int32), ("t0", C.c_int32), ("t1", C.c_int32), ("gx16", C.c_int32)]
 
 
 class LstmBwdRole(C.Structure):

@@ -236,6 +236,9 @@ struct BfP {
     // deterministic split-K (FT_GEMM_SPLITK_DET): slice blockIdx.y of the reduction writes ITS partial product, with plain stores, to
     // C + blockIdx.y * c_slice (a workspace); splitk_reduce_k adds the slices in a fixed order.  0: one slice, C is the output
     long c_slice;
+    // FT_GEMM_C16: C is a 16-BIT matrix of this build's operand format (ldc in 16-bit elements): the fp32 result (+ bias) is rounded
+    // once in the epilogue -- the gx rows a persistent recurrence reads (half the bytes written here and read there)
+    int c16;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -489,7 +492,11 @@ __global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
                 else if (p.act == FT_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
                 else if (p.act == FT_ACT_SIGMOID) v[r] = sigmoidf_(v[r]);
             }
-            if (full) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.c16) {
+                unsigned short* hp = reinterpret_cast<unsigned short*>(p.C) + (long)row * p.ldc + col;
+                if (full) *reinterpret_cast<uint2*>(hp) = make_uint2(pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3]));
+                else for (int r = 0; r < nv; ++r) hp[r] = f2op16(v[r]);
+            } else if (full) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
             else for (int r = 0; r < nv; ++r) cp[r] = v[r];
         }
     }
@@ -716,7 +723,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_k(BfP p) {
                 else if (p.act == FT_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
                 else if (p.act == FT_ACT_SIGMOID) v[r] = sigmoidf_(v[r]);
             }
-            if (full) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.c16) {
+                unsigned short* hp = reinterpret_cast<unsigned short*>(p.C) + (long)row * p.ldc + col;
+                if (full) *reinterpret_cast<uint2*>(hp) = make_uint2(pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3]));
+                else for (int r = 0; r < nv; ++r) hp[r] = f2op16(v[r]);
+            } else if (full) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
             else for (int r = 0; r < nv; ++r) cp[r] = v[r];
         }
     }
@@ -793,6 +804,9 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
     p.rowmap = rowmap; p.rows_dev = rows_dev; p.compact = compact; p.k_shift = k_shift;
     p.r1row = r1row; p.r1col = r1col;
     p.c_slice = 0;
+    p.c16 = (flags & FT_GEMM_C16) ? 1 : 0;
+    if (p.c16 && (beta != 0.f || (flags & (FT_GEMM_SPLITK | FT_GEMM_SPLITK_DET))))
+        return ft_fail(FT_EINVAL, "ft_gemm_img: FT_GEMM_C16 takes beta == 0 and no split-K");
     // deterministic split-K: the slices' partial products side by side in a workspace + a fixed-order reduction (for FORWARD GEMMs
     // with few output tiles and a long K: a forward pass must be a function of its inputs, which the atomics' order is not)
     const bool det = (flags & FT_GEMM_SPLITK_DET) && split_work && act == FT_ACT_NONE && beta == 0.f && compact == 0 && !r1row && K >= 2048 &&
@@ -802,7 +816,7 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
     long s = plan_slices(M, N, K, can_split, compact, &big);
     const int RTA = big ? 256 : TB;
     p.gx = cdiv(N, TB); p.gy = cdiv(M, RTA);
-    p.vec_c = (reinterpret_cast<uintptr_t>(C) % 16 == 0 && ldc % 4 == 0) ? 1 : 0;
+    p.vec_c = (reinterpret_cast<uintptr_t>(C) % 16 == 0 && ldc % 4 == 0) ? 1 : 0;      // (16-bit C: 8-byte pieces of rows that start 8-byte aligned)
     if (det) {                                   // as many slices as the workspace holds
         const long fit = (long)(split_work_bytes / ((size_t)M * N * sizeof(float)));
         if (s > fit) s = fit;

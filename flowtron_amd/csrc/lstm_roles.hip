@@ -40,7 +40,7 @@ struct FwdRoleP {
     const unsigned short* wfrag;         // make_wfrag_fwd_ug image
     float* st_h; float* st_c;            // [B][H]: read when t0 > 0, written at the end (either may be null together)
     int B, LB, t0, t1;
-};
+};                                       // (gx: fp32 rows, or 16-bit rows of the build's operand format in the GX16 kernels)
 struct FwdLaunchP {
     FwdRoleP role[2];
     int nroles;
@@ -70,7 +70,10 @@ __device__ __forceinline__ void preset_other(uint4* other, size_t n16, unsigned*
     if (wg == 0 && tid < 8) census_other[tid] = 0u;
 }
 
-template <int R, bool PROF>
+// GX16: the input-projection rows gx arrive as 16-BIT values of the operand format (written by the projection GEMM's epilogue,
+// FT_GEMM_C16) instead of fp32: half the bytes the GEMM writes and the bursts read, twice the steps per burst in the same LDS; the
+// value is widened exactly and added to the fp32 recurrent sums like the fp32 row was (round 6; VERDICT r5 #1c)
+template <int R, bool PROF, bool GX16>
 __global__ __launch_bounds__(256, 1) void lstm_roles_fwd_k(FwdLaunchP P) {
     // Epilogue layout.  R = 4 (the round-5 arrangement): waves 0-1 own one element each and run the cell update, waves 2-3 store the saved
     // tensors of the previous step out of LDS.  R >= 8 (SPLIT): ALL FOUR waves own R / 8 elements each (rows er0 + 8 e) and store their
@@ -82,13 +85,14 @@ __global__ __launch_bounds__(256, 1) void lstm_roles_fwd_k(FwdLaunchP P) {
     constexpr int ETH = SPLIT ? 256 : 128;         // epilogue threads
     constexpr int NE = R * UPC;                    // elements per CU
     constexpr int CPL = 16 / R, NLG = 8 / CPL;     // k-chunks per 16-byte load, loads per wave and step
-    constexpr int SB = R == 16 ? 4 : SBMAX * 4 / R;   // steps per gx burst (64 KB of LDS; 32 KB at R = 16, whose reduce buffers take 80)
+    constexpr int SBF = R == 16 ? 4 : SBMAX * 4 / R;  // steps per fp32 gx burst (64 KB of LDS; 32 KB at R = 16, whose reduce buffers take 80)
+    constexpr int SB = GX16 ? 2 * SBF : SBF;          // 16-bit rows: twice the steps in the same bytes
     constexpr int DWG = NCHUNK * 32 * R / 2;       // dwords per hand-off buffer and group
     // LDS: 4-wave reduce (double buffered) | SB steps of gx rows [s][gate][e] | 2 steps of outputs [parity][y,i,f,g,o,c][e]
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float (*red)[4][TPC][R][20] = reinterpret_cast<float (*)[4][TPC][R][20]>(smem);
     float* gxs = smem + 2 * 4 * TPC * R * 20;
-    float* outs = gxs + SB * 4 * NE;
+    float* outs = gxs + SBF * 4 * NE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
@@ -142,12 +146,25 @@ __global__ __launch_bounds__(256, 1) void lstm_roles_fwd_k(FwdLaunchP P) {
         __syncthreads();
         const int nst = (tg - t) < SB ? (tg - t) : SB;
         const unsigned dst0 = (unsigned)(size_t)(lds_void*)gxs;
+        if constexpr (GX16) {
+            // 16-bit rows: a step's [gate][row][unit] block is R / 4 pieces of 1 KiB (512 values, eight per lane)
+            const unsigned short* gx16 = reinterpret_cast<const unsigned short*>(p.gx);
 #pragma unroll
-        for (int kk = 0; kk < SB * R / 8; ++kk) {
-            const int c = 4 * kk + wu, st = c / (R / 2), pi = c % (R / 2);
-            const int f = pi * 256 + lane * 4, gate = f / NE, row = (f % NE) >> 5, unit = f & 31;
-            if (st < nst && b0 + row < B)
-                dma16(p.gx + (((size_t)(t + st) * LB + b0 + row) * 4 + gate) * PH + q * UPC + unit, dst0 + (unsigned)((st * 4 * NE + pi * 256) * 4));
+            for (int kk = 0; kk < SB * R / 16; ++kk) {
+                const int c = 4 * kk + wu, st = c / (R / 4), pi = c % (R / 4);
+                const int f = pi * 512 + lane * 8, gate = f / NE, row = (f % NE) >> 5, unit = f & 31;
+                if (st < nst && b0 + row < B)
+                    dma16(reinterpret_cast<const float*>(gx16 + (((size_t)(t + st) * LB + b0 + row) * 4 + gate) * PH + q * UPC + unit),
+                          dst0 + (unsigned)(st * 4 * NE * 2 + pi * 1024));
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < SB * R / 8; ++kk) {
+                const int c = 4 * kk + wu, st = c / (R / 2), pi = c % (R / 2);
+                const int f = pi * 256 + lane * 4, gate = f / NE, row = (f % NE) >> 5, unit = f & 31;
+                if (st < nst && b0 + row < B)
+                    dma16(p.gx + (((size_t)(t + st) * LB + b0 + row) * 4 + gate) * PH + q * UPC + unit, dst0 + (unsigned)((st * 4 * NE + pi * 256) * 4));
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -354,13 +371,14 @@ __global__ __launch_bounds__(256, 1) void lstm_roles_fwd_k(FwdLaunchP P) {
             for (int e = 0; e < EPT; ++e) {
                 const int row = er0 + ERW * e;
                 const float* gxr = gxs + (n % SB) * 4 * NE + row * UPC + el;
+                const unsigned short* gxr16 = reinterpret_cast<const unsigned short*>(gxs) + (n % SB) * 4 * NE + row * UPC + el;
                 // the four gates of (unit, row) are adjacent (make_wfrag_fwd_ug): one 16-byte read per wave partial; the sum keeps its
                 // order (wave 0 + 1 + 2 + 3, then gx)
                 const f32x4 p0 = *reinterpret_cast<const f32x4*>(&red[rb][0][j][row][ul * 4]), p1 = *reinterpret_cast<const f32x4*>(&red[rb][1][j][row][ul * 4]);
                 const f32x4 p2 = *reinterpret_cast<const f32x4*>(&red[rb][2][j][row][ul * 4]), p3 = *reinterpret_cast<const f32x4*>(&red[rb][3][j][row][ul * 4]);
                 float pre[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) pre[g] = p0[g] + p1[g] + p2[g] + p3[g] + gxr[g * NE];
+                for (int g = 0; g < 4; ++g) pre[g] = p0[g] + p1[g] + p2[g] + p3[g] + (GX16 ? op16_to_f(gxr16[g * NE]) : gxr[g * NE]);
                 ig[e] = fg[e] = gg[e] = og[e] = 0.f;
                 if (t < len[e]) {
                     float c_new, h_new;
@@ -916,14 +934,16 @@ extern "C" int FT_OPNAME(ft_lstm_roles_fwd)(const ft_lstm_fwd_role* roles, int n
     if (H != PH || !ft_lstm_persist_supported(8, H))
         return ft_fail(FT_EUNSUPPORTED, "ft_lstm_roles_fwd: needs H == 1024 and a 256-CU device (H=%d)", H);
     FwdLaunchP P{};
-    bool any = false;
+    bool any = false, g16 = false;
     for (int i = 0; i < n_roles; ++i) {
         const ft_lstm_fwd_role& r = roles[i];
         FT_CHECK_ARG(r.gx && r.lens && r.y && r.wimg && r.B >= 1 && r.B <= (8 / n_roles) * R && r.ldb >= r.B && r.ldy >= H);
         FT_CHECK_ARG((r.gates == nullptr) == (r.cell == nullptr) && (r.state_h == nullptr) == (r.state_c == nullptr));
         FT_CHECK_ARG(r.t0 >= 0 && r.t1 >= r.t0 && (r.t0 == 0 || r.state_h) && reinterpret_cast<uintptr_t>(r.gx) % 16 == 0);
-        P.role[i] = FwdRoleP{r.gx, r.lens, r.y, (long)r.ldy, r.gates, r.cell, reinterpret_cast<const unsigned short*>(r.wimg), r.state_h, r.state_c,
-                             r.B, r.ldb, r.t0, r.t1};
+        P.role[i] = FwdRoleP{reinterpret_cast<const float*>(r.gx), r.lens, r.y, (long)r.ldy, r.gates, r.cell, reinterpret_cast<const unsigned short*>(r.wimg),
+                             r.state_h, r.state_c, r.B, r.ldb, r.t0, r.t1};
+        FT_CHECK_ARG(i == 0 || (r.gx16 != 0) == g16);             // one gx format per launch (the kernel is instantiated on it)
+        g16 = r.gx16 != 0;
         any = any || r.t1 > r.t0;
     }
     if (!any) return FT_OK;
@@ -937,9 +957,13 @@ extern "C" int FT_OPNAME(ft_lstm_roles_fwd)(const ft_lstm_fwd_role* roles, int n
     auto lds = [](int R_, int SB_) { return sizeof(float) * ((size_t)2 * 4 * TPC * R_ * 20 + (size_t)SB_ * 4 * R_ * UPC + (size_t)2 * 6 * R_ * UPC); };
     int rc;
     const bool pf = ftint_roles_prof != nullptr;
-    if (R == 4) rc = pf ? roles_launch(lstm_roles_fwd_k<4, true>, lds(4, 32), P, st) : roles_launch(lstm_roles_fwd_k<4, false>, lds(4, 32), P, st);
-    else if (R == 8) rc = pf ? roles_launch(lstm_roles_fwd_k<8, true>, lds(8, 16), P, st) : roles_launch(lstm_roles_fwd_k<8, false>, lds(8, 16), P, st);
-    else rc = pf ? roles_launch(lstm_roles_fwd_k<16, true>, lds(16, 4), P, st) : roles_launch(lstm_roles_fwd_k<16, false>, lds(16, 4), P, st);
+#define FT_ROLES_FWD(R_, SB_) \
+    (g16 ? (pf ? roles_launch(lstm_roles_fwd_k<R_, true, true>, lds(R_, SB_), P, st) : roles_launch(lstm_roles_fwd_k<R_, false, true>, lds(R_, SB_), P, st)) \
+         : (pf ? roles_launch(lstm_roles_fwd_k<R_, true, false>, lds(R_, SB_), P, st) : roles_launch(lstm_roles_fwd_k<R_, false, false>, lds(R_, SB_), P, st)))
+    if (R == 4) rc = FT_ROLES_FWD(4, 32);
+    else if (R == 8) rc = FT_ROLES_FWD(8, 16);
+    else rc = FT_ROLES_FWD(16, 4);
+#undef FT_ROLES_FWD
     if (rc != FT_OK) return rc;
     FT_CHECK_LAUNCH();
     return FT_OK;

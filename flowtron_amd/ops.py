@@ -270,13 +270,31 @@ def shared_image(t, rows, cols, mode, rowmap=None):
     return img
 
 
+def op16_dtype(mode):
+    """torch dtype of a tensor that holds 16-bit values of the operand format `mode`"""
+    return torch.float16 if mode == L.FT_F16 else torch.bfloat16
+
+
+_GX16 = _os.environ.get("FLOWTRON_LSTM_GX16", "1") != "0"    # gx of the persistent forward recurrences as 16-bit rows (round 6)
+
+
+def gx16_ok(mode, rowmap, T, B, H, reverse, xs, N, device):
+    """whether an input projection may write its output as 16-BIT rows (FT_GEMM_C16): its only reader is a persistent forward recurrence
+    (csrc/lstm_roles.hip takes them) and its gradient travels back as the dgates image alone (so the fp32 face autograd would
+    otherwise round to 16 bits never carries values)"""
+    return (_GX16 and L.is16(mode) and rowmap is not None and not reverse and rowmap.T == T and rowmap.B == B and _PERSIST_IMG == "1"
+            and linear_uses_images(mode, T * B, N, xs) and (len(xs) == 1 or _CAT_IMAGES)
+            and bool(lstm_persist_groups(B, H, reverse, mode, device) or lstm_persist_slices(B, H, reverse, mode, device))
+            and B <= 32)
+
+
 def images_apply(mode, M, N, K):
     """same rule as ft_gemm_workspace_bytes: bf16 mode and a GEMM large enough to amortise the image passes."""
     return _BF16_IMAGES and L.is16(mode) and M >= 32 and N >= 32 and K >= 16 and M * N * K >= (1 << 20)
 
 
 def gemm_img(A, a_km, a_ptr, B, b_km, b_ptr, Cm, M, N, K, ldc, bias=None, act=L.ACT_NONE, alpha=1.0, beta=0.0, splitk=False,
-             rowmap=None, compact=0, k_shift=0, rank1=None):
+             rowmap=None, compact=0, k_shift=0, rank1=None, c16=False):
     """C[M,N] = act(alpha * A.B + beta*C + bias) from images.  a_ptr / b_ptr: A.ptr(...) / B.ptr(...) (may point inside).
     rowmap + compact: 1 = M runs over the map's compact rows (pass M = rowmap.cap), C rows are scattered through the map;
     2 = the reduction runs over compact rows (pass K = rowmap.cap; k_shift = a row shift already applied to a_ptr).
@@ -288,6 +306,9 @@ def gemm_img(A, a_km, a_ptr, B, b_km, b_ptr, Cm, M, N, K, ldc, bias=None, act=L.
         need = L.lib().ft_gemm_img_split_work_bytes(M, N, K)
         flags = L.GEMM_SPLITK_DET if need else 0
         work = torch.empty(need, device=Cm.device, dtype=torch.uint8) if need else None
+    if c16:                                      # C is a 16-bit tensor of the operands' format (FT_GEMM_C16)
+        assert Cm.dtype == op16_dtype(A.fmt) and not splitk and beta == 0.0
+        flags |= L.GEMM_C16
     a = L.GemmImgArgs(a_ptr, b_ptr, L.ptr(Cm), L.ptr(bias), M, N, K, A.ld, B.ld, ldc, int(a_km), int(b_km),
                       alpha, beta, act, flags,
                       L.ptr(rowmap.map) if rowmap is not None else None, L.ptr(rowmap.rows) if rowmap is not None else None,
@@ -319,7 +340,7 @@ def _handoff_clear():
     _HANDOFF["nan_next"] = 0
 
 
-def image_only_gradient(shape, device):
+def image_only_gradient(shape, device, dtype=torch.float32):
     """The fp32 face of a gradient that exists ONLY as a 16-bit operand image (ft_lstm_persist_bwd_img): every element reads NaN.
     No storage of the gradient's size is allocated -- ONE NaN float, expanded with zero strides; each such gradient of a backward
     pass takes its own slot of a small pool, so (device, data_ptr, shape) still identifies it for the image hand-off.  A foreign
@@ -329,7 +350,12 @@ def image_only_gradient(shape, device):
         pool = _NAN_POOL[device] = torch.full((64,), float("nan"), device=device, dtype=torch.float32)
     i = _HANDOFF["nan_next"]
     _HANDOFF["nan_next"] = i + 1
-    slot = pool[i:i + 1] if i < 64 else torch.full((1,), float("nan"), device=device, dtype=torch.float32)
+    if dtype != torch.float32:
+        # (a 16-bit face -- the gradient of 16-bit gx rows: its own pool of that dtype, the slot index keeps the address unique)
+        pool = _NAN_POOL.get((device, dtype))
+        if pool is None:
+            pool = _NAN_POOL[(device, dtype)] = torch.full((64,), float("nan"), device=device, dtype=dtype)
+    slot = pool[i:i + 1] if i < 64 else torch.full((1,), float("nan"), device=device, dtype=dtype)
     return slot.expand(*shape) if len(shape) else slot.reshape(())
 
 
@@ -512,7 +538,8 @@ class LinearFn(torch.autograd.Function):
         W = _c(W)
         N, Ktot = W.shape
         rows = xs[0].numel() // xs[0].shape[-1]
-        y = torch.empty(xs[0].shape[:-1] + (N,), device=W.device, dtype=torch.float32)
+        c16 = "c16" in fill                       # y as 16-bit rows for a persistent recurrence (gx16_ok: implies the image path below)
+        y = torch.empty(xs[0].shape[:-1] + (N,), device=W.device, dtype=op16_dtype(mode) if c16 else torch.float32)
         # mode = one operand format, or (forward, input gradient, weight gradient): mixed formats (the encoder convolutions keep
         # fp32 operands where 16-bit rounding is amplified, model.Encoder) take the per-GEMM path without shared images
         mode_dx = mode_dw = mode
@@ -549,7 +576,7 @@ class LinearFn(torch.autograd.Function):
                 # LSTM's input projection against ~330 for the single loop)
                 x_cat = Bf16Image.cat_rows([x.reshape(rows, x.shape[-1]) for x in xs], mode, rowmap)
                 ctx.imgs, ctx.cat = (w_img, [x_cat]), True
-                gemm_img(x_cat, 0, x_cat.ptr(), w_img, 0, w_img.ptr(), y, rowmap.cap, N, Ktot, N, bias=bias, act=act, rowmap=rowmap, compact=1)
+                gemm_img(x_cat, 0, x_cat.ptr(), w_img, 0, w_img.ptr(), y, rowmap.cap, N, Ktot, N, bias=bias, act=act, rowmap=rowmap, compact=1, c16=c16)
             else:
                 x_imgs = [shared_image(x, rows, x.shape[-1], mode, rowmap) for x in xs]
                 ctx.imgs = (w_img, x_imgs)          # reused by backward (dX reads W k-major, dW reads x k-major)
@@ -561,10 +588,12 @@ class LinearFn(torch.autograd.Function):
             K = x.shape[-1]
             last = i == len(xs) - 1
             if use_img:
+                assert not c16 or len(xs) == 1
                 gemm_img(x_imgs[i], 0, x_imgs[i].ptr(), w_img, 0, w_img.ptr(0, off), y, rows if rowmap is None else rowmap.cap, N, K, N,
                          bias=bias if last else None, act=act if last else L.ACT_NONE, beta=0.0 if i == 0 else 1.0,
-                         rowmap=rowmap, compact=1)
+                         rowmap=rowmap, compact=1, c16=c16)
             else:
+                assert not c16, "16-bit output rows come from the image GEMMs only"
                 gemm_raw(x, W[:, off:], y, rows, N, K, K, 1, 1, Ktot, N,
                          bias=bias if last else None, act=act if last else L.ACT_NONE,
                          beta=0.0 if i == 0 else 1.0, mode=mode)
@@ -593,7 +622,7 @@ class LinearFn(torch.autograd.Function):
             d_img_in = None
         if d_img_in is None:
             _require_written(dy)
-            dy = _c(dy)
+            dy = _c(dy.float())
         # an activated layer over a row map on the image path: dpre = dy act'(pre) is formed INSIDE the conversion pass (image + bias
         # column sums, ft_bf16_image_rows_act_bwd) -- no fp32 dpre tensor
         fuse_act = ctx.act != L.ACT_NONE and ctx.imgs is not None and rowmap is not None and _FUSE_ACT_BWD
@@ -683,11 +712,12 @@ class LinearGateFn(torch.autograd.Function):
         N, Ktot = W.shape
         assert Wg.shape == (1, Ktot) and xs[0].shape[-1] + xs[1].shape[-1] == Ktot
         rows = rowmap.T * rowmap.B
-        y = torch.empty(xs[0].shape[:-1] + (N,), device=W.device, dtype=torch.float32)
+        c16 = "c16" in fill                       # y as 16-bit rows for a persistent recurrence (gx16_ok)
+        y = torch.empty(xs[0].shape[:-1] + (N,), device=W.device, dtype=op16_dtype(mode) if c16 else torch.float32)
         gate = torch.empty(xs[0].shape[:-1] + (1,), device=W.device, dtype=torch.float32)
         w_img = Bf16Image.of_weight(W, mode)
         x_cat = Bf16Image.cat_rows([x.reshape(rows, x.shape[-1]) for x in xs], mode, rowmap)
-        gemm_img(x_cat, 0, x_cat.ptr(), w_img, 0, w_img.ptr(), y, rowmap.cap, N, Ktot, N, bias=bias, rowmap=rowmap, compact=1)
+        gemm_img(x_cat, 0, x_cat.ptr(), w_img, 0, w_img.ptr(), y, rowmap.cap, N, Ktot, N, bias=bias, rowmap=rowmap, compact=1, c16=c16)
         L.check(L.op16("ft_img_gemv_rows", mode)(L.ptr(x_cat.buf), x_cat.ld, Ktot, L.ptr(Wg), L.ptr(bg), L.ptr(gate), 1, L.ptr(rowmap.map),
                                                  L.ptr(rowmap.rows), L.ptr(rowmap.lens), rowmap.T, rowmap.B, L.stream()), "ft_img_gemv_rows")
         if "y" in fill:
@@ -710,7 +740,7 @@ class LinearGateFn(torch.autograd.Function):
             d_img = None
         if d_img is None:
             _require_written(dy)
-            d_img = Bf16Image(_c(dy).reshape(rows, N), colsum=want_db, mode=w_img.fmt, rowmap=rowmap)
+            d_img = Bf16Image(_c(dy.float()).reshape(rows, N), colsum=want_db, mode=w_img.fmt, rowmap=rowmap)
         db = d_img.colsum if want_db else None
         rank1 = None
         if dgate is not None:
@@ -1099,10 +1129,10 @@ def fwd_role(gx, lens, y, gates, cell, wimg, t0=0, t1=None, state=None, b0=0, nb
     """one forward recurrence of a roles launch over the batch rows [b0, b0 + nb) of time-major tensors, window [t0, t1)"""
     T, LB, H = gx.shape[0], gx.shape[1], y.shape[2]
     nb = LB - b0 if nb is None else nb
-    return L.LstmFwdRole(gx.data_ptr() + 16 * H * b0, lens.data_ptr() + 4 * b0, y.data_ptr() + 4 * y.stride(1) * b0, y.stride(1),
+    return L.LstmFwdRole(gx.data_ptr() + gx.element_size() * 4 * H * b0, lens.data_ptr() + 4 * b0, y.data_ptr() + 4 * y.stride(1) * b0, y.stride(1),
                          gates.data_ptr() + 16 * H * b0 if gates is not None else None, cell.data_ptr() + 4 * H * b0 if cell is not None else None,
                          L.ptr(wimg), L.ptr(state[0]) if state is not None else None, L.ptr(state[1]) if state is not None else None,
-                         nb, LB, t0, T if t1 is None else t1)
+                         nb, LB, t0, T if t1 is None else t1, int(gx.dtype != torch.float32))
 
 
 def bwd_role(dy, lens, gates, cell, dgx, wimg, t0=0, t1=None, state=None, carry_in=False, dimg=None, b0=0, nb=None):
@@ -1196,7 +1226,8 @@ class DecoderPairFn(torch.autograd.Function):
         f = dict(device=dev, dtype=torch.float32)
         y0, g0, c0 = torch.empty(T, B, H, **f), torch.empty(T, B, H4, **f), torch.empty(T, B, H, **f)
         y1, g1, c1 = torch.empty(T, B, H, **f), torch.empty(T, B, H4, **f), torch.empty(T, B, H, **f)
-        gx1 = torch.empty(T, B, H4, **f)
+        g16 = gx0.dtype != torch.float32          # 16-bit gx rows (decoder_pair: gx16_ok): layer 1's chunk projections write them too
+        gx1 = torch.empty(T, B, H4, device=dev, dtype=gx0.dtype)
         st0, st1 = torch.zeros(2, B, H, **f), torch.zeros(2, B, H, **f)
         wi0, wi1 = roles_wimg(w_hh0, mode, False), roles_wimg(w_hh1, mode, False)
         w_img = Bf16Image.of_weight(w_ih1, mode)
@@ -1214,10 +1245,10 @@ class DecoderPairFn(torch.autograd.Function):
                 # layer 1's input projection of chunk k over its valid rows, scattered into gx1[e_k : e_k+1]
                 a, b = edges[k], edges[k + 1]
                 x_img = Bf16Image(y0[a:b].reshape((b - a) * B, H), mode=mode, rowmap=rms[k])
-                gemm_img(x_img, 0, x_img.ptr(), w_img, 0, w_img.ptr(), gx1[a:b], rms[k].cap, H4, H, H4, bias=b1, rowmap=rms[k], compact=1)
+                gemm_img(x_img, 0, x_img.ptr(), w_img, 0, w_img.ptr(), gx1[a:b], rms[k].cap, H4, H, H4, bias=b1, rowmap=rms[k], compact=1, c16=g16)
         ctx.save_for_backward(w_hh0, w_ih1, w_hh1, lens, y0, g0, c0, y1, g1, c1)
         ctx.mode, ctx.rowmap, ctx.gx_private, ctx.nchunks = mode, rowmap, bool(gx_private), nchunks
-        ctx.chunk_maps, ctx.w_img = (edges, rms), w_img
+        ctx.chunk_maps, ctx.w_img, ctx.gx_dtype = (edges, rms), w_img, gx0.dtype
         return y1
 
     @staticmethod
@@ -1290,9 +1321,11 @@ class DecoderPairFn(torch.autograd.Function):
                     gemm_raw(dgx0[1:], y0[:-1], dW_hh0, H4, H, rows, 1, H4, H, 1, H, mode=mode, splitk=True)
                 gemm_raw(dgx1, y0, dW_ih1, H4, H, T * B, 1, H4, H, 1, H, mode=mode, splitk=True)
         if img_only:
-            dgx0 = image_only_gradient((T, B, H4), dev)
+            dgx0 = image_only_gradient((T, B, H4), dev, ctx.gx_dtype)
             _handoff_put_image_only(dgx0, d_img0)
         elif d_img0 is not None:
+            if ctx.gx_dtype != torch.float32:
+                dgx0 = dgx0.to(ctx.gx_dtype)
             _handoff_put(dgx0, d_img0)
         return dgx0, dW_hh0, dW_ih1, db1, db1, dW_hh1, None, None, None, None, None
 
@@ -1327,7 +1360,7 @@ def _pair_backward_sequential(ctx, dy1, w_img, img_only):
     gemm_img(d_img1, 1, d_img1.ptr(), y0_img, 1, y0_img.ptr(), dW_ih1, H4, H, rm.cap, H, beta=1.0, splitk=True, rowmap=rm, compact=2)
     d_img0 = recurrence(dy0, g0, c0, w_hh0)
     gemm_img(d_img0, 1, d_img0.ptr(1), y0_img, 1, y0_img.ptr(0), dW_hh0, H4, H, rm.cap, H, beta=1.0, splitk=True, rowmap=rm, compact=2, k_shift=1)
-    dgx0 = image_only_gradient((T, B, H4), dev)
+    dgx0 = image_only_gradient((T, B, H4), dev, ctx.gx_dtype)
     _handoff_put_image_only(dgx0, d_img0)
     db1 = d_img1.colsum
     return dgx0, dW_hh0, dW_ih1, db1, db1, dW_hh1, None, None, None, None, None
@@ -1342,6 +1375,8 @@ def decoder_pair(x, lens, p, mode, xs_extra, rowmap, fill, gate, nchunks):
     xs = [x] + list(xs_extra)
     T, B = x.shape[0], x.shape[1]
     gates = None
+    if gx16_ok(mode, rowmap, T, B, p.weight_hh_l0.shape[1], False, xs, p.weight_ih_l0.shape[0], x.device):
+        fill = fill + "|c16"
     if gate is not None and linear_gate_fusable(mode, rowmap, xs, p.weight_ih_l0.shape[0]):
         gx, gates = LinearGateFn.apply(p.weight_ih_l0, p.bias_ih_l0 + p.bias_hh_l0, gate[0], gate[1], mode, rowmap, fill, *xs)
     else:
@@ -1362,6 +1397,9 @@ class LSTMSeqFn(torch.autograd.Function):
         gx, w_hh = _c(gx), _c(w_hh)
         L.require_cuda(gx, w_hh, lens)
         T, B, H4 = gx.shape
+        ctx.gx_dtype = gx.dtype                       # fp32, or 16-bit rows (lstm_layer: gx16_ok) for the persistent forward kernel
+        if gx.dtype != torch.float32 and not (lstm_persist_groups(B, H4 // 4, reverse, mode, gx.device) or lstm_persist_slices(B, H4 // 4, reverse, mode, gx.device)):
+            gx = gx.float()                           # (the device left the persistent kernels since the projection ran)
         ctx.rowmap = rowmap if (rowmap is not None and not reverse and rowmap.T == T and rowmap.B == B) else None
         H = H4 // 4
         y = torch.empty(T, B, H, device=gx.device, dtype=torch.float32)
@@ -1432,7 +1470,12 @@ class LSTMSeqFn(torch.autograd.Function):
                                             L.ptr(work), T, B, H, int(ctx.reverse), ctx.mode, L.stream()), "ft_lstm_seq_bwd")
         if img_only:
             # the gradient autograd carries is the NaN face of the image: a foreign reader sees NaN, never unwritten memory
-            dgx = image_only_gradient((T, B, 4 * H), dy.device)
+            dgx = image_only_gradient((T, B, 4 * H), dy.device, ctx.gx_dtype)
+        dgx_f32 = dgx
+        if not img_only and ctx.gx_dtype != torch.float32:
+            # 16-bit gx rows (gx16_ok) in a pass that keeps fp32 dgates (anomaly mode, FLOWTRON_LSTM_PERSIST_IMG=both): autograd wants
+            # the gradient in gx's dtype -- cast here, so that the image hand-off below is keyed on the tensor it will carry
+            dgx = dgx.to(ctx.gx_dtype)
         dW = None
         if ctx.needs_input_grad[1]:
             # dW_hh[r,j] = sum_{t,b} da_t[b,r] * h_prev(t)[b,j];  h_prev = y[t-1] (fwd) / y[t+1] (reverse)
@@ -1442,7 +1485,7 @@ class LSTMSeqFn(torch.autograd.Function):
             if T > 1 and images_apply(ctx.mode, 4 * H, H, rows) and rm is not None:
                 # compact images (valid frames only, batch-major with one zero separator row per utterance): the one-step shift
                 # dgates_t <-> h_{t-1} is a shift by ONE compact row, and the utterance boundaries multiply with a separator
-                d_img = d_img_k if d_img_k is not None else Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True, mode=ctx.mode, rowmap=rm)
+                d_img = d_img_k if d_img_k is not None else Bf16Image(dgx_f32.reshape(T * B, 4 * H), colsum=True, mode=ctx.mode, rowmap=rm)
                 y_img = shared_image(y, T * B, H, ctx.mode, rm)
                 gemm_img(d_img, 1, d_img.ptr(1), y_img, 1, y_img.ptr(0), dW, 4 * H, H, rm.cap, H, beta=1.0, splitk=True, rowmap=rm, compact=2, k_shift=1)
                 if img_only:
@@ -1451,12 +1494,12 @@ class LSTMSeqFn(torch.autograd.Function):
                     _handoff_put(dgx, d_img)    # the input projection's backward reads the same dgates
             elif T > 1 and images_apply(ctx.mode, 4 * H, H, rows):
                 # images of dgates / outputs over all T*B rows; the one-step shift is a row offset into them
-                d_img, y_img = Bf16Image(dgx.reshape(T * B, 4 * H), colsum=True, mode=ctx.mode), shared_image(y, T * B, H, ctx.mode)
+                d_img, y_img = Bf16Image(dgx_f32.reshape(T * B, 4 * H), colsum=True, mode=ctx.mode), shared_image(y, T * B, H, ctx.mode)
                 fwd = not ctx.reverse
                 gemm_img(d_img, 1, d_img.ptr(B if fwd else 0), y_img, 1, y_img.ptr(0 if fwd else B), dW, 4 * H, H, rows, H, beta=1.0, splitk=True)
                 _handoff_put(dgx, d_img)        # the input projection's backward reads the same dgates
             elif T > 1:
-                da = dgx[1:] if not ctx.reverse else dgx[:-1]
+                da = dgx_f32[1:] if not ctx.reverse else dgx_f32[:-1]
                 hp = y[:-1] if not ctx.reverse else y[1:]
                 gemm_raw(da, hp, dW, 4 * H, H, rows, 1, 4 * H, H, 1, H, mode=ctx.mode, splitk=True)
         return dgx, dW, None, None, None, None, None
@@ -1482,6 +1525,9 @@ def lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=False, mode=None, xs_ext
         rowmap = None
     T, B = x.shape[0], x.shape[1]
     gates = None
+    H = w_hh.shape[1]
+    if gx16_ok(mode, rowmap, T, B, H, reverse, xs, w_ih.shape[0], x.device):
+        fill = fill + "|c16"                   # gx as 16-bit rows: half the bytes the projection writes and the recurrence reads
     if gate is not None and linear_gate_fusable(mode, rowmap, xs, w_ih.shape[0]):
         # gate = (weight [1, K], bias): the N = 1 projection over the same inputs rides on this projection's image (LinearGateFn)
         gx, gates = LinearGateFn.apply(w_ih, b_ih + b_hh, gate[0], gate[1], mode, rowmap, fill, *xs)
@@ -1490,7 +1536,6 @@ def lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=False, mode=None, xs_ext
         if gate is not None:
             gates = linear(xs, gate[0], gate[1], mode=mode)
     private = rowmap is not None and rowmap.T == T and rowmap.B == B and linear_uses_images(mode, T * B, w_ih.shape[0], xs)
-    H = w_hh.shape[1]
     if B > MAX_STEP_BATCH and not lstm_persist_slices(B, H, reverse, mode, gx.device):
         # the launch-per-step kernels take at most 64 batch rows (the reference's nn.LSTM takes any, flowtron.py:654-655): the rows
         # are independent, so the recurrence runs per batch chunk on contiguous copies and autograd splits the gradients again

@@ -71,7 +71,8 @@ extern "C" {
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1, FT_F16 = 2 };
 enum { FT_ACT_NONE = 0, FT_ACT_TANH = 1, FT_ACT_RELU = 2, FT_ACT_SIGMOID = 3 };
-enum { FT_GEMM_SPLITK = 1, FT_GEMM_SPLITK_DET = 2 };
+enum { FT_GEMM_SPLITK = 1, FT_GEMM_SPLITK_DET = 2, FT_GEMM_C16 = 4 };   /* FT_GEMM_C16 (ABI 13, ft_gemm_img only): C is a 16-bit matrix of the
+ * call's operand format (bf16; fp16 for the _f16 twin), ldc in 16-bit elements, beta = 0, no split-K: what the persistent forward recurrence reads as gx */
 
 int ft_abi_version(void);
 const char* ft_last_error(void);
@@ -299,10 +300,12 @@ int ft_lstm_persist_bwd_img(const float* dy, int64_t ldy, const float* w_hh, con
  * one stream.  `status` as for ft_lstm_persist_*.  Forward results are bit-identical to ft_lstm_seq_fwd for every R / windowing / role
  * placement; backward to fp32 rounding (R = 4: bit-identical to ft_lstm_persist_bwd's reduce-scatter transport). */
 typedef struct {
-    const float* gx; const int32_t* lens; float* y; int64_t ldy; float* gates; float* cell;   /* as ft_lstm_seq_fwd; time steps ldb rows apart */
+    const void* gx; const int32_t* lens; float* y; int64_t ldy; float* gates; float* cell;   /* as ft_lstm_seq_fwd; time steps ldb rows apart */
     const void* wimg;
     float* state_h; float* state_c;      /* [B][H] fp32: read when t0 > 0, written at the end of the window; NULL (both) for t0 == 0 without successor */
     int32_t B, ldb, t0, t1;
+    int32_t gx16;                        /* 0: gx = fp32 rows [T][ldb][4H]; 1: 16-bit rows of the call's operand format (what ft_gemm_img writes with
+                                          * FT_GEMM_C16: half the bytes; widened exactly before it is added to the fp32 recurrent sums) -- one format per launch */
 } ft_lstm_fwd_role;
 typedef struct {
     const float* dy; int64_t ldy; const int32_t* lens; const float* gates; const float* cell;

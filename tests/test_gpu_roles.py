@@ -95,6 +95,49 @@ def test_forward_rows_per_group_bit_identical_to_launch_per_step(env, B, R, fmt)
     assert float(out[0][pad].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("B,R,edges", [(32, 4, [0, 70]), (32, 8, [0, 33, 70]), (20, 8, [0, 70]), (100, 16, [0, 9, 70])])
+def test_forward_takes_16bit_gx_rows(env, B, R, edges, fmt):
+    """gx as 16-BIT rows of the operand format (what the projection GEMM writes with FT_GEMM_C16; ft_lstm_fwd_role.gx16): widened
+    exactly, so the launch equals the launch-per-step kernel fed with the same values in fp32 -- bit for bit, over several bursts of
+    the doubled burst length, with windows and partially filled groups"""
+    L, ops = env
+    T = edges[-1]
+    gx, w, lens = make(T, B, 7 * B + R + fmt)
+    gx16 = gx.to(ops.op16_dtype(fmt))
+    ref = step_fwd(L, gx16.float(), w, lens, fmt)
+    out = bufs(T, B)
+    st = torch.zeros(2, B, H, device="cuda")
+    wimg = ops.roles_wimg(w, fmt, False)
+    for k in range(len(edges) - 1):
+        ops.roles_launch([ops.fwd_role(gx16, lens, out[0], out[1], out[2], wimg, edges[k], edges[k + 1], st)], R, fmt, gx.device)
+    torch.cuda.synchronize()
+    clean(ops)
+    assert same_fwd(lens, ref, out)
+
+
+def test_image_gemm_writes_16bit_rows(env):
+    """ft_gemm_img with FT_GEMM_C16: the fp32 result + bias rounded ONCE to the operand format in the epilogue, through a row map
+    (compact rows scattered to their time-major places) -- equal to rounding the fp32 output of the same GEMM"""
+    L, ops = env
+    T, B, K, N = 40, 6, 96, 256
+    torch.manual_seed(2)
+    lens = torch.tensor([40, 33, 1, 17, 40, 8], dtype=torch.int32, device="cuda")
+    x = torch.randn(T, B, K, device="cuda")
+    W = torch.randn(N, K, device="cuda") * 0.2
+    bias = torch.randn(N, device="cuda")
+    for fmt in (1, 2):
+        rm = ops.RowMap(lens, T, B)
+        xi, wi = ops.Bf16Image(x.reshape(T * B, K), mode=fmt, rowmap=rm), ops.Bf16Image(W, mode=fmt)
+        y32 = torch.zeros(T, B, N, device="cuda")
+        y16 = torch.zeros(T, B, N, device="cuda", dtype=ops.op16_dtype(fmt))
+        ops.gemm_img(xi, 0, xi.ptr(), wi, 0, wi.ptr(), y32, rm.cap, N, K, N, bias=bias, rowmap=rm, compact=1)
+        ops.gemm_img(xi, 0, xi.ptr(), wi, 0, wi.ptr(), y16, rm.cap, N, K, N, bias=bias, rowmap=rm, compact=1, c16=True)
+        torch.cuda.synchronize()
+        valid = torch.arange(T, device="cuda")[:, None] < lens[None, :]
+        assert torch.equal(y16[valid], y32[valid].to(y16.dtype))
+
+
 @pytest.mark.parametrize("R", [4, 8])
 @pytest.mark.parametrize("edges", [[0, 13, 14, 40, 61], [0, 61], [0, 1, 60, 61]])
 def test_forward_windows_and_two_roles_bit_identical(env, R, edges):
