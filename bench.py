@@ -258,8 +258,8 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
                 decoder layer pair as a pipeline of n + 1 role launches over n time chunks (first / last at 4 rows, the n - 1
                 between them two roles at 8 rows per group) -- 2 x (1 + n + 1) launches per step.
     Algorithmic HBM bytes per launch: the 16-bit fragment image of W_hh once (4H*H*2) + per VALID (t, b) row the fp32
-    rows the recurrence must read and write -- forward: gx row in (4H) + y, saved gates, saved cell out (H + 4H + H); backward:
-    saved gates, cell, dy in (4H + H + H) + dgates out (4H, 16-bit in the image).  The kernels are bound by the per-step dependency
+    rows the recurrence must read and write -- forward: gx row in (4H, 16-bit since round 6) + y, saved gates, saved cell out
+    (H + 4H + H, fp32); backward: saved gates, cell, dy in (4H + H + H) + dgates out (4H, 16-bit in the image).  The kernels are bound by the per-step dependency
     (an L2 hand-off + the cell update per step), not by bandwidth: `frac` is small by construction and `us_per_step` is the figure
     of merit; the launch-per-step kernels they replace are timed beside them."""
     from flowtron_amd import _lib as L
@@ -282,6 +282,10 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
     dimg = ops.Bf16Image.empty_rows(4 * H, rm, mode, dev)
     img_only = os.environ.get("FLOWTRON_LSTM_PERSIST_IMG", "1") == "1"
     wimg = ops.roles_wimg(w, mode, False)
+    gx16 = ops._GX16 and L.is16(mode)              # the step's projections hand gx over as 16-bit rows (ops.gx16_ok)
+    if gx16:
+        gx = gx.to(ops.op16_dtype(mode))
+    gx32 = gx.float()                              # (the launch-per-step yardstick reads fp32 rows)
     n_pair = ops.decoder_pair_chunks(B, H, mode, dev, T)
     edges = ops._chunk_edges(T, n_pair) if n_pair else None
     s1, s2 = torch.zeros(2, B, H, **f), torch.zeros(2, B, H, **f)
@@ -303,7 +307,7 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
         if img_only else
         (lambda: L.check(L.op16("ft_lstm_persist_bwd", mode)(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
                                                                         L.ptr(wp), L.ptr(st), T, B, H, ng_bwd, L.stream()), "persist bwd")),
-        "lstm_fwd_step": lambda: L.check(lib.ft_lstm_seq_fwd(L.ptr(gx), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(ws),
+        "lstm_fwd_step": lambda: L.check(lib.ft_lstm_seq_fwd(L.ptr(gx32), L.ptr(w), L.ptr(lens), L.ptr(y), H, L.ptr(gates), L.ptr(cell), L.ptr(ws),
                                                               T, B, H, 0, mode, L.stream()), "step fwd"),
         "lstm_bwd_step_bf16": lambda: L.check(lib.ft_lstm_seq_bwd(L.ptr(dy), H, L.ptr(w), L.ptr(lens), L.ptr(gates), L.ptr(cell), L.ptr(dgx),
                                                                    L.ptr(ws), T, B, H, 0, mode, L.stream()), "step bwd"),
@@ -336,7 +340,7 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
     mfma_us = 0.47
     bwd_out = 2 * 4 * H if img_only else 4 * 4 * H
     for name, kname, per_row, repl, gran_kb in (("lstm_persist_bwd_k", "lstm_persist_bwd_rs_k", 4 * (4 * H + H + H) + bwd_out, "lstm_bwd_step_bf16", 32),
-                                                ("lstm_roles_fwd_k", "lstm_roles_fwd_k<4, false>", 4 * (4 * H + H + 4 * H + H), "lstm_fwd_step", 8)):
+                                                ("lstm_roles_fwd_k", "lstm_roles_fwd_k<4, false, %s>" % ("true" if gx16 else "false"), (2 if gx16 else 4) * 4 * H + 4 * (H + 4 * H + H), "lstm_fwd_step", 8)):
         nbytes = 2 * 4 * H * H + rows * per_row
         ach = nbytes / (us[name] * 1e-6) / 1e9
         per_step = us[name] / T
@@ -382,8 +386,8 @@ def persist_roofline(B, H, T, lens_cpu, mode=1):
         fwd["decoder_pair_pipeline"] = {
             "chunks": n_pair, "launches": n_pair + 1, "us_per_pipeline": round(us["pair_pipeline"], 1),
             "us_per_pair_step": round(us["pair_pipeline"] / T, 3), "two_single_launches_us_per_pair_step": round(2 * us["lstm_roles_fwd_k"] / T, 3),
-            "kernel": "lstm_roles_fwd_k<8, false> (two roles: layer 0 on XCDs 0-3, layer 1 one chunk behind on XCDs 4-7; mfma_rows_used 8/16) "
-                      "between one lstm_roles_fwd_k<4, false> launch at either end",
+            "kernel": "lstm_roles_fwd_k<8, ..> (two roles: layer 0 on XCDs 0-3, layer 1 one chunk behind on XCDs 4-7; mfma_rows_used 8/16) "
+                      "between one lstm_roles_fwd_k<4, ..> launch at either end",
             "note": "recurrence launches only; the chunks' input-projection GEMMs (ops.DecoderPairFn) run between them in the step"}
         fwd["launches_per_step"] = 2 * (1 + n_pair + 1)
         fwd["us_per_training_step"] = round(2 * (us["lstm_roles_fwd_k"] + us["pair_pipeline"]), 1)

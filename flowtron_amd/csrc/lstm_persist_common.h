@@ -42,7 +42,9 @@ __device__ __forceinline__ unsigned row_shl(unsigned v) {
 // for step n+1 has already gathered step n from every producer, hence stands behind every producer's reset: it can only see
 // the sentinel or the new value, never the value of step n-2.  A dword is two 16-bit operands; a pair of NaNs with all-ones
 // payloads (the converters produce the canonical 0x7FC0 / 0xFFC0 / 0x7E00) would read as "not yet" and end in the bounded
-// time-out like any other failure.  Buffer layout [group][3][w][lg][64 lanes][4 dwords].
+// time-out like any other failure.  Buffer layout [group][buffers][w][lg][64 lanes][4 dwords].  (Round 6, lstm_roles.hip: FOUR rotating
+// buffers -- the reset of a step targets the buffer two steps ahead and is issued BEHIND the publish, so the wait in front of a
+// publish covers a reset that is a whole step old instead of one just issued.)
 constexpr unsigned SENT = 0xFFFFFFFFu;
 template <int RPGP, int NCW>
 __device__ __forceinline__ int bare_index(int b, int k) {       // dword index of the operand pair (k, k+1), k even

@@ -31,7 +31,8 @@ constexpr int SBMAX = 32;
 constexpr int RRING = 8, RDIST = 6;                   // backward ring (see lstm_persist.hip)
 
 // ---- launch context layout (bytes): [256: census, 2 kinds x 2 sets x 8 counters] [fwd set 0][fwd set 1][bwd set 0][bwd set 1]
-constexpr size_t FWD_SET_DW = (size_t)8 * 3 * (NCHUNK * 32 * RMAX / 2);          // dwords: 8 groups x 3 buffers x 32 KB (R = 16)
+constexpr int NBUF = 4;                               // rotating hand-off buffers of the forward kernel (see its publish)
+constexpr size_t FWD_SET_DW = (size_t)8 * NBUF * (NCHUNK * 32 * RMAX / 2);       // dwords: 8 groups x 4 buffers x 32 KB (R = 16)
 constexpr size_t BWD_SET_FL = (size_t)2 * 8 * 32 * 32 * 32 * RMAX;               // floats: 2 parities x 8 groups x 2 MB (R = 16)
 constexpr size_t CTX_BYTES = 256 + 2 * FWD_SET_DW * 4 + 2 * BWD_SET_FL * 4;
 
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256, 1) void lstm_roles_fwd_k(FwdLaunchP P) {
     const int li = lane & 15, kg = lane >> 4;
     int grp, q;
     if (!join_group_local<CPG>(P.census + (P.phase & 1) * 8, P.status, tid, grp, q)) return;
-    preset_other(reinterpret_cast<uint4*>(P.hand + (size_t)((P.phase + 1) & 1) * FWD_SET_DW), (size_t)8 * 3 * (NCHUNK * 32 / 2) * P.reset_rows / 4,
+    preset_other(reinterpret_cast<uint4*>(P.hand + (size_t)((P.phase + 1) & 1) * FWD_SET_DW), (size_t)8 * NBUF * (NCHUNK * 32 / 2) * P.reset_rows / 4,
                  P.census + ((P.phase + 1) & 1) * 8, grp * CPG + q, tid);
     const int gpr = 8 / P.nroles;                                // XCD groups per role
     const FwdRoleP p = grp < gpr ? P.role[0] : P.role[1];
@@ -226,8 +227,8 @@ __global__ __launch_bounds__(256, 1) void lstm_roles_fwd_k(FwdLaunchP P) {
             *cp = po[e][5];
         }
     };
-    unsigned* const bare0 = uniform_ptr(P.hand + (size_t)(P.phase & 1) * FWD_SET_DW + (size_t)grp * 3 * DWG);
-    const __amdgpu_buffer_rsrc_t rbare = __builtin_amdgcn_make_buffer_rsrc(bare0, 0, 3 * DWG * 4, 0x00020000);
+    unsigned* const bare0 = uniform_ptr(P.hand + (size_t)(P.phase & 1) * FWD_SET_DW + (size_t)grp * NBUF * DWG);
+    const __amdgpu_buffer_rsrc_t rbare = __builtin_amdgcn_make_buffer_rsrc(bare0, 0, NBUF * DWG * 4, 0x00020000);
     auto publish = [&](int buf) {                                // h of this thread's elements as operand pairs (even units store)
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void lstm_roles_fwd_k(FwdLaunchP P) {
     int m3 = 0;                                                  // buffer the current step publishes into
     const bool carry = t0 > 0 && tg > t0;
     if (carry) {
-        // state of step t0 - 1 from the previous window: published as "step -1" into buffer 0, the window's steps then use 1, 2, 0, ..
+        // state of step t0 - 1 from the previous window: published as "step -1" into buffer 0, the window's steps then use 1, 2, 3, 0, ..
         if (erole) {
 #pragma unroll
             for (int e = 0; e < EPT; ++e)
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void lstm_roles_fwd_k(FwdLaunchP P) {
 #pragma unroll
         for (int j = 0; j < TPC; ++j) asm volatile("" : "+v"(acc[j]));
         if (n > 0 || carry) {
-            const int boff = __builtin_amdgcn_readfirstlane((m3 == 0 ? 2 : m3 - 1) * (DWG * 4));  // the previous step's buffer (scalar offset)
+            const int boff = __builtin_amdgcn_readfirstlane(((m3 + NBUF - 1) % NBUF) * (DWG * 4));  // the previous step's buffer (scalar offset)
             u32x4 ld[NLG];
 #pragma unroll
             for (int g = 0; g < NLG; ++g) ld[g] = __builtin_amdgcn_raw_buffer_load_b128(rbare, voff, soff_w + g * 1024 + boff, 2);
@@ -357,14 +358,6 @@ __global__ __launch_bounds__(256, 1) void lstm_roles_fwd_k(FwdLaunchP P) {
         if (prof) st2 = wall_clock64();
         if (n > 0) store_outputs(t - 1);
         if (erole) {
-            const int nxt = m3 == 2 ? 0 : m3 + 1;
-            // reset this thread's slots of the buffer after next's predecessor (it holds step t - 2, consumed by everybody) first: the
-            // acknowledgement returns under the cell update below, and the publish waits for it
-            if ((el & 1) == 0) {
-#pragma unroll
-                for (int e = 0; e < EPT; ++e)
-                    __hip_atomic_store((gu32*)(bare0 + nxt * DWG + bare_index<R, 8>(er0 + ERW * e, eu)), SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
             const int j = el >> 2, ul = el & 3;
             float ig[EPT], fg[EPT], gg[EPT], og[EPT];
 #pragma unroll
@@ -386,8 +379,21 @@ __global__ __launch_bounds__(256, 1) void lstm_roles_fwd_k(FwdLaunchP P) {
                     c_state[e] = c_new; h_state[e] = h_new;
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the resets above are in the L2 before the publish leaves
+            // Sentinel protocol over FOUR rotating buffers (round 6; three through round 5).  Step t publishes into buffer m3 and then
+            // resets this thread's slots of buffer m3 + 2 -- it holds step t - 2, which every consumer has finished reading: they all
+            // published step t - 1, and all four waves of this CU had gathered all of it when they passed the barrier above.  A
+            // consumer polls that buffer for step t + 2, i.e. after it has seen this CU's publish of step t + 1 -- and THAT publish
+            // waits (vmcnt(0) below, one step from now) for this reset's acknowledgement, which by then is a whole step old.  With three
+            // buffers the reset had to be acknowledged before the publish of the SAME step: a store round trip (~0.1-0.2 us) on the
+            // critical path of every step.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the previous step's reset is in the L2 before this publish leaves
             publish(m3);
+            if ((el & 1) == 0) {
+                const int rst = (m3 + 2) % NBUF;
+#pragma unroll
+                for (int e = 0; e < EPT; ++e)
+                    __hip_atomic_store((gu32*)(bare0 + rst * DWG + bare_index<R, 8>(er0 + ERW * e, eu)), SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             if (prof) st3 = wall_clock64();
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(256, 1) void lstm_roles_fwd_k(FwdLaunchP P) {
                 o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = npass;
             }
         }
-        m3 = m3 == 2 ? 0 : m3 + 1;
+        m3 = (m3 + 1) % NBUF;
     }
     if (dead) {
         if (lane == 0) atomicExch(P.status, 1);

@@ -1202,10 +1202,16 @@ def _chunk_rowmaps(lens, edges, B):
         k = torch.arange(n + 1, device=lens.device, dtype=torch.int64)
         e = torch.div(k * T + n // 2, n, rounding_mode="floor").to(torch.int32)
         if len(_EDGE_CACHE) > 64:
-            _EDGE_CACHE.clear()
+            _EDGE_CACHE.clear()                  # (drops the last-maps entries too)
         ev = _EDGE_CACHE[key] = (e[:-1].contiguous(), (e[1:] - e[:-1]).contiguous())
+    # both flows of a forward pass chunk the same lengths the same way: the maps of the last (lens tensor, edges) are kept
+    ck = (lens.data_ptr(), lens._version, key)
+    if _EDGE_CACHE.get("last_key") == ck and _EDGE_CACHE["last_lens"]() is lens:
+        return _EDGE_CACHE["last_maps"]
     lk = torch.minimum((lens[None, :] - ev[0][:, None]).clamp_(min=0), ev[1][:, None])
-    return [RowMap(lk[k], edges[k + 1] - edges[k], B) for k in range(len(edges) - 1)]
+    maps = [RowMap(lk[k], edges[k + 1] - edges[k], B) for k in range(len(edges) - 1)]
+    _EDGE_CACHE["last_key"], _EDGE_CACHE["last_lens"], _EDGE_CACHE["last_maps"] = ck, _weakref.ref(lens), maps
+    return maps
 
 
 class DecoderPairFn(torch.autograd.Function):
@@ -1228,7 +1234,8 @@ class DecoderPairFn(torch.autograd.Function):
         y1, g1, c1 = torch.empty(T, B, H, **f), torch.empty(T, B, H4, **f), torch.empty(T, B, H, **f)
         g16 = gx0.dtype != torch.float32          # 16-bit gx rows (decoder_pair: gx16_ok): layer 1's chunk projections write them too
         gx1 = torch.empty(T, B, H4, device=dev, dtype=gx0.dtype)
-        st0, st1 = torch.zeros(2, B, H, **f), torch.zeros(2, B, H, **f)
+        # (carried state: written by a window before the next one reads it -- a group that runs in window k ran in window k - 1)
+        st0, st1 = torch.empty(2, B, H, **f), torch.empty(2, B, H, **f)
         wi0, wi1 = roles_wimg(w_hh0, mode, False), roles_wimg(w_hh1, mode, False)
         w_img = Bf16Image.of_weight(w_ih1, mode)
         b1 = b_ih1 + b_hh1
