@@ -39,10 +39,53 @@ __device__ __forceinline__ float rs(float q, float k) {
     else return rsig(q + k);
 }
 
-// scores of one a-chunk for a 4x4 (t, l) micro-tile (UNI: one query row only); qs / ks hold q', k' (sum form) or 2^q', 2^k' (PROD)
+// scores of one a-chunk for a 4x4 (t, l) micro-tile (UNI: one query row only); qs / ks hold q', k' (sum form) or 2^q', 2^k' (PROD).
+// PROD form with PACKED fp32 math (round 6): the two non-transcendental operations per element -- Eq Ek + 1 and acc += v r -- run as
+// v_pk_fma_f32 on the (x, y) / (z, w) halves of the staged float4s, the accumulators as (even a, odd a) pairs that are added once at
+// the end of the chunk: 2 packed instructions per 4 elements instead of 8 scalar ones beside the 4 v_rcp_f32 (0.556 -> 0.529 ms per
+// call at the bench shape: the pass is stall-bound at two waves per SIMD -- 239 VGPRs, 64 KB of LDS --, VALU busy 44 %,
+// profiles/r06_pmc_VALU_TRANS.json; the backward pass, VALU busy 71 %, gains more from the same change).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 template <bool PROD, bool UNI>
 __device__ __forceinline__ void score_chunk(const float* qs, const float* ks, const float* vs, int tg, int tl, const bool (&jact)[4],
                                             float (&acc)[4][4], float& vsum, int LDAs, int ACs) {
+    if constexpr (PROD) {
+        f32x2 acc2[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x2){0.f, 0.f};
+        const f32x2 one = {1.f, 1.f};
+#pragma unroll 2
+        for (int a4 = 0; a4 < ACs / 4; ++a4) {
+            const float4 vv = *reinterpret_cast<const float4*>(vs + a4 * 4);
+            vsum += (vv.x + vv.y) + (vv.z + vv.w);
+            const f32x2 v01 = {vv.x, vv.y}, v23 = {vv.z, vv.w};
+            float4 q[4];
+#pragma unroll
+            for (int i = 0; i < (UNI ? 1 : 4); ++i) q[i] = *reinterpret_cast<const float4*>(qs + ((UNI ? 0 : tg * 4) + i) * LDAs + a4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (jact[j]) {
+                    const float4 kk = *reinterpret_cast<const float4*>(ks + (j * 32 + tl) * LDAs + a4 * 4);
+                    const f32x2 k01 = {kk.x, kk.y}, k23 = {kk.z, kk.w};
+#pragma unroll
+                    for (int i = 0; i < (UNI ? 1 : 4); ++i) {
+                        const f32x2 d01 = pk_fma((f32x2){q[i].x, q[i].y}, k01, one), d23 = pk_fma((f32x2){q[i].z, q[i].w}, k23, one);
+                        const f32x2 r01 = {__builtin_amdgcn_rcpf(d01.x), __builtin_amdgcn_rcpf(d01.y)};
+                        const f32x2 r23 = {__builtin_amdgcn_rcpf(d23.x), __builtin_amdgcn_rcpf(d23.y)};
+                        acc2[i][j] = pk_fma(v23, r23, pk_fma(v01, r01, acc2[i][j]));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (UNI ? 1 : 4); ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] += acc2[i][j].x + acc2[i][j].y;
+        return;
+    }
 #pragma unroll 2
     for (int a4 = 0; a4 < ACs / 4; ++a4) {
         const float4 vv = *reinterpret_cast<const float4*>(vs + a4 * 4);
@@ -303,21 +346,25 @@ __global__ __launch_bounds__(256) void attn_dqdk_k(const float* __restrict__ Q, 
     const int a = aw + lane;
     const bool av = a < A;
     const int ac = av ? a : A - 1;      // clamp: keeps the loads unconditional, results of idle lanes are dropped
-    float q[32], eq[32], dq[32];
+    // rows in PAIRS (2 i, 2 i + 1): the non-transcendental arithmetic of an element -- Eq Ek + 1, u = r - r^2, dq += d u, dk += d u,
+    // dv' += d r -- runs as v_pk_fma_f32 (round 6: five packed instructions per two elements where six scalar ones per element stood;
+    // sum_l,t d tanh = sum d - 2 sum d r, with sum d taken once per key from the de tile)
+    f32x2 eq2[16], dq2[16];
     bool qbig = false;
+    auto qrow = [&](int i) { return C2 * Q[((long)min(t0 + i, T - 1) * B + b) * A + ac]; };     // (the rare sum-form path re-reads it: 32 registers less)
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const int t = min(t0 + i, T - 1);
-        q[i] = C2 * Q[((long)t * B + b) * A + ac];
-        qbig |= !(fabsf(q[i]) <= EXP_SAFE);
-        eq[i] = __builtin_amdgcn_exp2f(q[i]);
-        dq[i] = 0.f;
+    for (int i = 0; i < 16; ++i) {
+        const float q0 = qrow(2 * i), q1 = qrow(2 * i + 1);
+        qbig |= !(fabsf(q0) <= EXP_SAFE) | !(fabsf(q1) <= EXP_SAFE);
+        eq2[i] = (f32x2){__builtin_amdgcn_exp2f(q0), __builtin_amdgcn_exp2f(q1)};
+        dq2[i] = (f32x2){0.f, 0.f};
     }
     float dva = 0.f;
     const float* kp = K + (long)b * A + ac;
     const long ks = (long)B * A;
     const float va4 = 4.f * v[ac];
     float kv_next = (len > 0) ? C2 * kp[0] : 0.f;
+    const f32x2 one = {1.f, 1.f};
     for (int l = 0; l < len; ++l) {
         const float kv = kv_next;
         if (l + 1 < len) kv_next = C2 * kp[(long)(l + 1) * ks];
@@ -325,20 +372,27 @@ __global__ __launch_bounds__(256) void attn_dqdk_k(const float* __restrict__ Q, 
         // product form (one v_rcp per element) unless this wave holds an out-of-range value for this key (wave-uniform choice)
         if (!__any(qbig || !(fabsf(kv) <= EXP_SAFE))) {
             const float ek = __builtin_amdgcn_exp2f(kv);
+            const f32x2 ek2 = {ek, ek};
+            f32x2 dk2 = {0.f, 0.f}, dr2 = {0.f, 0.f}, ds2 = {0.f, 0.f};
 #pragma unroll
             for (int i4 = 0; i4 < 8; ++i4) {
                 const float4 d4 = *reinterpret_cast<const float4*>(de_s + l * 32 + i4 * 4);     // same address in every lane: broadcast
-                const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+                const f32x2 d01 = {d4.x, d4.y}, d23 = {d4.z, d4.w};
+                ds2 = ds2 + d01 + d23;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = i4 * 4 + j;
-                    const float r = rsig_prod(eq[i], ek);
-                    const float u = fmaf(-r, r, r);              // r (1 - r) = (1 - tanh^2) / 4
-                    dq[i] = fmaf(d[j], u, dq[i]);
-                    dkp = fmaf(d[j], u, dkp);
-                    dva = fmaf(d[j], fmaf(-2.f, r, 1.f), dva);
+                for (int h = 0; h < 2; ++h) {
+                    const int i = i4 * 2 + h;
+                    const f32x2 d = h ? d23 : d01;
+                    const f32x2 den = pk_fma(eq2[i], ek2, one);
+                    const f32x2 r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                    const f32x2 u = pk_fma(-r, r, r);            // r (1 - r) = (1 - tanh^2) / 4
+                    dq2[i] = pk_fma(d, u, dq2[i]);
+                    dk2 = pk_fma(d, u, dk2);
+                    dr2 = pk_fma(d, r, dr2);
                 }
             }
+            dkp = dk2.x + dk2.y;
+            dva += (ds2.x + ds2.y) - 2.f * (dr2.x + dr2.y);
         } else {
 #pragma unroll
             for (int i4 = 0; i4 < 8; ++i4) {
@@ -347,9 +401,10 @@ __global__ __launch_bounds__(256) void attn_dqdk_k(const float* __restrict__ Q, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i = i4 * 4 + j;
-                    const float r = rsig(q[i] + kv);
+                    const float r = rsig(qrow(i) + kv);
                     const float u = fmaf(-r, r, r);
-                    dq[i] = fmaf(d[j], u, dq[i]);
+                    if (j & 1) dq2[i >> 1].y = fmaf(d[j], u, dq2[i >> 1].y);
+                    else dq2[i >> 1].x = fmaf(d[j], u, dq2[i >> 1].x);
                     dkp = fmaf(d[j], u, dkp);
                     dva = fmaf(d[j], fmaf(-2.f, r, 1.f), dva);
                 }
@@ -361,7 +416,7 @@ __global__ __launch_bounds__(256) void attn_dqdk_k(const float* __restrict__ Q, 
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
             const int t = t0 + i;
-            if (t < T) dQ[((long)t * B + b) * A + a] = dq[i] * va4;
+            if (t < T) dQ[((long)t * B + b) * A + a] = ((i & 1) ? dq2[i >> 1].y : dq2[i >> 1].x) * va4;
         }
         atomicAdd(dv + a, dva);
     }
