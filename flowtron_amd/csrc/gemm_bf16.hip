@@ -137,11 +137,12 @@ __global__ __launch_bounds__(256) void img_table_k(ImgTable t) {
 }
 
 // same image, plus the fp32 column sums of the SOURCE (bias gradients: the conversion pass reads the output gradient
-// anyway, so ft_colsum's second sweep over it disappears).  Block = 32 column groups x 8 row lanes over a 256-row slab;
-// grid (Cp/256, Rp/256); colsum [Cc] must be zero on entry, slabs combine with fp32 atomics (as ft_colsum does).
+// anyway, so ft_colsum's second sweep over it disappears).  Block = 32 column groups x 8 row lanes over a 64-row slab;
+// grid (Cp/256, Rp/64); colsum [Cc] must be zero on entry, slabs combine with fp32 atomics (as ft_colsum does).
 // ysrc != nullptr: src is an OUTPUT GRADIENT dy and ysrc the saved output y = act(pre) of the same rows: the pass images (and sums)
 // dpre = dy act'(pre) (ft_act_bwd's formulas) -- the activation backward of a dense layer rides on the conversion pass, no fp32
 // dpre tensor is written or read back.
+constexpr int IMG_SUM_SLAB = 64;
 __global__ __launch_bounds__(256) void img_rows_sum_k(const float* __restrict__ src, long sr, int R, int Cc,
                                                       unsigned short* __restrict__ dst, int Rp, int Cp, int vec,
                                                       float* __restrict__ colsum, const int* __restrict__ rowmap,
@@ -150,14 +151,16 @@ __global__ __launch_bounds__(256) void img_rows_sum_k(const float* __restrict__ 
     __shared__ float red[8][32][9];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = (blockIdx.x * 32 + tx) * 8;
-    const int r0 = blockIdx.y * 256;
+    // (slabs of 64 rows since round 6: a 256-row slab gave a [19 000 x 1024] gradient 300 workgroups -- 1.2 per CU, latency-bound at
+    //  1.7 TB/s; four times the workgroups, four times the column-sum atomics: one per column and slab)
+    const int r0 = blockIdx.y * IMG_SUM_SLAB;
     int Rz = Rp;
     if (rdev) R = mapped_rows(rdev, Rp, Rz);
     if (r0 >= Rz) return;                                           // whole slab beyond the mapped rows (uniform)
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (c < Cp) {
 #pragma unroll 4
-        for (int k = 0; k < 32; ++k) {
+        for (int k = 0; k < IMG_SUM_SLAB / 8; ++k) {
             const int ri = r0 + ty + 8 * k;
             if (ri >= Rz) break;
             int r = ri;
@@ -1084,7 +1087,7 @@ static int image_colsum_impl(const float* src, int64_t ld, int64_t rows, int64_t
     const int Rp = (int)up((size_t)rows + 32, 256), Cp = (int)up((size_t)cols, 256);
     const int vec = (reinterpret_cast<uintptr_t>(src) % 16 == 0 && ld % 4 == 0) ? 1 : 0;
     if (clear) FT_CHECK_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)cols, st));
-    hipLaunchKernelGGL(img_rows_sum_k, dim3(cdiv(Cp, 256), cdiv(Rp, 256)), dim3(256), 0, st, src, (long)ld, (int)rows, (int)cols,
+    hipLaunchKernelGGL(img_rows_sum_k, dim3(cdiv(Cp, 256), cdiv(Rp, IMG_SUM_SLAB)), dim3(256), 0, st, src, (long)ld, (int)rows, (int)cols,
                        reinterpret_cast<unsigned short*>(dst), Rp, Cp, vec, colsum, nullptr, nullptr);
     FT_CHECK_LAUNCH();
     return FT_OK;
@@ -1133,7 +1136,7 @@ static int image_rows_act_bwd_impl(const float* dy, int64_t ld, const float* y, 
     const int Rp = (int)up((size_t)cap_rows + 32, 256), Cp = (int)up((size_t)cols, 256);
     const int vec = (reinterpret_cast<uintptr_t>(dy) % 16 == 0 && ld % 4 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 && ldy % 4 == 0) ? 1 : 0;
     if (clear) FT_CHECK_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)cols, st));
-    hipLaunchKernelGGL(img_rows_sum_k, dim3(cdiv(Cp, 256), cdiv(Rp, 256)), dim3(256), 0, st, dy, (long)ld, (int)cap_rows, (int)cols,
+    hipLaunchKernelGGL(img_rows_sum_k, dim3(cdiv(Cp, 256), cdiv(Rp, IMG_SUM_SLAB)), dim3(256), 0, st, dy, (long)ld, (int)cap_rows, (int)cols,
                        reinterpret_cast<unsigned short*>(dst), Rp, Cp, vec, colsum, rowmap, rows_dev, y, (long)ldy, act);
     FT_CHECK_LAUNCH();
     return FT_OK;
@@ -1177,7 +1180,7 @@ static int image_rows_impl(const float* src, int64_t ld, int64_t cap_rows, int64
     } else {
         const int vec = (reinterpret_cast<uintptr_t>(src) % 16 == 0 && ld % 4 == 0) ? 1 : 0;
         if (clear) FT_CHECK_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)cols, st));
-        hipLaunchKernelGGL(img_rows_sum_k, dim3(cdiv(Cp, 256), cdiv(Rp, 256)), dim3(256), 0, st, src, (long)ld, (int)cap_rows, (int)cols,
+        hipLaunchKernelGGL(img_rows_sum_k, dim3(cdiv(Cp, 256), cdiv(Rp, IMG_SUM_SLAB)), dim3(256), 0, st, src, (long)ld, (int)cap_rows, (int)cols,
                            reinterpret_cast<unsigned short*>(dst), Rp, Cp, vec, colsum, rowmap, rows_dev);
     }
     FT_CHECK_LAUNCH();

@@ -1076,6 +1076,7 @@ def test_image_only_gradient_reads_nan_for_a_foreign_consumer_and_anomaly_mode_g
 
     def run(img_mode, hook, anomaly=False):
         monkeypatch.setattr(ops, "_PERSIST_IMG", img_mode)
+        monkeypatch.setattr(ops, "_GX16", False)                          # (bitwise comparison across the modes: gx as fp32 rows in all of them)
         torch.empty(64 << 20, device="cuda").fill_(7.0)                  # leave recognisable garbage in the allocator's pool
         x, w_ih, w_hh = x0.clone().requires_grad_(True), w_ih0.clone().requires_grad_(True), w_hh0.clone().requires_grad_(True)
         rm = ops.RowMap(lens, T, B)
@@ -1258,11 +1259,12 @@ def test_compact_linear_equals_padded_linear_on_valid_rows(env, monkeypatch, act
 
 
 @pytest.mark.parametrize("H", [128, 1024])
-def test_compact_lstm_layer_equals_padded(env, H):
+def test_compact_lstm_layer_equals_padded(env, H, monkeypatch):
     """ops.lstm_layer with a RowMap (compact input projection, compact dW_ih / dW_hh with the one-step shift as a one-ROW shift
     across the separator rows) against the padded path: y and dx bit-identical on valid frames, weight gradients to summation
     order.  H = 1024 runs the persistent recurrences, H = 128 the launch-per-step kernels."""
     L, ops = env
+    monkeypatch.setattr(ops, "_GX16", False)          # (bitwise: gx as fp32 rows on both paths; the 16-bit rows are held against fp32 ones below)
     torch.manual_seed(5)
     T, B, K = 37, 5, 80
     lens = [37, 37, 20, 3, 1]
@@ -1284,6 +1286,18 @@ def test_compact_lstm_layer_equals_padded(env, H):
     assert torch.equal(res[0][1][m], res[1][1][m]) and float(res[1][1][~m].abs().max()) == 0.0
     for a, b_, name in zip(res[1][2:], res[0][2:], ("dW_ih", "dW_hh", "db_ih", "db_hh")):
         assert rel(a, b_) < 5e-6, (name, rel(a, b_))
+    if H == 1024:
+        # round 6: the compact projection hands gx to the persistent recurrence as 16-BIT rows (ops.gx16_ok): one more operand-grade
+        # rounding (2^-9 relative on gx) -- y within 2e-2 absolute, gradients within 2e-2 relative of the fp32-row path
+        monkeypatch.setattr(ops, "_GX16", True)
+        d = [t.clone().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
+        y = ops.lstm_layer(d[0], lens32, d[1], d[2], d[3], d[4], mode=1, rowmap=ops.RowMap(lens32, T, B), fill="dx")
+        y.backward(go)
+        torch.cuda.synchronize()
+        ops.check_persist_status()
+        assert mad(y, res[1][0]) < 2e-2 and mad(y, res[1][0]) > 0.0, "the 16-bit rows were not used"
+        for a, b_, name in zip([t.grad for t in d], res[1][1:], ("dx", "dW_ih", "dW_hh", "db_ih", "db_hh")):
+            assert rel(a, b_) < 2e-2, (name, rel(a, b_))
 
 
 @pytest.mark.parametrize("act", [0, 1])
