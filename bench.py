@@ -950,8 +950,9 @@ def main():
                            "peak": 2500.0, "unit": "TFLOP/s", "frac": round(frames_per_gpu * 325e6 / 2.5e15, 5), "traffic": None,
                            "flop_per_valid_frame": 325e6,
                            "gemm_mfma_busy_frac_pmc": {k: dict(zip(("frac", "pmc_round"), pmc_value("MFMA_BUSY", k, "mfma_busy_frac", with_source=True)))
-                                                       for k in ("gemm_bf16_k<true, true, true, 256>", "gemm_bf16_k<false, true, false, 128>",
-                                                                 "gemm_bf16_k<false, false, false, 128>", "gemm_bf16_big_k")}}
+                                                       for k in ("gemm_bf16_k<true, true, true, 256, 32>", "gemm_bf16_k<false, true, false, 128, 64>",
+                                                                 "gemm_bf16_k<false, true, false, 128, 32>",
+                                                                 "gemm_bf16_k<false, false, false, 128, 32>", "gemm_bf16_p256_k")}}
         if args.config == "ljs_cumm":
             try:
                 res["roofline"]["cumulative_attention"] = cumm_roofline(args.batch, batch_cpu["in_lens"], mode)

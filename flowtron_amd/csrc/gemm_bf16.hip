@@ -325,18 +325,56 @@ __device__ __forceinline__ void tr_wait(bf16x4 (&t)[8], bf16x4 (&u)[8]) {
                  "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]));
 }
 
+// k-contiguous operand with 64-WIDE k stages: a DMA piece is 8 image rows x 128 B -- whole cache lines, where the 32-wide stage
+// above asks the L2 for 16 half lines per piece.  Measured with nothing but the DMAs in the loop (scripts/exp/dma_stream_probe.hip,
+// profiles/r06_dma_stream_probe.log): 16-row x 64 B pieces stream 16.5 TB/s into the LDS of the 256 CUs at 4 workgroups per CU,
+// 8-row x 128 B pieces 21 TB/s at 2 per CU (24.5 at 4).  LDS image: 128-byte rows, the 16-byte chunk c of row r stored at
+// c ^ ((r >> 1) & 7) (swizzle on the DMA source, as gemm_bf16_p256_k); the fragment of k-step ks is one ds_read_b128.
+template <int RT>
+struct Operand64 {
+    static constexpr int NS = RT / 32;         // pieces per wave and stage (the wave stages rows 8 NS wave .. + 8 NS - 1)
+    static constexpr int WT = RT / 32;         // 16-row fragments per wave tile
+    const unsigned short* src0;                // this lane's source of piece 0 (k = 0, chunk swizzle of the even pieces)
+    long ld8;                                  // elements between pieces (8 rows)
+    int dst0;                                  // byte offset of piece 0 inside the operand's stage buffer
+    int xodd;                                  // element offset that turns the even pieces' chunk into the odd pieces' (c ^ 4)
+    int roff;
+    __device__ __forceinline__ void init(const unsigned short* img, long ld, int r0, int wave, int lane, int wsel) {
+        const int li = lane & 15, kg = lane >> 4;
+        const int prow = lane >> 3, pch = lane & 7;
+        const int c = pch ^ (prow >> 1);                           // rows 8 (wave NS + g) + prow: ((r >> 1) & 7) = (prow >> 1) | 4 (g & 1)
+        src0 = img + (size_t)(r0 + wave * NS * 8 + prow) * ld + c * 8;
+        xodd = ((c ^ 4) - c) * 8;
+        ld8 = 8 * ld;
+        dst0 = wave * NS * 1024;
+        roff = (wsel * (RT / 2) + li) * 128 + ((kg ^ (li >> 1)) << 4);
+    }
+    __device__ __forceinline__ void issue(unsigned char* sbuf, int t) const {       // t counts 64-wide stages
+#pragma unroll
+        for (int g = 0; g < NS; ++g)
+            __builtin_amdgcn_global_load_lds((glb_void*)(src0 + (size_t)t * 64 + (size_t)g * ld8 + ((g & 1) ? xodd : 0)),
+                                             (lds_void*)(sbuf + dst0 + g * 1024), 16, 0, 0);
+    }
+    __device__ __forceinline__ bf16x8 frag(const unsigned char* sbuf, int i, int ks) const {
+        return *reinterpret_cast<const bf16x8*>(sbuf + ((roff + (i << 11)) ^ (ks << 6)));
+    }
+};
+
 // RTA = rows of the workgroup tile (128, or 256: wave tile 128 x 64 = 8 x 4 MFMA tiles -- 12 fragment reads feed 32 MFMAs instead of
 // 8 feeding 16, which takes the LDS pipe off the critical path; 2 workgroups per CU, 196 VGPRs)
-template <bool AKM, bool BKM, bool SPLIT, int RTA>
-__global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
-    constexpr int OPA = RTA * 64, OPB = 8192;          // bytes per operand per stage
+// KS = 64: 64-wide k stages (two MFMA k-steps per barrier; the k-contiguous operands as Operand64, a k-major operand as two of its
+// 32-wide sub-stages side by side), 64 KiB of LDS, 2 workgroups per CU; t0 / t1 / ksteps keep counting 32-wide steps (t0 even)
+template <bool AKM, bool BKM, bool SPLIT, int RTA, int KS = 32>
+__global__ __launch_bounds__(256, (RTA == 256 || KS == 64) ? 2 : 4) void gemm_bf16_k(BfP p) {
+    constexpr int KQ = KS / 32;                        // MFMA k-steps per stage
+    constexpr int OPA = RTA * 64 * KQ, OPB = 8192 * KQ;     // bytes per operand per stage
     constexpr int TI = RTA / 32;                       // 16-row fragments of the wave tile along M
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (OPA + OPB)];     // [stage][A | B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, kg = lane >> 4;
     int tile = blockIdx.x;
-    const int t0 = blockIdx.y * p.ksteps;
+    int t0 = blockIdx.y * p.ksteps;
     int t1 = (t0 + p.ksteps < p.nk) ? t0 + p.ksteps : p.nk;
     int rows_lim = p.M, gy = p.gy;
     if (p.compact) {
@@ -348,9 +386,17 @@ __global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
             gy = (rows_lim + RTA - 1) / RTA;
             if (gy == 0) return;
         } else {
-            const int nk_eff = (R - p.k_shift + 31) >> 5;
-            t1 = t1 < nk_eff ? t1 : nk_eff;
-            if (SPLIT && t0 >= t1) return;                          // this k-slice lies entirely in the unused tail
+            int nk_eff = (R - p.k_shift + 31) >> 5;
+            nk_eff = nk_eff < p.nk ? nk_eff : p.nk;
+            if constexpr (SPLIT) {
+                // the k-slices divide the rows the batch HAS, not the capacity the host sized the grid for: every workgroup of
+                // the launch gets the same share of the reduction (the host's even split of the capacity left ~30 % of the slices
+                // empty and one partial -- the workgroups of a tile then finished a slice apart)
+                const int ks = (nk_eff + (int)gridDim.y - 1) / (int)gridDim.y;
+                t0 = blockIdx.y * ks;
+                t1 = t0 + ks < nk_eff ? t0 + ks : nk_eff;
+                if (t0 >= t1) return;
+            } else t1 = t1 < nk_eff ? t1 : nk_eff;
         }
     }
     int mt, nt;
@@ -385,8 +431,10 @@ __global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
 
     Operand<AKM, RTA> oa;
     Operand<BKM, 128> ob;
-    oa.init(p.A, p.lda, m0, wave, lane, wm);
-    ob.init(p.B, p.ldb, n0, wave, lane, wn);
+    Operand64<RTA> oa64;
+    Operand64<128> ob64;
+    if constexpr (KS == 64 && !AKM) oa64.init(p.A, p.lda, m0, wave, lane, wm); else oa.init(p.A, p.lda, m0, wave, lane, wm);
+    if constexpr (KS == 64 && !BKM) ob64.init(p.B, p.ldb, n0, wave, lane, wn); else ob.init(p.B, p.ldb, n0, wave, lane, wn);
 
     // !SPLIT: acc[i][j] holds C^T: lane (li, kg), register r  <->  C[m = i*16 + li][n = j*16 + kg*4 + r]  (operands swapped
     //         in the MFMA so that a lane owns four CONSECUTIVE output columns: float4 stores / loads in the epilogue)
@@ -398,54 +446,61 @@ __global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (t0 < t1) { oa.issue(smem, t0); ob.issue(smem + OPA, t0); }
-    for (int t = t0; t < t1; ++t) {
-        const int stage = (t - t0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my DMAs of step t have landed
+    // stage s (of KS k) into the buffer at sbuf
+    auto issue_stage = [&](unsigned char* sbuf, int s) {
+        if constexpr (KS == 64) {
+            if constexpr (!AKM) oa64.issue(sbuf, s); else { oa.issue(sbuf, 2 * s); oa.issue(sbuf + OPA / 2, 2 * s + 1); }
+            if constexpr (!BKM) ob64.issue(sbuf + OPA, s); else { ob.issue(sbuf + OPA, 2 * s); ob.issue(sbuf + OPA + OPB / 2, 2 * s + 1); }
+        } else { oa.issue(sbuf, s); ob.issue(sbuf + OPA, s); }
+    };
+    const int s0 = t0 / KQ, s1 = (t1 + KQ - 1) / KQ;       // stages of this k-slice
+    if (s0 < s1) issue_stage(smem, s0);
+    for (int t = s0; t < s1; ++t) {
+        const int stage = (t - s0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my DMAs of stage t have landed
         __syncthreads();                                            // ... everyone's have; stage^1 is no longer being read
-        if (t + 1 < t1) {
-            unsigned char* nx = smem + (stage ^ 1) * (OPA + OPB);
-            oa.issue(nx, t + 1);
-            ob.issue(nx + OPA, t + 1);
-        }
-        const unsigned char* sa = smem + stage * (OPA + OPB);
-        const unsigned char* sb = sa + OPA;
-        bf16x8 a[TI], b[4];
-        bf16x4 ta[2 * TI], tb[8];
-        if constexpr (!AKM) {
+        if (t + 1 < s1) issue_stage(smem + (stage ^ 1) * (OPA + OPB), t + 1);
 #pragma unroll
-            for (int i = 0; i < TI; ++i) a[i] = oa.frag(sa, i);
-        }
-        if constexpr (!BKM) {
+        for (int ks = 0; ks < KQ; ++ks) {
+            const unsigned char* sa = smem + stage * (OPA + OPB) + ((KS == 64 && AKM) ? ks * (OPA / 2) : 0);
+            const unsigned char* sb = smem + stage * (OPA + OPB) + OPA + ((KS == 64 && BKM) ? ks * (OPB / 2) : 0);
+            bf16x8 a[TI], b[4];
+            bf16x4 ta[2 * TI], tb[8];
+            if constexpr (!AKM) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = ob.frag(sb, j);
-        }
-        if constexpr (AKM) {
-#pragma unroll
-            for (int i = 0; i < TI; ++i) oa.tr_issue(sa, i, ta[2 * i], ta[2 * i + 1]);
-        }
-        if constexpr (BKM) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ob.tr_issue(sb, j, tb[2 * j], tb[2 * j + 1]);
-        }
-        if constexpr (AKM && BKM) tr_wait(ta, tb);
-        else if constexpr (AKM) tr_wait(ta);
-        else if constexpr (BKM) tr_wait(tb);
-        if constexpr (AKM) {
-#pragma unroll
-            for (int i = 0; i < TI; ++i) a[i] = __builtin_shufflevector(ta[2 * i], ta[2 * i + 1], 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-        if constexpr (BKM) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = __builtin_shufflevector(tb[2 * j], tb[2 * j + 1], 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (SPLIT) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
-                else acc[i][j] = mfma16(b[j], a[i], acc[i][j]);
+                for (int i = 0; i < TI; ++i) { if constexpr (KS == 64) a[i] = oa64.frag(sa, i, ks); else a[i] = oa.frag(sa, i); }
             }
+            if constexpr (!BKM) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { if constexpr (KS == 64) b[j] = ob64.frag(sb, j, ks); else b[j] = ob.frag(sb, j); }
+            }
+            if constexpr (AKM) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) oa.tr_issue(sa, i, ta[2 * i], ta[2 * i + 1]);
+            }
+            if constexpr (BKM) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ob.tr_issue(sb, j, tb[2 * j], tb[2 * j + 1]);
+            }
+            if constexpr (AKM && BKM) tr_wait(ta, tb);
+            else if constexpr (AKM) tr_wait(ta);
+            else if constexpr (BKM) tr_wait(tb);
+            if constexpr (AKM) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) a[i] = __builtin_shufflevector(ta[2 * i], ta[2 * i + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            if constexpr (BKM) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = __builtin_shufflevector(tb[2 * j], tb[2 * j + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (SPLIT) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+                    else acc[i][j] = mfma16(b[j], a[i], acc[i][j]);
+                }
+        }
     }
 
     if constexpr (SPLIT) {          // C was zeroed (beta == 0) or holds the addend (beta == 1)
@@ -505,26 +560,6 @@ __global__ __launch_bounds__(256, RTA == 256 ? 2 : 4) void gemm_bf16_k(BfP p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// 256 x 256 x 64 kernel for the large k-contiguous x k-contiguous GEMMs (forward projections, input gradients against a
-// transposed weight image): 8 waves = two GROUPS of four (group g owns tile rows 128 g .. 128 g + 127, wave wc of a group the
-// columns 64 wc .. 64 wc + 63: a 128 x 64 wave tile = 8 x 4 MFMA tiles, 128 accumulator registers), one workgroup per CU,
-// 128 KiB of LDS = two K-tile buffers of [A 256 rows | B 256 rows] x 64 k.
-//   * One SIMD hosts one wave of each group, and the groups run HALF A PHASE APART (group 1 passes one extra barrier at
-//     entry, group 0 one at exit): while one wave of a SIMD issues the 16 MFMAs of a C quadrant (M segment), its partner
-//     fetches fragments from LDS and issues the DMAs of a later K-tile (L segment); every segment ends in a workgroup barrier.
-//   * A K-tile is four phases = the four 64 x 32 quadrants of the wave tile in the order (0,0) (0,1) (1,1) (1,0), so the
-//     fragment reads are minimal: L0 reads A(qm0) + B(qn0), L1 B(qn1), L2 A(qm1), L3 nothing (24 ds_read_b128 per K-tile).
-//   * Staging (global_load_lds, 16 B per lane, no VGPRs): a group stages its OWN A half and one B half of the NEXT K-tile, a
-//     quarter per L segment in the order A(qm0 rows), B(qn0 rows), B(qn1 rows), A(qm1 rows) -- two DMAs per lane and segment.
-//     Each segment ends with `s_waitcnt vmcnt(4)`: everything but the DMAs of the last two segments has landed, which is
-//     exactly what the NEXT L segment of either group reads (a part is issued >= 2 phases before its first reader); the
-//     barrier behind the wait publishes it.  WAR: a part's LDS rows were last read >= 2 phases before they are overwritten, and
-//     every L segment drains its own ds_reads (lgkmcnt(0)) before its barrier.
-//   * LDS image: 128-byte rows (64 k), the 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7): the four 16-lane
-//     service groups of ds_read_b128 then hit 16 distinct slots.  The DMA writes lane-linear, so the swizzle is applied to the
-//     SOURCE address (same 128-byte global line: coalescing is unaffected).
-// Same epilogue contract as gemm_bf16_k (alpha, beta, bias, activation, compact row map); no split-K.
 __device__ __forceinline__ void ds_read16(bf16x8& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); }
 template <int OFF>
 __device__ __forceinline__ void ds_read16o(bf16x8& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF)); }
@@ -539,175 +574,18 @@ __device__ __forceinline__ void frag_wait(bf16x8 (&b)[4]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
 }
 
-__global__ __launch_bounds__(512, 2) void gemm_bf16_big_k(BfP p) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];          // 2 x (32 KiB A + 32 KiB B)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), wc = __builtin_amdgcn_readfirstlane(wave & 3);
-    const int li = lane & 15, kg = lane >> 4;
-    int tile = blockIdx.x;
-    int rows_lim = p.M, gy = p.gy;
-    if (p.compact == 1) {
-        const int R = __builtin_amdgcn_readfirstlane(*p.rows_dev);
-        rows_lim = R < p.M ? R : p.M;
-        gy = (rows_lim + 255) >> 8;
-        if (gy == 0) return;
-    }
-    int mt, nt;
-    if (p.chunk_w > 0 && gy >= 16) {                      // L2-aware order, as gemm_bf16_k
-        const int xcd = tile & 7, idx = tile >> 3;
-        const int qm = gy >> 3, rm = gy & 7;
-        const int mh = qm + (xcd < rm ? 1 : 0);
-        const int m_lo = xcd * qm + (xcd < rm ? xcd : rm);
-        if (idx >= mh * p.gx) return;
-        const int per_chunk = mh * p.chunk_w;
-        const int ch = idx / per_chunk, within = idx - ch * per_chunk;
-        const int left = p.gx - ch * p.chunk_w;
-        const int cw = left < p.chunk_w ? left : p.chunk_w;
-        const int mi = within / cw;
-        mt = m_lo + mi;
-        nt = ch * p.chunk_w + (within - mi * cw);
-    } else {
-        const int total = p.gx * gy, q = total >> 3, r = total & 7;
-        const int xcd = tile & 7, idx = tile >> 3;
-        if (tile >= total) return;
-        tile = xcd * q + (xcd < r ? xcd : r) + idx;
-        mt = tile / p.gx;
-        nt = tile % p.gx;
-    }
-    const int m0 = mt * 256, n0 = nt * 256;
-    const int nkt = (p.nk + 1) >> 1;                      // K-tiles of 64 (p.nk counts 32-wide steps; images are zero-padded to 256)
-
-    // ---- staging: this lane's source pointers (K-tile 0) and LDS piece offsets of the four parts a group stages per K-tile.
-    // A piece = 8 LDS rows x 128 B = one wave-wide DMA; wave w of the group takes pieces 2w, 2w+1 of a part (8 pieces = 64 rows).
-    const int wg = wave & 3;                               // wave inside its group
-    const int prow = lane >> 3, pch = lane & 7;            // row inside a piece, physical 16-byte chunk
-    const unsigned short* src[4][2];
-    int dst[4][2];
-#pragma unroll
-    for (int part = 0; part < 4; ++part)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int pc = wg * 2 + h;                     // piece 0..7 of this part
-            int lrow;                                      // LDS row (0..255) of the piece's first row, inside the A or the B tile
-            bool isA;
-            if (part == 0) { isA = true; lrow = grp * 128 + pc * 8; }                    // A, qm0 rows of the own half
-            else if (part == 3) { isA = true; lrow = grp * 128 + 64 + pc * 8; }          // A, qm1 rows
-            else {                                                                      // B half `grp`: columns of waves 2 grp, 2 grp + 1
-                isA = false;
-                const int w2 = pc >> 2, blk = pc & 3;                                   // which wave's 32-row block, 8-row block inside
-                lrow = (grp * 2 + w2) * 64 + (part == 1 ? 0 : 32) + blk * 8;
-            }
-            const int r = lrow + prow;
-            const int c = pch ^ ((r >> 1) & 7);                                         // logical chunk stored at physical chunk pch
-            const unsigned short* img = isA ? p.A + (size_t)(m0 + r) * p.lda : p.B + (size_t)(n0 + r) * p.ldb;
-            src[part][h] = img + c * 8;
-            dst[part][h] = (isA ? 0 : 32768) + lrow * 128;
-        }
-    auto stage = [&](int part, int kt) {                   // part of K-tile kt into buffer kt & 1
-        unsigned char* base = smem + (kt & 1) * 65536;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            __builtin_amdgcn_global_load_lds((glb_void*)(src[part][h] + (size_t)kt * 64), (lds_void*)(base + dst[part][h]), 16, 0, 0);
-    };
-
-    // ---- fragment read addresses: row-dependent swizzle s = (li >> 1), chunk (ks * 4 + kg) ^ s -> byte offsets off0 (ks 0), off0 ^ 64 (ks 1)
-    const unsigned sw0 = (unsigned)((kg ^ (li >> 1)) << 4), sw1 = sw0 ^ 64u;
-    const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;
-    const unsigned a_row = lds0 + (unsigned)((grp * 128 + li) * 128);                    // + qm * 8192 + i * 2048
-    const unsigned b_row = lds0 + 32768u + (unsigned)((wc * 64 + li) * 128);             // + qn * 4096 + j * 2048
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 a[8], b0[4], b1[4];                             // a[ks * 4 + i]; b*[ks * 2 + j]
-
-    auto read_a = [&](int kt, int qm) {
-        const unsigned base0 = a_row + (unsigned)((kt & 1) * 65536 + qm * 8192) + sw0;
-        const unsigned b1a = a_row + (unsigned)((kt & 1) * 65536 + qm * 8192) + sw1;
-        ds_read16o<0>(a[0], base0); ds_read16o<2048>(a[1], base0); ds_read16o<4096>(a[2], base0); ds_read16o<6144>(a[3], base0);
-        ds_read16o<0>(a[4], b1a); ds_read16o<2048>(a[5], b1a); ds_read16o<4096>(a[6], b1a); ds_read16o<6144>(a[7], b1a);
-    };
-    auto read_b = [&](int kt, int qn, bf16x8 (&b)[4]) {
-        const unsigned base0 = b_row + (unsigned)((kt & 1) * 65536 + qn * 4096) + sw0;
-        const unsigned base1 = b_row + (unsigned)((kt & 1) * 65536 + qn * 4096) + sw1;
-        ds_read16o<0>(b[0], base0); ds_read16o<2048>(b[1], base0);
-        ds_read16o<0>(b[2], base1); ds_read16o<2048>(b[3], base1);
-    };
-    auto quad = [&](int qm, int qn, const bf16x8 (&b)[4]) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[qm * 4 + i][qn * 2 + j] = mfma16(b[ks * 2 + j], a[ks * 4 + i], acc[qm * 4 + i][qn * 2 + j]);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // end of an L segment: staged data older than the last two segments has landed, own fragment reads are complete, barrier
-    auto end_l = [&](int keep) {
-        if (keep >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (keep == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto end_m = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    // ---- prologue: K-tile 0 entirely
-#pragma unroll
-    for (int part = 0; part < 4; ++part) stage(part, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();            // group 1 runs half a phase behind group 0
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + 1 < nkt;
-        // phase 0
-        read_a(kt, 0); read_b(kt, 0, b0);
-        frag_wait(a, b0);
-        if (more) stage(0, kt + 1);
-        end_l(more ? 4 : 2);            // (last K-tile: the only younger DMAs are those of the previous segment)
-        quad(0, 0, b0);
-        end_m();
-        // phase 1
-        read_b(kt, 1, b1);
-        frag_wait(b1);
-        if (more) stage(1, kt + 1);
-        end_l(more ? 4 : 0);
-        quad(0, 1, b1);
-        end_m();
-        // phase 2
-        read_a(kt, 1);
-        frag_wait(a);
-        if (more) stage(2, kt + 1);
-        end_l(more ? 4 : 0);
-        quad(1, 1, b1);
-        end_m();
-        // phase 3
-        if (more) stage(3, kt + 1);
-        end_l(more ? 4 : 0);
-        quad(1, 0, b0);
-        end_m();
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();            // match group 1's extra barrier
-
-    // ---- epilogue: lane (li, kg), register r  <->  C[m = i*16 + li][n = j*16 + kg*4 + r]
+// epilogue of a 128 x 64 wave tile (8 x 4 accumulator tiles in C^T form): lane (li, kg), register r  <->
+// C[m = mw + i*16 + li][n = nw + j*16 + kg*4 + r]; alpha, beta, bias, rank-1 term, activation, compact row map, 16-bit C
+__device__ __forceinline__ void store_tile256(const BfP& p, const f32x4 (&acc)[8][4], int mw, int nw, int rows_lim, int li, int kg) {
     const bool vec = p.vec_c != 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        int row = m0 + grp * 128 + i * 16 + li;
+        int row = mw + i * 16 + li;
         if (row >= rows_lim) continue;
         if (p.compact == 1) { row = p.rowmap[row]; if (row < 0) continue; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int col = n0 + wc * 64 + j * 16 + kg * 4;
+            const int col = nw + j * 16 + kg * 4;
             if (col >= p.N) continue;
             float* cp = p.C + (long)row * p.ldc + col;
             float v[4] = {p.alpha * acc[i][j][0], p.alpha * acc[i][j][1], p.alpha * acc[i][j][2], p.alpha * acc[i][j][3]};
@@ -736,15 +614,195 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_k(BfP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 PERSISTENT kernel for the large k-contiguous x k-contiguous GEMMs with many tiles and a long reduction (the decoder
+// LSTM's input projection over the concatenated image): 8 identical waves (2 x 4, wave tile 128 x 64 = 8 x 4 MFMA tiles, 128
+// accumulator registers, two waves per SIMD), 128 KiB of LDS = two buffers of [A 256 rows | B 256 rows] x 64 k, one workgroup per CU
+// that walks its share of the XCD's tiles; the K-tiles of consecutive output tiles form ONE stream of units through the buffers.
+//   * unit u: [own DMAs of u landed: vmcnt(0); barrier] -> quadrants (0,0) (0,1) (1,1) (1,0) of the wave tile, the fragments of the
+//     next quadrant read behind the MFMAs of the current one (24 ds_read_b128 per unit) and the 8 DMAs of unit u + 1 (into the buffer
+//     u - 1 was read from) issued two at a time between the MFMA blocks.  ONE barrier per unit.
+//   * the first K-tile of the NEXT output tile is staged during the last K-tile of the current one (no prologue per tile); the C
+//     stores of a tile go out at the top of the next tile's first unit.
+//   * LDS image: 128-byte rows (64 k), the 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7): the four 16-lane service
+//     groups of ds_read_b128 hit 16 distinct slots (SQ_LDS_BANK_CONFLICT = 0).  The DMA writes lane-linear, so the swizzle is applied
+//     to the SOURCE address (same 128-byte global line: coalescing is unaffected; whole-line requests, TCP_TCC_READ_REQ = bytes / 128).
+// Rounds 3-5 ran this tile as one workgroup per TILE with two wave groups half a phase apart and eight barriers per K-tile
+// (gemm_bf16_big_k, removed): same speed within the box-to-box spread (0.347-0.371 ms against 0.344-0.365 at M 19 200, N 4096,
+// K 1664).  What the timing-only cuts say about either form (profiles/r06_gemm_bigk_cuts.log, r06_gemm_p256_cuts.log,
+// r06_gemm_nostore.log, r06_gemm_pmc.log): the 64 MFMAs of a unit are 0.85 us per SIMD pair, its 64 KB arrive in 1.2 us when nothing
+// else runs, the unit takes 2.8 -- the waves sit in s_waitcnt / s_barrier 45 % of their cycles and the TCP stalls on pending L2
+// returns 37 % of the time: with one workgroup per CU the L2 -> LDS stream drains at every unit boundary, and the 256 KB of C per
+// tile leave through the same in-order vmcnt the DMAs are waited on.  Same epilogue contract as gemm_bf16_k; no split-K; same k order
+// (bit-identical to the other kernels).
+__global__ __launch_bounds__(512, 2) void gemm_bf16_p256_k(BfP p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];          // 2 x (32 KiB A + 32 KiB B)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int li = lane & 15, kg = lane >> 4;
+    int rows_lim = p.M, gy = p.gy;
+    if (p.compact == 1) {
+        const int R = __builtin_amdgcn_readfirstlane(*p.rows_dev);
+        rows_lim = R < p.M ? R : p.M;
+        gy = (rows_lim + 255) >> 8;
+        if (gy == 0) return;
+    }
+    // ---- this workgroup's tiles: the XCD's list (L2-aware chunk order, or a contiguous run), every (gridDim.x / 8)-th entry
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const bool chunked = p.chunk_w > 0 && gy >= 16;
+    int cnt, mh = 0, m_lo = 0, base = 0;
+    if (chunked) {
+        const int qm = gy >> 3, rm = gy & 7;
+        mh = qm + (xcd < rm ? 1 : 0);
+        m_lo = xcd * qm + (xcd < rm ? xcd : rm);
+        cnt = mh * p.gx;
+    } else {
+        const int total = p.gx * gy, q = total >> 3, r = total & 7;
+        cnt = q + (xcd < r ? 1 : 0);
+        base = xcd * q + (xcd < r ? xcd : r);
+    }
+    if (slot >= cnt) return;
+    const int ntl = (cnt - slot + nslot - 1) / nslot;
+    auto tile_at = [&](int k, int& m0, int& n0) {          // k-th tile of this workgroup
+        const int idx = slot + k * nslot;
+        int mt, nt;
+        if (chunked) {
+            const int per_chunk = mh * p.chunk_w;
+            const int ch = idx / per_chunk, within = idx - ch * per_chunk;
+            const int left = p.gx - ch * p.chunk_w;
+            const int cw = left < p.chunk_w ? left : p.chunk_w;
+            const int mi = within / cw;
+            mt = m_lo + mi;
+            nt = ch * p.chunk_w + (within - mi * cw);
+        } else {
+            const int t = base + idx;
+            mt = t / p.gx;
+            nt = t % p.gx;
+        }
+        m0 = mt << 8; n0 = nt << 8;
+    };
+    const int nkt = (p.nk + 1) >> 1;                      // K-tiles of 64
+
+    // ---- staging: a unit is 512 LDS rows ([A 256 | B 256]) x 128 B = 64 pieces of 8 rows; wave w stages rows 64 w .. 64 w + 63
+    // (waves 0-3: A, 4-7: B).  Physical chunk pch of LDS row r holds logical chunk pch ^ ((r >> 1) & 7); with r = 8 h + prow
+    // inside the wave's 64 rows that is pch ^ (prow >> 1) ^ (4 (h & 1)).
+    const int prow = lane >> 3, pch = lane & 7;
+    const int c_even = pch ^ (prow >> 1);
+    const long ld_w = wave < 4 ? p.lda : p.ldb;
+    const unsigned short* img_w = wave < 4 ? p.A : p.B;
+    const int row_w = (wave & 3) * 64 + prow;
+    const long off_e = (long)c_even * 8, off_o = (long)(c_even ^ 4) * 8;
+    const unsigned short* srow;                            // this lane's row 0 of the tile being STAGED (k = 0)
+    auto set_stage_tile = [&](int k) {
+        int m0, n0;
+        tile_at(k, m0, n0);
+        srow = img_w + (size_t)((wave < 4 ? m0 : n0) + row_w) * ld_w;
+    };
+    const int dst_w = wave * 8192;
+    // (quarter q of a unit = this wave's pieces 2q, 2q + 1: the DMAs of a unit are issued two at a time between the MFMA blocks)
+    auto stage = [&](int kt, int buf, int q) {
+        unsigned char* bb = smem + buf * 65536 + dst_w;
+        const unsigned short* s0 = srow + (size_t)kt * 64;
+#pragma unroll
+        for (int h = 2 * q; h < 2 * q + 2; ++h)
+            __builtin_amdgcn_global_load_lds((glb_void*)(s0 + (size_t)h * 8 * ld_w + ((h & 1) ? off_o : off_e)), (lds_void*)(bb + h * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment read addresses: row-dependent swizzle s = (li >> 1), chunk (ks * 4 + kg) ^ s -> byte offsets sw0 (ks 0), sw0 ^ 64 (ks 1)
+    const unsigned sw0 = (unsigned)((kg ^ (li >> 1)) << 4), sw1 = sw0 ^ 64u;
+    const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;
+    const unsigned a_row = lds0 + (unsigned)((wr * 128 + li) * 128);                     // + qm * 8192 + i * 2048
+    const unsigned b_row = lds0 + 32768u + (unsigned)((wc * 64 + li) * 128);             // + qn * 4096 + j * 2048
+
+    f32x4 acc[8][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+    bf16x8 a[8], a2[8], b0[4], b1[4];                      // a*[ks * 4 + i]; b*[ks * 2 + j]
+    auto read_a = [&](int buf, int qm, bf16x8 (&d)[8]) {
+        const unsigned base0 = a_row + (unsigned)(buf * 65536 + qm * 8192) + sw0;
+        const unsigned base1 = a_row + (unsigned)(buf * 65536 + qm * 8192) + sw1;
+        ds_read16o<0>(d[0], base0); ds_read16o<2048>(d[1], base0); ds_read16o<4096>(d[2], base0); ds_read16o<6144>(d[3], base0);
+        ds_read16o<0>(d[4], base1); ds_read16o<2048>(d[5], base1); ds_read16o<4096>(d[6], base1); ds_read16o<6144>(d[7], base1);
+    };
+    auto read_b = [&](int buf, int qn, bf16x8 (&d)[4]) {
+        const unsigned base0 = b_row + (unsigned)(buf * 65536 + qn * 4096) + sw0;
+        const unsigned base1 = b_row + (unsigned)(buf * 65536 + qn * 4096) + sw1;
+        ds_read16o<0>(d[0], base0); ds_read16o<2048>(d[1], base0);
+        ds_read16o<0>(d[2], base1); ds_read16o<2048>(d[3], base1);
+    };
+    auto quad = [&](int qm, int qn, const bf16x8 (&av)[8], const bf16x8 (&bv)[4]) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[qm * 4 + i][qn * 2 + j] = mfma16(bv[ks * 2 + j], av[ks * 4 + i], acc[qm * 4 + i][qn * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    int tc = 0, ktc = 0;                                   // unit being multiplied: tile tc, K-tile ktc
+    int ts = 0, kts = 0;                                   // unit being staged
+    int m0c, n0c;
+    tile_at(0, m0c, n0c);
+    set_stage_tile(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stage(0, 0, q);
+    const int units = ntl * nkt;
+    for (int u = 0; u < units; ++u) {
+        const int buf = u & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of unit u have landed (and the C stores of the last tile are acknowledged)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                      // everyone's have; nobody reads unit u - 1 any more
+        __builtin_amdgcn_sched_barrier(0);
+        if (ktc == 0 && u > 0) {                           // the previous unit closed a tile: store it, then open the next
+            int mp, np;
+            tile_at(tc - 1, mp, np);
+            store_tile256(p, acc, mp + wr * 128, np + wc * 64, rows_lim, li, kg);
+            zero_acc();
+        }
+        const bool more = u + 1 < units;
+        if (more && ++kts == nkt) { kts = 0; set_stage_tile(++ts); }
+        read_a(buf, 0, a); read_b(buf, 0, b0);
+        if (more) stage(kts, buf ^ 1, 0);
+        frag_wait(a, b0);
+        read_b(buf, 1, b1);
+        if (more) stage(kts, buf ^ 1, 1);
+        quad(0, 0, a, b0);
+        frag_wait(b1);
+        read_a(buf, 1, a2);
+        if (more) stage(kts, buf ^ 1, 2);
+        quad(0, 1, a, b1);
+        frag_wait(a2);
+        if (more) stage(kts, buf ^ 1, 3);
+        quad(1, 1, a2, b1);
+        quad(1, 0, a2, b0);
+        if (++ktc == nkt) { ktc = 0; ++tc; }
+    }
+    tile_at(ntl - 1, m0c, n0c);
+    store_tile256(p, acc, m0c + wr * 128, n0c + wc * 64, rows_lim, li, kg);
+}
+
 template <bool AKM, bool BKM>
-void launch_s(const BfP& p, dim3 grid, bool big, hipStream_t st) {
+void launch_s(const BfP& p, dim3 grid, bool big, bool wide, hipStream_t st) {
     const bool atomics = p.splits > 1 && p.c_slice == 0;       // (deterministic split-K runs the store epilogue, one C slice per k-slice)
     if (big) {
         if (atomics) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, true, 256>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 256>), grid, dim3(256), 0, st, p);
     } else {
         if (atomics) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, true, 128>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 128>), grid, dim3(256), 0, st, p);
+        else if constexpr (!(AKM && BKM)) {
+            if (wide) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 128, 64>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 128>), grid, dim3(256), 0, st, p);
+        } else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 128>), grid, dim3(256), 0, st, p);
     }
 }
 
@@ -788,8 +846,9 @@ long plan_slices(int M, int N, int K, bool can_split, int compact, bool* big_out
         if (s < 1) s = 1;
     }
     if (compact == 1) s = 1;                   // scattered output rows: no split-K (the zero fill would have to be scattered too)
-    // compact reduction: K is the capacity, ~30 % of the k-slices of a typical batch are empty -- over-split to keep the slots filled
-    if (compact == 2 && s > 1) { s = s * 4 / 3; if (s > K / 512) s = K / 512; if (s > 64) s = 64; if (s < 1) s = 1; }
+    // (compact reduction: K is the capacity; the kernel divides the rows the batch HAS evenly over the s slices.  Until round 6 the
+    // slices divided the capacity and s was over-split by 4/3: dW_ih0 [4096 x 1664] 319 -> 273 us, the step's 18 tall split-K GEMMs
+    // 2.72 -> 2.51 ms, profiles/r06_gemm_split_sweep.log)
     *big_out = big;
     return s;
 }
@@ -825,7 +884,17 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
         if (s > fit) s = fit;
         if (s < 1) s = 1;
     }
+    // 64-wide k stages for the store kernels with a k-contiguous operand (Operand64: whole-line DMA pieces) -- where K is a whole number
+    // of them (else the last stage would read 32 columns past K, which only images padded by ft_bf16_image hold as zeros; a view
+    // into a wider image does not).  FT_GEMM_BF16_WIDE=0 (A/B hook, read per call): 32-wide stages everywhere
+    const char* wide_env = getenv("FT_GEMM_BF16_WIDE");
+    // Measured (scripts/exp/gemm_step_bench.py, profiles/r06_gemm_wide_stages.log): d[R,4096] W -> dX 711 -> 843 TFLOP/s (N 1664), 700 -> 829
+    // (N 1024); x[R,1664] W^T 607 -> 685; at K = 1024 the 16 stages of a tile no longer hide the prologue / epilogue of 2 workgroups
+    // per CU (636 -> 573): long reductions only.  FT_GEMM_BF16_WIDE = 2 forces it wherever K allows
+    const int wide_mode = wide_env ? atoi(wide_env) : 1;
+    const bool wide = wide_mode != 0 && (p.nk & 1) == 0 && !(a_km && b_km) && !big && (wide_mode == 2 || p.nk >= 48);
     p.ksteps = cdiv(p.nk, s);
+    if (wide && (p.ksteps & 1)) ++p.ksteps;            // (k-slices of whole 64-wide stages)
     p.splits = cdiv(p.nk, p.ksteps);
     const bool det_on = det && p.splits > 1;
     if (det_on) {
@@ -843,32 +912,30 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
         p.chunk_w = (int)(cw < 1 ? 1 : (cw > p.gx ? p.gx : cw));
         gridx = 8 * ((p.gy + 7) / 8) * p.gx;          // every XCD is handed the blocks of the largest row range
     }
-    // the 256 x 256 x 64 two-group kernel: both operands k-contiguous, no split-K, enough tiles to fill the chip
+    // the persistent 256 x 256 x 64 kernel: both operands k-contiguous, no split-K, enough tiles to fill the chip
     const char* big_env = getenv("FT_GEMM_BF16_BIG");
-    // Measured on MI355X (scripts/exp/gemm_img_bench.py, M = 19 200 compact rows, bit-identical outputs): it wins where a tile
-    // has a long reduction and the grid many rounds -- x[R,1664] W[4096,1664]^T 781 vs 615 TFLOP/s -- and loses where one
-    // workgroup per CU cannot hide its own prologue / epilogue behind a neighbour (K = 1024: 603 vs 640; N = 1024: 456 vs 603;
-    // 300 tiles are 1.2 rounds of 256 CUs).  FT_GEMM_BF16_BIG = 0 | 1 | 2: off | where it wins (default) | wherever it applies.
+    // Measured on MI355X (scripts/exp/gemm_img_bench.py, M = 19 200 rows of N(0,1) data, bit-identical outputs): it wins where a
+    // tile has a long reduction and the CUs several tiles each -- x[R,1664] W[4096,1664]^T 748 vs 685 TFLOP/s (607 with 32-wide
+    // stages) -- and loses elsewhere (K = 1024: 596 vs 636; N = 1024: 404 vs 594 -- 300 tiles are 1.2 rounds of 256 CUs).
+    // FT_GEMM_BF16_BIG = 0 | 1 | 2 (read per call): off | where it wins (default) | wherever it applies.
     const int big_mode = big_env ? atoi(big_env) : 1;
     const bool big256 = big_mode != 0 && !a_km && !b_km && p.splits == 1 && M >= 4096 && N >= 512 && K >= 256 &&
                         (big_mode == 2 || (N >= 2048 && K >= 1536));
     if (big256) {
         p.gx = cdiv(N, 256); p.gy = cdiv(M, 256);
         p.chunk_w = 0;
-        int gx256 = p.gx * p.gy;
         if (order_on && p.gy >= 16) {
             long cw = (2l << 20) / (256l * (long)p.nk * 32 * 2);
             p.chunk_w = (int)(cw < 1 ? 1 : (cw > p.gx ? p.gx : cw));
-            gx256 = 8 * ((p.gy + 7) / 8) * p.gx;
         }
-        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_k), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        hipLaunchKernelGGL(gemm_bf16_big_k, dim3(gx256), dim3(512), 131072, st, p);
+        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p256_k), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        hipLaunchKernelGGL(gemm_bf16_p256_k, dim3(256), dim3(512), 131072, st, p);
         FT_CHECK_LAUNCH();
         return FT_OK;
     }
     const dim3 grid(gridx, p.splits);
-    if (a_km) { if (b_km) launch_s<true, true>(p, grid, big, st); else launch_s<true, false>(p, grid, big, st); }
-    else      { if (b_km) launch_s<false, true>(p, grid, big, st); else launch_s<false, false>(p, grid, big, st); }
+    if (a_km) { if (b_km) launch_s<true, true>(p, grid, big, wide, st); else launch_s<true, false>(p, grid, big, wide, st); }
+    else      { if (b_km) launch_s<false, true>(p, grid, big, wide, st); else launch_s<false, false>(p, grid, big, wide, st); }
     if (det_on) {
         const long n4 = ((long)M * N) >> 2;
         const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);

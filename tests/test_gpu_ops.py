@@ -1302,7 +1302,7 @@ def test_compact_lstm_layer_equals_padded(env, H, monkeypatch):
 
 @pytest.mark.parametrize("act", [0, 1])
 def test_big_tile_image_gemm_is_bit_identical_to_the_128_tile_kernel(env, act, monkeypatch):
-    """gemm_bf16_big_k (256 x 256 x 64, two wave groups half a phase apart, counted DMA waits) against gemm_bf16_k on shapes that
+    """gemm_bf16_p256_k (256 x 256 x 64, persistent: one workgroup per CU walks its tiles, one barrier per K-tile) against gemm_bf16_k on shapes that
     select it (M >= 4096, N >= 512, K >= 256, both operands k-contiguous): the accumulation order per output element is the same
     (32-wide k steps in order), so the outputs must be BIT-identical -- any staging / swizzle / barrier slip shows as a mismatch.
     Covers ragged M / N / K against the tile, bias + activation, the accumulate-into-C (beta = 1, two-input) path and the compact
@@ -1327,6 +1327,41 @@ def test_big_tile_image_gemm_is_bit_identical_to_the_128_tile_kernel(env, act, m
     ref = torch.cat([x1, x2], 2).bfloat16().float() @ W.bfloat16().float().t() + b
     ref = torch.tanh(ref) if act else ref
     assert mad(res["2"][0], ref) < 2e-3
+
+
+@pytest.mark.parametrize("K", [256, 448, 1664])
+def test_wide_stage_image_gemm_is_bit_identical_to_the_32_wide_stages(env, K, monkeypatch):
+    """gemm_bf16_k<.., KS = 64> (64-wide k stages: whole-line DMA pieces for the k-contiguous operands, a k-major operand as two of
+    its 32-wide sub-stages; dispatched for K >= 1536, forced here with FT_GEMM_BF16_WIDE=2) against the 32-wide stages
+    (FT_GEMM_BF16_WIDE=0): same k order per output element, so forward (both operands k-contiguous, padded and compact rows, bias +
+    tanh) and input gradient (k-major weight image) must be BIT-identical.  K = 448: 7 whole 64-wide stages;  K = 1664: the decoder
+    projection's own width (dispatched there by default)."""
+    L, ops = env
+    torch.manual_seed(78)
+    T, B, N = 37, 8, 320
+    lens32 = torch.tensor([37 - 4 * i for i in range(B)], dtype=torch.int32, device="cuda")
+    x = torch.randn(T, B, K, device="cuda")
+    W = torch.randn(N, K, device="cuda") * 0.05
+    b = torch.randn(N, device="cuda")
+    dy = torch.randn(T * B, N, device="cuda")
+    res = {}
+    for wide in ("0", "2"):
+        monkeypatch.setenv("FT_GEMM_BF16_WIDE", wide)
+        monkeypatch.setenv("FT_GEMM_BF16_BIG", "0")
+        outs = []
+        for rm in (None, ops.RowMap(lens32, T, B)):
+            outs.append(ops.linear([x], W, b, act=1, mode=1, rowmap=rm, fill="y").detach().clone())
+        # dX[M, K] = dy[M, N] . W[N, K]: A k-contiguous (reduction over N), B = the weight image read k-major
+        d_img, w_img = ops.Bf16Image(dy, mode=1), ops.Bf16Image(W, mode=1)
+        dx = torch.empty(T * B, K, device="cuda")
+        ops.gemm_img(d_img, 0, d_img.ptr(), w_img, 1, w_img.ptr(), dx, T * B, K, N, K)
+        outs.append(dx)
+        res[wide] = outs
+    for a_, b_ in zip(res["0"], res["2"]):
+        assert torch.equal(a_, b_), (a_ - b_).abs().max().item()
+    ref = torch.tanh(x.bfloat16().float() @ W.bfloat16().float().t() + b)
+    assert mad(res["2"][0], ref) < 2e-3
+    assert mad(res["2"][2], dy.bfloat16().float() @ W.bfloat16().float()) < 2e-2
 
 
 # ---------------------------------------------------------------- cumulative attention, fused frames (csrc/cumm_fused.hip)
