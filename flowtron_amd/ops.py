@@ -75,7 +75,7 @@ class RowMap:
 
 _COMPACT = _os.environ.get("FLOWTRON_GEMM_COMPACT", "1") != "0"
 _FUSE_ACT_BWD = True       # activation backward inside the gradient's image pass (round 4)
-# split-K on the encoder's FORWARD split-image GEMM (160 output tiles, K = 7 680).  With fp32 atomics (FLOWTRON_ENC_SPLITK=atomic: the
+# split-K on the encoder's FORWARD split-image GEMM (160 output tiles, K = 7 680).  With fp32 atomics (the first form: the
 # first form, -0.2 ms per step) the order of the atomics makes the forward itself differ from run to run (z up to 8e-4, bf16 gradients
 # up to 1e-2 rel-L2 on the same batch and weights: scripts/exp/noise_debug.py, profiles/r05b_forward_noise.log).  Default "det": the
 # slices' partial products side by side + a fixed-order reduction (FT_GEMM_SPLITK_DET) -- a forward pass is a function of its inputs;
@@ -275,7 +275,7 @@ def op16_dtype(mode):
     return torch.float16 if mode == L.FT_F16 else torch.bfloat16
 
 
-_GX16 = _os.environ.get("FLOWTRON_LSTM_GX16", "1") != "0"    # gx of the persistent forward recurrences as 16-bit rows (round 6)
+_GX16 = True     # gx of the persistent forward recurrences as 16-bit rows (round 6; tests set it False to compare with fp32 rows)
 
 
 def gx16_ok(mode, rowmap, T, B, H, reverse, xs, N, device):
@@ -398,7 +398,7 @@ def _require_written(t):
 # Split-K weight-gradient GEMMs accumulate with fp32 atomics into an output that must start at zero.  One memset per output was 37
 # dispatches per training step (hipMemset2DAsync / zeros_like: 0.28 ms of ~5 us fills, profiles/r04_final_step_timeline.txt);
 # the outputs of a backward pass now come out of ONE zeroed allocation sized by the previous pass's demand, and the GEMMs run with
-# beta = 1 ("C holds the addend").  FLOWTRON_ZERO_SLAB=0: one zeroed tensor per output.
+# beta = 1 ("C holds the addend").  (_ZSLAB_ON = False: one zeroed tensor per output.)
 _ZSLAB = {"buf": None, "off": 0, "need": 0, "last": 0, "task": None}
 _ZSLAB_ON = True
 
@@ -430,7 +430,7 @@ _ARENA_GRADS = True
 def weight_grad_out(W):
     """the zero-filled fp32 output of W's weight-gradient kernel (split-K / atomic accumulation): inside a backward pass the slice of
     the flat gradient arena the parameter's .grad will live in anyway (dist.FlatArena.grad_view_for_pass: no copy into the arena
-    afterwards), else a piece of the pass's zeroed slab.  FLOWTRON_ARENA_GRADS=0: always the slab."""
+    afterwards), else a piece of the pass's zeroed slab.  (_ARENA_GRADS = False: always the slab.)"""
     if _ARENA_GRADS and _ZSLAB_ON:
         gt = _current_graph_task()
         if gt != -1:
@@ -453,7 +453,7 @@ def weight_grad_out(W):
 # into another tensor (a third, foreign contribution arriving first and adding ours in place) is simply not found again.
 # Caveat, by construction outside this model: if a FOREIGN owner (a user hook that stores gradient tensors) keeps the first buffer
 # alive AND a third contribution of another kind makes the engine replace it by an out-of-place sum, a later accumulation would
-# go into the orphan -- h_att and the encoder output have image-path consumers only; FLOWTRON_DX_INPLACE=0 restores autograd's adds.
+# go into the orphan -- h_att and the encoder output have image-path consumers only; _DX_INPLACE = False restores autograd's adds.
 _DX_INPLACE = True
 _DXACC = {"task": None, "bufs": {}}
 
@@ -1076,9 +1076,30 @@ def lstm_persist_slices(B, H, reverse, mode, device=None):
     return bool(lstm_persist_groups(32, H, reverse, mode, device))
 
 
+PERSIST_H = 1024                  # the hidden size the persistent recurrence kernels are built for
+_PAD_H = True    # hidden sizes below it on the persistent kernels through zero-padded gate blocks (tests set it False: the yardstick)
+
+
+def lstm_pad_width(B, H, reverse, mode, device, T):
+    """True where a layer with H < 1024 hidden units should run as its zero-padded 1024-unit twin (lstm_layer): the persistent kernels
+    take the padded shape and the sequence is long enough for 1.3-1.6 us per step against the launch-per-step kernels' 5-6 to pay for the
+    wider projection (4096 gate columns instead of 4 H)"""
+    if not _PAD_H or H >= PERSIST_H or H < 256 or H % 8 or reverse or T < 64:      # (H < 256: > 4 x the gate columns and saved gates)
+        return False
+    return bool(lstm_persist_groups(min(B, 32), PERSIST_H, reverse, mode, device))
+
+
+def pad_gate_blocks(w, pad_cols):
+    """[4 H, X] (or [4 H]) -> [4 * 1024, X + pad_cols]: each of the four gate blocks zero-padded to 1024 rows, X to X + pad_cols columns"""
+    H = w.shape[0] // 4
+    if w.dim() == 1:
+        return torch.nn.functional.pad(w.view(4, H), (0, PERSIST_H - H)).reshape(4 * PERSIST_H)
+    return torch.nn.functional.pad(w.view(4, H, w.shape[1]), (0, pad_cols, 0, PERSIST_H - H)).reshape(4 * PERSIST_H, w.shape[1] + pad_cols)
+
+
 def bilstm_persist_ok(B, H, mode, device):
     """the encoder-shaped persistent bidirectional kernels (H 256, B <= 32, 16-bit operands) on a device whose persistent grids
-    passed the self-test; FLOWTRON_BILSTM_PERSIST=0 or FLOWTRON_LSTM_PERSIST=0 keep the launch-per-step pair chain"""
+    passed the self-test; FLOWTRON_LSTM_PERSIST=0 keeps the launch-per-step pair chain"""
     # (the kernels form their groups from the XCD census like transports 1 / 9: not for the placement-independent fabric
     # transports 8 / 4 / 2, which are what one selects on a device where the census cannot come out)
     if int(_os.environ.get("FLOWTRON_LSTM_PERSIST", "1")) != 1:
@@ -1533,6 +1554,14 @@ def lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, reverse=False, mode=None, xs_ext
     T, B = x.shape[0], x.shape[1]
     gates = None
     H = w_hh.shape[1]
+    if lstm_pad_width(B, H, reverse, mode, x.device, T):
+        # a hidden size below the persistent kernels' 1024 (the reference's nn.LSTM takes any, flowtron.py:654-655): the recurrence of a
+        # layer whose gate blocks are zero-padded to 1024 units IS this layer's recurrence -- a padded unit has gx = 0 and zero weights,
+        # so its cell stays 0 (c = 0.5 c + 0.5 * 0) and its output 0 (0.5 tanh(0)) in every step, and the real units see zeros through
+        # zero weight columns.  The padding is torch ops on the parameters: autograd slices the gradients back.
+        w_ih_p, w_hh_p, b_p = pad_gate_blocks(w_ih, 0), pad_gate_blocks(w_hh, PERSIST_H - H), pad_gate_blocks(b_ih + b_hh, 0)
+        out = lstm_layer(x, lens, w_ih_p, w_hh_p, b_p, torch.zeros_like(b_p), reverse, mode, xs_extra, rowmap, fill, gate)
+        return out[..., :H].contiguous() if gate is None else (out[0][..., :H].contiguous(), out[1])
     if gx16_ok(mode, rowmap, T, B, H, reverse, xs, w_ih.shape[0], x.device):
         fill = fill + "|c16"                   # gx as 16-bit rows: half the bytes the projection writes and the recurrence reads
     if gate is not None and linear_gate_fusable(mode, rowmap, xs, w_ih.shape[0]):

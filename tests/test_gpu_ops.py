@@ -1300,6 +1300,44 @@ def test_compact_lstm_layer_equals_padded(env, H, monkeypatch):
             assert rel(a, b_) < 2e-2, (name, rel(a, b_))
 
 
+@pytest.mark.parametrize("H,gate", [(512, False), (640, True)])
+def test_hidden_size_below_1024_runs_on_the_persistent_kernels(env, H, gate, monkeypatch):
+    """A layer with H < 1024 hidden units (the reference's nn.LSTM takes any n_hidden, flowtron.py:654-655) runs as its zero-padded
+    1024-unit twin on the persistent kernels (ops.lstm_pad_width / pad_gate_blocks) instead of the launch-per-step kernels: outputs,
+    the gate-layer values riding on the projection, and every gradient against the unpadded launch-per-step path (_PAD_H = False) in
+    the same operand format -- the two differ by the summation order over k and by the 16-bit gx rows of the persistent path."""
+    L, ops = env
+    torch.manual_seed(6)
+    T, B, K = 96, 6, 80
+    lens = [96, 96, 70, 33, 2, 1]
+    lens32 = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    m = _valid_mask(T, B, lens).cuda()
+    x = torch.randn(T, B, K, device="cuda") * m[..., None]
+    w_ih, w_hh = torch.randn(4 * H, K, device="cuda") * 0.1, torch.randn(4 * H, H, device="cuda") / H ** 0.5
+    b_ih, b_hh = torch.randn(4 * H, device="cuda") * 0.1, torch.randn(4 * H, device="cuda") * 0.1
+    gw, gb = torch.randn(1, K, device="cuda") * 0.1, torch.randn(1, device="cuda")
+    go = torch.randn(T, B, H, device="cuda") * m[..., None]
+    assert ops.lstm_pad_width(B, H, False, 1, x.device, T)
+    res = []
+    for pad in (False, True):
+        monkeypatch.setattr(ops, "_PAD_H", pad)
+        d = [t.clone().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh, gw, gb)]
+        out = ops.lstm_layer(d[0], lens32, d[1], d[2], d[3], d[4], mode=1, rowmap=ops.RowMap(lens32, T, B), fill="dx",
+                             gate=(d[5], d[6]) if gate else None)
+        y, g = out if gate else (out, None)
+        assert y.shape == (T, B, H) and y.is_contiguous()
+        loss = (y * go).sum() + (g[m].sum() if gate else 0.0)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append([y.detach()] + ([g.detach()[m]] if gate else []) + [t.grad for t in d[:5 + 2 * int(gate)]])
+    ops.check_persist_status()
+    assert float((res[1][0] * (~m)[..., None]).abs().max()) == 0.0                  # padded frames stay zero
+    assert mad(res[1][0], res[0][0]) < 2e-2 and mad(res[1][0], res[0][0]) > 0.0, "the padded persistent path was not taken"
+    names = (["gate"] if gate else []) + ["dx", "dW_ih", "dW_hh", "db_ih", "db_hh"] + (["dgate_w", "dgate_b"] if gate else [])
+    for a, b_, name in zip(res[1][1:], res[0][1:], names):
+        assert rel(a, b_) < 2e-2, (name, rel(a, b_))
+
+
 @pytest.mark.parametrize("act", [0, 1])
 def test_big_tile_image_gemm_is_bit_identical_to_the_128_tile_kernel(env, act, monkeypatch):
     """gemm_bf16_p256_k (256 x 256 x 64, persistent: one workgroup per CU walks its tiles, one barrier per K-tile) against gemm_bf16_k on shapes that
