@@ -862,7 +862,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    log("timed region done: %.1f ms/step" % (dt / max(args.steps, 1) * 1e3))
+    log("timed region done: %.2f ms/step" % (dt / max(args.steps, 1) * 1e3))
     comm_ms = None
     if world > 1 and getattr(model, "_comm_events", None):
         evs = model._comm_events[-args.steps:]
@@ -950,9 +950,9 @@ def main():
                            "peak": 2500.0, "unit": "TFLOP/s", "frac": round(frames_per_gpu * 325e6 / 2.5e15, 5), "traffic": None,
                            "flop_per_valid_frame": 325e6,
                            "gemm_mfma_busy_frac_pmc": {k: dict(zip(("frac", "pmc_round"), pmc_value("MFMA_BUSY", k, "mfma_busy_frac", with_source=True)))
-                                                       for k in ("gemm_bf16_k<true, true, true, 256, 32>", "gemm_bf16_k<false, true, false, 128, 64>",
-                                                                 "gemm_bf16_k<false, true, false, 128, 32>",
-                                                                 "gemm_bf16_k<false, false, false, 128, 32>", "gemm_bf16_p256_k")}}
+                                                       for k in ("gemm_bf16_k<true, true, true, 256, 32, false>", "gemm_bf16_k<false, true, false, 128, 64, true>",
+                                                                 "gemm_bf16_k<false, false, false, 128, 64, true>",
+                                                                 "gemm_bf16_k<false, false, false, 128, 32, false>")}}
         if args.config == "ljs_cumm":
             try:
                 res["roofline"]["cumulative_attention"] = cumm_roofline(args.batch, batch_cpu["in_lens"], mode)

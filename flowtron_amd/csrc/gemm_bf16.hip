@@ -8,12 +8,16 @@
 //     row contiguous source -> image [ceil32(K)][ceil128(rows)]     (k-major: NO transpose, the kernel reads it with
 //                                                                    the LDS transpose-read ds_read_b64_tr_b16)
 // and the GEMM proper (templated on the layout of each operand) has no bounds checks in its main loop:
-//   * 128x128 tile, 32-wide k stages (64 optional), 4 waves (2x2, 64x64 per wave = 4x4 MFMA 16x16x32 tiles per stage),
-//   * operands go global -> LDS by `global_load_lds_dwordx4` (no VGPR staging, no ds_write pass), two LDS stages so the
-//     DMA of step t+1 is in flight under the MFMAs of step t, one barrier per step, 4 workgroups per CU (32 KiB LDS each),
-//   * the LDS image is a sequence of 1 KiB [16 rows][32 k] sub-tiles = exactly one wave-wide DMA each; the DMA writes
-//     lane-linear, so the bank swizzle is applied to the SOURCE address: LDS slot(row, kpart) = row*4 + (kpart ^ ((row>>2)&2)),
-//     which makes the four 16-lane service groups of ds_read_b128 ({0-3,12-15,20-27}, ...) hit 16 distinct 16-byte slots.
+//   * 128x128 tile (256x128 for the split-K weight gradients), 4 waves (2x2, 64x64 per wave = 4x4 MFMA 16x16x32 tiles per k-step),
+//   * operands go global -> LDS by `global_load_lds_dwordx4` (no VGPR staging, no ds_write pass), one barrier pair per stage,
+//     4 workgroups per CU (32 KiB LDS each),
+//   * store kernels with a k-contiguous operand (forward, input gradients; round 6): 64-wide k stages in ONE buffer -- a DMA piece is
+//     8 image rows x 128 B (whole cache lines), the LDS image has 128-byte rows with the 16-byte chunk c of row r at c ^ ((r >> 1) & 7);
+//     the DMAs of the next stage go out once every wave holds the stage's last fragments in registers (Operand64, template SB),
+//   * 32-wide double-buffered stages elsewhere (both operands k-major: the weight gradients; K not a multiple of 64): the LDS image is a
+//     sequence of 1 KiB [16 rows][32 k] sub-tiles = exactly one wave-wide DMA each; the DMA writes lane-linear, so the bank swizzle is
+//     applied to the SOURCE address: LDS slot(row, kpart) = row*4 + (kpart ^ ((row>>2)&2)), which makes the four 16-lane service groups
+//     of ds_read_b128 ({0-3,12-15,20-27}, ...) hit 16 distinct 16-byte slots.
 // Same epilogue contract as ft_gemm (alpha, beta, bias, activation, optional atomic split-K).
 // Rounding is identical to the staging kernel (RNE to bf16, fp32 accumulate); only the summation order differs.
 #include "common.h"
@@ -362,14 +366,16 @@ struct Operand64 {
 
 // RTA = rows of the workgroup tile (128, or 256: wave tile 128 x 64 = 8 x 4 MFMA tiles -- 12 fragment reads feed 32 MFMAs instead of
 // 8 feeding 16, which takes the LDS pipe off the critical path; 2 workgroups per CU, 196 VGPRs)
-// KS = 64: 64-wide k stages (two MFMA k-steps per barrier; the k-contiguous operands as Operand64, a k-major operand as two of its
-// 32-wide sub-stages side by side), 64 KiB of LDS, 2 workgroups per CU; t0 / t1 / ksteps keep counting 32-wide steps (t0 even)
-template <bool AKM, bool BKM, bool SPLIT, int RTA, int KS = 32>
-__global__ __launch_bounds__(256, (RTA == 256 || KS == 64) ? 2 : 4) void gemm_bf16_k(BfP p) {
+// KS = 64: 64-wide k stages (two MFMA k-steps per stage; the k-contiguous operands as Operand64, a k-major operand as two of its
+// 32-wide sub-stages side by side); t0 / t1 / ksteps keep counting 32-wide steps (t0 even).  SB: a single 32 KiB LDS buffer, 4
+// workgroups per CU (with two buffers the stage is 64 KiB and only 2 workgroups fit a CU: slower than 32-wide stages at K = 1024)
+template <bool AKM, bool BKM, bool SPLIT, int RTA, int KS = 32, bool SB = false>
+__global__ __launch_bounds__(256, SB ? 4 : (RTA == 256 || KS == 64) ? 2 : 4) void gemm_bf16_k(BfP p) {
+    static_assert(!SB || (KS == 64 && RTA == 128 && !SPLIT), "single-buffer form: 128 x 128 x 64 store kernels");
     constexpr int KQ = KS / 32;                        // MFMA k-steps per stage
     constexpr int OPA = RTA * 64 * KQ, OPB = 8192 * KQ;     // bytes per operand per stage
     constexpr int TI = RTA / 32;                       // 16-row fragments of the wave tile along M
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (OPA + OPB)];     // [stage][A | B]
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[(SB ? 1 : 2) * (OPA + OPB)];     // [stage][A | B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, kg = lane >> 4;
@@ -453,53 +459,77 @@ __global__ __launch_bounds__(256, (RTA == 256 || KS == 64) ? 2 : 4) void gemm_bf
             if constexpr (!BKM) ob64.issue(sbuf + OPA, s); else { ob.issue(sbuf + OPA, 2 * s); ob.issue(sbuf + OPA + OPB / 2, 2 * s + 1); }
         } else { oa.issue(sbuf, s); ob.issue(sbuf + OPA, s); }
     };
+    // the fragments of MFMA k-step ks of the stage at sbase, and its TI x 4 MFMAs
+    auto load_frags = [&](const unsigned char* sbase, int ks, bf16x8 (&a)[TI], bf16x8 (&b)[4]) {
+        const unsigned char* sa = sbase + ((KS == 64 && AKM) ? ks * (OPA / 2) : 0);
+        const unsigned char* sb = sbase + OPA + ((KS == 64 && BKM) ? ks * (OPB / 2) : 0);
+        bf16x4 ta[2 * TI], tb[8];
+        if constexpr (!AKM) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) { if constexpr (KS == 64) a[i] = oa64.frag(sa, i, ks); else a[i] = oa.frag(sa, i); }
+        }
+        if constexpr (!BKM) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { if constexpr (KS == 64) b[j] = ob64.frag(sb, j, ks); else b[j] = ob.frag(sb, j); }
+        }
+        if constexpr (AKM) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) oa.tr_issue(sa, i, ta[2 * i], ta[2 * i + 1]);
+        }
+        if constexpr (BKM) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ob.tr_issue(sb, j, tb[2 * j], tb[2 * j + 1]);
+        }
+        if constexpr (AKM && BKM) tr_wait(ta, tb);
+        else if constexpr (AKM) tr_wait(ta);
+        else if constexpr (BKM) tr_wait(tb);
+        if constexpr (AKM) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) a[i] = __builtin_shufflevector(ta[2 * i], ta[2 * i + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        if constexpr (BKM) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = __builtin_shufflevector(tb[2 * j], tb[2 * j + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+    auto multiply = [&](const bf16x8 (&a)[TI], const bf16x8 (&b)[4]) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (SPLIT) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+                else acc[i][j] = mfma16(b[j], a[i], acc[i][j]);
+            }
+    };
     const int s0 = t0 / KQ, s1 = (t1 + KQ - 1) / KQ;       // stages of this k-slice
     if (s0 < s1) issue_stage(smem, s0);
-    for (int t = s0; t < s1; ++t) {
-        const int stage = (t - s0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my DMAs of stage t have landed
-        __syncthreads();                                            // ... everyone's have; stage^1 is no longer being read
-        if (t + 1 < s1) issue_stage(smem + (stage ^ 1) * (OPA + OPB), t + 1);
+    if constexpr (SB) {
+        // ONE LDS buffer: the DMAs of stage t + 1 go out as soon as every wave holds the last fragments of stage t in registers, and
+        // fly under the second half of its MFMAs -- and under the other three workgroups of the CU, which is where the rest of the
+        // round trip hides
+        for (int t = s0; t < s1; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                            // stage t has landed for everyone
+            bf16x8 a0[TI], b0[4], a1[TI], b1[4];
+            load_frags(smem, 0, a0, b0);
+            multiply(a0, b0);
+            load_frags(smem, 1, a1, b1);
+            __syncthreads();                                            // (waits for the LDS reads too) nobody reads the buffer any more
+            if (t + 1 < s1) issue_stage(smem, t + 1);
+            multiply(a1, b1);
+        }
+    } else {
+        for (int t = s0; t < s1; ++t) {
+            const int stage = (t - s0) & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my DMAs of stage t have landed
+            __syncthreads();                                            // ... everyone's have; stage^1 is no longer being read
+            if (t + 1 < s1) issue_stage(smem + (stage ^ 1) * (OPA + OPB), t + 1);
 #pragma unroll
-        for (int ks = 0; ks < KQ; ++ks) {
-            const unsigned char* sa = smem + stage * (OPA + OPB) + ((KS == 64 && AKM) ? ks * (OPA / 2) : 0);
-            const unsigned char* sb = smem + stage * (OPA + OPB) + OPA + ((KS == 64 && BKM) ? ks * (OPB / 2) : 0);
-            bf16x8 a[TI], b[4];
-            bf16x4 ta[2 * TI], tb[8];
-            if constexpr (!AKM) {
-#pragma unroll
-                for (int i = 0; i < TI; ++i) { if constexpr (KS == 64) a[i] = oa64.frag(sa, i, ks); else a[i] = oa.frag(sa, i); }
+            for (int ks = 0; ks < KQ; ++ks) {
+                bf16x8 a[TI], b[4];
+                load_frags(smem + stage * (OPA + OPB), ks, a, b);
+                multiply(a, b);
             }
-            if constexpr (!BKM) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { if constexpr (KS == 64) b[j] = ob64.frag(sb, j, ks); else b[j] = ob.frag(sb, j); }
-            }
-            if constexpr (AKM) {
-#pragma unroll
-                for (int i = 0; i < TI; ++i) oa.tr_issue(sa, i, ta[2 * i], ta[2 * i + 1]);
-            }
-            if constexpr (BKM) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ob.tr_issue(sb, j, tb[2 * j], tb[2 * j + 1]);
-            }
-            if constexpr (AKM && BKM) tr_wait(ta, tb);
-            else if constexpr (AKM) tr_wait(ta);
-            else if constexpr (BKM) tr_wait(tb);
-            if constexpr (AKM) {
-#pragma unroll
-                for (int i = 0; i < TI; ++i) a[i] = __builtin_shufflevector(ta[2 * i], ta[2 * i + 1], 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-            if constexpr (BKM) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = __builtin_shufflevector(tb[2 * j], tb[2 * j + 1], 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (SPLIT) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
-                    else acc[i][j] = mfma16(b[j], a[i], acc[i][j]);
-                }
         }
     }
 
@@ -560,236 +590,15 @@ __global__ __launch_bounds__(256, (RTA == 256 || KS == 64) ? 2 : 4) void gemm_bf
     }
 }
 
-__device__ __forceinline__ void ds_read16(bf16x8& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); }
-template <int OFF>
-__device__ __forceinline__ void ds_read16o(bf16x8& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF)); }
-__device__ __forceinline__ void frag_wait(bf16x8 (&a)[8], bf16x8 (&b)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
-                 "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-}
-__device__ __forceinline__ void frag_wait(bf16x8 (&a)[8]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
-}
-__device__ __forceinline__ void frag_wait(bf16x8 (&b)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-}
-
-// epilogue of a 128 x 64 wave tile (8 x 4 accumulator tiles in C^T form): lane (li, kg), register r  <->
-// C[m = mw + i*16 + li][n = nw + j*16 + kg*4 + r]; alpha, beta, bias, rank-1 term, activation, compact row map, 16-bit C
-__device__ __forceinline__ void store_tile256(const BfP& p, const f32x4 (&acc)[8][4], int mw, int nw, int rows_lim, int li, int kg) {
-    const bool vec = p.vec_c != 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int row = mw + i * 16 + li;
-        if (row >= rows_lim) continue;
-        if (p.compact == 1) { row = p.rowmap[row]; if (row < 0) continue; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = nw + j * 16 + kg * 4;
-            if (col >= p.N) continue;
-            float* cp = p.C + (long)row * p.ldc + col;
-            float v[4] = {p.alpha * acc[i][j][0], p.alpha * acc[i][j][1], p.alpha * acc[i][j][2], p.alpha * acc[i][j][3]};
-            const int nv = (p.N - col < 4) ? p.N - col : 4;
-            const bool full = vec && nv == 4;
-            if (p.beta != 0.f) {
-                if (full) { const float4 c = *reinterpret_cast<const float4*>(cp); v[0] += p.beta * c.x; v[1] += p.beta * c.y; v[2] += p.beta * c.z; v[3] += p.beta * c.w; }
-                else for (int r = 0; r < nv; ++r) v[r] += p.beta * cp[r];
-            }
-            const float r1 = p.r1row ? p.r1row[row] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (r < nv && p.bias) v[r] += p.bias[col + r];
-                if (r < nv && p.r1row) v[r] = fmaf(r1, p.r1col[col + r], v[r]);
-                if (p.act == FT_ACT_TANH) v[r] = tanhf_(v[r]);
-                else if (p.act == FT_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
-                else if (p.act == FT_ACT_SIGMOID) v[r] = sigmoidf_(v[r]);
-            }
-            if (p.c16) {
-                unsigned short* hp = reinterpret_cast<unsigned short*>(p.C) + (long)row * p.ldc + col;
-                if (full) *reinterpret_cast<uint2*>(hp) = make_uint2(pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3]));
-                else for (int r = 0; r < nv; ++r) hp[r] = f2op16(v[r]);
-            } else if (full) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-            else for (int r = 0; r < nv; ++r) cp[r] = v[r];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// 256 x 256 x 64 PERSISTENT kernel for the large k-contiguous x k-contiguous GEMMs with many tiles and a long reduction (the decoder
-// LSTM's input projection over the concatenated image): 8 identical waves (2 x 4, wave tile 128 x 64 = 8 x 4 MFMA tiles, 128
-// accumulator registers, two waves per SIMD), 128 KiB of LDS = two buffers of [A 256 rows | B 256 rows] x 64 k, one workgroup per CU
-// that walks its share of the XCD's tiles; the K-tiles of consecutive output tiles form ONE stream of units through the buffers.
-//   * unit u: [own DMAs of u landed: vmcnt(0); barrier] -> quadrants (0,0) (0,1) (1,1) (1,0) of the wave tile, the fragments of the
-//     next quadrant read behind the MFMAs of the current one (24 ds_read_b128 per unit) and the 8 DMAs of unit u + 1 (into the buffer
-//     u - 1 was read from) issued two at a time between the MFMA blocks.  ONE barrier per unit.
-//   * the first K-tile of the NEXT output tile is staged during the last K-tile of the current one (no prologue per tile); the C
-//     stores of a tile go out at the top of the next tile's first unit.
-//   * LDS image: 128-byte rows (64 k), the 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7): the four 16-lane service
-//     groups of ds_read_b128 hit 16 distinct slots (SQ_LDS_BANK_CONFLICT = 0).  The DMA writes lane-linear, so the swizzle is applied
-//     to the SOURCE address (same 128-byte global line: coalescing is unaffected; whole-line requests, TCP_TCC_READ_REQ = bytes / 128).
-// Rounds 3-5 ran this tile as one workgroup per TILE with two wave groups half a phase apart and eight barriers per K-tile
-// (gemm_bf16_big_k, removed): same speed within the box-to-box spread (0.347-0.371 ms against 0.344-0.365 at M 19 200, N 4096,
-// K 1664).  What the timing-only cuts say about either form (profiles/r06_gemm_bigk_cuts.log, r06_gemm_p256_cuts.log,
-// r06_gemm_nostore.log, r06_gemm_pmc.log): the 64 MFMAs of a unit are 0.85 us per SIMD pair, its 64 KB arrive in 1.2 us when nothing
-// else runs, the unit takes 2.8 -- the waves sit in s_waitcnt / s_barrier 45 % of their cycles and the TCP stalls on pending L2
-// returns 37 % of the time: with one workgroup per CU the L2 -> LDS stream drains at every unit boundary, and the 256 KB of C per
-// tile leave through the same in-order vmcnt the DMAs are waited on.  Same epilogue contract as gemm_bf16_k; no split-K; same k order
-// (bit-identical to the other kernels).
-__global__ __launch_bounds__(512, 2) void gemm_bf16_p256_k(BfP p) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];          // 2 x (32 KiB A + 32 KiB B)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int li = lane & 15, kg = lane >> 4;
-    int rows_lim = p.M, gy = p.gy;
-    if (p.compact == 1) {
-        const int R = __builtin_amdgcn_readfirstlane(*p.rows_dev);
-        rows_lim = R < p.M ? R : p.M;
-        gy = (rows_lim + 255) >> 8;
-        if (gy == 0) return;
-    }
-    // ---- this workgroup's tiles: the XCD's list (L2-aware chunk order, or a contiguous run), every (gridDim.x / 8)-th entry
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-    const bool chunked = p.chunk_w > 0 && gy >= 16;
-    int cnt, mh = 0, m_lo = 0, base = 0;
-    if (chunked) {
-        const int qm = gy >> 3, rm = gy & 7;
-        mh = qm + (xcd < rm ? 1 : 0);
-        m_lo = xcd * qm + (xcd < rm ? xcd : rm);
-        cnt = mh * p.gx;
-    } else {
-        const int total = p.gx * gy, q = total >> 3, r = total & 7;
-        cnt = q + (xcd < r ? 1 : 0);
-        base = xcd * q + (xcd < r ? xcd : r);
-    }
-    if (slot >= cnt) return;
-    const int ntl = (cnt - slot + nslot - 1) / nslot;
-    auto tile_at = [&](int k, int& m0, int& n0) {          // k-th tile of this workgroup
-        const int idx = slot + k * nslot;
-        int mt, nt;
-        if (chunked) {
-            const int per_chunk = mh * p.chunk_w;
-            const int ch = idx / per_chunk, within = idx - ch * per_chunk;
-            const int left = p.gx - ch * p.chunk_w;
-            const int cw = left < p.chunk_w ? left : p.chunk_w;
-            const int mi = within / cw;
-            mt = m_lo + mi;
-            nt = ch * p.chunk_w + (within - mi * cw);
-        } else {
-            const int t = base + idx;
-            mt = t / p.gx;
-            nt = t % p.gx;
-        }
-        m0 = mt << 8; n0 = nt << 8;
-    };
-    const int nkt = (p.nk + 1) >> 1;                      // K-tiles of 64
-
-    // ---- staging: a unit is 512 LDS rows ([A 256 | B 256]) x 128 B = 64 pieces of 8 rows; wave w stages rows 64 w .. 64 w + 63
-    // (waves 0-3: A, 4-7: B).  Physical chunk pch of LDS row r holds logical chunk pch ^ ((r >> 1) & 7); with r = 8 h + prow
-    // inside the wave's 64 rows that is pch ^ (prow >> 1) ^ (4 (h & 1)).
-    const int prow = lane >> 3, pch = lane & 7;
-    const int c_even = pch ^ (prow >> 1);
-    const long ld_w = wave < 4 ? p.lda : p.ldb;
-    const unsigned short* img_w = wave < 4 ? p.A : p.B;
-    const int row_w = (wave & 3) * 64 + prow;
-    const long off_e = (long)c_even * 8, off_o = (long)(c_even ^ 4) * 8;
-    const unsigned short* srow;                            // this lane's row 0 of the tile being STAGED (k = 0)
-    auto set_stage_tile = [&](int k) {
-        int m0, n0;
-        tile_at(k, m0, n0);
-        srow = img_w + (size_t)((wave < 4 ? m0 : n0) + row_w) * ld_w;
-    };
-    const int dst_w = wave * 8192;
-    // (quarter q of a unit = this wave's pieces 2q, 2q + 1: the DMAs of a unit are issued two at a time between the MFMA blocks)
-    auto stage = [&](int kt, int buf, int q) {
-        unsigned char* bb = smem + buf * 65536 + dst_w;
-        const unsigned short* s0 = srow + (size_t)kt * 64;
-#pragma unroll
-        for (int h = 2 * q; h < 2 * q + 2; ++h)
-            __builtin_amdgcn_global_load_lds((glb_void*)(s0 + (size_t)h * 8 * ld_w + ((h & 1) ? off_o : off_e)), (lds_void*)(bb + h * 1024), 16, 0, 0);
-    };
-
-    // ---- fragment read addresses: row-dependent swizzle s = (li >> 1), chunk (ks * 4 + kg) ^ s -> byte offsets sw0 (ks 0), sw0 ^ 64 (ks 1)
-    const unsigned sw0 = (unsigned)((kg ^ (li >> 1)) << 4), sw1 = sw0 ^ 64u;
-    const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;
-    const unsigned a_row = lds0 + (unsigned)((wr * 128 + li) * 128);                     // + qm * 8192 + i * 2048
-    const unsigned b_row = lds0 + 32768u + (unsigned)((wc * 64 + li) * 128);             // + qn * 4096 + j * 2048
-
-    f32x4 acc[8][4];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    };
-    zero_acc();
-    bf16x8 a[8], a2[8], b0[4], b1[4];                      // a*[ks * 4 + i]; b*[ks * 2 + j]
-    auto read_a = [&](int buf, int qm, bf16x8 (&d)[8]) {
-        const unsigned base0 = a_row + (unsigned)(buf * 65536 + qm * 8192) + sw0;
-        const unsigned base1 = a_row + (unsigned)(buf * 65536 + qm * 8192) + sw1;
-        ds_read16o<0>(d[0], base0); ds_read16o<2048>(d[1], base0); ds_read16o<4096>(d[2], base0); ds_read16o<6144>(d[3], base0);
-        ds_read16o<0>(d[4], base1); ds_read16o<2048>(d[5], base1); ds_read16o<4096>(d[6], base1); ds_read16o<6144>(d[7], base1);
-    };
-    auto read_b = [&](int buf, int qn, bf16x8 (&d)[4]) {
-        const unsigned base0 = b_row + (unsigned)(buf * 65536 + qn * 4096) + sw0;
-        const unsigned base1 = b_row + (unsigned)(buf * 65536 + qn * 4096) + sw1;
-        ds_read16o<0>(d[0], base0); ds_read16o<2048>(d[1], base0);
-        ds_read16o<0>(d[2], base1); ds_read16o<2048>(d[3], base1);
-    };
-    auto quad = [&](int qm, int qn, const bf16x8 (&av)[8], const bf16x8 (&bv)[4]) {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[qm * 4 + i][qn * 2 + j] = mfma16(bv[ks * 2 + j], av[ks * 4 + i], acc[qm * 4 + i][qn * 2 + j]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    int tc = 0, ktc = 0;                                   // unit being multiplied: tile tc, K-tile ktc
-    int ts = 0, kts = 0;                                   // unit being staged
-    int m0c, n0c;
-    tile_at(0, m0c, n0c);
-    set_stage_tile(0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) stage(0, 0, q);
-    const int units = ntl * nkt;
-    for (int u = 0; u < units; ++u) {
-        const int buf = u & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of unit u have landed (and the C stores of the last tile are acknowledged)
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();                      // everyone's have; nobody reads unit u - 1 any more
-        __builtin_amdgcn_sched_barrier(0);
-        if (ktc == 0 && u > 0) {                           // the previous unit closed a tile: store it, then open the next
-            int mp, np;
-            tile_at(tc - 1, mp, np);
-            store_tile256(p, acc, mp + wr * 128, np + wc * 64, rows_lim, li, kg);
-            zero_acc();
-        }
-        const bool more = u + 1 < units;
-        if (more && ++kts == nkt) { kts = 0; set_stage_tile(++ts); }
-        read_a(buf, 0, a); read_b(buf, 0, b0);
-        if (more) stage(kts, buf ^ 1, 0);
-        frag_wait(a, b0);
-        read_b(buf, 1, b1);
-        if (more) stage(kts, buf ^ 1, 1);
-        quad(0, 0, a, b0);
-        frag_wait(b1);
-        read_a(buf, 1, a2);
-        if (more) stage(kts, buf ^ 1, 2);
-        quad(0, 1, a, b1);
-        frag_wait(a2);
-        if (more) stage(kts, buf ^ 1, 3);
-        quad(1, 1, a2, b1);
-        quad(1, 0, a2, b0);
-        if (++ktc == nkt) { ktc = 0; ++tc; }
-    }
-    tile_at(ntl - 1, m0c, n0c);
-    store_tile256(p, acc, m0c + wr * 128, n0c + wc * 64, rows_lim, li, kg);
-}
+// (Rounds 3-6 also carried a 256 x 256 x 64 tile for the k-contiguous x k-contiguous GEMMs with many tiles and a long reduction: 8 waves,
+// 128 KiB of LDS, one workgroup per CU -- first as two wave groups half a phase apart with eight barriers per K-tile, then as a
+// persistent kernel with one barrier per K-tile and the C stores of a tile issued behind the next tile's first unit.  Both reached
+// 718-760 TFLOP/s at M 19 200 x N 4096 x K 1664 on N(0,1) data; the timing-only cuts (profiles/r06_gemm_bigk_cuts.log,
+// r06_gemm_p256_cuts.log, r06_gemm_nostore.log, r06_gemm_pmc.log) say why: the 64 MFMAs of a K-tile are 0.85 us per SIMD pair and its
+// 64 KB arrive in 1.2 us when nothing else runs, but with ONE workgroup per CU the L2 -> LDS stream drains at every barrier (waves in
+// s_waitcnt / s_barrier 45 % of their cycles, TCP stalled on pending L2 returns 37 %) and the 256 KB of C per tile leave through the
+// same in-order vmcnt the DMAs are waited on.  The single-buffer 128 x 128 x 64 form above -- four workgroups per CU, whole-line
+// pieces -- is faster on the same shapes (759 / 798 with 16-bit C) and everywhere else, so the tile was removed.)
 
 template <bool AKM, bool BKM>
 void launch_s(const BfP& p, dim3 grid, bool big, bool wide, hipStream_t st) {
@@ -800,7 +609,7 @@ void launch_s(const BfP& p, dim3 grid, bool big, bool wide, hipStream_t st) {
     } else {
         if (atomics) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, true, 128>), grid, dim3(256), 0, st, p);
         else if constexpr (!(AKM && BKM)) {
-            if (wide) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 128, 64>), grid, dim3(256), 0, st, p);
+            if (wide) hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 128, 64, true>), grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 128>), grid, dim3(256), 0, st, p);
         } else hipLaunchKernelGGL((gemm_bf16_k<AKM, BKM, false, 128>), grid, dim3(256), 0, st, p);
     }
@@ -884,15 +693,15 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
         if (s > fit) s = fit;
         if (s < 1) s = 1;
     }
-    // 64-wide k stages for the store kernels with a k-contiguous operand (Operand64: whole-line DMA pieces) -- where K is a whole number
-    // of them (else the last stage would read 32 columns past K, which only images padded by ft_bf16_image hold as zeros; a view
-    // into a wider image does not).  FT_GEMM_BF16_WIDE=0 (A/B hook, read per call): 32-wide stages everywhere
+    // 64-wide k stages in ONE LDS buffer for the store kernels with a k-contiguous operand (Operand64: whole-line DMA pieces; 32 KiB of
+    // LDS, 4 workgroups per CU) -- where K is a whole number of them (else the last stage would read 32 columns past K, which only
+    // images padded by ft_bf16_image hold as zeros; a view into a wider image does not).  Measured on N(0,1) data, M 19 200
+    // (scripts/exp/gemm_img_bench.py / gemm_step_bench.py, profiles/r06_gemm_wide_stages.log; 32-wide double-buffered stages -> 64-wide
+    // double-buffered at 2 workgroups per CU -> 64-wide single-buffered at 4): x[R,1664] W[4096,1664]^T 602 -> 648 -> 759 TFLOP/s
+    // (the 256^2 kernels: 748), K 1024: 635 -> 599 -> 789, d[R,4096] W[4096,1664] (dX) 730 -> 884 -> 967, N = 1024 dense layers
+    // 580-600 -> 690-700.  FT_GEMM_BF16_WIDE=0 (A/B hook, read per call): 32-wide stages everywhere
     const char* wide_env = getenv("FT_GEMM_BF16_WIDE");
-    // Measured (scripts/exp/gemm_step_bench.py, profiles/r06_gemm_wide_stages.log): d[R,4096] W -> dX 711 -> 843 TFLOP/s (N 1664), 700 -> 829
-    // (N 1024); x[R,1664] W^T 607 -> 685; at K = 1024 the 16 stages of a tile no longer hide the prologue / epilogue of 2 workgroups
-    // per CU (636 -> 573): long reductions only.  FT_GEMM_BF16_WIDE = 2 forces it wherever K allows
-    const int wide_mode = wide_env ? atoi(wide_env) : 1;
-    const bool wide = wide_mode != 0 && (p.nk & 1) == 0 && !(a_km && b_km) && !big && (wide_mode == 2 || p.nk >= 48);
+    const bool wide = (!wide_env || atoi(wide_env) != 0) && (p.nk & 1) == 0 && !(a_km && b_km) && !big;
     p.ksteps = cdiv(p.nk, s);
     if (wide && (p.ksteps & 1)) ++p.ksteps;            // (k-slices of whole 64-wide stages)
     p.splits = cdiv(p.nk, p.ksteps);
@@ -911,27 +720,6 @@ int run_images(const unsigned short* A, long lda, int a_km, const unsigned short
         long cw = (2l << 20) / ((long)TB * (long)p.nk * 32 * 2);
         p.chunk_w = (int)(cw < 1 ? 1 : (cw > p.gx ? p.gx : cw));
         gridx = 8 * ((p.gy + 7) / 8) * p.gx;          // every XCD is handed the blocks of the largest row range
-    }
-    // the persistent 256 x 256 x 64 kernel: both operands k-contiguous, no split-K, enough tiles to fill the chip
-    const char* big_env = getenv("FT_GEMM_BF16_BIG");
-    // Measured on MI355X (scripts/exp/gemm_img_bench.py, M = 19 200 rows of N(0,1) data, bit-identical outputs): it wins where a
-    // tile has a long reduction and the CUs several tiles each -- x[R,1664] W[4096,1664]^T 748 vs 685 TFLOP/s (607 with 32-wide
-    // stages) -- and loses elsewhere (K = 1024: 596 vs 636; N = 1024: 404 vs 594 -- 300 tiles are 1.2 rounds of 256 CUs).
-    // FT_GEMM_BF16_BIG = 0 | 1 | 2 (read per call): off | where it wins (default) | wherever it applies.
-    const int big_mode = big_env ? atoi(big_env) : 1;
-    const bool big256 = big_mode != 0 && !a_km && !b_km && p.splits == 1 && M >= 4096 && N >= 512 && K >= 256 &&
-                        (big_mode == 2 || (N >= 2048 && K >= 1536));
-    if (big256) {
-        p.gx = cdiv(N, 256); p.gy = cdiv(M, 256);
-        p.chunk_w = 0;
-        if (order_on && p.gy >= 16) {
-            long cw = (2l << 20) / (256l * (long)p.nk * 32 * 2);
-            p.chunk_w = (int)(cw < 1 ? 1 : (cw > p.gx ? p.gx : cw));
-        }
-        FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p256_k), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        hipLaunchKernelGGL(gemm_bf16_p256_k, dim3(256), dim3(512), 131072, st, p);
-        FT_CHECK_LAUNCH();
-        return FT_OK;
     }
     const dim3 grid(gridx, p.splits);
     if (a_km) { if (b_km) launch_s<true, true>(p, grid, big, wide, st); else launch_s<true, false>(p, grid, big, wide, st); }

@@ -1,5 +1,6 @@
-"""Image GEMM (ft_gemm_img) on the training step's forward / input-gradient shapes: the 128 x 128 kernel against the 256 x 256 x 64
-two-group kernel (FT_GEMM_BF16_BIG=0 | 1, read per call).  Images are built once; only the GEMM launches are timed."""
+"""Image GEMM (ft_gemm_img) on the training step's forward / input-gradient shapes (N(0,1) data, padded rows): 32-wide double-buffered k
+stages against the 64-wide single-buffer stages (FT_GEMM_BF16_WIDE=0 | 1, read per call).  Images are built once; only the GEMM
+launches are timed."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from flowtron_amd import _lib as L, ops
@@ -14,8 +15,8 @@ for name, M, N, K in shapes[: int(os.environ.get("GEMM_BENCH_SHAPES", "99"))]:
     w = torch.randn(N, K, device="cuda") / K ** 0.5
     xi, wi = ops.Bf16Image(x, mode=1), ops.Bf16Image(w, mode=1)
     outs, res = [], []
-    for big in ("0", "2"):
-        os.environ["FT_GEMM_BF16_BIG"] = big
+    for wide in ("0", "1"):
+        os.environ["FT_GEMM_BF16_WIDE"] = wide
         y = torch.empty(M, N, device="cuda")
         for _ in range(3):
             ops.gemm_img(xi, 0, xi.ptr(), wi, 0, wi.ptr(), y, M, N, K, N)
@@ -29,6 +30,6 @@ for name, M, N, K in shapes[: int(os.environ.get("GEMM_BENCH_SHAPES", "99"))]:
         res.append((ms, 2.0 * M * N * K / ms / 1e9))
         outs.append(y)
     ref = (x.bfloat16().float() @ w.bfloat16().float().t())
-    print("%-38s 128^2 %7.3f ms %5.0f TF | 256^2 %7.3f ms %5.0f TF | identical %s | max err vs torch %.2e"
+    print("%-38s 32-wide %7.3f ms %5.0f TF | 64-wide %7.3f ms %5.0f TF | identical %s | max err vs torch %.2e"
           % (name, res[0][0], res[0][1], res[1][0], res[1][1], bool(torch.equal(outs[0], outs[1])), float((outs[1] - ref).abs().max())), flush=True)
-os.environ.pop("FT_GEMM_BF16_BIG", None)
+os.environ.pop("FT_GEMM_BF16_WIDE", None)

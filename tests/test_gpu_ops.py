@@ -1339,41 +1339,39 @@ def test_hidden_size_below_1024_runs_on_the_persistent_kernels(env, H, gate, mon
 
 
 @pytest.mark.parametrize("act", [0, 1])
-def test_big_tile_image_gemm_is_bit_identical_to_the_128_tile_kernel(env, act, monkeypatch):
-    """gemm_bf16_p256_k (256 x 256 x 64, persistent: one workgroup per CU walks its tiles, one barrier per K-tile) against gemm_bf16_k on shapes that
-    select it (M >= 4096, N >= 512, K >= 256, both operands k-contiguous): the accumulation order per output element is the same
-    (32-wide k steps in order), so the outputs must be BIT-identical -- any staging / swizzle / barrier slip shows as a mismatch.
-    Covers ragged M / N / K against the tile, bias + activation, the accumulate-into-C (beta = 1, two-input) path and the compact
-    row map."""
+def test_wide_stage_image_gemm_two_inputs_is_bit_identical_to_the_32_wide_stages(env, act, monkeypatch):
+    """The single-buffer 64-wide-stage kernel (gemm_bf16_k<.., 64, true>, the default wherever K is a whole number of 64-wide stages)
+    against the 32-wide stages (FT_GEMM_BF16_WIDE=0) on a Linear over TWO inputs (one GEMM over the concatenated image, K = 320 + 256),
+    4800 rows with ragged lengths, padded and compact row space, bias + activation: the accumulation order per output element is
+    the same (32-wide k steps in order), so the outputs must be BIT-identical -- any staging / swizzle / barrier slip shows."""
     L, ops = env
     torch.manual_seed(77)
-    T, B, K1, K2, N = 150, 32, 320, 264, 640                     # rows 4800; K 320 -> 5 K-tiles, 264 -> 5 (ragged last)
+    T, B, K1, K2, N = 150, 32, 320, 256, 640
     lens = [150 - 3 * i for i in range(B)]
     lens32 = torch.tensor(lens, dtype=torch.int32, device="cuda")
     x1, x2 = torch.randn(T, B, K1, device="cuda"), torch.randn(T, B, K2, device="cuda")
     W = torch.randn(N, K1 + K2, device="cuda") * 0.05
     b = torch.randn(N, device="cuda")
     res = {}
-    for big in ("0", "2"):                                        # 2 = wherever the kernel applies (1 = only where it is faster)
-        monkeypatch.setenv("FT_GEMM_BF16_BIG", big)
+    for wide in ("0", "1"):
+        monkeypatch.setenv("FT_GEMM_BF16_WIDE", wide)
         outs = []
         for rm in (None, ops.RowMap(lens32, T, B)):
             outs.append(ops.linear([x1, x2], W, b, act=act, mode=1, rowmap=rm, fill="y").detach().clone())
-        res[big] = outs
-    for a_, b_ in zip(res["0"], res["2"]):
+        res[wide] = outs
+    for a_, b_ in zip(res["0"], res["1"]):
         assert torch.equal(a_, b_), (a_ - b_).abs().max().item()
     ref = torch.cat([x1, x2], 2).bfloat16().float() @ W.bfloat16().float().t() + b
     ref = torch.tanh(ref) if act else ref
-    assert mad(res["2"][0], ref) < 2e-3
+    assert mad(res["1"][0], ref) < 2e-3
 
 
 @pytest.mark.parametrize("K", [256, 448, 1664])
 def test_wide_stage_image_gemm_is_bit_identical_to_the_32_wide_stages(env, K, monkeypatch):
-    """gemm_bf16_k<.., KS = 64> (64-wide k stages: whole-line DMA pieces for the k-contiguous operands, a k-major operand as two of
-    its 32-wide sub-stages; dispatched for K >= 1536, forced here with FT_GEMM_BF16_WIDE=2) against the 32-wide stages
-    (FT_GEMM_BF16_WIDE=0): same k order per output element, so forward (both operands k-contiguous, padded and compact rows, bias +
-    tanh) and input gradient (k-major weight image) must be BIT-identical.  K = 448: 7 whole 64-wide stages;  K = 1664: the decoder
-    projection's own width (dispatched there by default)."""
+    """gemm_bf16_k<.., 64, true> (64-wide k stages in one LDS buffer: whole-line DMA pieces for the k-contiguous operands, a k-major
+    operand as two of its 32-wide sub-stages) against the 32-wide stages (FT_GEMM_BF16_WIDE=0): same k order per output element, so
+    forward (both operands k-contiguous, padded and compact rows, bias + tanh) and input gradient (k-major weight image) must be
+    BIT-identical.  K = 448: 7 whole 64-wide stages;  K = 1664: the decoder projection's own width."""
     L, ops = env
     torch.manual_seed(78)
     T, B, N = 37, 8, 320
@@ -1383,9 +1381,8 @@ def test_wide_stage_image_gemm_is_bit_identical_to_the_32_wide_stages(env, K, mo
     b = torch.randn(N, device="cuda")
     dy = torch.randn(T * B, N, device="cuda")
     res = {}
-    for wide in ("0", "2"):
+    for wide in ("0", "1"):
         monkeypatch.setenv("FT_GEMM_BF16_WIDE", wide)
-        monkeypatch.setenv("FT_GEMM_BF16_BIG", "0")
         outs = []
         for rm in (None, ops.RowMap(lens32, T, B)):
             outs.append(ops.linear([x], W, b, act=1, mode=1, rowmap=rm, fill="y").detach().clone())
@@ -1395,11 +1392,11 @@ def test_wide_stage_image_gemm_is_bit_identical_to_the_32_wide_stages(env, K, mo
         ops.gemm_img(d_img, 0, d_img.ptr(), w_img, 1, w_img.ptr(), dx, T * B, K, N, K)
         outs.append(dx)
         res[wide] = outs
-    for a_, b_ in zip(res["0"], res["2"]):
+    for a_, b_ in zip(res["0"], res["1"]):
         assert torch.equal(a_, b_), (a_ - b_).abs().max().item()
     ref = torch.tanh(x.bfloat16().float() @ W.bfloat16().float().t() + b)
-    assert mad(res["2"][0], ref) < 2e-3
-    assert mad(res["2"][2], dy.bfloat16().float() @ W.bfloat16().float()) < 2e-2
+    assert mad(res["1"][0], ref) < 2e-3
+    assert mad(res["1"][2], dy.bfloat16().float() @ W.bfloat16().float()) < 2e-2
 
 
 # ---------------------------------------------------------------- cumulative attention, fused frames (csrc/cumm_fused.hip)
