@@ -423,9 +423,11 @@ def _pmc_key_matches(key, kernel):
     return k == kernel or (k.startswith(kernel) and k[len(kernel)] in "<(")
 
 
-def _pmc_scalar(v):
-    """a field of scripts/pmc_summarize.py's output: either a number or {"avg": number, "dispatches": n}"""
-    return float(v["avg"]) if isinstance(v, dict) else float(v)
+def _pmc_scalar(v, stat="avg"):
+    """a field of scripts/pmc_summarize.py's output: either a number or {"avg": number, "dispatches": n, "max": largest dispatch}"""
+    if isinstance(v, dict):
+        return float(v[stat]) if stat in v else float(v["avg"])
+    return float(v)
 
 
 def pmc_value(counter_file, kernel_substr, field, with_source=False):
@@ -450,7 +452,8 @@ def pmc_traffic(kernel_name, algorithmic_bytes=None):
     reads 1/2 of a wide coalesced 16 B/lane stream; counters are KiB).  bench.py cannot run rocprofv3 on itself, so this is
     the last measured value, or null when no round lists the kernel.  Both counters come from the SAME kernel entry (the first key
     that matches, of the instantiation with the most dispatches when a bare name matches several -- the step's kernel, not a
-    self-test's), and a figure below 0.9 x the algorithmic bytes is refused: the counters then belong to another launch shape."""
+    self-test's; of its dispatches the largest one), and a figure below 0.9 x the algorithmic bytes is refused: the counters then
+    belong to another launch shape."""
     for prefix in PMC_PREFIXES:
         fd, wd = _pmc_file(prefix, "FETCH_SIZE"), _pmc_file(prefix, "WRITE_SIZE")
         if fd is None or wd is None:
@@ -463,7 +466,9 @@ def pmc_traffic(kernel_name, algorithmic_bytes=None):
             v = fd[k]["FETCH_SIZE"]
             return v.get("dispatches", 1) if isinstance(v, dict) else fd[k].get("dispatches", 1)
         k = max(keys, key=dispatches)
-        val = int((2.0 * _pmc_scalar(fd[k]["FETCH_SIZE"]) + _pmc_scalar(wd[k]["WRITE_SIZE"])) * 1024)
+        # the LARGEST dispatch of the kernel: the step also launches the roles kernels over time windows (the ends of the decoder pair
+        # pipeline), and the figure is held against the bytes of a whole-sequence launch
+        val = int((2.0 * _pmc_scalar(fd[k]["FETCH_SIZE"], "max") + _pmc_scalar(wd[k]["WRITE_SIZE"], "max")) * 1024)
         if algorithmic_bytes is not None and val < 0.9 * algorithmic_bytes:
             return None
         return val
