@@ -1288,20 +1288,20 @@ class DecoderPairFn(torch.autograd.Function):
         dev = dy1.device
         f = dict(device=dev, dtype=torch.float32)
         edges, rms = ctx.chunk_maps
-        dgx1 = torch.empty(T, B, H4, **f)
-        dy0 = torch.empty(T, B, H, **f)
         # layer 0's dgates leave as the compact 16-bit image alone where the only consumer is the input projection's backward
         img_ok = rm is not None and _PERSIST_IMG != "0" and images_apply(mode, H4, H, (T - 1) * B) and (ctx.gx_private or _PERSIST_IMG == "both")
         img_only = img_ok and _PERSIST_IMG != "both" and not torch.is_anomaly_enabled()
-        d_img0 = Bf16Image.empty_rows(H4, rm, mode, dev) if img_ok else None
-        dgx0 = None if img_only else torch.empty(T, B, H4, **f)
-        sb1 = (torch.zeros(B, H4, **f), torch.zeros(B, H, **f))
-        sb0 = (torch.zeros(B, H4, **f), torch.zeros(B, H, **f))
         w_img = ctx.w_img
         ctx.w_img = None
         nb = _PAIR_CHUNKS_BWD if _PAIR_CHUNKS_BWD >= 0 else n
         if nb == 0 and rm is not None and img_ok and ctx.needs_input_grad[1] and ctx.needs_input_grad[5]:
-            return DecoderPairFn._backward_sequential(ctx, dy1, w_img, img_only)
+            return DecoderPairFn._backward_sequential(ctx, dy1, w_img, img_only)      # (before the pipeline's buffers: four fills less per pass)
+        dgx1 = torch.empty(T, B, H4, **f)
+        dy0 = torch.empty(T, B, H, **f)
+        d_img0 = Bf16Image.empty_rows(H4, rm, mode, dev) if img_ok else None
+        dgx0 = None if img_only else torch.empty(T, B, H4, **f)
+        sb1 = (torch.zeros(B, H4, **f), torch.zeros(B, H, **f))
+        sb0 = (torch.zeros(B, H4, **f), torch.zeros(B, H, **f))
         if nb != n and nb > 0:
             n = nb
             edges = _chunk_edges(T, n)
