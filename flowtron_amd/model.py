@@ -528,10 +528,24 @@ class Flowtron(nn.Module):
         attn_prior [B,T,L] | None -> the reference's 8-tuple (flowtron.py:898-899)."""
         L.require_cuda(mel, text, in_lens, out_lens, attn_prior)
         ops.weight_images_begin(self)                # (the weights this model's previous forward rounded: one launch at the first request)
+        ops.bias_sums_begin(self._lstm_bias_pairs())  # (b_ih + b_hh of every LSTM: one multi-tensor add)
         try:
             return self._forward(mel, speaker_ids, text, in_lens, out_lens, attn_prior)
         finally:
+            ops.bias_sums_end()
             ops.weight_images_end(self)
+
+    def _lstm_bias_pairs(self):
+        """[(b_ih, b_hh)] groups, one per flow / for the encoder: a group is one autograd node, and its parameters' gradients become
+        ready together -- per flow, so that the per-flow gradient buckets of the DP overlap regime still complete in backward order"""
+        groups = {}
+        for mname, m in self.named_modules():
+            if isinstance(m, torch.nn.LSTM):
+                key = ".".join(mname.split(".")[:2]) if mname.startswith("flows.") else mname.split(".")[0]
+                for name, p in m.named_parameters(recurse=False):
+                    if name.startswith("bias_ih"):
+                        groups.setdefault(key, []).append((p, getattr(m, "bias_hh" + name[len("bias_ih"):])))
+        return list(groups.values())
 
     def _forward(self, mel, speaker_ids, text, in_lens, out_lens, attn_prior=None):
         enc, in32 = self._encode(speaker_ids, text, in_lens)
