@@ -753,6 +753,11 @@ def main():
                          "use_cumm_attention (location-sensitive attention, SURVEY 8a row a17: the key projection is redone every frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
+    ap.add_argument("--hidden", type=int, default=None,
+                    help="n_hidden of the attention / decoder LSTMs (default: the config's 1024).  A variant of the workload, not the "
+                         "BASELINE line: the roofline / parity / infer / trainpy legs are skipped")
+    ap.add_argument("--no-pad-hidden", action="store_true",
+                    help="with --hidden < 1024: the launch-per-step recurrence kernels instead of the zero-padded persistent ones (yardstick)")
     ap.add_argument("--no-trainpy", action="store_true", help="skip the train.py-call-sequence block (trainpy_step)")
     args = ap.parse_args()
 
@@ -769,6 +774,9 @@ def main():
     libri = args.config in ("libritts", "libritts_fp16")
     use_prior = args.config != "libritts_fp16"
     model_config = dict(MODEL_CONFIG, n_speakers=123) if libri else dict(MODEL_CONFIG, use_cumm_attention=args.config == "ljs_cumm")
+    if args.hidden is not None and args.hidden != MODEL_CONFIG["n_hidden"]:
+        model_config["n_hidden"] = args.hidden
+        args.no_infer = args.no_trainpy = args.no_cpu_baseline = True
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "6000")
     # test hook (tests/test_gpu_dist.py): the N > 1 control flow of this script on a ONE-GPU box -- every rank on cuda:0 and gloo
@@ -784,6 +792,9 @@ def main():
     from flowtron_amd.optim import RAdam
     import torch.distributed as dist
     L.lib()                                                   # fail loudly if the HIP library is missing
+    if args.no_pad_hidden:
+        from flowtron_amd import ops as _ops0
+        _ops0._PAD_H = False
     if world > 1:
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):          # the reference-style "> initializing distributed" chatter
@@ -908,6 +919,9 @@ def main():
                        "global_batch": args.batch * world, "valid_frames_per_step": int(frames_all),
                        "padded_frames_per_step": args.batch * T * world, "parallelism": "dp%d" % world,
                        "mfma_operands": args.mfma, "storage": "fp32", "final_loss": round(loss_val, 5),
+                       **({"n_hidden": model_config["n_hidden"], "variant": "NOT the BASELINE model: n_hidden %d instead of 1024 (%s recurrence kernels)"
+                           % (model_config["n_hidden"], "launch-per-step" if args.no_pad_hidden else "zero-padded persistent")}
+                          if model_config["n_hidden"] != MODEL_CONFIG["n_hidden"] else {}),
                        **({"test_hook": "BENCH_SHARED_GPU: all ranks on ONE GPU over gloo -- not a scaling measurement"} if shared_gpu else {})},
         }
         res["config"]["skipped_steps"] = skipped             # updates dropped by the device-side non-finite-norm guard (0 = none)
@@ -963,7 +977,13 @@ def main():
                 res["roofline"]["cumulative_attention"] = cumm_roofline(args.batch, batch_cpu["in_lens"], mode)
             except Exception as e:
                 res["roofline"]["cumulative_attention"] = {"error": repr(e)}
+        variant = model_config["n_hidden"] != MODEL_CONFIG["n_hidden"]
+        if variant:           # (a workload variant: the 325 MFLOP per frame and the kernel legs below describe the BASELINE model)
+            res["roofline"] = {"bound": "mfma", "achieved": None, "peak": 2500.0, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                               "note": "--hidden variant: not priced (the roofline legs describe the n_hidden = 1024 model)"}
         try:
+            if variant:
+                raise RuntimeError("skipped for a --hidden variant")
             from flowtron_amd import ops as _ops
             _dev = torch.device("cuda", torch.cuda.current_device())
             _slices = _ops.lstm_persist_slices(args.batch, MODEL_CONFIG["n_hidden"], False, mode, _dev)

@@ -253,7 +253,8 @@ class AR_Step(nn.Module):
         # concatenated operand image, the N = 1 gate projection is taken from the same image (ops.LinearGateFn)
         g = self.gate_layer.linear_layer if hasattr(self, "gate_layer") else None
         persist = (ops.lstm_persist_groups(B, p.weight_hh_l0.shape[1], False, mode, mel.device)
-                   or bool(ops.lstm_persist_slices(B, p.weight_hh_l0.shape[1], False, mode, mel.device)))     # (B > 32: sliced launches)
+                   or bool(ops.lstm_persist_slices(B, p.weight_hh_l0.shape[1], False, mode, mel.device))     # (B > 32: sliced launches)
+                   or ops.lstm_pad_width(B, p.weight_hh_l0.shape[1], False, mode, mel.device, T))             # (H < 1024: zero-padded twin)
         fuse_gate = g is not None and (self.n_lstm_layers != 2 or persist or not ops.lstm2_supported(B, p.weight_hh_l0.shape[1], mode))
         if g is not None and not fuse_gate:
             gates = ops.linear([h_att, ctx], g.weight, g.bias, mode=mode)     # Linear over [h_att ; ctx], no concat

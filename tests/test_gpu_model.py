@@ -722,6 +722,57 @@ def test_bf16_mode_gradients_track_fp32_full_width():
     assert w2[1] < 6e-2, w2
 
 
+def test_hidden_size_512_model_runs_the_persistent_kernels_and_tracks_fp32():
+    """n_hidden = 512 (the reference takes any: flowtron.py:654-655): in the 16-bit modes the attention LSTM and both decoder layers
+    run as zero-padded 1024-unit twins on the persistent kernels (ops.lstm_pad_width; AR_Step.forward routes the decoder pair
+    through ops.lstm_layer for them).  Loss terms, z and every gradient in bf16 mode against (a) the same model on the
+    launch-per-step kernels (ops._PAD_H = False) and (b) the fp32 run -- T 96 so that the padded path is taken."""
+    import flowtron
+    from flowtron_amd import ops
+    from oracle import synth
+    cfg = dict(synth.DEFAULT_MODEL_CONFIG, n_text=60, n_hidden=512)
+    b = cuda_batch(synth.make_batch(cfg, [96, 83, 40, 96], [14, 12, 12, 5], seed=8, with_prior=True))
+    res = {}
+    try:
+        for name, mode, pad in (("f32", "f32", True), ("bf16_pad", "bf16", True), ("bf16_step", "bf16", False)):
+            ops._PAD_H = pad
+            m, _ = build(cfg, 8, mode)
+            crit = flowtron.FlowtronLoss(1.0, False, True, True, 0.01, -8)
+            if mode == "bf16":
+                assert bool(ops.lstm_pad_width(4, 512, False, L_mode(), torch.device("cuda"), 96)) == pad
+            out = m(b["mel"], b["speaker_ids"], b["text"], b["in_lens"], b["out_lens"], b["attn_prior"])
+            nll, gl, ctc = crit(out, b["gate_target"], b["in_lens"], b["out_lens"])
+            (nll + gl + 0.01 * ctc).sum().backward()
+            torch.cuda.synchronize()
+            ops.check_persist_status()
+            res[name] = ({k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}, float(nll), out[0].detach().cpu())
+    finally:
+        ops._PAD_H = True
+        os.environ.update(FLOWTRON_MFMA="f32")
+
+    def worst(a, r, skip=()):
+        w = ("", 0.0)
+        for k in r:
+            if any(k.startswith(p_) for p_ in skip):
+                continue
+            e = (a[k] - r[k]).norm().item() / max(r[k].norm().item(), 1e-4 * r[k].numel() ** 0.5)
+            if e > w[1]:
+                w = (k, e)
+        return w
+
+    assert abs(res["bf16_pad"][1] - res["bf16_step"][1]) < 2e-3 * abs(res["bf16_step"][1]) + 1e-4
+    assert mad(res["bf16_pad"][2], res["bf16_step"][2]) < 5e-2 and mad(res["bf16_pad"][2], res["bf16_step"][2]) > 0.0
+    w1 = worst(res["bf16_pad"][0], res["bf16_step"][0])
+    assert w1[1] < 3e-2, w1
+    w2 = worst(res["bf16_pad"][0], res["f32"][0], skip=("encoder.convolutions", "embedding."))
+    assert w2[1] < 6e-2, w2
+
+
+def L_mode():
+    from flowtron_amd import _lib
+    return _lib.mfma_mode()
+
+
 def test_rccl_process_group_single_rank_step():
     """torch.distributed backend "nccl" (= RCCL) on the GPU box: init through flowtron_amd.dist exactly as bench.py / train.py
     do, the flat-arena wrapper around a small model, one forward/backward, the explicit collectives of the step
