@@ -867,6 +867,17 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
+    if os.environ.get("BENCH_HOST_PROFILE"):          # debugging aid: where does the HOST spend its time enqueueing a step?
+        import cProfile, io, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(10):
+            step()
+        pr.disable()
+        torch.cuda.synchronize()
+        sio = io.StringIO()
+        pstats.Stats(pr, stream=sio).sort_stats("tottime").print_stats(60)
+        log(sio.getvalue())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
