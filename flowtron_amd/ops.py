@@ -359,7 +359,7 @@ def image_only_gradient(shape, device, dtype=torch.float32):
     return slot.expand(*shape) if len(shape) else slot.reshape(())
 
 
-def _handoff_put(t, img):
+def _handoff_put(t, img, key=None):
     # one clear callback per backward PASS.  The engine drops its callbacks when a backward raises, which used to leave `armed`
     # set for good: imgs / unwritten / nan_next were then never cleared again.  A pass is identified by the engine's
     # current graph task; a put from another pass than the one that armed the state clears the leftovers and arms again.
@@ -373,7 +373,27 @@ def _handoff_put(t, img):
             return
         _HANDOFF["armed"] = True
         _HANDOFF["task"] = gt
-    _HANDOFF["imgs"][(t.device.index, t.data_ptr(), tuple(t.shape))] = img
+    _HANDOFF["imgs"][(t.device.index, t.data_ptr(), tuple(t.shape) if key is None else key)] = img
+
+
+def _handoff_put_x(x, img):
+    """the operand image a Linear's backward has just used for its INPUT x, left for the node that produced x: an LSTM's backward
+    multiplies the same compact image of its output (dW_hh = dgates^T . y shifted by one row) and would otherwise convert y again"""
+    if img is not None and img.rowmap is not None:
+        _handoff_put(x, img, key=("x", x.numel()))
+
+
+def _handoff_take_x(y, cols, mode, rowmap):
+    img = _HANDOFF["imgs"].get((y.device.index, y.data_ptr(), ("x", y.numel()))) if _HANDOFF["armed"] else None
+    if img is not None and img.rowmap is rowmap and img.fmt == mode and img.cols == cols and img.rows == rowmap.cap:
+        return img
+    return None
+
+
+def y_image(y, rows, cols, mode, rowmap):
+    """the compact image of an LSTM output for its own weight-gradient GEMM: the one a consumer's backward left (same pass), else made here"""
+    img = _handoff_take_x(y, cols, mode, rowmap) if rowmap is not None else None
+    return img if img is not None else shared_image(y, rows, cols, mode, rowmap)
 
 
 def _handoff_take(t):
@@ -679,6 +699,8 @@ class LinearFn(torch.autograd.Function):
                 if imgs is not None:
                     gemm_img(d_img, 1, d_img.ptr(), x_imgs[i], 1, x_imgs[i].ptr(), dW[:, off:], N, K, mrows, Ktot, beta=1.0, splitk=True,
                              rowmap=rowmap, compact=2)
+                    if rowmap is not None:
+                        _handoff_put_x(x, x_imgs[i])
                 else:
                     gemm_raw(dpre, x, dW[:, off:], N, K, rows, 1, N, K, 1, Ktot, mode=ctx.mode_dw, splitk=True)
             off += K
@@ -1426,7 +1448,7 @@ def _pair_backward_sequential(ctx, dy1, w_img, img_only):
         return img
 
     d_img1 = recurrence(dy1, g1, c1, w_hh1)
-    y0_img, y1_img = shared_image(y0, T * B, H, mode, rm), shared_image(y1, T * B, H, mode, rm)
+    y0_img, y1_img = y_image(y0, T * B, H, mode, rm), y_image(y1, T * B, H, mode, rm)
     dW_hh1, dW_ih1, dW_hh0 = weight_grad_out(w_hh1), weight_grad_out(w_ih1), weight_grad_out(w_hh0)
     gemm_img(d_img1, 1, d_img1.ptr(1), y1_img, 1, y1_img.ptr(0), dW_hh1, H4, H, rm.cap, H, beta=1.0, splitk=True, rowmap=rm, compact=2, k_shift=1)
     dy0 = torch.empty(T, B, H, device=dev, dtype=torch.float32)
@@ -1560,7 +1582,7 @@ class LSTMSeqFn(torch.autograd.Function):
                 # compact images (valid frames only, batch-major with one zero separator row per utterance): the one-step shift
                 # dgates_t <-> h_{t-1} is a shift by ONE compact row, and the utterance boundaries multiply with a separator
                 d_img = d_img_k if d_img_k is not None else Bf16Image(dgx_f32.reshape(T * B, 4 * H), colsum=True, mode=ctx.mode, rowmap=rm)
-                y_img = shared_image(y, T * B, H, ctx.mode, rm)
+                y_img = y_image(y, T * B, H, ctx.mode, rm)
                 gemm_img(d_img, 1, d_img.ptr(1), y_img, 1, y_img.ptr(0), dW, 4 * H, H, rm.cap, H, beta=1.0, splitk=True, rowmap=rm, compact=2, k_shift=1)
                 if img_only:
                     _handoff_put_image_only(dgx, d_img)     # ... and ONLY the image exists
