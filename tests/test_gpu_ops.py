@@ -1366,14 +1366,17 @@ def test_wide_stage_image_gemm_two_inputs_is_bit_identical_to_the_32_wide_stages
     assert mad(res["1"][0], ref) < 2e-3
 
 
+@pytest.mark.parametrize("fmt", [1, 2])
 @pytest.mark.parametrize("K", [256, 448, 1664])
-def test_wide_stage_image_gemm_is_bit_identical_to_the_32_wide_stages(env, K, monkeypatch):
+def test_wide_stage_image_gemm_is_bit_identical_to_the_32_wide_stages(env, K, fmt, monkeypatch):
     """gemm_bf16_k<.., 64, true> (64-wide k stages in one LDS buffer: whole-line DMA pieces for the k-contiguous operands, a k-major
     operand as two of its 32-wide sub-stages) against the 32-wide stages (FT_GEMM_BF16_WIDE=0): same k order per output element, so
     forward (both operands k-contiguous, padded and compact rows, bias + tanh) and input gradient (k-major weight image) must be
-    BIT-identical.  K = 448: 7 whole 64-wide stages;  K = 1664: the decoder projection's own width."""
+    BIT-identical.  K = 448: 7 whole 64-wide stages;  K = 1664: the decoder projection's own width.  fmt 1 / 2: bf16 / fp16 operands
+    (the two builds of the same source)."""
     L, ops = env
     torch.manual_seed(78)
+    rnd = (lambda t: t.bfloat16().float()) if fmt == 1 else (lambda t: t.half().float())
     T, B, N = 37, 8, 320
     lens32 = torch.tensor([37 - 4 * i for i in range(B)], dtype=torch.int32, device="cuda")
     x = torch.randn(T, B, K, device="cuda")
@@ -1385,18 +1388,18 @@ def test_wide_stage_image_gemm_is_bit_identical_to_the_32_wide_stages(env, K, mo
         monkeypatch.setenv("FT_GEMM_BF16_WIDE", wide)
         outs = []
         for rm in (None, ops.RowMap(lens32, T, B)):
-            outs.append(ops.linear([x], W, b, act=1, mode=1, rowmap=rm, fill="y").detach().clone())
+            outs.append(ops.linear([x], W, b, act=1, mode=fmt, rowmap=rm, fill="y").detach().clone())
         # dX[M, K] = dy[M, N] . W[N, K]: A k-contiguous (reduction over N), B = the weight image read k-major
-        d_img, w_img = ops.Bf16Image(dy, mode=1), ops.Bf16Image(W, mode=1)
+        d_img, w_img = ops.Bf16Image(dy, mode=fmt), ops.Bf16Image(W, mode=fmt)
         dx = torch.empty(T * B, K, device="cuda")
         ops.gemm_img(d_img, 0, d_img.ptr(), w_img, 1, w_img.ptr(), dx, T * B, K, N, K)
         outs.append(dx)
         res[wide] = outs
     for a_, b_ in zip(res["0"], res["1"]):
         assert torch.equal(a_, b_), (a_ - b_).abs().max().item()
-    ref = torch.tanh(x.bfloat16().float() @ W.bfloat16().float().t() + b)
+    ref = torch.tanh(rnd(x) @ rnd(W).t() + b)
     assert mad(res["1"][0], ref) < 2e-3
-    assert mad(res["1"][2], dy.bfloat16().float() @ W.bfloat16().float()) < 2e-2
+    assert mad(res["1"][2], rnd(dy) @ rnd(W)) < 2e-2
 
 
 # ---------------------------------------------------------------- cumulative attention, fused frames (csrc/cumm_fused.hip)
