@@ -91,6 +91,8 @@ SIGNATURES = {
     "ft_gemm_img": ([C.POINTER(GemmImgArgs), _p], _i),
     "ft_gemm_img_split_work_bytes": ([_i, _i, _i], _sz),
     "ft_bf16_image_split3": ([_p, _l, _l, _l, _p, _i, _p], _i),
+    "ft_bf16_image_split3_im2col": ([_p, _p, _i, _i, _i, _i, _p, _p], _i),
+    "ft_bf16_image_split3_im2col_f16": ([_p, _p, _i, _i, _i, _i, _p, _p], _i),
     "ft_bf16_image_table": ([C.POINTER(ImgDesc), _i, _p], _i),
     "ft_bf16_image_table_f16": ([C.POINTER(ImgDesc), _i, _p], _i),
     "ft_bf16_image_split3_f16": ([_p, _l, _l, _l, _p, _i, _p], _i),
@@ -200,7 +202,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argt
             fn.restype = rest
-        if l.ft_abi_version() != 13:
+        if l.ft_abi_version() != 14:
             raise RuntimeError("libflowtron_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -119,6 +119,40 @@ __global__ __launch_bounds__(256) void img_split3_k(const float* __restrict__ sr
     img_split3_body(src, sr, R, K, dst, Rp, Cp, weight, blockIdx.x * (size_t)blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
 
+// The split ACTIVATION image [hi | lo | hi] of the encoder convolution's im2col matrix, taken straight from x (ft_bf16_image_split3_im2col):
+// image row r = l * B + b, column j = c * KW + k holds x[l + k - KW / 2][b][c] where that position exists in the utterance (ft_im2col's
+// rule), so the fp32 [L * B][C * KW] matrix -- 51 MB per layer at the bench shape, written once and read once -- never exists.
+__global__ __launch_bounds__(256) void img_split3_im2col_k(const float* __restrict__ x, const int* __restrict__ lens, int Lx, int B, int Cc, int KW,
+                                                           unsigned short* __restrict__ dst, int Rp, int Cp) {
+    const int R = Lx * B, K = Cc * KW;
+    const int kq = K >> 3, cq = Cp >> 3;
+    const size_t total = (size_t)Rp * cq;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cq), q = (int)(i % cq);
+        uint4 out = make_uint4(0u, 0u, 0u, 0u);
+        if (r < R && q < 3 * kq) {
+            const int blk = q / kq, c0 = (q - blk * kq) * 8;
+            const int l = r / B, b = r - l * B;
+            const int len = lens[b];
+            float v[8], lo[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = c0 + e, ch = j / KW, k = j - ch * KW;
+                const int ls = l + k - KW / 2;
+                v[e] = (ls >= 0 && ls < len) ? x[((size_t)ls * B + b) * Cc + ch] : 0.f;
+            }
+            if (blk == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) lo[e] = v[e] - op16_to_f(f2op16(v[e]));
+                out = pack8(lo);
+            } else {
+                out = pack8(v);
+            }
+        }
+        *reinterpret_cast<uint4*>(dst + (size_t)r * Cp + (size_t)q * 8) = out;
+    }
+}
+
 // Descriptor table (ft_bf16_image_table): the plain and split WEIGHT images of one forward pass in ONE launch -- a training step
 // rounds 23 weight matrices (60 M parameters) afresh, each in a launch of 5-15 us for 1-5 us of work.  Workgroup ranges per image
 // (blk0), each range walks its image with the single-image kernels' own bodies.
@@ -929,6 +963,18 @@ extern "C" int FT_OPNAME(ft_bf16_image_split3)(const float* src, int64_t ld, int
     const int blocks = (int)((chunks + 255) / 256 < 16384 ? (chunks + 255) / 256 : 16384);
     hipLaunchKernelGGL(img_split3_k, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, (long)ld, (int)rows, (int)cols,
                        reinterpret_cast<unsigned short*>(dst), Rp, Cp, weight ? 1 : 0);
+    FT_CHECK_LAUNCH();
+    return FT_OK;
+}
+
+extern "C" int FT_OPNAME(ft_bf16_image_split3_im2col)(const float* x, const int32_t* lens, int L, int B, int C, int KW, void* dst, void* stream) {
+    FT_CHECK_ARG(x && lens && dst && L >= 1 && B >= 1 && C >= 1 && KW >= 1 && (KW & 1) && ((int64_t)C * KW) % 8 == 0);
+    FT_CHECK_ARG((int64_t)L * B < (1ll << 31) - 256 && 3ll * C * KW < (1ll << 31) - 256 && reinterpret_cast<uintptr_t>(dst) % 256 == 0);
+    const int Rp = (int)up((size_t)L * B + 32, 256), Cp = (int)up((size_t)3 * C * KW, 256);
+    const size_t chunks = (size_t)Rp * (Cp >> 3);
+    const int blocks = (int)((chunks + 255) / 256 < 16384 ? (chunks + 255) / 256 : 16384);
+    hipLaunchKernelGGL(img_split3_im2col_k, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, lens, L, B, C, KW,
+                       reinterpret_cast<unsigned short*>(dst), Rp, Cp);
     FT_CHECK_LAUNCH();
     return FT_OK;
 }

@@ -145,6 +145,19 @@ class Bf16Image:
         return self
 
     @classmethod
+    def split3_im2col(cls, x, lens, KW, mode):
+        """the [hi | lo | hi] image of ft_im2col(x, lens, KW) -- x [L, B, C] -- made straight from x (ft_bf16_image_split3_im2col): the
+        fp32 column matrix is never written"""
+        Lx, B, Cc = x.shape
+        self = cls.__new__(cls)
+        self.rows, self.cols, self.fmt, self.rowmap, self.colsum = int(Lx * B), 3 * int(Cc * KW), mode, None, None
+        self.ld = (self.cols + 255) // 256 * 256
+        self.buf = torch.empty(L.lib().ft_bf16_image_bytes(self.rows, self.cols), device=x.device, dtype=torch.uint8)
+        L.check(L.op16("ft_bf16_image_split3_im2col", mode)(L.ptr(x), L.ptr(lens), int(Lx), int(B), int(Cc), int(KW), L.ptr(self.buf), L.stream()),
+                "ft_bf16_image_split3_im2col")
+        return self
+
+    @classmethod
     def _blank(cls, rows, cols, mode, device):
         self = cls.__new__(cls)
         self.rows, self.cols, self.fmt, self.rowmap, self.colsum = int(rows), int(cols), mode, None, None
@@ -571,12 +584,15 @@ class LinearFn(torch.autograd.Function):
             x2d = xs[0].reshape(rows, Ktot)
             split_imgs = None
             if Ktot % 32 == 0 and images_apply(mode_dx, rows, N, Ktot):
-                xi, wi = Bf16Image.split3(x2d, mode_dx, False), Bf16Image.of_weight(W, mode_dx, split=True)
+                lazy = _LAZY_COLS.pop(xs[0].data_ptr(), None)     # (an Im2colFn output whose values were never written: image from ITS source)
+                xi = Bf16Image.split3_im2col(*lazy, mode_dx) if lazy is not None else Bf16Image.split3(x2d, mode_dx, False)
+                wi = Bf16Image.of_weight(W, mode_dx, split=True)
                 # K = 3 Ktot over only (rows / 128) x (N / 128) output tiles (160 for the encoder: a sixth of the chip's workgroup slots,
                 # 240 k-steps each: 130 us): split-K fills the chip -- in its deterministic form (see _ENC_SPLITK)
                 gemm_img(xi, 0, xi.ptr(), wi, 0, wi.ptr(), y, rows, N, 3 * Ktot, N, bias=bias, splitk=_ENC_SPLITK)
                 split_imgs = (wi.view_cols(Ktot), [xi.view_cols(Ktot)])      # their [hi] blocks serve the backward's GEMMs as they are
             else:
+                _materialize_col(xs[0])
                 gemm_raw(x2d, W, y, rows, N, Ktot, Ktot, 1, 1, Ktot, N, bias=bias, mode=L.FT_F32)
             mode = L.FT_F32                          # (what the rest of this node records as its forward format)
         mixed = not (mode == mode_dx == mode_dw)
@@ -846,14 +862,31 @@ def embedding(ids, W, run_stride=0):
 # --------------------------------------------------------------------------
 # encoder conv as im2col + GEMM, masked instance norm + relu (+dropout mask)
 # --------------------------------------------------------------------------
+# Im2colFn outputs whose VALUES have not been written (lazy = True): data_ptr -> (x, lens, KW).  conv_norm_relu passes such a matrix
+# straight to the split-image Linear, whose forward makes the operand image from x itself (Bf16Image.split3_im2col) and whose backward
+# reads only that image; any other reader must call _materialize_col first.
+_LAZY_COLS = {}
+
+
+def _materialize_col(col):
+    src = _LAZY_COLS.pop(col.data_ptr(), None)
+    if src is not None:
+        x, lens, KW = src
+        Lx, B, Cc = x.shape
+        L.check(L.lib().ft_im2col(L.ptr(x), L.ptr(col), L.ptr(lens), Lx, B, Cc, KW, L.stream()), "ft_im2col")
+
+
 class Im2colFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, lens, KW):
+    def forward(ctx, x, lens, KW, lazy=False):
         x = _c(x)
         L.require_cuda(x, lens)
         Lx, B, Cc = x.shape
         col = torch.empty(Lx, B, Cc * KW, device=x.device, dtype=torch.float32)
-        L.check(L.lib().ft_im2col(L.ptr(x), L.ptr(col), L.ptr(lens), Lx, B, Cc, KW, L.stream()), "ft_im2col")
+        if lazy:
+            _LAZY_COLS[col.data_ptr()] = (x, lens, KW)
+        else:
+            L.check(L.lib().ft_im2col(L.ptr(x), L.ptr(col), L.ptr(lens), Lx, B, Cc, KW, L.stream()), "ft_im2col")
         ctx.save_for_backward(lens)
         ctx.dims = (Lx, B, Cc, KW)
         return col
@@ -865,7 +898,7 @@ class Im2colFn(torch.autograd.Function):
         dcol = _c(dcol)
         dx = torch.empty(Lx, B, Cc, device=dcol.device, dtype=torch.float32)
         L.check(L.lib().ft_col2im(L.ptr(dcol), L.ptr(dx), L.ptr(lens), Lx, B, Cc, KW, L.stream()), "ft_col2im")
-        return dx, None, None
+        return dx, None, None, None
 
 
 class InstNormReluFn(torch.autograd.Function):
@@ -901,8 +934,15 @@ class InstNormReluFn(torch.autograd.Function):
 def conv_norm_relu(x, lens, conv_w, conv_b, gamma, beta, keep=None, eps=1e-5, mode=None):
     """x [L,B,C] -> relu(masked_instance_norm(conv1d_k5(x))) * keep  (flowtron.py:499-502)."""
     Cout, Cin, KW = conv_w.shape
-    col = Im2colFn.apply(x, lens, KW)
+    # split-image forward (model.Encoder's default in the 16-bit modes): the column matrix is needed as an operand image only -- made from
+    # x itself; the fp32 matrix stays unwritten (Im2colFn lazy) unless the Linear cannot take the image path after all
+    rows, K = x.shape[0] * x.shape[1], Cin * KW
+    lazy = (isinstance(mode, tuple) and mode[0] == "split3" and L.is16(mode[1]) and mode[1] == mode[2] and K % 32 == 0
+            and images_apply(mode[1], rows, Cout, K))
+    col = Im2colFn.apply(x, lens, KW, lazy)
     y = linear(col, conv_w.reshape(Cout, Cin * KW), conv_b, mode=mode)
+    if lazy:
+        _materialize_col(col)                    # (a no-op when the Linear took the image from x: it popped the entry)
     return InstNormReluFn.apply(y, gamma, beta, keep, lens, eps)
 
 

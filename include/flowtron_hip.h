@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 13
+#define FT_ABI_VERSION 14
 
 enum { FT_OK = 0, FT_EINVAL = -1, FT_EHIP = -2, FT_EUNSUPPORTED = -3 };
 enum { FT_F32 = 0, FT_BF16 = 1, FT_F16 = 2 };
@@ -169,6 +169,11 @@ int ft_bf16_image_rows_act_bwd_acc_f16(const float* dy, int64_t ld, const float*
  * (measured round 5: fp32 forward products alone bring it to 0.008).  cols % 8 == 0. */
 int ft_bf16_image_split3(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, int weight, void* stream);
 int ft_bf16_image_split3_f16(const float* src, int64_t ld, int64_t rows, int64_t cols, void* dst, int weight, void* stream);
+/* ABI 14: the split ACTIVATION image of the im2col matrix of ft_im2col(x, lens, L, B, C, KW) -- [L * B rows][3 * C * KW] as [hi | lo | hi] --
+ * made straight from x [L][B][C] (flowtron.py:499-502: the encoder convolution as a GEMM): the fp32 column matrix is never written.
+ * dst: ft_bf16_image_bytes(L * B, 3 * C * KW) bytes; (C * KW) % 8 == 0, KW odd. */
+int ft_bf16_image_split3_im2col(const float* x, const int32_t* lens, int L, int B, int C, int KW, void* dst, void* stream);
+int ft_bf16_image_split3_im2col_f16(const float* x, const int32_t* lens, int L, int B, int C, int KW, void* dst, void* stream);
 /* The weight images of one forward pass in ONE launch (ABI 12): descs = HOST array of n <= 32 descriptors, kind 0 = what
  * ft_bf16_image(src, ld, rows, cols, dst) writes, kind 1 = ft_bf16_image_split3(src, ld, rows, cols, dst, weight = 1).  A training step
  * rounds its 23 weight matrices afresh every iteration; one dispatch instead of 23 of 5-15 us each. */

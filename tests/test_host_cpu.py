@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert h.ft_abi_version() == 13
+    assert h.ft_abi_version() == 14
 
 
 def test_state_dict_layout_matches_reference_spec():
