@@ -477,7 +477,10 @@ extern "C" int ft_attention_bwd(const float* Q, const float* K, const float* v, 
     // workgroups per CU but only two 5-wave ones; the dK sums of four tiles combined in LDS before leaving the CU (a quarter of
     // the atomics, 115 KB of LDS = one workgroup per CU): 1 045 us.  The pass is VALU-bound, not atomics-bound.
     const int nchunk = cdiv(A, 64);
-    const int nw = nchunk < 4 ? nchunk : 4;
+    // ... and a workgroup of four waves whose last group covers fewer chunks carries idle waves (A = 640: 4 + 4 + 2): the largest of
+    // 4 / 3 / 2 waves that divides the chunk count (round 6: A = 640 as five workgroups of two waves, 0.554 -> 0.521 ms per backward call)
+    int nw = nchunk < 4 ? nchunk : 4;
+    if (nchunk > 4) { if (nchunk % 4 == 0) nw = 4; else if (nchunk % 3 == 0) nw = 3; else if (nchunk % 2 == 0) nw = 2; }
     if (lds_q > 48 * 1024)      // (the kernel also has a few static LDS bytes: ask for what this launch needs, not for all 160 KiB)
         FT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dqdk_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
     hipLaunchKernelGGL(attn_dqdk_k, dim3(cdiv(T, 32), B, cdiv(nchunk, nw)), dim3(64 * nw), lds_q, st, Q, K, v, in_lens, de_work, dQ, dK, dv,
